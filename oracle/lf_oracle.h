@@ -1,0 +1,136 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the lane-slam line-feature front
+ * end (detect -> describe -> ground-project -> sanity -> associate).  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (lane_slam_amd/, liblanefront.so) never does.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle pinning"):
+ *   pinned by the reference's own runnable Python (tests/golden/ npz fixtures):
+ *     scaleandshift2, _findNormal/_checkBounds/_correctPixelOrdering,
+ *     fancyFilters/processSegmentList.
+ *   restated from in-tree reference source, PARITY UNPINNED (C++ needs OpenCV
+ *   headers to build, none in this image): LBD (computeLBD, binaryConversion),
+ *   Hamming matcher semantics, vector2pixel/pixel2ground arithmetic.
+ *   restated from the published OpenCV 3.x algorithms the reference calls,
+ *   PARITY UNPINNED (OpenCV is not vendored and not installed): resize-nearest,
+ *   convertScaleAbs, BGR2HSV, BGR2GRAY, inRange, dilate, Canny, LSD,
+ *   GaussianBlur, Sobel, undistortPoints, LineIterator count.
+ *
+ * Every function cites the reference file:line it follows.
+ */
+#ifndef LF_ORACLE_H
+#define LF_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFO_WHITE 0
+#define LFO_YELLOW 1
+#define LFO_RED 2
+
+typedef struct lfo_config {
+    /* geometry: line_detector_node.py:163-169, default.yaml:1-2 */
+    int32_t in_rows, in_cols;        /* incoming frame, e.g. 480 x 640 */
+    int32_t img_rows, img_cols;      /* img_size */
+    int32_t top_cutoff;
+    /* AntiInstagram transform, channel order = image channel order (BGR): scale_and_shift.py:25-33 */
+    float ai_scale[3], ai_shift[3];
+    /* HSV boxes: [0]=white, [1]=yellow, [2]=red1..red2, [3]=red3..red4 (line_detector_lsd.py:38-47) */
+    int32_t hsv_lo[4][3], hsv_hi[4][3];
+    int32_t dilation_kernel_size;    /* line_detector_lsd.py:52 */
+    double canny_lo, canny_hi;       /* line_detector_lsd.py:61 */
+    /* cv2.createLineSegmentDetector defaults (line_detector_lsd.py:65) */
+    int32_t lsd_refine;              /* 0 none, 1 std, 2 adv */
+    int32_t lsd_n_bins;
+    double lsd_scale, lsd_sigma_scale, lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th;
+    /* ground projection: GroundProjection.py:38-78, calibrations yaml */
+    double H[9], K[9], D[5], R[9], P[12];
+    int32_t cam_w, cam_h;
+    /* line_sanity_node.py:17-23 */
+    double lanewidth, linewidth_white, linewidth_yellow, d_min, d_max, phi_min, phi_max;
+} lfo_config;
+
+/* working image size after resize+crop */
+static inline int lfo_work_rows(const lfo_config* c) { return c->img_rows - c->top_cutoff; }
+static inline int lfo_work_cols(const lfo_config* c) { return c->img_cols; }
+
+/* ---- image stages (lf_oracle_image.c) ---- */
+/* a-1: resize-nearest + crop + scaleandshift2 + convertScaleAbs. out: Hc*W*3 u8 */
+void lfo_preprocess(const lfo_config* c, const uint8_t* bgr_in, uint8_t* bgr_out);
+/* a-2: cvtColor BGR2HSV 8-bit */
+void lfo_bgr2hsv(const uint8_t* bgr, int npix, uint8_t* hsv);
+/* a-3: inRange masks (red = OR of two boxes); bw: 3 planes of npix */
+void lfo_color_masks(const lfo_config* c, const uint8_t* hsv, int npix, uint8_t* bw3);
+/* a-3: dilate with MORPH_ELLIPSE ksize x ksize */
+void lfo_dilate_ellipse(const uint8_t* src, int rows, int cols, int ksize, uint8_t* dst);
+/* a-2: Canny on 3-channel u8, aperture 3, L1 norm */
+void lfo_canny_bgr(const uint8_t* bgr, int rows, int cols, double lo, double hi, uint8_t* edges);
+/* a-9 inputs: BGR2GRAY, GaussianBlur 5x5 sigma 1 (u8), Sobel 3x3 -> s16 */
+void lfo_bgr2gray(const uint8_t* bgr, int npix, uint8_t* gray);
+void lfo_gaussian5_u8(const uint8_t* src, int rows, int cols, uint8_t* dst);
+void lfo_sobel3_s16(const uint8_t* src, int rows, int cols, int16_t* dx, int16_t* dy);
+
+/* ---- LSD (lf_oracle_lsd.c) ---- */
+/* scaled-image size for an input of rows x cols */
+void lfo_lsd_scaled_size(const lfo_config* c, int rows, int cols, int* srows, int* scols);
+/* Gaussian + resize (f64) */
+void lfo_lsd_scaled_image(const lfo_config* c, const uint8_t* img, int rows, int cols, double* scaled);
+/* ll_angle: angle (rad, NOTDEF=-1024), modgrad, and the pseudo-ordered seed list
+   (pixel addresses, descending bin then raster); returns list length */
+int lfo_lsd_ll_angle(const lfo_config* c, const double* scaled, int srows, int scols,
+                     double* angles, double* modgrad, int32_t* order);
+/* full detector: lines (x1,y1,x2,y2) float32, returns count (<= cap); extra = width,prec,nfa per line or NULL */
+int lfo_lsd_detect(const lfo_config* c, const uint8_t* img, int rows, int cols,
+                   float* lines4, double* extra3, int cap);
+
+/* ---- per-segment stages (lf_oracle_segments.c) ---- */
+/* a-5: normals (f64, value-equal to the f32 product), centers f32, lines reordered in place */
+void lfo_find_normals(const uint8_t* bw, int rows, int cols, float* lines4, int n,
+                      double* normals2, float* centers2);
+/* a-6: float32((float64(x)+cut) * (1/size)) */
+void lfo_normalize_lines(const lfo_config* c, const float* lines4, int n, float* out4);
+/* a-7: vector2ground for both endpoints; pts: n*4 doubles (x0,y0,x1,y1), z==0 */
+void lfo_ground_project(const lfo_config* c, const float* pixels_normalized4, int n, double* pts4);
+/* a-8: keep mask + (d_i, phi_i, l_i, state) per segment */
+void lfo_line_sanity(const lfo_config* c, const double* pts4, const uint8_t* color, int n,
+                     uint8_t* keep, double* dphil3, int32_t* state);
+
+/* ---- LBD + matcher (lf_oracle_lbd.c) ---- */
+/* KeyLine fields used by computeLBD, from LSD lines in octave 0 (LSDDetector_custom.cpp:169-197) */
+void lfo_keylines(const float* lines4, int n, int rows, int cols,
+                  float* ext4 /*clamped sx,sy,ex,ey*/, float* angle, int32_t* num_pixels);
+/* a-9: float (72) and binary (32 B) LBD descriptors */
+void lfo_lbd(const int16_t* dx, const int16_t* dy, int rows, int cols,
+             const float* ext4, const float* angle, const int32_t* num_pixels, int n,
+             float* desc72, uint8_t* code32);
+/* a-10: exact Hamming NN, distance > 128 => idx -1, dist -1; ties -> lowest train index */
+void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
+               int32_t* idx, float* dist);
+/* float-descriptor L2 NN (72-d) */
+void lfo_match_float(const float* q72, int nq, const float* t72, int nt, int32_t* idx, float* dist);
+
+/* ---- whole frame (lf_oracle_frame.c) ---- */
+typedef struct lfo_frame_out {
+    int32_t n;                  /* segments, order white, yellow, red */
+    int32_t n_color[3];
+    float* lines;               /* n*4  cropped-image px, reordered */
+    float* normals;             /* n*2  float32(normal) as stored in Segment.msg */
+    uint8_t* color;             /* n */
+    float* pixels_normalized;   /* n*4 */
+    double* ground;             /* n*4 */
+    uint8_t* keep;              /* n */
+    float* desc;                /* n*72 */
+    uint8_t* code;              /* n*32 */
+} lfo_frame_out;
+
+/* runs a-1..a-9 on one frame; arrays in out must hold cap segments; returns n (clamped to cap) */
+int lfo_process_frame(const lfo_config* c, const uint8_t* bgr_in, lfo_frame_out* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

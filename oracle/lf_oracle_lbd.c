@@ -1,0 +1,238 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (see lf_oracle.h).
+ * a-9 LBD descriptor and a-10 matcher semantics, restated from the reference's
+ * in-tree C++ (never built by the reference, needs OpenCV headers -> cannot be
+ * compiled here without stand-ins -> PARITY UNPINNED):
+ *   /root/reference/src/line_descriptor/src/binary_descriptor_custom.cpp
+ *     :74-107   pair table            :217-259  Gaussian weights
+ *     :401-412  binaryConversion      :653-667  32-byte code
+ *     :1026-1372 computeLBD
+ *   /root/reference/src/line_descriptor/src/LSDDetector_custom.cpp:73-102,169-197 (KeyLine fill)
+ *   /root/reference/src/line_descriptor/src/binary_descriptor_matcher.cpp:197-254,635-753
+ *   /root/reference/src/line_descriptor/src/bitops_custom.hpp:83-96 (Hamming)
+ */
+#include "lf_oracle.h"
+#include "lf_detmath.h"
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define NUM_OF_BANDS 9
+#define WIDTH_OF_BAND 7
+
+static const int COMB[32][2] = {
+    {0,1},{0,2},{0,3},{0,4},{0,5},{0,6},{1,2},{1,3},{1,4},{1,5},{1,6},{2,3},{2,4},{2,5},{2,6},{2,7},
+    {2,8},{3,4},{3,5},{3,6},{3,7},{3,8},{4,5},{4,6},{4,7},{4,8},{5,6},{5,7},{5,8},{6,7},{6,8},{7,8} };
+
+static int cv_round(double v)
+{
+    double f = (double)(long long)v;
+    double d = v - f;
+    long long i = (long long)f;
+    if (d > 0.5 || (d == 0.5 && (i & 1))) i += 1;
+    else if (d < -0.5 || (d == -0.5 && (i & 1))) i -= 1;
+    return (int)i;
+}
+
+static double c_round(double v) /* C round(): half away from zero */
+{
+    double f = (double)(long long)v;
+    double d = v - f;
+    if (d >= 0.5) return f + 1.0;
+    if (d <= -0.5) return f - 1.0;
+    return f;
+}
+
+/* LSDDetector_custom.cpp:73-102 checkLineExtremes, :169-197 KeyLine fields (octave 0, scale 1) */
+void lfo_keylines(const float* lines, int n, int rows, int cols, float* ext, float* angle, int32_t* npx)
+{
+    for (int i = 0; i < n; ++i) {
+        float e[4] = { lines[4 * i], lines[4 * i + 1], lines[4 * i + 2], lines[4 * i + 3] };
+        if (e[0] < 0) e[0] = 0;
+        if (e[0] >= cols) e[0] = (float)cols - 1.0f;
+        if (e[2] < 0) e[2] = 0;
+        if (e[2] >= cols) e[2] = (float)cols - 1.0f;
+        if (e[1] < 0) e[1] = 0;
+        if (e[1] >= rows) e[1] = (float)rows - 1.0f;
+        if (e[3] < 0) e[3] = 0;
+        if (e[3] >= rows) e[3] = (float)rows - 1.0f;
+        for (int k = 0; k < 4; ++k) ext[4 * i + k] = e[k];
+        /* cv::LineIterator(img, Point(round), Point(round)), 8-connected: count = max(|dx|,|dy|)+1 */
+        int x0 = cv_round(e[0]), y0 = cv_round(e[1]), x1 = cv_round(e[2]), y1 = cv_round(e[3]);
+        int adx = x1 - x0; if (adx < 0) adx = -adx;
+        int ady = y1 - y0; if (ady < 0) ady = -ady;
+        npx[i] = (adx > ady ? adx : ady) + 1;
+        float ddy = e[3] - e[1], ddx = e[2] - e[0];
+        angle[i] = (float)lfo_atan2((double)ddy, (double)ddx);
+    }
+}
+
+void lfo_lbd(const int16_t* pdx, const int16_t* pdy, int rows, int cols,
+             const float* ext, const float* angle, const int32_t* npx, int n,
+             float* desc72, uint8_t* code32)
+{
+    /* binary_descriptor_custom.cpp:217-259 (integer divisions in u and sigma kept) */
+    double gaussCoefL[WIDTH_OF_BAND * 3], gaussCoefG[NUM_OF_BANDS * WIDTH_OF_BAND];
+    {
+        double u = (WIDTH_OF_BAND * 3 - 1) / 2;
+        double sigma = (WIDTH_OF_BAND * 2 + 1) / 2;
+        double invsigma2 = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < WIDTH_OF_BAND * 3; ++i) { double dis = i - u; gaussCoefL[i] = lfo_exp(dis * dis * invsigma2); }
+        u = (NUM_OF_BANDS * WIDTH_OF_BAND - 1) / 2;
+        sigma = u;
+        invsigma2 = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < NUM_OF_BANDS * WIDTH_OF_BAND; ++i) { double dis = i - u; gaussCoefG[i] = lfo_exp(dis * dis * invsigma2); }
+    }
+    const short heightOfLSP = WIDTH_OF_BAND * NUM_OF_BANDS;
+    const short halfHeight = (heightOfLSP - 1) / 2;
+    const short realWidth = (short)cols;
+    const short imageWidth = realWidth - 1;
+    const short imageHeight = (short)(rows - 1);
+    for (int li = 0; li < n; ++li) {
+        float pgdLBandSum[NUM_OF_BANDS] = {0}, ngdLBandSum[NUM_OF_BANDS] = {0};
+        float pgdL2BandSum[NUM_OF_BANDS] = {0}, ngdL2BandSum[NUM_OF_BANDS] = {0};
+        float pgdOBandSum[NUM_OF_BANDS] = {0}, ngdOBandSum[NUM_OF_BANDS] = {0};
+        float pgdO2BandSum[NUM_OF_BANDS] = {0}, ngdO2BandSum[NUM_OF_BANDS] = {0};
+        const short lengthOfLSP = (short)npx[li];
+        const short halfWidth = (lengthOfLSP - 1) / 2;
+        const float sX = ext[4 * li], sY = ext[4 * li + 1], eX = ext[4 * li + 2], eY = ext[4 * li + 3];
+        const float lineMiddlePointX = (float)(0.5 * (sX + eX));
+        const float lineMiddlePointY = (float)(0.5 * (sY + eY));
+        float dL[2], dO[2];
+        dL[0] = (float)lfo_cos((double)angle[li]);
+        dL[1] = (float)lfo_sin((double)angle[li]);
+        dO[0] = -dL[1];
+        dO[1] = dL[0];
+        float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
+        float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + lineMiddlePointY;
+        for (short hID = 0; hID < heightOfLSP; hID++) {
+            float sCorX = sCorX0, sCorY = sCorY0;
+            float pgdLRowSum = 0, ngdLRowSum = 0, pgdORowSum = 0, ngdORowSum = 0;
+            for (short wID = 0; wID < lengthOfLSP; wID++) {
+                short tempCor = (short)c_round((double)sCorX);
+                short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+                tempCor = (short)c_round((double)sCorY);
+                short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+                short dx = pdx[yCor * realWidth + xCor];
+                short dy = pdy[yCor * realWidth + xCor];
+                float gDL = dx * dL[0] + dy * dL[1];
+                float gDO = dx * dO[0] + dy * dO[1];
+                if (gDL > 0) pgdLRowSum += gDL; else ngdLRowSum -= gDL;
+                if (gDO > 0) pgdORowSum += gDO; else ngdORowSum -= gDO;
+                sCorX += dL[0];
+                sCorY += dL[1];
+            }
+            sCorX0 -= dL[1];
+            sCorY0 += dL[0];
+            float coef = (float)gaussCoefG[hID];
+            pgdLRowSum = coef * pgdLRowSum;
+            ngdLRowSum = coef * ngdLRowSum;
+            float pgdL2RowSum = pgdLRowSum * pgdLRowSum;
+            float ngdL2RowSum = ngdLRowSum * ngdLRowSum;
+            pgdORowSum = coef * pgdORowSum;
+            ngdORowSum = coef * ngdORowSum;
+            float pgdO2RowSum = pgdORowSum * pgdORowSum;
+            float ngdO2RowSum = ngdORowSum * ngdORowSum;
+            short bandID = (short)(hID / WIDTH_OF_BAND);
+            for (int pass = 0; pass < 3; ++pass) {
+                short b; int tap;
+                if (pass == 0) { b = bandID; tap = hID % WIDTH_OF_BAND + WIDTH_OF_BAND; }
+                else if (pass == 1) { b = bandID - 1; tap = hID % WIDTH_OF_BAND + 2 * WIDTH_OF_BAND; if (b < 0) continue; }
+                else { b = bandID + 1; tap = hID % WIDTH_OF_BAND; if (b >= NUM_OF_BANDS) continue; }
+                coef = (float)gaussCoefL[tap];
+                pgdLBandSum[b] += coef * pgdLRowSum;
+                ngdLBandSum[b] += coef * ngdLRowSum;
+                pgdL2BandSum[b] += coef * coef * pgdL2RowSum;
+                ngdL2BandSum[b] += coef * coef * ngdL2RowSum;
+                pgdOBandSum[b] += coef * pgdORowSum;
+                ngdOBandSum[b] += coef * ngdORowSum;
+                pgdO2BandSum[b] += coef * coef * pgdO2RowSum;
+                ngdO2BandSum[b] += coef * coef * ngdO2RowSum;
+            }
+        }
+        float* desVec = desc72 + (size_t)72 * li;
+        const float invN2 = (float)(1.0 / (WIDTH_OF_BAND * 2.0));
+        const float invN3 = (float)(1.0 / (WIDTH_OF_BAND * 3.0));
+        for (int b = 0; b < NUM_OF_BANDS; ++b) {
+            float invN = (b == 0 || b == NUM_OF_BANDS - 1) ? invN2 : invN3;
+            int d = b * 8;
+            float temp = pgdLBandSum[b] * invN;
+            desVec[d] = temp;
+            desVec[d + 4] = (float)sqrt((double)(pgdL2BandSum[b] * invN - temp * temp));
+            temp = ngdLBandSum[b] * invN;
+            desVec[d + 1] = temp;
+            desVec[d + 5] = (float)sqrt((double)(ngdL2BandSum[b] * invN - temp * temp));
+            temp = pgdOBandSum[b] * invN;
+            desVec[d + 2] = temp;
+            desVec[d + 6] = (float)sqrt((double)(pgdO2BandSum[b] * invN - temp * temp));
+            temp = ngdOBandSum[b] * invN;
+            desVec[d + 3] = temp;
+            desVec[d + 7] = (float)sqrt((double)(ngdO2BandSum[b] * invN - temp * temp));
+        }
+        float tempM = 0, tempS = 0;
+        for (int b = 0; b < NUM_OF_BANDS; ++b) {
+            const float* v = desVec + 8 * b;
+            tempM += v[0] * v[0]; tempM += v[1] * v[1]; tempM += v[2] * v[2]; tempM += v[3] * v[3];
+            tempS += v[4] * v[4]; tempS += v[5] * v[5]; tempS += v[6] * v[6]; tempS += v[7] * v[7];
+        }
+        tempM = (float)(1 / sqrt((double)tempM));
+        tempS = (float)(1 / sqrt((double)tempS));
+        for (int b = 0; b < NUM_OF_BANDS; ++b) {
+            float* v = desVec + 8 * b;
+            v[0] = v[0] * tempM; v[1] = v[1] * tempM; v[2] = v[2] * tempM; v[3] = v[3] * tempM;
+            v[4] = v[4] * tempS; v[5] = v[5] * tempS; v[6] = v[6] * tempS; v[7] = v[7] * tempS;
+        }
+        for (int i = 0; i < 72; ++i) if ((double)desVec[i] > 0.4) desVec[i] = (float)0.4;
+        float temp = 0;
+        for (int i = 0; i < 72; ++i) temp += desVec[i] * desVec[i];
+        temp = (float)(1 / sqrt((double)temp));
+        for (int i = 0; i < 72; ++i) desVec[i] = desVec[i] * temp;
+        /* :653-667 + :401-412 */
+        uint8_t* code = code32 + (size_t)32 * li;
+        for (int cidx = 0; cidx < 32; ++cidx) {
+            const float* f1 = desVec + 8 * COMB[cidx][0];
+            const float* f2 = desVec + 8 * COMB[cidx][1];
+            unsigned r = 0;
+            for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) r += 1u << i;
+            code[cidx] = (uint8_t)r;
+        }
+    }
+}
+
+/* binary_descriptor_matcher.cpp:197-254 with Mihasher(256,32), K=1: exact Hamming
+ * nearest neighbour; candidates farther than D = 128 are never reported
+ * (:721, the result slot stays unset -> defined here as idx -1, dist -1).
+ * The reference breaks distance ties by hash-table discovery order; the oracle
+ * (and the GPU) take the lowest train index; tests compare indices only where
+ * the minimum is unique.
+ */
+void lfo_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist)
+{
+    for (int i = 0; i < nq; ++i) {
+        int best = 1 << 30, bi = -1;
+        const uint32_t* a = (const uint32_t*)(q + (size_t)32 * i);
+        for (int j = 0; j < nt; ++j) {
+            const uint32_t* b = (const uint32_t*)(t + (size_t)32 * j);
+            int d = 0;
+            for (int k = 0; k < 8; ++k) d += __builtin_popcount(a[k] ^ b[k]);
+            if (d < best) { best = d; bi = j; }
+        }
+        if (bi >= 0 && best <= 128) { idx[i] = bi; dist[i] = (float)best; }
+        else { idx[i] = -1; dist[i] = -1.f; }
+    }
+}
+
+/* float LBD nearest neighbour (Euclidean); double accumulation, float result */
+void lfo_match_float(const float* q, int nq, const float* t, int nt, int32_t* idx, float* dist)
+{
+    for (int i = 0; i < nq; ++i) {
+        double best = 1e300; int bi = -1;
+        for (int j = 0; j < nt; ++j) {
+            double s = 0;
+            for (int k = 0; k < 72; ++k) { double d = (double)q[72 * (size_t)i + k] - (double)t[72 * (size_t)j + k]; s += d * d; }
+            if (s < best) { best = s; bi = j; }
+        }
+        idx[i] = bi;
+        dist[i] = bi >= 0 ? (float)sqrt(best) : -1.f;
+    }
+}

@@ -1,0 +1,292 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes wrapper around oracle/_build/liblforacle.so (the plain-C CPU restatement of
+the reference's line-feature front end).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; nothing under lane_slam_amd/
+does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liblforacle.so")
+
+
+def build(force=False):
+    """Compile the oracle with gcc (idempotent)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class LfoConfig(ctypes.Structure):
+    """ctypes mirror of `lfo_config` (oracle/lf_oracle.h)."""
+    _fields_ = [
+        ("in_rows", ctypes.c_int32), ("in_cols", ctypes.c_int32),
+        ("img_rows", ctypes.c_int32), ("img_cols", ctypes.c_int32),
+        ("top_cutoff", ctypes.c_int32),
+        ("ai_scale", ctypes.c_float * 3), ("ai_shift", ctypes.c_float * 3),
+        ("hsv_lo", (ctypes.c_int32 * 3) * 4), ("hsv_hi", (ctypes.c_int32 * 3) * 4),
+        ("dilation_kernel_size", ctypes.c_int32),
+        ("canny_lo", ctypes.c_double), ("canny_hi", ctypes.c_double),
+        ("lsd_refine", ctypes.c_int32), ("lsd_n_bins", ctypes.c_int32),
+        ("lsd_scale", ctypes.c_double), ("lsd_sigma_scale", ctypes.c_double),
+        ("lsd_quant", ctypes.c_double), ("lsd_ang_th", ctypes.c_double),
+        ("lsd_log_eps", ctypes.c_double), ("lsd_density_th", ctypes.c_double),
+        ("H", ctypes.c_double * 9), ("K", ctypes.c_double * 9), ("D", ctypes.c_double * 5),
+        ("R", ctypes.c_double * 9), ("P", ctypes.c_double * 12),
+        ("cam_w", ctypes.c_int32), ("cam_h", ctypes.c_int32),
+        ("lanewidth", ctypes.c_double), ("linewidth_white", ctypes.c_double),
+        ("linewidth_yellow", ctypes.c_double), ("d_min", ctypes.c_double),
+        ("d_max", ctypes.c_double), ("phi_min", ctypes.c_double), ("phi_max", ctypes.c_double),
+    ]
+
+
+class _FrameOut(ctypes.Structure):
+    _fields_ = [
+        ("n", ctypes.c_int32), ("n_color", ctypes.c_int32 * 3),
+        ("lines", ctypes.c_void_p), ("normals", ctypes.c_void_p), ("color", ctypes.c_void_p),
+        ("pixels_normalized", ctypes.c_void_p), ("ground", ctypes.c_void_p),
+        ("keep", ctypes.c_void_p), ("desc", ctypes.c_void_p), ("code", ctypes.c_void_p),
+    ]
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _struct_from_dict(cfg):
+    s = LfoConfig()
+    det = cfg["detector"]
+    s.in_rows, s.in_cols = cfg["in_size"]
+    s.img_rows, s.img_cols = cfg["img_size"]
+    s.top_cutoff = cfg["top_cutoff"]
+    for i in range(3):
+        s.ai_scale[i] = float(cfg["ai_scale"][i])
+        s.ai_shift[i] = float(cfg["ai_shift"][i])
+    boxes = [("hsv_white1", "hsv_white2"), ("hsv_yellow1", "hsv_yellow2"),
+             ("hsv_red1", "hsv_red2"), ("hsv_red3", "hsv_red4")]
+    for k, (lo, hi) in enumerate(boxes):
+        for ch in range(3):
+            s.hsv_lo[k][ch] = int(det[lo][ch])
+            s.hsv_hi[k][ch] = int(det[hi][ch])
+    s.dilation_kernel_size = int(det["dilation_kernel_size"])
+    s.canny_lo, s.canny_hi = float(det["canny_thresholds"][0]), float(det["canny_thresholds"][1])
+    lsd = cfg["lsd"]
+    s.lsd_refine, s.lsd_n_bins = int(lsd["refine"]), int(lsd["n_bins"])
+    s.lsd_scale, s.lsd_sigma_scale = float(lsd["scale"]), float(lsd["sigma_scale"])
+    s.lsd_quant, s.lsd_ang_th = float(lsd["quant"]), float(lsd["ang_th"])
+    s.lsd_log_eps, s.lsd_density_th = float(lsd["log_eps"]), float(lsd["density_th"])
+    for name, n in (("H", 9), ("K", 9), ("D", 5), ("R", 9), ("P", 12)):
+        arr = getattr(s, name)
+        for i in range(n):
+            arr[i] = float(cfg[name][i])
+    s.cam_h, s.cam_w = cfg["cam_size"]
+    for k, v in cfg["sanity"].items():
+        setattr(s, k, float(v))
+    return s
+
+
+class Oracle(object):
+    """CPU oracle bound to one configuration dict (lane_slam_amd.config.default_config layout)."""
+
+    def __init__(self, cfg):
+        build()
+        self.lib = ctypes.CDLL(_SO)
+        self.lib.lfo_lsd_detect.restype = ctypes.c_int
+        self.lib.lfo_lsd_ll_angle.restype = ctypes.c_int
+        self.lib.lfo_process_frame.restype = ctypes.c_int
+        self.cfg = cfg
+        self.c = _struct_from_dict(cfg)
+        self.rows = cfg["img_size"][0] - cfg["top_cutoff"]
+        self.cols = cfg["img_size"][1]
+
+    # ---- image stages
+    def preprocess(self, bgr_in):
+        bgr_in = np.ascontiguousarray(bgr_in, dtype=np.uint8)
+        assert bgr_in.shape == (self.c.in_rows, self.c.in_cols, 3)
+        out = np.empty((self.rows, self.cols, 3), np.uint8)
+        self.lib.lfo_preprocess(ctypes.byref(self.c), _p(bgr_in), _p(out))
+        return out
+
+    def bgr2hsv(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        out = np.empty_like(bgr)
+        self.lib.lfo_bgr2hsv(_p(bgr), bgr.size // 3, _p(out))
+        return out
+
+    def color_masks(self, hsv):
+        hsv = np.ascontiguousarray(hsv, dtype=np.uint8)
+        npix = hsv.size // 3
+        out = np.empty((3,) + hsv.shape[:-1], np.uint8)
+        self.lib.lfo_color_masks(ctypes.byref(self.c), _p(hsv), npix, _p(out))
+        return out
+
+    def dilate(self, bw, ksize=None):
+        bw = np.ascontiguousarray(bw, dtype=np.uint8)
+        out = np.empty_like(bw)
+        k = self.c.dilation_kernel_size if ksize is None else ksize
+        self.lib.lfo_dilate_ellipse(_p(bw), bw.shape[0], bw.shape[1], k, _p(out))
+        return out
+
+    def canny(self, bgr, lo=None, hi=None):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        out = np.empty(bgr.shape[:2], np.uint8)
+        lo = self.c.canny_lo if lo is None else lo
+        hi = self.c.canny_hi if hi is None else hi
+        self.lib.lfo_canny_bgr(_p(bgr), bgr.shape[0], bgr.shape[1],
+                               ctypes.c_double(lo), ctypes.c_double(hi), _p(out))
+        return out
+
+    def bgr2gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint8)
+        out = np.empty(bgr.shape[:-1], np.uint8)
+        self.lib.lfo_bgr2gray(_p(bgr), out.size, _p(out))
+        return out
+
+    def gaussian5(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        out = np.empty_like(gray)
+        self.lib.lfo_gaussian5_u8(_p(gray), gray.shape[0], gray.shape[1], _p(out))
+        return out
+
+    def sobel3(self, gray):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        dx = np.empty(gray.shape, np.int16)
+        dy = np.empty(gray.shape, np.int16)
+        self.lib.lfo_sobel3_s16(_p(gray), gray.shape[0], gray.shape[1], _p(dx), _p(dy))
+        return dx, dy
+
+    # ---- LSD
+    def lsd_scaled_size(self, rows, cols):
+        a, b = ctypes.c_int(), ctypes.c_int()
+        self.lib.lfo_lsd_scaled_size(ctypes.byref(self.c), rows, cols, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def lsd_scaled_image(self, img):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        sr, sc = self.lsd_scaled_size(*img.shape)
+        out = np.empty((sr, sc), np.float64)
+        self.lib.lfo_lsd_scaled_image(ctypes.byref(self.c), _p(img), img.shape[0], img.shape[1], _p(out))
+        return out
+
+    def lsd_ll_angle(self, scaled):
+        scaled = np.ascontiguousarray(scaled, dtype=np.float64)
+        ang = np.empty_like(scaled)
+        mod = np.empty_like(scaled)
+        order = np.empty(scaled.size, np.int32)
+        n = self.lib.lfo_lsd_ll_angle(ctypes.byref(self.c), _p(scaled), scaled.shape[0], scaled.shape[1],
+                                      _p(ang), _p(mod), _p(order))
+        return ang, mod, order[:n]
+
+    def lsd(self, img, cap=4096, extra=False):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        lines = np.empty((cap, 4), np.float32)
+        ex = np.empty((cap, 3), np.float64)
+        n = self.lib.lfo_lsd_detect(ctypes.byref(self.c), _p(img), img.shape[0], img.shape[1],
+                                    _p(lines), _p(ex), cap)
+        return (lines[:n].copy(), ex[:n].copy()) if extra else lines[:n].copy()
+
+    # ---- per segment
+    def find_normals(self, bw, lines):
+        bw = np.ascontiguousarray(bw, dtype=np.uint8)
+        lines = np.array(lines, dtype=np.float32, order="C").reshape(-1, 4)
+        n = lines.shape[0]
+        normals = np.empty((n, 2), np.float64)
+        centers = np.empty((n, 2), np.float32)
+        self.lib.lfo_find_normals(_p(bw), bw.shape[0], bw.shape[1], _p(lines), n, _p(normals), _p(centers))
+        return lines, normals, centers
+
+    def normalize_lines(self, lines):
+        lines = np.ascontiguousarray(lines, dtype=np.float32).reshape(-1, 4)
+        out = np.empty_like(lines)
+        self.lib.lfo_normalize_lines(ctypes.byref(self.c), _p(lines), lines.shape[0], _p(out))
+        return out
+
+    def ground_project(self, pn):
+        pn = np.ascontiguousarray(pn, dtype=np.float32).reshape(-1, 4)
+        out = np.empty((pn.shape[0], 4), np.float64)
+        self.lib.lfo_ground_project(ctypes.byref(self.c), _p(pn), pn.shape[0], _p(out))
+        return out
+
+    def line_sanity(self, pts, color):
+        pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 4)
+        color = np.ascontiguousarray(color, dtype=np.uint8)
+        n = pts.shape[0]
+        keep = np.empty(n, np.uint8)
+        dphil = np.empty((n, 3), np.float64)
+        state = np.empty(n, np.int32)
+        self.lib.lfo_line_sanity(ctypes.byref(self.c), _p(pts), _p(color), n, _p(keep), _p(dphil), _p(state))
+        return keep, dphil, state
+
+    # ---- LBD / matcher
+    def keylines(self, lines, rows, cols):
+        lines = np.ascontiguousarray(lines, dtype=np.float32).reshape(-1, 4)
+        n = lines.shape[0]
+        ext = np.empty((n, 4), np.float32)
+        ang = np.empty(n, np.float32)
+        npx = np.empty(n, np.int32)
+        self.lib.lfo_keylines(_p(lines), n, rows, cols, _p(ext), _p(ang), _p(npx))
+        return ext, ang, npx
+
+    def lbd(self, dx, dy, ext, ang, npx):
+        dx = np.ascontiguousarray(dx, dtype=np.int16)
+        dy = np.ascontiguousarray(dy, dtype=np.int16)
+        ext = np.ascontiguousarray(ext, dtype=np.float32)
+        ang = np.ascontiguousarray(ang, dtype=np.float32)
+        npx = np.ascontiguousarray(npx, dtype=np.int32)
+        n = ext.shape[0]
+        desc = np.empty((n, 72), np.float32)
+        code = np.empty((n, 32), np.uint8)
+        self.lib.lfo_lbd(_p(dx), _p(dy), dx.shape[0], dx.shape[1], _p(ext), _p(ang), _p(npx), n,
+                         _p(desc), _p(code))
+        return desc, code
+
+    def match(self, q, t):
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        self.lib.lfo_match(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist))
+        return idx, dist
+
+    def match_float(self, q, t):
+        q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 72)
+        t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 72)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        self.lib.lfo_match_float(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist))
+        return idx, dist
+
+    # ---- whole frame
+    def process_frame(self, bgr_in, cap=4096, describe=True):
+        bgr_in = np.ascontiguousarray(bgr_in, dtype=np.uint8)
+        assert bgr_in.shape == (self.c.in_rows, self.c.in_cols, 3), bgr_in.shape
+        arr = {
+            "lines": np.zeros((cap, 4), np.float32), "normals": np.zeros((cap, 2), np.float32),
+            "color": np.zeros(cap, np.uint8), "pixels_normalized": np.zeros((cap, 4), np.float32),
+            "ground": np.zeros((cap, 4), np.float64), "keep": np.zeros(cap, np.uint8),
+            "desc": np.zeros((cap, 72), np.float32), "code": np.zeros((cap, 32), np.uint8),
+        }
+        fo = _FrameOut()
+        for k, v in arr.items():
+            setattr(fo, k, v.ctypes.data)
+        if not describe:
+            fo.desc = None
+            fo.code = None
+        n = self.lib.lfo_process_frame(ctypes.byref(self.c), _p(bgr_in), ctypes.byref(fo), cap)
+        out = {k: v[:n].copy() for k, v in arr.items()}
+        out["n"] = n
+        out["n_color"] = [fo.n_color[i] for i in range(3)]
+        return out
+
+
+def detmath_lib():
+    build()
+    return ctypes.CDLL(_SO)
