@@ -1,0 +1,183 @@
+/*
+ * lanefront -- MI355X-native line-feature front end for lane-slam.  C ABI.
+ *
+ * The reference has no FFI: its hot path is Python calling cv2 / numpy, plus an
+ * unbuilt C++ library.  Each entry point below names the reference interface it
+ * replaces (paths relative to /root/reference).  INTEGRATION.md shows the
+ * ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions: every function returns an lf_status (0 = ok, < 0 = error) and
+ * never throws or aborts across the ABI; lf_last_error() returns a static,
+ * NUL-terminated description of the last failure on that handle.  Pointers are
+ * plain host or device addresses as stated per argument; nothing returned by
+ * the library is owned by it.  A handle is NOT thread-safe: one in-flight
+ * frame/batch per handle, exactly like the reference node, which holds a
+ * non-blocking lock around its detector
+ * (src/line_detector/src/line_detector_node.py:129-139).
+ * There is no CPU fallback: without a HIP device lf_create fails with
+ * LF_ERR_HIP.
+ */
+#ifndef LANEFRONT_H
+#define LANEFRONT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LF_ABI_VERSION 1
+
+typedef enum lf_status {
+    LF_OK = 0,
+    LF_ERR_BAD_ARG = -1,
+    LF_ERR_CAPACITY = -2,     /* caller buffer / configured capacity exceeded */
+    LF_ERR_HIP = -3,          /* HIP runtime error or no device */
+    LF_ERR_NOT_INITIALISED = -4,
+    LF_ERR_UNSUPPORTED = -5
+} lf_status;
+
+/* colour codes: src/duckietown_msgs/msg/Segment.msg:1-3 */
+#define LF_WHITE 0
+#define LF_YELLOW 1
+#define LF_RED 2
+
+/*
+ * Configuration.  Field sources:
+ *   in_*, img_*, top_cutoff  line_detector_node.py:163-169, default.yaml:1-2
+ *   ai_scale / ai_shift      anti_instagram/scale_and_shift.py:25-33 (BGR channel order)
+ *   hsv_*, dilation, canny   line_detector_lsd.py:20-34,38-62; default.yaml:11-23
+ *                            box 0 white, 1 yellow, 2 red1..red2, 3 red3..red4
+ *   lsd_*                    cv2.createLineSegmentDetector arguments (line_detector_lsd.py:65)
+ *   H, K, D, R, P, cam_*     ground_projection/GroundProjection.py:38-78,143-157
+ *   sanity constants         line_sanity/src/line_sanity_node.py:17-23
+ */
+typedef struct lf_config {
+    int32_t in_rows, in_cols;
+    int32_t img_rows, img_cols;
+    int32_t top_cutoff;
+    float ai_scale[3], ai_shift[3];
+    int32_t hsv_lo[4][3], hsv_hi[4][3];
+    int32_t dilation_kernel_size;
+    double canny_lo, canny_hi;
+    int32_t lsd_refine;            /* 0 none, 1 standard, 2 advanced (reference uses 2) */
+    int32_t lsd_n_bins;
+    double lsd_scale, lsd_sigma_scale, lsd_quant, lsd_ang_th, lsd_log_eps, lsd_density_th;
+    double H[9], K[9], D[5], R[9], P[12];
+    int32_t cam_w, cam_h;
+    double lanewidth, linewidth_white, linewidth_yellow, d_min, d_max, phi_min, phi_max;
+} lf_config;
+
+typedef struct lf_handle lf_handle;
+
+/* Struct-of-arrays segment block (the SegmentList of a batch).  Every array is
+ * caller-allocated with room for `capacity` segments; NULL arrays are skipped.
+ * Segments are ordered by frame, then white, yellow, red, then detection order
+ * (line_detector_node.py:197-205).  Field meaning per segment:
+ *   lines              x1,y1,x2,y2 in working-image pixels after endpoint ordering (line_detector_lsd.py:79-84)
+ *   normals            Segment.normal (float32)                     (line_detector_node.py:262-263)
+ *   color              Segment.color
+ *   pixels_normalized  Segment.pixels_normalized[0..1]              (line_detector_node.py:195-205)
+ *   ground             Segment.points[0..1].(x,y); z is 0           (ground_projection_node.py:60-61)
+ *   keep               1 if LineSanityNode.processSegmentList keeps it (line_sanity_node.py:48-72)
+ *   desc / code        float (72) / binary (32 B) LBD descriptor    (binary_descriptor_custom.cpp:1026-1372,653-667)
+ *   frame_offset       n_frames+1 prefix offsets into the arrays
+ */
+typedef struct lf_segments {
+    int32_t capacity;
+    int32_t* frame_offset;
+    float* lines;
+    float* normals;
+    uint8_t* color;
+    float* pixels_normalized;
+    double* ground;
+    uint8_t* keep;
+    float* desc;
+    uint8_t* code;
+} lf_segments;
+
+/* ---- lifetime ------------------------------------------------------------ */
+int lf_abi_version(void);
+
+/* max_frames: largest batch lf_process_batch will be given (1 for the plugin path).
+ * max_lines_per_color: capacity of one LSD run (one frame, one colour). */
+int lf_create(const lf_config* cfg, int device_id, int max_frames, int max_lines_per_color,
+              lf_handle** out);
+void lf_destroy(lf_handle* h);
+const char* lf_last_error(const lf_handle* h);
+/* wait for all work queued on the handle's HIP stream */
+int lf_synchronize(lf_handle* h);
+
+/* ---- plugin path: replaces LineDetectorLSD (line_detector_lsd.py:11-142) ---
+ * lf_set_image  <-> LineDetectorLSD.setImage(bgr)      (:135-139)
+ * lf_detect_lines <-> LineDetectorLSD.detectLines(color) (:127-133): returns
+ *   lines (n,4) float32 reordered, normals (n,2) float64, centers (n,2) float32,
+ *   area = dilated colour mask (rows*cols u8, may be NULL).
+ * The image is the already resized / cropped / colour-corrected working image
+ * (line_detector_node.py:180); it must be rows x cols == the handle's working
+ * size (img_rows - top_cutoff, img_cols).  Host pointers.
+ */
+int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes);
+int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, float* centers2,
+                    uint8_t* area_or_null, int cap, int* n_out);
+
+/* ---- batch path: processImage_ + ground_projection + line_sanity + describe -
+ * Replaces, for a batch of raw camera frames (n_frames x in_rows x in_cols x 3, BGR u8):
+ *   line_detector_node.py:163-213, ground_projection_node.py:55-65,
+ *   line_sanity_node.py:48-72, and BinaryDescriptor::compute
+ *   (binary_descriptor_custom.cpp:524-687) on the detected segments.
+ * frames_on_device / out_on_device: 0 = host pointers, 1 = device pointers
+ * (all arrays of `out` alike).  n_segments receives the total (host int).
+ * With device outputs the call is asynchronous except for the final count
+ * read-back; with host outputs it returns when the data is in place.
+ */
+int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+                     lf_segments* out, int out_on_device, int describe, int* n_segments);
+
+/* ---- association: replaces BinaryDescriptorMatcher::match ------------------
+ * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
+ * each 256-bit query code in the map; idx = -1 and dist = -1 when the nearest
+ * neighbour is farther than 128 bits (:721); ties -> lowest map index.
+ * Computed as an int8 MFMA contraction.  on_device applies to all four arrays.
+ */
+int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
+                 int32_t* idx, float* dist, int on_device);
+/* float LBD (72-d, unit norm) Euclidean nearest neighbour on fp32 MFMA */
+int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
+                       int32_t* idx, float* dist, int on_device);
+
+/* ---- introspection for tests and the benchmark ---------------------------- */
+typedef enum lf_buffer_id {
+    LF_BUF_BGR = 0,          /* u8  [frames][Hc][W][3]   corrected working image          */
+    LF_BUF_MASKS = 1,        /* u8  [frames][3][Hc][W]   dilated colour masks 0/255       */
+    LF_BUF_EDGES = 2,        /* u8  [frames][Hc][W]      Canny edges 0/255                */
+    LF_BUF_LSD_ANGLE = 3,    /* f32 [frames][3][Hs][Ws]  level-line angle, degrees, NOTDEF = -1024 */
+    LF_BUF_LSD_MODGRAD = 4,  /* f64 [frames][3][Hs][Ws]  gradient magnitude               */
+    LF_BUF_LSD_ORDER = 5,    /* i32 [frames][3][Hs*Ws]   seed order (pixel addresses)     */
+    LF_BUF_LSD_NORDER = 6,   /* i32 [frames][3]          seeds per run                    */
+    LF_BUF_LBD_DX = 7,       /* i16 [frames][Hc][W]                                        */
+    LF_BUF_LBD_DY = 8,       /* i16 [frames][Hc][W]                                        */
+    LF_BUF_LSD_COUNTS = 9    /* i32 [frames][3]          lines per run                    */
+} lf_buffer_id;
+/* copy an intermediate buffer of the last batch to host memory (synchronises) */
+int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes);
+/* evaluate one deterministic-math routine on the device (host arrays in/out):
+ * which = 0 exp 1 log 2 sin 3 cos 4 atan 5 asin 6 log10 7 sinh_small 8 atan2(a,b) 9 pow(a,b)
+ *         10 sqrt 11 a/b 12 fastAtan2(float a, float b) 13 sqrtf 14 float a/b */
+int lf_debug_detmath(lf_handle* h, int which, const double* a, const double* b_or_null, double* y, int n);
+/* scaled LSD image size for this handle */
+int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
+
+/* per-kernel timing with HIP events on the handle's stream */
+#define LF_N_STAGES 12
+int lf_set_profiling(lf_handle* h, int enabled);
+/* ms accumulated per stage since the last reset, and launches counted */
+int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n);
+int lf_reset_timing(lf_handle* h);
+const char* lf_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANEFRONT_H */

@@ -1,0 +1,16 @@
+"""lanefront: MI355X-native line-feature front end for lane-slam (detect, describe,
+ground-project, sanity-filter, associate) behind a C ABI (include/lanefront.h).
+
+The package is a thin host-side mirror of the reference's interfaces for this path:
+  LineDetectorHIP  <->  line_detector.LineDetectorLSD (LineDetectorInterface plugin)
+  FrontEnd         <->  batch form of line_detector_node / ground_projection_node /
+                        line_sanity_node callbacks + BinaryDescriptor / BinaryDescriptorMatcher
+There is no CPU fallback: importing works anywhere, but creating a detector without the
+HIP library or without a GPU raises.
+"""
+from .config import (COLOR_NAMES, DEFAULT_DETECTOR_CONFIGURATION, RED, WHITE, YELLOW, default_config)
+from .frontend import FrontEnd, LanefrontError, Segments
+from .line_detector_hip import Detections, LineDetectorHIP, LineDetectorInterface
+
+__all__ = ["FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorInterface", "Detections",
+           "default_config", "DEFAULT_DETECTOR_CONFIGURATION", "WHITE", "YELLOW", "RED", "COLOR_NAMES"]

@@ -1,0 +1,74 @@
+"""ctypes binding of liblanefront.so (include/lanefront.h).  Fails loudly when the HIP
+library has not been built: there is no Python or CPU fallback for any entry point."""
+import ctypes
+import os
+
+from .config import LfConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "liblanefront.so")
+
+LF_N_STAGES = 12
+(LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,
+ LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS) = range(10)
+
+# every symbol include/lanefront.h declares
+EXPORTS = (
+    "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize",
+    "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_associate", "lf_associate_float",
+    "lf_debug_fetch", "lf_debug_detmath", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
+)
+
+
+class LfSegments(ctypes.Structure):
+    _fields_ = [
+        ("capacity", ctypes.c_int32),
+        ("frame_offset", ctypes.c_void_p),
+        ("lines", ctypes.c_void_p), ("normals", ctypes.c_void_p), ("color", ctypes.c_void_p),
+        ("pixels_normalized", ctypes.c_void_p), ("ground", ctypes.c_void_p), ("keep", ctypes.c_void_p),
+        ("desc", ctypes.c_void_p), ("code", ctypes.c_void_p),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load liblanefront.so (built by `make -C lane_slam_amd/csrc` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            "lanefront: %s is missing. Build the HIP library first (python -c 'import __graft_entry__ as g; "
+            "g.build()' or make -C lane_slam_amd/csrc). There is no CPU fallback." % SO_PATH)
+    lib = ctypes.CDLL(SO_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.lf_abi_version.restype = ci
+    lib.lf_create.argtypes = [ctypes.POINTER(LfConfig), ci, ci, ci, ctypes.POINTER(vp)]
+    lib.lf_create.restype = ci
+    lib.lf_destroy.argtypes = [vp]
+    lib.lf_destroy.restype = None
+    lib.lf_last_error.argtypes = [vp]
+    lib.lf_last_error.restype = ctypes.c_char_p
+    lib.lf_synchronize.argtypes = [vp]
+    lib.lf_set_image.argtypes = [vp, vp, ci, ci, ci]
+    lib.lf_detect_lines.argtypes = [vp, ci, vp, vp, vp, vp, ci, ctypes.POINTER(ci)]
+    lib.lf_process_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(LfSegments), ci, ci, ctypes.POINTER(ci)]
+    lib.lf_associate.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci]
+    lib.lf_associate_float.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci]
+    lib.lf_debug_fetch.argtypes = [vp, ci, vp, ctypes.c_size_t]
+    lib.lf_debug_detmath.argtypes = [vp, ci, vp, vp, vp, ci]
+    lib.lf_debug_detmath.restype = ci
+    lib.lf_lsd_size.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.lf_set_profiling.argtypes = [vp, ci]
+    lib.lf_get_timing.argtypes = [vp, vp, vp, ci]
+    lib.lf_reset_timing.argtypes = [vp]
+    lib.lf_stage_name.argtypes = [ci]
+    lib.lf_stage_name.restype = ctypes.c_char_p
+    for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_associate",
+              "lf_associate_float", "lf_debug_fetch", "lf_debug_detmath", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",
+              "lf_reset_timing"):
+        getattr(lib, f).restype = ci
+    _lib = lib
+    return lib

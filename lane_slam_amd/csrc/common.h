@@ -1,0 +1,112 @@
+// lanefront internal declarations shared by the HIP translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/lanefront.h"
+#include "detmath.h"
+
+namespace lf {
+
+constexpr int kMaxKsize = 9;        // dilation structuring element
+constexpr int kMaxGaussTaps = 15;   // LSD Gaussian
+constexpr float kNotDef = -1024.0f; // LSD NOTDEF marker (angle plane, degrees)
+
+enum Stage {
+    ST_PRE = 0, ST_CANNY, ST_HYST, ST_LSD_GRAD, ST_LSD_ORDER, ST_LSD_GROW, ST_SEGMENTS,
+    ST_LBD_GRAD, ST_LBD, ST_ASSOC_PACK, ST_ASSOC, ST_MISC, ST_COUNT
+};
+static_assert(ST_COUNT == LF_N_STAGES, "stage table out of sync with lanefront.h");
+
+struct PreParams {
+    int in_rows, in_cols, img_rows, img_cols, top_cutoff, Hc, W;
+    int resize;
+    double ifx, ify;
+    float ai_scale[3], ai_shift[3];
+    int lo[4][3], hi[4][3];
+    int ksize, r;
+    int j1[kMaxKsize], j2[kMaxKsize];
+};
+
+struct CannyParams {
+    int Hc, W, Ww;      // Ww = 32-bit words per row of the bit planes
+    int low, high;
+};
+
+struct LsdParams {
+    int Hc, W;          // working image
+    int Hs, Ws;         // scaled image
+    int Ww;             // words per row of the edge bit plane
+    int scaled;         // lsd_scale != 1
+    int ntaps, half;    // Gaussian
+    double k[kMaxGaussTaps];
+    double rho;         // gradient threshold quant / sin(prec)
+    double prec, p;     // angle tolerance (rad) and its probability
+    double log_nt, log_eps, density_th, scale;
+    int min_reg_size, n_bins, refine;
+    int cap_lines;
+};
+
+struct SegParams {
+    int Hc, W, img_rows, img_cols, top_cutoff, cap_lines;
+    double rx, ry, cut;
+    double cw, ch;
+    double H[9], K[9], D[5], RR[9];
+    double lanewidth, linewidth_white, linewidth_yellow, d_min, d_max, phi_min, phi_max;
+};
+
+// device resize tables for the LSD bilinear step (cv::resize INTER_LINEAR on CV_64F)
+struct ResizeTables {
+    const int* xofs;      // [Ws]
+    const float* xa;      // [2*Ws]
+    const int* y0;        // [Hs]
+    const int* y1;        // [Hs]
+    const float* yb;      // [2*Hs]
+    int xmax;
+};
+
+}  // namespace lf
+
+#define LF_HIP_CHECK(h, expr)                                                              \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            lf_set_error((h), LF_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                         __FILE__, __LINE__);                                              \
+            return LF_ERR_HIP;                                                             \
+        }                                                                                  \
+    } while (0)
+
+extern "C" void lf_set_error(lf_handle* h, int code, const char* fmt, ...);
+
+// kernel launchers (one per translation unit)
+namespace lf {
+void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint8_t* bgr, uint8_t* masks,
+                const int* sdiv, const int* hdiv, hipStream_t s);
+void launch_canny(const CannyParams& p, const uint8_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
+                  hipStream_t s);
+int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, const uint32_t* weak, hipStream_t s);
+void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, uint8_t* edges, hipStream_t s);
+void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
+                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn,
+                     unsigned long long* maxgrad, int max_nsx, int max_nsy, hipStream_t s);
+void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
+                      const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
+                      hipStream_t s);
+void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
+                     const double* sn, const uint32_t* order, const int* norder, uint32_t* reg,
+                     float* lines, int* counts, hipStream_t s);
+void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
+                        int* overflow, hipStream_t s);
+void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,
+                     const int* seg_offset, const uint8_t* masks, lf_segments out, int* seg_frame,
+                     double* normals64, float* centers, hipStream_t s);
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s);
+void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
+                const int16_t* dx, const int16_t* dy, const float* gauss_g, const float* gauss_l,
+                float* desc, uint8_t* code, hipStream_t s);
+void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* mx,
+                  unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
+void launch_assoc_float(const float* q, int nq, const float* m, int nm, float* qn, float* mn,
+                        unsigned long long* best, int32_t* idx, float* dist, hipStream_t s);
+}  // namespace lf

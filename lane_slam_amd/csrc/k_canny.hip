@@ -1,0 +1,199 @@
+// K_canny: cv2.Canny(bgr, lo, hi, apertureSize=3) on the 3-channel working image.
+//
+// Reference call site: /root/reference/src/line_detector/include/line_detector/line_detector_lsd.py:60-62,139.
+// Arithmetic (OpenCV 3.x canny.cpp, restated): Sobel 3x3 -> s16 per channel with
+// BORDER_REPLICATE, L1 magnitude, per pixel the channel with the largest magnitude (first
+// wins ties), non-maximum suppression with the 15-bit TG22 sector test against a
+// zero-padded magnitude image, then 8-connected hysteresis.
+//
+// k_canny_nms: one 64x16 tile per workgroup; BGR tile (+2 halo) -> LDS, magnitude tile
+//   (+1 halo) -> LDS, NMS classification; each wave owns image rows so the 64-lane ballot
+//   IS the 64-pixel bit-plane word pair.  Output: `weak` (m > low and local max) and
+//   `strong` (also m > high) bit planes, 1 bit per pixel -- 8x fewer bytes than u8 maps.
+//   Algorithmic bytes per pixel: 3 read, 2/8 written.
+// k_hysteresis: one workgroup per frame, both bit planes resident in LDS; Jacobi sweeps of
+//   "strong |= weak & dilate3x3(strong)" with an exact in-word run fill (carry trick) until
+//   a sweep changes nothing.  The fixpoint is unique, so the result does not depend on
+//   sweep order (== the reference's stack-based flood fill).
+#include "common.h"
+
+namespace lf {
+
+constexpr int CT_W = 64, CT_H = 16;
+
+__global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint8_t* __restrict__ bgr,
+                                                   uint32_t* __restrict__ strong, uint32_t* __restrict__ weak)
+{
+    __shared__ uint32_t px[(CT_H + 4) * (CT_W + 4)];
+    __shared__ int mag[(CT_H + 2) * (CT_W + 2)];
+    __shared__ int gxy[(CT_H + 2) * (CT_W + 2)];
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H, f = blockIdx.z;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const uint8_t* img = bgr + (size_t)f * p.Hc * p.W * 3;
+    constexpr int PW = CT_W + 4, PH = CT_H + 4, MW = CT_W + 2, MH = CT_H + 2;
+
+    for (int idx = tid; idx < PW * PH; idx += 256) {
+        int ty = idx / PW, tx = idx - ty * PW;
+        int gx = min(max(x0 + tx - 2, 0), p.W - 1);
+        int gy = min(max(y0 + ty - 2, 0), p.Hc - 1);
+        const uint8_t* q = img + ((size_t)gy * p.W + gx) * 3;
+        px[idx] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MW * MH; idx += 256) {
+        int ty = idx / MW, tx = idx - ty * MW;
+        int gx = x0 + tx - 1, gy = y0 + ty - 1;
+        int best = 0, bx = 0, by = 0;
+        if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
+            best = -1;
+            const uint32_t* c = px + (ty + 1) * PW + (tx + 1);
+            uint32_t a00 = c[-PW - 1], a01 = c[-PW], a02 = c[-PW + 1];
+            uint32_t a10 = c[-1], a12 = c[1];
+            uint32_t a20 = c[PW - 1], a21 = c[PW], a22 = c[PW + 1];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                int sh = 8 * ch;
+                int v00 = (a00 >> sh) & 255, v01 = (a01 >> sh) & 255, v02 = (a02 >> sh) & 255;
+                int v10 = (a10 >> sh) & 255, v12 = (a12 >> sh) & 255;
+                int v20 = (a20 >> sh) & 255, v21 = (a21 >> sh) & 255, v22 = (a22 >> sh) & 255;
+                int dx = (v02 - v00) + 2 * (v12 - v10) + (v22 - v20);
+                int dy = (v20 - v00) + 2 * (v21 - v01) + (v22 - v02);
+                int m = abs(dx) + abs(dy);
+                if (m > best) { best = m; bx = dx; by = dy; }
+            }
+        }
+        mag[idx] = best;
+        gxy[idx] = (bx & 0xFFFF) | (by << 16);
+    }
+    __syncthreads();
+    const int TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5);
+    for (int ry = threadIdx.y; ry < CT_H; ry += 4) {
+        const int gx = x0 + threadIdx.x, gy = y0 + ry;
+        bool keep = false, hi = false;
+        if (gx < p.W && gy < p.Hc) {
+            const int* pm = mag + (ry + 1) * MW + threadIdx.x + 1;
+            int m = pm[0];
+            if (m > p.low) {
+                int g = gxy[(ry + 1) * MW + threadIdx.x + 1];
+                int xs = (int)(short)(g & 0xFFFF), ys = g >> 16;
+                int ax = abs(xs);
+                int ay = abs(ys) << 15;
+                int tg22x = ax * TG22;
+                if (ay < tg22x) keep = (m > pm[-1] && m >= pm[1]);
+                else {
+                    int tg67x = tg22x + (ax << 16);
+                    if (ay > tg67x) keep = (m > pm[-MW] && m >= pm[MW]);
+                    else {
+                        int s = (xs ^ ys) < 0 ? -1 : 1;
+                        keep = (m > pm[-MW - s] && m > pm[MW + s]);
+                    }
+                }
+                hi = keep && m > p.high;
+            }
+        }
+        unsigned long long bw = __ballot(keep), bs = __ballot(hi);
+        if (gy < p.Hc) {
+            int word = (x0 >> 5) + (threadIdx.x >> 5);
+            if ((threadIdx.x & 31) == 0 && word < p.Ww) {
+                size_t o = ((size_t)f * p.Hc + gy) * p.Ww + word;
+                int sh = threadIdx.x & 32;
+                weak[o] = (uint32_t)(bw >> sh);
+                strong[o] = (uint32_t)(bs >> sh);
+            }
+        }
+    }
+}
+
+void launch_canny(const CannyParams& p, const uint8_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
+                  hipStream_t s)
+{
+    dim3 grid((p.W + CT_W - 1) / CT_W, (p.Hc + CT_H - 1) / CT_H, n_frames);
+    hipLaunchKernelGGL(k_canny_nms, grid, dim3(64, 4), 0, s, p, bgr, strong, weak);
+}
+
+// fill every run of ones in w that contains a one of s (s is a subset of w), upward direction
+__device__ __forceinline__ uint32_t fill_up(uint32_t w, uint32_t s) { return (((w + s) ^ w) & w) | s; }
+
+__global__ __launch_bounds__(1024) void k_hysteresis(CannyParams p, uint32_t* __restrict__ strong,
+                                                      const uint32_t* __restrict__ weak)
+{
+    extern __shared__ uint32_t lds[];
+    const int nw = p.Hc * p.Ww;
+    uint32_t* S = lds;
+    uint32_t* Wk = lds + nw;
+    const int f = blockIdx.x;
+    uint32_t* gs = strong + (size_t)f * nw;
+    const uint32_t* gw = weak + (size_t)f * nw;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) { S[i] = gs[i]; Wk[i] = gw[i]; }
+    __syncthreads();
+    const int Ww = p.Ww;
+    for (int iter = 0; iter < 65536; ++iter) {
+        int changed = 0;
+        // Jacobi sweep: read S (old), write into registers, then store after a barrier
+        uint32_t upd[8];
+#pragma unroll
+        for (int cnt = 0; cnt < 8; ++cnt) {
+            const int i = threadIdx.x + cnt * 1024;
+            upd[cnt] = 0;
+            if (i >= nw) continue;
+            int y = i / Ww, x = i - y * Ww;
+            uint32_t w = Wk[i];
+            uint32_t cur = S[i];
+            uint32_t acc = 0;
+            if (w) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    int yy = y + dy;
+                    if (yy < 0 || yy >= p.Hc) continue;
+                    const uint32_t* row = S + yy * Ww;
+                    uint32_t c = row[x];
+                    uint32_t l = x > 0 ? row[x - 1] : 0u;
+                    uint32_t r = x + 1 < Ww ? row[x + 1] : 0u;
+                    acc |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+                }
+                uint32_t s = acc & w;
+                // exact horizontal run fill inside the word, both directions
+                s = fill_up(w, s);
+                s = __brev(fill_up(__brev(w), __brev(s)));
+                acc = s;
+            }
+            upd[cnt] = acc | cur;
+            changed |= (upd[cnt] != cur);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cnt = 0; cnt < 8; ++cnt) {
+            const int i = threadIdx.x + cnt * 1024;
+            if (i < nw) S[i] = upd[cnt];
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) gs[i] = S[i];
+}
+
+int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, const uint32_t* weak, hipStream_t s)
+{
+    const int nw = p.Hc * p.Ww;
+    const size_t lds = (size_t)nw * 2 * sizeof(uint32_t);
+    if (lds > 160 * 1024 || nw > 8 * 1024) return -1;   // larger images: not in this round
+    hipLaunchKernelGGL(k_hysteresis, dim3(n_frames), dim3(1024), lds, s, p, strong, weak);
+    return 0;
+}
+
+__global__ void k_edges_u8(CannyParams p, int n_frames, const uint32_t* __restrict__ bits, uint8_t* __restrict__ edges)
+{
+    size_t total = (size_t)n_frames * p.Hc * p.W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t row = i / p.W;
+        int x = (int)(i - row * p.W);
+        uint32_t w = bits[row * p.Ww + (x >> 5)];
+        edges[i] = ((w >> (x & 31)) & 1u) ? 255 : 0;
+    }
+}
+
+void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, uint8_t* edges, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_edges_u8, dim3(1024), dim3(256), 0, s, p, n_frames, bits, edges);
+}
+
+}  // namespace lf

@@ -1,0 +1,241 @@
+// LBD line descriptor (a-9).
+//
+// Reference (never built by the reference itself; restated, see oracle/lf_oracle_lbd.c):
+//   /root/reference/src/line_descriptor/src/binary_descriptor_custom.cpp
+//     :350-398 computeSobel   (cvtColor BGR2GRAY, GaussianBlur 5x5 sigma 1, Sobel 3x3 -> s16)
+//     :1026-1372 computeLBD   :401-412,653-667 binary code   :74-107 pair table
+//   /root/reference/src/line_descriptor/src/LSDDetector_custom.cpp:73-102,169-197 KeyLine fields
+//
+// k_lbd_grad: 64x16 tile per workgroup; gray (+3 halo, BORDER_REFLECT_101) -> LDS, 5x5
+//   fixed-point Gaussian {14,63,103,63,14}/256 twice -> LDS, Sobel -> s16 dx,dy.  Integer exact.
+//   Algorithmic bytes per pixel: 3 read, 4 written.
+// k_lbd: ONE WAVE PER SEGMENT.  Lane r (< 63) walks row r of the 63 x len support region
+//   with the reference's running float coordinates (rounded per step, clamped), gathering
+//   s16 gradients; the per-row sums are scaled by the global Gaussian, staged in LDS, and
+//   lanes 0..71 each accumulate one (band, statistic) sum in the reference's row order;
+//   the three normalisations are wave reductions done in the reference's summation order.
+#include "common.h"
+
+namespace lf {
+
+constexpr int LT_W = 64, LT_H = 16;
+
+__device__ __forceinline__ int refl101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { p = p < 0 ? -p : 2 * (n - 1) - p; }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* __restrict__ bgr,
+                                                  int16_t* __restrict__ dxo, int16_t* __restrict__ dyo)
+{
+    constexpr int GW = LT_W + 6, GH = LT_H + 6;     // gray tile
+    constexpr int RW = LT_W + 2;                     // row-filtered: GH rows x RW cols
+    constexpr int BW_ = LT_W + 2, BH = LT_H + 2;     // blurred tile
+    __shared__ uint8_t gray[GH * GW];
+    __shared__ int rowf[GH * RW];
+    __shared__ uint8_t blur[BH * BW_];
+    const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H, f = blockIdx.z;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const uint8_t* img = bgr + (size_t)f * Hc * W * 3;
+    for (int idx = tid; idx < GW * GH; idx += 256) {
+        int ty = idx / GW, tx = idx - ty * GW;
+        int gx = refl101(x0 + tx - 3, W), gy = refl101(y0 + ty - 3, Hc);
+        const uint8_t* q = img + ((size_t)gy * W + gx) * 3;
+        gray[idx] = (uint8_t)((q[0] * 1868 + q[1] * 9617 + q[2] * 4899 + (1 << 13)) >> 14);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < GH * RW; idx += 256) {
+        int ty = idx / RW, tx = idx - ty * RW;
+        const uint8_t* s = gray + ty * GW + tx;
+        rowf[idx] = 14 * s[0] + 63 * s[1] + 103 * s[2] + 63 * s[3] + 14 * s[4];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < BH * BW_; idx += 256) {
+        int ty = idx / BW_, tx = idx - ty * BW_;
+        const int* s = rowf + ty * RW + tx;
+        int v = 14 * s[0] + 63 * s[RW] + 103 * s[2 * RW] + 63 * s[3 * RW] + 14 * s[4 * RW];
+        v = (v + (1 << 15)) >> 16;
+        blur[idx] = (uint8_t)min(max(v, 0), 255);
+    }
+    __syncthreads();
+    for (int ry = threadIdx.y; ry < LT_H; ry += 4) {
+        int gx = x0 + threadIdx.x, gy = y0 + ry;
+        if (gx >= W || gy >= Hc) continue;
+        const uint8_t* c = blur + (ry + 1) * BW_ + threadIdx.x + 1;
+        int vx = (c[-BW_ + 1] - c[-BW_ - 1]) + 2 * (c[1] - c[-1]) + (c[BW_ + 1] - c[BW_ - 1]);
+        int vy = (c[BW_ - 1] - c[-BW_ - 1]) + 2 * (c[BW_] - c[-BW_]) + (c[BW_ + 1] - c[-BW_ + 1]);
+        size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
+        dxo[o] = (int16_t)vx;
+        dyo[o] = (int16_t)vy;
+    }
+}
+
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s)
+{
+    dim3 grid((W + LT_W - 1) / LT_W, (Hc + LT_H - 1) / LT_H, n_frames);
+    hipLaunchKernelGGL(k_lbd_grad, grid, dim3(64, 4), 0, s, Hc, W, bgr, dx, dy);
+}
+
+__constant__ int c_comb[32][2] = {
+    {0,1},{0,2},{0,3},{0,4},{0,5},{0,6},{1,2},{1,3},{1,4},{1,5},{1,6},{2,3},{2,4},{2,5},{2,6},{2,7},
+    {2,8},{3,4},{3,5},{3,6},{3,7},{3,8},{4,5},{4,6},{4,7},{4,8},{5,6},{5,7},{5,8},{6,7},{6,8},{7,8} };
+
+constexpr int NBANDS = 9, WBAND = 7, LSP_H = 63;
+
+__global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restrict__ n_seg_ptr,
+                                             const float* __restrict__ lines, const int* __restrict__ seg_frame,
+                                             const int16_t* __restrict__ dxi, const int16_t* __restrict__ dyi,
+                                             const float* __restrict__ gauss_g /*63*/, const float* __restrict__ gauss_l /*21*/,
+                                             float* __restrict__ desc, uint8_t* __restrict__ code)
+{
+    __shared__ float rows[4][LSP_H][4];      // per wave: row sums pgdL, ngdL, pgdO, ngdO (already * coefG)
+    __shared__ float dsc[4][72];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * 4 + wave;
+    const int n_seg = *n_seg_ptr;
+    if (seg >= n_seg) return;                // whole wave exits together
+    const int f = seg_frame[seg];
+    const int16_t* pdx = dxi + (size_t)f * Hc * W;
+    const int16_t* pdy = dyi + (size_t)f * Hc * W;
+    // KeyLine fields (LSDDetector_custom.cpp:73-102,169-197), octave 0
+    float e0 = lines[4 * (size_t)seg], e1 = lines[4 * (size_t)seg + 1], e2 = lines[4 * (size_t)seg + 2], e3 = lines[4 * (size_t)seg + 3];
+    if (e0 < 0) e0 = 0;
+    if (e0 >= W) e0 = (float)W - 1.0f;
+    if (e2 < 0) e2 = 0;
+    if (e2 >= W) e2 = (float)W - 1.0f;
+    if (e1 < 0) e1 = 0;
+    if (e1 >= Hc) e1 = (float)Hc - 1.0f;
+    if (e3 < 0) e3 = 0;
+    if (e3 >= Hc) e3 = (float)Hc - 1.0f;
+    const int ix0 = dm::round_half_even((double)e0), iy0 = dm::round_half_even((double)e1);
+    const int ix1 = dm::round_half_even((double)e2), iy1 = dm::round_half_even((double)e3);
+    const int lengthOfLSP = max(abs(ix1 - ix0), abs(iy1 - iy0)) + 1;
+    const float ddy = e3 - e1, ddx = e2 - e0;
+    const float direction = (float)dm::datan2((double)ddy, (double)ddx);
+    const int halfWidth = (lengthOfLSP - 1) / 2;
+    const int halfHeight = (LSP_H - 1) / 2;
+    const int imageWidth = W - 1, imageHeight = Hc - 1;
+    const float midX = (float)(0.5 * (e0 + e2));
+    const float midY = (float)(0.5 * (e1 + e3));
+    double sn_, cs_;
+    dm::dsincos((double)direction, sn_, cs_);
+    const float dL0 = (float)cs_, dL1 = (float)sn_;
+    const float dO0 = -dL1, dO1 = dL0;
+    float sCorX0 = -dL0 * halfWidth + dL1 * halfHeight + midX;
+    float sCorY0 = -dL1 * halfWidth - dL0 * halfHeight + midY;
+    if (lane < LSP_H) {
+        // the reference advances the row origin by repeated float updates: replay them
+        for (int hh = 0; hh < lane; ++hh) { sCorX0 -= dL1; sCorY0 += dL0; }
+        float sCorX = sCorX0, sCorY = sCorY0;
+        float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
+        for (int w = 0; w < lengthOfLSP; ++w) {
+            int tx = (int)dm::round_half_away((double)sCorX);
+            int xCor = tx < 0 ? 0 : (tx > imageWidth ? imageWidth : tx);
+            int ty = (int)dm::round_half_away((double)sCorY);
+            int yCor = ty < 0 ? 0 : (ty > imageHeight ? imageHeight : ty);
+            int dx = pdx[yCor * W + xCor];
+            int dy = pdy[yCor * W + xCor];
+            float gDL = (float)dx * dL0 + (float)dy * dL1;
+            float gDO = (float)dx * dO0 + (float)dy * dO1;
+            if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
+            if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
+            sCorX += dL0;
+            sCorY += dL1;
+        }
+        const float cg = gauss_g[lane];
+        rows[wave][lane][0] = cg * pgdL;
+        rows[wave][lane][1] = cg * ngdL;
+        rows[wave][lane][2] = cg * pgdO;
+        rows[wave][lane][3] = cg * ngdO;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // band accumulation: 72 sums (band b, statistic q in 0..7: pgdL ngdL pgdO ngdO pgdL2 ngdL2 pgdO2 ngdO2),
+    // each the reference's ordered sum over rows hID of band b-1 (tap hID%7), b (tap +7), b+1 (tap +14)
+    float* D = dsc[wave];
+    for (int e = lane; e < 72; e += 64) {
+        const int b = e >> 3, q = e & 7;
+        const bool sq = q >= 4;
+        const int src = q & 3;
+        float acc = 0;
+        for (int hID = max(0, (b - 1) * WBAND); hID < min(LSP_H, (b + 2) * WBAND); ++hID) {
+            const int rb = hID / WBAND;
+            const int tap = hID % WBAND + (rb == b ? WBAND : (rb == b + 1 ? 2 * WBAND : 0));
+            const float coef = gauss_l[tap];
+            const float v = rows[wave][hID][src];
+            if (!sq) acc += coef * v;
+            else acc += coef * coef * (v * v);
+        }
+        D[e] = acc;     // temporarily: band sums laid out [b][q]
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // mean / std per band (lanes 0..8), reference layout: desVec[b*8 + {0:pgdL,1:ngdL,2:pgdO,3:ngdO, 4..7 std}]
+    float mean[4] = {0, 0, 0, 0}, sd[4] = {0, 0, 0, 0};
+    if (lane < NBANDS) {
+        const float invN = (lane == 0 || lane == NBANDS - 1) ? (float)(1.0 / (WBAND * 2.0)) : (float)(1.0 / (WBAND * 3.0));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float temp = D[lane * 8 + q] * invN;
+            mean[q] = temp;
+            sd[q] = (float)dm::dsqrt((double)(D[lane * 8 + 4 + q] * invN - temp * temp));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < NBANDS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { D[lane * 8 + q] = mean[q]; D[lane * 8 + 4 + q] = sd[q]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // normalisation: sequential float sums in the reference's order (uniform across lanes)
+    float tempM = 0, tempS = 0;
+    for (int b = 0; b < NBANDS; ++b) {
+        const float* v = D + 8 * b;
+        tempM += v[0] * v[0]; tempM += v[1] * v[1]; tempM += v[2] * v[2]; tempM += v[3] * v[3];
+        tempS += v[4] * v[4]; tempS += v[5] * v[5]; tempS += v[6] * v[6]; tempS += v[7] * v[7];
+    }
+    tempM = (float)(1 / dm::dsqrt((double)tempM));
+    tempS = (float)(1 / dm::dsqrt((double)tempS));
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < 72; e += 64) {
+        float v = D[e] * (((e & 7) < 4) ? tempM : tempS);
+        if ((double)v > 0.4) v = (float)0.4;
+        D[e] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float temp = 0;
+    for (int i = 0; i < 72; ++i) temp += D[i] * D[i];
+    temp = (float)(1 / dm::dsqrt((double)temp));
+    __builtin_amdgcn_wave_barrier();
+    for (int e = lane; e < 72; e += 64) {
+        float v = D[e] * temp;
+        D[e] = v;
+        if (desc) desc[(size_t)seg * 72 + e] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (code && lane < 32) {
+        const float* f1 = D + 8 * c_comb[lane][0];
+        const float* f2 = D + 8 * c_comb[lane][1];
+        unsigned r = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) r += 1u << i;
+        code[(size_t)seg * 32 + lane] = (uint8_t)r;
+    }
+}
+
+void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
+                const int16_t* dx, const int16_t* dy, const float* gauss_g, const float* gauss_l,
+                float* desc, uint8_t* code, hipStream_t s)
+{
+    if (n_seg_cap <= 0) return;
+    hipLaunchKernelGGL(k_lbd, dim3((n_seg_cap + 3) / 4), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dx, dy,
+                       gauss_g, gauss_l, desc, code);
+}
+
+}  // namespace lf

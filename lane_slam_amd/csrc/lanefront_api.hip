@@ -1,0 +1,712 @@
+// lanefront C ABI (include/lanefront.h): handle, device memory plan, stage sequencing.
+// Host-side constants that enter the arithmetic (Gaussian taps, rho, LOG_NT, resize taps,
+// HSV division tables, LBD weights) are computed here with the same deterministic
+// routines (detmath.h) the kernels use, so they carry the same bits as the CPU oracle's.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <new>
+#include "common.h"
+
+using namespace lf;
+
+static const char* kStageNames[LF_N_STAGES] = {
+    "pre(resize+correct+hsv+masks+dilate)", "canny_nms", "canny_hysteresis", "lsd_blur_resample_grad",
+    "lsd_order", "lsd_grow", "segments(normal+project+sanity)", "lbd_gray_blur_sobel", "lbd_descriptor",
+    "assoc_pack", "assoc_mfma", "misc" };
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct lf_handle {
+    lf_config cfg;
+    int device = 0;
+    int max_frames = 0, cap_lines = 0;
+    hipStream_t stream = nullptr;
+    char err[512];
+    int err_code = 0;
+    // geometry
+    int Hc = 0, W = 0, Hs = 0, Ws = 0, Ww = 0;
+    size_t P = 0, Ps = 0;
+    PreParams pre;
+    CannyParams canny;
+    LsdParams lsd;
+    SegParams seg;
+    ResizeTables rt;
+    int max_nsx = 0, max_nsy = 0;
+    // device buffers
+    uint8_t *d_frames = nullptr, *d_bgr = nullptr, *d_masks = nullptr, *d_edges_u8 = nullptr;
+    uint32_t *d_strong = nullptr, *d_weak = nullptr;
+    int *d_sdiv = nullptr, *d_hdiv = nullptr;
+    float* d_ang = nullptr;
+    double *d_mod = nullptr, *d_cs = nullptr, *d_sn = nullptr;
+    unsigned long long* d_maxgrad = nullptr;
+    uint32_t *d_order_a = nullptr, *d_order_b = nullptr, *d_reg = nullptr;
+    int *d_norder = nullptr, *d_counts = nullptr, *d_seg_offset = nullptr, *d_frame_offset = nullptr, *d_overflow = nullptr;
+    float* d_slot_lines = nullptr;
+    int* d_seg_frame = nullptr;
+    int16_t *d_dx = nullptr, *d_dy = nullptr;
+    float *d_gauss_g = nullptr, *d_gauss_l = nullptr;
+    int *d_xofs = nullptr, *d_y0 = nullptr, *d_y1 = nullptr;
+    float *d_xa = nullptr, *d_yb = nullptr;
+    // output staging (device side of host-output calls, and the plugin path)
+    lf_segments d_out;
+    double* d_normals64 = nullptr;
+    float* d_centers = nullptr;
+    int out_capacity = 0;
+    // associator scratch (grown on demand)
+    DevBuf a_q, a_m, a_qx, a_mx, a_best, a_idx, a_dist, a_qn, a_mn;
+    // pinned host scalars
+    int* h_pinned = nullptr;     // [0] total segments, [1] overflow
+    int last_frames = 0;
+    bool plugin_ready = false;
+    std::vector<int> h_counts, h_seg_offset;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double ms[LF_N_STAGES];
+    int32_t launches[LF_N_STAGES];
+};
+
+extern "C" void lf_set_error(lf_handle* h, int code, const char* fmt, ...)
+{
+    if (!h) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(h->err, sizeof(h->err), fmt, ap);
+    va_end(ap);
+    h->err_code = code;
+}
+
+static char g_create_err[512] = "no error";
+
+template <typename T>
+static int dalloc(lf_handle* h, T** p, size_t count)
+{
+    LF_HIP_CHECK(h, hipMalloc((void**)p, count ? count * sizeof(T) : sizeof(T)));
+    return LF_OK;
+}
+
+static int ensure(lf_handle* h, DevBuf& b, size_t bytes)
+{
+    if (b.bytes >= bytes) return LF_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.bytes = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    LF_HIP_CHECK(h, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return LF_OK;
+}
+
+struct StageTimer {
+    lf_handle* h; int st;
+    StageTimer(lf_handle* h_, int st_) : h(h_), st(st_) { if (h->profiling) (void)hipEventRecord(h->ev0, h->stream); }
+    ~StageTimer()
+    {
+        if (h->profiling) {
+            (void)hipEventRecord(h->ev1, h->stream);
+            (void)hipEventSynchronize(h->ev1);
+            float t = 0;
+            (void)hipEventElapsedTime(&t, h->ev0, h->ev1);
+            h->ms[st] += t;
+        }
+        h->launches[st] += 1;
+    }
+};
+
+static int cv_round_host(double v) { return dm::round_half_even(v); }
+
+static int build_params(lf_handle* h)
+{
+    const lf_config& c = h->cfg;
+    h->Hc = c.img_rows - c.top_cutoff;
+    h->W = c.img_cols;
+    if (h->Hc <= 0 || h->W <= 0 || c.in_rows <= 0 || c.in_cols <= 0 || c.top_cutoff < 0) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "bad geometry: in %dx%d img %dx%d cutoff %d", c.in_rows, c.in_cols, c.img_rows,
+                     c.img_cols, c.top_cutoff);
+        return LF_ERR_BAD_ARG;
+    }
+    if (h->W % 4 != 0) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols must be a multiple of 4 (got %d)", h->W); return LF_ERR_UNSUPPORTED; }
+    h->P = (size_t)h->Hc * h->W;
+    h->Ww = (h->W + 31) / 32;
+    // ---- pre
+    PreParams& p = h->pre;
+    memset(&p, 0, sizeof(p));
+    p.in_rows = c.in_rows; p.in_cols = c.in_cols; p.img_rows = c.img_rows; p.img_cols = c.img_cols;
+    p.top_cutoff = c.top_cutoff; p.Hc = h->Hc; p.W = h->W;
+    p.resize = (c.img_rows != c.in_rows) || (c.img_cols != c.in_cols);
+    const double fx = (double)c.img_cols / (double)c.in_cols, fy = (double)c.img_rows / (double)c.in_rows;
+    p.ifx = 1.0 / fx; p.ify = 1.0 / fy;
+    for (int i = 0; i < 3; ++i) { p.ai_scale[i] = c.ai_scale[i]; p.ai_shift[i] = c.ai_shift[i]; }
+    for (int k = 0; k < 4; ++k) for (int ch = 0; ch < 3; ++ch) { p.lo[k][ch] = c.hsv_lo[k][ch]; p.hi[k][ch] = c.hsv_hi[k][ch]; }
+    p.ksize = c.dilation_kernel_size;
+    if (p.ksize < 1 || p.ksize > kMaxKsize) { lf_set_error(h, LF_ERR_UNSUPPORTED, "dilation_kernel_size %d not in [1,%d]", p.ksize, kMaxKsize); return LF_ERR_UNSUPPORTED; }
+    p.r = p.ksize / 2;
+    {
+        // cv::getStructuringElement(MORPH_ELLIPSE)
+        int r = p.ksize / 2, cc = p.ksize / 2;
+        double inv_r2 = r ? 1.0 / ((double)r * r) : 0.0;
+        for (int i = 0; i < p.ksize; ++i) {
+            int dy = i - r;
+            p.j1[i] = 0; p.j2[i] = 0;
+            if (abs(dy) <= r) {
+                int dx = cv_round_host(cc * sqrt((r * r - dy * dy) * inv_r2));
+                p.j1[i] = cc - dx > 0 ? cc - dx : 0;
+                p.j2[i] = cc + dx + 1 < p.ksize ? cc + dx + 1 : p.ksize;
+            }
+        }
+        if (p.ksize % 2 == 0) { lf_set_error(h, LF_ERR_UNSUPPORTED, "even dilation kernels are not supported"); return LF_ERR_UNSUPPORTED; }
+    }
+    // ---- canny
+    h->canny.Hc = h->Hc; h->canny.W = h->W; h->canny.Ww = h->Ww;
+    double lo = c.canny_lo, hi = c.canny_hi;
+    if (lo > hi) { double t = lo; lo = hi; hi = t; }
+    h->canny.low = dm::ifloor(lo); h->canny.high = dm::ifloor(hi);
+    // ---- LSD
+    LsdParams& L = h->lsd;
+    memset(&L, 0, sizeof(L));
+    L.Hc = h->Hc; L.W = h->W; L.Ww = h->Ww;
+    L.scaled = c.lsd_scale != 1.0;
+    L.scale = c.lsd_scale;
+    if (c.lsd_scale <= 0 || c.lsd_scale > 1.0) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_scale must be in (0,1]"); return LF_ERR_UNSUPPORTED; }
+    if (L.scaled) { L.Ws = cv_round_host(h->W * c.lsd_scale); L.Hs = cv_round_host(h->Hc * c.lsd_scale); }
+    else { L.Ws = h->W; L.Hs = h->Hc; }
+    h->Hs = L.Hs; h->Ws = L.Ws; h->Ps = (size_t)L.Hs * L.Ws;
+    if (h->Ps >= (1u << 20) || L.Ws > 65535 || L.Hs > 65535) { lf_set_error(h, LF_ERR_UNSUPPORTED, "scaled LSD image too large"); return LF_ERR_UNSUPPORTED; }
+    if (c.lsd_n_bins < 2 || c.lsd_n_bins > 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_n_bins must be in [2,1024]"); return LF_ERR_UNSUPPORTED; }
+    if (L.scaled) {
+        const double sigma = (c.lsd_scale < 1) ? (c.lsd_sigma_scale / c.lsd_scale) : c.lsd_sigma_scale;
+        const double sprec = 3;
+        const unsigned hh = (unsigned)ceil(sigma * sqrt(2 * sprec * dm::dlog(10.0)));
+        const int n = 1 + 2 * (int)hh;
+        if (n > kMaxGaussTaps) { lf_set_error(h, LF_ERR_UNSUPPORTED, "LSD Gaussian needs %d taps (max %d)", n, kMaxGaussTaps); return LF_ERR_UNSUPPORTED; }
+        const double scale2X = -0.5 / (sigma * sigma);
+        double sum = 0;
+        for (int i = 0; i < n; ++i) { double x = i - (n - 1) * 0.5; double t = dm::dexp(scale2X * x * x); L.k[i] = t; sum += t; }
+        sum = 1.0 / sum;
+        for (int i = 0; i < n; ++i) L.k[i] *= sum;
+        L.ntaps = n; L.half = n / 2;
+    } else { L.ntaps = 1; L.half = 0; L.k[0] = 1.0; }
+    L.prec = 3.14159265358979323846 * c.lsd_ang_th / 180;
+    L.p = c.lsd_ang_th / 180;
+    L.rho = c.lsd_quant / dm::dsin(L.prec);
+    L.log_nt = 5 * (dm::dlog10((double)L.Ws) + dm::dlog10((double)L.Hs)) / 2 + dm::dlog10(11.0);
+    L.min_reg_size = (int)(-L.log_nt / dm::dlog10(L.p));
+    L.log_eps = c.lsd_log_eps; L.density_th = c.lsd_density_th;
+    L.n_bins = c.lsd_n_bins; L.refine = c.lsd_refine; L.cap_lines = h->cap_lines;
+    // ---- segments
+    SegParams& S = h->seg;
+    memset(&S, 0, sizeof(S));
+    S.Hc = h->Hc; S.W = h->W; S.img_rows = c.img_rows; S.img_cols = c.img_cols; S.top_cutoff = c.top_cutoff;
+    S.cap_lines = h->cap_lines;
+    S.rx = 1.0 / (double)c.img_cols; S.ry = 1.0 / (double)c.img_rows; S.cut = (double)c.top_cutoff;
+    S.cw = (double)c.cam_w; S.ch = (double)c.cam_h;
+    memcpy(S.H, c.H, sizeof(S.H)); memcpy(S.K, c.K, sizeof(S.K)); memcpy(S.D, c.D, sizeof(S.D));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int t = 0; t < 3; ++t) s += c.P[4 * i + t] * c.R[3 * t + j];
+            S.RR[3 * i + j] = s;
+        }
+    S.lanewidth = c.lanewidth; S.linewidth_white = c.linewidth_white; S.linewidth_yellow = c.linewidth_yellow;
+    S.d_min = c.d_min; S.d_max = c.d_max; S.phi_min = c.phi_min; S.phi_max = c.phi_max;
+    return LF_OK;
+}
+
+static int upload_tables(lf_handle* h)
+{
+    // HSV fixed-point division tables (OpenCV RGB2HSV_b)
+    std::vector<int> sdiv(256), hdiv(256);
+    sdiv[0] = hdiv[0] = 0;
+    for (int i = 1; i < 256; ++i) {
+        sdiv[i] = cv_round_host((255 << 12) / (1.0 * i));
+        hdiv[i] = cv_round_host((180 << 12) / (6.0 * i));
+    }
+    if (dalloc(h, &h->d_sdiv, 256) || dalloc(h, &h->d_hdiv, 256)) return LF_ERR_HIP;
+    LF_HIP_CHECK(h, hipMemcpy(h->d_sdiv, sdiv.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_hdiv, hdiv.data(), 256 * sizeof(int), hipMemcpyHostToDevice));
+    // LSD resize tables (cv::resize INTER_LINEAR, CV_64F)
+    const LsdParams& L = h->lsd;
+    const int Ws = L.Ws, Hs = L.Hs, W = h->W, Hc = h->Hc;
+    std::vector<int> xofs(Ws), y0(Hs), y1(Hs);
+    std::vector<float> xa(2 * (size_t)Ws), yb(2 * (size_t)Hs);
+    int xmax = Ws;
+    const double scale_x = 1.0 / L.scale, scale_y = 1.0 / L.scale;
+    for (int dx = 0; dx < Ws; ++dx) {
+        float fx; int sx;
+        if (L.scaled) {
+            fx = (float)((dx + 0.5) * scale_x - 0.5);
+            sx = dm::ifloor((double)fx);
+            fx -= sx;
+        } else { fx = 0.f; sx = dx; }
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx + 1 >= W) {
+            if (dx < xmax) xmax = dx;
+            if (sx >= W - 1) { fx = 0; sx = W - 1; }
+        }
+        xofs[dx] = sx; xa[2 * dx] = 1.f - fx; xa[2 * dx + 1] = fx;
+    }
+    for (int dy = 0; dy < Hs; ++dy) {
+        float fy; int sy;
+        if (L.scaled) {
+            fy = (float)((dy + 0.5) * scale_y - 0.5);
+            sy = dm::ifloor((double)fy);
+            fy -= sy;
+        } else { fy = 0.f; sy = dy; }
+        yb[2 * dy] = 1.f - fy; yb[2 * dy + 1] = fy;
+        y0[dy] = sy < 0 ? 0 : (sy > Hc - 1 ? Hc - 1 : sy);
+        y1[dy] = sy + 1 < 0 ? 0 : (sy + 1 > Hc - 1 ? Hc - 1 : sy + 1);
+    }
+    // LDS footprint of the worst tile
+    const int GT = 32;
+    int mx = 0, my = 0;
+    for (int X0 = 0; X0 < Ws; X0 += GT) {
+        int X1 = X0 + GT < Ws - 1 ? X0 + GT : Ws - 1;
+        int lo = xofs[X0], hi = xofs[X1] + 1 < W - 1 ? xofs[X1] + 1 : W - 1;
+        if (hi - lo + 1 > mx) mx = hi - lo + 1;
+    }
+    for (int Y0 = 0; Y0 < Hs; Y0 += GT) {
+        int Y1 = Y0 + GT < Hs - 1 ? Y0 + GT : Hs - 1;
+        int lo = y0[Y0], hi = y1[Y1];
+        if (hi - lo + 1 > my) my = hi - lo + 1;
+    }
+    h->max_nsx = mx; h->max_nsy = my;
+    {
+        const int hh = L.half;
+        size_t lds = sizeof(double) * ((size_t)(my + 2 * hh) * mx + (size_t)my * mx + (size_t)my * (GT + 1) + (size_t)(GT + 1) * (GT + 1)) +
+                     (size_t)(my + 2 * hh) * (mx + 2 * hh);
+        if (lds > 64 * 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_scale %.3f needs %zu B of LDS per tile (max 65536)", L.scale, lds); return LF_ERR_UNSUPPORTED; }
+    }
+    if (dalloc(h, &h->d_xofs, Ws) || dalloc(h, &h->d_y0, Hs) || dalloc(h, &h->d_y1, Hs) || dalloc(h, &h->d_xa, 2 * (size_t)Ws) ||
+        dalloc(h, &h->d_yb, 2 * (size_t)Hs)) return LF_ERR_HIP;
+    LF_HIP_CHECK(h, hipMemcpy(h->d_xofs, xofs.data(), Ws * sizeof(int), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_y0, y0.data(), Hs * sizeof(int), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_y1, y1.data(), Hs * sizeof(int), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_xa, xa.data(), 2 * (size_t)Ws * sizeof(float), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_yb, yb.data(), 2 * (size_t)Hs * sizeof(float), hipMemcpyHostToDevice));
+    h->rt.xofs = h->d_xofs; h->rt.xa = h->d_xa; h->rt.y0 = h->d_y0; h->rt.y1 = h->d_y1; h->rt.yb = h->d_yb; h->rt.xmax = xmax;
+    // LBD Gaussian weights (binary_descriptor_custom.cpp:217-259; integer divisions kept)
+    float gg[63], gl[21];
+    {
+        double u = (7 * 3 - 1) / 2;
+        double sigma = (7 * 2 + 1) / 2;
+        double inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < 21; ++i) { double d = i - u; gl[i] = (float)dm::dexp(d * d * inv); }
+        u = (9 * 7 - 1) / 2;
+        sigma = u;
+        inv = -1 / (2 * sigma * sigma);
+        for (int i = 0; i < 63; ++i) { double d = i - u; gg[i] = (float)dm::dexp(d * d * inv); }
+    }
+    if (dalloc(h, &h->d_gauss_g, 63) || dalloc(h, &h->d_gauss_l, 21)) return LF_ERR_HIP;
+    LF_HIP_CHECK(h, hipMemcpy(h->d_gauss_g, gg, sizeof(gg), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_gauss_l, gl, sizeof(gl), hipMemcpyHostToDevice));
+    return LF_OK;
+}
+
+static int alloc_buffers(lf_handle* h)
+{
+    const size_t B = (size_t)h->max_frames, P = h->P, Ps = h->Ps;
+    const size_t in_px = (size_t)h->cfg.in_rows * h->cfg.in_cols;
+    const size_t nprob = B * 3;
+    const size_t cap = nprob * (size_t)h->cap_lines;
+    if (dalloc(h, &h->d_frames, B * in_px * 3) || dalloc(h, &h->d_bgr, B * P * 3) || dalloc(h, &h->d_masks, nprob * P) ||
+        dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) ||
+        dalloc(h, &h->d_ang, nprob * Ps) || dalloc(h, &h->d_mod, nprob * Ps) || dalloc(h, &h->d_cs, nprob * Ps) ||
+        dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
+        dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
+        dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
+        dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
+        dalloc(h, &h->d_dx, B * P) || dalloc(h, &h->d_dy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
+        dalloc(h, &h->d_centers, cap * 2))
+        return LF_ERR_HIP;
+    h->out_capacity = (int)cap;
+    lf_segments& o = h->d_out;
+    memset(&o, 0, sizeof(o));
+    o.capacity = (int)cap;
+    if (dalloc(h, &o.lines, cap * 4) || dalloc(h, &o.normals, cap * 2) || dalloc(h, &o.color, cap) ||
+        dalloc(h, &o.pixels_normalized, cap * 4) || dalloc(h, &o.ground, cap * 4) || dalloc(h, &o.keep, cap) ||
+        dalloc(h, &o.desc, cap * 72) || dalloc(h, &o.code, cap * 32))
+        return LF_ERR_HIP;
+    o.frame_offset = h->d_frame_offset;
+    LF_HIP_CHECK(h, hipHostMalloc((void**)&h->h_pinned, 16 * sizeof(int)));
+    return LF_OK;
+}
+
+extern "C" int lf_abi_version(void) { return LF_ABI_VERSION; }
+
+extern "C" const char* lf_last_error(const lf_handle* h) { return h ? h->err : g_create_err; }
+
+extern "C" const char* lf_stage_name(int stage) { return (stage >= 0 && stage < LF_N_STAGES) ? kStageNames[stage] : "?"; }
+
+extern "C" void lf_destroy(lf_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_sdiv, h->d_hdiv,
+                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg,
+                     h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
+                     h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
+                     h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
+                     h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
+                     h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" int lf_create(const lf_config* cfg, int device_id, int max_frames, int max_lines_per_color, lf_handle** out)
+{
+    if (!cfg || !out || max_frames < 1 || max_lines_per_color < 1) {
+        snprintf(g_create_err, sizeof(g_create_err), "lf_create: bad argument");
+        return LF_ERR_BAD_ARG;
+    }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        snprintf(g_create_err, sizeof(g_create_err), "lf_create: no HIP device (%s); lanefront has no CPU fallback",
+                 e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return LF_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        snprintf(g_create_err, sizeof(g_create_err), "lf_create: device %d out of range (%d devices)", device_id, ndev);
+        return LF_ERR_BAD_ARG;
+    }
+    lf_handle* h = new (std::nothrow) lf_handle();
+    if (!h) return LF_ERR_HIP;
+    h->cfg = *cfg; h->device = device_id; h->max_frames = max_frames; h->cap_lines = max_lines_per_color;
+    h->err[0] = 0;
+    memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches));
+    int rc = LF_OK;
+    do {
+        if (hipSetDevice(device_id) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipSetDevice(%d) failed", device_id); rc = LF_ERR_HIP; break; }
+        if ((rc = build_params(h)) != LF_OK) break;
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipStreamCreate failed"); rc = LF_ERR_HIP; break; }
+        if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipEventCreate failed"); rc = LF_ERR_HIP; break; }
+        if ((rc = upload_tables(h)) != LF_OK) break;
+        if ((rc = alloc_buffers(h)) != LF_OK) break;
+    } while (0);
+    if (rc != LF_OK) {
+        snprintf(g_create_err, sizeof(g_create_err), "%s", h->err);
+        lf_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return LF_OK;
+}
+
+extern "C" int lf_synchronize(lf_handle* h)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    return LF_OK;
+}
+
+// detect stages a-1..a-4 on device-resident frames
+static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_working_image)
+{
+    hipStream_t s = h->stream;
+    PreParams pp = h->pre;
+    if (from_working_image) {
+        // plugin path: the caller already resized, cropped and colour-corrected (line_detector_node.py:163-180)
+        pp.in_rows = h->Hc; pp.in_cols = h->W; pp.img_rows = h->Hc; pp.img_cols = h->W; pp.top_cutoff = 0;
+        pp.resize = 0;
+        for (int i = 0; i < 3; ++i) { pp.ai_scale[i] = 1.f; pp.ai_shift[i] = 0.f; }
+    }
+    { StageTimer t(h, ST_PRE); launch_pre(pp, d_frames, n, h->d_bgr, h->d_masks, h->d_sdiv, h->d_hdiv, s); }
+    { StageTimer t(h, ST_CANNY); launch_canny(h->canny, h->d_bgr, n, h->d_strong, h->d_weak, s); }
+    {
+        StageTimer t(h, ST_HYST);
+        if (launch_hysteresis(h->canny, n, h->d_strong, h->d_weak, s) != 0) {
+            lf_set_error(h, LF_ERR_UNSUPPORTED, "working image %dx%d too large for the LDS-resident hysteresis", h->W, h->Hc);
+            return LF_ERR_UNSUPPORTED;
+        }
+    }
+    {
+        StageTimer t(h, ST_LSD_GRAD);
+        LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, (size_t)n * 3 * sizeof(unsigned long long), s));
+        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_masks, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad,
+                        h->max_nsx, h->max_nsy, s);
+    }
+    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, s); }
+    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_order_a, h->d_norder, h->d_reg, h->d_slot_lines, h->d_counts, s); }
+    LF_HIP_CHECK(h, hipGetLastError());
+    h->last_frames = n;
+    return LF_OK;
+}
+
+static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
+{
+    hipStream_t s = h->stream;
+    {
+        StageTimer t(h, ST_SEGMENTS);
+        LF_HIP_CHECK(h, hipMemsetAsync(h->d_overflow, 0, sizeof(int), s));
+        launch_seg_offsets(n, h->cap_lines, h->d_counts, h->d_seg_offset, dev_out.frame_offset ? dev_out.frame_offset : h->d_frame_offset,
+                           h->d_overflow, s);
+        launch_segments(h->seg, n, h->d_slot_lines, h->d_counts, h->d_seg_offset, h->d_masks, dev_out, h->d_seg_frame,
+                        h->d_normals64, h->d_centers, s);
+    }
+    if (describe) {
+        { StageTimer t(h, ST_LBD_GRAD); launch_lbd_grad(h->Hc, h->W, n, h->d_bgr, h->d_dx, h->d_dy, s); }
+        {
+            StageTimer t(h, ST_LBD);
+            int cap = dev_out.capacity < n * 3 * h->cap_lines ? dev_out.capacity : n * 3 * h->cap_lines;
+            launch_lbd(h->Hc, h->W, cap, h->d_seg_offset + n * 3, dev_out.lines, h->d_seg_frame, h->d_dx, h->d_dy,
+                       h->d_gauss_g, h->d_gauss_l, dev_out.desc, dev_out.code, s);
+        }
+    }
+    LF_HIP_CHECK(h, hipGetLastError());
+    return LF_OK;
+}
+
+extern "C" int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+                                lf_segments* out, int out_on_device, int describe, int* n_segments)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!frames || !out || n_frames < 1) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_process_batch: null argument or n_frames < 1"); return LF_ERR_BAD_ARG; }
+    if (n_frames > h->max_frames) { lf_set_error(h, LF_ERR_CAPACITY, "n_frames %d exceeds max_frames %d", n_frames, h->max_frames); return LF_ERR_CAPACITY; }
+    if (describe && (!out->lines)) { lf_set_error(h, LF_ERR_BAD_ARG, "describe needs out->lines"); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t frame_bytes = (size_t)h->cfg.in_rows * h->cfg.in_cols * 3;
+    const uint8_t* d_in = frames;
+    if (!frames_on_device) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->d_frames, frames, frame_bytes * n_frames, hipMemcpyHostToDevice, s));
+        d_in = h->d_frames;
+    }
+    h->plugin_ready = false;
+    int rc = run_detect(h, d_in, n_frames, false);
+    if (rc != LF_OK) return rc;
+    lf_segments dev = out_on_device ? *out : h->d_out;
+    if (!out_on_device) {
+        dev.capacity = out->capacity < h->out_capacity ? out->capacity : h->out_capacity;
+        // only compute what the caller asked for
+        if (!out->normals) dev.normals = nullptr;
+        if (!out->color) dev.color = nullptr;
+        if (!out->pixels_normalized) dev.pixels_normalized = nullptr;
+        if (!out->ground) dev.ground = nullptr;
+        if (!out->keep) dev.keep = nullptr;
+        if (!out->desc) dev.desc = nullptr;
+        if (!out->code) dev.code = nullptr;
+        dev.frame_offset = h->d_frame_offset;
+    }
+    rc = run_segments(h, n_frames, dev, describe != 0);
+    if (rc != LF_OK) return rc;
+    // total + overflow flag back to the host (one small synchronising copy)
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    const int total = h->h_pinned[0];
+    if (n_segments) *n_segments = total;
+    if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
+    if (total > dev.capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, dev.capacity); return LF_ERR_CAPACITY; }
+    if (!out_on_device) {
+        const size_t n = (size_t)total;
+        if (out->frame_offset) LF_HIP_CHECK(h, hipMemcpyAsync(out->frame_offset, h->d_frame_offset, (n_frames + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (out->lines) LF_HIP_CHECK(h, hipMemcpyAsync(out->lines, dev.lines, n * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (out->normals) LF_HIP_CHECK(h, hipMemcpyAsync(out->normals, dev.normals, n * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (out->color) LF_HIP_CHECK(h, hipMemcpyAsync(out->color, dev.color, n, hipMemcpyDeviceToHost, s));
+        if (out->pixels_normalized) LF_HIP_CHECK(h, hipMemcpyAsync(out->pixels_normalized, dev.pixels_normalized, n * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (out->ground) LF_HIP_CHECK(h, hipMemcpyAsync(out->ground, dev.ground, n * 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (out->keep) LF_HIP_CHECK(h, hipMemcpyAsync(out->keep, dev.keep, n, hipMemcpyDeviceToHost, s));
+        if (describe && out->desc) LF_HIP_CHECK(h, hipMemcpyAsync(out->desc, dev.desc, n * 72 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (describe && out->code) LF_HIP_CHECK(h, hipMemcpyAsync(out->code, dev.code, n * 32, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
+extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!bgr) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_set_image: null image"); return LF_ERR_BAD_ARG; }
+    if (rows != h->Hc || cols != h->W) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_set_image: image is %dx%d, handle expects %dx%d", rows, cols, h->Hc, h->W); return LF_ERR_BAD_ARG; }
+    if (row_stride_bytes < cols * 3) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_set_image: row stride %d < %d", row_stride_bytes, cols * 3); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    h->plugin_ready = false;
+    // the copy completes before return: the caller may reuse its buffer (np.copy in line_detector_lsd.py:136)
+    LF_HIP_CHECK(h, hipMemcpy2DAsync(h->d_frames, (size_t)cols * 3, bgr, (size_t)row_stride_bytes, (size_t)cols * 3, rows, hipMemcpyHostToDevice, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    int rc = run_detect(h, h->d_frames, 1, true);
+    if (rc != LF_OK) return rc;
+    lf_segments dev = h->d_out;
+    dev.desc = nullptr; dev.code = nullptr;
+    rc = run_segments(h, 1, dev, false);
+    if (rc != LF_OK) return rc;
+    h->h_counts.resize(3); h->h_seg_offset.resize(4);
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->h_counts.data(), h->d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->h_seg_offset.data(), h->d_seg_offset, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    h->plugin_ready = true;
+    return LF_OK;
+}
+
+extern "C" int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, float* centers2,
+                               uint8_t* area_or_null, int cap, int* n_out)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (color < 0 || color > 2) { lf_set_error(h, LF_ERR_BAD_ARG, "Error: Undefined color strings..."); return LF_ERR_BAD_ARG; }
+    if (!h->plugin_ready) { lf_set_error(h, LF_ERR_NOT_INITIALISED, "lf_detect_lines before lf_set_image"); return LF_ERR_NOT_INITIALISED; }
+    if (!n_out) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_detect_lines: n_out is null"); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int n = h->h_counts[color];
+    if (n > h->cap_lines) { lf_set_error(h, LF_ERR_CAPACITY, "LSD found %d lines, max_lines_per_color is %d", n, h->cap_lines); return LF_ERR_CAPACITY; }
+    if (n > cap) { lf_set_error(h, LF_ERR_CAPACITY, "%d lines exceed caller capacity %d", n, cap); return LF_ERR_CAPACITY; }
+    const size_t off = (size_t)h->h_seg_offset[color];
+    if (n > 0) {
+        if (lines4) LF_HIP_CHECK(h, hipMemcpyAsync(lines4, h->d_out.lines + off * 4, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (normals2) LF_HIP_CHECK(h, hipMemcpyAsync(normals2, h->d_normals64 + off * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (centers2) LF_HIP_CHECK(h, hipMemcpyAsync(centers2, h->d_centers + off * 2, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    if (area_or_null) LF_HIP_CHECK(h, hipMemcpyAsync(area_or_null, h->d_masks + (size_t)color * h->P, h->P, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    *n_out = n;
+    return LF_OK;
+}
+
+extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
+                            int32_t* idx, float* dist, int on_device)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (nq < 0 || nm < 0 || (nq > 0 && (!query32 || !idx || !dist)) || (nm > 0 && !map32)) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_associate: bad argument"); return LF_ERR_BAD_ARG; }
+    if (nm > (1 << 21)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "map larger than 2^21 entries"); return LF_ERR_UNSUPPORTED; }
+    if (nq == 0) return LF_OK;
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (nm == 0) {
+        // descriptor matrices cannot be void (binary_descriptor_matcher.cpp:201-205): report "no match"
+        std::vector<int32_t> hi(nq, -1); std::vector<float> hd(nq, -1.f);
+        if (on_device) {
+            LF_HIP_CHECK(h, hipMemcpyAsync(idx, hi.data(), nq * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            LF_HIP_CHECK(h, hipMemcpyAsync(dist, hd.data(), nq * sizeof(float), hipMemcpyHostToDevice, s));
+            LF_HIP_CHECK(h, hipStreamSynchronize(s));
+        } else { memcpy(idx, hi.data(), nq * sizeof(int32_t)); memcpy(dist, hd.data(), nq * sizeof(float)); }
+        return LF_OK;
+    }
+    const size_t nq_pad = ((size_t)nq + 127) / 128 * 128, nm_pad = ((size_t)nm + 63) / 64 * 64;
+    int rc;
+    if ((rc = ensure(h, h->a_qx, nq_pad * 256)) || (rc = ensure(h, h->a_mx, nm_pad * 256)) || (rc = ensure(h, h->a_best, (size_t)nq * 8))) return rc;
+    const uint8_t *dq = query32, *dmp = map32;
+    int32_t* didx = idx; float* ddist = dist;
+    if (!on_device) {
+        if ((rc = ensure(h, h->a_q, (size_t)nq * 32)) || (rc = ensure(h, h->a_m, (size_t)nm * 32)) ||
+            (rc = ensure(h, h->a_idx, (size_t)nq * 4)) || (rc = ensure(h, h->a_dist, (size_t)nq * 4))) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, query32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_m.p, map32, (size_t)nm * 32, hipMemcpyHostToDevice, s));
+        dq = (const uint8_t*)h->a_q.p; dmp = (const uint8_t*)h->a_m.p; didx = (int32_t*)h->a_idx.p; ddist = (float*)h->a_dist.p;
+    }
+    {
+        StageTimer t(h, ST_ASSOC);
+        launch_assoc(dq, nq, dmp, nm, (int8_t*)h->a_qx.p, (int8_t*)h->a_mx.p, (unsigned int*)h->a_best.p, didx, ddist, s);
+    }
+    LF_HIP_CHECK(h, hipGetLastError());
+    if (!on_device) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(idx, didx, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(dist, ddist, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
+extern "C" int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
+                                  int32_t* idx, float* dist, int on_device)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (nq <= 0 || nm <= 0 || !query72 || !map72 || !idx || !dist) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_associate_float: bad argument"); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure(h, h->a_best, (size_t)nq * 8)) || (rc = ensure(h, h->a_qn, (size_t)nq * 4)) || (rc = ensure(h, h->a_mn, (size_t)nm * 4))) return rc;
+    const float *dq = query72, *dmp = map72;
+    int32_t* didx = idx; float* ddist = dist;
+    if (!on_device) {
+        if ((rc = ensure(h, h->a_q, (size_t)nq * 288)) || (rc = ensure(h, h->a_m, (size_t)nm * 288)) ||
+            (rc = ensure(h, h->a_idx, (size_t)nq * 4)) || (rc = ensure(h, h->a_dist, (size_t)nq * 4))) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, query72, (size_t)nq * 288, hipMemcpyHostToDevice, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_m.p, map72, (size_t)nm * 288, hipMemcpyHostToDevice, s));
+        dq = (const float*)h->a_q.p; dmp = (const float*)h->a_m.p; didx = (int32_t*)h->a_idx.p; ddist = (float*)h->a_dist.p;
+    }
+    {
+        StageTimer t(h, ST_ASSOC);
+        launch_assoc_float(dq, nq, dmp, nm, (float*)h->a_qn.p, (float*)h->a_mn.p, (unsigned long long*)h->a_best.p, didx, ddist, s);
+    }
+    LF_HIP_CHECK(h, hipGetLastError());
+    if (!on_device) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(idx, didx, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(dist, ddist, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
+extern "C" int lf_lsd_size(const lf_handle* h, int* rows, int* cols)
+{
+    if (!h || !rows || !cols) return LF_ERR_BAD_ARG;
+    *rows = h->Hs; *cols = h->Ws;
+    return LF_OK;
+}
+
+extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!dst) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_debug_fetch: null dst"); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t n = (size_t)h->last_frames;
+    const void* src = nullptr;
+    size_t avail = 0;
+    switch (buffer_id) {
+    case LF_BUF_BGR: src = h->d_bgr; avail = n * h->P * 3; break;
+    case LF_BUF_MASKS: src = h->d_masks; avail = n * 3 * h->P; break;
+    case LF_BUF_EDGES:
+        launch_edges_u8(h->canny, (int)n, h->d_strong, h->d_edges_u8, s);
+        src = h->d_edges_u8; avail = n * h->P; break;
+    case LF_BUF_LSD_ANGLE: src = h->d_ang; avail = n * 3 * h->Ps * sizeof(float); break;
+    case LF_BUF_LSD_MODGRAD: src = h->d_mod; avail = n * 3 * h->Ps * sizeof(double); break;
+    case LF_BUF_LSD_ORDER: src = h->d_order_a; avail = n * 3 * h->Ps * sizeof(uint32_t); break;
+    case LF_BUF_LSD_NORDER: src = h->d_norder; avail = n * 3 * sizeof(int); break;
+    case LF_BUF_LBD_DX: src = h->d_dx; avail = n * h->P * sizeof(int16_t); break;
+    case LF_BUF_LBD_DY: src = h->d_dy; avail = n * h->P * sizeof(int16_t); break;
+    case LF_BUF_LSD_COUNTS: src = h->d_counts; avail = n * 3 * sizeof(int); break;
+    default: lf_set_error(h, LF_ERR_BAD_ARG, "unknown buffer id %d", buffer_id); return LF_ERR_BAD_ARG;
+    }
+    if (bytes > avail) { lf_set_error(h, LF_ERR_CAPACITY, "buffer %d holds %zu bytes, %zu requested", buffer_id, avail, bytes); return LF_ERR_CAPACITY; }
+    LF_HIP_CHECK(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    return LF_OK;
+}
+
+extern "C" int lf_set_profiling(lf_handle* h, int enabled)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    h->profiling = enabled != 0;
+    return LF_OK;
+}
+
+extern "C" int lf_reset_timing(lf_handle* h)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches));
+    return LF_OK;
+}
+
+extern "C" int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    for (int i = 0; i < n && i < LF_N_STAGES; ++i) {
+        if (ms_per_stage) ms_per_stage[i] = h->ms[i];
+        if (launches_per_stage) launches_per_stage[i] = h->launches[i];
+    }
+    return LF_OK;
+}

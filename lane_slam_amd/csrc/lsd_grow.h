@@ -1,0 +1,612 @@
+// LSD region growing, rectangle fit, refinement and NFA validation for ONE (frame, colour)
+// problem, executed by ONE 64-lane wavefront.
+//
+// Restates OpenCV 3.x lsd.cpp (flsd main loop, region_grow, region2rect, get_theta, refine,
+// reduce_region_radius, rect_improve, rect_nfa, nfa) exactly as the CPU oracle does
+// (oracle/lf_oracle_lsd.c) -- reached in the reference through
+// /root/reference/src/line_detector/include/line_detector/line_detector_lsd.py:64-72.
+//
+// Why one wave per problem: region growing is order dependent (seed order, USED flags, the
+// running float angle sums), so the sequential order is part of the result.  Parallelism
+// comes from (a) 3 x B independent problems per batch, one per SIMD, and (b) inside a
+// problem, lanes cooperate wherever the arithmetic is order independent or can be staged:
+//   * the 8-neighbour probe loads all neighbours in one memory round trip (lanes 0..8),
+//     then the accept/angle-update chain runs on wave-uniform values (v_readlane);
+//   * ordered f64 sums (centroid, inertia, refine statistics) prefetch 64 region points per
+//     round trip and accumulate in region order from lane registers;
+//   * min/max extents, USED-flag resets and the rectangle pixel counts of the NFA test are
+//     integer / min-max reductions across lanes (exact, order free).
+// The USED bitmap (USED or NOTDEF = 1) and the first REG_LDS region points live in LDS.
+//
+// The same source compiles for the host (LF_HOST_SIM, one lane) so the control flow can be
+// checked against the oracle without a GPU (tests/hostsim); that build is a test harness,
+// not a product path.
+#pragma once
+#include "detmath.h"
+
+#ifndef LF_HOST_SIM
+#include <hip/hip_runtime.h>
+#define LFG_DEV __device__ __forceinline__
+#define LFG_NL 64
+#else
+#include <math.h>
+#include <string.h>
+#define LFG_DEV static inline
+#define LFG_NL 1
+#endif
+
+namespace lf {
+namespace grow {
+
+constexpr double PI_ = 3.14159265358979323846;
+constexpr double M_3_2_PI_ = (3 * PI_) / 2;
+constexpr double M_2__PI_ = 2 * PI_;
+constexpr double DEG2RAD = PI_ / 180;
+constexpr float NOTDEF_F = -1024.0f;
+constexpr double NOTDEF_D = -1024.0;
+
+// ------------------------------------------------------------------ wave primitives
+#ifndef LF_HOST_SIM
+LFG_DEV int lane_id() { return (int)threadIdx.x; }
+LFG_DEV int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+LFG_DEV float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+LFG_DEV double rl_d(double v, int src)
+{
+    long long b = __double_as_longlong(v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+LFG_DEV int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+LFG_DEV double wave_max_d(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
+LFG_DEV double wave_min_d(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d); v = o < v ? o : v; }
+    return v;
+}
+LFG_DEV void mem_fence() { __threadfence_block(); }
+#else
+LFG_DEV int lane_id() { return 0; }
+LFG_DEV int rl_i(int v, int) { return v; }
+LFG_DEV float rl_f(float v, int) { return v; }
+LFG_DEV double rl_d(double v, int) { return v; }
+LFG_DEV int wave_sum_i(int v) { return v; }
+LFG_DEV double wave_max_d(double v) { return v; }
+LFG_DEV double wave_min_d(double v) { return v; }
+LFG_DEV void mem_fence() {}
+#endif
+
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+
+struct Ctx {
+    int W, H;
+    const float* ang;      // degrees, NOTDEF_F where undefined
+    const double* mod;
+    const double* cs;      // cos((double)(float)angle_rad), defined pixels only
+    const double* sn;
+    uint32_t* used;        // LDS bitmap, 1 = USED or NOTDEF
+    uint32_t* lreg;        // LDS part of the region list
+    uint32_t* greg;        // global part (index >= reg_lds)
+    int reg_lds;
+    double log_nt, log_eps, density_th, prec, p, scale;
+    int min_reg_size, refine;
+};
+
+LFG_DEV uint32_t reg_get(const Ctx& c, int i) { return i < c.reg_lds ? c.lreg[i] : c.greg[i]; }
+LFG_DEV void reg_set(const Ctx& c, int i, uint32_t v)
+{
+    if (lane_id() == 0) { if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v; }
+}
+LFG_DEV bool used_get(const Ctx& c, int addr) { return (c.used[addr >> 5] >> (addr & 31)) & 1u; }
+LFG_DEV void used_set(const Ctx& c, int addr) { if (lane_id() == 0) c.used[addr >> 5] |= 1u << (addr & 31); }
+LFG_DEV void used_clr(const Ctx& c, int addr) { if (lane_id() == 0) c.used[addr >> 5] &= ~(1u << (addr & 31)); }
+
+LFG_DEV double angle_of(float deg) { return deg == NOTDEF_F ? NOTDEF_D : (double)deg * DEG2RAD; }
+
+LFG_DEV bool aligned_val(double a, double theta, double prec)
+{
+    if (a == NOTDEF_D) return false;
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_) {
+        n_theta -= M_2__PI_;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta <= prec;
+}
+
+LFG_DEV double angle_diff_signed(double a, double b)
+{
+    double diff = a - b;
+    while (diff <= -PI_) diff += M_2__PI_;
+    while (diff > PI_) diff -= M_2__PI_;
+    return diff;
+}
+LFG_DEV double dabs(double v) { return v < 0 ? -v : v; }
+LFG_DEV double dist_sq(double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); }
+LFG_DEV double dist_(double x1, double y1, double x2, double y2) { return dm::dsqrt(dist_sq(x1, y1, x2, y2)); }
+
+LFG_DEV bool double_equal(double a, double b)
+{
+    if (a == b) return true;
+    double abs_diff = dabs(a - b);
+    double aa = dabs(a), bb = dabs(b);
+    double abs_max = (aa > bb) ? aa : bb;
+    const double DBL_MIN_ = 2.2250738585072014e-308, DBL_EPS_ = 2.2204460492503131e-16;
+    if (abs_max < DBL_MIN_) abs_max = DBL_MIN_;
+    return (abs_diff / abs_max) <= (100.0 * DBL_EPS_);
+}
+
+// ------------------------------------------------------------------ region_grow
+LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& reg_angle, double prec)
+{
+    const int W = c.W, H = c.H;
+    const int lane = lane_id();
+    int n = 1;
+    const int saddr = sx + sy * W;
+    reg_set(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
+    reg_angle = angle_of(c.ang[saddr]);
+    double s0, c0;
+    dm::dsincos(reg_angle, s0, c0);
+    float sumdx = (float)c0, sumdy = (float)s0;
+    used_set(c, saddr);
+    for (int i = 0; i < n; ++i) {
+        const uint32_t pk = reg_get(c, i);
+        const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+#ifndef LF_HOST_SIM
+        // lanes 0..8 fetch the 3x3 neighbourhood in one round trip
+        const int k9 = lane < 9 ? lane : 4;
+        const int xx = px + (k9 % 3) - 1, yy = py + (k9 / 3) - 1;
+        const bool inb = lane < 9 && xx >= 0 && xx < W && yy >= 0 && yy < H;
+        const int caddr = inb ? yy * W + xx : saddr;
+        int u = inb ? (int)used_get(c, caddr) : 1;
+        float a = NOTDEF_F;
+        double ck = 0.0, sk = 0.0;
+        if (!u) { a = c.ang[caddr]; ck = c.cs[caddr]; sk = c.sn[caddr]; }
+        bool added = false;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (rl_i(u, k)) continue;
+            const double ak = angle_of(rl_f(a, k));
+            if (aligned_val(ak, reg_angle, prec)) {
+                const int ax = px + (k % 3) - 1, ay = py + (k / 3) - 1;
+                used_set(c, ay * W + ax);
+                reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
+                ++n;
+                sumdx = (float)((double)sumdx + rl_d(ck, k));
+                sumdy = (float)((double)sumdy + rl_d(sk, k));
+                reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+                added = true;
+            }
+        }
+        if (added) mem_fence();
+#else
+        for (int k = 0; k < 9; ++k) {
+            const int xx = px + (k % 3) - 1, yy = py + (k / 3) - 1;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const int caddr = yy * W + xx;
+            if (used_get(c, caddr)) continue;
+            const double ak = angle_of(c.ang[caddr]);
+            if (aligned_val(ak, reg_angle, prec)) {
+                used_set(c, caddr);
+                reg_set(c, n, ((uint32_t)yy << 16) | (uint32_t)xx);
+                ++n;
+                sumdx = (float)((double)sumdx + c.cs[caddr]);
+                sumdy = (float)((double)sumdy + c.sn[caddr]);
+                reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+            }
+        }
+#endif
+    }
+    reg_size = n;
+}
+
+// ------------------------------------------------------------------ region2rect
+LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double prec, double p, Rect& rec)
+{
+    const int lane = lane_id();
+    const int W = c.W;
+    double x = 0, y = 0, sum = 0;
+    for (int base = 0; base < reg_size; base += LFG_NL) {
+        const int i = base + lane;
+        const bool v = i < reg_size;
+        const uint32_t pk = v ? reg_get(c, i) : 0u;
+        const double w = v ? c.mod[(int)(pk >> 16) * W + (int)(pk & 0xffffu)] : 0.0;
+        const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t q = (uint32_t)rl_i((int)pk, j);
+            const double weight = rl_d(w, j);
+            x += (double)(int)(q & 0xffffu) * weight;
+            y += (double)(int)(q >> 16) * weight;
+            sum += weight;
+        }
+    }
+    x /= sum;
+    y /= sum;
+    // get_theta
+    double Ixx = 0.0, Iyy = 0.0, Ixy = 0.0;
+    for (int base = 0; base < reg_size; base += LFG_NL) {
+        const int i = base + lane;
+        const bool v = i < reg_size;
+        const uint32_t pk = v ? reg_get(c, i) : 0u;
+        const double w = v ? c.mod[(int)(pk >> 16) * W + (int)(pk & 0xffffu)] : 0.0;
+        const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t q = (uint32_t)rl_i((int)pk, j);
+            const double weight = rl_d(w, j);
+            const double ddx = (double)(int)(q & 0xffffu) - x;
+            const double ddy = (double)(int)(q >> 16) - y;
+            Ixx += ddy * ddy * weight;
+            Iyy += ddx * ddx * weight;
+            Ixy -= ddx * ddy * weight;
+        }
+    }
+    const double lambda = 0.5 * (Ixx + Iyy - dm::dsqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+    double theta = (dabs(Ixx) > dabs(Iyy)) ? (double)dm::fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
+                                           : (double)dm::fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
+    theta *= DEG2RAD;
+    if (dabs(angle_diff_signed(theta, reg_angle)) > prec) theta += PI_;
+    double dsn, dcs;
+    dm::dsincos(theta, dsn, dcs);
+    const double dx = dcs, dy = dsn;
+    // extents: max/min are order independent -> lane-parallel
+    double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+    for (int i = lane; i < reg_size; i += LFG_NL) {
+        const uint32_t pk = reg_get(c, i);
+        const double regdx = (double)(int)(pk & 0xffffu) - x;
+        const double regdy = (double)(int)(pk >> 16) - y;
+        const double l = regdx * dx + regdy * dy;
+        const double w = -regdx * dy + regdy * dx;
+        if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
+        if (w > w_max) w_max = w; else if (w < w_min) w_min = w;
+    }
+    l_max = wave_max_d(l_max); l_min = wave_min_d(l_min);
+    w_max = wave_max_d(w_max); w_min = wave_min_d(w_min);
+    rec.x1 = x + l_min * dx;
+    rec.y1 = y + l_min * dy;
+    rec.x2 = x + l_max * dx;
+    rec.y2 = y + l_max * dy;
+    rec.width = w_max - w_min;
+    rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
+    rec.prec = prec; rec.p = p;
+    if (rec.width < 1.0) rec.width = 1.0;
+}
+
+// ------------------------------------------------------------------ refine
+LFG_DEV bool reduce_region_radius(const Ctx& c, int& reg_size, double reg_angle, double prec, double p, Rect& rec,
+                                  double density, double density_th)
+{
+    const uint32_t p0 = reg_get(c, 0);
+    const double xc = (double)(int)(p0 & 0xffffu), yc = (double)(int)(p0 >> 16);
+    const double radSq1 = dist_sq(xc, yc, rec.x1, rec.y1);
+    const double radSq2 = dist_sq(xc, yc, rec.x2, rec.y2);
+    double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+    while (density < density_th) {
+        radSq *= 0.75 * 0.75;
+        for (int i = 0; i < reg_size; ++i) {
+            const uint32_t pk = reg_get(c, i);
+            const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+            if (dist_sq(xc, yc, (double)px, (double)py) > radSq) {
+                used_clr(c, py * c.W + px);
+                const uint32_t last = reg_get(c, reg_size - 1);
+                reg_set(c, i, last);
+                reg_set(c, reg_size - 1, pk);
+                mem_fence();
+                --reg_size;
+                --i;
+            }
+        }
+        if (reg_size < 2) return false;
+        region2rect(c, reg_size, reg_angle, prec, p, rec);
+        density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    }
+    return true;
+}
+
+LFG_DEV bool refine(const Ctx& c, int& reg_size, double reg_angle, double prec, double p, Rect& rec, double density_th)
+{
+    const int lane = lane_id();
+    const int W = c.W;
+    double density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density >= density_th) return true;
+    const uint32_t p0 = reg_get(c, 0);
+    const int x0 = (int)(p0 & 0xffffu), y0 = (int)(p0 >> 16);
+    const double xc = (double)x0, yc = (double)y0;
+    const double ang_c = angle_of(c.ang[y0 * W + x0]);
+    double sum = 0, s_sum = 0;
+    int n = 0;
+    for (int base = 0; base < reg_size; base += LFG_NL) {
+        const int i = base + lane;
+        const bool v = i < reg_size;
+        const uint32_t pk = v ? reg_get(c, i) : 0u;
+        const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+        const float af = v ? c.ang[py * W + px] : NOTDEF_F;
+        const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t q = (uint32_t)rl_i((int)pk, j);
+            const int qx = (int)(q & 0xffffu), qy = (int)(q >> 16);
+            used_clr(c, qy * W + qx);
+            if (dist_(xc, yc, (double)qx, (double)qy) < rec.width) {
+                const double angle = angle_of(rl_f(af, j));
+                const double ang_d = angle_diff_signed(angle, ang_c);
+                sum += ang_d;
+                s_sum += ang_d * ang_d;
+                ++n;
+            }
+        }
+    }
+    const double mean_angle = sum / (double)n;
+    const double tau = 2.0 * dm::dsqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
+    region_grow(c, x0, y0, reg_size, reg_angle, tau);
+    if (reg_size < 2) return false;
+    region2rect(c, reg_size, reg_angle, prec, p, rec);
+    density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+    if (density < density_th) return reduce_region_radius(c, reg_size, reg_angle, prec, p, rec, density, density_th);
+    return true;
+}
+
+// ------------------------------------------------------------------ NFA
+LFG_DEV double log_gamma_lanczos(double x)
+{
+    const double q[7] = { 75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705,
+                          1168.92649479, 83.8676043424, 2.50662827511 };
+    double a = (x + 0.5) * dm::dlog(x + 5.5) - (x + 5.5);
+    double b = 0;
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        a -= dm::dlog(x + (double)n);
+        b += q[n] * dm::dpow(x, (double)n);
+    }
+    return a + dm::dlog(b);
+}
+LFG_DEV double log_gamma_windschitl(double x)
+{
+    return 0.918938533204673 + (x - 0.5) * dm::dlog(x) - x
+         + 0.5 * x * dm::dlog(x * dm::dsinh_small(1 / x) + 1 / (810.0 * dm::dpow(x, 6.0)));
+}
+LFG_DEV double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
+
+LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
+{
+    const double LOG_NT = c.log_nt;
+    if (n == 0 || k == 0) return -LOG_NT;
+    if (n == k) return -LOG_NT - (double)n * dm::dlog10(p);
+    const double p_term = p / (1 - p);
+    const double log1term = ((double)n + 1) - log_gamma((double)k + 1) - log_gamma((double)(n - k) + 1)
+                          + (double)k * dm::dlog(p) + (double)(n - k) * dm::dlog(1.0 - p);
+    double term = dm::dexp(log1term);
+    if (double_equal(term, 0)) {
+        if (k > n * p) return -log1term / 2.30258509299404568402 - LOG_NT;
+        else return -LOG_NT;
+    }
+    double bin_tail = term;
+    const double tolerance = 0.1;
+    for (int i = k + 1; i <= n; ++i) {
+        const double bin_term = (double)(n - i + 1) / (double)i;
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1) {
+            const double err = term * ((1 - dm::dpow(mult_term, (double)(n - i + 1))) / (1 - mult_term) - 1);
+            if (err < tolerance * dabs(-dm::dlog10(bin_tail) - LOG_NT) * bin_tail) break;
+        }
+    }
+    return -dm::dlog10(bin_tail) - LOG_NT;
+}
+
+struct Edge { int x, y; };
+
+LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
+{
+    const double half_width = rec.width / 2.0;
+    const double dyhw = rec.dy * half_width;
+    const double dxhw = rec.dx * half_width;
+    int ex[4], ey[4];
+    ex[0] = (int)(rec.x1 - dyhw); ey[0] = (int)(rec.y1 + dxhw);
+    ex[1] = (int)(rec.x2 - dyhw); ey[1] = (int)(rec.y2 + dxhw);
+    ex[2] = (int)(rec.x2 + dyhw); ey[2] = (int)(rec.y2 - dxhw);
+    ex[3] = (int)(rec.x1 + dyhw); ey[3] = (int)(rec.y1 - dxhw);
+    // sort 4 corners by (x, y) with a fixed compare-exchange network (same result as the
+    // oracle's insertion sort: equal keys are identical points)
+#define LFG_CX(a, b)                                                                   \
+    {                                                                                  \
+        bool sw = (ex[b] < ex[a]) || (ex[b] == ex[a] && ey[b] < ey[a]);                \
+        int tx = sw ? ex[b] : ex[a], ty = sw ? ey[b] : ey[a];                          \
+        int ux = sw ? ex[a] : ex[b], uy = sw ? ey[a] : ey[b];                          \
+        ex[a] = tx; ey[a] = ty; ex[b] = ux; ey[b] = uy;                                \
+    }
+    LFG_CX(0, 1) LFG_CX(2, 3) LFG_CX(0, 2) LFG_CX(1, 3) LFG_CX(1, 2)
+#undef LFG_CX
+    int imin = 0;
+    int min_x = ex[0], min_yv = ey[0], max_yv = ey[0];
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        if (min_yv > ey[i]) { min_yv = ey[i]; min_x = ex[i]; imin = i; }   // first minimum in sorted order
+        if (max_yv < ey[i]) max_yv = ey[i];
+    }
+    bool taken[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) taken[i] = (i == imin);
+    int lx = 0, ly = 0, rx = 0, ry = 0, tx_ = 0;
+    {
+        int sel = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!taken[i]) { if (sel < 0) { sel = i; lx = ex[i]; ly = ey[i]; } else if (lx > ex[i]) { sel = i; lx = ex[i]; ly = ey[i]; } }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i == sel) taken[i] = true;
+        sel = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!taken[i]) { if (sel < 0) { sel = i; rx = ex[i]; ry = ey[i]; } else if (rx < ex[i]) { sel = i; rx = ex[i]; ry = ey[i]; } }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i == sel) taken[i] = true;
+        sel = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (!taken[i]) { if (sel < 0) { sel = i; tx_ = ex[i]; } else if (tx_ > ex[i]) { sel = i; tx_ = ex[i]; } }
+    }
+    // integer edge steps and the y-vs-x comparisons of OpenCV 3.x, kept as in the oracle
+    const int flstep = (min_yv != ly) ? (min_x - lx) / (min_yv - ly) : 0;
+    const int slstep = (ly != tx_) ? (lx - tx_) / (ly - tx_) : 0;
+    const int frstep = (min_yv != ry) ? (min_x - rx) / (min_yv - ry) : 0;
+    const int srstep = (ry != tx_) ? (rx - tx_) / (ry - tx_) : 0;
+    // The oracle walks rows sequentially, skipping (without stepping) rows outside the image.
+    // All quantities are integers, so the bounds of row y have the closed form below.
+    const int y_start = min_yv > 0 ? min_yv : 0;
+    const int y_end = max_yv < c.H - 1 ? max_yv : c.H - 1;
+    const int nrows = y_end - y_start + 1;
+    int total_pts = 0, alg_pts = 0;
+    const int lane = lane_id();
+    if (nrows > 0) {
+#ifndef LF_HOST_SIM
+        const bool by_row = nrows >= 24;
+#else
+        const bool by_row = true;
+#endif
+        if (by_row) {
+            for (int y = y_start + lane; y <= y_end; y += LFG_NL) {
+                const int steps = y - y_start;
+                int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
+                int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
+                int xl = min_x + flstep * nf + slstep * (steps - nf);
+                int xr = min_x + frstep * nr + srstep * (steps - nr);
+                const int xa = xl < 0 ? 0 : xl, xb = xr > c.W - 1 ? c.W - 1 : xr;
+                for (int x = xa; x <= xb; ++x) {
+                    ++total_pts;
+                    if (aligned_val(angle_of(c.ang[y * c.W + x]), rec.theta, rec.prec)) ++alg_pts;
+                }
+            }
+        } else {
+            for (int y = y_start; y <= y_end; ++y) {
+                const int steps = y - y_start;
+                int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
+                int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
+                int xl = min_x + flstep * nf + slstep * (steps - nf);
+                int xr = min_x + frstep * nr + srstep * (steps - nr);
+                const int xa = xl < 0 ? 0 : xl, xb = xr > c.W - 1 ? c.W - 1 : xr;
+                for (int x = xa + lane; x <= xb; x += LFG_NL) {
+                    ++total_pts;
+                    if (aligned_val(angle_of(c.ang[y * c.W + x]), rec.theta, rec.prec)) ++alg_pts;
+                }
+            }
+        }
+        total_pts = wave_sum_i(total_pts);
+        alg_pts = wave_sum_i(alg_pts);
+    }
+    return nfa(c, total_pts, alg_pts, rec.p);
+}
+
+LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
+{
+    const double LOG_EPS = c.log_eps;
+    const double delta = 0.5;
+    const double delta_2 = delta / 2.0;
+    double log_nfa = rect_nfa(c, rec);
+    if (log_nfa > LOG_EPS) return log_nfa;
+    Rect r = rec;
+    for (int n = 0; n < 5; ++n) {
+        r.p /= 2;
+        r.prec = r.p * PI_;
+        double v = rect_nfa(c, r);
+        if (v > log_nfa) { log_nfa = v; rec = r; }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.width -= delta;
+            double v = rect_nfa(c, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 += -r.dy * delta_2;
+            r.y1 += r.dx * delta_2;
+            r.x2 += -r.dy * delta_2;
+            r.y2 += r.dx * delta_2;
+            r.width -= delta;
+            double v = rect_nfa(c, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.x1 -= -r.dy * delta_2;
+            r.y1 -= r.dx * delta_2;
+            r.x2 -= -r.dy * delta_2;
+            r.y2 -= r.dx * delta_2;
+            r.width -= delta;
+            double v = rect_nfa(c, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    r = rec;
+    for (int n = 0; n < 5; ++n) {
+        if ((r.width - delta) >= 0.5) {
+            r.p /= 2;
+            r.prec = r.p * PI_;
+            double v = rect_nfa(c, r);
+            if (v > log_nfa) { rec = r; log_nfa = v; }
+        }
+    }
+    return log_nfa;
+}
+
+// ------------------------------------------------------------------ main loop (flsd)
+// order: sorted seed items ((1023-bin) << 20 | addr); returns the number of lines found
+// (may exceed cap; only the first cap are stored).
+LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* lines, int cap)
+{
+    int n_lines = 0;
+    for (int i = 0; i < n_order; ++i) {
+        const int adx = (int)(order[i] & 0xfffffu);
+        if (used_get(c, adx)) continue;
+        int reg_size;
+        double reg_angle;
+        region_grow(c, adx % c.W, adx / c.W, reg_size, reg_angle, c.prec);
+        if (reg_size < c.min_reg_size) continue;
+        Rect rec;
+        region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
+        double log_nfa = -1;
+        if (c.refine > 0) {
+            if (!refine(c, reg_size, reg_angle, c.prec, c.p, rec, c.density_th)) continue;
+            if (c.refine >= 2) {
+                log_nfa = rect_improve(c, rec);
+                if (log_nfa <= c.log_eps) continue;
+            }
+        }
+        rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+        if (c.scale != 1) {
+            rec.x1 /= c.scale; rec.y1 /= c.scale; rec.x2 /= c.scale; rec.y2 /= c.scale;
+        }
+        if (n_lines < cap && lane_id() == 0) {
+            lines[4 * n_lines + 0] = (float)rec.x1;
+            lines[4 * n_lines + 1] = (float)rec.y1;
+            lines[4 * n_lines + 2] = (float)rec.x2;
+            lines[4 * n_lines + 3] = (float)rec.y2;
+        }
+        ++n_lines;
+    }
+    return n_lines;
+}
+
+}  // namespace grow
+}  // namespace lf

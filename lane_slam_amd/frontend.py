@@ -1,0 +1,195 @@
+"""Batch front end: the arithmetic of
+
+    src/line_detector/src/line_detector_node.py:163-213      (processImage_)
+    src/ground_projection/src/ground_projection_node.py:55-65 (lineseglist_cb)
+    src/line_sanity/src/line_sanity_node.py:48-72             (processSegmentList)
+    src/line_descriptor/src/binary_descriptor_custom.cpp:524-687 (BinaryDescriptor::compute)
+    src/line_descriptor/src/binary_descriptor_matcher.cpp:197-254 (BinaryDescriptorMatcher::match)
+
+(paths relative to /root/reference) for a whole batch of camera frames per call, on one
+MI355X through liblanefront.so.  Inputs and outputs are numpy arrays (host) or raw device
+pointers / torch CUDA tensors (device resident, no copies).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .config import LfConfig, default_config, fill_struct, work_size
+
+
+class LanefrontError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "lanefront error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Segments(object):
+    """Struct-of-arrays SegmentList of a batch (numpy, host).  Field meaning: include/lanefront.h."""
+
+    __slots__ = ("n", "frame_offset", "lines", "normals", "color", "pixels_normalized", "ground", "keep",
+                 "desc", "code")
+
+    def frame(self, f):
+        a, b = int(self.frame_offset[f]), int(self.frame_offset[f + 1])
+        out = Segments()
+        out.n = b - a
+        out.frame_offset = np.array([0, b - a], np.int32)
+        for k in ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "desc", "code"):
+            v = getattr(self, k)
+            setattr(out, k, None if v is None else v[a:b])
+        return out
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class FrontEnd(object):
+    def __init__(self, cfg=None, device=0, max_frames=1, max_lines_per_color=512):
+        self.lib = _lib.load()
+        self.cfg = default_config("parity") if cfg is None else cfg
+        self.c = fill_struct(LfConfig(), self.cfg)
+        self.max_frames = int(max_frames)
+        self.cap_lines = int(max_lines_per_color)
+        self.rows, self.cols = work_size(self.cfg)
+        self.in_rows, self.in_cols = self.cfg["in_size"]
+        self.h = ctypes.c_void_p()
+        rc = self.lib.lf_create(ctypes.byref(self.c), int(device), self.max_frames, self.cap_lines, ctypes.byref(self.h))
+        if rc != 0:
+            msg = self.lib.lf_last_error(None).decode()
+            self.h = None
+            raise LanefrontError(rc, msg)
+        r, c = ctypes.c_int(), ctypes.c_int()
+        self.lib.lf_lsd_size(self.h, ctypes.byref(r), ctypes.byref(c))
+        self.lsd_rows, self.lsd_cols = r.value, c.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LanefrontError(rc, self.lib.lf_last_error(self.h).decode())
+
+    @property
+    def capacity(self):
+        return self.max_frames * 3 * self.cap_lines
+
+    def synchronize(self):
+        self._check(self.lib.lf_synchronize(self.h))
+
+    # ------------------------------------------------------------------ host arrays
+    def process_batch(self, frames, describe=True):
+        """frames: uint8 (n, in_rows, in_cols, 3) BGR.  Returns a host `Segments`."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim == 3:
+            frames = frames[None]
+        n = frames.shape[0]
+        if frames.shape[1:] != (self.in_rows, self.in_cols, 3):
+            raise ValueError("frames must be (n,%d,%d,3), got %r" % (self.in_rows, self.in_cols, frames.shape))
+        cap = n * 3 * self.cap_lines
+        out = Segments()
+        out.frame_offset = np.zeros(n + 1, np.int32)
+        out.lines = np.empty((cap, 4), np.float32)
+        out.normals = np.empty((cap, 2), np.float32)
+        out.color = np.empty(cap, np.uint8)
+        out.pixels_normalized = np.empty((cap, 4), np.float32)
+        out.ground = np.empty((cap, 4), np.float64)
+        out.keep = np.empty(cap, np.uint8)
+        out.desc = np.empty((cap, 72), np.float32) if describe else None
+        out.code = np.empty((cap, 32), np.uint8) if describe else None
+        s = _lib.LfSegments()
+        s.capacity = cap
+        for k in ("frame_offset", "lines", "normals", "color", "pixels_normalized", "ground", "keep"):
+            setattr(s, k, getattr(out, k).ctypes.data)
+        if describe:
+            s.desc, s.code = out.desc.ctypes.data, out.code.ctypes.data
+        total = ctypes.c_int()
+        self._check(self.lib.lf_process_batch(self.h, _ptr(frames), n, 0, ctypes.byref(s), 0, int(bool(describe)),
+                                              ctypes.byref(total)))
+        t = total.value
+        out.n = t
+        for k in ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "desc", "code"):
+            v = getattr(out, k)
+            if v is not None:
+                setattr(out, k, v[:t])
+        return out
+
+    # ------------------------------------------------------------------ device resident
+    def process_batch_device(self, frames_ptr, n_frames, out_ptrs, capacity, describe=True):
+        """frames_ptr: device address of uint8 (n, in_rows, in_cols, 3).  out_ptrs: dict of device
+        addresses for any of frame_offset, lines, normals, color, pixels_normalized, ground, keep,
+        desc, code (capacity segments each).  Returns the total segment count."""
+        s = _lib.LfSegments()
+        s.capacity = int(capacity)
+        for k, v in out_ptrs.items():
+            setattr(s, k, int(v))
+        total = ctypes.c_int()
+        self._check(self.lib.lf_process_batch(self.h, ctypes.c_void_p(int(frames_ptr)), int(n_frames), 1,
+                                              ctypes.byref(s), 1, int(bool(describe)), ctypes.byref(total)))
+        return total.value
+
+    # ------------------------------------------------------------------ association
+    def associate(self, query_codes, map_codes):
+        """Exact Hamming NN (binary_descriptor_matcher.cpp:197-254).  Returns (idx int32, dist float32);
+        idx == -1 where the nearest map entry is farther than 128 bits or the map is empty."""
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8).reshape(-1, 32)
+        m = np.ascontiguousarray(map_codes, dtype=np.uint8).reshape(-1, 32)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        self._check(self.lib.lf_associate(self.h, _ptr(q), q.shape[0], _ptr(m), m.shape[0], _ptr(idx), _ptr(dist), 0))
+        return idx, dist
+
+    def associate_device(self, q_ptr, nq, m_ptr, nm, idx_ptr, dist_ptr):
+        self._check(self.lib.lf_associate(self.h, ctypes.c_void_p(int(q_ptr)), int(nq), ctypes.c_void_p(int(m_ptr)),
+                                          int(nm), ctypes.c_void_p(int(idx_ptr)), ctypes.c_void_p(int(dist_ptr)), 1))
+
+    def associate_float(self, query_desc, map_desc):
+        q = np.ascontiguousarray(query_desc, dtype=np.float32).reshape(-1, 72)
+        m = np.ascontiguousarray(map_desc, dtype=np.float32).reshape(-1, 72)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        self._check(self.lib.lf_associate_float(self.h, _ptr(q), q.shape[0], _ptr(m), m.shape[0], _ptr(idx), _ptr(dist), 0))
+        return idx, dist
+
+    # ------------------------------------------------------------------ introspection
+    def fetch(self, buffer_id, n_frames):
+        """Intermediate buffer of the last batch (tests / debugging)."""
+        P, Ps = self.rows * self.cols, self.lsd_rows * self.lsd_cols
+        shapes = {
+            _lib.LF_BUF_BGR: ((n_frames, self.rows, self.cols, 3), np.uint8),
+            _lib.LF_BUF_MASKS: ((n_frames, 3, self.rows, self.cols), np.uint8),
+            _lib.LF_BUF_EDGES: ((n_frames, self.rows, self.cols), np.uint8),
+            _lib.LF_BUF_LSD_ANGLE: ((n_frames, 3, self.lsd_rows, self.lsd_cols), np.float32),
+            _lib.LF_BUF_LSD_MODGRAD: ((n_frames, 3, self.lsd_rows, self.lsd_cols), np.float64),
+            _lib.LF_BUF_LSD_ORDER: ((n_frames, 3, Ps), np.uint32),
+            _lib.LF_BUF_LSD_NORDER: ((n_frames, 3), np.int32),
+            _lib.LF_BUF_LBD_DX: ((n_frames, self.rows, self.cols), np.int16),
+            _lib.LF_BUF_LBD_DY: ((n_frames, self.rows, self.cols), np.int16),
+            _lib.LF_BUF_LSD_COUNTS: ((n_frames, 3), np.int32),
+        }
+        shape, dt = shapes[buffer_id]
+        a = np.empty(shape, dt)
+        self._check(self.lib.lf_debug_fetch(self.h, buffer_id, _ptr(a), a.nbytes))
+        return a
+
+    def set_profiling(self, on):
+        self._check(self.lib.lf_set_profiling(self.h, int(bool(on))))
+
+    def reset_timing(self):
+        self._check(self.lib.lf_reset_timing(self.h))
+
+    def timing(self):
+        """{stage name: (ms accumulated, launches)} measured with HIP events on the handle's stream."""
+        ms = np.zeros(_lib.LF_N_STAGES, np.float64)
+        ln = np.zeros(_lib.LF_N_STAGES, np.int32)
+        self._check(self.lib.lf_get_timing(self.h, _ptr(ms), _ptr(ln), _lib.LF_N_STAGES))
+        return {self.lib.lf_stage_name(i).decode(): (float(ms[i]), int(ln[i])) for i in range(_lib.LF_N_STAGES)}

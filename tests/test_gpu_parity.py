@@ -1,0 +1,255 @@
+"""GPU parity tests: every stage of the HIP path (through the C ABI) against the CPU oracle
+on identical seeded inputs.  Integer/byte/index work and endpoints must be bit-exact;
+descriptor floats are checked both bit-exact (same deterministic arithmetic) and within the
+north-star tolerance 1e-4."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from lane_slam_amd import FrontEnd, LineDetectorHIP, default_config, synth
+from lane_slam_amd import _lib
+from lane_slam_amd.config import DEFAULT_DETECTOR_CONFIGURATION
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(n, seed0=0, with_noise=True):
+    fr = synth.make_batch(n, seed0)
+    if with_noise:
+        rng = np.random.default_rng(99)
+        fr[-1] = rng.integers(0, 256, fr[-1].shape, dtype=np.uint8)       # worst case: pure noise
+    return fr
+
+
+@pytest.fixture(scope="module", params=["parity", "fullres"])
+def setup(request):
+    from oracle.oracle import Oracle
+    geo = request.param
+    cfg = default_config(geo)
+    n = 6 if geo == "parity" else 3
+    fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=4096)
+    frames = _frames(n)
+    seg = fe.process_batch(frames, describe=True)
+    yield geo, cfg, fe, Oracle(cfg), frames, seg
+    fe.close()
+
+
+def test_detmath_device_matches_oracle():
+    from oracle.oracle import detmath_lib
+    fe = FrontEnd(default_config("parity"))
+    L = detmath_lib()
+    rng = np.random.default_rng(5)
+    vp = ctypes.c_void_p
+
+    def dev(which, a, b=None):
+        a = np.ascontiguousarray(a, np.float64)
+        y = np.empty_like(a)
+        bp = None if b is None else np.ascontiguousarray(b, np.float64).ctypes.data_as(vp)
+        fe._check(fe.lib.lf_debug_detmath(fe.h, which, a.ctypes.data_as(vp), bp, y.ctypes.data_as(vp), a.size))
+        return y
+
+    def host1(which, a):
+        a = np.ascontiguousarray(a, np.float64)
+        y = np.empty_like(a)
+        L.lfo_vec_unary(which, a.ctypes.data_as(vp), y.ctypes.data_as(vp), a.size)
+        return y
+
+    def host2(which, a, b):
+        a = np.ascontiguousarray(a, np.float64)
+        b = np.ascontiguousarray(b, np.float64)
+        y = np.empty_like(a)
+        L.lfo_vec_binary(which, a.ctypes.data_as(vp), b.ctypes.data_as(vp), y.ctypes.data_as(vp), a.size)
+        return y
+
+    n = 200000
+    for which, lo, hi in [(0, -50, 50), (1, 1e-9, 1e9), (2, -30, 30), (3, -30, 30), (4, -100, 100), (5, -1, 1),
+                          (6, 1e-9, 1e9), (7, -0.2, 0.2)]:
+        x = rng.uniform(lo, hi, n)
+        assert np.array_equal(dev(which, x), host1(which, x)), "detmath fn %d differs on device" % which
+    a, b = rng.uniform(-5, 5, n), rng.uniform(-5, 5, n)
+    assert np.array_equal(dev(8, a, b), host2(0, a, b))
+    a = rng.uniform(0.01, 30, n)
+    b = np.where(rng.random(n) < 0.5, rng.integers(0, 40, n).astype(float), rng.uniform(-3, 3, n))
+    assert np.array_equal(dev(9, a, b), host2(1, a, b))
+    # IEEE basics the whole contract rests on: sqrt and division, double and float
+    x = np.concatenate([rng.uniform(0, 1e6, n), rng.uniform(0, 1e-300, 1000)])
+    assert np.array_equal(dev(10, x), np.sqrt(x))
+    a, b = rng.uniform(-1e3, 1e3, n), rng.uniform(-1e3, 1e3, n)
+    assert np.array_equal(dev(11, a, b), a / b)
+    xf = rng.uniform(0, 1e6, n).astype(np.float32)
+    assert np.array_equal(dev(13, xf.astype(np.float64)).astype(np.float32), np.sqrt(xf))
+    af, bf = rng.uniform(-1e3, 1e3, n).astype(np.float32), rng.uniform(-1e3, 1e3, n).astype(np.float32)
+    assert np.array_equal(dev(14, af.astype(np.float64), bf.astype(np.float64)).astype(np.float32), af / bf)
+    yf, xf2 = rng.uniform(-10, 10, n).astype(np.float32), rng.uniform(-10, 10, n).astype(np.float32)
+    ref = np.empty(n, np.float32)
+    L.lfo_vec_fast_atan2(yf.ctypes.data_as(vp), xf2.ctypes.data_as(vp), ref.ctypes.data_as(vp), n)
+    assert np.array_equal(dev(12, yf.astype(np.float64), xf2.astype(np.float64)).astype(np.float32), ref)
+    fe.close()
+
+
+def test_pre_masks_canny(setup):
+    geo, cfg, fe, o, frames, seg = setup
+    n = frames.shape[0]
+    bgr = fe.fetch(_lib.LF_BUF_BGR, n)
+    masks = fe.fetch(_lib.LF_BUF_MASKS, n)
+    edges = fe.fetch(_lib.LF_BUF_EDGES, n)
+    for f in range(n):
+        ob = o.preprocess(frames[f])
+        assert np.array_equal(bgr[f], ob)
+        bw = o.color_masks(o.bgr2hsv(ob))
+        for c in range(3):
+            assert np.array_equal(masks[f, c], o.dilate(bw[c])), (f, c)
+        oe = o.canny(ob)
+        assert np.array_equal(edges[f], oe), "canny frame %d: %d px differ" % (f, (edges[f] != oe).sum())
+    assert edges.any() and masks.any()
+
+
+def test_lsd_gradient_and_order(setup):
+    geo, cfg, fe, o, frames, seg = setup
+    n = frames.shape[0]
+    ang = fe.fetch(_lib.LF_BUF_LSD_ANGLE, n)
+    mod = fe.fetch(_lib.LF_BUF_LSD_MODGRAD, n)
+    order = fe.fetch(_lib.LF_BUF_LSD_ORDER, n)
+    norder = fe.fetch(_lib.LF_BUF_LSD_NORDER, n)
+    masks = fe.fetch(_lib.LF_BUF_MASKS, n)
+    edges = fe.fetch(_lib.LF_BUF_EDGES, n)
+    for f in range(n):
+        for c in range(3):
+            ec = masks[f, c] & edges[f]
+            scaled = o.lsd_scaled_image(ec)
+            oang, omod, oorder = o.lsd_ll_angle(scaled)
+            defined = oang != -1024.0
+            g_def = ang[f, c] != np.float32(-1024.0)
+            assert np.array_equal(defined, g_def), (f, c)
+            rad = ang[f, c].astype(np.float64) * (np.pi / 180)
+            assert np.array_equal(rad[defined], oang[defined])
+            assert np.array_equal(mod[f, c][:-1, :-1], omod[:-1, :-1])
+            k = int(norder[f, c])
+            assert k == int(defined.sum())
+            got = (order[f, c, :k] & 0xFFFFF).astype(np.int64)
+            want = oorder[defined.ravel()[oorder]]          # the oracle lists every pixel; keep defined ones
+            assert np.array_equal(got, want), (f, c)
+
+
+def test_segments_match_oracle(setup):
+    geo, cfg, fe, o, frames, seg = setup
+    n = frames.shape[0]
+    total = 0
+    for f in range(n):
+        r = o.process_frame(frames[f], cap=3 * 4096)
+        s = seg.frame(f)
+        assert s.n == r["n"], "frame %d: %d segments vs oracle %d" % (f, s.n, r["n"])
+        total += s.n
+        assert np.array_equal(s.lines, r["lines"])                       # endpoints: bit exact
+        assert np.array_equal(s.normals, r["normals"])                   # normals: bit exact
+        assert np.array_equal(s.color, r["color"])                       # colour labels
+        assert np.array_equal(s.pixels_normalized, r["pixels_normalized"])
+        assert np.array_equal(s.ground, r["ground"])
+        assert np.array_equal(s.keep, r["keep"])
+        np.testing.assert_allclose(s.desc, r["desc"], rtol=0, atol=1e-4, equal_nan=True)   # north-star tolerance
+        assert np.array_equal(s.desc, r["desc"], equal_nan=True)          # and in fact the same bits
+        assert np.array_equal(s.code, r["code"])
+    assert total > 20
+    assert seg.n == total
+
+
+def test_plugin_matches_reference_interface():
+    from oracle.oracle import Oracle
+    cfg = default_config("parity")
+    o = Oracle(cfg)
+    det = LineDetectorHIP(dict(DEFAULT_DETECTOR_CONFIGURATION))
+    for seed in (0, 4, 7):
+        work = o.preprocess(synth.make_frame(seed))          # what the node hands to setImage
+        det.setImage(work)
+        assert np.array_equal(det.getImage(), work)
+        bw = o.color_masks(o.bgr2hsv(work))
+        edges = o.canny(work)
+        for ci, color in enumerate(("white", "yellow", "red")):
+            d = det.detectLines(color)
+            area = o.dilate(bw[ci])
+            lines = o.lsd(area & edges)
+            assert np.array_equal(d.area, area)
+            if len(lines) == 0:
+                assert isinstance(d.lines, list) and len(d.lines) == 0      # line_detector_lsd.py:68-71
+                continue
+            ol, on, oc = o.find_normals(area, lines)
+            assert d.lines.dtype == np.float32 and d.normals.dtype == np.float64 and d.centers.dtype == np.float32
+            assert np.array_equal(d.lines, ol) and np.array_equal(d.normals, on) and np.array_equal(d.centers, oc)
+    with pytest.raises(Exception):
+        det.detectLines("blue")
+    with pytest.raises(ValueError):
+        LineDetectorHIP({"hsv_white1": [0, 0, 0]})
+    # empty image -> [] for every colour, like cv2 returning None
+    det.setImage(np.zeros((80, 160, 3), np.uint8))
+    for color in ("white", "yellow", "red"):
+        assert det.detectLines(color).lines == []
+
+
+def test_associate_matches_matcher_semantics():
+    from oracle.oracle import Oracle
+    o = Oracle(default_config("parity"))
+    fe = FrontEnd(default_config("parity"))
+    rng = np.random.default_rng(17)
+    nm, nq = 3000, 700
+    m = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    # planted neighbours at distances 0..128, duplicates (ties), and far queries
+    for i in range(0, 300):
+        src = m[rng.integers(0, nm)].copy()
+        bits = rng.choice(256, size=i % 129, replace=False)
+        for b in bits:
+            src[b >> 3] ^= np.uint8(1 << (b & 7))
+        q[i] = src
+    m[10] = m[5]
+    q[300] = m[5]
+    idx, dist = fe.associate(q, m)
+    oi, od = o.match(q, m)
+    assert np.array_equal(dist, od)
+    assert np.array_equal(idx, oi)                 # both sides resolve ties to the lowest index
+    assert idx[300] == 5 and dist[300] == 0
+    assert (idx == -1).any() and (idx >= 0).any()
+    # ragged sizes and the empty map
+    for a, b in [(1, 1), (5, 63), (129, 64), (33, 65), (128, 1000)]:
+        i2, d2 = fe.associate(q[:a], m[:b])
+        o2, e2 = o.match(q[:a], m[:b])
+        assert np.array_equal(i2, o2) and np.array_equal(d2, e2)
+    i3, d3 = fe.associate(q[:7], m[:0])
+    assert (i3 == -1).all() and (d3 == -1).all()
+    # float LBD distances within the north-star tolerance
+    qd = rng.random((200, 72)).astype(np.float32)
+    md = rng.random((900, 72)).astype(np.float32)
+    qd /= np.linalg.norm(qd, axis=1, keepdims=True)
+    md /= np.linalg.norm(md, axis=1, keepdims=True)
+    fi, fd = fe.associate_float(qd, md)
+    gi, gd = o.match_float(qd, md)
+    np.testing.assert_allclose(fd, gd, rtol=0, atol=1e-4)
+    true_d = np.linalg.norm(qd.astype(np.float64) - md[fi].astype(np.float64), axis=1)
+    np.testing.assert_allclose(true_d, gd, rtol=0, atol=1e-4)     # the chosen neighbour is (near-)optimal
+    fe.close()
+
+
+def test_full_size_properties():
+    """BASELINE config 2 size (256 x 640x480, full-res geometry): size-independent properties."""
+    cfg = default_config("fullres")
+    n = 256
+    fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=1024)
+    base = synth.make_batch(8, 100)
+    frames = np.ascontiguousarray(np.tile(base, (n // 8, 1, 1, 1)))
+    seg = fe.process_batch(frames, describe=True)
+    ref = fe.process_batch(frames[:8], describe=True) if False else None
+    # identical frames give identical segment lists wherever they sit in the batch
+    first = [seg.frame(f) for f in range(8)]
+    for f in range(8, n):
+        a, b = first[f % 8], seg.frame(f)
+        assert a.n == b.n
+        assert np.array_equal(a.lines, b.lines) and np.array_equal(a.code, b.code) and np.array_equal(a.keep, b.keep)
+    assert np.all(np.diff(seg.frame_offset) >= 0) and seg.frame_offset[-1] == seg.n
+    assert np.isin(seg.color, (0, 1, 2)).all()
+    # colour order inside every frame: white, yellow, red
+    for f in range(8):
+        assert np.all(np.diff(seg.frame(f).color.astype(int)) >= 0)
+    # a frame's descriptors match themselves at distance 0
+    idx, dist = fe.associate(seg.code, seg.code)
+    assert (dist == 0).all()
+    fe.close()

@@ -1,0 +1,57 @@
+"""Pin the CPU oracle against vectors produced by the reference's own runnable Python
+(tests/golden/make_golden.py documents how each fixture was made)."""
+import os
+
+import numpy as np
+
+
+def test_find_normal_matches_reference(oracle_parity, golden_dir):
+    g = np.load(os.path.join(golden_dir, "find_normal.npz"))
+    for ci in range(int(g["n_cases"])):
+        lines, normals, centers = oracle_parity.find_normals(g["bw%d" % ci], g["lines_in%d" % ci])
+        # bit-exact: endpoints (reordered), normals, centers
+        assert np.array_equal(lines, g["lines_out%d" % ci])
+        assert np.array_equal(normals, g["normals%d" % ci])
+        assert np.array_equal(centers, g["centers%d" % ci])
+        # both sign outcomes and both orderings are exercised
+        assert (g["lines_out%d" % ci] != g["lines_in%d" % ci]).any()
+
+
+def test_line_sanity_matches_reference(oracle_parity, golden_dir):
+    g = np.load(os.path.join(golden_dir, "line_sanity.npz"))
+    s = oracle_parity.cfg["sanity"]
+    consts = [s["lanewidth"], s["linewidth_white"], s["linewidth_yellow"], s["d_min"], s["d_max"],
+              s["phi_min"], s["phi_max"]]
+    assert np.array_equal(np.array(consts), g["consts"])     # line_sanity_node.py:17-23
+    keep, dphil, state = oracle_parity.line_sanity(g["pts"], g["color"])
+    assert np.array_equal(keep, g["keep"])
+    assert np.array_equal(state, g["state"])
+    # numpy evaluates norm/inner through BLAS (may fuse multiply-adds); the oracle is plain IEEE
+    np.testing.assert_allclose(dphil[:, 0], g["d"], rtol=0, atol=1e-14, equal_nan=True)
+    # asin is ill-conditioned near +-1 (d asin/dt = 1/sqrt(1-t^2)): compare t = sin(phi) tightly
+    # and phi itself at sqrt(eps) level
+    np.testing.assert_allclose(np.sin(dphil[:, 1]), np.sin(g["phi"]), rtol=0, atol=1e-15, equal_nan=True)
+    np.testing.assert_allclose(dphil[:, 1], g["phi"], rtol=0, atol=2e-8, equal_nan=True)
+    np.testing.assert_allclose(dphil[:, 2], g["l"], rtol=0, atol=1e-14, equal_nan=True)
+    # degenerate p1 == p2 -> NaN -> kept (reference behaviour), RED and x<0 rejected
+    assert keep[0] == 1 and keep[1] == 1 and keep[3] == 0 and keep[6] == 0
+
+
+def test_scaleandshift_matches_reference(golden_dir):
+    """scaleandshift2 feeds cv2.convertScaleAbs; the float32 stage must be bit-exact."""
+    from lane_slam_amd.config import default_config
+    from oracle.oracle import Oracle
+    g = np.load(os.path.join(golden_dir, "scaleandshift.npz"))
+    img = g["img"]
+    for i in range(g["scales"].shape[0]):
+        cfg = default_config("parity")
+        cfg["in_size"] = list(img.shape[:2])
+        cfg["img_size"] = list(img.shape[:2])
+        cfg["top_cutoff"] = 0
+        cfg["ai_scale"] = list(g["scales"][i])
+        cfg["ai_shift"] = list(g["shifts"][i])
+        out = Oracle(cfg).preprocess(img)
+        ref_f32 = g["out"][i]
+        # convertScaleAbs: saturate_u8(round_half_even(|x|))
+        expect = np.clip(np.rint(np.abs(ref_f32.astype(np.float64))), 0, 255).astype(np.uint8)
+        assert np.array_equal(out, expect)
