@@ -239,6 +239,12 @@ LF_HD double dsqrt(double x)
 #endif
 }
 
+// Correctly rounded float sqrt / divide through double (53 >= 2*24+2 bits makes the second
+// rounding innocuous).  HIP's __fsqrt_rn / __fdiv_rn intrinsics lower to approximate
+// native instructions on gfx950 and are NOT usable for a bit-exact contract.
+LF_HD float fsqrt(float x) { return (float)dsqrt((double)x); }
+LF_HD float fdiv(float a, float b) { return (float)((double)a / (double)b); }
+
 LF_HD double dasin(double x)
 {
     if (x != x) return x;

@@ -221,7 +221,7 @@ __global__ void k_assoc_float_finish(const unsigned long long* __restrict__ best
     if (q >= nq) return;
     unsigned long long v = best[q];
     if (v == ~0ull) { idx[q] = -1; dist[q] = -1.f; }
-    else { idx[q] = (int)(v & 0xffffffffull); dist[q] = __fsqrt_rn(__uint_as_float((unsigned int)(v >> 32))); }
+    else { idx[q] = (int)(v & 0xffffffffull); dist[q] = dm::fsqrt(__uint_as_float((unsigned int)(v >> 32))); }
 }
 
 __global__ void k_fill_u64(unsigned long long* p, int n, unsigned long long v)

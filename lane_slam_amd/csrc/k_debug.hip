@@ -24,8 +24,8 @@ __global__ void k_detmath(int which, const double* __restrict__ a, const double*
     case 10: r = dm::dsqrt(x); break;
     case 11: r = x / z; break;
     case 12: r = (double)dm::fast_atan2_deg((float)x, (float)z); break;
-    case 13: r = (double)__fsqrt_rn((float)x); break;
-    case 14: r = (double)__fdiv_rn((float)x, (float)z); break;
+    case 13: r = (double)dm::fsqrt((float)x); break;
+    case 14: r = (double)dm::fdiv((float)x, (float)z); break;
     default: r = 0.0;
     }
     y[i] = r;

@@ -109,9 +109,9 @@ __global__ void k_segments(SegParams p, int n_frames, const float* __restrict__ 
     float x1 = L[0], y1 = L[1], x2 = L[2], y2 = L[3];
     // a-5
     const float ex = x1 - x2, ey = y1 - y2;
-    const float len = __fsqrt_rn(ex * ex + ey * ey);
-    const float dx = __fdiv_rn(y2 - y1, len);
-    const float dy = __fdiv_rn(x1 - x2, len);
+    const float len = dm::fsqrt(ex * ex + ey * ey);
+    const float dx = dm::fdiv(y2 - y1, len);
+    const float dy = dm::fdiv(x1 - x2, len);
     const float cx = (x1 + x2) / 2, cy = (y1 + y2) / 2;
     int x3 = (int)(cx - 3.f * dx), y3 = (int)(cy - 3.f * dy);
     int x4 = (int)(cx + 3.f * dx), y4 = (int)(cy + 3.f * dy);

@@ -208,7 +208,13 @@ def test_associate_matches_matcher_semantics():
     assert np.array_equal(dist, od)
     assert np.array_equal(idx, oi)                 # both sides resolve ties to the lowest index
     assert idx[300] == 5 and dist[300] == 0
-    assert (idx == -1).any() and (idx >= 0).any()
+    assert (idx >= 0).all()       # 3000 random codes: every random query has a neighbour within 128 bits
+    # farther than D = 128 -> "no match" (binary_descriptor_matcher.cpp:721)
+    far_q = np.concatenate([~m[:1], m[:1]])
+    i_far, d_far = fe.associate(far_q, m[:1])
+    assert i_far.tolist() == [-1, 0] and d_far.tolist() == [-1.0, 0.0]
+    o_far, e_far = o.match(far_q, m[:1])
+    assert np.array_equal(i_far, o_far) and np.array_equal(d_far, e_far)
     # ragged sizes and the empty map
     for a, b in [(1, 1), (5, 63), (129, 64), (33, 65), (128, 1000)]:
         i2, d2 = fe.associate(q[:a], m[:b])
@@ -237,7 +243,6 @@ def test_full_size_properties():
     base = synth.make_batch(8, 100)
     frames = np.ascontiguousarray(np.tile(base, (n // 8, 1, 1, 1)))
     seg = fe.process_batch(frames, describe=True)
-    ref = fe.process_batch(frames[:8], describe=True) if False else None
     # identical frames give identical segment lists wherever they sit in the batch
     first = [seg.frame(f) for f in range(8)]
     for f in range(8, n):
