@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s through detect -> describe -> ground-project -> sanity ->
+associate on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the whole hot path over one batch of 256 synthetic 640x480 BGR frames
+per GPU, already resident in HBM (BASELINE.json configs[1], full-res geometry: img_size
+[480,640], top_cutoff 160 -> 640x320 working image), followed by association of the step's
+descriptors against a live map of 50 000 codes.  With N > 1 GPUs frames shard across ranks
+(weak scaling, 256 frames per GPU per step) and the per-rank segment blocks are merged with
+one RCCL all-gather before the map is updated; association itself needs no collective (the
+map is replicated, queries stay local).
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant streaming kernel with live
+HIP-event timings from the library's own stream; `cpu_baseline` times the CPU oracle
+(oracle/, a single-threaded restatement of the reference path) on a bounded sample of the
+same workload on the GPU box's host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def stage_bytes(P, Ps, resize):
+    """ALGORITHMIC HBM bytes per frame of each streaming kernel."""
+    return {
+        "pre(resize+correct+hsv+masks+dilate)": 3 * P + 3 * P + 3 * P,
+        "canny_nms": 3 * P + 2 * (P // 8),
+        "canny_hysteresis": 3 * (P // 8),
+        "lsd_blur_resample_grad": 3 * ((P // 8) + P + 4 * Ps + 8 * Ps),
+        "lbd_gray_blur_sobel": 3 * P + 4 * P,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity"])
+    ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
+    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames per rank (tiled to --batch)")
+    ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from lane_slam_amd import FrontEnd, default_config, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    cfg = default_config(args.geometry)
+    fe = FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap)
+    P, Ps = fe.rows * fe.cols, fe.lsd_rows * fe.lsd_cols
+
+    # ---- synthetic input, resident in HBM before the timed region
+    uniq = min(args.unique, B)
+    host = synth.make_batch(uniq, seed0=10000 * rank)
+    reps = (B + uniq - 1) // uniq
+    host = np.ascontiguousarray(np.tile(host, (reps, 1, 1, 1))[:B])
+    frames = torch.from_numpy(host).to(dev)
+
+    cap = B * 3 * args.cap
+    out = {
+        "frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev),
+        "lines": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+        "normals": torch.zeros(cap, 2, dtype=torch.float32, device=dev),
+        "color": torch.zeros(cap, dtype=torch.uint8, device=dev),
+        "pixels_normalized": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+        "ground": torch.zeros(cap, 4, dtype=torch.float64, device=dev),
+        "keep": torch.zeros(cap, dtype=torch.uint8, device=dev),
+        "desc": torch.zeros(cap, 72, dtype=torch.float32, device=dev),
+        "code": torch.zeros(cap, 32, dtype=torch.uint8, device=dev),
+    }
+    ptrs = {k: v.data_ptr() for k, v in out.items()}
+    # live map: M random codes (seed 1234, identical on every rank) + a rolling region that
+    # receives the segments all ranks produced (append-only map, show_map.py:28-42)
+    G = 64 * 1024                                   # gathered segments per rank (padded block)
+    roll = min(G, 16384) * world
+    map_codes = torch.from_numpy(np.concatenate([synth.random_codes(args.map, 1234),
+                                                 synth.random_codes(roll, 4321)])).to(dev)
+    M = map_codes.shape[0]
+    a_idx = torch.zeros(cap, dtype=torch.int32, device=dev)
+    a_dist = torch.zeros(cap, dtype=torch.float32, device=dev)
+    block = torch.zeros(G, 34, dtype=torch.uint8, device=dev)          # code(32) + keep + colour per segment
+    gathered = torch.zeros(world * G, 34, dtype=torch.uint8, device=dev)
+    counts_local = torch.zeros(1, dtype=torch.int32, device=dev)
+    counts_all = torch.zeros(world, dtype=torch.int32, device=dev)
+    seg_total = [0]
+
+    def step():
+        total = fe.process_batch_device(frames.data_ptr(), B, ptrs, cap, describe=True)
+        seg_total[0] = total
+        n = min(total, G)
+        if world > 1:
+            block[:n, :32] = out["code"][:n]
+            block[:n, 32] = out["keep"][:n]
+            block[:n, 33] = out["color"][:n]
+            counts_local[0] = n
+            dist.all_gather_into_tensor(counts_all, counts_local)
+            dist.all_gather_into_tensor(gathered, block)
+            src = gathered.view(world, G, 34)[:, : roll // world, :32]
+        else:
+            src = out["code"][: roll].view(1, -1, 32)[:, : roll]
+        # association: this rank's segments against the replicated map (before this step's update)
+        torch.cuda.current_stream().synchronize()
+        if total > 0:
+            fe.associate_device(out["code"].data_ptr(), total, map_codes.data_ptr(), M, a_idx.data_ptr(), a_dist.data_ptr())
+            fe.synchronize()
+        # map update, rank-major / frame-minor so every rank holds the same map
+        k = src.shape[1]
+        map_codes[args.map: args.map + world * k] = src.reshape(-1, 32)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    fe.reset_timing()
+    fe.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    fe.set_profiling(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    timing = fe.timing()
+
+    result = None
+    if rank == 0:
+        frames_total = world * B * args.steps
+        value = frames_total / dt
+        sb = stage_bytes(P, Ps, cfg["img_size"] != cfg["in_size"])
+        kernels = []
+        for name, (ms, launches) in timing.items():
+            if launches == 0:
+                continue
+            avg = ms / launches
+            e = {"stage": name, "avg_ms": round(avg, 4), "launches": launches}
+            if name in sb and avg > 0:
+                e["algorithmic_bytes"] = sb[name] * B
+                e["GBps"] = round(sb[name] * B / (avg * 1e-3) / 1e9, 1)
+            kernels.append(e)
+        streaming = [k for k in kernels if "GBps" in k]
+        dom = max(streaming, key=lambda k: k["avg_ms"]) if streaming else None
+        roofline = None
+        if dom:
+            roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"]}
+        result = {
+            "metric": "frames/sec (640x480) detect->descript->project->sanity->associate",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (i8 MFMA for association)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d-frame batch per GPU of 640x480 synthetic lane frames, "
+                                   "%s geometry (working image %dx%d, LSD image %dx%d), LSD+LBD+project+sanity, "
+                                   "Hamming association vs %d-code live map" % (B, args.geometry, fe.cols, fe.rows,
+                                                                                 fe.lsd_cols, fe.lsd_rows, M),
+                       "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0],
+                       "parallelism": "frame-sharded x%d, all-gather of segment blocks" % world},
+            "roofline": roofline,
+            "kernels": kernels,
+        }
+        # ---- CPU baseline: the oracle (single-threaded restatement of the reference path)
+        if world == 1 and args.cpu_frames >= 0:
+            from oracle.oracle import Oracle
+            o = Oracle(cfg)
+            nf = args.cpu_frames or (160 if args.geometry == "fullres" else 1500)
+            nf = min(nf, B)
+            mc = map_codes.cpu().numpy()
+            t1 = time.perf_counter()
+            nseg = 0
+            for f in range(nf):
+                r = o.process_frame(host[f], cap=3 * args.cap)
+                nseg += r["n"]
+                if r["n"]:
+                    o.match(r["code"], mc)
+            cdt = time.perf_counter() - t1
+            result["cpu_baseline"] = {
+                "value": round(nf / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+                "sample": "%d of the %d frames of one step (same synthetic frames, same config, same %d-code map), "
+                          "oracle/liblforacle.so single thread, %.1f s" % (nf, B, M, cdt),
+                "host_cpus": os.cpu_count()}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    fe.close()
+    return result
+
+
+if __name__ == "__main__":
+    main()

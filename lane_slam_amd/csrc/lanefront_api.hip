@@ -17,6 +17,7 @@ static const char* kStageNames[LF_N_STAGES] = {
     "lsd_order", "lsd_grow", "segments(normal+project+sanity)", "lbd_gray_blur_sobel", "lbd_descriptor",
     "assoc_pack", "assoc_mfma", "misc" };
 
+struct EvPair { hipEvent_t a, b; int st; };
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -67,7 +68,7 @@ struct lf_handle {
     std::vector<int> h_counts, h_seg_offset;
     // profiling
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<EvPair> ev_free, ev_used;
     double ms[LF_N_STAGES];
     int32_t launches[LF_N_STAGES];
 };
@@ -102,18 +103,39 @@ static int ensure(lf_handle* h, DevBuf& b, size_t bytes)
     return LF_OK;
 }
 
+// Per-stage timing with HIP events recorded on the handle's stream.  Events are only
+// recorded here (no host synchronisation inside the pipeline); lf_get_timing resolves them.
+static void timing_resolve(lf_handle* h)
+{
+    for (EvPair& e : h->ev_used) {
+        (void)hipEventSynchronize(e.b);
+        float t = 0;
+        if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) h->ms[e.st] += t;
+        h->ev_free.push_back(e);
+    }
+    h->ev_used.clear();
+}
+
 struct StageTimer {
-    lf_handle* h; int st;
-    StageTimer(lf_handle* h_, int st_) : h(h_), st(st_) { if (h->profiling) (void)hipEventRecord(h->ev0, h->stream); }
+    lf_handle* h; int st; EvPair e; bool on;
+    StageTimer(lf_handle* h_, int st_) : h(h_), st(st_), on(h_->profiling)
+    {
+        if (!on) return;
+        if (h->ev_free.empty()) {
+            if (h->ev_used.size() >= 8192) timing_resolve(h);
+            else {
+                EvPair n; n.st = 0;
+                if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) { on = false; return; }
+                h->ev_free.push_back(n);
+            }
+        }
+        e = h->ev_free.back(); h->ev_free.pop_back();
+        e.st = st;
+        (void)hipEventRecord(e.a, h->stream);
+    }
     ~StageTimer()
     {
-        if (h->profiling) {
-            (void)hipEventRecord(h->ev1, h->stream);
-            (void)hipEventSynchronize(h->ev1);
-            float t = 0;
-            (void)hipEventElapsedTime(&t, h->ev0, h->ev1);
-            h->ms[st] += t;
-        }
+        if (on) { (void)hipEventRecord(e.b, h->stream); h->ev_used.push_back(e); }
         h->launches[st] += 1;
     }
 };
@@ -356,8 +378,8 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    timing_resolve(h);
+    for (EvPair& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -390,7 +412,6 @@ extern "C" int lf_create(const lf_config* cfg, int device_id, int max_frames, in
         if (hipSetDevice(device_id) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipSetDevice(%d) failed", device_id); rc = LF_ERR_HIP; break; }
         if ((rc = build_params(h)) != LF_OK) break;
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipStreamCreate failed"); rc = LF_ERR_HIP; break; }
-        if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipEventCreate failed"); rc = LF_ERR_HIP; break; }
         if ((rc = upload_tables(h)) != LF_OK) break;
         if ((rc = alloc_buffers(h)) != LF_OK) break;
     } while (0);
@@ -697,6 +718,7 @@ extern "C" int lf_set_profiling(lf_handle* h, int enabled)
 extern "C" int lf_reset_timing(lf_handle* h)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
+    timing_resolve(h);
     memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches));
     return LF_OK;
 }
@@ -704,6 +726,7 @@ extern "C" int lf_reset_timing(lf_handle* h)
 extern "C" int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
+    timing_resolve(h);
     for (int i = 0; i < n && i < LF_N_STAGES; ++i) {
         if (ms_per_stage) ms_per_stage[i] = h->ms[i];
         if (launches_per_stage) launches_per_stage[i] = h->launches[i];
