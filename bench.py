@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames per rank (tiled to --batch)")
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
+    ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     args = ap.parse_args()
 
@@ -77,6 +78,7 @@ def main():
 
     B = args.batch
     cfg = default_config(args.geometry)
+    cfg["lsd"]["refine"] = args.lsd_refine
     fe = FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap)
     P, Ps = fe.rows * fe.cols, fe.lsd_rows * fe.lsd_cols
 

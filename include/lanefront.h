@@ -158,7 +158,8 @@ typedef enum lf_buffer_id {
     LF_BUF_LSD_NORDER = 6,   /* i32 [frames][3]          seeds per run                    */
     LF_BUF_LBD_DX = 7,       /* i16 [frames][Hc][W]                                        */
     LF_BUF_LBD_DY = 8,       /* i16 [frames][Hc][W]                                        */
-    LF_BUF_LSD_COUNTS = 9    /* i32 [frames][3]          lines per run                    */
+    LF_BUF_LSD_COUNTS = 9,   /* i32 [frames][3]          lines per run                    */
+    LF_BUF_LSD_SCRATCH = 10  /* u32 [frames][3][Hs*Ws]   region-list scratch (diagnostic builds park counters here) */
 } lf_buffer_id;
 /* copy an intermediate buffer of the last batch to host memory (synchronises) */
 int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes);

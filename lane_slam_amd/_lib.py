@@ -10,7 +10,7 @@ SO_PATH = os.path.join(_HERE, "liblanefront.so")
 
 LF_N_STAGES = 12
 (LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,
- LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS) = range(10)
+ LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS, LF_BUF_LSD_SCRATCH) = range(11)
 
 # every symbol include/lanefront.h declares
 EXPORTS = (

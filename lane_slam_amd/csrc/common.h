@@ -92,10 +92,10 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
                      unsigned long long* maxgrad, int max_nsx, int max_nsy, hipStream_t s);
 void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
                       const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
-                      hipStream_t s);
+                      uint2* deflist, int* row_start, hipStream_t s);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
-                     const double* sn, const uint32_t* order, const int* norder, uint32_t* reg,
-                     float* lines, int* counts, hipStream_t s);
+                     const double* sn, const uint32_t* order, const int* norder, const uint2* deflist,
+                     const int* row_start, uint32_t* reg, float* lines, int* counts, hipStream_t s);
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,

@@ -9,7 +9,9 @@
 // items = (1023-bin) << 20 | address, (2) a stable LSD radix sort on the 10-bit key, three
 // 4-bit passes.  Each lane owns a contiguous run of items, per-lane bucket counters live in
 // a [16][512] LDS matrix, and one wave scans each bucket row, so no atomics are needed and
-// the order is deterministic.
+// the order is deterministic.  The compaction also leaves, per problem, the raster-ordered list
+// of defined pixels with their angles and the first entry of every row: k_lsd_grow's NFA
+// rectangle counts walk these row lists instead of the (96 % undefined) angle plane.
 #include "common.h"
 
 namespace lf {
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
                                                   const double* __restrict__ mod,
                                                   const unsigned long long* __restrict__ maxgrad,
                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b,
-                                                  int* __restrict__ norder)
+                                                  int* __restrict__ norder, uint2* __restrict__ deflist,
+                                                  int* __restrict__ row_start)
 {
     __shared__ uint32_t cnt[NB * OT];
     __shared__ int tot[NB];
@@ -80,6 +83,8 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
     const double* m = mod + (size_t)pc * Ps;
     uint32_t* A = order_a + (size_t)pc * Ps;
     uint32_t* B = order_b + (size_t)pc * Ps;
+    uint2* DL = deflist + (size_t)pc * Ps;                 // raster-ordered (y<<16|x, angle bits) of defined pixels
+    int* RS = row_start + (size_t)pc * (p.Hs + 1);         // first list entry of every scaled-image row
     const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
     const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -95,16 +100,21 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
         int off = running;
         int total = 0;
         for (int w = 0; w < OT / 64; ++w) { int s = wsum[w]; if (w < wave) off += s; total += s; }
-        if (def) {
-            int bin = (int)(m[i] * bin_coef);
-            uint32_t key = (uint32_t)((p.n_bins - 1) - bin);
-            B[off + pre] = (key << 20) | (uint32_t)i;
+        if (i < Ps) {
+            const int y = (int)(i / p.Ws), x = (int)(i - (size_t)y * p.Ws);
+            if (x == 0) RS[y] = off + pre;
+            if (def) {
+                int bin = (int)(m[i] * bin_coef);
+                uint32_t key = (uint32_t)((p.n_bins - 1) - bin);
+                B[off + pre] = (key << 20) | (uint32_t)i;
+                DL[off + pre] = make_uint2(((uint32_t)y << 16) | (uint32_t)x, __float_as_uint(a[i]));
+            }
         }
         running += total;
         __syncthreads();
     }
     const int n = running;
-    if (t == 0) norder[pc] = n;
+    if (t == 0) { norder[pc] = n; RS[p.Hs] = n; }
     __syncthreads();
     radix_pass(B, A, n, 20, cnt, tot, base);
     radix_pass(A, B, n, 24, cnt, tot, base);
@@ -113,10 +123,10 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
 
 void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
                       const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
-                      hipStream_t s)
+                      uint2* deflist, int* row_start, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lsd_order, dim3(n_frames * 3), dim3(OT), 0, s, p, ang, mod, maxgrad, order_a, order_b,
-                       norder);
+                       norder, deflist, row_start);
 }
 
 }  // namespace lf

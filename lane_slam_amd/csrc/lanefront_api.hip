@@ -47,6 +47,8 @@ struct lf_handle {
     double *d_mod = nullptr, *d_cs = nullptr, *d_sn = nullptr;
     unsigned long long* d_maxgrad = nullptr;
     uint32_t *d_order_a = nullptr, *d_order_b = nullptr, *d_reg = nullptr;
+    uint2* d_deflist = nullptr;
+    int* d_row_start = nullptr;
     int *d_norder = nullptr, *d_counts = nullptr, *d_seg_offset = nullptr, *d_frame_offset = nullptr, *d_overflow = nullptr;
     float* d_slot_lines = nullptr;
     int* d_seg_frame = nullptr;
@@ -339,7 +341,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) ||
         dalloc(h, &h->d_ang, nprob * Ps) || dalloc(h, &h->d_mod, nprob * Ps) || dalloc(h, &h->d_cs, nprob * Ps) ||
         dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
-        dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
+        dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_deflist, nprob * Ps) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
         dalloc(h, &h->d_dx, B * P) || dalloc(h, &h->d_dy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
@@ -370,7 +372,7 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_sdiv, h->d_hdiv,
-                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg,
+                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_deflist, h->d_row_start,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
                      h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
@@ -458,8 +460,8 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_masks, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad,
                         h->max_nsx, h->max_nsy, s);
     }
-    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, s); }
-    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_order_a, h->d_norder, h->d_reg, h->d_slot_lines, h->d_counts, s); }
+    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_deflist, h->d_row_start, s); }
+    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_order_a, h->d_norder, h->d_deflist, h->d_row_start, h->d_reg, h->d_slot_lines, h->d_counts, s); }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
     return LF_OK;
@@ -700,6 +702,7 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
     case LF_BUF_LBD_DX: src = h->d_dx; avail = n * h->P * sizeof(int16_t); break;
     case LF_BUF_LBD_DY: src = h->d_dy; avail = n * h->P * sizeof(int16_t); break;
     case LF_BUF_LSD_COUNTS: src = h->d_counts; avail = n * 3 * sizeof(int); break;
+    case LF_BUF_LSD_SCRATCH: src = h->d_reg; avail = n * 3 * h->Ps * sizeof(uint32_t); break;
     default: lf_set_error(h, LF_ERR_BAD_ARG, "unknown buffer id %d", buffer_id); return LF_ERR_BAD_ARG;
     }
     if (bytes > avail) { lf_set_error(h, LF_ERR_CAPACITY, "buffer %d holds %zu bytes, %zu requested", buffer_id, avail, bytes); return LF_ERR_CAPACITY; }

@@ -33,6 +33,9 @@
 #include <string.h>
 #define LFG_DEV static inline
 #define LFG_NL 1
+struct uint2 { unsigned int x, y; };
+static inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r; r.x = x; r.y = y; return r; }
+static inline float __uint_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 #endif
 
 namespace lf {
@@ -75,8 +78,15 @@ LFG_DEV double wave_min_d(double v)
     for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d); v = o < v ? o : v; }
     return v;
 }
+LFG_DEV int wave_max_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
+    return v;
+}
 LFG_DEV void mem_fence() { __threadfence_block(); }
 #else
+LFG_DEV int wave_max_i(int v) { return v; }
 LFG_DEV int lane_id() { return 0; }
 LFG_DEV int rl_i(int v, int) { return v; }
 LFG_DEV float rl_f(float v, int) { return v; }
@@ -89,6 +99,15 @@ LFG_DEV void mem_fence() {}
 
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
+// Diagnostic build only (-DLFG_STAMPS): cycle totals per phase, never enabled in the product.
+#if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
+#define LFG_T0 unsigned long long _t0 = __builtin_readcyclecounter();
+#define LFG_T1(c, k) { unsigned long long _t1 = __builtin_readcyclecounter(); (c).stamps[k] += _t1 - _t0; _t0 = _t1; }
+#else
+#define LFG_T0
+#define LFG_T1(c, k)
+#endif
+
 struct Ctx {
     int W, H;
     const float* ang;      // degrees, NOTDEF_F where undefined
@@ -99,11 +118,20 @@ struct Ctx {
     uint32_t* lreg;        // LDS part of the region list
     uint32_t* greg;        // global part (index >= reg_lds)
     int reg_lds;
+    // raster-ordered defined pixels: entry = (y<<16|x, angle bits); rows[y]..rows[y+1] = row y
+    const int* rows;       // LDS, H+1 entries
+    const uint2* ldef;     // LDS part of the list
+    const uint2* gdef;     // global list (whole)
+    int def_lds;
     double log_nt, log_eps, density_th, prec, p, scale;
     int min_reg_size, refine;
+#if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
+    mutable unsigned long long stamps[8];   // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math
+#endif
 };
 
 LFG_DEV uint32_t reg_get(const Ctx& c, int i) { return i < c.reg_lds ? c.lreg[i] : c.greg[i]; }
+LFG_DEV uint32_t reg_get_lane(const Ctx& c, int i) { return i < c.reg_lds ? c.lreg[i] : c.greg[i]; }   // per-lane index
 LFG_DEV void reg_set(const Ctx& c, int i, uint32_t v)
 {
     if (lane_id() == 0) { if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v; }
@@ -161,37 +189,51 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& re
     dm::dsincos(reg_angle, s0, c0);
     float sumdx = (float)c0, sumdy = (float)s0;
     used_set(c, saddr);
+#ifndef LF_HOST_SIM
+    // Frontier points are taken in list order, 7 at a time: lane = 9*slot + neighbour, so
+    // ascending lane order IS the reference's visiting order (point i, then its 3x3 window in
+    // raster order).  Angles are read only, so all 63 neighbours are fetched in one round
+    // trip.  The reference tests neighbours one by one against the running region angle, which
+    // only changes when a pixel is accepted; so "the next accepted pixel" is the lowest lane
+    // at or after the cursor whose pixel is free and aligned under the CURRENT angle -- one
+    // vector evaluation + ballot per accepted pixel instead of a 9-step scalar chain per point.
+    for (int i = 0; i < n;) {
+        const int m = n - i < 7 ? n - i : 7;
+        const int slot = lane / 9, k9 = lane - slot * 9;
+        const bool lv = slot < m;
+        const uint32_t pkl = lv ? reg_get_lane(c, i + slot) : 0u;
+        const int pxl = (int)(pkl & 0xffffu), pyl = (int)(pkl >> 16);
+        const int xx = pxl + (k9 % 3) - 1, yy = pyl + (k9 / 3) - 1;
+        const bool inb = lv && xx >= 0 && xx < W && yy >= 0 && yy < H;
+        const int caddr = inb ? yy * W + xx : -1;
+        bool cand = inb && !used_get(c, caddr);          // free (and therefore defined) at batch start
+        double a = NOTDEF_D, ck = 0.0, sk = 0.0;
+        if (cand) { a = angle_of(c.ang[caddr]); ck = c.cs[caddr]; sk = c.sn[caddr]; }
+        unsigned long long later = ~0ull;                 // lanes at or after the cursor
+        bool added = false;
+        for (;;) {
+            const unsigned long long hit = __ballot(cand && aligned_val(a, reg_angle, prec)) & later;
+            if (hit == 0ull) break;
+            const int L = __builtin_ctzll(hit);
+            const int ca = rl_i(caddr, L);
+            const int ay = rl_i(yy, L), ax = rl_i(xx, L);
+            used_set(c, ca);
+            reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
+            ++n;
+            sumdx = (float)((double)sumdx + rl_d(ck, L));
+            sumdy = (float)((double)sumdy + rl_d(sk, L));
+            reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+            if (caddr == ca) cand = false;                // the same pixel seen from a later point is now USED
+            later = L >= 63 ? 0ull : (~0ull << (L + 1));
+            added = true;
+        }
+        if (added) mem_fence();
+        i += m;
+    }
+#else
     for (int i = 0; i < n; ++i) {
         const uint32_t pk = reg_get(c, i);
         const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
-#ifndef LF_HOST_SIM
-        // lanes 0..8 fetch the 3x3 neighbourhood in one round trip
-        const int k9 = lane < 9 ? lane : 4;
-        const int xx = px + (k9 % 3) - 1, yy = py + (k9 / 3) - 1;
-        const bool inb = lane < 9 && xx >= 0 && xx < W && yy >= 0 && yy < H;
-        const int caddr = inb ? yy * W + xx : saddr;
-        int u = inb ? (int)used_get(c, caddr) : 1;
-        float a = NOTDEF_F;
-        double ck = 0.0, sk = 0.0;
-        if (!u) { a = c.ang[caddr]; ck = c.cs[caddr]; sk = c.sn[caddr]; }
-        bool added = false;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            if (rl_i(u, k)) continue;
-            const double ak = angle_of(rl_f(a, k));
-            if (aligned_val(ak, reg_angle, prec)) {
-                const int ax = px + (k % 3) - 1, ay = py + (k / 3) - 1;
-                used_set(c, ay * W + ax);
-                reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
-                ++n;
-                sumdx = (float)((double)sumdx + rl_d(ck, k));
-                sumdy = (float)((double)sumdy + rl_d(sk, k));
-                reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
-                added = true;
-            }
-        }
-        if (added) mem_fence();
-#else
         for (int k = 0; k < 9; ++k) {
             const int xx = px + (k % 3) - 1, yy = py + (k / 3) - 1;
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
@@ -207,8 +249,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& re
                 reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
             }
         }
-#endif
     }
+#endif
     reg_size = n;
 }
 
@@ -409,6 +451,7 @@ struct Edge { int x, y; };
 
 LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
 {
+    LFG_T0
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width;
     const double dxhw = rec.dx * half_width;
@@ -466,46 +509,58 @@ LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
     // All quantities are integers, so the bounds of row y have the closed form below.
     const int y_start = min_yv > 0 ? min_yv : 0;
     const int y_end = max_yv < c.H - 1 ? max_yv : c.H - 1;
-    const int nrows = y_end - y_start + 1;
     int total_pts = 0, alg_pts = 0;
     const int lane = lane_id();
-    if (nrows > 0) {
-#ifndef LF_HOST_SIM
-        const bool by_row = nrows >= 24;
-#else
-        const bool by_row = true;
-#endif
-        if (by_row) {
-            for (int y = y_start + lane; y <= y_end; y += LFG_NL) {
-                const int steps = y - y_start;
-                int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
-                int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
-                int xl = min_x + flstep * nf + slstep * (steps - nf);
-                int xr = min_x + frstep * nr + srstep * (steps - nr);
-                const int xa = xl < 0 ? 0 : xl, xb = xr > c.W - 1 ? c.W - 1 : xr;
-                for (int x = xa; x <= xb; ++x) {
-                    ++total_pts;
-                    if (aligned_val(angle_of(c.ang[y * c.W + x]), rec.theta, rec.prec)) ++alg_pts;
-                }
+    // Rows are taken 64 at a time (lane = row computes that row's closed-form bounds); the
+    // chunk's pixels are then spread over all lanes as (row r = lane % R, column slots
+    // lane / R), four loads in flight per lane, so small rectangles (most rejected regions)
+    // cost one memory round trip instead of one per row.  Integer counts: order free.
+    for (int yc = y_start; yc <= y_end; yc += LFG_NL) {
+        const int R = y_end - yc + 1 < LFG_NL ? y_end - yc + 1 : LFG_NL;
+        int xa = 0, cnt = 0;
+        if (lane < R) {
+            const int y = yc + lane;
+            const int steps = y - y_start;
+            int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
+            int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
+            const int xl = min_x + flstep * nf + slstep * (steps - nf);
+            const int xr = min_x + frstep * nr + srstep * (steps - nr);
+            xa = xl < 0 ? 0 : xl;
+            const int xb = xr > c.W - 1 ? c.W - 1 : xr;
+            cnt = xb >= xa ? xb - xa + 1 : 0;
+        }
+        total_pts += cnt;
+        // walk the row's defined pixels (sorted by x) instead of the mostly undefined plane
+        int e0 = 0, e1 = 0;
+        if (lane < R && cnt > 0) { e0 = c.rows[yc + lane]; e1 = c.rows[yc + lane + 1]; }
+        const int lmax = wave_max_i(e1 - e0);
+        const int xb_ = xa + cnt - 1;
+        for (int k0 = 0; k0 < lmax; k0 += 4) {
+            uint2 ent[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = e0 + k0 + u;
+                ok[u] = idx < e1;
+                ent[u] = ok[u] ? (idx < c.def_lds ? c.ldef[idx] : c.gdef[idx]) : make_uint2(0u, 0u);
             }
-        } else {
-            for (int y = y_start; y <= y_end; ++y) {
-                const int steps = y - y_start;
-                int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
-                int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
-                int xl = min_x + flstep * nf + slstep * (steps - nf);
-                int xr = min_x + frstep * nr + srstep * (steps - nr);
-                const int xa = xl < 0 ? 0 : xl, xb = xr > c.W - 1 ? c.W - 1 : xr;
-                for (int x = xa + lane; x <= xb; x += LFG_NL) {
-                    ++total_pts;
-                    if (aligned_val(angle_of(c.ang[y * c.W + x]), rec.theta, rec.prec)) ++alg_pts;
-                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = (int)(ent[u].x & 0xffffu);
+                if (ok[u] && x >= xa && x <= xb_ &&
+                    aligned_val((double)__uint_as_float(ent[u].y) * DEG2RAD, rec.theta, rec.prec)) ++alg_pts;
             }
         }
-        total_pts = wave_sum_i(total_pts);
-        alg_pts = wave_sum_i(alg_pts);
     }
-    return nfa(c, total_pts, alg_pts, rec.p);
+    total_pts = wave_sum_i(total_pts);
+    alg_pts = wave_sum_i(alg_pts);
+    LFG_T1(c, 4)
+#if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
+    c.stamps[7] += (1ull << 40) + (unsigned long long)total_pts;
+#endif
+    const double r_ = nfa(c, total_pts, alg_pts, rec.p);
+    LFG_T1(c, 5)
+    return r_;
 }
 
 LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
@@ -576,18 +631,27 @@ LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* lines, int cap)
 {
     int n_lines = 0;
+    LFG_T0
+    uint32_t seed_items = 0;
     for (int i = 0; i < n_order; ++i) {
-        const int adx = (int)(order[i] & 0xfffffu);
+        // seeds are fetched 64 at a time (one coalesced load), then visited in order
+        if ((i % LFG_NL) == 0) seed_items = (i + lane_id() < n_order) ? order[i + lane_id()] : 0u;
+        const int adx = (int)((uint32_t)rl_i((int)seed_items, i % LFG_NL) & 0xfffffu);
         if (used_get(c, adx)) continue;
+        LFG_T1(c, 0)
         int reg_size;
         double reg_angle;
         region_grow(c, adx % c.W, adx / c.W, reg_size, reg_angle, c.prec);
+        LFG_T1(c, 1)
         if (reg_size < c.min_reg_size) continue;
         Rect rec;
         region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
+        LFG_T1(c, 2)
         double log_nfa = -1;
         if (c.refine > 0) {
-            if (!refine(c, reg_size, reg_angle, c.prec, c.p, rec, c.density_th)) continue;
+            bool ok_ = refine(c, reg_size, reg_angle, c.prec, c.p, rec, c.density_th);
+            LFG_T1(c, 3)
+            if (!ok_) continue;
             if (c.refine >= 2) {
                 log_nfa = rect_improve(c, rec);
                 if (log_nfa <= c.log_eps) continue;
@@ -604,7 +668,9 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
             lines[4 * n_lines + 3] = (float)rec.y2;
         }
         ++n_lines;
+        LFG_T1(c, 6)
     }
+    LFG_T1(c, 0)
     return n_lines;
 }
 

@@ -47,7 +47,18 @@ extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, dou
     std::vector<uint32_t> used((Ps + 31) / 32, 0u), lreg(reg_lds > 0 ? reg_lds : 1), greg(Ps);
     for (size_t a = 0; a < Ps; ++a)
         if (ang[a] == grow::NOTDEF_F) used[a >> 5] |= 1u << (a & 31);
+    std::vector<uint2> deflist;
+    std::vector<int> rows(H + 1, 0);
+    for (int y = 0; y < H; ++y) {
+        rows[y] = (int)deflist.size();
+        for (int x = 0; x < W; ++x) {
+            size_t a = (size_t)y * W + x;
+            if (ang[a] != grow::NOTDEF_F) deflist.push_back(make_uint2(((unsigned)y << 16) | (unsigned)x, __builtin_bit_cast(unsigned, ang[a])));
+        }
+    }
+    rows[H] = (int)deflist.size();
     grow::Ctx c;
+    c.rows = rows.data(); c.ldef = deflist.data(); c.gdef = deflist.data(); c.def_lds = reg_lds;
     c.W = W; c.H = H; c.ang = ang.data(); c.mod = mod.data(); c.cs = cs.data(); c.sn = sn.data();
     c.used = used.data(); c.lreg = lreg.data(); c.greg = greg.data(); c.reg_lds = reg_lds;
     c.log_nt = log_nt; c.log_eps = log_eps; c.density_th = density_th; c.prec = prec; c.p = p; c.scale = scale;

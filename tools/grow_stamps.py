@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle totals of k_lsd_grow.  Needs a library built with
+`make -C lane_slam_amd/csrc EXTRA=-DLFG_STAMPS` (never the shipped build)."""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lane_slam_amd import FrontEnd, default_config, synth
+from lane_slam_amd import _lib
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+cfg = default_config("fullres")
+fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=512)
+frames = synth.make_batch(n, 0)
+fe.process_batch(frames)
+seg = fe.process_batch(frames)
+scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
+Ps = scr.shape[2]
+d = scr[:, :, Ps - 32:].copy().view(np.uint64).reshape(n * 3, 16)[:, :11].astype(np.float64)
+names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "emit", "-", "total", "n_order", "n_lines"]
+raw7 = scr[:, :, Ps - 32:].copy().view(np.uint64).reshape(n * 3, 16)[:, 7]
+print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
+order = np.argsort(d[:, 8])
+print("problems", n * 3, "segments", seg.n)
+for label, rows in (("median", d[order[len(order) // 2]]), ("p90", d[order[int(len(order) * 0.9)]]), ("max", d[order[-1]]), ("mean", d.mean(0))):
+    print(label, " ".join("%s=%.0f" % (nm, v / (1000.0 if i < 9 else 1.0)) for i, (nm, v) in enumerate(zip(names, rows))), "(kcycles)")
