@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames per rank (tiled to --batch)")
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
+    ap.add_argument("--depth", type=int, default=2, help="independent batches in flight (handles/streams)")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     args = ap.parse_args()
@@ -77,9 +78,12 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B = args.batch
+    D = max(1, args.depth)
     cfg = default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
-    fe = FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap)
+    # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers)
+    fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D)]
+    fe = fes[0]
     P, Ps = fe.rows * fe.cols, fe.lsd_rows * fe.lsd_cols
 
     # ---- synthetic input, resident in HBM before the timed region
@@ -90,18 +94,22 @@ def main():
     frames = torch.from_numpy(host).to(dev)
 
     cap = B * 3 * args.cap
-    out = {
-        "frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev),
-        "lines": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
-        "normals": torch.zeros(cap, 2, dtype=torch.float32, device=dev),
-        "color": torch.zeros(cap, dtype=torch.uint8, device=dev),
-        "pixels_normalized": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
-        "ground": torch.zeros(cap, 4, dtype=torch.float64, device=dev),
-        "keep": torch.zeros(cap, dtype=torch.uint8, device=dev),
-        "desc": torch.zeros(cap, 72, dtype=torch.float32, device=dev),
-        "code": torch.zeros(cap, 32, dtype=torch.uint8, device=dev),
-    }
-    ptrs = {k: v.data_ptr() for k, v in out.items()}
+
+    def alloc_out():
+        return {
+            "frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev),
+            "lines": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+            "normals": torch.zeros(cap, 2, dtype=torch.float32, device=dev),
+            "color": torch.zeros(cap, dtype=torch.uint8, device=dev),
+            "pixels_normalized": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+            "ground": torch.zeros(cap, 4, dtype=torch.float64, device=dev),
+            "keep": torch.zeros(cap, dtype=torch.uint8, device=dev),
+            "desc": torch.zeros(cap, 72, dtype=torch.float32, device=dev),
+            "code": torch.zeros(cap, 32, dtype=torch.uint8, device=dev),
+        }
+
+    outs = [alloc_out() for _ in range(D)]
+    ptrs = [{k: v.data_ptr() for k, v in o.items()} for o in outs]
     # live map: M random codes (seed 1234, identical on every rank) + a rolling region that
     # receives the segments all ranks produced (append-only map, show_map.py:28-42)
     G = 64 * 1024                                   # gathered segments per rank (padded block)
@@ -109,16 +117,18 @@ def main():
     map_codes = torch.from_numpy(np.concatenate([synth.random_codes(args.map, 1234),
                                                  synth.random_codes(roll, 4321)])).to(dev)
     M = map_codes.shape[0]
-    a_idx = torch.zeros(cap, dtype=torch.int32, device=dev)
-    a_dist = torch.zeros(cap, dtype=torch.float32, device=dev)
+    a_idx = [torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(D)]
+    a_dist = [torch.zeros(cap, dtype=torch.float32, device=dev) for _ in range(D)]
     block = torch.zeros(G, 34, dtype=torch.uint8, device=dev)          # code(32) + keep + colour per segment
     gathered = torch.zeros(world * G, 34, dtype=torch.uint8, device=dev)
     counts_local = torch.zeros(1, dtype=torch.int32, device=dev)
     counts_all = torch.zeros(world, dtype=torch.int32, device=dev)
     seg_total = [0]
 
-    def step():
-        total = fe.process_batch_device(frames.data_ptr(), B, ptrs, cap, describe=True)
+    def finish(slot):
+        """Complete the batch queued on `slot`: merge segment lists across ranks, associate, update the map."""
+        f, out = fes[slot], outs[slot]
+        total = f.wait()
         seg_total[0] = total
         n = min(total, G)
         if world > 1:
@@ -131,36 +141,53 @@ def main():
             src = gathered.view(world, G, 34)[:, : roll // world, :32]
         else:
             src = out["code"][: roll].view(1, -1, 32)[:, : roll]
-        # association: this rank's segments against the replicated map (before this step's update)
+        # association: this rank's segments against the replicated map as it stood before this batch
         torch.cuda.current_stream().synchronize()
         if total > 0:
-            fe.associate_device(out["code"].data_ptr(), total, map_codes.data_ptr(), M, a_idx.data_ptr(), a_dist.data_ptr())
-            fe.synchronize()
+            f.associate_device(out["code"].data_ptr(), total, map_codes.data_ptr(), M, a_idx[slot].data_ptr(),
+                               a_dist[slot].data_ptr())
+            f.synchronize()
         # map update, rank-major / frame-minor so every rank holds the same map
         k = src.shape[1]
         map_codes[args.map: args.map + world * k] = src.reshape(-1, 32)
+        torch.cuda.current_stream().synchronize()
+
+    def run(steps):
+        inflight = []
+        for k in range(steps):
+            slot = k % D
+            if len(inflight) == D:
+                finish(inflight.pop(0))
+            fes[slot].submit_device(frames.data_ptr(), B, ptrs[slot], cap, describe=True)
+            inflight.append(slot)
+        while inflight:
+            finish(inflight.pop(0))
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     sync_all()
-    fe.reset_timing()
-    fe.set_profiling(True)
+    for f in fes:
+        f.reset_timing()
+        f.set_profiling(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
-    fe.set_profiling(False)
+    for f in fes:
+        f.set_profiling(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    timing = fe.timing()
+    timing = {}
+    for f in fes:
+        for name, (ms, launches) in f.timing().items():
+            a0, b0 = timing.get(name, (0.0, 0))
+            timing[name] = (a0 + ms, b0 + launches)
 
     result = None
     if rank == 0:
@@ -194,6 +221,7 @@ def main():
                                    "Hamming association vs %d-code live map" % (B, args.geometry, fe.cols, fe.rows,
                                                                                  fe.lsd_cols, fe.lsd_rows, M),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0],
+                       "batches_in_flight": D,
                        "parallelism": "frame-sharded x%d, all-gather of segment blocks" % world},
             "roofline": roofline,
             "kernels": kernels,
@@ -222,7 +250,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    fe.close()
+    for f in fes:
+        f.close()
     return result
 
 

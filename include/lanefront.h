@@ -135,6 +135,15 @@ int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, fl
 int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
                      lf_segments* out, int out_on_device, int describe, int* n_segments);
 
+/* Pipelined form: lf_process_batch_async queues the whole batch on the handle's HIP stream and
+ * returns at once (device outputs only); lf_wait blocks until it is done and returns the
+ * segment count.  Two handles used alternately keep two independent batches in flight, which
+ * lets one batch's latency-bound LSD region growing overlap the next batch's streaming
+ * kernels.  One batch in flight per handle. */
+int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+                           lf_segments* out_dev, int describe);
+int lf_wait(lf_handle* h, int* n_segments);
+
 /* ---- association: replaces BinaryDescriptorMatcher::match ------------------
  * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
  * each 256-bit query code in the map; idx = -1 and dist = -1 when the nearest

@@ -15,7 +15,7 @@ LF_N_STAGES = 12
 # every symbol include/lanefront.h declares
 EXPORTS = (
     "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize",
-    "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_associate", "lf_associate_float",
+    "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
     "lf_debug_fetch", "lf_debug_detmath", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
 )
 
@@ -55,6 +55,10 @@ def load():
     lib.lf_set_image.argtypes = [vp, vp, ci, ci, ci]
     lib.lf_detect_lines.argtypes = [vp, ci, vp, vp, vp, vp, ci, ctypes.POINTER(ci)]
     lib.lf_process_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(LfSegments), ci, ci, ctypes.POINTER(ci)]
+    lib.lf_process_batch_async.argtypes = [vp, vp, ci, ci, ctypes.POINTER(LfSegments), ci]
+    lib.lf_process_batch_async.restype = ci
+    lib.lf_wait.argtypes = [vp, ctypes.POINTER(ci)]
+    lib.lf_wait.restype = ci
     lib.lf_associate.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci]
     lib.lf_associate_float.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci]
     lib.lf_debug_fetch.argtypes = [vp, ci, vp, ctypes.c_size_t]
@@ -66,7 +70,7 @@ def load():
     lib.lf_reset_timing.argtypes = [vp]
     lib.lf_stage_name.argtypes = [ci]
     lib.lf_stage_name.restype = ctypes.c_char_p
-    for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_associate",
+    for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate",
               "lf_associate_float", "lf_debug_fetch", "lf_debug_detmath", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",
               "lf_reset_timing"):
         getattr(lib, f).restype = ci

@@ -88,13 +88,13 @@ void launch_canny(const CannyParams& p, const uint8_t* bgr, int n_frames, uint32
 int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, const uint32_t* weak, hipStream_t s);
 void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, uint8_t* edges, hipStream_t s);
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
-                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn,
+                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn, float2* seedcs,
                      unsigned long long* maxgrad, int max_nsx, int max_nsy, hipStream_t s);
 void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
                       const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
                       uint2* deflist, int* row_start, hipStream_t s);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
-                     const double* sn, const uint32_t* order, const int* norder, const uint2* deflist,
+                     const double* sn, const float2* seedcs, const uint32_t* order, const int* norder, const uint2* deflist,
                      const int* row_start, uint32_t* reg, float* lines, int* counts, hipStream_t s);
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);

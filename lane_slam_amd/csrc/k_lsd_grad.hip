@@ -30,8 +30,8 @@ __device__ __forceinline__ int reflect101(int p, int n)
 __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
                                                   const uint8_t* __restrict__ masks, float* __restrict__ ang,
                                                   double* __restrict__ mod, double* __restrict__ cs,
-                                                  double* __restrict__ sn, unsigned long long* __restrict__ maxgrad,
-                                                  int max_nsx, int max_nsy)
+                                                  double* __restrict__ sn, float2* __restrict__ seedcs,
+                                                  unsigned long long* __restrict__ maxgrad, int max_nsx, int max_nsy)
 {
     extern __shared__ double lds_d[];
     const int h = p.half;
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
     double local_max = -1.0;
     double* o_cs = cs + (size_t)pc * Ps;
     double* o_sn = sn + (size_t)pc * Ps;
+    float2* o_seed = seedcs + (size_t)pc * Ps;
     for (int idx = threadIdx.x; idx < ox_n * oy_n; idx += 256) {
         int oy = idx / ox_n, ox = idx - oy * ox_n;
         int dx = X0 + ox, dy = Y0 + oy;
@@ -141,6 +142,9 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
                 dm::dsincos((double)(float)arad, s_, c_);
                 o_cs[a] = c_;
                 o_sn[a] = s_;
+                // a region's first pixel enters the angle sums as float(cos/sin) of the UNROUNDED angle
+                dm::dsincos(arad, s_, c_);
+                o_seed[a] = make_float2((float)c_, (float)s_);
                 if (norm > local_max) local_max = norm;
             }
         }
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
 }
 
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
-                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn,
+                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn, float2* seedcs,
                      unsigned long long* maxgrad, int max_nsx, int max_nsy, hipStream_t s)
 {
     const int h = p.half;
@@ -159,8 +163,8 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
                                    (size_t)max_nsy * (GT + 1) + (size_t)(GT + 1) * (GT + 1)) +
                  (size_t)(max_nsy + 2 * h) * (max_nsx + 2 * h);
     dim3 grid((p.Ws + GT - 1) / GT, (p.Hs + GT - 1) / GT, n_frames * 3);
-    hipLaunchKernelGGL(k_lsd_grad, grid, dim3(256), lds, s, p, rt, edge_bits, masks, ang, mod, cs, sn, maxgrad,
-                       max_nsx, max_nsy);
+    hipLaunchKernelGGL(k_lsd_grad, grid, dim3(256), lds, s, p, rt, edge_bits, masks, ang, mod, cs, sn, seedcs,
+                       maxgrad, max_nsx, max_nsy);
 }
 
 }  // namespace lf

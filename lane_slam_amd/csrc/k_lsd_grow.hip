@@ -7,7 +7,8 @@ namespace lf {
 
 __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const float* __restrict__ ang,
                                                  const double* __restrict__ mod, const double* __restrict__ cs,
-                                                 const double* __restrict__ sn, const uint32_t* __restrict__ order,
+                                                 const double* __restrict__ sn, const float2* __restrict__ seedcs,
+                                                 const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint2* __restrict__ deflist,
                                                  const int* __restrict__ row_start, uint32_t* reg, float* lines,
                                                  int* counts, int reg_lds, int def_lds)
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const float* __res
     c.mod = mod + (size_t)pc * Ps;
     c.cs = cs + (size_t)pc * Ps;
     c.sn = sn + (size_t)pc * Ps;
+    c.seedcs = seedcs + (size_t)pc * Ps;
     c.used = used; c.lreg = lreg; c.greg = reg + (size_t)pc * Ps; c.reg_lds = reg_lds;
     c.rows = rows; c.ldef = ldef; c.gdef = gdef; c.def_lds = def_lds;
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
@@ -69,22 +71,24 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const float* __res
 }
 
 void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
-                     const double* sn, const uint32_t* order, const int* norder, const uint2* deflist,
+                     const double* sn, const float2* seedcs, const uint32_t* order, const int* norder,
+                     const uint2* deflist,
                      const int* row_start, uint32_t* reg, float* lines, int* counts, hipStream_t s)
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
     const int nwords = (int)((Ps + 31) / 32);
-    // LDS budget: 64 KB per workgroup (2 problems per CU); fixed parts first, then the region
+    // LDS budget per workgroup; fixed parts first, then the region
     // list (2048 points; longer regions spill to HBM) and whatever is left for the pixel list
     const size_t fixed = (size_t)(((nwords + 1) & ~1) + ((p.Hs + 2) & ~1)) * 4;
-    const size_t budget = 64 * 1024;
+    const size_t budget = 52 * 1024;   // 3 problems per CU (160 KB LDS): 768 problems of a 256-frame batch all resident
     int reg_lds = 2048;
     while (fixed + (size_t)reg_lds * 4 + 1024 * 8 > budget && reg_lds > 64) reg_lds /= 2;
     long long left = (long long)budget - (long long)fixed - (long long)reg_lds * 4;
     int def_lds = left > 0 ? (int)(left / 8) : 0;
     if ((size_t)def_lds > Ps) def_lds = (int)Ps;
     const size_t lds = fixed + (size_t)reg_lds * 4 + (size_t)def_lds * 8;
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64), lds, s, p, ang, mod, cs, sn, order, norder, deflist,
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64), lds, s, p, ang, mod, cs, sn, seedcs, order, norder,
+                       deflist,
                        row_start, reg, lines, counts, reg_lds, def_lds);
 }
 

@@ -45,6 +45,7 @@ struct lf_handle {
     int *d_sdiv = nullptr, *d_hdiv = nullptr;
     float* d_ang = nullptr;
     double *d_mod = nullptr, *d_cs = nullptr, *d_sn = nullptr;
+    float2* d_seedcs = nullptr;
     unsigned long long* d_maxgrad = nullptr;
     uint32_t *d_order_a = nullptr, *d_order_b = nullptr, *d_reg = nullptr;
     uint2* d_deflist = nullptr;
@@ -67,6 +68,8 @@ struct lf_handle {
     int* h_pinned = nullptr;     // [0] total segments, [1] overflow
     int last_frames = 0;
     bool plugin_ready = false;
+    bool pending = false;
+    int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
     // profiling
     bool profiling = false;
@@ -340,7 +343,7 @@ static int alloc_buffers(lf_handle* h)
     if (dalloc(h, &h->d_frames, B * in_px * 3) || dalloc(h, &h->d_bgr, B * P * 3) || dalloc(h, &h->d_masks, nprob * P) ||
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) ||
         dalloc(h, &h->d_ang, nprob * Ps) || dalloc(h, &h->d_mod, nprob * Ps) || dalloc(h, &h->d_cs, nprob * Ps) ||
-        dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
+        dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_seedcs, nprob * Ps) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_deflist, nprob * Ps) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
@@ -372,7 +375,7 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_sdiv, h->d_hdiv,
-                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_deflist, h->d_row_start,
+                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_seedcs, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_deflist, h->d_row_start,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
                      h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
@@ -457,11 +460,11 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     {
         StageTimer t(h, ST_LSD_GRAD);
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, (size_t)n * 3 * sizeof(unsigned long long), s));
-        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_masks, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad,
-                        h->max_nsx, h->max_nsy, s);
+        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_masks, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_seedcs,
+                        h->d_maxgrad, h->max_nsx, h->max_nsy, s);
     }
     { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_deflist, h->d_row_start, s); }
-    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_order_a, h->d_norder, h->d_deflist, h->d_row_start, h->d_reg, h->d_slot_lines, h->d_counts, s); }
+    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_seedcs, h->d_order_a, h->d_norder, h->d_deflist, h->d_row_start, h->d_reg, h->d_slot_lines, h->d_counts, s); }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
     return LF_OK;
@@ -491,13 +494,15 @@ static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
     return LF_OK;
 }
 
-extern "C" int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
-                                lf_segments* out, int out_on_device, int describe, int* n_segments)
+// queue a-1..a-9 for a batch on the handle's stream; device outputs only; no host sync
+extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+                                      lf_segments* out_dev, int describe)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
-    if (!frames || !out || n_frames < 1) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_process_batch: null argument or n_frames < 1"); return LF_ERR_BAD_ARG; }
+    if (!frames || !out_dev || n_frames < 1) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_process_batch: null argument or n_frames < 1"); return LF_ERR_BAD_ARG; }
     if (n_frames > h->max_frames) { lf_set_error(h, LF_ERR_CAPACITY, "n_frames %d exceeds max_frames %d", n_frames, h->max_frames); return LF_ERR_CAPACITY; }
-    if (describe && (!out->lines)) { lf_set_error(h, LF_ERR_BAD_ARG, "describe needs out->lines"); return LF_ERR_BAD_ARG; }
+    if (describe && (!out_dev->lines)) { lf_set_error(h, LF_ERR_BAD_ARG, "describe needs out->lines"); return LF_ERR_BAD_ARG; }
+    if (h->pending) { lf_set_error(h, LF_ERR_BAD_ARG, "a batch is already in flight on this handle: call lf_wait first"); return LF_ERR_BAD_ARG; }
     LF_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const size_t frame_bytes = (size_t)h->cfg.in_rows * h->cfg.in_cols * 3;
@@ -509,6 +514,35 @@ extern "C" int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frame
     h->plugin_ready = false;
     int rc = run_detect(h, d_in, n_frames, false);
     if (rc != LF_OK) return rc;
+    rc = run_segments(h, n_frames, *out_dev, describe != 0);
+    if (rc != LF_OK) return rc;
+    // total + overflow flag travel to pinned host memory behind the kernels
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    h->pending = true;
+    h->pending_capacity = out_dev->capacity;
+    return LF_OK;
+}
+
+extern "C" int lf_wait(lf_handle* h, int* n_segments)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (!h->pending) { if (n_segments) *n_segments = 0; return LF_OK; }
+    h->pending = false;
+    const int total = h->h_pinned[0];
+    if (n_segments) *n_segments = total;
+    if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
+    if (total > h->pending_capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, h->pending_capacity); return LF_ERR_CAPACITY; }
+    return LF_OK;
+}
+
+extern "C" int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+                                lf_segments* out, int out_on_device, int describe, int* n_segments)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!out) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_process_batch: null out"); return LF_ERR_BAD_ARG; }
     lf_segments dev = out_on_device ? *out : h->d_out;
     if (!out_on_device) {
         dev.capacity = out->capacity < h->out_capacity ? out->capacity : h->out_capacity;
@@ -521,17 +555,15 @@ extern "C" int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frame
         if (!out->desc) dev.desc = nullptr;
         if (!out->code) dev.code = nullptr;
         dev.frame_offset = h->d_frame_offset;
+        if (describe && !out->lines) { lf_set_error(h, LF_ERR_BAD_ARG, "describe needs out->lines"); return LF_ERR_BAD_ARG; }
     }
-    rc = run_segments(h, n_frames, dev, describe != 0);
+    int rc = lf_process_batch_async(h, frames, n_frames, frames_on_device, &dev, describe);
     if (rc != LF_OK) return rc;
-    // total + overflow flag back to the host (one small synchronising copy)
-    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
-    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
-    LF_HIP_CHECK(h, hipStreamSynchronize(s));
-    const int total = h->h_pinned[0];
+    int total = 0;
+    rc = lf_wait(h, &total);
     if (n_segments) *n_segments = total;
-    if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
-    if (total > dev.capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, dev.capacity); return LF_ERR_CAPACITY; }
+    if (rc != LF_OK) return rc;
+    hipStream_t s = h->stream;
     if (!out_on_device) {
         const size_t n = (size_t)total;
         if (out->frame_offset) LF_HIP_CHECK(h, hipMemcpyAsync(out->frame_offset, h->d_frame_offset, (n_frames + 1) * sizeof(int), hipMemcpyDeviceToHost, s));

@@ -34,6 +34,7 @@
 #define LFG_DEV static inline
 #define LFG_NL 1
 struct uint2 { unsigned int x, y; };
+struct float2 { float x, y; };
 static inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r; r.x = x; r.y = y; return r; }
 static inline float __uint_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 #endif
@@ -114,6 +115,7 @@ struct Ctx {
     const double* mod;
     const double* cs;      // cos((double)(float)angle_rad), defined pixels only
     const double* sn;
+    const float2* seedcs;  // (float)cos/sin of the unrounded angle: a region's first pixel
     uint32_t* used;        // LDS bitmap, 1 = USED or NOTDEF
     uint32_t* lreg;        // LDS part of the region list
     uint32_t* greg;        // global part (index >= reg_lds)
@@ -137,8 +139,14 @@ LFG_DEV void reg_set(const Ctx& c, int i, uint32_t v)
     if (lane_id() == 0) { if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v; }
 }
 LFG_DEV bool used_get(const Ctx& c, int addr) { return (c.used[addr >> 5] >> (addr & 31)) & 1u; }
-LFG_DEV void used_set(const Ctx& c, int addr) { if (lane_id() == 0) c.used[addr >> 5] |= 1u << (addr & 31); }
-LFG_DEV void used_clr(const Ctx& c, int addr) { if (lane_id() == 0) c.used[addr >> 5] &= ~(1u << (addr & 31)); }
+#ifndef LF_HOST_SIM
+// LDS atomics without return value: no read-modify-write round trip on the sequential path
+LFG_DEV void used_set(const Ctx& c, int addr) { if (lane_id() == 0) atomicOr(&c.used[addr >> 5], 1u << (addr & 31)); }
+LFG_DEV void used_clr(const Ctx& c, int addr) { if (lane_id() == 0) atomicAnd(&c.used[addr >> 5], ~(1u << (addr & 31))); }
+#else
+LFG_DEV void used_set(const Ctx& c, int addr) { c.used[addr >> 5] |= 1u << (addr & 31); }
+LFG_DEV void used_clr(const Ctx& c, int addr) { c.used[addr >> 5] &= ~(1u << (addr & 31)); }
+#endif
 
 LFG_DEV double angle_of(float deg) { return deg == NOTDEF_F ? NOTDEF_D : (double)deg * DEG2RAD; }
 
@@ -185,9 +193,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& re
     const int saddr = sx + sy * W;
     reg_set(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
     reg_angle = angle_of(c.ang[saddr]);
-    double s0, c0;
-    dm::dsincos(reg_angle, s0, c0);
-    float sumdx = (float)c0, sumdy = (float)s0;
+    const float2 sd = c.seedcs[saddr];
+    float sumdx = sd.x, sumdy = sd.y;
     used_set(c, saddr);
 #ifndef LF_HOST_SIM
     // Frontier points are taken in list order, 7 at a time: lane = 9*slot + neighbour, so
@@ -449,7 +456,13 @@ LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
 
 struct Edge { int x, y; };
 
-LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
+// Aligned-point count + NFA of one rectangle, evaluated by a GROUP of GS consecutive lanes
+// (GS = 64: the whole wave on one rectangle; GS = 8: eight rectangles at once, one per lane
+// group -- the per-rectangle work below is then pure SIMD across groups, including the
+// log-gamma / binomial-tail arithmetic of nfa()).  `rec` is per-lane data; lanes of a group
+// hold the same rectangle.  Lanes with `on == false` only take part in the shuffles.
+template <int GS>
+LFG_DEV double rect_nfa_g(const Ctx& c, const Rect& rec, bool on)
 {
     LFG_T0
     const double half_width = rec.width / 2.0;
@@ -510,59 +523,74 @@ LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
     const int y_start = min_yv > 0 ? min_yv : 0;
     const int y_end = max_yv < c.H - 1 ? max_yv : c.H - 1;
     int total_pts = 0, alg_pts = 0;
-    const int lane = lane_id();
-    // Rows are taken 64 at a time (lane = row computes that row's closed-form bounds); the
-    // chunk's pixels are then spread over all lanes as (row r = lane % R, column slots
-    // lane / R), four loads in flight per lane, so small rectangles (most rejected regions)
-    // cost one memory round trip instead of one per row.  Integer counts: order free.
-    for (int yc = y_start; yc <= y_end; yc += LFG_NL) {
-        const int R = y_end - yc + 1 < LFG_NL ? y_end - yc + 1 : LFG_NL;
-        int xa = 0, cnt = 0;
-        if (lane < R) {
-            const int y = yc + lane;
+    const int li = lane_id() % GS;
+    // Each lane of the group takes rows y_start+li, +GS, ...; a row's aligned pixels are found
+    // in its sorted defined-pixel list (LDS) instead of the 96 % undefined angle plane.
+    // Integer counts: order free.
+    if (on) {
+        for (int y = y_start + li; y <= y_end; y += GS) {
             const int steps = y - y_start;
             int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
             int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
             const int xl = min_x + flstep * nf + slstep * (steps - nf);
             const int xr = min_x + frstep * nr + srstep * (steps - nr);
-            xa = xl < 0 ? 0 : xl;
+            const int xa = xl < 0 ? 0 : xl;
             const int xb = xr > c.W - 1 ? c.W - 1 : xr;
-            cnt = xb >= xa ? xb - xa + 1 : 0;
-        }
-        total_pts += cnt;
-        // walk the row's defined pixels (sorted by x) instead of the mostly undefined plane
-        int e0 = 0, e1 = 0;
-        if (lane < R && cnt > 0) { e0 = c.rows[yc + lane]; e1 = c.rows[yc + lane + 1]; }
-        const int lmax = wave_max_i(e1 - e0);
-        const int xb_ = xa + cnt - 1;
-        for (int k0 = 0; k0 < lmax; k0 += 4) {
-            uint2 ent[4];
-            bool ok[4];
+            if (xb < xa) continue;
+            total_pts += xb - xa + 1;
+            const int e0 = c.rows[y], e1 = c.rows[y + 1];
+            for (int k0 = e0; k0 < e1; k0 += 4) {
+                uint2 ent[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int idx = e0 + k0 + u;
-                ok[u] = idx < e1;
-                ent[u] = ok[u] ? (idx < c.def_lds ? c.ldef[idx] : c.gdef[idx]) : make_uint2(0u, 0u);
-            }
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = k0 + u < e1 ? k0 + u : e1 - 1;
+                    ent[u] = idx < c.def_lds ? c.ldef[idx] : c.gdef[idx];
+                }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int x = (int)(ent[u].x & 0xffffu);
-                if (ok[u] && x >= xa && x <= xb_ &&
-                    aligned_val((double)__uint_as_float(ent[u].y) * DEG2RAD, rec.theta, rec.prec)) ++alg_pts;
+                for (int u = 0; u < 4; ++u) {
+                    const int x = (int)(ent[u].x & 0xffffu);
+                    if (k0 + u < e1 && x >= xa && x <= xb &&
+                        aligned_val((double)__uint_as_float(ent[u].y) * DEG2RAD, rec.theta, rec.prec)) ++alg_pts;
+                }
             }
         }
     }
-    total_pts = wave_sum_i(total_pts);
-    alg_pts = wave_sum_i(alg_pts);
+#ifndef LF_HOST_SIM
+#pragma unroll
+    for (int d = GS / 2; d >= 1; d >>= 1) { total_pts += __shfl_xor(total_pts, d); alg_pts += __shfl_xor(alg_pts, d); }
+#endif
     LFG_T1(c, 4)
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
     c.stamps[7] += (1ull << 40) + (unsigned long long)total_pts;
 #endif
-    const double r_ = nfa(c, total_pts, alg_pts, rec.p);
+    const double r_ = on ? nfa(c, total_pts, alg_pts, rec.p) : -1e300;
     LFG_T1(c, 5)
     return r_;
 }
 
+LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec) { return rect_nfa_g<LFG_NL>(c, rec, true); }
+
+// Five candidate rectangles of one rect_improve stage at once (lane group g evaluates cand[g]).
+LFG_DEV void rect_nfa5(const Ctx& c, const Rect* cand, const bool* valid, double* v)
+{
+#ifndef LF_HOST_SIM
+    const int g = lane_id() >> 3;
+    Rect mine = cand[0];
+    bool on = g == 0 && valid[0];
+#pragma unroll
+    for (int k = 1; k < 5; ++k)
+        if (g == k) { mine = cand[k]; on = valid[k]; }
+    const double r = rect_nfa_g<8>(c, mine, on);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = rl_d(r, 8 * k);
+#else
+    for (int k = 0; k < 5; ++k) v[k] = valid[k] ? rect_nfa_g<1>(c, cand[k], true) : -1e300;
+#endif
+}
+
+// rect_improve: the reference tries 5 x 5 variants one after another, but a stage's variants
+// depend only on the stage's starting rectangle, never on each other's NFA -- so each stage is
+// evaluated as one 5-wide rect_nfa5 and then folded in the reference's order.
 LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 {
     const double LOG_EPS = c.log_eps;
@@ -570,57 +598,48 @@ LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
     const double delta_2 = delta / 2.0;
     double log_nfa = rect_nfa(c, rec);
     if (log_nfa > LOG_EPS) return log_nfa;
-    Rect r = rec;
-    for (int n = 0; n < 5; ++n) {
-        r.p /= 2;
-        r.prec = r.p * PI_;
-        double v = rect_nfa(c, r);
-        if (v > log_nfa) { log_nfa = v; rec = r; }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.width -= delta;
-            double v = rect_nfa(c, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
+    Rect cand[5];
+    bool valid[5];
+    double v[5];
+    for (int stage = 0; stage < 5; ++stage) {
+        Rect r = rec;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            bool ok = true;
+            if (stage == 0) {
+                r.p /= 2;
+                r.prec = r.p * PI_;
+            } else {
+                ok = (r.width - delta) >= 0.5;
+                if (ok) {
+                    if (stage == 1) {
+                        r.width -= delta;
+                    } else if (stage == 2) {
+                        r.x1 += -r.dy * delta_2;
+                        r.y1 += r.dx * delta_2;
+                        r.x2 += -r.dy * delta_2;
+                        r.y2 += r.dx * delta_2;
+                        r.width -= delta;
+                    } else if (stage == 3) {
+                        r.x1 -= -r.dy * delta_2;
+                        r.y1 -= r.dx * delta_2;
+                        r.x2 -= -r.dy * delta_2;
+                        r.y2 -= r.dx * delta_2;
+                        r.width -= delta;
+                    } else {
+                        r.p /= 2;
+                        r.prec = r.p * PI_;
+                    }
+                }
+            }
+            cand[n] = r;
+            valid[n] = ok;
         }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.x1 += -r.dy * delta_2;
-            r.y1 += r.dx * delta_2;
-            r.x2 += -r.dy * delta_2;
-            r.y2 += r.dx * delta_2;
-            r.width -= delta;
-            double v = rect_nfa(c, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.x1 -= -r.dy * delta_2;
-            r.y1 -= r.dx * delta_2;
-            r.x2 -= -r.dy * delta_2;
-            r.y2 -= r.dx * delta_2;
-            r.width -= delta;
-            double v = rect_nfa(c, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
-    }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) {
-        if ((r.width - delta) >= 0.5) {
-            r.p /= 2;
-            r.prec = r.p * PI_;
-            double v = rect_nfa(c, r);
-            if (v > log_nfa) { rec = r; log_nfa = v; }
-        }
+        rect_nfa5(c, cand, valid, v);
+#pragma unroll
+        for (int n = 0; n < 5; ++n)
+            if (valid[n] && v[n] > log_nfa) { log_nfa = v[n]; rec = cand[n]; }
+        if (stage < 4 && log_nfa > LOG_EPS) return log_nfa;
     }
     return log_nfa;
 }

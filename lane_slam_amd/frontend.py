@@ -137,6 +137,21 @@ class FrontEnd(object):
                                               ctypes.byref(s), 1, int(bool(describe)), ctypes.byref(total)))
         return total.value
 
+    def submit_device(self, frames_ptr, n_frames, out_ptrs, capacity, describe=True):
+        """Queue a batch (device pointers as in process_batch_device) and return immediately."""
+        s = _lib.LfSegments()
+        s.capacity = int(capacity)
+        for k, v in out_ptrs.items():
+            setattr(s, k, int(v))
+        self._check(self.lib.lf_process_batch_async(self.h, ctypes.c_void_p(int(frames_ptr)), int(n_frames), 1,
+                                                    ctypes.byref(s), int(bool(describe))))
+
+    def wait(self):
+        """Block until the queued batch is complete; returns its segment count."""
+        total = ctypes.c_int()
+        self._check(self.lib.lf_wait(self.h, ctypes.byref(total)))
+        return total.value
+
     # ------------------------------------------------------------------ association
     def associate(self, query_codes, map_codes):
         """Exact Hamming NN (binary_descriptor_matcher.cpp:197-254).  Returns (idx int32, dist float32);
