@@ -36,10 +36,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/
 def stage_bytes(P, Ps, resize):
     """ALGORITHMIC HBM bytes per frame of each streaming kernel."""
     return {
-        "pre(resize+correct+hsv+masks+dilate)": 3 * P + 3 * P + 3 * P,
+        "pre(resize+correct+hsv+masks+dilate)": 3 * P + 3 * P + 3 * P + 3 * (P // 8),
         "canny_nms": 3 * P + 2 * (P // 8),
         "canny_hysteresis": 3 * (P // 8),
-        "lsd_blur_resample_grad": 3 * ((P // 8) + P + 4 * Ps + 8 * Ps),
+        "lsd_blur_resample_grad": 3 * (2 * (P // 8) + 4 * Ps + 8 * Ps),
         "lbd_gray_blur_sobel": 3 * P + 4 * P,
     }
 

@@ -21,6 +21,7 @@ static_assert(ST_COUNT == LF_N_STAGES, "stage table out of sync with lanefront.h
 struct PreParams {
     int in_rows, in_cols, img_rows, img_cols, top_cutoff, Hc, W;
     int resize;
+    int identity_ai;    // ai_scale == 1 and ai_shift == 0 for all channels
     double ifx, ify;
     float ai_scale[3], ai_shift[3];
     int lo[4][3], hi[4][3];
@@ -81,27 +82,29 @@ extern "C" void lf_set_error(lf_handle* h, int code, const char* fmt, ...);
 
 // kernel launchers (one per translation unit)
 namespace lf {
-void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint8_t* bgr, uint8_t* masks,
-                const int* sdiv, const int* hdiv, hipStream_t s);
-void launch_canny(const CannyParams& p, const uint8_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
+void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* masks,
+                uint32_t* maskbits, const int* sdiv, const int* hdiv, hipStream_t s);
+void launch_canny(const CannyParams& p, const uint32_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
                   hipStream_t s);
 int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, const uint32_t* weak, hipStream_t s);
+void launch_bgrx_to_bgr(int n_pix, const uint32_t* bgrx, uint8_t* bgr, hipStream_t s);
 void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, uint8_t* edges, hipStream_t s);
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
-                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn, float2* seedcs,
-                     unsigned long long* maxgrad, int max_nsx, int max_nsy, hipStream_t s);
+                     const uint32_t* mask_bits, float* ang, double* mod, double* cs, double* sn,
+                     unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
+                     hipStream_t s);
 void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
                       const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
                       uint2* deflist, int* row_start, hipStream_t s);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
-                     const double* sn, const float2* seedcs, const uint32_t* order, const int* norder, const uint2* deflist,
+                     const double* sn, const uint32_t* order, const int* norder, const uint2* deflist,
                      const int* row_start, uint32_t* reg, float* lines, int* counts, hipStream_t s);
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,
                      const int* seg_offset, const uint8_t* masks, lf_segments out, int* seg_frame,
                      double* normals64, float* centers, hipStream_t s);
-void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s);
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s);
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
                 const int16_t* dx, const int16_t* dy, const float* gauss_g, const float* gauss_l,
                 float* desc, uint8_t* code, hipStream_t s);

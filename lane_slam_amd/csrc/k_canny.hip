@@ -10,7 +10,7 @@
 //   (+1 halo) -> LDS, NMS classification; each wave owns image rows so the 64-lane ballot
 //   IS the 64-pixel bit-plane word pair.  Output: `weak` (m > low and local max) and
 //   `strong` (also m > high) bit planes, 1 bit per pixel -- 8x fewer bytes than u8 maps.
-//   Algorithmic bytes per pixel: 3 read, 2/8 written.
+//   Algorithmic bytes per pixel: 3 read (moved as one BGRX dword), 2/8 written.
 // k_hysteresis: one workgroup per frame, both bit planes resident in LDS; Jacobi sweeps of
 //   "strong |= weak & dilate3x3(strong)" with an exact in-word run fill (carry trick) until
 //   a sweep changes nothing.  The fixpoint is unique, so the result does not depend on
@@ -21,7 +21,7 @@ namespace lf {
 
 constexpr int CT_W = 64, CT_H = 16;
 
-__global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint8_t* __restrict__ bgr,
+__global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint32_t* __restrict__ bgr,
                                                    uint32_t* __restrict__ strong, uint32_t* __restrict__ weak)
 {
     __shared__ uint32_t px[(CT_H + 4) * (CT_W + 4)];
@@ -29,15 +29,14 @@ __global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint8_t*
     __shared__ int gxy[(CT_H + 2) * (CT_W + 2)];
     const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H, f = blockIdx.z;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const uint8_t* img = bgr + (size_t)f * p.Hc * p.W * 3;
+    const uint32_t* img = bgr + (size_t)f * p.Hc * p.W;
     constexpr int PW = CT_W + 4, PH = CT_H + 4, MW = CT_W + 2, MH = CT_H + 2;
 
     for (int idx = tid; idx < PW * PH; idx += 256) {
         int ty = idx / PW, tx = idx - ty * PW;
         int gx = min(max(x0 + tx - 2, 0), p.W - 1);
         int gy = min(max(y0 + ty - 2, 0), p.Hc - 1);
-        const uint8_t* q = img + ((size_t)gy * p.W + gx) * 3;
-        px[idx] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+        px[idx] = img[(size_t)gy * p.W + gx];
     }
     __syncthreads();
     for (int idx = tid; idx < MW * MH; idx += 256) {
@@ -104,7 +103,7 @@ __global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint8_t*
     }
 }
 
-void launch_canny(const CannyParams& p, const uint8_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
+void launch_canny(const CannyParams& p, const uint32_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
                   hipStream_t s)
 {
     dim3 grid((p.W + CT_W - 1) / CT_W, (p.Hc + CT_H - 1) / CT_H, n_frames);
@@ -189,6 +188,19 @@ __global__ void k_edges_u8(CannyParams p, int n_frames, const uint32_t* __restri
         uint32_t w = bits[row * p.Ww + (x >> 5)];
         edges[i] = ((w >> (x & 31)) & 1u) ? 255 : 0;
     }
+}
+
+__global__ void k_bgrx_to_bgr(int n_pix, const uint32_t* __restrict__ bgrx, uint8_t* __restrict__ bgr)
+{
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < (size_t)n_pix; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t v = bgrx[i];
+        bgr[3 * i] = (uint8_t)v; bgr[3 * i + 1] = (uint8_t)(v >> 8); bgr[3 * i + 2] = (uint8_t)(v >> 16);
+    }
+}
+
+void launch_bgrx_to_bgr(int n_pix, const uint32_t* bgrx, uint8_t* bgr, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_bgrx_to_bgr, dim3(1024), dim3(256), 0, s, n_pix, bgrx, bgr);
 }
 
 void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, uint8_t* edges, hipStream_t s)

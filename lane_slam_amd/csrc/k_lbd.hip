@@ -27,7 +27,7 @@ __device__ __forceinline__ int refl101(int p, int n)
     return p;
 }
 
-__global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* __restrict__ bgr,
+__global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t* __restrict__ bgr,
                                                   int16_t* __restrict__ dxo, int16_t* __restrict__ dyo)
 {
     constexpr int GW = LT_W + 6, GH = LT_H + 6;     // gray tile
@@ -38,12 +38,12 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* 
     __shared__ uint8_t blur[BH * BW_];
     const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H, f = blockIdx.z;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const uint8_t* img = bgr + (size_t)f * Hc * W * 3;
+    const uint32_t* img = bgr + (size_t)f * Hc * W;
     for (int idx = tid; idx < GW * GH; idx += 256) {
         int ty = idx / GW, tx = idx - ty * GW;
         int gx = refl101(x0 + tx - 3, W), gy = refl101(y0 + ty - 3, Hc);
-        const uint8_t* q = img + ((size_t)gy * W + gx) * 3;
-        gray[idx] = (uint8_t)((q[0] * 1868 + q[1] * 9617 + q[2] * 4899 + (1 << 13)) >> 14);
+        const uint32_t q = img[(size_t)gy * W + gx];
+        gray[idx] = (uint8_t)(((q & 255u) * 1868 + ((q >> 8) & 255u) * 9617 + ((q >> 16) & 255u) * 4899 + (1 << 13)) >> 14);
     }
     __syncthreads();
     for (int idx = tid; idx < GH * RW; idx += 256) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* 
     }
 }
 
-void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s)
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s)
 {
     dim3 grid((W + LT_W - 1) / LT_W, (Hc + LT_H - 1) / LT_H, n_frames);
     hipLaunchKernelGGL(k_lbd_grad, grid, dim3(64, 4), 0, s, Hc, W, bgr, dx, dy);

@@ -10,10 +10,10 @@
 //
 // One workgroup produces a 32x32 tile of the scaled image.  All intermediates (raw tile with
 // blur halo, row-filtered, blurred, h-resized, v-resized) live in LDS; HBM sees one read of
-// the bit-packed edges + the u8 mask and one write of angle (f32 degrees), modgrad (f64) and,
+// the bit-packed edges and mask (1 bit/pixel each) and one write of angle (f32 degrees), modgrad (f64) and,
 // only where the gradient is defined, cos/sin of the float-rounded angle (f64) that region
 // growing accumulates.  Tiles whose raw footprint holds no edge pixel skip all arithmetic.
-// Algorithmic bytes per scaled pixel: (1/0.64)*(1+1/8) read + 4 + 8 written.
+// Algorithmic bytes per scaled pixel: (1/0.64)*(2/8) read + 4 + 8 written.
 #include "common.h"
 
 namespace lf {
@@ -27,144 +27,277 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+// ---- pass 1: classify tiles from the bit planes (edges & colour mask) and finish the empty ones
+// One workgroup per strip of 32 scaled rows.  (1) every edge-word AND mask-word under the strip's
+// raw footprint is tested once; non-zero words mark their word column in LDS.  (2) a tile is empty
+// iff no marked column lies under its footprint; non-empty tiles go to the work list of pass 2.
+// (3) the strip is streamed out ROW-MAJOR with 16-byte stores -- angle NOTDEF, modgrad 0 -- skipping
+// the 32-pixel segments that belong to listed tiles.  No arithmetic, no LDS tiles: this pass runs at
+// store bandwidth, and most of the image (no edges of that colour) never reaches pass 2.
+__global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
+                                                     const uint32_t* __restrict__ mask_bits, float* __restrict__ ang,
+                                                     double* __restrict__ mod, uint32_t* __restrict__ list,
+                                                     int* __restrict__ list_count)
+{
+    __shared__ uint32_t colnz[256];
+    __shared__ uint8_t tflag[256];
+    const int h = p.half;
+    const int pc = blockIdx.y, f = pc / 3, tid = threadIdx.x;
+    const int ty = blockIdx.x, Y0 = ty * GT;
+    const int Y1 = min(Y0 + GT, p.Hs - 1);
+    const int sy_lo = rt.y0[Y0], sy_hi = rt.y1[Y1];
+    // BORDER_REFLECT_101 only folds indices back inside these clamped ranges
+    const int r0 = max(0, sy_lo - h), r1 = min(p.Hc - 1, sy_hi + h);
+    const int Ww = p.Ww;
+    for (int i = tid; i < Ww; i += 256) colnz[i] = 0;
+    __syncthreads();
+    const uint32_t* eb = edge_bits + (size_t)f * p.Hc * Ww;
+    const uint32_t* mb = mask_bits + (size_t)pc * p.Hc * Ww;
+    const int total = (r1 - r0 + 1) * Ww;
+    for (int i = tid; i < total; i += 256) {
+        const size_t o = (size_t)r0 * Ww + i;
+        if (eb[o] & mb[o]) colnz[i % Ww] = 1;              // edge_color = dilated mask & edges
+    }
+    __syncthreads();
+    const int ntx = (p.Ws + GT - 1) / GT;
+    for (int tx = tid; tx < ntx; tx += 256) {
+        const int X0 = tx * GT, X1 = min(X0 + GT, p.Ws - 1);
+        const int sx_lo = rt.xofs[X0], sx_hi = min(rt.xofs[X1] + 1, p.W - 1);
+        const int w0 = max(0, sx_lo - h) >> 5, w1 = min(p.W - 1, sx_hi + h) >> 5;
+        uint32_t any = 0;
+        for (int w = w0; w <= w1; ++w) any |= colnz[w];
+        tflag[tx] = (uint8_t)any;
+        if (any) {
+            int slot = atomicAdd(list_count, 1);
+            list[slot] = ((uint32_t)pc << 16) | ((uint32_t)ty << 8) | (uint32_t)tx;
+        }
+    }
+    __syncthreads();
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    float* o_ang = ang + (size_t)pc * Ps + (size_t)Y0 * p.Ws;
+    double* o_mod = mod + (size_t)pc * Ps + (size_t)Y0 * p.Ws;
+    const int oy_n = min(GT, p.Hs - Y0);
+    if ((p.Ws & 3) == 0) {
+        const int g_row = p.Ws >> 2;                       // 4-pixel groups per row
+        const float4 nd = make_float4(kNotDef, kNotDef, kNotDef, kNotDef);
+        const double2 z2 = make_double2(0.0, 0.0);
+        for (int i = tid; i < oy_n * g_row; i += 256) {
+            const int oy = i / g_row, g = i - oy * g_row;
+            if (tflag[(4 * g) / GT]) continue;
+            const size_t a = (size_t)oy * p.Ws + 4 * g;
+            *reinterpret_cast<float4*>(o_ang + a) = nd;
+            *reinterpret_cast<double2*>(o_mod + a) = z2;
+            *reinterpret_cast<double2*>(o_mod + a + 2) = z2;
+        }
+    } else {
+        for (int i = tid; i < oy_n * p.Ws; i += 256) {
+            const int ox = i % p.Ws;
+            if (tflag[ox / GT]) continue;
+            o_ang[i] = kNotDef;
+            o_mod[i] = 0.0;
+        }
+    }
+}
+
+// ---- pass 2: blur + resample + gradient for the listed tiles (persistent workgroups) ---------
+// The raw tile is binary, so cv::RowFilter's ordered sum s = k[0]*S[0]; s += k[j]*S[j] only ever
+// adds the constants k[j]*255 for set pixels (adding +0.0 is exact): each row-filter output is a
+// lookup in a 2^ntaps-entry table indexed by the bits under the taps, and the raw tile lives in
+// LDS as one 64-bit window per row.  Angles/sines are evaluated after compacting the tile's defined
+// pixels so the expensive double-precision path runs on full waves.
 __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
-                                                  const uint8_t* __restrict__ masks, float* __restrict__ ang,
+                                                  const uint32_t* __restrict__ mask_bits, float* __restrict__ ang,
                                                   double* __restrict__ mod, double* __restrict__ cs,
-                                                  double* __restrict__ sn, float2* __restrict__ seedcs,
-                                                  unsigned long long* __restrict__ maxgrad, int max_nsx, int max_nsy)
+                                                  double* __restrict__ sn, unsigned long long* __restrict__ maxgrad,
+                                                  int max_nsx, int max_nsy, const uint32_t* __restrict__ list,
+                                                  const int* __restrict__ list_count)
 {
     extern __shared__ double lds_d[];
+    __shared__ double T[128];                     // ordered partial sums of k[j]*255 per 7-bit pattern
+    __shared__ unsigned long long rowbits[GT * 2 + 2 * kMaxGaussTaps];
+    __shared__ int n_def;
     const int h = p.half;
-    const int pc = blockIdx.z;                 // problem = frame*3 + colour
-    const int f = pc / 3;
-    const int X0 = blockIdx.x * GT, Y0 = blockIdx.y * GT;
-    const int X1 = min(X0 + GT, p.Ws - 1), Y1 = min(Y0 + GT, p.Hs - 1);
-    const int sx_lo = rt.xofs[X0], sx_hi = min(rt.xofs[X1] + 1, p.W - 1);
-    const int sy_lo = rt.y0[Y0], sy_hi = rt.y1[Y1];
-    const int nsx = sx_hi - sx_lo + 1, nsy = sy_hi - sy_lo + 1;
-    const int nox = X1 - X0 + 1, noy = Y1 - Y0 + 1;   // scaled samples needed (incl. +1 neighbour)
-    const int rw = nsx + 2 * h, rh = nsy + 2 * h;
-
-    // LDS carve (doubles first for alignment)
-    double* F = lds_d;                                   // [rh][nsx]
-    double* Bl = F + (size_t)(max_nsy + 2 * h) * max_nsx;        // [nsy][nsx]
-    double* Hb = Bl + (size_t)max_nsy * max_nsx;                 // [nsy][GT+1]
-    double* Sc = Hb + (size_t)max_nsy * (GT + 1);                // [GT+1][GT+1]
-    uint8_t* raw = reinterpret_cast<uint8_t*>(Sc + (GT + 1) * (GT + 1));   // [rh][rw]
-
-    const size_t P = (size_t)p.Hc * p.W;
-    const uint8_t* mk = masks + (size_t)pc * P;
-    const uint32_t* eb = edge_bits + (size_t)f * p.Hc * p.Ww;
-    int any = 0;
-    for (int idx = threadIdx.x; idx < rw * rh; idx += 256) {
-        int ty = idx / rw, tx = idx - ty * rw;
-        int gx = reflect101(sx_lo - h + tx, p.W), gy = reflect101(sy_lo - h + ty, p.Hc);
-        uint32_t w = eb[(size_t)gy * p.Ww + (gx >> 5)];
-        uint8_t v = (((w >> (gx & 31)) & 1u) && mk[(size_t)gy * p.W + gx]) ? 255 : 0;
-        raw[idx] = v;
-        any |= v;
-    }
-    any = __syncthreads_or(any);
-
-    const size_t Ps = (size_t)p.Hs * p.Ws;
-    float* o_ang = ang + (size_t)pc * Ps;
-    double* o_mod = mod + (size_t)pc * Ps;
-    const int ox_n = min(GT, p.Ws - X0), oy_n = min(GT, p.Hs - Y0);
-    if (!any) {
-        for (int idx = threadIdx.x; idx < ox_n * oy_n; idx += 256) {
-            int oy = idx / ox_n, ox = idx - oy * ox_n;
-            size_t a = (size_t)(Y0 + oy) * p.Ws + X0 + ox;
-            o_ang[a] = kNotDef;
-            o_mod[a] = 0.0;
+    const int n_tiles = *list_count;
+    const bool use_table = p.ntaps <= 7;
+    if (use_table) {
+        for (int m = threadIdx.x; m < (1 << p.ntaps); m += 256) {
+            double s = 0.0;
+            bool first = true;
+            for (int j = 0; j < p.ntaps; ++j) {
+                const double term = p.k[j] * ((m >> j) & 1 ? 255.0 : 0.0);
+                if (first) { s = term; first = false; } else s += term;
+            }
+            T[m] = s;
         }
-        return;
     }
-    // row filter
-    for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
-        int ry = idx / nsx, cx = idx - ry * nsx;
-        const uint8_t* S = raw + ry * rw + cx;
-        double s = p.k[0] * (double)S[0];
-        for (int j = 1; j < p.ntaps; ++j) s += p.k[j] * (double)S[j];
-        F[ry * nsx + cx] = s;
-    }
-    __syncthreads();
-    // column filter
-    for (int idx = threadIdx.x; idx < nsy * nsx; idx += 256) {
-        int by = idx / nsx, cx = idx - by * nsx;
-        const double* S = F + (by + h) * nsx + cx;
-        double s = p.k[h] * S[0] + 0.0;
-        for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
-        Bl[by * nsx + cx] = s;
-    }
-    __syncthreads();
-    // horizontal resize
-    for (int idx = threadIdx.x; idx < nsy * nox; idx += 256) {
-        int by = idx / nox, ox = idx - by * nox;
-        int dx = X0 + ox;
-        int sx = rt.xofs[dx] - sx_lo;
-        const double* S = Bl + by * nsx;
-        double v;
-        if (dx < rt.xmax) v = S[sx] * (double)rt.xa[2 * dx] + S[sx + 1] * (double)rt.xa[2 * dx + 1];
-        else v = S[sx] * 1.0;
-        Hb[by * (GT + 1) + ox] = v;
-    }
-    __syncthreads();
-    // vertical resize
-    for (int idx = threadIdx.x; idx < noy * nox; idx += 256) {
-        int oy = idx / nox, ox = idx - oy * nox;
-        int dy = Y0 + oy;
-        int r0 = rt.y0[dy] - sy_lo, r1 = rt.y1[dy] - sy_lo;
-        Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)rt.yb[2 * dy] + Hb[r1 * (GT + 1) + ox] * (double)rt.yb[2 * dy + 1];
-    }
-    __syncthreads();
-    // gradient + angle
+    const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
+    const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
+    size_t regA = szF > szHb ? szF : szHb;
+    if (regA < (size_t)GT * GT) regA = (size_t)GT * GT;      // also hosts the defined-pixel list (8 B entries)
+    const size_t regB = szBl > szSc ? szBl : szSc;
+    double* F = lds_d;                                   // [rh][nsx]     row-filtered
+    double* Bl = lds_d + regA;                           // [nsy][nsx]    blurred
+    double* Hb = lds_d;                                  // [nsy][GT+1]   h-resized   (reuses F)
+    double* Sc = lds_d + regA;                           // [GT+1][GT+1]  v-resized   (reuses Bl)
+    uint2* dl = reinterpret_cast<uint2*>(lds_d);         // defined pixels (reuses F/Hb once Sc is built)
+    const size_t Ps = (size_t)p.Hs * p.Ws;
     const double DEG_TO_RADS = 3.14159265358979323846 / 180;
-    double local_max = -1.0;
-    double* o_cs = cs + (size_t)pc * Ps;
-    double* o_sn = sn + (size_t)pc * Ps;
-    float2* o_seed = seedcs + (size_t)pc * Ps;
-    for (int idx = threadIdx.x; idx < ox_n * oy_n; idx += 256) {
-        int oy = idx / ox_n, ox = idx - oy * ox_n;
-        int dx = X0 + ox, dy = Y0 + oy;
-        size_t a = (size_t)dy * p.Ws + dx;
-        float av = kNotDef;
-        double norm = 0.0;
-        if (dx < p.Ws - 1 && dy < p.Hs - 1) {
-            const double* q = Sc + oy * (GT + 1) + ox;
-            double DA = q[GT + 2] - q[0];
-            double BC = q[1] - q[GT + 1];
-            double gx = DA + BC, gy = DA - BC;
-            norm = dm::dsqrt((gx * gx + gy * gy) / 4);
-            if (!(norm <= p.rho)) {
-                av = dm::fast_atan2_deg((float)gx, (float)(-gy));
-                double arad = (double)av * DEG_TO_RADS;
-                double s_, c_;
-                dm::dsincos((double)(float)arad, s_, c_);
-                o_cs[a] = c_;
-                o_sn[a] = s_;
-                // a region's first pixel enters the angle sums as float(cos/sin) of the UNROUNDED angle
-                dm::dsincos(arad, s_, c_);
-                o_seed[a] = make_float2((float)c_, (float)s_);
-                if (norm > local_max) local_max = norm;
+
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+        __syncthreads();                           // LDS reuse across tiles
+        const uint32_t tile = list[ti];
+        const int pc = (int)(tile >> 16);          // problem = frame*3 + colour
+        const int f = pc / 3;
+        const int X0 = (int)(tile & 255u) * GT, Y0 = (int)((tile >> 8) & 255u) * GT;
+        const int X1 = min(X0 + GT, p.Ws - 1), Y1 = min(Y0 + GT, p.Hs - 1);
+        const int sx_lo = rt.xofs[X0], sx_hi = min(rt.xofs[X1] + 1, p.W - 1);
+        const int sy_lo = rt.y0[Y0], sy_hi = rt.y1[Y1];
+        const int nsx = sx_hi - sx_lo + 1, nsy = sy_hi - sy_lo + 1;
+        const int nox = X1 - X0 + 1, noy = Y1 - Y0 + 1;   // scaled samples needed (incl. +1 neighbour)
+        const int rw = nsx + 2 * h, rh = nsy + 2 * h;
+        const uint32_t* mk = mask_bits + (size_t)pc * p.Hc * p.Ww;
+        const uint32_t* eb = edge_bits + (size_t)f * p.Hc * p.Ww;
+        if (threadIdx.x == 0) n_def = 0;
+        // raw rows as bit windows: bit t of rowbits[ty] = edge_color(reflect(sx_lo-h+t), reflect(sy_lo-h+ty))
+        const int xs = sx_lo - h;
+        const bool interior_x = xs >= 0 && xs + rw <= p.W && rw <= 64;
+        for (int ty = threadIdx.x; ty < rh; ty += 256) {
+            const int gy = reflect101(sy_lo - h + ty, p.Hc);
+            const uint32_t* er = eb + (size_t)gy * p.Ww;
+            const uint32_t* mr = mk + (size_t)gy * p.Ww;
+            unsigned long long bits = 0;
+            if (interior_x) {
+                const int w0 = xs >> 5, sh = xs & 31;
+                const int wl = p.Ww - 1;
+                unsigned long long lo = (unsigned long long)(er[w0] & mr[w0]);
+                unsigned long long mid = w0 + 1 <= wl ? (unsigned long long)(er[w0 + 1] & mr[w0 + 1]) : 0ull;
+                unsigned long long hi = w0 + 2 <= wl ? (unsigned long long)(er[w0 + 2] & mr[w0 + 2]) : 0ull;
+                bits = ((lo | (mid << 32)) >> sh) | (sh ? (hi << (64 - sh)) : 0ull);
+            } else {
+                for (int t = 0; t < rw && t < 64; ++t) {
+                    const int gx = reflect101(xs + t, p.W);
+                    const uint32_t w = er[gx >> 5] & mr[gx >> 5];
+                    bits |= (unsigned long long)((w >> (gx & 31)) & 1u) << t;
+                }
+            }
+            if (rw < 64) bits &= (1ull << rw) - 1ull;
+            rowbits[ty] = bits;
+        }
+        __syncthreads();
+        float* o_ang = ang + (size_t)pc * Ps;
+        double* o_mod = mod + (size_t)pc * Ps;
+        const int ox_n = min(GT, p.Ws - X0), oy_n = min(GT, p.Hs - Y0);
+        // row filter (table lookup; general path for wide kernels or windows > 64 bits)
+        if (use_table && rw <= 64) {
+            const int msk = (1 << p.ntaps) - 1;
+            for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
+                int ry = idx / nsx, cx = idx - ry * nsx;
+                F[idx] = T[(int)(rowbits[ry] >> cx) & msk];
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
+                int ry = idx / nsx, cx = idx - ry * nsx;
+                const int gy = reflect101(sy_lo - h + ry, p.Hc);
+                double s = 0.0;
+                for (int j = 0; j < p.ntaps; ++j) {
+                    const int gx = reflect101(xs + cx + j, p.W);
+                    const uint32_t w = eb[(size_t)gy * p.Ww + (gx >> 5)] & mk[(size_t)gy * p.Ww + (gx >> 5)];
+                    const double term = p.k[j] * (((w >> (gx & 31)) & 1u) ? 255.0 : 0.0);
+                    if (j == 0) s = term; else s += term;
+                }
+                F[idx] = s;
             }
         }
-        o_ang[a] = av;
-        o_mod[a] = norm;
+        __syncthreads();
+        // column filter
+        for (int idx = threadIdx.x; idx < nsy * nsx; idx += 256) {
+            int by = idx / nsx, cx = idx - by * nsx;
+            const double* S = F + (by + h) * nsx + cx;
+            double s = p.k[h] * S[0] + 0.0;
+            for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
+            Bl[by * nsx + cx] = s;
+        }
+        __syncthreads();
+        // horizontal resize
+        for (int idx = threadIdx.x; idx < nsy * nox; idx += 256) {
+            int by = idx / nox, ox = idx - by * nox;
+            int dx = X0 + ox;
+            int sx = rt.xofs[dx] - sx_lo;
+            const double* S = Bl + by * nsx;
+            double v;
+            if (dx < rt.xmax) v = S[sx] * (double)rt.xa[2 * dx] + S[sx + 1] * (double)rt.xa[2 * dx + 1];
+            else v = S[sx] * 1.0;
+            Hb[by * (GT + 1) + ox] = v;
+        }
+        __syncthreads();
+        // vertical resize
+        for (int idx = threadIdx.x; idx < noy * nox; idx += 256) {
+            int oy = idx / nox, ox = idx - oy * nox;
+            int dy = Y0 + oy;
+            int r0 = rt.y0[dy] - sy_lo, r1 = rt.y1[dy] - sy_lo;
+            Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)rt.yb[2 * dy] + Hb[r1 * (GT + 1) + ox] * (double)rt.yb[2 * dy + 1];
+        }
+        __syncthreads();
+        // gradient + level-line angle; defined pixels are queued for the trigonometry pass
+        double local_max = -1.0;
+        for (int idx = threadIdx.x; idx < ox_n * oy_n; idx += 256) {
+            int oy = idx / ox_n, ox = idx - oy * ox_n;
+            int dx = X0 + ox, dy = Y0 + oy;
+            size_t a = (size_t)dy * p.Ws + dx;
+            float av = kNotDef;
+            double norm = 0.0;
+            if (dx < p.Ws - 1 && dy < p.Hs - 1) {
+                const double* q = Sc + oy * (GT + 1) + ox;
+                double DA = q[GT + 2] - q[0];
+                double BC = q[1] - q[GT + 1];
+                double gx = DA + BC, gy = DA - BC;
+                norm = dm::dsqrt((gx * gx + gy * gy) / 4);
+                if (!(norm <= p.rho)) {
+                    av = dm::fast_atan2_deg((float)gx, (float)(-gy));
+                    if (norm > local_max) local_max = norm;
+                    const int slot = atomicAdd(&n_def, 1);
+                    dl[slot] = make_uint2((uint32_t)a, __float_as_uint(av));
+                }
+            }
+            o_ang[a] = av;
+            o_mod[a] = norm;
+        }
+        if (local_max > 0.0) atomicMax(maxgrad + pc, (unsigned long long)__double_as_longlong(local_max));
+        __syncthreads();
+        // cos/sin of the float-rounded angle (what region growing accumulates), on full waves
+        double* o_cs = cs + (size_t)pc * Ps;
+        double* o_sn = sn + (size_t)pc * Ps;
+        const int nd = n_def;
+        for (int e = threadIdx.x; e < nd; e += 256) {
+            const uint2 it = dl[e];
+            const double arad = (double)__uint_as_float(it.y) * DEG_TO_RADS;
+            double s_, c_;
+            dm::dsincos((double)(float)arad, s_, c_);
+            o_cs[it.x] = c_;
+            o_sn[it.x] = s_;
+        }
     }
-    if (local_max > 0.0) atomicMax(maxgrad + pc, (unsigned long long)__double_as_longlong(local_max));
 }
 
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
-                     const uint8_t* masks, float* ang, double* mod, double* cs, double* sn, float2* seedcs,
-                     unsigned long long* maxgrad, int max_nsx, int max_nsy, hipStream_t s)
+                     const uint32_t* mask_bits, float* ang, double* mod, double* cs, double* sn,
+                     unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
+                     hipStream_t s)
 {
     const int h = p.half;
-    size_t lds = sizeof(double) * ((size_t)(max_nsy + 2 * h) * max_nsx + (size_t)max_nsy * max_nsx +
-                                   (size_t)max_nsy * (GT + 1) + (size_t)(GT + 1) * (GT + 1)) +
-                 (size_t)(max_nsy + 2 * h) * (max_nsx + 2 * h);
-    dim3 grid((p.Ws + GT - 1) / GT, (p.Hs + GT - 1) / GT, n_frames * 3);
-    hipLaunchKernelGGL(k_lsd_grad, grid, dim3(256), lds, s, p, rt, edge_bits, masks, ang, mod, cs, sn, seedcs,
-                       maxgrad, max_nsx, max_nsy);
+    const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
+    const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
+    size_t regA = szF > szHb ? szF : szHb;
+    if (regA < (size_t)GT * GT) regA = (size_t)GT * GT;
+    const size_t regB = szBl > szSc ? szBl : szSc;
+    const size_t lds = sizeof(double) * (regA + regB);
+    dim3 grid((p.Hs + GT - 1) / GT, n_frames * 3);
+    (void)hipMemsetAsync(list_count, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, ang, mod, list, list_count);
+    const int per_cu = (int)((150 * 1024) / (lds + 2048));
+    const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(256), lds, s, p, rt, edge_bits, mask_bits, ang, mod, cs, sn,
+                       maxgrad, max_nsx, max_nsy, list, list_count);
 }
 
 }  // namespace lf

@@ -7,7 +7,7 @@ namespace lf {
 
 __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const float* __restrict__ ang,
                                                  const double* __restrict__ mod, const double* __restrict__ cs,
-                                                 const double* __restrict__ sn, const float2* __restrict__ seedcs,
+                                                 const double* __restrict__ sn,
                                                  const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint2* __restrict__ deflist,
                                                  const int* __restrict__ row_start, uint32_t* reg, float* lines,
@@ -46,7 +46,6 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const float* __res
     c.mod = mod + (size_t)pc * Ps;
     c.cs = cs + (size_t)pc * Ps;
     c.sn = sn + (size_t)pc * Ps;
-    c.seedcs = seedcs + (size_t)pc * Ps;
     c.used = used; c.lreg = lreg; c.greg = reg + (size_t)pc * Ps; c.reg_lds = reg_lds;
     c.rows = rows; c.ldef = ldef; c.gdef = gdef; c.def_lds = def_lds;
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
@@ -71,7 +70,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const float* __res
 }
 
 void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
-                     const double* sn, const float2* seedcs, const uint32_t* order, const int* norder,
+                     const double* sn, const uint32_t* order, const int* norder,
                      const uint2* deflist,
                      const int* row_start, uint32_t* reg, float* lines, int* counts, hipStream_t s)
 {
@@ -87,7 +86,7 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const d
     int def_lds = left > 0 ? (int)(left / 8) : 0;
     if ((size_t)def_lds > Ps) def_lds = (int)Ps;
     const size_t lds = fixed + (size_t)reg_lds * 4 + (size_t)def_lds * 8;
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64), lds, s, p, ang, mod, cs, sn, seedcs, order, norder,
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64), lds, s, p, ang, mod, cs, sn, order, norder,
                        deflist,
                        row_start, reg, lines, counts, reg_lds, def_lds);
 }

@@ -5,22 +5,37 @@
 //   src/anti_instagram/include/anti_instagram/scale_and_shift.py:25-33
 //   src/line_detector/include/line_detector/line_detector_lsd.py:38-53,138   BGR2HSV, inRange (red = OR), dilate
 //
-// Layout: each workgroup owns a 128x8 tile of the working image.  Phase 1 converts the
+// Layout: each workgroup owns a 128x14 tile of the working image (16 rows with the 3x3 halo).  Phase 1 converts the
 // tile plus its dilation halo to packed (b,g,r,maskbits) words in LDS (HSV is computed
 // once per pixel, never written to HBM).  Phase 2: each lane owns 4 adjacent pixels,
-// ORs the structuring element over the LDS mask bits and writes 12 B of corrected BGR
-// and 4 B per colour plane -- dword stores, fully coalesced.
-// Algorithmic bytes per working pixel: 3 read + 3 (bgr) + 3 (masks) written.
+// ORs the structuring element over the LDS mask bits and writes 16 B of corrected BGRX (one dword
+// per pixel, so the Canny and LBD stencils load whole pixels)
+// and 4 B per colour plane -- dword stores, fully coalesced -- plus a 1-bit-per-pixel copy of the
+// masks (8 lanes OR their nibbles into one word) that the LSD stage ANDs with the edge bit plane.
+// Algorithmic bytes per working pixel: 3 read + 3 (bgr) + 3 (masks) + 3/8 (mask bits) written.
 #include "common.h"
 
 namespace lf {
 
-constexpr int TW = 128, TH = 8, PRE_THREADS = 256;
+constexpr int TW = 128, TH = 14, PRE_THREADS = 256;   // (TH + 2) rows x 32 four-pixel groups = 512 = 2 per lane
 
-__device__ __forceinline__ int hsv_bits(int b, int g, int r, const PreParams& p, const int* __restrict__ sdiv,
-                                        const int* __restrict__ hdiv)
+struct PixOut { uint32_t packed; };
+
+__device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const PreParams& p, const int* sdiv, const int* hdiv)
 {
-    // OpenCV RGB2HSV_b, hsv_shift = 12, hue range 180
+    // scaleandshift2 (float32) + convertScaleAbs, then OpenCV RGB2HSV_b (hsv_shift 12, hue range 180) + 4 inRange boxes
+    int c[3] = {b0, g0, r0};
+    if (!p.identity_ai) {                      // scale 1, shift 0 leaves every u8 value unchanged: skip
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float v = (float)c[ch] * p.ai_scale[ch];
+            v = v + p.ai_shift[ch];
+            float a = v < 0 ? -v : v;
+            int iv = (int)__builtin_rintf(a);  // v_rndne_f32: round half to even, as cvRound
+            c[ch] = min(max(iv, 0), 255);
+        }
+    }
+    const int b = c[0], g = c[1], r = c[2];
     int v = max(b, max(g, r)), vmin = min(b, min(g, r));
     int diff = v - vmin;
     int vr = v == r ? -1 : 0;
@@ -35,82 +50,141 @@ __device__ __forceinline__ int hsv_bits(int b, int g, int r, const PreParams& p,
     for (int k = 0; k < 4; ++k)
         in[k] = (h >= p.lo[k][0]) & (h <= p.hi[k][0]) & (s >= p.lo[k][1]) & (s <= p.hi[k][1]) &
                 (v >= p.lo[k][2]) & (v <= p.hi[k][2]);
-    return in[0] | (in[1] << 1) | ((in[2] | in[3]) << 2);
+    const int bits = in[0] | (in[1] << 1) | ((in[2] | in[3]) << 2);
+    return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | ((uint32_t)bits << 24);
 }
 
 __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t* __restrict__ frames,
-                                                      uint8_t* __restrict__ bgr_out, uint8_t* __restrict__ masks,
-                                                      const int* __restrict__ sdiv, const int* __restrict__ hdiv)
+                                                      uint32_t* __restrict__ bgrx_out, uint8_t* __restrict__ masks,
+                                                      uint32_t* __restrict__ maskbits, const int* __restrict__ sdiv_g,
+                                                      const int* __restrict__ hdiv_g)
 {
     __shared__ uint32_t tile[(TH + 2 * (kMaxKsize / 2)) * (TW + 2 * (kMaxKsize / 2))];
+    __shared__ int sdiv[256], hdiv[256];
     const int r = p.r;
     const int tw = TW + 2 * r, th = TH + 2 * r;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
     const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
+    sdiv[threadIdx.x] = sdiv_g[threadIdx.x];
+    hdiv[threadIdx.x] = hdiv_g[threadIdx.x];
+    __syncthreads();
 
-    for (int idx = threadIdx.x; idx < tw * th; idx += PRE_THREADS) {
-        int ty = idx / tw, tx = idx - ty * tw;
-        int gx = x0 + tx - r, gy = y0 + ty - r;
-        uint32_t packed = 0;
-        if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
-            int yy = gy + p.top_cutoff;
-            int sy = yy, sx = gx;
-            if (p.resize) {
-                sy = min(dm::ifloor(yy * p.ify), p.in_rows - 1);
-                sx = min(dm::ifloor(gx * p.ifx), p.in_cols - 1);
+    const bool fast = !p.resize && (p.in_cols & 3) == 0 && (p.W & 3) == 0;
+    if (fast) {
+        // interior columns: one lane = 4 pixels = 3 aligned dwords of the source row
+        const int groups = th * (TW / 4);
+        for (int g = threadIdx.x; g < groups; g += PRE_THREADS) {
+            const int ty = g / (TW / 4), cg = g - ty * (TW / 4);
+            const int gx = x0 + 4 * cg, gy = y0 + ty - r;
+            uint32_t o[4] = {0, 0, 0, 0};
+            if (gx < p.W && gy >= 0 && gy < p.Hc) {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3);
+                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                o[0] = convert_pixel(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, p, sdiv, hdiv);
+                o[1] = convert_pixel(d0 >> 24, d1 & 255, (d1 >> 8) & 255, p, sdiv, hdiv);
+                o[2] = convert_pixel((d1 >> 16) & 255, d1 >> 24, d2 & 255, p, sdiv, hdiv);
+                o[3] = convert_pixel((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, p, sdiv, hdiv);
             }
-            const uint8_t* q = src + ((size_t)sy * p.in_cols + sx) * 3;
-            int c[3];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float v = (float)q[ch] * p.ai_scale[ch];
-                v = v + p.ai_shift[ch];
-                float a = v < 0 ? -v : v;
-                int iv = dm::round_half_even((double)a);
-                c[ch] = min(max(iv, 0), 255);
-            }
-            int bits = hsv_bits(c[0], c[1], c[2], p, sdiv, hdiv);
-            packed = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)bits << 24);
+            uint32_t* t = tile + ty * tw + r + 4 * cg;
+            t[0] = o[0]; t[1] = o[1]; t[2] = o[2]; t[3] = o[3];
         }
-        tile[idx] = packed;
+        // halo columns (2*r per row): single pixels
+        for (int i = threadIdx.x; i < th * 2 * r; i += PRE_THREADS) {
+            const int ty = i / (2 * r), j = i - ty * (2 * r);
+            const int tx = j < r ? j : TW + j;                       // left r columns, right r columns
+            const int gx = x0 + tx - r, gy = y0 + ty - r;
+            uint32_t packed = 0;
+            if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
+                const uint8_t* q = src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3;
+                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv);
+            }
+            tile[ty * tw + tx] = packed;
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < tw * th; idx += PRE_THREADS) {
+            int ty = idx / tw, tx = idx - ty * tw;
+            int gx = x0 + tx - r, gy = y0 + ty - r;
+            uint32_t packed = 0;
+            if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
+                int yy = gy + p.top_cutoff;
+                int sy = yy, sx = gx;
+                if (p.resize) {
+                    sy = min(dm::ifloor(yy * p.ify), p.in_rows - 1);
+                    sx = min(dm::ifloor(gx * p.ifx), p.in_cols - 1);
+                }
+                const uint8_t* q = src + ((size_t)sy * p.in_cols + sx) * 3;
+                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv);
+            }
+            tile[idx] = packed;
+        }
     }
     __syncthreads();
 
-    const int lx = (threadIdx.x & 31) * 4, ly = threadIdx.x >> 5;
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx >= p.W || gy >= p.Hc) return;
-    uint32_t px[4];
-    uint32_t m[3] = {0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        px[k] = tile[(ly + r) * tw + lx + r + k];
-        uint32_t bits = 0;
-        for (int i = 0; i < p.ksize; ++i)
-            for (int j = p.j1[i]; j < p.j2[i]; ++j)
-                bits |= tile[(ly + i) * tw + lx + k + j] >> 24;
-        m[0] |= ((bits & 1u) ? 0xFFu : 0u) << (8 * k);
-        m[1] |= ((bits & 2u) ? 0xFFu : 0u) << (8 * k);
-        m[2] |= ((bits & 4u) ? 0xFFu : 0u) << (8 * k);
-    }
-    // 4 pixels = 12 bytes of BGR -> 3 dwords
-    uint32_t w0 = (px[0] & 0xFFFFFFu) | (px[1] << 24);
-    uint32_t w1 = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
-    uint32_t w2 = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
     const size_t P = (size_t)p.Hc * p.W;
-    const size_t pix = (size_t)gy * p.W + gx;
-    uint32_t* bo = reinterpret_cast<uint32_t*>(bgr_out + ((size_t)f * P + pix) * 3);
-    bo[0] = w0; bo[1] = w1; bo[2] = w2;
-    uint8_t* mo = masks + (size_t)f * 3 * P + pix;
-    *reinterpret_cast<uint32_t*>(mo) = m[0];
-    *reinterpret_cast<uint32_t*>(mo + P) = m[1];
-    *reinterpret_cast<uint32_t*>(mo + 2 * P) = m[2];
+    const int Ww = (p.W + 31) >> 5;
+    const int sub = threadIdx.x & 7;
+    // phase 2: TH rows x 32 groups; every lane of a wave takes part in the shuffles
+    for (int g = threadIdx.x; g < ((TH * (TW / 4) + PRE_THREADS - 1) / PRE_THREADS) * PRE_THREADS; g += PRE_THREADS) {
+        const int ly = g / (TW / 4), lx = (g - ly * (TW / 4)) * 4;
+        const int gx = x0 + lx, gy = y0 + ly;
+        const bool valid = ly < TH && gx < p.W && gy < p.Hc;
+        uint32_t px[4] = {0, 0, 0, 0};
+        uint32_t m[3] = {0, 0, 0};
+        uint32_t nib[3] = {0, 0, 0};
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                px[k] = tile[(ly + r) * tw + lx + r + k];
+                uint32_t bits = 0;
+                if (p.ksize == 3) {
+                    // 3x3 MORPH_ELLIPSE is the plus shape
+                    const uint32_t* c = tile + (ly + 1) * tw + lx + 1 + k;
+                    bits = (c[0] | c[-1] | c[1] | c[-tw] | c[tw]) >> 24;
+                } else {
+                    for (int i = 0; i < p.ksize; ++i)
+                        for (int j = p.j1[i]; j < p.j2[i]; ++j)
+                            bits |= tile[(ly + i) * tw + lx + k + j] >> 24;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t on = (bits >> c) & 1u;
+                    m[c] |= (on ? 0xFFu : 0u) << (8 * k);
+                    nib[c] |= on << k;
+                }
+            }
+        }
+        // bit-plane copy of the dilated masks (1 bit / pixel): 8 lanes x 4 pixels = one 32-pixel word
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t w = nib[c] << (4 * sub);
+            w |= __shfl_xor(w, 1);
+            w |= __shfl_xor(w, 2);
+            w |= __shfl_xor(w, 4);
+            nib[c] = w;
+        }
+        if (!valid) continue;
+        if (sub == 0) {
+            uint32_t* mb = maskbits + ((size_t)f * 3 * p.Hc + gy) * Ww + (gx >> 5);
+            mb[0] = nib[0];
+            mb[(size_t)p.Hc * Ww] = nib[1];
+            mb[(size_t)2 * p.Hc * Ww] = nib[2];
+        }
+        // corrected working image as BGRX dwords: one 16-byte store for the lane's 4 pixels
+        const size_t pix = (size_t)gy * p.W + gx;
+        *reinterpret_cast<uint4*>(bgrx_out + (size_t)f * P + pix) =
+            make_uint4(px[0] & 0xFFFFFFu, px[1] & 0xFFFFFFu, px[2] & 0xFFFFFFu, px[3] & 0xFFFFFFu);
+        uint8_t* mo = masks + (size_t)f * 3 * P + pix;
+        *reinterpret_cast<uint32_t*>(mo) = m[0];
+        *reinterpret_cast<uint32_t*>(mo + P) = m[1];
+        *reinterpret_cast<uint32_t*>(mo + 2 * P) = m[2];
+    }
 }
 
-void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint8_t* bgr, uint8_t* masks,
-                const int* sdiv, const int* hdiv, hipStream_t s)
+void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* masks,
+                uint32_t* maskbits, const int* sdiv, const int* hdiv, hipStream_t s)
 {
     dim3 grid((p.W + TW - 1) / TW, (p.Hc + TH - 1) / TH, n_frames);
-    hipLaunchKernelGGL(k_pre, grid, dim3(PRE_THREADS), 0, s, p, frames, bgr, masks, sdiv, hdiv);
+    hipLaunchKernelGGL(k_pre, grid, dim3(PRE_THREADS), 0, s, p, frames, bgr, masks, maskbits, sdiv, hdiv);
 }
 
 }  // namespace lf

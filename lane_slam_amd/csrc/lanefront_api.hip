@@ -40,15 +40,18 @@ struct lf_handle {
     ResizeTables rt;
     int max_nsx = 0, max_nsy = 0;
     // device buffers
-    uint8_t *d_frames = nullptr, *d_bgr = nullptr, *d_masks = nullptr, *d_edges_u8 = nullptr;
-    uint32_t *d_strong = nullptr, *d_weak = nullptr;
+    uint8_t *d_frames = nullptr, *d_masks = nullptr, *d_edges_u8 = nullptr;
+    uint32_t* d_bgr = nullptr;          // corrected working image, BGRX dword per pixel
+    DevBuf dbg_bgr;
+    uint32_t *d_strong = nullptr, *d_weak = nullptr, *d_maskbits = nullptr;
     int *d_sdiv = nullptr, *d_hdiv = nullptr;
     float* d_ang = nullptr;
     double *d_mod = nullptr, *d_cs = nullptr, *d_sn = nullptr;
-    float2* d_seedcs = nullptr;
     unsigned long long* d_maxgrad = nullptr;
     uint32_t *d_order_a = nullptr, *d_order_b = nullptr, *d_reg = nullptr;
     uint2* d_deflist = nullptr;
+    uint32_t* d_tile_list = nullptr;
+    int* d_tile_count = nullptr;
     int* d_row_start = nullptr;
     int *d_norder = nullptr, *d_counts = nullptr, *d_seg_offset = nullptr, *d_frame_offset = nullptr, *d_overflow = nullptr;
     float* d_slot_lines = nullptr;
@@ -157,7 +160,7 @@ static int build_params(lf_handle* h)
                      c.img_cols, c.top_cutoff);
         return LF_ERR_BAD_ARG;
     }
-    if (h->W % 4 != 0) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols must be a multiple of 4 (got %d)", h->W); return LF_ERR_UNSUPPORTED; }
+    if (h->W % 32 != 0) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols must be a multiple of 32 (got %d)", h->W); return LF_ERR_UNSUPPORTED; }
     h->P = (size_t)h->Hc * h->W;
     h->Ww = (h->W + 31) / 32;
     // ---- pre
@@ -168,7 +171,8 @@ static int build_params(lf_handle* h)
     p.resize = (c.img_rows != c.in_rows) || (c.img_cols != c.in_cols);
     const double fx = (double)c.img_cols / (double)c.in_cols, fy = (double)c.img_rows / (double)c.in_rows;
     p.ifx = 1.0 / fx; p.ify = 1.0 / fy;
-    for (int i = 0; i < 3; ++i) { p.ai_scale[i] = c.ai_scale[i]; p.ai_shift[i] = c.ai_shift[i]; }
+    p.identity_ai = 1;
+    for (int i = 0; i < 3; ++i) { p.ai_scale[i] = c.ai_scale[i]; p.ai_shift[i] = c.ai_shift[i]; if (c.ai_scale[i] != 1.f || c.ai_shift[i] != 0.f) p.identity_ai = 0; }
     for (int k = 0; k < 4; ++k) for (int ch = 0; ch < 3; ++ch) { p.lo[k][ch] = c.hsv_lo[k][ch]; p.hi[k][ch] = c.hsv_hi[k][ch]; }
     p.ksize = c.dilation_kernel_size;
     if (p.ksize < 1 || p.ksize > kMaxKsize) { lf_set_error(h, LF_ERR_UNSUPPORTED, "dilation_kernel_size %d not in [1,%d]", p.ksize, kMaxKsize); return LF_ERR_UNSUPPORTED; }
@@ -340,10 +344,11 @@ static int alloc_buffers(lf_handle* h)
     const size_t in_px = (size_t)h->cfg.in_rows * h->cfg.in_cols;
     const size_t nprob = B * 3;
     const size_t cap = nprob * (size_t)h->cap_lines;
-    if (dalloc(h, &h->d_frames, B * in_px * 3) || dalloc(h, &h->d_bgr, B * P * 3) || dalloc(h, &h->d_masks, nprob * P) ||
-        dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) ||
+    if (dalloc(h, &h->d_frames, B * in_px * 3) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_masks, nprob * P) ||
+        dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) || dalloc(h, &h->d_maskbits, nprob * h->Hc * h->Ww) ||
         dalloc(h, &h->d_ang, nprob * Ps) || dalloc(h, &h->d_mod, nprob * Ps) || dalloc(h, &h->d_cs, nprob * Ps) ||
-        dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_seedcs, nprob * Ps) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
+        dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
+        dalloc(h, &h->d_tile_count, 1) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_deflist, nprob * Ps) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
@@ -374,13 +379,13 @@ extern "C" void lf_destroy(lf_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_sdiv, h->d_hdiv,
-                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_seedcs, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_deflist, h->d_row_start,
+    void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
+                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_deflist, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
                      h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p };
+                     h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     timing_resolve(h);
@@ -447,8 +452,9 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         pp.in_rows = h->Hc; pp.in_cols = h->W; pp.img_rows = h->Hc; pp.img_cols = h->W; pp.top_cutoff = 0;
         pp.resize = 0;
         for (int i = 0; i < 3; ++i) { pp.ai_scale[i] = 1.f; pp.ai_shift[i] = 0.f; }
+        pp.identity_ai = 1;
     }
-    { StageTimer t(h, ST_PRE); launch_pre(pp, d_frames, n, h->d_bgr, h->d_masks, h->d_sdiv, h->d_hdiv, s); }
+    { StageTimer t(h, ST_PRE); launch_pre(pp, d_frames, n, h->d_bgr, h->d_masks, h->d_maskbits, h->d_sdiv, h->d_hdiv, s); }
     { StageTimer t(h, ST_CANNY); launch_canny(h->canny, h->d_bgr, n, h->d_strong, h->d_weak, s); }
     {
         StageTimer t(h, ST_HYST);
@@ -460,11 +466,11 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     {
         StageTimer t(h, ST_LSD_GRAD);
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, (size_t)n * 3 * sizeof(unsigned long long), s));
-        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_masks, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_seedcs,
-                        h->d_maxgrad, h->max_nsx, h->max_nsy, s);
+        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_ang, h->d_mod, h->d_cs, h->d_sn,
+                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
     }
     { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_deflist, h->d_row_start, s); }
-    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_seedcs, h->d_order_a, h->d_norder, h->d_deflist, h->d_row_start, h->d_reg, h->d_slot_lines, h->d_counts, s); }
+    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_order_a, h->d_norder, h->d_deflist, h->d_row_start, h->d_reg, h->d_slot_lines, h->d_counts, s); }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
     return LF_OK;
@@ -722,7 +728,12 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
     const void* src = nullptr;
     size_t avail = 0;
     switch (buffer_id) {
-    case LF_BUF_BGR: src = h->d_bgr; avail = n * h->P * 3; break;
+    case LF_BUF_BGR: {
+        int rc = ensure(h, h->dbg_bgr, n * h->P * 3);
+        if (rc != LF_OK) return rc;
+        launch_bgrx_to_bgr((int)(n * h->P), h->d_bgr, (uint8_t*)h->dbg_bgr.p, s);
+        src = h->dbg_bgr.p; avail = n * h->P * 3; break;
+    }
     case LF_BUF_MASKS: src = h->d_masks; avail = n * 3 * h->P; break;
     case LF_BUF_EDGES:
         launch_edges_u8(h->canny, (int)n, h->d_strong, h->d_edges_u8, s);

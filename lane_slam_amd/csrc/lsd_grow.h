@@ -34,7 +34,6 @@
 #define LFG_DEV static inline
 #define LFG_NL 1
 struct uint2 { unsigned int x, y; };
-struct float2 { float x, y; };
 static inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r; r.x = x; r.y = y; return r; }
 static inline float __uint_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 #endif
@@ -115,7 +114,6 @@ struct Ctx {
     const double* mod;
     const double* cs;      // cos((double)(float)angle_rad), defined pixels only
     const double* sn;
-    const float2* seedcs;  // (float)cos/sin of the unrounded angle: a region's first pixel
     uint32_t* used;        // LDS bitmap, 1 = USED or NOTDEF
     uint32_t* lreg;        // LDS part of the region list
     uint32_t* greg;        // global part (index >= reg_lds)
@@ -193,8 +191,9 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& re
     const int saddr = sx + sy * W;
     reg_set(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
     reg_angle = angle_of(c.ang[saddr]);
-    const float2 sd = c.seedcs[saddr];
-    float sumdx = sd.x, sumdy = sd.y;
+    double s0, c0;
+    dm::dsincos(reg_angle, s0, c0);
+    float sumdx = (float)c0, sumdy = (float)s0;
     used_set(c, saddr);
 #ifndef LF_HOST_SIM
     // Frontier points are taken in list order, 7 at a time: lane = 9*slot + neighbour, so

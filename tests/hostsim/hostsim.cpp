@@ -19,7 +19,6 @@ extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, dou
     const size_t Ps = (size_t)H * W;
     std::vector<float> ang(Ps, grow::NOTDEF_F);
     std::vector<double> mod(Ps, 0.0), cs(Ps, 0.0), sn(Ps, 0.0);
-    std::vector<float2> seedcs(Ps);
     double max_grad = -1;
     for (int y = 0; y < H - 1; ++y)
         for (int x = 0; x < W - 1; ++x) {
@@ -34,9 +33,6 @@ extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, dou
                 ang[a] = av;
                 double arad = (double)av * grow::DEG2RAD;
                 dm::dsincos((double)(float)arad, sn[a], cs[a]);
-                double s0, c0;
-                dm::dsincos(arad, s0, c0);
-                seedcs[a].x = (float)c0; seedcs[a].y = (float)s0;
                 if (norm > max_grad) max_grad = norm;
             }
         }
@@ -63,7 +59,7 @@ extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, dou
     rows[H] = (int)deflist.size();
     grow::Ctx c;
     c.rows = rows.data(); c.ldef = deflist.data(); c.gdef = deflist.data(); c.def_lds = reg_lds;
-    c.W = W; c.H = H; c.ang = ang.data(); c.mod = mod.data(); c.cs = cs.data(); c.sn = sn.data(); c.seedcs = seedcs.data();
+    c.W = W; c.H = H; c.ang = ang.data(); c.mod = mod.data(); c.cs = cs.data(); c.sn = sn.data();
     c.used = used.data(); c.lreg = lreg.data(); c.greg = greg.data(); c.reg_lds = reg_lds;
     c.log_nt = log_nt; c.log_eps = log_eps; c.density_th = density_th; c.prec = prec; c.p = p; c.scale = scale;
     c.min_reg_size = min_reg_size; c.refine = refine;

@@ -258,3 +258,27 @@ def test_full_size_properties():
     idx, dist = fe.associate(seg.code, seg.code)
     assert (dist == 0).all()
     fe.close()
+
+
+def test_anti_instagram_transform_on_device(golden_dir):
+    """a-1 with a non-identity AntiInstagram transform (the fast identity path is skipped):
+    float32 scale/shift + convertScaleAbs rounding must match the oracle, which itself is pinned
+    to the reference's scaleandshift2 by tests/golden/scaleandshift.npz."""
+    import os
+    from oracle.oracle import Oracle
+    g = np.load(os.path.join(golden_dir, "scaleandshift.npz"))
+    frames = synth.make_batch(2, 50)
+    for i in range(1, g["scales"].shape[0]):
+        for geo in ("parity", "fullres"):
+            cfg = default_config(geo)
+            cfg["ai_scale"] = list(g["scales"][i])
+            cfg["ai_shift"] = list(g["shifts"][i])
+            fe = FrontEnd(cfg, max_frames=2, max_lines_per_color=4096)
+            seg = fe.process_batch(frames, describe=False)
+            o = Oracle(cfg)
+            bgr = fe.fetch(_lib.LF_BUF_BGR, 2)
+            for f in range(2):
+                assert np.array_equal(bgr[f], o.preprocess(frames[f])), (i, geo, f)
+                r = o.process_frame(frames[f], cap=3 * 4096, describe=False)
+                assert np.array_equal(seg.frame(f).lines, r["lines"])
+            fe.close()
