@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
     __shared__ double T[128];                     // ordered partial sums of k[j]*255 per 7-bit pattern
     __shared__ unsigned long long rowbits[GT * 2 + 2 * kMaxGaussTaps];
     __shared__ int n_def;
+    __shared__ unsigned long long tile_max;
+    __shared__ int t_xofs[GT + 1], t_y0[GT + 1], t_y1[GT + 1];
+    __shared__ float t_xa[2 * (GT + 1)], t_yb[2 * (GT + 1)];
     const int h = p.half;
     const int n_tiles = *list_count;
     const bool use_table = p.ntaps <= 7;
@@ -157,7 +160,20 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         const int rw = nsx + 2 * h, rh = nsy + 2 * h;
         const uint32_t* mk = mask_bits + (size_t)pc * p.Hc * p.Ww;
         const uint32_t* eb = edge_bits + (size_t)f * p.Hc * p.Ww;
-        if (threadIdx.x == 0) n_def = 0;
+        if (threadIdx.x == 0) { n_def = 0; tile_max = 0ull; }
+        // this tile's slice of the resize tables -> LDS (no dependent global loads in the passes below)
+        if (threadIdx.x < nox) {
+            const int dx = X0 + threadIdx.x;
+            t_xofs[threadIdx.x] = rt.xofs[dx] - sx_lo;
+            t_xa[2 * threadIdx.x] = rt.xa[2 * dx];
+            t_xa[2 * threadIdx.x + 1] = rt.xa[2 * dx + 1];
+        } else if (threadIdx.x >= 64 && threadIdx.x < 64 + noy) {
+            const int oy = threadIdx.x - 64, dy = Y0 + oy;
+            t_y0[oy] = rt.y0[dy] - sy_lo;
+            t_y1[oy] = rt.y1[dy] - sy_lo;
+            t_yb[2 * oy] = rt.yb[2 * dy];
+            t_yb[2 * oy + 1] = rt.yb[2 * dy + 1];
+        }
         // raw rows as bit windows: bit t of rowbits[ty] = edge_color(reflect(sx_lo-h+t), reflect(sy_lo-h+ty))
         const int xs = sx_lo - h;
         const bool interior_x = xs >= 0 && xs + rw <= p.W && rw <= 64;
@@ -190,9 +206,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         // row filter (table lookup; general path for wide kernels or windows > 64 bits)
         if (use_table && rw <= 64) {
             const int msk = (1 << p.ntaps) - 1;
-            for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
-                int ry = idx / nsx, cx = idx - ry * nsx;
-                F[idx] = T[(int)(rowbits[ry] >> cx) & msk];
+            for (int ry = threadIdx.x >> 6; ry < rh; ry += 4) {
+                const unsigned long long rb = rowbits[ry];
+                for (int cx = threadIdx.x & 63; cx < nsx; cx += 64)
+                    F[ry * nsx + cx] = rb ? T[(int)(rb >> cx) & msk] : 0.0;
             }
         } else {
             for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
@@ -210,38 +227,49 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         }
         __syncthreads();
         // column filter
-        for (int idx = threadIdx.x; idx < nsy * nsx; idx += 256) {
-            int by = idx / nsx, cx = idx - by * nsx;
-            const double* S = F + (by + h) * nsx + cx;
-            double s = p.k[h] * S[0] + 0.0;
-            for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
-            Bl[by * nsx + cx] = s;
+        for (int by = threadIdx.x >> 6; by < nsy; by += 4) {
+            for (int cx = threadIdx.x & 63; cx < nsx; cx += 64) {
+                const double* S = F + (by + h) * nsx + cx;
+                // F holds sums of positive constants (or +0.0): an all-zero window gives exactly +0.0
+                unsigned long long nz = __double_as_longlong(S[0]);
+                for (int j = 1; j <= h; ++j) nz |= __double_as_longlong(S[j * nsx]) | __double_as_longlong(S[-j * nsx]);
+                double s = 0.0;
+                if (nz) {
+                    s = p.k[h] * S[0] + 0.0;
+                    for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
+                }
+                Bl[by * nsx + cx] = s;
+            }
         }
         __syncthreads();
         // horizontal resize
-        for (int idx = threadIdx.x; idx < nsy * nox; idx += 256) {
-            int by = idx / nox, ox = idx - by * nox;
-            int dx = X0 + ox;
-            int sx = rt.xofs[dx] - sx_lo;
-            const double* S = Bl + by * nsx;
-            double v;
-            if (dx < rt.xmax) v = S[sx] * (double)rt.xa[2 * dx] + S[sx + 1] * (double)rt.xa[2 * dx + 1];
-            else v = S[sx] * 1.0;
-            Hb[by * (GT + 1) + ox] = v;
+        for (int by = threadIdx.x >> 6; by < nsy; by += 4) {
+            const int ox = threadIdx.x & 63;
+            if (ox < nox) {
+                const int dx = X0 + ox;
+                const int sx = t_xofs[ox];
+                const double* S = Bl + by * nsx;
+                double v;
+                if (dx < rt.xmax) v = S[sx] * (double)t_xa[2 * ox] + S[sx + 1] * (double)t_xa[2 * ox + 1];
+                else v = S[sx] * 1.0;
+                Hb[by * (GT + 1) + ox] = v;
+            }
         }
         __syncthreads();
         // vertical resize
-        for (int idx = threadIdx.x; idx < noy * nox; idx += 256) {
-            int oy = idx / nox, ox = idx - oy * nox;
-            int dy = Y0 + oy;
-            int r0 = rt.y0[dy] - sy_lo, r1 = rt.y1[dy] - sy_lo;
-            Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)rt.yb[2 * dy] + Hb[r1 * (GT + 1) + ox] * (double)rt.yb[2 * dy + 1];
+        for (int oy = threadIdx.x >> 6; oy < noy; oy += 4) {
+            const int ox = threadIdx.x & 63;
+            if (ox < nox) {
+                const int r0 = t_y0[oy], r1 = t_y1[oy];
+                Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)t_yb[2 * oy] + Hb[r1 * (GT + 1) + ox] * (double)t_yb[2 * oy + 1];
+            }
         }
         __syncthreads();
         // gradient + level-line angle; defined pixels are queued for the trigonometry pass
         double local_max = -1.0;
-        for (int idx = threadIdx.x; idx < ox_n * oy_n; idx += 256) {
-            int oy = idx / ox_n, ox = idx - oy * ox_n;
+        for (int oy = threadIdx.x >> 5; oy < oy_n; oy += 8) {
+            const int ox = threadIdx.x & 31;
+            if (ox >= ox_n) continue;
             int dx = X0 + ox, dy = Y0 + oy;
             size_t a = (size_t)dy * p.Ws + dx;
             float av = kNotDef;
@@ -251,19 +279,29 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
                 double DA = q[GT + 2] - q[0];
                 double BC = q[1] - q[GT + 1];
                 double gx = DA + BC, gy = DA - BC;
-                norm = dm::dsqrt((gx * gx + gy * gy) / 4);
-                if (!(norm <= p.rho)) {
-                    av = dm::fast_atan2_deg((float)gx, (float)(-gy));
-                    if (norm > local_max) local_max = norm;
-                    const int slot = atomicAdd(&n_def, 1);
-                    dl[slot] = make_uint2((uint32_t)a, __float_as_uint(av));
+                const double n2 = (gx * gx + gy * gy) / 4;
+                if (n2 != 0.0) {                                   // sqrt(+0) = +0: flat pixels skip the root
+                    norm = dm::dsqrt(n2);
+                    if (!(norm <= p.rho)) {
+                        av = dm::fast_atan2_deg((float)gx, (float)(-gy));
+                        if (norm > local_max) local_max = norm;
+                        const int slot = atomicAdd(&n_def, 1);
+                        dl[slot] = make_uint2((uint32_t)a, __float_as_uint(av));
+                    }
                 }
             }
             o_ang[a] = av;
             o_mod[a] = norm;
         }
-        if (local_max > 0.0) atomicMax(maxgrad + pc, (unsigned long long)__double_as_longlong(local_max));
+        // one global atomic per tile: positive doubles order like their bit patterns
+        {
+            unsigned long long m = local_max > 0.0 ? (unsigned long long)__double_as_longlong(local_max) : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { unsigned long long o = __shfl_xor(m, d); m = o > m ? o : m; }
+            if ((threadIdx.x & 63) == 0 && m) atomicMax(&tile_max, m);
+        }
         __syncthreads();
+        if (threadIdx.x == 0 && tile_max) atomicMax(maxgrad + pc, tile_max);
         // cos/sin of the float-rounded angle (what region growing accumulates), on full waves
         double* o_cs = cs + (size_t)pc * Ps;
         double* o_sn = sn + (size_t)pc * Ps;
@@ -294,7 +332,7 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
     dim3 grid((p.Hs + GT - 1) / GT, n_frames * 3);
     (void)hipMemsetAsync(list_count, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, ang, mod, list, list_count);
-    const int per_cu = (int)((150 * 1024) / (lds + 2048));
+    const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(256), lds, s, p, rt, edge_bits, mask_bits, ang, mod, cs, sn,
                        maxgrad, max_nsx, max_nsy, list, list_count);
