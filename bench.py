@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames per rank (tiled to --batch)")
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
     ap.add_argument("--depth", type=int, default=2, help="independent batches in flight (handles/streams)")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
@@ -66,6 +68,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("LF_SHARED_GPU"):          # dry runs: every rank on device 0
+        local_rank = 0
     if world != args.gpus:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
@@ -75,7 +79,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     B = args.batch
     D = max(1, args.depth)
@@ -136,8 +143,15 @@ def main():
             block[:n, 32] = out["keep"][:n]
             block[:n, 33] = out["color"][:n]
             counts_local[0] = n
-            dist.all_gather_into_tensor(counts_all, counts_local)
-            dist.all_gather_into_tensor(gathered, block)
+            if args.backend == "nccl":           # RCCL over xGMI, device buffers
+                dist.all_gather_into_tensor(counts_all, counts_local)
+                dist.all_gather_into_tensor(gathered, block)
+            else:                                # gloo dry run: stage through the host
+                hc, hb = counts_all.cpu(), gathered.cpu()
+                dist.all_gather_into_tensor(hc, counts_local.cpu())
+                dist.all_gather_into_tensor(hb, block.cpu())
+                counts_all.copy_(hc)
+                gathered.copy_(hb)
             src = gathered.view(world, G, 34)[:, : roll // world, :32]
         else:
             src = out["code"][: roll].view(1, -1, 32)[:, : roll]
@@ -180,7 +194,7 @@ def main():
     for f in fes:
         f.set_profiling(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     def collect():

@@ -282,3 +282,64 @@ def test_anti_instagram_transform_on_device(golden_dir):
                 r = o.process_frame(frames[f], cap=3 * 4096, describe=False)
                 assert np.array_equal(seg.frame(f).lines, r["lines"])
             fe.close()
+
+
+def test_edge_cases_and_errors():
+    from oracle.oracle import Oracle
+    from lane_slam_amd import LanefrontError
+    cfg = default_config("parity")
+    fe = FrontEnd(cfg, max_frames=3, max_lines_per_color=2048)
+    # all-black and all-white frames: no segments, offsets stay zero (cv2 LSD returning None -> [])
+    blank = np.zeros((3, 480, 640, 3), np.uint8)
+    blank[1] = 255
+    seg = fe.process_batch(blank)
+    assert seg.n == 0 and seg.frame_offset.tolist() == [0, 0, 0, 0]
+    # a single frame, then a ragged batch mixing empty and busy frames
+    frames = synth.make_batch(3, 20)
+    frames[1] = 0
+    o = Oracle(cfg)
+    seg = fe.process_batch(frames)
+    for f in range(3):
+        r = o.process_frame(frames[f])
+        assert seg.frame(f).n == r["n"] and np.array_equal(seg.frame(f).lines, r["lines"])
+    assert seg.frame(1).n == 0
+    one = fe.process_batch(frames[2])
+    assert one.n == seg.frame(2).n and np.array_equal(one.code, seg.frame(2).code)
+    # too many frames / too few line slots -> LF_ERR_CAPACITY, never silent truncation
+    with pytest.raises(LanefrontError) as e:
+        fe.process_batch(np.zeros((4, 480, 640, 3), np.uint8))
+    assert e.value.code == -2
+    fe.close()
+    small = FrontEnd(cfg, max_frames=1, max_lines_per_color=2)
+    with pytest.raises(LanefrontError) as e:
+        small.process_batch(frames[0])
+    assert e.value.code == -2 and "max_lines_per_color" in str(e.value)
+    small.close()
+    with pytest.raises(ValueError):
+        FrontEnd(cfg).process_batch(np.zeros((1, 100, 100, 3), np.uint8))
+    # a different camera size feeding the same working geometry (nearest-neighbour resize 2x)
+    cfg2 = default_config("parity")
+    cfg2["in_size"] = [240, 320]
+    fe2 = FrontEnd(cfg2, max_frames=2, max_lines_per_color=2048)
+    fr2 = np.ascontiguousarray(synth.make_batch(2, 30)[:, ::2, ::2])
+    s2 = fe2.process_batch(fr2)
+    o2 = Oracle(cfg2)
+    for f in range(2):
+        r = o2.process_frame(fr2[f])
+        assert np.array_equal(s2.frame(f).lines, r["lines"]) and np.array_equal(s2.frame(f).ground, r["ground"])
+    fe2.close()
+
+
+def test_plugin_handles_changing_image_size():
+    from oracle.oracle import Oracle
+    det = LineDetectorHIP(dict(DEFAULT_DETECTOR_CONFIGURATION))
+    for geo in ("parity", "fullres", "parity"):
+        cfg = default_config(geo)
+        o = Oracle(cfg)
+        work = o.preprocess(synth.make_frame(3))
+        det.setImage(work)
+        d = det.detectLines("yellow")
+        bw = o.color_masks(o.bgr2hsv(work))
+        area = o.dilate(bw[1])
+        ol, on, oc = o.find_normals(area, o.lsd(area & o.canny(work)))
+        assert np.array_equal(d.lines, ol) and np.array_equal(d.normals, on)
