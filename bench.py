@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
-    ap.add_argument("--depth", type=int, default=2, help="independent batches in flight (handles/streams)")
+    ap.add_argument("--depth", type=int, default=3, help="independent batches in flight (handles/streams)")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     args = ap.parse_args()

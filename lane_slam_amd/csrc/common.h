@@ -95,10 +95,11 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
                      hipStream_t s);
 void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
                       const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
-                      uint2* deflist, int* row_start, hipStream_t s);
-void launch_lsd_grow(const LsdParams& p, int n_frames, const float* ang, const double* mod, const double* cs,
-                     const double* sn, const uint32_t* order, const int* norder, const uint2* deflist,
-                     const int* row_start, uint32_t* reg, float* lines, int* counts, hipStream_t s);
+                      const double* cs, const double* sn, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs,
+                      double* c_sn, int* row_start, hipStream_t s);
+void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
+                     const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
+                     const int* row_start, uint32_t* reg, uint32_t* gused, float* lines, int* counts, hipStream_t s);
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,

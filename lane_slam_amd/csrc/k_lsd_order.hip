@@ -6,12 +6,13 @@
 // so only defined pixels are listed.
 //
 // Integer work, exact: (1) stable raster-order compaction of defined pixels into
-// items = (1023-bin) << 20 | address, (2) a stable LSD radix sort on the 10-bit key, three
+// items = (1023-bin) << 20 | compact index, (2) a stable LSD radix sort on the 10-bit key, three
 // 4-bit passes.  Each lane owns a contiguous run of items, per-lane bucket counters live in
 // a [16][512] LDS matrix, and one wave scans each bucket row, so no atomics are needed and
-// the order is deterministic.  The compaction also leaves, per problem, the raster-ordered list
-// of defined pixels with their angles and the first entry of every row: k_lsd_grow's NFA
-// rectangle counts walk these row lists instead of the (96 % undefined) angle plane.
+// the order is deterministic.  The compaction also gathers every defined pixel's coordinates,
+// angle, magnitude and cos/sin into COMPACT arrays (raster order) plus the first entry of every
+// row: k_lsd_grow works entirely in that index space (a few hundred KB per problem, cache
+// resident) and never touches the 96 %-undefined dense planes.
 #include "common.h"
 
 namespace lf {
@@ -70,7 +71,10 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
                                                   const double* __restrict__ mod,
                                                   const unsigned long long* __restrict__ maxgrad,
                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b,
-                                                  int* __restrict__ norder, uint2* __restrict__ deflist,
+                                                  int* __restrict__ norder, const double* __restrict__ cs,
+                                                  const double* __restrict__ sn, uint32_t* __restrict__ c_xy,
+                                                  float* __restrict__ c_deg, double* __restrict__ c_mod,
+                                                  double* __restrict__ c_cs, double* __restrict__ c_sn,
                                                   int* __restrict__ row_start)
 {
     __shared__ uint32_t cnt[NB * OT];
@@ -83,31 +87,55 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
     const double* m = mod + (size_t)pc * Ps;
     uint32_t* A = order_a + (size_t)pc * Ps;
     uint32_t* B = order_b + (size_t)pc * Ps;
-    uint2* DL = deflist + (size_t)pc * Ps;                 // raster-ordered (y<<16|x, angle bits) of defined pixels
+    // compact per-pixel arrays, indexed by e = raster rank among the problem's defined pixels
+    uint32_t* CXY = c_xy + (size_t)pc * Ps;
+    float* CDEG = c_deg + (size_t)pc * Ps;
+    double* CMOD = c_mod + (size_t)pc * Ps;
+    double* CCS = c_cs + (size_t)pc * Ps;
+    double* CSN = c_sn + (size_t)pc * Ps;
+    const double* csd = cs + (size_t)pc * Ps;
+    const double* snd = sn + (size_t)pc * Ps;
     int* RS = row_start + (size_t)pc * (p.Hs + 1);         // first list entry of every scaled-image row
     const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
     const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
     int running = 0;
-    for (size_t c0 = 0; c0 < Ps; c0 += OT) {
-        size_t i = c0 + t;
-        bool def = i < Ps && a[i] != kNotDef;
-        unsigned long long bal = __ballot(def);
-        int pre = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(bal);
+    // stable raster-order compaction, 4 pixels per lane per sweep (one 16-byte load of the angle plane)
+    const bool vec = (Ps & 3) == 0;
+    const size_t step = vec ? (size_t)OT * 4 : (size_t)OT;
+    for (size_t c0 = 0; c0 < Ps; c0 += step) {
+        float av[4] = {kNotDef, kNotDef, kNotDef, kNotDef};
+        const size_t i0 = vec ? c0 + (size_t)t * 4 : c0 + t;
+        if (vec) {
+            if (i0 < Ps) { const float4 q = *reinterpret_cast<const float4*>(a + i0); av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w; }
+        } else if (i0 < Ps) av[0] = a[i0];
+        const int npx = vec ? 4 : 1;
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) cnt += (k < npx && av[k] != kNotDef) ? 1 : 0;
+        const int inc = wave_incl_scan(cnt, lane);
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        int off = running;
-        int total = 0;
-        for (int w = 0; w < OT / 64; ++w) { int s = wsum[w]; if (w < wave) off += s; total += s; }
-        if (i < Ps) {
+        int off = running, total = 0;
+        for (int w = 0; w < OT / 64; ++w) { int s_ = wsum[w]; if (w < wave) off += s_; total += s_; }
+        int e = off + inc - cnt;                           // entries before this lane's first pixel
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = i0 + k;
+            if (k >= npx || i >= Ps) continue;
             const int y = (int)(i / p.Ws), x = (int)(i - (size_t)y * p.Ws);
-            if (x == 0) RS[y] = off + pre;
-            if (def) {
+            if (x == 0) RS[y] = e;
+            if (av[k] != kNotDef) {
                 int bin = (int)(m[i] * bin_coef);
                 uint32_t key = (uint32_t)((p.n_bins - 1) - bin);
-                B[off + pre] = (key << 20) | (uint32_t)i;
-                DL[off + pre] = make_uint2(((uint32_t)y << 16) | (uint32_t)x, __float_as_uint(a[i]));
+                B[e] = (key << 20) | (uint32_t)e;        // seeds carry the compact index
+                CXY[e] = ((uint32_t)y << 16) | (uint32_t)x;
+                CDEG[e] = av[k];
+                CMOD[e] = m[i];
+                CCS[e] = csd[i];
+                CSN[e] = snd[i];
+                ++e;
             }
         }
         running += total;
@@ -123,10 +151,11 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const float* __re
 
 void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
                       const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
-                      uint2* deflist, int* row_start, hipStream_t s)
+                      const double* cs, const double* sn, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs,
+                      double* c_sn, int* row_start, hipStream_t s)
 {
     hipLaunchKernelGGL(k_lsd_order, dim3(n_frames * 3), dim3(OT), 0, s, p, ang, mod, maxgrad, order_a, order_b,
-                       norder, deflist, row_start);
+                       norder, cs, sn, c_xy, c_deg, c_mod, c_cs, c_sn, row_start);
 }
 
 }  // namespace lf

@@ -49,7 +49,9 @@ struct lf_handle {
     double *d_mod = nullptr, *d_cs = nullptr, *d_sn = nullptr;
     unsigned long long* d_maxgrad = nullptr;
     uint32_t *d_order_a = nullptr, *d_order_b = nullptr, *d_reg = nullptr;
-    uint2* d_deflist = nullptr;
+    uint32_t *d_cxy = nullptr, *d_gused = nullptr;
+    float* d_cdeg = nullptr;
+    double *d_cmod = nullptr, *d_ccs = nullptr, *d_csn = nullptr;
     uint32_t* d_tile_list = nullptr;
     int* d_tile_count = nullptr;
     int* d_row_start = nullptr;
@@ -349,7 +351,8 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_ang, nprob * Ps) || dalloc(h, &h->d_mod, nprob * Ps) || dalloc(h, &h->d_cs, nprob * Ps) ||
         dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
         dalloc(h, &h->d_tile_count, 1) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
-        dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_deflist, nprob * Ps) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
+        dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
+        dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
         dalloc(h, &h->d_dx, B * P) || dalloc(h, &h->d_dy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
@@ -380,7 +383,7 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
-                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_deflist, h->d_row_start, h->d_tile_list, h->d_tile_count,
+                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
                      h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
@@ -466,8 +469,8 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_ang, h->d_mod, h->d_cs, h->d_sn,
                         h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
     }
-    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_deflist, h->d_row_start, s); }
-    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_order_a, h->d_norder, h->d_deflist, h->d_row_start, h->d_reg, h->d_slot_lines, h->d_counts, s); }
+    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_cs, h->d_sn, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s); }
+    { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, h->d_reg, h->d_gused, h->d_slot_lines, h->d_counts, s); }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
     return LF_OK;

@@ -16,7 +16,9 @@
 //     round trip and accumulate in region order from lane registers;
 //   * min/max extents, USED-flag resets and the rectangle pixel counts of the NFA test are
 //     integer / min-max reductions across lanes (exact, order free).
-// The USED bitmap (USED or NOTDEF = 1) and the first REG_LDS region points live in LDS.
+// Per-pixel data are addressed by COMPACT index (raster rank among defined pixels); LDS holds
+// the row starts, the sorted x lists, one USED bit per defined pixel and the head of the region list
+// (~20 KB for a 512x256 problem), so many problems are resident per CU.
 //
 // The same source compiles for the host (LF_HOST_SIM, one lane) so the control flow can be
 // checked against the oracle without a GPU (tests/hostsim); that build is a test harness,
@@ -33,9 +35,6 @@
 #include <string.h>
 #define LFG_DEV static inline
 #define LFG_NL 1
-struct uint2 { unsigned int x, y; };
-static inline uint2 make_uint2(unsigned int x, unsigned int y) { uint2 r; r.x = x; r.y = y; return r; }
-static inline float __uint_as_float(unsigned int u) { return __builtin_bit_cast(float, u); }
 #endif
 
 namespace lf {
@@ -108,21 +107,24 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 #define LFG_T1(c, k)
 #endif
 
+// All per-pixel data live in COMPACT arrays indexed by e = raster rank among the problem's
+// defined pixels (written by k_lsd_order); the dense scaled-image planes are never touched here.
 struct Ctx {
     int W, H;
-    const float* ang;      // degrees, NOTDEF_F where undefined
-    const double* mod;
-    const double* cs;      // cos((double)(float)angle_rad), defined pixels only
-    const double* sn;
-    uint32_t* used;        // LDS bitmap, 1 = USED or NOTDEF
-    uint32_t* lreg;        // LDS part of the region list
-    uint32_t* greg;        // global part (index >= reg_lds)
-    int reg_lds;
-    // raster-ordered defined pixels: entry = (y<<16|x, angle bits); rows[y]..rows[y+1] = row y
-    const int* rows;       // LDS, H+1 entries
-    const uint2* ldef;     // LDS part of the list
-    const uint2* gdef;     // global list (whole)
+    const int* rows;          // LDS  [H+1]  first entry of each row; rows[H] = number of defined pixels
+    const uint16_t* lxs;      // LDS  x coordinate of entries e < def_lds (sorted inside a row)
+    const uint32_t* gxy;      // HBM  y<<16|x of every entry
     int def_lds;
+    const float* deg;         // HBM  level-line angle, degrees (OpenCV fastAtan2 output)
+    const double* mod;        // HBM  gradient magnitude
+    const double* cs;         // HBM  cos((double)(float)angle_rad)
+    const double* sn;
+    uint32_t* usedc;          // LDS  USED bit per entry e < used_lds
+    uint32_t* gused;          // HBM  USED bits of the remaining entries
+    int used_lds;
+    uint32_t* lreg;           // LDS  region list (y<<16|x), first reg_lds points
+    uint32_t* greg;           // HBM  rest of the region list
+    int reg_lds;
     double log_nt, log_eps, density_th, prec, p, scale;
     int min_reg_size, refine;
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
@@ -130,20 +132,44 @@ struct Ctx {
 #endif
 };
 
-LFG_DEV uint32_t reg_get(const Ctx& c, int i) { return i < c.reg_lds ? c.lreg[i] : c.greg[i]; }
-LFG_DEV uint32_t reg_get_lane(const Ctx& c, int i) { return i < c.reg_lds ? c.lreg[i] : c.greg[i]; }   // per-lane index
+LFG_DEV uint32_t reg_get(const Ctx& c, int i) { return i < c.reg_lds ? c.lreg[i] : c.greg[i]; }   // any lane, any index
 LFG_DEV void reg_set(const Ctx& c, int i, uint32_t v)
 {
     if (lane_id() == 0) { if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v; }
 }
-LFG_DEV bool used_get(const Ctx& c, int addr) { return (c.used[addr >> 5] >> (addr & 31)) & 1u; }
+LFG_DEV int xs_get(const Ctx& c, int e) { return e < c.def_lds ? (int)c.lxs[e] : (int)(c.gxy[e] & 0xffffu); }
+
+// entry of pixel (x, y), or -1 when its gradient is undefined: binary search in row y's sorted list
+LFG_DEV int find_e(const Ctx& c, int x, int y)
+{
+    int lo = c.rows[y];
+    const int end = c.rows[y + 1];
+    int hi = end;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (xs_get(c, mid) < x) lo = mid + 1; else hi = mid;
+    }
+    return (lo < end && xs_get(c, lo) == x) ? lo : -1;
+}
+
+LFG_DEV bool used_get(const Ctx& c, int e)
+{
+    const uint32_t w = e < c.used_lds ? c.usedc[e >> 5] : c.gused[e >> 5];
+    return (w >> (e & 31)) & 1u;
+}
 #ifndef LF_HOST_SIM
-// LDS atomics without return value: no read-modify-write round trip on the sequential path
-LFG_DEV void used_set(const Ctx& c, int addr) { if (lane_id() == 0) atomicOr(&c.used[addr >> 5], 1u << (addr & 31)); }
-LFG_DEV void used_clr(const Ctx& c, int addr) { if (lane_id() == 0) atomicAnd(&c.used[addr >> 5], ~(1u << (addr & 31))); }
+// atomics without return value: no read-modify-write round trip on the sequential path
+LFG_DEV void used_set(const Ctx& c, int e)
+{
+    if (lane_id() == 0) { if (e < c.used_lds) atomicOr(&c.usedc[e >> 5], 1u << (e & 31)); else atomicOr(&c.gused[e >> 5], 1u << (e & 31)); }
+}
+LFG_DEV void used_clr(const Ctx& c, int e)
+{
+    if (lane_id() == 0) { if (e < c.used_lds) atomicAnd(&c.usedc[e >> 5], ~(1u << (e & 31))); else atomicAnd(&c.gused[e >> 5], ~(1u << (e & 31))); }
+}
 #else
-LFG_DEV void used_set(const Ctx& c, int addr) { c.used[addr >> 5] |= 1u << (addr & 31); }
-LFG_DEV void used_clr(const Ctx& c, int addr) { c.used[addr >> 5] &= ~(1u << (addr & 31)); }
+LFG_DEV void used_set(const Ctx& c, int e) { if (e < c.used_lds) c.usedc[e >> 5] |= 1u << (e & 31); else c.gused[e >> 5] |= 1u << (e & 31); }
+LFG_DEV void used_clr(const Ctx& c, int e) { if (e < c.used_lds) c.usedc[e >> 5] &= ~(1u << (e & 31)); else c.gused[e >> 5] &= ~(1u << (e & 31)); }
 #endif
 
 LFG_DEV double angle_of(float deg) { return deg == NOTDEF_F ? NOTDEF_D : (double)deg * DEG2RAD; }
@@ -183,53 +209,54 @@ LFG_DEV bool double_equal(double a, double b)
 }
 
 // ------------------------------------------------------------------ region_grow
-LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& reg_angle, double prec)
+// seed_e: compact entry of the seed pixel (sx, sy)
+LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size, double& reg_angle, double prec)
 {
     const int W = c.W, H = c.H;
     const int lane = lane_id();
     int n = 1;
-    const int saddr = sx + sy * W;
     reg_set(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
-    reg_angle = angle_of(c.ang[saddr]);
+    reg_angle = angle_of(c.deg[seed_e]);
     double s0, c0;
     dm::dsincos(reg_angle, s0, c0);
     float sumdx = (float)c0, sumdy = (float)s0;
-    used_set(c, saddr);
+    used_set(c, seed_e);
 #ifndef LF_HOST_SIM
     // Frontier points are taken in list order, 7 at a time: lane = 9*slot + neighbour, so
     // ascending lane order IS the reference's visiting order (point i, then its 3x3 window in
-    // raster order).  Angles are read only, so all 63 neighbours are fetched in one round
-    // trip.  The reference tests neighbours one by one against the running region angle, which
-    // only changes when a pixel is accepted; so "the next accepted pixel" is the lowest lane
-    // at or after the cursor whose pixel is free and aligned under the CURRENT angle -- one
-    // vector evaluation + ballot per accepted pixel instead of a 9-step scalar chain per point.
+    // raster order).  Each lane locates its neighbour in the row lists (LDS binary search) and
+    // fetches angle / cos / sin from the compact arrays in one round trip.  The reference tests
+    // neighbours one by one against the running region angle, which only changes when a pixel is
+    // accepted; so "the next accepted pixel" is the lowest lane at or after the cursor whose
+    // pixel is free and aligned under the CURRENT angle -- one vector evaluation + ballot per
+    // accepted pixel instead of a 9-step scalar chain per point.
     for (int i = 0; i < n;) {
         const int m = n - i < 7 ? n - i : 7;
         const int slot = lane / 9, k9 = lane - slot * 9;
         const bool lv = slot < m;
-        const uint32_t pkl = lv ? reg_get_lane(c, i + slot) : 0u;
+        const uint32_t pkl = lv ? reg_get(c, i + slot) : 0u;
         const int pxl = (int)(pkl & 0xffffu), pyl = (int)(pkl >> 16);
         const int xx = pxl + (k9 % 3) - 1, yy = pyl + (k9 / 3) - 1;
         const bool inb = lv && xx >= 0 && xx < W && yy >= 0 && yy < H;
-        const int caddr = inb ? yy * W + xx : -1;
-        bool cand = inb && !used_get(c, caddr);          // free (and therefore defined) at batch start
+        const int e = inb ? find_e(c, xx, yy) : -1;
+        bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
         double a = NOTDEF_D, ck = 0.0, sk = 0.0;
-        if (cand) { a = angle_of(c.ang[caddr]); ck = c.cs[caddr]; sk = c.sn[caddr]; }
+        if (cand) { a = (double)c.deg[e] * DEG2RAD; ck = c.cs[e]; sk = c.sn[e]; }
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
             const unsigned long long hit = __ballot(cand && aligned_val(a, reg_angle, prec)) & later;
             if (hit == 0ull) break;
             const int L = __builtin_ctzll(hit);
-            const int ca = rl_i(caddr, L);
+            const int eL = rl_i(e, L);
             const int ay = rl_i(yy, L), ax = rl_i(xx, L);
-            used_set(c, ca);
+            used_set(c, eL);
             reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
             ++n;
             sumdx = (float)((double)sumdx + rl_d(ck, L));
             sumdy = (float)((double)sumdy + rl_d(sk, L));
             reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
-            if (caddr == ca) cand = false;                // the same pixel seen from a later point is now USED
+            if (e == eL) cand = false;                    // the same pixel seen from a later point is now USED
             later = L >= 63 ? 0ull : (~0ull << (L + 1));
             added = true;
         }
@@ -243,15 +270,15 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& re
         for (int k = 0; k < 9; ++k) {
             const int xx = px + (k % 3) - 1, yy = py + (k / 3) - 1;
             if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
-            const int caddr = yy * W + xx;
-            if (used_get(c, caddr)) continue;
-            const double ak = angle_of(c.ang[caddr]);
+            const int e = find_e(c, xx, yy);
+            if (e < 0 || used_get(c, e)) continue;
+            const double ak = (double)c.deg[e] * DEG2RAD;
             if (aligned_val(ak, reg_angle, prec)) {
-                used_set(c, caddr);
+                used_set(c, e);
                 reg_set(c, n, ((uint32_t)yy << 16) | (uint32_t)xx);
                 ++n;
-                sumdx = (float)((double)sumdx + c.cs[caddr]);
-                sumdy = (float)((double)sumdy + c.sn[caddr]);
+                sumdx = (float)((double)sumdx + c.cs[e]);
+                sumdy = (float)((double)sumdy + c.sn[e]);
                 reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
             }
         }
@@ -264,13 +291,12 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int& reg_size, double& re
 LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double prec, double p, Rect& rec)
 {
     const int lane = lane_id();
-    const int W = c.W;
     double x = 0, y = 0, sum = 0;
     for (int base = 0; base < reg_size; base += LFG_NL) {
         const int i = base + lane;
         const bool v = i < reg_size;
         const uint32_t pk = v ? reg_get(c, i) : 0u;
-        const double w = v ? c.mod[(int)(pk >> 16) * W + (int)(pk & 0xffffu)] : 0.0;
+        const double w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
@@ -288,7 +314,7 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
         const int i = base + lane;
         const bool v = i < reg_size;
         const uint32_t pk = v ? reg_get(c, i) : 0u;
-        const double w = v ? c.mod[(int)(pk >> 16) * W + (int)(pk & 0xffffu)] : 0.0;
+        const double w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
@@ -346,7 +372,7 @@ LFG_DEV bool reduce_region_radius(const Ctx& c, int& reg_size, double reg_angle,
             const uint32_t pk = reg_get(c, i);
             const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
             if (dist_sq(xc, yc, (double)px, (double)py) > radSq) {
-                used_clr(c, py * c.W + px);
+                used_clr(c, find_e(c, px, py));
                 const uint32_t last = reg_get(c, reg_size - 1);
                 reg_set(c, i, last);
                 reg_set(c, reg_size - 1, pk);
@@ -365,13 +391,13 @@ LFG_DEV bool reduce_region_radius(const Ctx& c, int& reg_size, double reg_angle,
 LFG_DEV bool refine(const Ctx& c, int& reg_size, double reg_angle, double prec, double p, Rect& rec, double density_th)
 {
     const int lane = lane_id();
-    const int W = c.W;
     double density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density >= density_th) return true;
     const uint32_t p0 = reg_get(c, 0);
     const int x0 = (int)(p0 & 0xffffu), y0 = (int)(p0 >> 16);
     const double xc = (double)x0, yc = (double)y0;
-    const double ang_c = angle_of(c.ang[y0 * W + x0]);
+    const int e0 = find_e(c, x0, y0);
+    const double ang_c = angle_of(c.deg[e0]);
     double sum = 0, s_sum = 0;
     int n = 0;
     for (int base = 0; base < reg_size; base += LFG_NL) {
@@ -379,12 +405,13 @@ LFG_DEV bool refine(const Ctx& c, int& reg_size, double reg_angle, double prec, 
         const bool v = i < reg_size;
         const uint32_t pk = v ? reg_get(c, i) : 0u;
         const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
-        const float af = v ? c.ang[py * W + px] : NOTDEF_F;
+        const int ei = v ? find_e(c, px, py) : 0;
+        const float af = v ? c.deg[ei] : NOTDEF_F;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
             const int qx = (int)(q & 0xffffu), qy = (int)(q >> 16);
-            used_clr(c, qy * W + qx);
+            used_clr(c, rl_i(ei, j));
             if (dist_(xc, yc, (double)qx, (double)qy) < rec.width) {
                 const double angle = angle_of(rl_f(af, j));
                 const double ang_d = angle_diff_signed(angle, ang_c);
@@ -396,7 +423,7 @@ LFG_DEV bool refine(const Ctx& c, int& reg_size, double reg_angle, double prec, 
     }
     const double mean_angle = sum / (double)n;
     const double tau = 2.0 * dm::dsqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-    region_grow(c, x0, y0, reg_size, reg_angle, tau);
+    region_grow(c, x0, y0, e0, reg_size, reg_angle, tau);
     if (reg_size < 2) return false;
     region2rect(c, reg_size, reg_angle, prec, p, rec);
     density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
@@ -537,20 +564,29 @@ LFG_DEV double rect_nfa_g(const Ctx& c, const Rect& rec, bool on)
             const int xb = xr > c.W - 1 ? c.W - 1 : xr;
             if (xb < xa) continue;
             total_pts += xb - xa + 1;
-            const int e0 = c.rows[y], e1 = c.rows[y + 1];
-            for (int k0 = e0; k0 < e1; k0 += 4) {
-                uint2 ent[4];
+            // entries of this row with xa <= x <= xb: lower bound by binary search, then walk
+            int lo = c.rows[y];
+            const int e1 = c.rows[y + 1];
+            {
+                int hi = e1;
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs_get(c, mid) < xa) lo = mid + 1; else hi = mid; }
+            }
+            for (int k0 = lo; k0 < e1; k0 += 4) {
+                int xv[4];
+                float dv[4];
+                bool stop = false;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int idx = k0 + u < e1 ? k0 + u : e1 - 1;
-                    ent[u] = idx < c.def_lds ? c.ldef[idx] : c.gdef[idx];
+                    xv[u] = xs_get(c, idx);
+                    dv[u] = c.deg[idx];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int x = (int)(ent[u].x & 0xffffu);
-                    if (k0 + u < e1 && x >= xa && x <= xb &&
-                        aligned_val((double)__uint_as_float(ent[u].y) * DEG2RAD, rec.theta, rec.prec)) ++alg_pts;
+                    if (k0 + u >= e1 || xv[u] > xb) { stop = true; break; }
+                    if (aligned_val((double)dv[u] * DEG2RAD, rec.theta, rec.prec)) ++alg_pts;
                 }
+                if (stop) break;
             }
         }
     }
@@ -644,22 +680,27 @@ LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 }
 
 // ------------------------------------------------------------------ main loop (flsd)
-// order: sorted seed items ((1023-bin) << 20 | addr); returns the number of lines found
+// order: sorted seed items ((1023-bin) << 20 | compact entry e); returns the number of lines found
 // (may exceed cap; only the first cap are stored).
 LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* lines, int cap)
 {
     int n_lines = 0;
     LFG_T0
-    uint32_t seed_items = 0;
+    uint32_t seed_items = 0, seed_xy = 0;
     for (int i = 0; i < n_order; ++i) {
-        // seeds are fetched 64 at a time (one coalesced load), then visited in order
-        if ((i % LFG_NL) == 0) seed_items = (i + lane_id() < n_order) ? order[i + lane_id()] : 0u;
-        const int adx = (int)((uint32_t)rl_i((int)seed_items, i % LFG_NL) & 0xfffffu);
-        if (used_get(c, adx)) continue;
+        // seeds are fetched 64 at a time (one coalesced load + their coordinates), then visited in order
+        if ((i % LFG_NL) == 0) {
+            const bool v = i + lane_id() < n_order;
+            seed_items = v ? order[i + lane_id()] : 0u;
+            seed_xy = v ? c.gxy[seed_items & 0xfffffu] : 0u;
+        }
+        const int se = (int)((uint32_t)rl_i((int)seed_items, i % LFG_NL) & 0xfffffu);
+        if (used_get(c, se)) continue;
+        const uint32_t sxy = (uint32_t)rl_i((int)seed_xy, i % LFG_NL);
         LFG_T1(c, 0)
         int reg_size;
         double reg_angle;
-        region_grow(c, adx % c.W, adx / c.W, reg_size, reg_angle, c.prec);
+        region_grow(c, (int)(sxy & 0xffffu), (int)(sxy >> 16), se, reg_size, reg_angle, c.prec);
         LFG_T1(c, 1)
         if (reg_size < c.min_reg_size) continue;
         Rect rec;

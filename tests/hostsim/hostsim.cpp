@@ -37,30 +37,37 @@ extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, dou
             }
         }
     const double bin_coef = (max_grad > 0) ? (double)(n_bins - 1) / max_grad : 0;
-    std::vector<uint32_t> order;
-    for (size_t a = 0; a < Ps; ++a)
-        if (ang[a] != grow::NOTDEF_F) {
-            int bin = (int)(mod[a] * bin_coef);
-            order.push_back(((uint32_t)((n_bins - 1) - bin) << 20) | (uint32_t)a);
-        }
-    std::stable_sort(order.begin(), order.end(), [](uint32_t u, uint32_t v) { return (u >> 20) < (v >> 20); });
-    std::vector<uint32_t> used((Ps + 31) / 32, 0u), lreg(reg_lds > 0 ? reg_lds : 1), greg(Ps);
-    for (size_t a = 0; a < Ps; ++a)
-        if (ang[a] == grow::NOTDEF_F) used[a >> 5] |= 1u << (a & 31);
-    std::vector<uint2> deflist;
+    // compact arrays in raster order, as k_lsd_order leaves them
+    std::vector<uint32_t> gxy;
+    std::vector<uint16_t> xs;
+    std::vector<float> deg;
+    std::vector<double> modc, csc, snc;
     std::vector<int> rows(H + 1, 0);
+    std::vector<uint32_t> order;
     for (int y = 0; y < H; ++y) {
-        rows[y] = (int)deflist.size();
+        rows[y] = (int)gxy.size();
         for (int x = 0; x < W; ++x) {
             size_t a = (size_t)y * W + x;
-            if (ang[a] != grow::NOTDEF_F) deflist.push_back(make_uint2(((unsigned)y << 16) | (unsigned)x, __builtin_bit_cast(unsigned, ang[a])));
+            if (ang[a] == grow::NOTDEF_F) continue;
+            int bin = (int)(mod[a] * bin_coef);
+            order.push_back(((uint32_t)((n_bins - 1) - bin) << 20) | (uint32_t)gxy.size());
+            gxy.push_back(((uint32_t)y << 16) | (uint32_t)x);
+            xs.push_back((uint16_t)x);
+            deg.push_back(ang[a]); modc.push_back(mod[a]); csc.push_back(cs[a]); snc.push_back(sn[a]);
         }
     }
-    rows[H] = (int)deflist.size();
+    rows[H] = (int)gxy.size();
+    std::stable_sort(order.begin(), order.end(), [](uint32_t u, uint32_t v) { return (u >> 20) < (v >> 20); });
+    const int n_def = (int)gxy.size();
+    // reg_lds doubles as the split point of every LDS/HBM-backed structure in this harness
+    std::vector<uint32_t> usedc((n_def + 63) / 32 + 1, 0u), gused((n_def + 63) / 32 + 1, 0u);
+    std::vector<uint32_t> lreg(reg_lds > 0 ? reg_lds : 1), greg(Ps);
     grow::Ctx c;
-    c.rows = rows.data(); c.ldef = deflist.data(); c.gdef = deflist.data(); c.def_lds = reg_lds;
-    c.W = W; c.H = H; c.ang = ang.data(); c.mod = mod.data(); c.cs = cs.data(); c.sn = sn.data();
-    c.used = used.data(); c.lreg = lreg.data(); c.greg = greg.data(); c.reg_lds = reg_lds;
+    c.W = W; c.H = H;
+    c.rows = rows.data(); c.lxs = xs.data(); c.gxy = gxy.data(); c.def_lds = reg_lds < n_def ? reg_lds : n_def;
+    c.deg = deg.data(); c.mod = modc.data(); c.cs = csc.data(); c.sn = snc.data();
+    c.usedc = usedc.data(); c.gused = gused.data(); c.used_lds = (reg_lds / 32) * 32;
+    c.lreg = lreg.data(); c.greg = greg.data(); c.reg_lds = reg_lds;
     c.log_nt = log_nt; c.log_eps = log_eps; c.density_th = density_th; c.prec = prec; c.p = p; c.scale = scale;
     c.min_reg_size = min_reg_size; c.refine = refine;
     return grow::detect(c, order.data(), (int)order.size(), lines, cap);

@@ -127,9 +127,10 @@ def test_lsd_gradient_and_order(setup):
             assert np.array_equal(mod[f, c][:-1, :-1], omod[:-1, :-1])
             k = int(norder[f, c])
             assert k == int(defined.sum())
-            got = (order[f, c, :k] & 0xFFFFF).astype(np.int64)
-            want = oorder[defined.ravel()[oorder]]          # the oracle lists every pixel; keep defined ones
-            assert np.array_equal(got, want), (f, c)
+            got = (order[f, c, :k] & 0xFFFFF).astype(np.int64)      # compact index = raster rank among defined pixels
+            want_addr = oorder[defined.ravel()[oorder]]             # the oracle lists every pixel; keep defined ones
+            rank = np.cumsum(defined.ravel()) - 1
+            assert np.array_equal(got, rank[want_addr]), (f, c)
 
 
 def test_segments_match_oracle(setup):
