@@ -60,15 +60,26 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t*
         blur[idx] = (uint8_t)min(max(v, 0), 255);
     }
     __syncthreads();
-    for (int ry = threadIdx.y; ry < LT_H; ry += 4) {
-        int gx = x0 + threadIdx.x, gy = y0 + ry;
+    // two adjacent pixels per lane: 32 lanes cover a 64-pixel row, s16 pairs go out as dwords
+    for (int ry = tid >> 5; ry < LT_H; ry += 8) {
+        const int lx = (tid & 31) * 2;
+        const int gx = x0 + lx, gy = y0 + ry;
         if (gx >= W || gy >= Hc) continue;
-        const uint8_t* c = blur + (ry + 1) * BW_ + threadIdx.x + 1;
-        int vx = (c[-BW_ + 1] - c[-BW_ - 1]) + 2 * (c[1] - c[-1]) + (c[BW_ + 1] - c[BW_ - 1]);
-        int vy = (c[BW_ - 1] - c[-BW_ - 1]) + 2 * (c[BW_] - c[-BW_]) + (c[BW_ + 1] - c[-BW_ + 1]);
-        size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
-        dxo[o] = (int16_t)vx;
-        dyo[o] = (int16_t)vy;
+        int vx[2], vy[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const uint8_t* c = blur + (ry + 1) * BW_ + lx + k + 1;
+            vx[k] = (c[-BW_ + 1] - c[-BW_ - 1]) + 2 * (c[1] - c[-1]) + (c[BW_ + 1] - c[BW_ - 1]);
+            vy[k] = (c[BW_ - 1] - c[-BW_ - 1]) + 2 * (c[BW_] - c[-BW_]) + (c[BW_ + 1] - c[-BW_ + 1]);
+        }
+        const size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
+        if (gx + 1 < W && (W & 1) == 0) {
+            *reinterpret_cast<uint32_t*>(dxo + o) = (uint32_t)(uint16_t)vx[0] | ((uint32_t)(uint16_t)vx[1] << 16);
+            *reinterpret_cast<uint32_t*>(dyo + o) = (uint32_t)(uint16_t)vy[0] | ((uint32_t)(uint16_t)vy[1] << 16);
+        } else {
+            dxo[o] = (int16_t)vx[0]; dyo[o] = (int16_t)vy[0];
+            if (gx + 1 < W) { dxo[o + 1] = (int16_t)vx[1]; dyo[o + 1] = (int16_t)vy[1]; }
+        }
     }
 }
 
@@ -93,9 +104,11 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
     __shared__ float rows[4][LSP_H][4];      // per wave: row sums pgdL, ngdL, pgdO, ngdO (already * coefG)
     __shared__ float dsc[4][72];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int seg = blockIdx.x * 4 + wave;
     const int n_seg = *n_seg_ptr;
-    if (seg >= n_seg) return;                // whole wave exits together
+    // the segment count is only known on the device: a fixed grid of waves strides over the segments
+  for (int seg = blockIdx.x * 4 + wave; seg < n_seg; seg += gridDim.x * 4) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int f = seg_frame[seg];
     const int16_t* pdx = dxi + (size_t)f * Hc * W;
     const int16_t* pdy = dyi + (size_t)f * Hc * W;
@@ -130,19 +143,28 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
         for (int hh = 0; hh < lane; ++hh) { sCorX0 -= dL1; sCorY0 += dL0; }
         float sCorX = sCorX0, sCorY = sCorY0;
         float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
-        for (int w = 0; w < lengthOfLSP; ++w) {
-            int tx = (int)dm::round_half_away((double)sCorX);
-            int xCor = tx < 0 ? 0 : (tx > imageWidth ? imageWidth : tx);
-            int ty = (int)dm::round_half_away((double)sCorY);
-            int yCor = ty < 0 ? 0 : (ty > imageHeight ? imageHeight : ty);
-            int dx = pdx[yCor * W + xCor];
-            int dy = pdy[yCor * W + xCor];
-            float gDL = (float)dx * dL0 + (float)dy * dL1;
-            float gDO = (float)dx * dO0 + (float)dy * dO1;
-            if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
-            if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
-            sCorX += dL0;
-            sCorY += dL1;
+        // coordinates never depend on the gathered data: 4 steps of addresses first, 8 loads in flight
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += 4) {
+            int dxv[4], dyv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int tx = (int)dm::round_half_away((double)sCorX);
+                int xCor = tx < 0 ? 0 : (tx > imageWidth ? imageWidth : tx);
+                int ty = (int)dm::round_half_away((double)sCorY);
+                int yCor = ty < 0 ? 0 : (ty > imageHeight ? imageHeight : ty);
+                dxv[u] = pdx[yCor * W + xCor];
+                dyv[u] = pdy[yCor * W + xCor];
+                sCorX += dL0;
+                sCorY += dL1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (w0 + u >= lengthOfLSP) break;
+                float gDL = (float)dxv[u] * dL0 + (float)dyv[u] * dL1;
+                float gDO = (float)dxv[u] * dO0 + (float)dyv[u] * dO1;
+                if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
+                if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
+            }
         }
         const float cg = gauss_g[lane];
         rows[wave][lane][0] = cg * pgdL;
@@ -227,6 +249,7 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
         for (int i = 0; i < 8; ++i) if (f1[i] > f2[i]) r += 1u << i;
         code[(size_t)seg * 32 + lane] = (uint8_t)r;
     }
+  }
 }
 
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
@@ -234,7 +257,9 @@ void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lin
                 float* desc, uint8_t* code, hipStream_t s)
 {
     if (n_seg_cap <= 0) return;
-    hipLaunchKernelGGL(k_lbd, dim3((n_seg_cap + 3) / 4), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dx, dy,
+    int blocks = (n_seg_cap + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_lbd, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dx, dy,
                        gauss_g, gauss_l, desc, code);
 }
 
