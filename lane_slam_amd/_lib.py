@@ -16,7 +16,7 @@ LF_N_STAGES = 12
 EXPORTS = (
     "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize",
     "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
-    "lf_debug_fetch", "lf_debug_detmath", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
+    "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
 )
 
 
@@ -64,6 +64,8 @@ def load():
     lib.lf_debug_fetch.argtypes = [vp, ci, vp, ctypes.c_size_t]
     lib.lf_debug_detmath.argtypes = [vp, ci, vp, vp, vp, ci]
     lib.lf_debug_detmath.restype = ci
+    lib.lf_debug_lsd_binary.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.lf_debug_lsd_binary.restype = ci
     lib.lf_lsd_size.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.lf_set_profiling.argtypes = [vp, ci]
     lib.lf_get_timing.argtypes = [vp, vp, vp, ci]
@@ -71,7 +73,7 @@ def load():
     lib.lf_stage_name.argtypes = [ci]
     lib.lf_stage_name.restype = ctypes.c_char_p
     for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate",
-              "lf_associate_float", "lf_debug_fetch", "lf_debug_detmath", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",
+              "lf_associate_float", "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",
               "lf_reset_timing"):
         getattr(lib, f).restype = ci
     _lib = lib

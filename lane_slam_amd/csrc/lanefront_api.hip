@@ -711,6 +711,43 @@ extern "C" int lf_associate_float(lf_handle* h, const float* query72, int nq, co
     return LF_OK;
 }
 
+// LSD alone on a caller-supplied binary image (any non-zero byte = edge pixel): the LSD stages
+// of the pipeline (gradient -> order -> grow) with the colour mask forced to all ones.  Test and
+// diagnosis entry; lines are in working-image pixels before normal-based reordering, exactly what
+// cv2's detect() would return for this image under the oracle's restatement.
+extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!img || !lines4 || !n_out || rows != h->Hc || cols != h->W) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_debug_lsd_binary: bad argument (image must be %dx%d)", h->Hc, h->W); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t nw = (size_t)h->Hc * h->Ww;
+    std::vector<uint32_t> bits(nw, 0u), ones(nw * 3, 0xffffffffu);
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x)
+            if (img[(size_t)y * cols + x]) bits[(size_t)y * h->Ww + (x >> 5)] |= 1u << (x & 31);
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->d_strong, bits.data(), nw * 4, hipMemcpyHostToDevice, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->d_maskbits, ones.data(), nw * 12, hipMemcpyHostToDevice, s));
+    LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, 3 * sizeof(unsigned long long), s));
+    launch_lsd_grad(h->lsd, h->rt, 1, h->d_strong, h->d_maskbits, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad,
+                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
+    launch_lsd_order(h->lsd, 1, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_cs, h->d_sn,
+                     h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
+    launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
+                    h->d_reg, h->d_gused, h->d_slot_lines, h->d_counts, s);
+    LF_HIP_CHECK(h, hipGetLastError());
+    int n = 0;
+    LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->d_counts, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    h->last_frames = 1;
+    h->plugin_ready = false;
+    *n_out = n;
+    if (n > h->cap_lines) { lf_set_error(h, LF_ERR_CAPACITY, "LSD found %d lines, max_lines_per_color is %d", n, h->cap_lines); return LF_ERR_CAPACITY; }
+    if (n > cap) { lf_set_error(h, LF_ERR_CAPACITY, "%d lines exceed caller capacity %d", n, cap); return LF_ERR_CAPACITY; }
+    if (n > 0) LF_HIP_CHECK(h, hipMemcpy(lines4, h->d_slot_lines, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return LF_OK;
+}
+
 extern "C" int lf_lsd_size(const lf_handle* h, int* rows, int* cols)
 {
     if (!h || !rows || !cols) return LF_ERR_BAD_ARG;

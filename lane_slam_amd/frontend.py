@@ -197,6 +197,14 @@ class FrontEnd(object):
         self._check(self.lib.lf_debug_fetch(self.h, buffer_id, _ptr(a), a.nbytes))
         return a
 
+    def lsd_binary(self, img, cap=8192):
+        """LSD stages alone on a binary working-size image (tests / diagnosis)."""
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        lines = np.empty((cap, 4), np.float32)
+        n = ctypes.c_int()
+        self._check(self.lib.lf_debug_lsd_binary(self.h, _ptr(img), img.shape[0], img.shape[1], _ptr(lines), cap, ctypes.byref(n)))
+        return lines[:n.value].copy()
+
     def set_profiling(self, on):
         self._check(self.lib.lf_set_profiling(self.h, int(bool(on))))
 

@@ -366,3 +366,39 @@ def test_1080p_geometry_matches_oracle():
         assert np.array_equal(s.lines, r["lines"]) and np.array_equal(s.code, r["code"])
         assert np.array_equal(s.ground, r["ground"]) and np.array_equal(s.keep, r["keep"])
     fe.close()
+
+
+def _clutter(rng, rows, cols, n_strokes, noise):
+    img = np.zeros((rows, cols), np.uint8)
+    for _ in range(n_strokes):
+        y, x = rng.integers(0, rows), rng.integers(0, cols)
+        dy, dx = rng.integers(-rows // 8, rows // 8 + 1), rng.integers(-cols // 5, cols // 5 + 1)
+        for s in np.linspace(0, 1, 4 * max(abs(dy), abs(dx), 1)):
+            yy, xx = int(y + s * dy + rng.normal(0, 0.6)), int(x + s * dx + rng.normal(0, 0.6))
+            if 0 <= yy < rows and 0 <= xx < cols:
+                img[yy, xx] = 255
+    img[rng.random(img.shape) < noise] = 255
+    return img
+
+
+@pytest.mark.parametrize("geo", ["parity", "fullres"])
+def test_lsd_on_clutter_matches_oracle(geo):
+    """Jittered strokes, blobs and salt noise drive regions through refine, reduce_region_radius
+    and every rect_improve stage on the 64-lane code paths (most regions end up rejected)."""
+    from oracle.oracle import Oracle
+    cfg = default_config(geo)
+    o = Oracle(cfg)
+    fe = FrontEnd(cfg, max_frames=1, max_lines_per_color=8192)
+    rng = np.random.default_rng(2026)
+    total = 0
+    for t in range(6):
+        img = _clutter(rng, fe.rows, fe.cols, 30 + 10 * t, 0.01 * (t % 3 + 1))
+        if t == 5:
+            img[:] = (rng.random(img.shape) < 0.3) * 255            # dense noise: huge regions, region-list spill
+        ref = o.lsd(img, cap=8192)
+        got = fe.lsd_binary(img)
+        assert got.shape == ref.shape, (geo, t, got.shape, ref.shape)
+        assert np.array_equal(got, ref), (geo, t)
+        total += len(ref)
+    assert total > 10
+    fe.close()
