@@ -27,58 +27,98 @@ __device__ __forceinline__ int refl101(int p, int n)
     return p;
 }
 
+// Four horizontally adjacent outputs per lane in every phase: the LDS tiles are read as dwords /
+// 16-byte vectors with sliding windows instead of one byte (or int) per tap.
 __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t* __restrict__ bgr,
                                                   int16_t* __restrict__ dxo, int16_t* __restrict__ dyo)
 {
-    constexpr int GW = LT_W + 6, GH = LT_H + 6;     // gray tile
-    constexpr int RW = LT_W + 2;                     // row-filtered: GH rows x RW cols
-    constexpr int BW_ = LT_W + 2, BH = LT_H + 2;     // blurred tile
-    __shared__ uint8_t gray[GH * GW];
-    __shared__ int rowf[GH * RW];
-    __shared__ uint8_t blur[BH * BW_];
+    constexpr int GW = 72, GH = LT_H + 6;            // gray tile: 70 columns used (x0-3 .. x0+66), rows padded to dwords
+    constexpr int RW = 68, RG = RW / 4;              // row-filtered: 66 columns used (x0-1 .. x0+64)
+    constexpr int BW_ = 72, BH = LT_H + 2;           // blurred: column c <-> x0-1+c, 66 used
+    __shared__ __attribute__((aligned(16))) uint8_t gray[GH * GW];
+    __shared__ __attribute__((aligned(16))) int rowf[GH * RW];
+    __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
     const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H, f = blockIdx.z;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint32_t* img = bgr + (size_t)f * Hc * W;
-    for (int idx = tid; idx < GW * GH; idx += 256) {
-        int ty = idx / GW, tx = idx - ty * GW;
-        int gx = refl101(x0 + tx - 3, W), gy = refl101(y0 + ty - 3, Hc);
-        const uint32_t q = img[(size_t)gy * W + gx];
-        gray[idx] = (uint8_t)(((q & 255u) * 1868 + ((q >> 8) & 255u) * 9617 + ((q >> 16) & 255u) * 4899 + (1 << 13)) >> 14);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < GH * RW; idx += 256) {
-        int ty = idx / RW, tx = idx - ty * RW;
-        const uint8_t* s = gray + ty * GW + tx;
-        rowf[idx] = 14 * s[0] + 63 * s[1] + 103 * s[2] + 63 * s[3] + 14 * s[4];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < BH * BW_; idx += 256) {
-        int ty = idx / BW_, tx = idx - ty * BW_;
-        const int* s = rowf + ty * RW + tx;
-        int v = 14 * s[0] + 63 * s[RW] + 103 * s[2 * RW] + 63 * s[3 * RW] + 14 * s[4 * RW];
-        v = (v + (1 << 15)) >> 16;
-        blur[idx] = (uint8_t)min(max(v, 0), 255);
-    }
-    __syncthreads();
-    // two adjacent pixels per lane: 32 lanes cover a 64-pixel row, s16 pairs go out as dwords
-    for (int ry = tid >> 5; ry < LT_H; ry += 8) {
-        const int lx = (tid & 31) * 2;
-        const int gx = x0 + lx, gy = y0 + ry;
-        if (gx >= W || gy >= Hc) continue;
-        int vx[2], vy[2];
+    // gray (BGR2GRAY fixed point), 4 pixels per lane -> one dword store
+    for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
+        const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
+        const int gy = refl101(y0 + ty - 3, Hc);
+        uint32_t packed = 0;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const uint8_t* c = blur + (ry + 1) * BW_ + lx + k + 1;
-            vx[k] = (c[-BW_ + 1] - c[-BW_ - 1]) + 2 * (c[1] - c[-1]) + (c[BW_ + 1] - c[BW_ - 1]);
-            vy[k] = (c[BW_ - 1] - c[-BW_ - 1]) + 2 * (c[BW_] - c[-BW_]) + (c[BW_ + 1] - c[-BW_ + 1]);
+        for (int k = 0; k < 4; ++k) {
+            const int gx = refl101(x0 + 4 * g + k - 3, W);
+            const uint32_t q = img[(size_t)gy * W + gx];
+            const uint32_t v = ((q & 255u) * 1868 + ((q >> 8) & 255u) * 9617 + ((q >> 16) & 255u) * 4899 + (1 << 13)) >> 14;
+            packed |= (v & 255u) << (8 * k);
         }
-        const size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
-        if (gx + 1 < W && (W & 1) == 0) {
-            *reinterpret_cast<uint32_t*>(dxo + o) = (uint32_t)(uint16_t)vx[0] | ((uint32_t)(uint16_t)vx[1] << 16);
-            *reinterpret_cast<uint32_t*>(dyo + o) = (uint32_t)(uint16_t)vy[0] | ((uint32_t)(uint16_t)vy[1] << 16);
-        } else {
-            dxo[o] = (int16_t)vx[0]; dyo[o] = (int16_t)vy[0];
-            if (gx + 1 < W) { dxo[o + 1] = (int16_t)vx[1]; dyo[o + 1] = (int16_t)vy[1]; }
+        *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = packed;
+    }
+    __syncthreads();
+    // horizontal 5-tap {14,63,103,63,14}: outputs c..c+3 (c = 4g) need gray[c .. c+7] = two dwords
+    for (int idx = tid; idx < GH * RG; idx += 256) {
+        const int ty = idx / RG, g = idx - ty * RG;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(gray + ty * GW + 4 * g);
+        const uint32_t lo = src[0], hi = src[1];
+        int b[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { b[k] = (lo >> (8 * k)) & 255; b[4 + k] = (hi >> (8 * k)) & 255; }
+        int* o = rowf + ty * RW + 4 * g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = 14 * b[k] + 63 * b[k + 1] + 103 * b[k + 2] + 63 * b[k + 3] + 14 * b[k + 4];
+    }
+    __syncthreads();
+    // vertical 5-tap, (acc + 2^15) >> 16, saturate -> blurred u8
+    for (int idx = tid; idx < BH * RG; idx += 256) {
+        const int ty = idx / RG, g = idx - ty * RG;
+        const int* s = rowf + ty * RW + 4 * g;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = 14 * s[k] + 63 * s[RW + k] + 103 * s[2 * RW + k] + 63 * s[3 * RW + k] + 14 * s[4 * RW + k];
+        uint32_t q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int t = (v[k] + (1 << 15)) >> 16;
+            // ROCm 7.2 / gfx950: hipcc fuses "shift, clamp to u8, pack two" into v_ashr_pk_u8_i32 and then
+            // ORs further bytes into the result as if its upper 16 bits were zero; on the MI355X they are
+            // not (byte 2 of the packed word came out wrong, found by the parity test).  The empty asm
+            // keeps the shift and the clamp apart so the fused instruction is never selected.
+            asm volatile("" : "+v"(t));
+            t = t < 0 ? 0 : (t > 255 ? 255 : t);
+            q[k] = (uint32_t)t;
+        }
+        *reinterpret_cast<uint32_t*>(blur + ty * BW_ + 4 * g) = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
+    }
+    __syncthreads();
+    // Sobel 3x3 on the blurred tile: 4 outputs per lane from three rows of 6 bytes (two dwords each)
+    {
+        const int ry = tid >> 4, g = tid & 15;         // 16 rows x 16 groups = 256 lanes
+        const int lx = 4 * g, gx = x0 + lx, gy = y0 + ry;
+        if (gx < W && gy < Hc) {
+            int r[3][8];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint32_t* src = reinterpret_cast<const uint32_t*>(blur + (ry + j) * BW_ + lx);   // columns lx .. lx+7 <-> x-1 ..
+                const uint32_t lo = src[0], hi = src[1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { r[j][k] = (lo >> (8 * k)) & 255; r[j][4 + k] = (hi >> (8 * k)) & 255; }
+            }
+            int vx[4], vy[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vx[k] = (r[0][k + 2] - r[0][k]) + 2 * (r[1][k + 2] - r[1][k]) + (r[2][k + 2] - r[2][k]);
+                vy[k] = (r[2][k] - r[0][k]) + 2 * (r[2][k + 1] - r[0][k + 1]) + (r[2][k + 2] - r[0][k + 2]);
+            }
+            const size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
+            if (gx + 3 < W && (W & 3) == 0) {
+                *reinterpret_cast<uint2*>(dxo + o) = make_uint2((uint32_t)(uint16_t)vx[0] | ((uint32_t)(uint16_t)vx[1] << 16),
+                                                                (uint32_t)(uint16_t)vx[2] | ((uint32_t)(uint16_t)vx[3] << 16));
+                *reinterpret_cast<uint2*>(dyo + o) = make_uint2((uint32_t)(uint16_t)vy[0] | ((uint32_t)(uint16_t)vy[1] << 16),
+                                                                (uint32_t)(uint16_t)vy[2] | ((uint32_t)(uint16_t)vy[3] << 16));
+            } else {
+                for (int k = 0; k < 4 && gx + k < W; ++k) { dxo[o + k] = (int16_t)vx[k]; dyo[o + k] = (int16_t)vy[k]; }
+            }
         }
     }
 }

@@ -70,3 +70,24 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liblforacle" not in txt, f
                 assert not [l for l in txt.splitlines() if l.lstrip().startswith("#include") and "oracle" in l], f
+
+
+def test_no_fused_pack_shift_instruction_in_device_code():
+    """ROCm 7.2 hipcc may fuse `(x >> 16)` + clamp-to-u8 + pack into v_ashr_pk_u8_i32 and then treat the
+    upper half of its result as zero, which the MI355X does not honour (wrong byte in k_lbd_grad, found
+    by the GPU parity tests).  The kernels keep the shift and the clamp apart; make sure no translation
+    unit gets the instruction back."""
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "lane_slam_amd", "csrc", "k_lbd.hip")
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "k_lbd.s")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
+                               "--cuda-device-only", "-S", src, "-o", out], stderr=subprocess.DEVNULL)
+        asm = open(out).read()
+    assert "v_ashr_pk_u8_i32" not in asm
+    assert "k_lbd_grad" in asm

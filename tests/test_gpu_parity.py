@@ -402,3 +402,15 @@ def test_lsd_on_clutter_matches_oracle(geo):
         total += len(ref)
     assert total > 10
     fe.close()
+
+
+def test_lbd_gradient_planes(setup):
+    """gray -> 5x5 fixed-point Gaussian -> Sobel (the LBD inputs) must be integer-exact everywhere.
+    (This test caught hipcc's v_ashr_pk_u8_i32 fusion producing a wrong byte on gfx950.)"""
+    geo, cfg, fe, o, frames, seg = setup
+    n = frames.shape[0]
+    dx = fe.fetch(_lib.LF_BUF_LBD_DX, n)
+    dy = fe.fetch(_lib.LF_BUF_LBD_DY, n)
+    for f in range(n):
+        odx, ody = o.sobel3(o.gaussian5(o.bgr2gray(o.preprocess(frames[f]))))
+        assert np.array_equal(dx[f], odx) and np.array_equal(dy[f], ody), f
