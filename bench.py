@@ -34,12 +34,13 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/
 
 
 def stage_bytes(P, Ps, resize):
-    """ALGORITHMIC HBM bytes per frame of each streaming kernel."""
+    """ALGORITHMIC HBM bytes per frame of each streaming kernel.  The LSD stages are
+    not listed: their traffic is proportional to the number of edge pixels (sparse records), they are
+    latency / issue bound and are reported as time only."""
     return {
         "pre(resize+correct+hsv+masks+dilate)": 3 * P + 3 * P + 3 * P + 3 * (P // 8),
         "canny_nms": 3 * P + 2 * (P // 8),
         "canny_hysteresis": 3 * (P // 8),
-        "lsd_blur_resample_grad": 3 * (2 * (P // 8) + 4 * Ps + 8 * Ps),
         "lbd_gray_blur_sobel": 3 * P + 4 * P,
     }
 
@@ -235,7 +236,8 @@ def main():
                 e["GBps"] = round(sb[name] * B / (avg * 1e-3) / 1e9, 1)
             kernels.append(e)
         streaming = [k for k in kernels if "GBps" in k]
-        dom = max(streaming, key=lambda k: k["avg_ms"]) if streaming else None
+        # dominant streaming kernel = the one that has to move the most bytes
+        dom = max(streaming, key=lambda k: k["algorithmic_bytes"]) if streaming else None
         roofline = None
         if dom:
             traffic = None

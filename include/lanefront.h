@@ -161,9 +161,9 @@ typedef enum lf_buffer_id {
     LF_BUF_BGR = 0,          /* u8  [frames][Hc][W][3]   corrected working image          */
     LF_BUF_MASKS = 1,        /* u8  [frames][3][Hc][W]   dilated colour masks 0/255       */
     LF_BUF_EDGES = 2,        /* u8  [frames][Hc][W]      Canny edges 0/255                */
-    LF_BUF_LSD_ANGLE = 3,    /* f32 [frames][3][Hs][Ws]  level-line angle, degrees, NOTDEF = -1024 */
-    LF_BUF_LSD_MODGRAD = 4,  /* f64 [frames][3][Hs][Ws]  gradient magnitude               */
-    LF_BUF_LSD_ORDER = 5,    /* i32 [frames][3][Hs*Ws]   seed order (pixel addresses)     */
+    LF_BUF_LSD_ANGLE = 3,    /* f32 [frames][3][Hs][Ws]  level-line angle, degrees, NOTDEF = -1024 (rebuilt from the compact arrays) */
+    LF_BUF_LSD_MODGRAD = 4,  /* f64 [frames][3][Hs][Ws]  gradient magnitude where defined, 0 elsewhere */
+    LF_BUF_LSD_ORDER = 5,    /* u32 [frames][3][Hs*Ws]   seed order: (n_bins-1-bin) << 20 | compact index */
     LF_BUF_LSD_NORDER = 6,   /* i32 [frames][3]          seeds per run                    */
     LF_BUF_LBD_DX = 7,       /* i16 [frames][Hc][W]                                        */
     LF_BUF_LBD_DY = 8,       /* i16 [frames][Hc][W]                                        */

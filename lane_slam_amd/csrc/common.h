@@ -90,13 +90,16 @@ int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, cons
 void launch_bgrx_to_bgr(int n_pix, const uint32_t* bgrx, uint8_t* bgr, hipStream_t s);
 void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, uint8_t* edges, hipStream_t s);
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
-                     const uint32_t* mask_bits, float* ang, double* mod, double* cs, double* sn,
-                     unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
+                     const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
+                     int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
                      hipStream_t s);
-void launch_lsd_order(const LsdParams& p, int n_frames, const float* ang, const double* mod,
-                      const unsigned long long* maxgrad, uint32_t* order_a, uint32_t* order_b, int* norder,
-                      const double* cs, const double* sn, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs,
-                      double* c_sn, int* row_start, hipStream_t s);
+void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, const float* r_deg, const double* r_mod,
+                      const double* r_cs, const double* r_sn, const int* n_rec, const unsigned long long* maxgrad,
+                      unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b,
+                      int* norder, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs, double* c_sn,
+                      int* row_start, hipStream_t s);
+void launch_lsd_dense_debug(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const float* c_deg,
+                            const double* c_mod, float* ang, double* mod, hipStream_t s);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, uint32_t* reg, uint32_t* gused, float* lines, int* counts, hipStream_t s);

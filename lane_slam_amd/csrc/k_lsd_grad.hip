@@ -8,12 +8,13 @@
 //   cv::resize INTER_LINEAR/f64:  float taps, double accumulation, horizontal then vertical
 //   gradient: gx=(D-A)+(B-C), gy=(D-A)-(B-C), norm=sqrt((gx^2+gy^2)/4), fastAtan2(gx,-gy)
 //
-// One workgroup produces a 32x32 tile of the scaled image.  All intermediates (raw tile with
-// blur halo, row-filtered, blurred, h-resized, v-resized) live in LDS; HBM sees one read of
-// the bit-packed edges and mask (1 bit/pixel each) and one write of angle (f32 degrees), modgrad (f64) and,
-// only where the gradient is defined, cos/sin of the float-rounded angle (f64) that region
-// growing accumulates.  Tiles whose raw footprint holds no edge pixel skip all arithmetic.
-// Algorithmic bytes per scaled pixel: (1/0.64)*(2/8) read + 4 + 8 written.
+// The scaled image is never materialised in HBM, and neither are dense angle / magnitude
+// planes: ~96 % of a colour's LSD image has no gradient at all.  Pass 1 ANDs the two bit planes
+// under every 32x32 tile's footprint and lists the tiles that contain edge pixels (reads
+// 2 bits per working pixel, writes a few KB).  Pass 2 runs the arithmetic for the listed tiles
+// in LDS and appends one RECORD per pixel whose gradient is defined (address, angle, magnitude,
+// cos/sin of the float-rounded angle) to the problem's record list; k_lsd_order sorts the
+// records into raster order.  HBM traffic is proportional to the number of edge pixels.
 #include "common.h"
 
 namespace lf {
@@ -27,16 +28,12 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
-// ---- pass 1: classify tiles from the bit planes (edges & colour mask) and finish the empty ones
-// One workgroup per strip of 32 scaled rows.  (1) every edge-word AND mask-word under the strip's
-// raw footprint is tested once; non-zero words mark their word column in LDS.  (2) a tile is empty
-// iff no marked column lies under its footprint; non-empty tiles go to the work list of pass 2.
-// (3) the strip is streamed out ROW-MAJOR with 16-byte stores -- angle NOTDEF, modgrad 0 -- skipping
-// the 32-pixel segments that belong to listed tiles.  No arithmetic, no LDS tiles: this pass runs at
-// store bandwidth, and most of the image (no edges of that colour) never reaches pass 2.
+// ---- pass 1: list the tiles whose raw footprint contains edge_color pixels ------------------
+// One workgroup per strip of 32 scaled rows: every edge-word AND mask-word under the strip's raw
+// footprint is tested once; non-zero words mark their word column in LDS; a tile is listed iff a
+// marked column lies under its footprint.
 __global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
-                                                     const uint32_t* __restrict__ mask_bits, float* __restrict__ ang,
-                                                     double* __restrict__ mod, uint32_t* __restrict__ list,
+                                                     const uint32_t* __restrict__ mask_bits, uint32_t* __restrict__ list,
                                                      int* __restrict__ list_count)
 {
     __shared__ uint32_t colnz[256];
@@ -72,31 +69,6 @@ __global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables 
             list[slot] = ((uint32_t)pc << 16) | ((uint32_t)ty << 8) | (uint32_t)tx;
         }
     }
-    __syncthreads();
-    const size_t Ps = (size_t)p.Hs * p.Ws;
-    float* o_ang = ang + (size_t)pc * Ps + (size_t)Y0 * p.Ws;
-    double* o_mod = mod + (size_t)pc * Ps + (size_t)Y0 * p.Ws;
-    const int oy_n = min(GT, p.Hs - Y0);
-    if ((p.Ws & 3) == 0) {
-        const int g_row = p.Ws >> 2;                       // 4-pixel groups per row
-        const float4 nd = make_float4(kNotDef, kNotDef, kNotDef, kNotDef);
-        const double2 z2 = make_double2(0.0, 0.0);
-        for (int i = tid; i < oy_n * g_row; i += 256) {
-            const int oy = i / g_row, g = i - oy * g_row;
-            if (tflag[(4 * g) / GT]) continue;
-            const size_t a = (size_t)oy * p.Ws + 4 * g;
-            *reinterpret_cast<float4*>(o_ang + a) = nd;
-            *reinterpret_cast<double2*>(o_mod + a) = z2;
-            *reinterpret_cast<double2*>(o_mod + a + 2) = z2;
-        }
-    } else {
-        for (int i = tid; i < oy_n * p.Ws; i += 256) {
-            const int ox = i % p.Ws;
-            if (tflag[ox / GT]) continue;
-            o_ang[i] = kNotDef;
-            o_mod[i] = 0.0;
-        }
-    }
 }
 
 // ---- pass 2: blur + resample + gradient for the listed tiles (persistent workgroups) ---------
@@ -106,16 +78,17 @@ __global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables 
 // LDS as one 64-bit window per row.  Angles/sines are evaluated after compacting the tile's defined
 // pixels so the expensive double-precision path runs on full waves.
 __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
-                                                  const uint32_t* __restrict__ mask_bits, float* __restrict__ ang,
-                                                  double* __restrict__ mod, double* __restrict__ cs,
-                                                  double* __restrict__ sn, unsigned long long* __restrict__ maxgrad,
+                                                  const uint32_t* __restrict__ mask_bits, uint32_t* __restrict__ r_addr,
+                                                  float* __restrict__ r_deg, double* __restrict__ r_mod,
+                                                  double* __restrict__ r_cs, double* __restrict__ r_sn,
+                                                  int* __restrict__ n_rec, unsigned long long* __restrict__ maxgrad,
                                                   int max_nsx, int max_nsy, const uint32_t* __restrict__ list,
                                                   const int* __restrict__ list_count)
 {
     extern __shared__ double lds_d[];
     __shared__ double T[128];                     // ordered partial sums of k[j]*255 per 7-bit pattern
     __shared__ unsigned long long rowbits[GT * 2 + 2 * kMaxGaussTaps];
-    __shared__ int n_def;
+    __shared__ int n_def, rec_base;
     __shared__ unsigned long long tile_max;
     __shared__ int t_xofs[GT + 1], t_y0[GT + 1], t_y1[GT + 1];
     __shared__ float t_xa[2 * (GT + 1)], t_yb[2 * (GT + 1)];
@@ -136,13 +109,13 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
     const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
     const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
     size_t regA = szF > szHb ? szF : szHb;
-    if (regA < (size_t)GT * GT) regA = (size_t)GT * GT;      // also hosts the defined-pixel list (8 B entries)
-    const size_t regB = szBl > szSc ? szBl : szSc;
+    if (regA < (size_t)2 * GT * GT) regA = (size_t)2 * GT * GT;      // also hosts the defined-pixel list (8 + 8 B entries)
     double* F = lds_d;                                   // [rh][nsx]     row-filtered
     double* Bl = lds_d + regA;                           // [nsy][nsx]    blurred
     double* Hb = lds_d;                                  // [nsy][GT+1]   h-resized   (reuses F)
     double* Sc = lds_d + regA;                           // [GT+1][GT+1]  v-resized   (reuses Bl)
-    uint2* dl = reinterpret_cast<uint2*>(lds_d);         // defined pixels (reuses F/Hb once Sc is built)
+    uint2* dl = reinterpret_cast<uint2*>(lds_d);         // defined pixels (address, angle): reuses F/Hb once Sc is built
+    double* dln = lds_d + (size_t)GT * GT;               // their gradient magnitudes
     const size_t Ps = (size_t)p.Hs * p.Ws;
     const double DEG_TO_RADS = 3.14159265358979323846 / 180;
 
@@ -200,8 +173,6 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
             rowbits[ty] = bits;
         }
         __syncthreads();
-        float* o_ang = ang + (size_t)pc * Ps;
-        double* o_mod = mod + (size_t)pc * Ps;
         const int ox_n = min(GT, p.Ws - X0), oy_n = min(GT, p.Hs - Y0);
         // row filter (table lookup; general path for wide kernels or windows > 64 bits)
         if (use_table && rw <= 64) {
@@ -287,11 +258,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
                         if (norm > local_max) local_max = norm;
                         const int slot = atomicAdd(&n_def, 1);
                         dl[slot] = make_uint2((uint32_t)a, __float_as_uint(av));
+                        dln[slot] = norm;
                     }
                 }
             }
-            o_ang[a] = av;
-            o_mod[a] = norm;
         }
         // one global atomic per tile: positive doubles order like their bit patterns
         {
@@ -301,41 +271,50 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
             if ((threadIdx.x & 63) == 0 && m) atomicMax(&tile_max, m);
         }
         __syncthreads();
-        if (threadIdx.x == 0 && tile_max) atomicMax(maxgrad + pc, tile_max);
-        // cos/sin of the float-rounded angle (what region growing accumulates), on full waves
-        double* o_cs = cs + (size_t)pc * Ps;
-        double* o_sn = sn + (size_t)pc * Ps;
         const int nd = n_def;
+        if (threadIdx.x == 0) {
+            if (tile_max) atomicMax(maxgrad + pc, tile_max);
+            rec_base = nd ? atomicAdd(n_rec + pc, nd) : 0;        // reserve this tile's slots in the problem's record list
+        }
+        __syncthreads();
+        // one record per defined pixel; cos/sin of the float-rounded angle (what region growing
+        // accumulates) evaluated on full waves.  Record order is arbitrary (k_lsd_order sorts by address).
+        const size_t rb = (size_t)pc * Ps + rec_base;
         for (int e = threadIdx.x; e < nd; e += 256) {
             const uint2 it = dl[e];
-            const double arad = (double)__uint_as_float(it.y) * DEG_TO_RADS;
+            const float av = __uint_as_float(it.y);
+            const double arad = (double)av * DEG_TO_RADS;
             double s_, c_;
             dm::dsincos((double)(float)arad, s_, c_);
-            o_cs[it.x] = c_;
-            o_sn[it.x] = s_;
+            r_addr[rb + e] = it.x;
+            r_deg[rb + e] = av;
+            r_mod[rb + e] = dln[e];
+            r_cs[rb + e] = c_;
+            r_sn[rb + e] = s_;
         }
     }
 }
 
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
-                     const uint32_t* mask_bits, float* ang, double* mod, double* cs, double* sn,
-                     unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
+                     const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
+                     int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
                      hipStream_t s)
 {
     const int h = p.half;
     const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
     const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
     size_t regA = szF > szHb ? szF : szHb;
-    if (regA < (size_t)GT * GT) regA = (size_t)GT * GT;
+    if (regA < (size_t)2 * GT * GT) regA = (size_t)2 * GT * GT;
     const size_t regB = szBl > szSc ? szBl : szSc;
     const size_t lds = sizeof(double) * (regA + regB);
     dim3 grid((p.Hs + GT - 1) / GT, n_frames * 3);
     (void)hipMemsetAsync(list_count, 0, sizeof(int), s);
-    hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, ang, mod, list, list_count);
+    (void)hipMemsetAsync(n_rec, 0, (size_t)n_frames * 3 * sizeof(int), s);
+    hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, list, list_count);
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-    hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(256), lds, s, p, rt, edge_bits, mask_bits, ang, mod, cs, sn,
-                       maxgrad, max_nsx, max_nsy, list, list_count);
+    hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(256), lds, s, p, rt, edge_bits, mask_bits, r_addr, r_deg, r_mod, r_cs,
+                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count);
 }
 
 }  // namespace lf

@@ -5,7 +5,7 @@
 //   src/anti_instagram/include/anti_instagram/scale_and_shift.py:25-33
 //   src/line_detector/include/line_detector/line_detector_lsd.py:38-53,138   BGR2HSV, inRange (red = OR), dilate
 //
-// Layout: each workgroup owns a 128x14 tile of the working image (16 rows with the 3x3 halo).  Phase 1 converts the
+// Layout: each workgroup owns a 128x30 tile of the working image (32 rows with the 3x3 halo).  Phase 1 converts the
 // tile plus its dilation halo to packed (b,g,r,maskbits) words in LDS (HSV is computed
 // once per pixel, never written to HBM).  Phase 2: each lane owns 4 adjacent pixels,
 // ORs the structuring element over the LDS mask bits and writes 16 B of corrected BGRX (one dword
@@ -17,7 +17,7 @@
 
 namespace lf {
 
-constexpr int TW = 128, TH = 14, PRE_THREADS = 256;   // (TH + 2) rows x 32 four-pixel groups = 512 = 2 per lane
+constexpr int TW = 128, TH = 30, PRE_THREADS = 256;   // (TH + 2) rows x 32 four-pixel groups = 1024 = 4 per lane
 
 struct PixOut { uint32_t packed; };
 

@@ -45,8 +45,13 @@ struct lf_handle {
     DevBuf dbg_bgr;
     uint32_t *d_strong = nullptr, *d_weak = nullptr, *d_maskbits = nullptr;
     int *d_sdiv = nullptr, *d_hdiv = nullptr;
-    float* d_ang = nullptr;
-    double *d_mod = nullptr, *d_cs = nullptr, *d_sn = nullptr;
+    // unordered per-problem records of defined LSD pixels (k_lsd_grad -> k_lsd_order)
+    uint32_t* d_raddr = nullptr;
+    float* d_rdeg = nullptr;
+    double *d_rmod = nullptr, *d_rcs = nullptr, *d_rsn = nullptr;
+    int* d_nrec = nullptr;
+    unsigned long long *d_sort_a = nullptr, *d_sort_b = nullptr;
+    DevBuf dbg_ang, dbg_mod;
     unsigned long long* d_maxgrad = nullptr;
     uint32_t *d_order_a = nullptr, *d_order_b = nullptr, *d_reg = nullptr;
     uint32_t *d_cxy = nullptr, *d_gused = nullptr;
@@ -348,8 +353,9 @@ static int alloc_buffers(lf_handle* h)
     const size_t cap = nprob * (size_t)h->cap_lines;
     if (dalloc(h, &h->d_frames, B * in_px * 3) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_masks, nprob * P) ||
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) || dalloc(h, &h->d_maskbits, nprob * h->Hc * h->Ww) ||
-        dalloc(h, &h->d_ang, nprob * Ps) || dalloc(h, &h->d_mod, nprob * Ps) || dalloc(h, &h->d_cs, nprob * Ps) ||
-        dalloc(h, &h->d_sn, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
+        dalloc(h, &h->d_raddr, nprob * Ps) || dalloc(h, &h->d_rdeg, nprob * Ps) || dalloc(h, &h->d_rmod, nprob * Ps) ||
+        dalloc(h, &h->d_rcs, nprob * Ps) || dalloc(h, &h->d_rsn, nprob * Ps) || dalloc(h, &h->d_nrec, nprob) ||
+        dalloc(h, &h->d_sort_a, nprob * Ps) || dalloc(h, &h->d_sort_b, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
         dalloc(h, &h->d_tile_count, 1) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
         dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
@@ -383,7 +389,7 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
-                     h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
+                     h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
                      h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
@@ -466,10 +472,10 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     {
         StageTimer t(h, ST_LSD_GRAD);
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, (size_t)n * 3 * sizeof(unsigned long long), s));
-        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_ang, h->d_mod, h->d_cs, h->d_sn,
+        launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec,
                         h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
     }
-    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_cs, h->d_sn, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s); }
+    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s); }
     { StageTimer t(h, ST_LSD_GROW); launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, h->d_reg, h->d_gused, h->d_slot_lines, h->d_counts, s); }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
@@ -729,9 +735,9 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     LF_HIP_CHECK(h, hipMemcpyAsync(h->d_strong, bits.data(), nw * 4, hipMemcpyHostToDevice, s));
     LF_HIP_CHECK(h, hipMemcpyAsync(h->d_maskbits, ones.data(), nw * 12, hipMemcpyHostToDevice, s));
     LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, 3 * sizeof(unsigned long long), s));
-    launch_lsd_grad(h->lsd, h->rt, 1, h->d_strong, h->d_maskbits, h->d_ang, h->d_mod, h->d_cs, h->d_sn, h->d_maxgrad,
+    launch_lsd_grad(h->lsd, h->rt, 1, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad,
                     h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
-    launch_lsd_order(h->lsd, 1, h->d_ang, h->d_mod, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_norder, h->d_cs, h->d_sn,
+    launch_lsd_order(h->lsd, 1, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder,
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_reg, h->d_gused, h->d_slot_lines, h->d_counts, s);
@@ -775,8 +781,17 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
     case LF_BUF_EDGES:
         launch_edges_u8(h->canny, (int)n, h->d_strong, h->d_edges_u8, s);
         src = h->d_edges_u8; avail = n * h->P; break;
-    case LF_BUF_LSD_ANGLE: src = h->d_ang; avail = n * 3 * h->Ps * sizeof(float); break;
-    case LF_BUF_LSD_MODGRAD: src = h->d_mod; avail = n * 3 * h->Ps * sizeof(double); break;
+    case LF_BUF_LSD_ANGLE:
+    case LF_BUF_LSD_MODGRAD: {
+        // the pipeline keeps no dense LSD planes: rebuild them from the compact arrays
+        int rc = ensure(h, h->dbg_ang, n * 3 * h->Ps * sizeof(float));
+        if (rc == LF_OK) rc = ensure(h, h->dbg_mod, n * 3 * h->Ps * sizeof(double));
+        if (rc != LF_OK) return rc;
+        launch_lsd_dense_debug(h->lsd, (int)n, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, (float*)h->dbg_ang.p, (double*)h->dbg_mod.p, s);
+        if (buffer_id == LF_BUF_LSD_ANGLE) { src = h->dbg_ang.p; avail = n * 3 * h->Ps * sizeof(float); }
+        else { src = h->dbg_mod.p; avail = n * 3 * h->Ps * sizeof(double); }
+        break;
+    }
     case LF_BUF_LSD_ORDER: src = h->d_order_a; avail = n * 3 * h->Ps * sizeof(uint32_t); break;
     case LF_BUF_LSD_NORDER: src = h->d_norder; avail = n * 3 * sizeof(int); break;
     case LF_BUF_LBD_DX: src = h->d_dx; avail = n * h->P * sizeof(int16_t); break;
