@@ -59,10 +59,12 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                                                       uint32_t* __restrict__ maskbits, const int* __restrict__ sdiv_g,
                                                       const int* __restrict__ hdiv_g)
 {
-    __shared__ uint32_t tile[(TH + 2 * (kMaxKsize / 2)) * (TW + 2 * (kMaxKsize / 2))];
+    // LDS tile rows: [4 - r pad][r halo][TW interior, 16-byte aligned][r halo][pad]
+    constexpr int tw = TW + 8, XO = 4;
+    __shared__ __attribute__((aligned(16))) uint32_t tile[(TH + 2 * (kMaxKsize / 2)) * tw];
     __shared__ int sdiv[256], hdiv[256];
     const int r = p.r;
-    const int tw = TW + 2 * r, th = TH + 2 * r;
+    const int th = TH + 2 * r;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
     const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
     sdiv[threadIdx.x] = sdiv_g[threadIdx.x];
@@ -85,14 +87,13 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                 o[2] = convert_pixel((d1 >> 16) & 255, d1 >> 24, d2 & 255, p, sdiv, hdiv);
                 o[3] = convert_pixel((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, p, sdiv, hdiv);
             }
-            uint32_t* t = tile + ty * tw + r + 4 * cg;
-            t[0] = o[0]; t[1] = o[1]; t[2] = o[2]; t[3] = o[3];
+            *reinterpret_cast<uint4*>(tile + ty * tw + XO + 4 * cg) = make_uint4(o[0], o[1], o[2], o[3]);
         }
         // halo columns (2*r per row): single pixels
         for (int i = threadIdx.x; i < th * 2 * r; i += PRE_THREADS) {
             const int ty = i / (2 * r), j = i - ty * (2 * r);
-            const int tx = j < r ? j : TW + j;                       // left r columns, right r columns
-            const int gx = x0 + tx - r, gy = y0 + ty - r;
+            const int tx = j < r ? XO - r + j : XO + TW + (j - r);   // left r columns, right r columns
+            const int gx = x0 + tx - XO, gy = y0 + ty - r;
             uint32_t packed = 0;
             if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
                 const uint8_t* q = src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3;
@@ -101,9 +102,10 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
             tile[ty * tw + tx] = packed;
         }
     } else {
-        for (int idx = threadIdx.x; idx < tw * th; idx += PRE_THREADS) {
-            int ty = idx / tw, tx = idx - ty * tw;
-            int gx = x0 + tx - r, gy = y0 + ty - r;
+        const int twr = TW + 2 * r;
+        for (int idx = threadIdx.x; idx < twr * th; idx += PRE_THREADS) {
+            int ty = idx / twr, tx = idx - ty * twr + XO - r;
+            int gx = x0 + tx - XO, gy = y0 + ty - r;
             uint32_t packed = 0;
             if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
                 int yy = gy + p.top_cutoff;
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                 const uint8_t* q = src + ((size_t)sy * p.in_cols + sx) * 3;
                 packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv);
             }
-            tile[idx] = packed;
+            tile[ty * tw + tx] = packed;
         }
     }
     __syncthreads();
@@ -132,18 +134,27 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
         uint32_t m[3] = {0, 0, 0};
         uint32_t nib[3] = {0, 0, 0};
         if (valid) {
+            const uint32_t* ctr = tile + (ly + r) * tw + XO + lx;
+            const uint4 c4 = *reinterpret_cast<const uint4*>(ctr);
+            px[0] = c4.x; px[1] = c4.y; px[2] = c4.z; px[3] = c4.w;
+            uint32_t cross[4] = {0, 0, 0, 0};
+            if (p.ksize == 3) {
+                // 3x3 MORPH_ELLIPSE is the plus shape: five 16-byte / 4-byte LDS reads serve 4 pixels
+                const uint4 up = *reinterpret_cast<const uint4*>(ctr - tw), dn = *reinterpret_cast<const uint4*>(ctr + tw);
+                const uint32_t lft = ctr[-1], rgt = ctr[4];
+                cross[0] = c4.x | lft | c4.y | up.x | dn.x;
+                cross[1] = c4.y | c4.x | c4.z | up.y | dn.y;
+                cross[2] = c4.z | c4.y | c4.w | up.z | dn.z;
+                cross[3] = c4.w | c4.z | rgt | up.w | dn.w;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                px[k] = tile[(ly + r) * tw + lx + r + k];
-                uint32_t bits = 0;
-                if (p.ksize == 3) {
-                    // 3x3 MORPH_ELLIPSE is the plus shape
-                    const uint32_t* c = tile + (ly + 1) * tw + lx + 1 + k;
-                    bits = (c[0] | c[-1] | c[1] | c[-tw] | c[tw]) >> 24;
-                } else {
+                uint32_t bits = cross[k] >> 24;
+                if (p.ksize != 3) {
+                    bits = 0;
                     for (int i = 0; i < p.ksize; ++i)
                         for (int j = p.j1[i]; j < p.j2[i]; ++j)
-                            bits |= tile[(ly + i) * tw + lx + k + j] >> 24;
+                            bits |= tile[(ly + i) * tw + XO - r + lx + k + j] >> 24;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {

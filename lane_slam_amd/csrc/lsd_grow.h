@@ -230,13 +230,14 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     // accepted; so "the next accepted pixel" is the lowest lane at or after the cursor whose
     // pixel is free and aligned under the CURRENT angle -- one vector evaluation + ballot per
     // accepted pixel instead of a 9-step scalar chain per point.
+    const int slot = lane / 9, k9 = lane - slot * 9;      // lane constants
+    const int ddx = (k9 % 3) - 1, ddy = (k9 / 3) - 1;
     for (int i = 0; i < n;) {
         const int m = n - i < 7 ? n - i : 7;
-        const int slot = lane / 9, k9 = lane - slot * 9;
         const bool lv = slot < m;
         const uint32_t pkl = lv ? reg_get(c, i + slot) : 0u;
         const int pxl = (int)(pkl & 0xffffu), pyl = (int)(pkl >> 16);
-        const int xx = pxl + (k9 % 3) - 1, yy = pyl + (k9 / 3) - 1;
+        const int xx = pxl + ddx, yy = pyl + ddy;
         const bool inb = lv && xx >= 0 && xx < W && yy >= 0 && yy < H;
         const int e = inb ? find_e(c, xx, yy) : -1;
         bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
@@ -245,6 +246,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
+            if ((__ballot(cand) & later) == 0ull) break;  // nobody left to test: skip the f64 alignment pass
             const unsigned long long hit = __ballot(cand && aligned_val(a, reg_angle, prec)) & later;
             if (hit == 0ull) break;
             const int L = __builtin_ctzll(hit);

@@ -415,3 +415,22 @@ def test_lbd_gradient_planes(setup):
     for f in range(n):
         odx, ody = o.sobel3(o.gaussian5(o.bgr2gray(o.preprocess(frames[f]))))
         assert np.array_equal(dx[f], odx) and np.array_equal(dy[f], ody), f
+
+
+def test_larger_dilation_kernel():
+    """dilation_kernel_size 5: the generic MORPH_ELLIPSE path of k_pre (the default 3x3 cross has its own)."""
+    from oracle.oracle import Oracle
+    cfg = default_config("parity")
+    cfg["detector"]["dilation_kernel_size"] = 5
+    fe = FrontEnd(cfg, max_frames=2, max_lines_per_color=4096)
+    frames = synth.make_batch(2, 40)
+    seg = fe.process_batch(frames)
+    o = Oracle(cfg)
+    masks = fe.fetch(_lib.LF_BUF_MASKS, 2)
+    for f in range(2):
+        bw = o.color_masks(o.bgr2hsv(o.preprocess(frames[f])))
+        for c in range(3):
+            assert np.array_equal(masks[f, c], o.dilate(bw[c]))
+        r = o.process_frame(frames[f])
+        assert np.array_equal(seg.frame(f).lines, r["lines"]) and np.array_equal(seg.frame(f).code, r["code"])
+    fe.close()
