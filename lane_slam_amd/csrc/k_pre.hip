@@ -21,7 +21,8 @@ constexpr int TW = 128, TH = 30, PRE_THREADS = 256;   // (TH + 2) rows x 32 four
 
 struct PixOut { uint32_t packed; };
 
-__device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const PreParams& p, const int* sdiv, const int* hdiv)
+__device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const PreParams& p, const int* sdiv, const int* hdiv,
+                                                  const uint8_t* boxes)
 {
     // scaleandshift2 (float32) + convertScaleAbs, then OpenCV RGB2HSV_b (hsv_shift 12, hue range 180) + 4 inRange boxes
     int c[3] = {b0, g0, r0};
@@ -45,12 +46,9 @@ __device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const 
     h = (h * hdiv[diff] + (1 << 11)) >> 12;
     h += h < 0 ? 180 : 0;
     h = min(max(h, 0), 255);
-    int in[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        in[k] = (h >= p.lo[k][0]) & (h <= p.hi[k][0]) & (s >= p.lo[k][1]) & (s <= p.hi[k][1]) &
-                (v >= p.lo[k][2]) & (v <= p.hi[k][2]);
-    const int bits = in[0] | (in[1] << 1) | ((in[2] | in[3]) << 2);
+    // inRange against the 4 HSV boxes: per-channel acceptance masks (bit k = box k) from LDS tables
+    const int in4 = boxes[h] & boxes[256 + s] & boxes[512 + v];
+    const int bits = (in4 & 3) | (((in4 >> 2) | (in4 >> 3)) & 1) << 2;       // white, yellow, red = red1 | red2
     return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | ((uint32_t)bits << 24);
 }
 
@@ -63,12 +61,20 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
     constexpr int tw = TW + 8, XO = 4;
     __shared__ __attribute__((aligned(16))) uint32_t tile[(TH + 2 * (kMaxKsize / 2)) * tw];
     __shared__ int sdiv[256], hdiv[256];
+    __shared__ uint8_t boxes[3 * 256];           // boxes[ch*256 + value] bit k: lo[k][ch] <= value <= hi[k][ch]
     const int r = p.r;
     const int th = TH + 2 * r;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
     const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
     sdiv[threadIdx.x] = sdiv_g[threadIdx.x];
     hdiv[threadIdx.x] = hdiv_g[threadIdx.x];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        int mk = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mk |= (((int)threadIdx.x >= p.lo[k][ch]) & ((int)threadIdx.x <= p.hi[k][ch])) << k;
+        boxes[ch * 256 + threadIdx.x] = (uint8_t)mk;
+    }
     __syncthreads();
 
     const bool fast = !p.resize && (p.in_cols & 3) == 0 && (p.W & 3) == 0;
@@ -82,10 +88,10 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
             if (gx < p.W && gy >= 0 && gy < p.Hc) {
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3);
                 const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-                o[0] = convert_pixel(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, p, sdiv, hdiv);
-                o[1] = convert_pixel(d0 >> 24, d1 & 255, (d1 >> 8) & 255, p, sdiv, hdiv);
-                o[2] = convert_pixel((d1 >> 16) & 255, d1 >> 24, d2 & 255, p, sdiv, hdiv);
-                o[3] = convert_pixel((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, p, sdiv, hdiv);
+                o[0] = convert_pixel(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, p, sdiv, hdiv, boxes);
+                o[1] = convert_pixel(d0 >> 24, d1 & 255, (d1 >> 8) & 255, p, sdiv, hdiv, boxes);
+                o[2] = convert_pixel((d1 >> 16) & 255, d1 >> 24, d2 & 255, p, sdiv, hdiv, boxes);
+                o[3] = convert_pixel((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, p, sdiv, hdiv, boxes);
             }
             *reinterpret_cast<uint4*>(tile + ty * tw + XO + 4 * cg) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
             uint32_t packed = 0;
             if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
                 const uint8_t* q = src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3;
-                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv);
+                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv, boxes);
             }
             tile[ty * tw + tx] = packed;
         }
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                     sx = min(dm::ifloor(gx * p.ifx), p.in_cols - 1);
                 }
                 const uint8_t* q = src + ((size_t)sy * p.in_cols + sx) * 3;
-                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv);
+                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv, boxes);
             }
             tile[ty * tw + tx] = packed;
         }
