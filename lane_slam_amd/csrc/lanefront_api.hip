@@ -315,8 +315,13 @@ static int upload_tables(lf_handle* h)
     h->max_nsx = mx; h->max_nsy = my;
     {
         const int hh = L.half;
-        size_t lds = sizeof(double) * ((size_t)(my + 2 * hh) * mx + (size_t)my * mx + (size_t)my * (GT + 1) + (size_t)(GT + 1) * (GT + 1)) +
-                     (size_t)(my + 2 * hh) * (mx + 2 * hh);
+        // same carve as launch_lsd_grad: F|Hb|pixel list share one region, Bl|Sc the other
+        const size_t szF = (size_t)(my + 2 * hh) * mx, szBl = (size_t)my * mx;
+        const size_t szHb = (size_t)my * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
+        size_t regA = szF > szHb ? szF : szHb;
+        if (regA < (size_t)2 * GT * GT) regA = (size_t)2 * GT * GT;
+        const size_t regB = szBl > szSc ? szBl : szSc;
+        size_t lds = sizeof(double) * (regA + regB);
         if (lds > 64 * 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_scale %.3f needs %zu B of LDS per tile (max 65536)", L.scale, lds); return LF_ERR_UNSUPPORTED; }
     }
     if (dalloc(h, &h->d_xofs, Ws) || dalloc(h, &h->d_y0, Hs) || dalloc(h, &h->d_y1, Hs) || dalloc(h, &h->d_xa, 2 * (size_t)Ws) ||

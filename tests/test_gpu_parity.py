@@ -434,3 +434,44 @@ def test_larger_dilation_kernel():
         r = o.process_frame(frames[f])
         assert np.array_equal(seg.frame(f).lines, r["lines"]) and np.array_equal(seg.frame(f).code, r["code"])
     fe.close()
+
+
+@pytest.mark.parametrize("variant", ["scale1", "scale06", "refine0", "refine1", "bins256_ang15", "canny_swapped_hsv"])
+def test_configuration_variants(variant):
+    """Non-default detector / LSD parameters take the generic code paths (no Gaussian at scale 1, an
+    11-tap... 9-tap row filter without the lookup table at scale 0.6, other refine levels, bins, tolerances)."""
+    from oracle.oracle import Oracle
+    cfg = default_config("parity")
+    if variant == "scale1":
+        cfg["lsd"]["scale"] = 1.0
+    elif variant == "scale06":
+        cfg["lsd"]["scale"] = 0.6
+    elif variant == "refine0":
+        cfg["lsd"]["refine"] = 0
+    elif variant == "refine1":
+        cfg["lsd"]["refine"] = 1
+    elif variant == "bins256_ang15":
+        cfg["lsd"]["n_bins"] = 256
+        cfg["lsd"]["ang_th"] = 15.0
+        cfg["lsd"]["density_th"] = 0.8
+        cfg["lsd"]["log_eps"] = 1.0
+    else:
+        cfg["detector"]["canny_thresholds"] = [150, 60]            # OpenCV swaps them
+        cfg["detector"]["hsv_white1"] = [0, 0, 120]
+        cfg["detector"]["hsv_yellow1"] = [20, 100, 80]
+        cfg["detector"]["hsv_red4"] = [179, 255, 250]
+    fe = FrontEnd(cfg, max_frames=3, max_lines_per_color=4096)
+    o = Oracle(cfg)
+    frames = synth.make_batch(3, 60)
+    seg = fe.process_batch(frames)
+    total = 0
+    for f in range(3):
+        r = o.process_frame(frames[f])
+        s = seg.frame(f)
+        assert s.n == r["n"], (variant, f, s.n, r["n"])
+        assert np.array_equal(s.lines, r["lines"]) and np.array_equal(s.normals, r["normals"])
+        assert np.array_equal(s.ground, r["ground"]) and np.array_equal(s.keep, r["keep"])
+        assert np.array_equal(s.code, r["code"])
+        total += s.n
+    assert total > 5
+    fe.close()
