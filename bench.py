@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# Six batches are kept in flight on six HIP streams (plus torch's); ROCclr maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Must be
+# set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -48,8 +53,8 @@ def stage_bytes(P, Ps, resize):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity"])
     ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
@@ -57,7 +62,7 @@ def main():
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
-    ap.add_argument("--depth", type=int, default=3, help="independent batches in flight (handles/streams)")
+    ap.add_argument("--depth", type=int, default=6, help="independent batches in flight (handles/streams)")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     args = ap.parse_args()
@@ -263,7 +268,7 @@ def main():
                                    "Hamming association vs %d-code live map" % (B, args.geometry, fe.cols, fe.rows,
                                                                                  fe.lsd_cols, fe.lsd_rows, M),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0],
-                       "batches_in_flight": D,
+                       "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, all-gather of segment blocks" % world},
             "roofline": roofline,
             "kernels": kernels,

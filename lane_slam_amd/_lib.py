@@ -6,7 +6,9 @@ import os
 from .config import LfConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "liblanefront.so")
+# LANEFRONT_LIBRARY points at an alternative build of the same HIP library (diagnostic builds such as
+# -DLFG_STAMPS); the default is the in-tree product build.
+SO_PATH = os.environ.get("LANEFRONT_LIBRARY") or os.path.join(_HERE, "liblanefront.so")
 
 LF_N_STAGES = 12
 (LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const uint32_t* __
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
     c.min_reg_size = p.min_reg_size; c.refine = p.refine;
 #ifdef LFG_STAMPS
-    for (int k = 0; k < 8; ++k) c.stamps[k] = 0;
+    for (int k = 0; k < 12; ++k) c.stamps[k] = 0;
     unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
     int n = grow::detect(c, order + (size_t)pc * Ps, n_def, lines + (size_t)pc * p.cap_lines * 4, p.cap_lines);
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const uint32_t* __
     if (lane == 0) {
         // diagnostic: park the phase totals in the (otherwise unused) tail of this problem's region scratch
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reg + (size_t)pc * Ps + Ps - 32);
-        for (int k = 0; k < 8; ++k) dbg[k] = c.stamps[k];
-        dbg[8] = __builtin_readcyclecounter() - tb0;
-        dbg[9] = (unsigned long long)norder[pc];
-        dbg[10] = (unsigned long long)n;
+        for (int k = 0; k < 12; ++k) dbg[k] = c.stamps[k];
+        dbg[12] = __builtin_readcyclecounter() - tb0;
+        dbg[13] = (unsigned long long)norder[pc];
+        dbg[14] = (unsigned long long)n;
     }
 #endif
 }
@@ -68,9 +68,10 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + region-list head.
-    // 20 KB -> 8 problems per CU (the kernel's register budget allows 2 waves per SIMD).
+    // 16 KB x 8 problems per CU (the kernel's register budget allows 2 waves per SIMD) leaves a fifth of
+    // the CU's LDS to the streaming kernels of the other batches in flight.
     const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4;
-    const size_t budget = 20 * 1024;
+    const size_t budget = 16 * 1024;
     int reg_lds = 1024;
     long long left = (long long)budget - (long long)fixed - (long long)reg_lds * 4 - 8;
     int def_lds = left > 0 ? (int)(left * 8 / 17) : 0;         // 2 B + 1/8 B per entry

@@ -18,7 +18,7 @@
 //     integer / min-max reductions across lanes (exact, order free).
 // Per-pixel data are addressed by COMPACT index (raster rank among defined pixels); LDS holds
 // the row starts, the sorted x lists, one USED bit per defined pixel and the head of the region list
-// (~20 KB for a 512x256 problem), so many problems are resident per CU.
+// (~16 KB for a 512x256 problem), so many problems are resident per CU.
 //
 // The same source compiles for the host (LF_HOST_SIM, one lane) so the control flow can be
 // checked against the oracle without a GPU (tests/hostsim); that build is a test harness,
@@ -102,7 +102,9 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
 #define LFG_T0 unsigned long long _t0 = __builtin_readcyclecounter();
 #define LFG_T1(c, k) { unsigned long long _t1 = __builtin_readcyclecounter(); (c).stamps[k] += _t1 - _t0; _t0 = _t1; }
+#define LFG_CNT(c, k, v) { (c).stamps[k] += (unsigned long long)(v); }
 #else
+#define LFG_CNT(c, k, v)
 #define LFG_T0
 #define LFG_T1(c, k)
 #endif
@@ -128,7 +130,8 @@ struct Ctx {
     double log_nt, log_eps, density_th, prec, p, scale;
     int min_reg_size, refine;
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
-    mutable unsigned long long stamps[8];   // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math
+    mutable unsigned long long stamps[12];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
+                                            // 8 seed fetch, 9 regions, 10 region points, 11 grow batches
 #endif
 };
 
@@ -263,6 +266,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             added = true;
         }
         if (added) mem_fence();
+        LFG_CNT(c, 11, 1)
         i += m;
     }
 #else
@@ -692,9 +696,11 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
     for (int i = 0; i < n_order; ++i) {
         // seeds are fetched 64 at a time (one coalesced load + their coordinates), then visited in order
         if ((i % LFG_NL) == 0) {
+            LFG_T1(c, 0)
             const bool v = i + lane_id() < n_order;
             seed_items = v ? order[i + lane_id()] : 0u;
             seed_xy = v ? c.gxy[seed_items & 0xfffffu] : 0u;
+            LFG_T1(c, 8)
         }
         const int se = (int)((uint32_t)rl_i((int)seed_items, i % LFG_NL) & 0xfffffu);
         if (used_get(c, se)) continue;
@@ -704,6 +710,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         double reg_angle;
         region_grow(c, (int)(sxy & 0xffffu), (int)(sxy >> 16), se, reg_size, reg_angle, c.prec);
         LFG_T1(c, 1)
+        LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size)
         if (reg_size < c.min_reg_size) continue;
         Rect rec;
         region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
@@ -715,6 +722,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
             if (!ok_) continue;
             if (c.refine >= 2) {
                 log_nfa = rect_improve(c, rec);
+                LFG_T1(c, 6)
                 if (log_nfa <= c.log_eps) continue;
             }
         }
