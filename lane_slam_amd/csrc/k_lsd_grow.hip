@@ -5,7 +5,21 @@
 
 namespace lf {
 
-__global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
+// Occupancy knobs.  The kernel is latency bound (one wave per problem, long dependent chains), so what
+// matters is how many problems -- and how many waves of the OTHER batches' streaming kernels -- fit on
+// a CU next to each other: 128 VGPRs (4 waves per SIMD; rect_improve regenerates its candidates instead
+// of keeping five rectangles live, so nothing hot spills) and 13 KB of LDS per problem (12 per CU).
+#ifndef LFG_WAVES
+#define LFG_WAVES 4
+#endif
+#ifndef LFG_LDS_KB
+#define LFG_LDS_KB 13
+#endif
+#ifndef LFG_REG_LDS
+#define LFG_REG_LDS 512
+#endif
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
                                                  const double* __restrict__ c_cs, const double* __restrict__ c_sn,
@@ -45,7 +59,7 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const uint32_t* __
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
     c.min_reg_size = p.min_reg_size; c.refine = p.refine;
 #ifdef LFG_STAMPS
-    for (int k = 0; k < 12; ++k) c.stamps[k] = 0;
+    for (int k = 0; k < 24; ++k) c.stamps[k] = 0;
     unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
     int n = grow::detect(c, order + (size_t)pc * Ps, n_def, lines + (size_t)pc * p.cap_lines * 4, p.cap_lines);
@@ -53,11 +67,11 @@ __global__ __launch_bounds__(64) void k_lsd_grow(LsdParams p, const uint32_t* __
 #ifdef LFG_STAMPS
     if (lane == 0) {
         // diagnostic: park the phase totals in the (otherwise unused) tail of this problem's region scratch
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reg + (size_t)pc * Ps + Ps - 32);
-        for (int k = 0; k < 12; ++k) dbg[k] = c.stamps[k];
-        dbg[12] = __builtin_readcyclecounter() - tb0;
-        dbg[13] = (unsigned long long)norder[pc];
-        dbg[14] = (unsigned long long)n;
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reg + (size_t)pc * Ps + Ps - 64);
+        for (int k = 0; k < 24; ++k) dbg[k] = c.stamps[k];
+        dbg[24] = __builtin_readcyclecounter() - tb0;
+        dbg[25] = (unsigned long long)norder[pc];
+        dbg[26] = (unsigned long long)n;
     }
 #endif
 }
@@ -68,11 +82,9 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + region-list head.
-    // 16 KB x 8 problems per CU (the kernel's register budget allows 2 waves per SIMD) leaves a fifth of
-    // the CU's LDS to the streaming kernels of the other batches in flight.
     const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4;
-    const size_t budget = 16 * 1024;
-    int reg_lds = 1024;
+    const size_t budget = LFG_LDS_KB * 1024;
+    int reg_lds = LFG_REG_LDS;
     long long left = (long long)budget - (long long)fixed - (long long)reg_lds * 4 - 8;
     int def_lds = left > 0 ? (int)(left * 8 / 17) : 0;         // 2 B + 1/8 B per entry
     def_lds &= ~31;

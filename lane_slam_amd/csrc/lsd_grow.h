@@ -100,8 +100,8 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 // Diagnostic build only (-DLFG_STAMPS): cycle totals per phase, never enabled in the product.
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
-#define LFG_T0 unsigned long long _t0 = __builtin_readcyclecounter();
-#define LFG_T1(c, k) { unsigned long long _t1 = __builtin_readcyclecounter(); (c).stamps[k] += _t1 - _t0; _t0 = _t1; }
+#define LFG_T0 __builtin_amdgcn_sched_barrier(0); unsigned long long _t0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#define LFG_T1(c, k) { __builtin_amdgcn_sched_barrier(0); unsigned long long _t1 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); (c).stamps[k] += _t1 - _t0; _t0 = _t1; }
 #define LFG_CNT(c, k, v) { (c).stamps[k] += (unsigned long long)(v); }
 #else
 #define LFG_CNT(c, k, v)
@@ -130,7 +130,7 @@ struct Ctx {
     double log_nt, log_eps, density_th, prec, p, scale;
     int min_reg_size, refine;
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
-    mutable unsigned long long stamps[12];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
+    mutable unsigned long long stamps[24];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
                                             // 8 seed fetch, 9 regions, 10 region points, 11 grow batches
 #endif
 };
@@ -233,8 +233,24 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     // accepted; so "the next accepted pixel" is the lowest lane at or after the cursor whose
     // pixel is free and aligned under the CURRENT angle -- one vector evaluation + ballot per
     // accepted pixel instead of a 9-step scalar chain per point.
+    LFG_T0
     const int slot = lane / 9, k9 = lane - slot * 9;      // lane constants
     const int ddx = (k9 % 3) - 1, ddy = (k9 / 3) - 1;
+    // Seed window: the 9 x 7 pixels around the seed, one per lane (lane = 9*row + column), located and
+    // fetched in ONE round trip when the region starts.  Most regions are a handful of pixels (noise
+    // that fails min_reg_size, short dashes) and never leave it, so their later batches need neither the
+    // row search nor another trip to the compact arrays: a neighbour inside the window is a lane
+    // shuffle away.  Neighbours outside it take the per-lane search + fetch below, as before.
+    const int wx0 = sx - 4, wy0 = sy - 3;
+    int w_e = -1;
+    float w_deg = 0.0f;
+    double w_cs = 0.0, w_sn = 0.0;
+    {
+        const int x = wx0 + k9, y = wy0 + slot;
+        if (lane < 63 && x >= 0 && x < W && y >= 0 && y < H) w_e = find_e(c, x, y);
+        if (w_e >= 0) { w_deg = c.deg[w_e]; w_cs = c.cs[w_e]; w_sn = c.sn[w_e]; }
+    }
+    LFG_T1(c, 16)
     for (int i = 0; i < n;) {
         const int m = n - i < 7 ? n - i : 7;
         const bool lv = slot < m;
@@ -242,10 +258,21 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         const int pxl = (int)(pkl & 0xffffu), pyl = (int)(pkl >> 16);
         const int xx = pxl + ddx, yy = pyl + ddy;
         const bool inb = lv && xx >= 0 && xx < W && yy >= 0 && yy < H;
-        const int e = inb ? find_e(c, xx, yy) : -1;
+        const int rx = xx - wx0, ry = yy - wy0;
+        const bool inwin = lv && rx >= 0 && rx < 9 && ry >= 0 && ry < 7;
+        const int widx = inwin ? ry * 9 + rx : 0;
+        int e = __shfl(w_e, widx);
+        float dg = __shfl(w_deg, widx);
+        double ck = __shfl(w_cs, widx), sk = __shfl(w_sn, widx);
+        LFG_T1(c, 12)
+        LFG_CNT(c, 15, __ballot(inb && !inwin) != 0ull)
+        if (!inwin) {
+            e = inb ? find_e(c, xx, yy) : -1;
+            if (e >= 0 && !used_get(c, e)) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }
+        }
         bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
-        double a = NOTDEF_D, ck = 0.0, sk = 0.0;
-        if (cand) { a = (double)c.deg[e] * DEG2RAD; ck = c.cs[e]; sk = c.sn[e]; }
+        const double a = (double)dg * DEG2RAD;
+        LFG_T1(c, 13)
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
@@ -266,6 +293,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             added = true;
         }
         if (added) mem_fence();
+        LFG_T1(c, 14)
         LFG_CNT(c, 11, 1)
         i += m;
     }
@@ -474,6 +502,7 @@ LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
     double bin_tail = term;
     const double tolerance = 0.1;
     for (int i = k + 1; i <= n; ++i) {
+        LFG_CNT(c, 17, 1)
         const double bin_term = (double)(n - i + 1) / (double)i;
         const double mult_term = bin_term * p_term;
         term *= mult_term;
@@ -486,17 +515,11 @@ LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
     return -dm::dlog10(bin_tail) - LOG_NT;
 }
 
-struct Edge { int x, y; };
+// Row geometry of one rectangle: everything rect_nfa's scan-line walk needs, all integers.
+struct RowGeom { int min_x, flstep, slstep, frstep, srstep, ly, ry, y_start, y_end; };
 
-// Aligned-point count + NFA of one rectangle, evaluated by a GROUP of GS consecutive lanes
-// (GS = 64: the whole wave on one rectangle; GS = 8: eight rectangles at once, one per lane
-// group -- the per-rectangle work below is then pure SIMD across groups, including the
-// log-gamma / binomial-tail arithmetic of nfa()).  `rec` is per-lane data; lanes of a group
-// hold the same rectangle.  Lanes with `on == false` only take part in the shuffles.
-template <int GS>
-LFG_DEV double rect_nfa_g(const Ctx& c, const Rect& rec, bool on)
+LFG_DEV RowGeom edge_setup(const Rect& rec, int H)
 {
-    LFG_T0
     const double half_width = rec.width / 2.0;
     const double dyhw = rec.dy * half_width;
     const double dxhw = rec.dx * half_width;
@@ -545,88 +568,242 @@ LFG_DEV double rect_nfa_g(const Ctx& c, const Rect& rec, bool on)
         for (int i = 0; i < 4; ++i)
             if (!taken[i]) { if (sel < 0) { sel = i; tx_ = ex[i]; } else if (tx_ > ex[i]) { sel = i; tx_ = ex[i]; } }
     }
+    RowGeom g;
     // integer edge steps and the y-vs-x comparisons of OpenCV 3.x, kept as in the oracle
-    const int flstep = (min_yv != ly) ? (min_x - lx) / (min_yv - ly) : 0;
-    const int slstep = (ly != tx_) ? (lx - tx_) / (ly - tx_) : 0;
-    const int frstep = (min_yv != ry) ? (min_x - rx) / (min_yv - ry) : 0;
-    const int srstep = (ry != tx_) ? (rx - tx_) / (ry - tx_) : 0;
+    g.min_x = min_x;
+    g.flstep = (min_yv != ly) ? (min_x - lx) / (min_yv - ly) : 0;
+    g.slstep = (ly != tx_) ? (lx - tx_) / (ly - tx_) : 0;
+    g.frstep = (min_yv != ry) ? (min_x - rx) / (min_yv - ry) : 0;
+    g.srstep = (ry != tx_) ? (rx - tx_) / (ry - tx_) : 0;
+    g.ly = ly; g.ry = ry;
     // The oracle walks rows sequentially, skipping (without stepping) rows outside the image.
-    // All quantities are integers, so the bounds of row y have the closed form below.
-    const int y_start = min_yv > 0 ? min_yv : 0;
-    const int y_end = max_yv < c.H - 1 ? max_yv : c.H - 1;
+    g.y_start = min_yv > 0 ? min_yv : 0;
+    g.y_end = max_yv < H - 1 ? max_yv : H - 1;
+    return g;
+}
+
+// The rectangle is the same in every lane: tell the compiler, so the nine fields live in scalar registers.
+LFG_DEV RowGeom uniform_geom(const RowGeom& g)
+{
+#ifndef LF_HOST_SIM
+    RowGeom u;
+    u.min_x = __builtin_amdgcn_readfirstlane(g.min_x); u.flstep = __builtin_amdgcn_readfirstlane(g.flstep);
+    u.slstep = __builtin_amdgcn_readfirstlane(g.slstep); u.frstep = __builtin_amdgcn_readfirstlane(g.frstep);
+    u.srstep = __builtin_amdgcn_readfirstlane(g.srstep); u.ly = __builtin_amdgcn_readfirstlane(g.ly);
+    u.ry = __builtin_amdgcn_readfirstlane(g.ry); u.y_start = __builtin_amdgcn_readfirstlane(g.y_start);
+    u.y_end = __builtin_amdgcn_readfirstlane(g.y_end);
+    return u;
+#else
+    return g;
+#endif
+}
+
+// Pixel span [xa, xb] of row y (y_start <= y <= y_end), clipped to the image.  All quantities are
+// integers, so the oracle's step-by-step edge walk has this closed form.
+LFG_DEV void row_span(const RowGeom& g, int y, int W, int& xa, int& xb)
+{
+    const int steps = y - g.y_start;
+    int nf = (y < g.ly ? y : g.ly) - g.y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
+    int nr = (y < g.ry ? y : g.ry) - g.y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
+    const int xl = g.min_x + g.flstep * nf + g.slstep * (steps - nf);
+    const int xr = g.min_x + g.frstep * nr + g.srstep * (steps - nr);
+    xa = xl < 0 ? 0 : xl;
+    xb = xr > W - 1 ? W - 1 : xr;
+}
+
+// first entry of row y whose x is >= xa (binary search in the row's sorted x list)
+LFG_DEV int row_lower_bound(const Ctx& c, int y, int xa)
+{
+    int lo = c.rows[y], hi = c.rows[y + 1];
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs_get(c, mid) < xa) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+// folded angle distance used by isAligned (entries always have a defined angle)
+LFG_DEV double angle_dist(float deg, double theta)
+{
+    double n_theta = theta - (double)deg * DEG2RAD;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_) {
+        n_theta -= M_2__PI_;
+        if (n_theta < 0) n_theta = -n_theta;
+    }
+    return n_theta;
+}
+
+// Aligned-point count + NFA of one rectangle: the wave's lanes take rows y_start+lane, +64, ...; a
+// row's aligned pixels are found in its sorted defined-pixel list (LDS) instead of the 96 %
+// undefined angle plane.  Integer counts: order free.
+LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
+{
+    LFG_T0
+    const RowGeom g = edge_setup(rec, c.H);
     int total_pts = 0, alg_pts = 0;
-    const int li = lane_id() % GS;
-    // Each lane of the group takes rows y_start+li, +GS, ...; a row's aligned pixels are found
-    // in its sorted defined-pixel list (LDS) instead of the 96 % undefined angle plane.
-    // Integer counts: order free.
-    if (on) {
-        for (int y = y_start + li; y <= y_end; y += GS) {
-            const int steps = y - y_start;
-            int nf = (y < ly ? y : ly) - y_start; nf = nf < 0 ? 0 : (nf > steps ? steps : nf);
-            int nr = (y < ry ? y : ry) - y_start; nr = nr < 0 ? 0 : (nr > steps ? steps : nr);
-            const int xl = min_x + flstep * nf + slstep * (steps - nf);
-            const int xr = min_x + frstep * nr + srstep * (steps - nr);
-            const int xa = xl < 0 ? 0 : xl;
-            const int xb = xr > c.W - 1 ? c.W - 1 : xr;
-            if (xb < xa) continue;
-            total_pts += xb - xa + 1;
-            // entries of this row with xa <= x <= xb: lower bound by binary search, then walk
-            int lo = c.rows[y];
-            const int e1 = c.rows[y + 1];
-            {
-                int hi = e1;
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs_get(c, mid) < xa) lo = mid + 1; else hi = mid; }
-            }
-            for (int k0 = lo; k0 < e1; k0 += 4) {
-                int xv[4];
-                float dv[4];
-                bool stop = false;
+    for (int y = g.y_start + lane_id(); y <= g.y_end; y += LFG_NL) {
+        int xa, xb;
+        row_span(g, y, c.W, xa, xb);
+        if (xb < xa) continue;
+        total_pts += xb - xa + 1;
+        const int lo = row_lower_bound(c, y, xa);
+        const int e1 = c.rows[y + 1];
+        for (int k0 = lo; k0 < e1; k0 += 4) {
+            int xv[4];
+            float dv[4];
+            bool stop = false;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = k0 + u < e1 ? k0 + u : e1 - 1;
-                    xv[u] = xs_get(c, idx);
-                    dv[u] = c.deg[idx];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (k0 + u >= e1 || xv[u] > xb) { stop = true; break; }
-                    if (aligned_val((double)dv[u] * DEG2RAD, rec.theta, rec.prec)) ++alg_pts;
-                }
-                if (stop) break;
+            for (int u = 0; u < 4; ++u) {
+                const int idx = k0 + u < e1 ? k0 + u : e1 - 1;
+                xv[u] = xs_get(c, idx);
+                dv[u] = c.deg[idx];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u >= e1 || xv[u] > xb) { stop = true; break; }
+                if (angle_dist(dv[u], rec.theta) <= rec.prec) ++alg_pts;
+            }
+            if (stop) break;
         }
     }
-#ifndef LF_HOST_SIM
-#pragma unroll
-    for (int d = GS / 2; d >= 1; d >>= 1) { total_pts += __shfl_xor(total_pts, d); alg_pts += __shfl_xor(alg_pts, d); }
-#endif
+    total_pts = wave_sum_i(total_pts);
+    alg_pts = wave_sum_i(alg_pts);
     LFG_T1(c, 4)
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
     c.stamps[7] += (1ull << 40) + (unsigned long long)total_pts;
 #endif
-    const double r_ = on ? nfa(c, total_pts, alg_pts, rec.p) : -1e300;
+    const double r_ = nfa(c, total_pts, alg_pts, rec.p);
     LFG_T1(c, 5)
     return r_;
 }
 
-LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec) { return rect_nfa_g<LFG_NL>(c, rec, true); }
-
-// Five candidate rectangles of one rect_improve stage at once (lane group g evaluates cand[g]).
-LFG_DEV void rect_nfa5(const Ctx& c, const Rect* cand, const bool* valid, double* v)
+// The five candidate rectangles of one rect_improve stage at once.  They share theta and differ by
+// half a pixel of width / offset or by the precision only, so their rows and x spans nearly coincide:
+// ONE pass over the union of the spans (all 64 lanes on rows, one angle fetch per entry) feeds five
+// pairs of counters; the five NFA values -- log-gamma, binomial tail -- are then computed SIMD, one
+// candidate per 8-lane group.
+// Candidate n of a rect_improve stage: the stage's step applied n+1 times to the stage's starting
+// rectangle (the reference's inner loops are cumulative).  Returns false when the reference would
+// skip the candidate (width cannot shrink further); the rectangle is then left as it was.
+LFG_DEV bool improve_step(Rect& r, int stage)
 {
+    const double delta = 0.5;
+    const double delta_2 = delta / 2.0;
+    if (stage == 0) {
+        r.p /= 2;
+        r.prec = r.p * PI_;
+        return true;
+    }
+    if (!((r.width - delta) >= 0.5)) return false;     // OpenCV keeps this guard on the last stage too
+    if (stage == 4) {
+        r.p /= 2;
+        r.prec = r.p * PI_;
+        return true;
+    }
+    if (stage == 2) {
+        r.x1 += -r.dy * delta_2;
+        r.y1 += r.dx * delta_2;
+        r.x2 += -r.dy * delta_2;
+        r.y2 += r.dx * delta_2;
+    } else if (stage == 3) {
+        r.x1 -= -r.dy * delta_2;
+        r.y1 -= r.dx * delta_2;
+        r.x2 -= -r.dy * delta_2;
+        r.y2 -= r.dx * delta_2;
+    }
+    r.width -= delta;
+    return true;
+}
+LFG_DEV bool improve_candidate(const Rect& base, int stage, int n, Rect& r)
+{
+    r = base;
+    bool ok = true;
+    for (int j = 0; j <= n; ++j) ok = improve_step(r, stage);
+    return ok;
+}
+
+LFG_DEV void rect_nfa5(const Ctx& c, const Rect& base, int stage, bool* valid, double* v)
+{
+    LFG_T0
+    RowGeom G[5];
+    double prec[5], pp[5];
+    int y_lo = c.H, y_hi = -1;
+    {
+        Rect r = base;
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (ok) ok = improve_step(r, stage);        // once a step is refused the rectangle stays put
+            valid[k] = ok;
+            G[k] = uniform_geom(edge_setup(r, c.H));
+            prec[k] = r.prec; pp[k] = r.p;
+            if (ok) {
+                y_lo = G[k].y_start < y_lo ? G[k].y_start : y_lo;
+                y_hi = G[k].y_end > y_hi ? G[k].y_end : y_hi;
+            }
+        }
+    }
+    const double theta = base.theta;                 // rect_improve never changes theta
+    int tot[5] = { 0, 0, 0, 0, 0 }, alg[5] = { 0, 0, 0, 0, 0 };
+    for (int y = y_lo + lane_id(); y <= y_hi; y += LFG_NL) {
+        int xa[5], xb[5];
+        int ua = c.W, ub = -1;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            xa[k] = 1; xb[k] = 0;
+            if (valid[k] && y >= G[k].y_start && y <= G[k].y_end) {
+                row_span(G[k], y, c.W, xa[k], xb[k]);
+                if (xb[k] >= xa[k]) {
+                    tot[k] += xb[k] - xa[k] + 1;
+                    ua = xa[k] < ua ? xa[k] : ua;
+                    ub = xb[k] > ub ? xb[k] : ub;
+                }
+            }
+        }
+        if (ub < ua) continue;
+        const int lo = row_lower_bound(c, y, ua);
+        const int e1 = c.rows[y + 1];
+        for (int k0 = lo; k0 < e1; k0 += 4) {
+            int xv[4];
+            float dv[4];
+            bool stop = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = k0 + u < e1 ? k0 + u : e1 - 1;
+                xv[u] = xs_get(c, idx);
+                dv[u] = c.deg[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u >= e1 || xv[u] > ub) { stop = true; break; }
+                const double nt = angle_dist(dv[u], theta);
+#pragma unroll
+                for (int k = 0; k < 5; ++k)
+                    if (xv[u] >= xa[k] && xv[u] <= xb[k] && nt <= prec[k]) ++alg[k];
+            }
+            if (stop) break;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { tot[k] = wave_sum_i(tot[k]); alg[k] = wave_sum_i(alg[k]); }
+    LFG_T1(c, 4)
+#if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
+    c.stamps[7] += (1ull << 40) + (unsigned long long)tot[0];
+#endif
 #ifndef LF_HOST_SIM
     const int g = lane_id() >> 3;
-    Rect mine = cand[0];
-    bool on = g == 0 && valid[0];
+    int n_ = tot[0], k_ = alg[0];
+    double p_ = pp[0];
+    bool on = valid[0];
 #pragma unroll
     for (int k = 1; k < 5; ++k)
-        if (g == k) { mine = cand[k]; on = valid[k]; }
-    const double r = rect_nfa_g<8>(c, mine, on);
+        if (g == k) { n_ = tot[k]; k_ = alg[k]; p_ = pp[k]; on = valid[k]; }
+    if (g > 4) on = false;
+    const double r = on ? nfa(c, n_, k_, p_) : -1e300;
 #pragma unroll
     for (int k = 0; k < 5; ++k) v[k] = rl_d(r, 8 * k);
 #else
-    for (int k = 0; k < 5; ++k) v[k] = valid[k] ? rect_nfa_g<1>(c, cand[k], true) : -1e300;
+    for (int k = 0; k < 5; ++k) v[k] = valid[k] ? nfa(c, tot[k], alg[k], pp[k]) : -1e300;
 #endif
+    LFG_T1(c, 5)
 }
 
 // rect_improve: the reference tries 5 x 5 variants one after another, but a stage's variants
@@ -635,51 +812,21 @@ LFG_DEV void rect_nfa5(const Ctx& c, const Rect* cand, const bool* valid, double
 LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 {
     const double LOG_EPS = c.log_eps;
-    const double delta = 0.5;
-    const double delta_2 = delta / 2.0;
     double log_nfa = rect_nfa(c, rec);
     if (log_nfa > LOG_EPS) return log_nfa;
-    Rect cand[5];
     bool valid[5];
     double v[5];
     for (int stage = 0; stage < 5; ++stage) {
-        Rect r = rec;
-#pragma unroll
-        for (int n = 0; n < 5; ++n) {
-            bool ok = true;
-            if (stage == 0) {
-                r.p /= 2;
-                r.prec = r.p * PI_;
-            } else {
-                ok = (r.width - delta) >= 0.5;
-                if (ok) {
-                    if (stage == 1) {
-                        r.width -= delta;
-                    } else if (stage == 2) {
-                        r.x1 += -r.dy * delta_2;
-                        r.y1 += r.dx * delta_2;
-                        r.x2 += -r.dy * delta_2;
-                        r.y2 += r.dx * delta_2;
-                        r.width -= delta;
-                    } else if (stage == 3) {
-                        r.x1 -= -r.dy * delta_2;
-                        r.y1 -= r.dx * delta_2;
-                        r.x2 -= -r.dy * delta_2;
-                        r.y2 -= r.dx * delta_2;
-                        r.width -= delta;
-                    } else {
-                        r.p /= 2;
-                        r.prec = r.p * PI_;
-                    }
-                }
-            }
-            cand[n] = r;
-            valid[n] = ok;
-        }
-        rect_nfa5(c, cand, valid, v);
+        rect_nfa5(c, rec, stage, valid, v);
+        int best = -1;
 #pragma unroll
         for (int n = 0; n < 5; ++n)
-            if (valid[n] && v[n] > log_nfa) { log_nfa = v[n]; rec = cand[n]; }
+            if (valid[n] && v[n] > log_nfa) { log_nfa = v[n]; best = n; }
+        if (best >= 0) {
+            Rect r;
+            improve_candidate(rec, stage, best, r);
+            rec = r;
+        }
         if (stage < 4 && log_nfa > LOG_EPS) return log_nfa;
     }
     return log_nfa;
@@ -692,20 +839,36 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
 {
     int n_lines = 0;
     LFG_T0
-    uint32_t seed_items = 0, seed_xy = 0;
-    for (int i = 0; i < n_order; ++i) {
-        // seeds are fetched 64 at a time (one coalesced load + their coordinates), then visited in order
-        if ((i % LFG_NL) == 0) {
-            LFG_T1(c, 0)
-            const bool v = i + lane_id() < n_order;
-            seed_items = v ? order[i + lane_id()] : 0u;
-            seed_xy = v ? c.gxy[seed_items & 0xfffffu] : 0u;
-            LFG_T1(c, 8)
-        }
-        const int se = (int)((uint32_t)rl_i((int)seed_items, i % LFG_NL) & 0xfffffu);
-        if (used_get(c, se)) continue;
-        const uint32_t sxy = (uint32_t)rl_i((int)seed_xy, i % LFG_NL);
+#ifndef LF_HOST_SIM
+    // Seeds are fetched 64 at a time (one coalesced load + their coordinates).  Every lane tests the
+    // USED bit of its own seed; the next seed the reference would start from is the lowest lane past
+    // the cursor whose pixel is free NOW (a region can free pixels again in refine(), so the test is
+    // repeated after every region) -- one vector test + ballot per region instead of a scalar
+    // test per seed.
+    for (int base = 0; base < n_order; base += LFG_NL) {
         LFG_T1(c, 0)
+        const bool sv = base + lane_id() < n_order;
+        const uint32_t seed_items = sv ? order[base + lane_id()] : 0u;
+        const int my_e = (int)(seed_items & 0xfffffu);
+        const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;
+        LFG_T1(c, 8)
+        unsigned long long pending = ~0ull;
+      for (;;) {
+        mem_fence();
+        const unsigned long long fr = __ballot(sv && !used_get(c, my_e)) & pending;
+        if (fr == 0ull) break;
+        const int sl = __builtin_ctzll(fr);
+        pending = sl >= 63 ? 0ull : (~0ull << (sl + 1));
+        const int se = rl_i(my_e, sl);
+        const uint32_t sxy = (uint32_t)rl_i((int)seed_xy, sl);
+        LFG_T1(c, 0)
+#else
+    for (int i = 0; i < n_order; ++i) {
+      {
+        const int se = (int)(order[i] & 0xfffffu);
+        if (used_get(c, se)) continue;
+        const uint32_t sxy = c.gxy[se];
+#endif
         int reg_size;
         double reg_angle;
         region_grow(c, (int)(sxy & 0xffffu), (int)(sxy >> 16), se, reg_size, reg_angle, c.prec);
@@ -738,6 +901,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         }
         ++n_lines;
         LFG_T1(c, 6)
+      }
     }
     LFG_T1(c, 0)
     return n_lines;

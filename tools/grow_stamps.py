@@ -15,12 +15,13 @@ fe.process_batch(frames)
 seg = fe.process_batch(frames)
 scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
 Ps = scr.shape[2]
-d = scr[:, :, Ps - 32:].copy().view(np.uint64).reshape(n * 3, 16)[:, :15].astype(np.float64)
-names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "emit", "-", "fetch", "regions", "reg_pts", "batches", "total", "n_order", "n_lines"]
-CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12}
-raw7 = scr[:, :, Ps - 32:].copy().view(np.uint64).reshape(n * 3, 16)[:, 7]
+d = scr[:, :, Ps - 64:].copy().view(np.uint64).reshape(n * 3, 32)[:, :27].astype(np.float64)
+names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
+         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters"] + ["-"] * 6 + ["total", "n_order", "n_lines"]
+CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
+raw7 = scr[:, :, Ps - 64:].copy().view(np.uint64).reshape(n * 3, 32)[:, 7]
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
-order = np.argsort(d[:, 12])
+order = np.argsort(d[:, 24])
 print("problems", n * 3, "segments", seg.n)
 for label, rows in (("median", d[order[len(order) // 2]]), ("p90", d[order[int(len(order) * 0.9)]]), ("max", d[order[-1]]), ("mean", d.mean(0))):
-    print(label, " ".join("%s=%.0f" % (nm, v / (1000.0 if i in CYC else 1.0)) for i, (nm, v) in enumerate(zip(names, rows))), "(kcycles)")
+    print(label, " ".join("%s=%.0f" % (nm, v / (1000.0 if i in CYC else 1.0)) for i, (nm, v) in enumerate(zip(names, rows)) if nm != "-"), "(kcycles)")
