@@ -22,6 +22,7 @@
  */
 #ifndef LF_ORACLE_H
 #define LF_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -129,6 +130,11 @@ typedef struct lfo_frame_out {
 
 /* runs a-1..a-9 on one frame; arrays in out must hold cap segments; returns n (clamped to cap) */
 int lfo_process_frame(const lfo_config* c, const uint8_t* bgr_in, lfo_frame_out* out, int cap);
+
+/* host ingest: cv2.imdecode(data, IMREAD_COLOR), ref duckietown_utils/jpg.py:21-31.
+ * 0 ok, -6 corrupt, -5 unsupported stream.  bgr: rows x cols x 3 for the size lfo_jpeg_info reports. */
+int lfo_jpeg_info(const uint8_t* data, size_t size, int* rows, int* cols, int* ncomp, int* hmax, int* vmax);
+int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr);
 
 #ifdef __cplusplus
 }

@@ -287,6 +287,37 @@ class Oracle(object):
         return out
 
 
+def _jpeg_lib():
+    build()
+    lib = ctypes.CDLL(_SO)
+    lib.lfo_jpeg_info.restype = ctypes.c_int
+    lib.lfo_jpeg_decode.restype = ctypes.c_int
+    return lib
+
+
+def jpeg_info(data):
+    """(rows, cols, components, hmax, vmax) of a JPEG stream; raises ValueError like image_cv_from_jpg."""
+    lib = _jpeg_lib()
+    buf = np.frombuffer(bytes(data), np.uint8)
+    v = [ctypes.c_int() for _ in range(5)]
+    rc = lib.lfo_jpeg_info(_p(buf), ctypes.c_size_t(buf.size), *[ctypes.byref(x) for x in v])
+    if rc != 0:
+        raise ValueError("Could not decode image (oracle rc %d)" % rc)
+    return tuple(x.value for x in v)
+
+
+def jpeg_decode(data):
+    """BGR u8 image cv2.imdecode(data, IMREAD_COLOR) would return (oracle/lf_oracle_jpeg.c)."""
+    lib = _jpeg_lib()
+    rows, cols = jpeg_info(data)[:2]
+    buf = np.frombuffer(bytes(data), np.uint8)
+    out = np.empty((rows, cols, 3), np.uint8)
+    rc = lib.lfo_jpeg_decode(_p(buf), ctypes.c_size_t(buf.size), _p(out))
+    if rc != 0:
+        raise ValueError("Could not decode image (oracle rc %d)" % rc)
+    return out
+
+
 def detmath_lib():
     build()
     return ctypes.CDLL(_SO)
