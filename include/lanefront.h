@@ -35,7 +35,8 @@ typedef enum lf_status {
     LF_ERR_CAPACITY = -2,     /* caller buffer / configured capacity exceeded */
     LF_ERR_HIP = -3,          /* HIP runtime error or no device */
     LF_ERR_NOT_INITIALISED = -4,
-    LF_ERR_UNSUPPORTED = -5
+    LF_ERR_UNSUPPORTED = -5,
+    LF_ERR_DECODE = -6        /* undecodable JPEG stream (the reference gets None from cv2.imdecode and drops the frame) */
 } lf_status;
 
 /* colour codes: src/duckietown_msgs/msg/Segment.msg:1-3 */
@@ -156,6 +157,35 @@ int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* ma
 int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
                        int32_t* idx, float* dist, int on_device);
 
+/* ---- host ingest: replaces duckietown_utils.jpg.image_cv_from_jpg ---------------
+ * = cv2.imdecode(np.fromstring(data, np.uint8), cv2.IMREAD_COLOR)
+ * (src/duckietown/include/duckietown_utils/jpg.py:21-31, called per frame from
+ *  src/line_detector/src/line_detector_node.py:153-158), i.e. libjpeg-turbo's default decoder.
+ * Host threads parse and Huffman-decode the streams into sparse coefficient lists; dequantisation,
+ * inverse DCT, chroma upsampling and YCbCr -> BGR run on the handle's stream.  Output: u8 BGR
+ * [n_frames][rows][cols][3], bit identical to libjpeg-turbo for baseline / extended-sequential
+ * Huffman streams with 4:4:4, 4:2:2, 4:2:0 or grayscale sampling (anything else: LF_ERR_UNSUPPORTED).
+ *
+ * jpeg[i] / jpeg_size[i]  host pointers to the n_frames streams
+ * rows, cols              expected image size; a stream of another size gets LF_ERR_BAD_ARG
+ * frames                  device pointer (frames_on_device = 1: the call returns once the work is
+ *                         queued on the handle's stream, order it with lf_synchronize or simply pass the
+ *                         buffer to lf_process_batch on the same handle) or host pointer (= 0: synchronous)
+ * n_threads               host threads for entropy decoding (<= 0: one per frame, at most 64)
+ * frame_status            optional [n_frames] lf_status per frame.  A frame that cannot be decoded is
+ *                         written as zeros -- the reference logs and drops such a frame
+ *                         (line_detector_node.py:155-158).  Without frame_status the call returns
+ *                         LF_ERR_DECODE if any frame failed.
+ */
+int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
+                         int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
+                         int* frame_status);
+/* size and layout of one stream without decoding it (hmax x vmax = luma sampling factors) */
+int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax);
+/* the handle's own device staging buffer for input frames ([max_frames][in_rows][in_cols][3] u8): decode
+ * into it, then hand the same pointer to lf_process_batch with frames_on_device = 1 */
+int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* bytes);
+
 /* ---- introspection for tests and the benchmark ---------------------------- */
 typedef enum lf_buffer_id {
     LF_BUF_BGR = 0,          /* u8  [frames][Hc][W][3]   corrected working image          */
@@ -183,7 +213,7 @@ int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, fl
 int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
 
 /* per-kernel timing with HIP events on the handle's stream */
-#define LF_N_STAGES 12
+#define LF_N_STAGES 13
 int lf_set_profiling(lf_handle* h, int enabled);
 /* ms accumulated per stage since the last reset, and launches counted */
 int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n);

@@ -14,7 +14,7 @@ constexpr float kNotDef = -1024.0f; // LSD NOTDEF marker (angle plane, degrees)
 
 enum Stage {
     ST_PRE = 0, ST_CANNY, ST_HYST, ST_LSD_GRAD, ST_LSD_ORDER, ST_LSD_GROW, ST_SEGMENTS,
-    ST_LBD_GRAD, ST_LBD, ST_ASSOC_PACK, ST_ASSOC, ST_MISC, ST_COUNT
+    ST_LBD_GRAD, ST_LBD, ST_ASSOC_PACK, ST_ASSOC, ST_MISC, ST_JPEG, ST_COUNT
 };
 static_assert(ST_COUNT == LF_N_STAGES, "stage table out of sync with lanefront.h");
 
@@ -116,4 +116,11 @@ void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx
                   unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc_float(const float* q, int nq, const float* m, int nm, float* qn, float* mn,
                         unsigned long long* best, int32_t* idx, float* dist, hipStream_t s);
+// ---- JPEG ingest (k_jpeg.hip)
+namespace jpeg { struct FrameHeader; }
+struct JpegGeom { int rows, cols, Wp, Hp; };     // Wp x Hp: padded component plane (multiples of 16)
+void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const jpeg::FrameHeader* hdrs,
+                        const uint32_t* entries, const uint32_t* block_end, uint8_t* planes, uint8_t* frames,
+                        hipStream_t s);
+
 }  // namespace lf

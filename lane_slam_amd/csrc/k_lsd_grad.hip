@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
             T[m] = s;
         }
     }
-    const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
-    const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
+    const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx;
+    const size_t szHb = (size_t)max_nsy * (GT + 1);
     size_t regA = szF > szHb ? szF : szHb;
     if (regA < (size_t)2 * GT * GT) regA = (size_t)2 * GT * GT;      // also hosts the defined-pixel list (8 + 8 B entries)
     double* F = lds_d;                                   // [rh][nsx]     row-filtered

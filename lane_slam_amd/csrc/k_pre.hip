@@ -72,7 +72,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
     for (int ch = 0; ch < 3; ++ch) {
         int mk = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) mk |= (((int)threadIdx.x >= p.lo[k][ch]) & ((int)threadIdx.x <= p.hi[k][ch])) << k;
+        for (int k = 0; k < 4; ++k) mk |= (int)((int)threadIdx.x >= p.lo[k][ch] && (int)threadIdx.x <= p.hi[k][ch]) << k;
         boxes[ch * 256 + threadIdx.x] = (uint8_t)mk;
     }
     __syncthreads();

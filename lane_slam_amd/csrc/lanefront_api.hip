@@ -8,19 +8,33 @@
 #include <math.h>
 #include <vector>
 #include <new>
+#include <atomic>
+#include <thread>
 #include "common.h"
+#include "jpeg_entropy.h"
 
 using namespace lf;
 
 static const char* kStageNames[LF_N_STAGES] = {
     "pre(resize+correct+hsv+masks+dilate)", "canny_nms", "canny_hysteresis", "lsd_blur_resample_grad",
     "lsd_order", "lsd_grow", "segments(normal+project+sanity)", "lbd_gray_blur_sobel", "lbd_descriptor",
-    "assoc_pack", "assoc_mfma", "misc" };
+    "assoc_pack", "assoc_mfma", "misc", "jpeg(idct+upsample+color)" };
 
 struct EvPair { hipEvent_t a, b; int st; };
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+};
+
+// JPEG ingest state (allocated on first use, grown on demand)
+struct JpegState {
+    std::vector<lf::jpeg::FrameCoefs> frames;       // per-frame host coefficient lists (capacity is kept)
+    int rows = 0, cols = 0, max_frames = 0;         // geometry the planes were sized for
+    DevBuf planes, entries, block_end, hdrs, out;   // device
+    void* h_stage = nullptr;                        // pinned staging: headers | block_end | entries
+    size_t h_stage_bytes = 0;
+    hipEvent_t staged = nullptr;                    // the last H2D out of h_stage has completed
+    bool staged_pending = false;
 };
 
 struct lf_handle {
@@ -81,6 +95,7 @@ struct lf_handle {
     bool pending = false;
     int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
+    JpegState* jpeg = nullptr;
     // profiling
     bool profiling = false;
     std::vector<EvPair> ev_free, ev_used;
@@ -402,6 +417,13 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->jpeg) {
+        JpegState* j = h->jpeg;
+        for (DevBuf* b : { &j->planes, &j->entries, &j->block_end, &j->hdrs, &j->out }) if (b->p) (void)hipFree(b->p);
+        if (j->h_stage) (void)hipHostFree(j->h_stage);
+        if (j->staged) (void)hipEventDestroy(j->staged);
+        delete j;
+    }
     timing_resolve(h);
     for (EvPair& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -833,6 +855,141 @@ extern "C" int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launch
     for (int i = 0; i < n && i < LF_N_STAGES; ++i) {
         if (ms_per_stage) ms_per_stage[i] = h->ms[i];
         if (launches_per_stage) launches_per_stage[i] = h->launches[i];
+    }
+    return LF_OK;
+}
+
+// ---------------------------------------------------------------------------------------- JPEG ingest
+extern "C" int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax)
+{
+    if (!jpeg) return LF_ERR_BAD_ARG;
+    return lf::jpeg::peek(jpeg, jpeg_size, rows, cols, components, hmax, vmax);
+}
+
+extern "C" int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* bytes)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (device_ptr) *device_ptr = h->d_frames;
+    if (bytes) *bytes = (size_t)h->max_frames * h->cfg.in_rows * h->cfg.in_cols * 3;
+    return LF_OK;
+}
+
+extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
+                                    int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
+                                    int* frame_status)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!jpeg || !jpeg_size || !frames || n_frames < 1 || rows < 1 || cols < 1 || rows > 65535 || cols > 65535) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_jpeg_decode_batch: null argument, n_frames < 1 or bad size %dx%d", rows, cols);
+        return LF_ERR_BAD_ARG;
+    }
+    if (n_frames > 65535) { lf_set_error(h, LF_ERR_CAPACITY, "lf_jpeg_decode_batch: at most 65535 frames per call"); return LF_ERR_CAPACITY; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    if (!h->jpeg) {
+        h->jpeg = new (std::nothrow) JpegState();
+        if (!h->jpeg) { lf_set_error(h, LF_ERR_HIP, "out of host memory"); return LF_ERR_HIP; }
+        LF_HIP_CHECK(h, hipEventCreateWithFlags(&h->jpeg->staged, hipEventDisableTiming));
+    }
+    JpegState& J = *h->jpeg;
+    hipStream_t s = h->stream;
+    if ((int)J.frames.size() < n_frames) J.frames.resize((size_t)n_frames);
+
+    // ---- host: entropy decoding, one frame per task
+    int nt = n_threads > 0 ? n_threads : (n_frames < 64 ? n_frames : 64);
+    if (nt > n_frames) nt = n_frames;
+    {
+        std::atomic<int> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n_frames) break;
+                lf::jpeg::FrameCoefs& fc = J.frames[(size_t)i];
+                if (!jpeg[i]) { fc.status = LF_ERR_BAD_ARG; fc.hdr.valid = 0; fc.hdr.nblocks = 0; fc.n_entries = 0; continue; }
+                int rc = lf::jpeg::decode_coefficients(jpeg[i], jpeg_size[i], fc);
+                if (rc == LF_OK && (fc.rows != rows || fc.cols != cols)) {
+                    fc.status = LF_ERR_BAD_ARG;          // decodable, but not the size the batch was declared with
+                    fc.hdr.valid = 0; fc.hdr.nblocks = 0; fc.n_entries = 0;
+                }
+            }
+        };
+        if (nt <= 1) work();
+        else {
+            std::vector<std::thread> pool;
+            pool.reserve((size_t)nt);
+            for (int t = 0; t < nt; ++t) pool.emplace_back(work);
+            for (std::thread& t : pool) t.join();
+        }
+    }
+    // ---- layout of the batch
+    size_t total_entries = 0, total_blocks = 0;
+    int max_blocks = 0, n_failed = 0, first_error = LF_OK;
+    for (int i = 0; i < n_frames; ++i) {
+        lf::jpeg::FrameCoefs& fc = J.frames[(size_t)i];
+        if (frame_status) frame_status[i] = fc.status;
+        if (fc.status != LF_OK) { ++n_failed; if (first_error == LF_OK) first_error = fc.status; }
+        fc.hdr.entry_base = (uint32_t)total_entries;
+        fc.hdr.block_base = (uint32_t)total_blocks;
+        total_entries += fc.n_entries;
+        total_blocks += (size_t)fc.hdr.nblocks;
+        if (fc.hdr.nblocks > max_blocks) max_blocks = fc.hdr.nblocks;
+    }
+    if (total_entries >= (1ull << 32) || total_blocks >= (1ull << 32)) { lf_set_error(h, LF_ERR_CAPACITY, "batch too large"); return LF_ERR_CAPACITY; }
+    const size_t hdr_bytes = (size_t)n_frames * sizeof(lf::jpeg::FrameHeader);
+    const size_t blk_bytes = (total_blocks + 1) * sizeof(uint32_t);
+    const size_t ent_bytes = (total_entries + 1) * sizeof(uint32_t);
+    const size_t off_blk = (hdr_bytes + 255) & ~(size_t)255, off_ent = (off_blk + blk_bytes + 255) & ~(size_t)255;
+    const size_t stage_bytes = off_ent + ent_bytes;
+    // the previous call's copy out of the staging buffer must have completed before it is rewritten
+    if (J.staged_pending) { LF_HIP_CHECK(h, hipEventSynchronize(J.staged)); J.staged_pending = false; }
+    if (J.h_stage_bytes < stage_bytes) {
+        if (J.h_stage) (void)hipHostFree(J.h_stage);
+        J.h_stage = nullptr; J.h_stage_bytes = 0;
+        const size_t want = stage_bytes + stage_bytes / 4 + 4096;
+        LF_HIP_CHECK(h, hipHostMalloc(&J.h_stage, want, hipHostMallocDefault));
+        J.h_stage_bytes = want;
+    }
+    {
+        uint8_t* st = static_cast<uint8_t*>(J.h_stage);
+        for (int i = 0; i < n_frames; ++i) {
+            const lf::jpeg::FrameCoefs& fc = J.frames[(size_t)i];
+            memcpy(st + (size_t)i * sizeof(lf::jpeg::FrameHeader), &fc.hdr, sizeof(lf::jpeg::FrameHeader));
+            if (fc.hdr.nblocks) memcpy(st + off_blk + (size_t)fc.hdr.block_base * 4, fc.block_end.data(), (size_t)fc.hdr.nblocks * 4);
+            if (fc.n_entries) memcpy(st + off_ent + (size_t)fc.hdr.entry_base * 4, fc.entries.data(), fc.n_entries * 4);
+        }
+    }
+    // ---- device
+    JpegGeom g;
+    g.rows = rows; g.cols = cols;
+    g.Wp = (cols + 15) / 16 * 16;
+    g.Hp = (rows + 15) / 16 * 16;
+    int rc;
+    if ((rc = ensure(h, J.planes, (size_t)n_frames * 3 * g.Wp * g.Hp)) != LF_OK) return rc;
+    if ((rc = ensure(h, J.hdrs, stage_bytes)) != LF_OK) return rc;       // one device image of the staging buffer
+    uint8_t* d_stage = static_cast<uint8_t*>(J.hdrs.p);
+    LF_HIP_CHECK(h, hipMemcpyAsync(d_stage, J.h_stage, stage_bytes, hipMemcpyHostToDevice, s));
+    LF_HIP_CHECK(h, hipEventRecord(J.staged, s));
+    J.staged_pending = true;
+    uint8_t* d_out = frames;
+    const size_t out_bytes = (size_t)n_frames * rows * cols * 3;
+    if (!frames_on_device) {
+        if ((rc = ensure(h, J.out, out_bytes)) != LF_OK) return rc;
+        d_out = static_cast<uint8_t*>(J.out.p);
+    }
+    {
+        StageTimer t(h, ST_JPEG);
+        launch_jpeg_decode(g, n_frames, max_blocks, reinterpret_cast<const lf::jpeg::FrameHeader*>(d_stage),
+                           reinterpret_cast<const uint32_t*>(d_stage + off_ent), reinterpret_cast<const uint32_t*>(d_stage + off_blk),
+                           static_cast<uint8_t*>(J.planes.p), d_out, s);
+    }
+    LF_HIP_CHECK(h, hipGetLastError());
+    if (!frames_on_device) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(frames, d_out, out_bytes, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+        J.staged_pending = false;
+    }
+    if (n_failed && !frame_status) {
+        lf_set_error(h, first_error, "%d of %d JPEG streams could not be decoded (first status %d)", n_failed, n_frames, first_error);
+        return LF_ERR_DECODE;
     }
     return LF_OK;
 }

@@ -87,14 +87,21 @@ class FrontEnd(object):
         self._check(self.lib.lf_synchronize(self.h))
 
     # ------------------------------------------------------------------ host arrays
-    def process_batch(self, frames, describe=True):
-        """frames: uint8 (n, in_rows, in_cols, 3) BGR.  Returns a host `Segments`."""
-        frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        if frames.ndim == 3:
-            frames = frames[None]
-        n = frames.shape[0]
-        if frames.shape[1:] != (self.in_rows, self.in_cols, 3):
-            raise ValueError("frames must be (n,%d,%d,3), got %r" % (self.in_rows, self.in_cols, frames.shape))
+    def process_batch(self, frames, describe=True, n_frames=None):
+        """frames: uint8 (n, in_rows, in_cols, 3) BGR on the host -- or, with n_frames given, the device
+        address of such a block (e.g. frames_buffer() filled by decode_jpeg_batch).  Returns a host `Segments`."""
+        on_device = n_frames is not None
+        if on_device:
+            n = int(n_frames)
+            frames_arg = ctypes.c_void_p(int(frames))
+        else:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
+            if frames.ndim == 3:
+                frames = frames[None]
+            n = frames.shape[0]
+            if frames.shape[1:] != (self.in_rows, self.in_cols, 3):
+                raise ValueError("frames must be (n,%d,%d,3), got %r" % (self.in_rows, self.in_cols, frames.shape))
+            frames_arg = _ptr(frames)
         cap = n * 3 * self.cap_lines
         out = Segments()
         out.frame_offset = np.zeros(n + 1, np.int32)
@@ -113,7 +120,7 @@ class FrontEnd(object):
         if describe:
             s.desc, s.code = out.desc.ctypes.data, out.code.ctypes.data
         total = ctypes.c_int()
-        self._check(self.lib.lf_process_batch(self.h, _ptr(frames), n, 0, ctypes.byref(s), 0, int(bool(describe)),
+        self._check(self.lib.lf_process_batch(self.h, frames_arg, n, int(on_device), ctypes.byref(s), 0, int(bool(describe)),
                                               ctypes.byref(total)))
         t = total.value
         out.n = t
@@ -174,6 +181,37 @@ class FrontEnd(object):
         dist = np.empty(q.shape[0], np.float32)
         self._check(self.lib.lf_associate_float(self.h, _ptr(q), q.shape[0], _ptr(m), m.shape[0], _ptr(idx), _ptr(dist), 0))
         return idx, dist
+
+    # ------------------------------------------------------------------ host ingest (JPEG)
+    def decode_jpeg_batch(self, streams, rows=None, cols=None, n_threads=0, device_ptr=None):
+        """Decode a list of JPEG byte strings (what CompressedImage.data carries) into BGR frames --
+        the batched form of duckietown_utils.jpg.image_cv_from_jpg = cv2.imdecode(data, IMREAD_COLOR)
+        (ref: duckietown_utils/jpg.py:21-31).  Huffman decoding on host threads, everything else on the GPU.
+
+        device_ptr None: returns (frames u8 [n, rows, cols, 3] on the host, status int32 [n]);
+        device_ptr = a device address: frames are written there (asynchronously on the handle's stream)
+        and only status is returned.  Frames whose status is not 0 are zeros (the reference drops them)."""
+        n = len(streams)
+        rows = self.cfg["in_size"][0] if rows is None else rows
+        cols = self.cfg["in_size"][1] if cols is None else cols
+        bufs = [np.frombuffer(bytes(b), np.uint8) for b in streams]
+        ptrs = (ctypes.c_void_p * n)(*[b.ctypes.data if b.size else None for b in bufs])
+        sizes = (ctypes.c_size_t * n)(*[b.size for b in bufs])
+        status = np.zeros(n, np.int32)
+        st = status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        if device_ptr is None:
+            out = np.empty((n, rows, cols, 3), np.uint8)
+            self._check(self.lib.lf_jpeg_decode_batch(self.h, ptrs, sizes, n, rows, cols, _ptr(out), 0, n_threads, st))
+            return out, status
+        self._check(self.lib.lf_jpeg_decode_batch(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), 1,
+                                                  n_threads, st))
+        return status
+
+    def frames_buffer(self):
+        """(device address, bytes) of the handle's own input staging buffer ([max_frames][in_rows][in_cols][3])."""
+        p, nb = ctypes.c_void_p(), ctypes.c_size_t()
+        self._check(self.lib.lf_frames_buffer(self.h, ctypes.byref(p), ctypes.byref(nb)))
+        return p.value, nb.value
 
     # ------------------------------------------------------------------ introspection
     def fetch(self, buffer_id, n_frames):

@@ -135,6 +135,7 @@ int lfo_process_frame(const lfo_config* c, const uint8_t* bgr_in, lfo_frame_out*
  * 0 ok, -6 corrupt, -5 unsupported stream.  bgr: rows x cols x 3 for the size lfo_jpeg_info reports. */
 int lfo_jpeg_info(const uint8_t* data, size_t size, int* rows, int* cols, int* ncomp, int* hmax, int* vmax);
 int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr);
+int lfo_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* qcoef, int cap_blocks, int* n_blocks);
 
 #ifdef __cplusplus
 }

@@ -375,8 +375,9 @@ int lfo_jpeg_info(const uint8_t* data, size_t size, int* rows, int* cols, int* n
     return JERR_OK;
 }
 
-/* bgr: rows x cols x 3, caller allocated for the size lfo_jpeg_info reports */
-int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
+/* bgr: rows x cols x 3, caller allocated for the size lfo_jpeg_info reports (NULL: skip the pixels);
+ * qcoef: optional dump of the QUANTISED coefficients, [block in scan order][64 natural order] */
+static int decode_impl(const uint8_t* data, size_t size, uint8_t* bgr, int16_t* qcoef, int cap_blocks, int* n_blocks)
 {
     jpeg_t j;
     int rc = parse_headers(data, size, &j);
@@ -395,6 +396,7 @@ int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
     bits_t b = { j.scan, j.end, 0, 0, 0 };
     int next_rst = 0;
     long mcu_index = 0;
+    long block_index = 0;
     for (int my = 0; my < mcuy && rc == JERR_OK; ++my) {
         for (int mx = 0; mx < mcux && rc == JERR_OK; ++mx, ++mcu_index) {
             if (j.restart && mcu_index > 0 && mcu_index % j.restart == 0) {
@@ -414,6 +416,9 @@ int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
                         if (s < 0 || s > 11) { rc = JERR_CORRUPT; break; }
                         const int diff = s ? extend(receive(&b, s), s) : 0;
                         cp->pred += diff;
+                        int16_t* qd = (qcoef && block_index < cap_blocks) ? qcoef + block_index * 64 : NULL;
+                        if (qd) { memset(qd, 0, 64 * sizeof(int16_t)); qd[0] = (int16_t)cp->pred; }
+                        ++block_index;
                         coef[0] = MULW((int16_t)cp->pred, j.qt[cp->tq][0]);
                         for (int k = 1; k < 64;) {
                             const int rs = huff_symbol(&b, &j.ac[cp->ta]);
@@ -428,6 +433,7 @@ int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
                             if (k > 63) { rc = JERR_CORRUPT; break; }
                             const int val = extend(receive(&b, sz), sz);
                             coef[kNatural[k]] = MULW((int16_t)val, j.qt[cp->tq][kNatural[k]]);
+                            if (qd) qd[kNatural[k]] = (int16_t)val;
                             ++k;
                         }
                         if (b.bad) rc = JERR_CORRUPT;
@@ -438,7 +444,8 @@ int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
             }
         }
     }
-    if (rc == JERR_OK) {
+    if (n_blocks) *n_blocks = (int)block_index;
+    if (rc == JERR_OK && bgr) {
         /* libjpeg's YCbCr -> RGB constants: 16-bit fixed point, rounded once per table entry */
         const int32_t c_r = (int32_t)(1.40200 * 65536 + 0.5), c_b = (int32_t)(1.77200 * 65536 + 0.5);
         const int32_t c_gr = (int32_t)(0.71414 * 65536 + 0.5), c_gb = (int32_t)(0.34414 * 65536 + 0.5);
@@ -459,4 +466,16 @@ int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
     }
     for (int c = 0; c < j.ncomp; ++c) free(j.comp[c].plane);
     return rc;
+}
+
+int lfo_jpeg_decode(const uint8_t* data, size_t size, uint8_t* bgr)
+{
+    return decode_impl(data, size, bgr, NULL, 0, NULL);
+}
+
+/* quantised coefficients of every 8x8 block in scan (MCU) order, natural order inside a block: what
+ * the product's host-side entropy decoder must reproduce (tests/test_jpeg_host.py) */
+int lfo_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* qcoef, int cap_blocks, int* n_blocks)
+{
+    return decode_impl(data, size, NULL, qcoef, cap_blocks, n_blocks);
 }

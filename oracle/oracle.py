@@ -318,6 +318,23 @@ def jpeg_decode(data):
     return out
 
 
+def jpeg_coefficients(data):
+    """Quantised coefficients int16 [blocks in scan order][64 natural order] (host-decoder check)."""
+    lib = _jpeg_lib()
+    rows, cols, ncomp, hmax, vmax = jpeg_info(data)
+    mcux = (cols + 8 * hmax - 1) // (8 * hmax)
+    mcuy = (rows + 8 * vmax - 1) // (8 * vmax)
+    nblocks = mcux * mcuy * (1 if ncomp == 1 else hmax * vmax + 2)
+    buf = np.frombuffer(bytes(data), np.uint8)
+    out = np.zeros((nblocks, 64), np.int16)
+    n = ctypes.c_int()
+    lib.lfo_jpeg_coefficients.restype = ctypes.c_int
+    rc = lib.lfo_jpeg_coefficients(_p(buf), ctypes.c_size_t(buf.size), _p(out), nblocks, ctypes.byref(n))
+    if rc != 0 or n.value != nblocks:
+        raise ValueError("Could not decode image (oracle rc %d)" % rc)
+    return out
+
+
 def detmath_lib():
     build()
     return ctypes.CDLL(_SO)

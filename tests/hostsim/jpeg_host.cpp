@@ -1,0 +1,31 @@
+// Test harness only: exposes the product's host-side JPEG entropy decoder
+// (lane_slam_amd/csrc/jpeg_entropy.cpp) so tests/test_jpeg_host.py can compare its sparse
+// coefficient lists with the oracle's dense dump on the CPU.  Not part of the product.
+#include <cstring>
+
+#include "../../lane_slam_amd/csrc/jpeg_entropy.cpp"
+
+extern "C" int hs_jpeg_peek(const uint8_t* d, size_t n, int* rows, int* cols, int* ncomp, int* hmax, int* vmax)
+{
+    return lf::jpeg::peek(d, n, rows, cols, ncomp, hmax, vmax);
+}
+
+// dense: int16 [cap_blocks][64], natural order; qt: uint16 [3][64]; returns lf_status
+extern "C" int hs_jpeg_coefficients(const uint8_t* d, size_t n, int16_t* dense, int cap_blocks, int* n_blocks,
+                                    uint16_t* qt, int* layout /* ncomp, hmax, vmax, mcux, mcuy, is_rgb */, long* n_entries)
+{
+    lf::jpeg::FrameCoefs fc;
+    const int rc = lf::jpeg::decode_coefficients(d, n, fc);
+    *n_blocks = fc.hdr.nblocks;
+    if (rc != 0) return rc;
+    std::memcpy(qt, fc.hdr.qt, sizeof(fc.hdr.qt));
+    layout[0] = fc.hdr.ncomp; layout[1] = fc.hdr.hmax; layout[2] = fc.hdr.vmax;
+    layout[3] = fc.hdr.mcux; layout[4] = fc.hdr.mcuy; layout[5] = fc.hdr.is_rgb;
+    *n_entries = (long)fc.n_entries;
+    std::memset(dense, 0, sizeof(int16_t) * 64 * (size_t)cap_blocks);
+    for (int b = 0; b < fc.hdr.nblocks && b < cap_blocks; ++b) {
+        const uint32_t e0 = b ? fc.block_end[(size_t)b - 1] : 0u, e1 = fc.block_end[(size_t)b];
+        for (uint32_t e = e0; e < e1; ++e) dense[(size_t)b * 64 + (fc.entries[e] >> 16)] = (int16_t)(fc.entries[e] & 0xffffu);
+    }
+    return 0;
+}

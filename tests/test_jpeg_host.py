@@ -1,0 +1,72 @@
+"""CPU check of the product's host-side JPEG entropy decoder (lane_slam_amd/csrc/jpeg_entropy.cpp,
+built into a test harness by tests/hostsim/jpeg_host.cpp): its sparse coefficient lists must equal the
+oracle's dense coefficient dump for every golden stream, and it must refuse what the oracle refuses.
+The device half (IDCT, upsampling, colour) is covered by the -m gpu tests."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def host():
+    so = os.path.join(HERE, "hostsim", "_build", "libjpeghost.so")
+    src = os.path.join(HERE, "hostsim", "jpeg_host.cpp")
+    deps = [src] + [os.path.join(HERE, "..", "lane_slam_amd", "csrc", f) for f in ("jpeg_entropy.cpp", "jpeg_entropy.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-o", so, src])
+    lib = ctypes.CDLL(so)
+    lib.hs_jpeg_coefficients.restype = ctypes.c_int
+    lib.hs_jpeg_peek.restype = ctypes.c_int
+    return lib
+
+
+@pytest.fixture(scope="module")
+def vectors(golden_dir):
+    return np.load(os.path.join(golden_dir, "jpeg_vectors.npz"))
+
+
+def _coefs(lib, data, cap=1 << 16):
+    buf = np.frombuffer(bytes(data), np.uint8)
+    dense = np.zeros((cap, 64), np.int16)
+    qt = np.zeros((3, 64), np.uint16)
+    layout = (ctypes.c_int * 6)()
+    nb, ne = ctypes.c_int(), ctypes.c_long()
+    rc = lib.hs_jpeg_coefficients(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.size),
+                                  dense.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(nb),
+                                  qt.ctypes.data_as(ctypes.c_void_p), layout, ctypes.byref(ne))
+    return rc, dense[: nb.value], list(layout), ne.value
+
+
+def test_host_entropy_decoder_matches_oracle_coefficients(host, vectors):
+    from oracle.oracle import jpeg_coefficients, jpeg_info
+    for name in [str(n) for n in vectors["names"]]:
+        data = bytes(vectors["jpeg_" + name])
+        rc, dense, layout, n_entries = _coefs(host, data)
+        assert rc == 0, name
+        ref = jpeg_coefficients(data)
+        assert dense.shape == ref.shape and np.array_equal(dense, ref), name
+        assert n_entries == int(np.count_nonzero(ref)), name              # the lists hold the non-zeros and nothing else
+        rows, cols, ncomp, hmax, vmax = jpeg_info(data)
+        assert layout[:3] == [ncomp, hmax, vmax]
+        assert layout[3] == -(-cols // (8 * hmax)) and layout[4] == -(-rows // (8 * vmax))
+
+
+def test_host_decoder_refuses_bad_streams(host, vectors):
+    LF_ERR_UNSUPPORTED, LF_ERR_DECODE = -5, -6
+    assert _coefs(host, bytes(vectors["jpeg_progressive"]))[0] == LF_ERR_UNSUPPORTED
+    assert _coefs(host, bytes(vectors["jpeg_truncated"]))[0] == LF_ERR_DECODE
+    good = bytes(vectors["jpeg_lane_q75_420"])
+    for junk in (b"\xff\xd8", b"garbage", good[:100], good[:-200]):
+        assert _coefs(host, junk)[0] in (LF_ERR_DECODE, LF_ERR_UNSUPPORTED)
+    # a flipped bit inside the entropy data must never crash; it either still parses or is refused
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        b = bytearray(good)
+        b[int(rng.integers(len(good) // 2, len(good) - 2))] ^= 1 << int(rng.integers(0, 8))
+        assert _coefs(host, bytes(b))[0] in (0, LF_ERR_DECODE, LF_ERR_UNSUPPORTED)
