@@ -382,5 +382,52 @@ int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out)
     return LF_OK;
 }
 
+WorkerPool::~WorkerPool()
+{
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = true;
+    }
+    start_.notify_all();
+    for (std::thread& t : threads_) t.join();
+}
+
+void WorkerPool::loop(int id)
+{
+    unsigned long seen = 0;
+    for (;;) {
+        const std::function<void(int)>* job = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            start_.wait(lk, [&] { return stop_ || generation_ != seen; });
+            if (stop_) return;
+            seen = generation_;
+            if (id < active_) job = job_;
+        }
+        if (job) {
+            (*job)(id);
+            std::lock_guard<std::mutex> lk(m_);
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+}
+
+void WorkerPool::run(int n_workers, const std::function<void(int)>& job)
+{
+    if (n_workers <= 1) { job(0); return; }
+    while ((int)threads_.size() < n_workers) {
+        const int id = (int)threads_.size();
+        threads_.emplace_back([this, id] { loop(id); });
+    }
+    std::unique_lock<std::mutex> lk(m_);
+    job_ = &job;
+    active_ = n_workers;
+    pending_ = n_workers;
+    ++generation_;
+    start_.notify_all();
+    done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+}
+
 }  // namespace jpeg
 }  // namespace lf

@@ -8,8 +8,12 @@
 // IMREAD_COLOR) (ref: src/duckietown/include/duckietown_utils/jpg.py:21-31), i.e. libjpeg-turbo's
 // default decoder (ITU-T T.81 baseline sequential Huffman).
 #pragma once
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 namespace lf {
@@ -44,6 +48,28 @@ int peek(const uint8_t* data, size_t size, int* rows, int* cols, int* ncomp, int
 // Parse and entropy-decode one stream.  Returns the frame's lf_status (also stored in out.status);
 // on failure out.hdr.valid = 0 and the coefficient lists are empty.
 int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out);
+
+// Persistent host threads for the per-frame work (entropy decoding, packing the staging buffer):
+// run(n, job) executes job(worker) on n workers and returns when all are done.  Threads are created
+// once and parked on a condition variable between calls.
+class WorkerPool {
+public:
+    WorkerPool() = default;
+    ~WorkerPool();
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+    void run(int n_workers, const std::function<void(int)>& job);
+
+private:
+    void loop(int id);
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable start_, done_;
+    const std::function<void(int)>* job_ = nullptr;
+    unsigned long generation_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
 
 }  // namespace jpeg
 }  // namespace lf

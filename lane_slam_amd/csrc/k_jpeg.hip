@@ -137,48 +137,121 @@ __device__ __forceinline__ int chroma_at(const uint8_t* pl, int Wp, int hm, int 
 
 __device__ __forceinline__ uint32_t clamp255(int v) { return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
+// Eight consecutive chroma samples for output pixels x0 .. x0+7 of row y (x0 % 8 == 0, cols % 8 == 0, so
+// the four source samples of a 2:1 plane are one aligned dword and only the two outer neighbours need
+// single-byte loads).  Same arithmetic as chroma_at.
+__device__ __forceinline__ void chroma8(const uint8_t* pl, int Wp, int hm, int vm, int dw, int dh, int x0, int y, int out[8])
+{
+    if (hm == 1) {
+        const uint2 w = *reinterpret_cast<const uint2*>(pl + (size_t)y * Wp + x0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { out[i] = (int)((w.x >> (8 * i)) & 255u); out[4 + i] = (int)((w.y >> (8 * i)) & 255u); }
+        return;
+    }
+    const int c0 = x0 >> 1;
+    int s[6];                                     // samples (2x1) or column sums 3*near + far (2x2) for c0-1 .. c0+4
+    if (vm == 1) {
+        const uint8_t* in = pl + (size_t)y * Wp;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(in + c0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[1 + i] = (int)((w >> (8 * i)) & 255u);
+        s[0] = c0 > 0 ? in[c0 - 1] : 0;
+        s[5] = c0 + 4 < dw ? in[c0 + 4] : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cc = c0 + i;
+            out[2 * i] = cc == 0 ? s[1] : (3 * s[1 + i] + s[i] + 1) >> 2;
+            out[2 * i + 1] = cc == dw - 1 ? s[1 + i] : (3 * s[1 + i] + s[2 + i] + 2) >> 2;
+        }
+        return;
+    }
+    const int r = y >> 1;
+    int rn = (y & 1) ? r + 1 : r - 1;
+    rn = rn < 0 ? 0 : (rn > dh - 1 ? dh - 1 : rn);
+    const uint8_t* in0 = pl + (size_t)r * Wp;
+    const uint8_t* in1 = pl + (size_t)rn * Wp;
+    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(in0 + c0);
+    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(in1 + c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[1 + i] = 3 * (int)((w0 >> (8 * i)) & 255u) + (int)((w1 >> (8 * i)) & 255u);
+    s[0] = c0 > 0 ? 3 * in0[c0 - 1] + in1[c0 - 1] : 0;
+    s[5] = c0 + 4 < dw ? 3 * in0[c0 + 4] + in1[c0 + 4] : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + i;
+        out[2 * i] = cc == 0 ? (s[1] * 4 + 8) >> 4 : (s[1 + i] * 3 + s[i] + 8) >> 4;
+        out[2 * i + 1] = cc == dw - 1 ? (s[1 + i] * 4 + 7) >> 4 : (s[1 + i] * 3 + s[2 + i] + 7) >> 4;
+    }
+}
+
 }  // namespace
 
-// frames: [frame][rows][cols][3] u8 BGR.  One thread = 4 horizontally adjacent pixels.
+// frames: [frame][rows][cols][3] u8 BGR.  One thread = 8 horizontally adjacent pixels (24 output bytes).
 __global__ __launch_bounds__(256) void k_jpeg_color(JpegGeom g, const jpeg::FrameHeader* __restrict__ hdrs,
                                                     const uint8_t* __restrict__ planes, uint8_t* __restrict__ frames)
 {
     const int f = blockIdx.z, y = blockIdx.y;
-    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (x0 >= g.cols) return;
     const jpeg::FrameHeader* H = hdrs + f;
     uint8_t* out = frames + ((size_t)f * g.rows + y) * g.cols * 3 + (size_t)x0 * 3;
-    const int npx = g.cols - x0 < 4 ? g.cols - x0 : 4;
-    uint32_t px[4][3];
+    const int npx = g.cols - x0 < 8 ? g.cols - x0 : 8;
+    uint32_t px[8][3];
     if (!H->valid) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) px[i][0] = px[i][1] = px[i][2] = 0u;
+        for (int i = 0; i < 8; ++i) px[i][0] = px[i][1] = px[i][2] = 0u;
     } else {
         const size_t plane = (size_t)g.Hp * g.Wp;
         const uint8_t* pY = planes + (size_t)f * 3 * plane;
         const int hm = H->hmax, vm = H->vmax;
         const int dw = (g.cols + hm - 1) / hm, dh = (g.rows + vm - 1) / vm;
+        int Y[8], u[8], v[8];
+        const bool fast = (g.cols & 7) == 0 && dw > 2;
+        if (fast) {
+            const uint2 w = *reinterpret_cast<const uint2*>(pY + (size_t)y * g.Wp + x0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { Y[i] = (int)((w.x >> (8 * i)) & 255u); Y[4 + i] = (int)((w.y >> (8 * i)) & 255u); }
+            if (H->ncomp == 3) {
+                chroma8(pY + plane, g.Wp, hm, vm, dw, dh, x0, y, u);
+                chroma8(pY + 2 * plane, g.Wp, hm, vm, dw, dh, x0, y, v);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int x = x0 + i < g.cols ? x0 + i : g.cols - 1;
+                Y[i] = pY[(size_t)y * g.Wp + x];
+                u[i] = v[i] = 0;
+                if (H->ncomp == 3) {
+                    u[i] = chroma_at(pY + plane, g.Wp, hm, vm, dw, dh, x, y);
+                    v[i] = chroma_at(pY + 2 * plane, g.Wp, hm, vm, dw, dh, x, y);
+                }
+            }
+        }
         // libjpeg's constants: FIX(1.40200), FIX(1.77200), FIX(0.71414), FIX(0.34414) at 16 bits
         const int c_r = 91881, c_b = 116130, c_gr = 46802, c_gb = 22554;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int x = x0 + i < g.cols ? x0 + i : g.cols - 1;
-            const int Y = pY[(size_t)y * g.Wp + x];
-            if (H->ncomp == 1) { px[i][0] = px[i][1] = px[i][2] = (uint32_t)Y; continue; }
-            const int u = chroma_at(pY + plane, g.Wp, hm, vm, dw, dh, x, y);
-            const int v = chroma_at(pY + 2 * plane, g.Wp, hm, vm, dw, dh, x, y);
-            if (H->is_rgb) { px[i][2] = (uint32_t)Y; px[i][1] = (uint32_t)u; px[i][0] = (uint32_t)v; continue; }
-            const int cb = u - 128, cr = v - 128;
-            px[i][2] = clamp255(Y + ((c_r * cr + 32768) >> 16));
-            px[i][1] = clamp255(Y + ((-c_gb * cb + 32768 - c_gr * cr) >> 16));
-            px[i][0] = clamp255(Y + ((c_b * cb + 32768) >> 16));
+        for (int i = 0; i < 8; ++i) {
+            if (H->ncomp == 1) { px[i][0] = px[i][1] = px[i][2] = (uint32_t)Y[i]; continue; }
+            if (H->is_rgb) { px[i][2] = (uint32_t)Y[i]; px[i][1] = (uint32_t)u[i]; px[i][0] = (uint32_t)v[i]; continue; }
+            const int cb = u[i] - 128, cr = v[i] - 128;
+            px[i][2] = clamp255(Y[i] + ((c_r * cr + 32768) >> 16));
+            px[i][1] = clamp255(Y[i] + ((-c_gb * cb + 32768 - c_gr * cr) >> 16));
+            px[i][0] = clamp255(Y[i] + ((c_b * cb + 32768) >> 16));
         }
     }
-    if (npx == 4 && (g.cols & 3) == 0) {
-        uint32_t* o = reinterpret_cast<uint32_t*>(out);        // 12 bytes, 4-byte aligned when cols % 4 == 0
-        o[0] = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
-        o[1] = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
-        o[2] = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+    if (npx == 8 && (g.cols & 7) == 0) {
+        uint32_t o[6];                                           // 24 bytes, 8-byte aligned when cols % 8 == 0
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int b = 4 * q;
+            o[3 * q + 0] = px[b][0] | (px[b][1] << 8) | (px[b][2] << 16) | (px[b + 1][0] << 24);
+            o[3 * q + 1] = px[b + 1][1] | (px[b + 1][2] << 8) | (px[b + 2][0] << 16) | (px[b + 2][1] << 24);
+            o[3 * q + 2] = px[b + 2][2] | (px[b + 3][0] << 8) | (px[b + 3][1] << 16) | (px[b + 3][2] << 24);
+        }
+        uint2* o2 = reinterpret_cast<uint2*>(out);
+        o2[0] = make_uint2(o[0], o[1]);
+        o2[1] = make_uint2(o[2], o[3]);
+        o2[2] = make_uint2(o[4], o[5]);
     } else {
         for (int i = 0; i < npx; ++i) {
             out[3 * i + 0] = (uint8_t)px[i][0];
@@ -197,7 +270,7 @@ void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const j
         hipLaunchKernelGGL(k_jpeg_idct, grid, dim3(256), 0, s, g, hdrs, entries, block_end, planes);
     }
     const int tx = 64;
-    const dim3 cgrid((unsigned)((g.cols + 4 * tx - 1) / (4 * tx)), (unsigned)g.rows, (unsigned)n_frames);
+    const dim3 cgrid((unsigned)((g.cols + 8 * tx - 1) / (8 * tx)), (unsigned)g.rows, (unsigned)n_frames);
     hipLaunchKernelGGL(k_jpeg_color, cgrid, dim3(tx), 0, s, g, hdrs, planes, frames);
 }
 

@@ -9,7 +9,9 @@
 #include <vector>
 #include <new>
 #include <atomic>
-#include <thread>
+#include <chrono>
+#include <cstdlib>
+#include <functional>
 #include "common.h"
 #include "jpeg_entropy.h"
 
@@ -28,6 +30,7 @@ struct DevBuf {
 
 // JPEG ingest state (allocated on first use, grown on demand)
 struct JpegState {
+    lf::jpeg::WorkerPool pool;                      // persistent host threads
     std::vector<lf::jpeg::FrameCoefs> frames;       // per-frame host coefficient lists (capacity is kept)
     int rows = 0, cols = 0, max_frames = 0;         // geometry the planes were sized for
     DevBuf planes, entries, block_end, hdrs, out;   // device
@@ -892,6 +895,11 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
     }
     JpegState& J = *h->jpeg;
     hipStream_t s = h->stream;
+    static const bool trace = getenv("LF_JPEG_TRACE") != nullptr;       // diagnostic: per-phase host times on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
+    const auto t_begin = now();
+    double t_decode = 0, t_wait = 0, t_pack = 0;
     if ((int)J.frames.size() < n_frames) J.frames.resize((size_t)n_frames);
 
     // ---- host: entropy decoding, one frame per task
@@ -899,7 +907,7 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
     if (nt > n_frames) nt = n_frames;
     {
         std::atomic<int> next(0);
-        auto work = [&]() {
+        J.pool.run(nt, [&](int) {
             for (;;) {
                 const int i = next.fetch_add(1);
                 if (i >= n_frames) break;
@@ -911,15 +919,9 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
                     fc.hdr.valid = 0; fc.hdr.nblocks = 0; fc.n_entries = 0;
                 }
             }
-        };
-        if (nt <= 1) work();
-        else {
-            std::vector<std::thread> pool;
-            pool.reserve((size_t)nt);
-            for (int t = 0; t < nt; ++t) pool.emplace_back(work);
-            for (std::thread& t : pool) t.join();
-        }
+        });
     }
+    t_decode = ms_since(t_begin);
     // ---- layout of the batch
     size_t total_entries = 0, total_blocks = 0;
     int max_blocks = 0, n_failed = 0, first_error = LF_OK;
@@ -940,7 +942,9 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
     const size_t off_blk = (hdr_bytes + 255) & ~(size_t)255, off_ent = (off_blk + blk_bytes + 255) & ~(size_t)255;
     const size_t stage_bytes = off_ent + ent_bytes;
     // the previous call's copy out of the staging buffer must have completed before it is rewritten
+    const auto t_w = now();
     if (J.staged_pending) { LF_HIP_CHECK(h, hipEventSynchronize(J.staged)); J.staged_pending = false; }
+    t_wait = ms_since(t_w);
     if (J.h_stage_bytes < stage_bytes) {
         if (J.h_stage) (void)hipHostFree(J.h_stage);
         J.h_stage = nullptr; J.h_stage_bytes = 0;
@@ -948,15 +952,23 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
         LF_HIP_CHECK(h, hipHostMalloc(&J.h_stage, want, hipHostMallocDefault));
         J.h_stage_bytes = want;
     }
+    const auto t_p = now();
     {
+        // pack headers | block ends | entries into the pinned staging buffer, frames in parallel
         uint8_t* st = static_cast<uint8_t*>(J.h_stage);
-        for (int i = 0; i < n_frames; ++i) {
-            const lf::jpeg::FrameCoefs& fc = J.frames[(size_t)i];
-            memcpy(st + (size_t)i * sizeof(lf::jpeg::FrameHeader), &fc.hdr, sizeof(lf::jpeg::FrameHeader));
-            if (fc.hdr.nblocks) memcpy(st + off_blk + (size_t)fc.hdr.block_base * 4, fc.block_end.data(), (size_t)fc.hdr.nblocks * 4);
-            if (fc.n_entries) memcpy(st + off_ent + (size_t)fc.hdr.entry_base * 4, fc.entries.data(), fc.n_entries * 4);
-        }
+        std::atomic<int> next(0);
+        J.pool.run(nt, [&](int) {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= n_frames) break;
+                const lf::jpeg::FrameCoefs& fc = J.frames[(size_t)i];
+                memcpy(st + (size_t)i * sizeof(lf::jpeg::FrameHeader), &fc.hdr, sizeof(lf::jpeg::FrameHeader));
+                if (fc.hdr.nblocks) memcpy(st + off_blk + (size_t)fc.hdr.block_base * 4, fc.block_end.data(), (size_t)fc.hdr.nblocks * 4);
+                if (fc.n_entries) memcpy(st + off_ent + (size_t)fc.hdr.entry_base * 4, fc.entries.data(), fc.n_entries * 4);
+            }
+        });
     }
+    t_pack = ms_since(t_p);
     // ---- device
     JpegGeom g;
     g.rows = rows; g.cols = cols;
@@ -987,6 +999,9 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
         LF_HIP_CHECK(h, hipStreamSynchronize(s));
         J.staged_pending = false;
     }
+    if (trace)
+        fprintf(stderr, "lf_jpeg_decode_batch: %d frames, %d threads: decode %.2f ms, wait %.2f, pack %.2f (%.1f MB), total host %.2f ms\n",
+                n_frames, nt, t_decode, t_wait, t_pack, stage_bytes / 1e6, ms_since(t_begin));
     if (n_failed && !frame_status) {
         lf_set_error(h, first_error, "%d of %d JPEG streams could not be decoded (first status %d)", n_failed, n_frames, first_error);
         return LF_ERR_DECODE;
