@@ -186,6 +186,32 @@ int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, in
  * into it, then hand the same pointer to lf_process_batch with frames_on_device = 1 */
 int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* bytes);
 
+/* ---- SegmentList glue ---------------------------------------------------------------
+ * The reference hands segments from node to node as duckietown_msgs/SegmentList and builds / walks them one
+ * Python object at a time (line_detector_node.py:251-265 toSegmentMsg, ground_projection_node.py:55-65,
+ * line_sanity_node.py:48-72).  These two calls convert between the struct-of-arrays block and the ROS 1 wire
+ * form of `duckietown_msgs/Segment[] segments` (src/duckietown_msgs/msg/Segment.msg:1-8, Vector2D.msg:1-2,
+ * geometry_msgs/Point): little endian, u32 count, then 73 bytes per segment
+ *   u8 color | f32 pixels_normalized[0].x .y [1].x .y | f32 normal.x .y | f64 points[0].x .y .z [1].x .y .z
+ * so a node publishes  serialised Header + body  without touching a segment in Python.
+ *   LF_MSG_DETECTOR  what line_detector_node publishes: color, pixels_normalized, normal (points 0)
+ *   LF_MSG_GROUND    what ground_projection_node publishes: color, points with z = 0 (the rest 0)
+ *   LF_MSG_FILTERED  what line_sanity_node publishes: the LF_MSG_GROUND segments with keep == 1, order kept
+ * lf_serialize_segments: segs needs frame_offset, color and the stage's arrays (host or device pointers, all
+ *   the same kind); out receives the n_frames bodies back to back, frame_byte_offset[n_frames + 1] (host) where
+ *   each starts.  LF_ERR_CAPACITY if out_capacity is too small (frame_byte_offset[n_frames] then holds the need).
+ * lf_deserialize_segments: the inverse, every field of the message is kept (frame_offset, color,
+ *   pixels_normalized, normals, ground x/y of the two points; NULL arrays are skipped); LF_ERR_DECODE if a
+ *   body's count does not match its length.
+ */
+#define LF_MSG_DETECTOR 0
+#define LF_MSG_GROUND 1
+#define LF_MSG_FILTERED 2
+int lf_serialize_segments(lf_handle* h, const lf_segments* segs, int segs_on_device, int n_frames, int stage,
+                          uint8_t* out, size_t out_capacity, int out_on_device, int64_t* frame_byte_offset);
+int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int bodies_on_device, const int64_t* frame_byte_offset,
+                            int n_frames, lf_segments* out, int out_on_device, int* n_segments);
+
 /* ---- introspection for tests and the benchmark ---------------------------- */
 typedef enum lf_buffer_id {
     LF_BUF_BGR = 0,          /* u8  [frames][Hc][W][3]   corrected working image          */

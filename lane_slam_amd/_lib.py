@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("LANEFRONT_LIBRARY") or os.path.join(_HERE, "liblanefront.so")
 
 LF_N_STAGES = 13
+LF_MSG_DETECTOR, LF_MSG_GROUND, LF_MSG_FILTERED = 0, 1, 2
 (LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,
  LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS, LF_BUF_LSD_SCRATCH) = range(11)
 
@@ -18,7 +19,7 @@ LF_N_STAGES = 13
 EXPORTS = (
     "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize",
     "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
-    "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer",
+    "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
 )
 
@@ -71,6 +72,12 @@ def load():
     lib.lf_jpeg_info.restype = ci
     lib.lf_frames_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
     lib.lf_frames_buffer.restype = ci
+    lib.lf_serialize_segments.argtypes = [vp, ctypes.POINTER(LfSegments), ci, ci, ci, vp, ctypes.c_size_t, ci,
+                                          ctypes.POINTER(ctypes.c_int64)]
+    lib.lf_serialize_segments.restype = ci
+    lib.lf_deserialize_segments.argtypes = [vp, vp, ci, ctypes.POINTER(ctypes.c_int64), ci, ctypes.POINTER(LfSegments), ci,
+                                            ctypes.POINTER(ci)]
+    lib.lf_deserialize_segments.restype = ci
     lib.lf_debug_fetch.argtypes = [vp, ci, vp, ctypes.c_size_t]
     lib.lf_debug_detmath.argtypes = [vp, ci, vp, vp, vp, ci]
     lib.lf_debug_detmath.restype = ci
@@ -83,7 +90,7 @@ def load():
     lib.lf_stage_name.argtypes = [ci]
     lib.lf_stage_name.restype = ctypes.c_char_p
     for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate",
-              "lf_associate_float", "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer",
+              "lf_associate_float", "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",
               "lf_reset_timing"):
         getattr(lib, f).restype = ci

@@ -123,4 +123,13 @@ void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const j
                         const uint32_t* entries, const uint32_t* block_end, uint8_t* planes, uint8_t* frames,
                         hipStream_t s);
 
+// ---- SegmentList wire bodies (k_msgs.hip)
+void launch_msg_layout(int n_frames, int stage, const int* frame_offset, const uint8_t* keep, int* counts,
+                       long long* byte_offset, hipStream_t s);
+void launch_msg_write(int n_frames, int stage, const int* frame_offset, const uint8_t* color, const float* pixels_normalized,
+                      const float* normals, const double* ground, const uint8_t* keep, const int* counts,
+                      const long long* byte_offset, uint8_t* out, hipStream_t s);
+void launch_msg_read(int n_frames, int capacity, const uint8_t* body, const long long* byte_offset, int* frame_offset,
+                     int* bad, uint8_t* color, float* pixels_normalized, float* normals, double* ground, hipStream_t s);
+
 }  // namespace lf

@@ -99,6 +99,7 @@ struct lf_handle {
     int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
     JpegState* jpeg = nullptr;
+    DevBuf m_fo, m_color, m_pn, m_nm, m_gr, m_keep, m_counts, m_boff, m_body, m_bad;   // SegmentList glue scratch
     // profiling
     bool profiling = false;
     std::vector<EvPair> ev_free, ev_used;
@@ -420,6 +421,8 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    for (DevBuf* b : { &h->m_fo, &h->m_color, &h->m_pn, &h->m_nm, &h->m_gr, &h->m_keep, &h->m_counts, &h->m_boff, &h->m_body, &h->m_bad })
+        if (b->p) (void)hipFree(b->p);
     if (h->jpeg) {
         JpegState* j = h->jpeg;
         for (DevBuf* b : { &j->planes, &j->entries, &j->block_end, &j->hdrs, &j->out }) if (b->p) (void)hipFree(b->p);
@@ -1005,6 +1008,140 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
     if (n_failed && !frame_status) {
         lf_set_error(h, first_error, "%d of %d JPEG streams could not be decoded (first status %d)", n_failed, n_frames, first_error);
         return LF_ERR_DECODE;
+    }
+    return LF_OK;
+}
+
+// ---------------------------------------------------------------------------------------- SegmentList glue
+extern "C" int lf_serialize_segments(lf_handle* h, const lf_segments* segs, int segs_on_device, int n_frames, int stage,
+                                     uint8_t* out, size_t out_capacity, int out_on_device, int64_t* frame_byte_offset)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!segs || !out || !frame_byte_offset || n_frames < 1 || stage < LF_MSG_DETECTOR || stage > LF_MSG_FILTERED || !segs->frame_offset || !segs->color) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_serialize_segments: null argument, n_frames < 1 or unknown stage");
+        return LF_ERR_BAD_ARG;
+    }
+    if (stage == LF_MSG_DETECTOR ? (!segs->pixels_normalized || !segs->normals) : (!segs->ground || (stage == LF_MSG_FILTERED && !segs->keep))) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_serialize_segments: the arrays of stage %d are missing", stage);
+        return LF_ERR_BAD_ARG;
+    }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int* d_fo = segs->frame_offset;
+    const uint8_t* d_color = segs->color;
+    const float* d_pn = segs->pixels_normalized;
+    const float* d_nm = segs->normals;
+    const double* d_gr = segs->ground;
+    const uint8_t* d_keep = segs->keep;
+    int rc;
+    if (!segs_on_device) {
+        const int total = segs->frame_offset[n_frames];
+        if (total < 0) { lf_set_error(h, LF_ERR_BAD_ARG, "negative segment count"); return LF_ERR_BAD_ARG; }
+        const size_t n = (size_t)total;
+        if ((rc = ensure(h, h->m_fo, (size_t)(n_frames + 1) * sizeof(int))) != LF_OK) return rc;
+        if ((rc = ensure(h, h->m_color, n + 1)) != LF_OK) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->m_fo.p, segs->frame_offset, (size_t)(n_frames + 1) * sizeof(int), hipMemcpyHostToDevice, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->m_color.p, segs->color, n, hipMemcpyHostToDevice, s));
+        d_fo = static_cast<const int*>(h->m_fo.p);
+        d_color = static_cast<const uint8_t*>(h->m_color.p);
+        if (stage == LF_MSG_DETECTOR) {
+            if ((rc = ensure(h, h->m_pn, n * 16 + 16)) != LF_OK) return rc;
+            if ((rc = ensure(h, h->m_nm, n * 8 + 8)) != LF_OK) return rc;
+            LF_HIP_CHECK(h, hipMemcpyAsync(h->m_pn.p, segs->pixels_normalized, n * 16, hipMemcpyHostToDevice, s));
+            LF_HIP_CHECK(h, hipMemcpyAsync(h->m_nm.p, segs->normals, n * 8, hipMemcpyHostToDevice, s));
+            d_pn = static_cast<const float*>(h->m_pn.p);
+            d_nm = static_cast<const float*>(h->m_nm.p);
+        } else {
+            if ((rc = ensure(h, h->m_gr, n * 32 + 32)) != LF_OK) return rc;
+            LF_HIP_CHECK(h, hipMemcpyAsync(h->m_gr.p, segs->ground, n * 32, hipMemcpyHostToDevice, s));
+            d_gr = static_cast<const double*>(h->m_gr.p);
+            if (stage == LF_MSG_FILTERED) {
+                if ((rc = ensure(h, h->m_keep, n + 1)) != LF_OK) return rc;
+                LF_HIP_CHECK(h, hipMemcpyAsync(h->m_keep.p, segs->keep, n, hipMemcpyHostToDevice, s));
+                d_keep = static_cast<const uint8_t*>(h->m_keep.p);
+            }
+        }
+    }
+    if ((rc = ensure(h, h->m_counts, (size_t)n_frames * sizeof(int))) != LF_OK) return rc;
+    if ((rc = ensure(h, h->m_boff, (size_t)(n_frames + 1) * sizeof(long long))) != LF_OK) return rc;
+    launch_msg_layout(n_frames, stage, d_fo, d_keep, static_cast<int*>(h->m_counts.p), static_cast<long long*>(h->m_boff.p), s);
+    static_assert(sizeof(long long) == sizeof(int64_t), "byte offsets are int64");
+    LF_HIP_CHECK(h, hipMemcpyAsync(frame_byte_offset, h->m_boff.p, (size_t)(n_frames + 1) * sizeof(long long), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    const size_t need = (size_t)frame_byte_offset[n_frames];
+    if (need > out_capacity) {
+        lf_set_error(h, LF_ERR_CAPACITY, "lf_serialize_segments: %zu bytes needed, %zu available", need, out_capacity);
+        return LF_ERR_CAPACITY;
+    }
+    uint8_t* d_out = out;
+    if (!out_on_device) {
+        if ((rc = ensure(h, h->m_body, need + 16)) != LF_OK) return rc;
+        d_out = static_cast<uint8_t*>(h->m_body.p);
+    }
+    launch_msg_write(n_frames, stage, d_fo, d_color, d_pn, d_nm, d_gr, d_keep, static_cast<const int*>(h->m_counts.p),
+                     static_cast<const long long*>(h->m_boff.p), d_out, s);
+    LF_HIP_CHECK(h, hipGetLastError());
+    if (!out_on_device) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(out, d_out, need, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
+extern "C" int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int bodies_on_device, const int64_t* frame_byte_offset,
+                                       int n_frames, lf_segments* out, int out_on_device, int* n_segments)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!bodies || !frame_byte_offset || !out || n_frames < 1 || !out->frame_offset) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_deserialize_segments: null argument or n_frames < 1");
+        return LF_ERR_BAD_ARG;
+    }
+    for (int f = 0; f < n_frames; ++f)
+        if (frame_byte_offset[f + 1] < frame_byte_offset[f] + 4) { lf_set_error(h, LF_ERR_DECODE, "body %d is shorter than its count field", f); return LF_ERR_DECODE; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t bytes = (size_t)frame_byte_offset[n_frames];
+    const size_t max_segs = bytes / 73 + 1;
+    int rc;
+    const uint8_t* d_body = bodies;
+    if (!bodies_on_device) {
+        if ((rc = ensure(h, h->m_body, bytes + 16)) != LF_OK) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->m_body.p, bodies, bytes, hipMemcpyHostToDevice, s));
+        d_body = static_cast<const uint8_t*>(h->m_body.p);
+    }
+    if ((rc = ensure(h, h->m_boff, (size_t)(n_frames + 1) * sizeof(long long))) != LF_OK) return rc;
+    if ((rc = ensure(h, h->m_bad, sizeof(int))) != LF_OK) return rc;
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->m_boff.p, frame_byte_offset, (size_t)(n_frames + 1) * sizeof(long long), hipMemcpyHostToDevice, s));
+    LF_HIP_CHECK(h, hipMemsetAsync(h->m_bad.p, 0, sizeof(int), s));
+    lf_segments dev = *out;
+    if (!out_on_device) {
+        if ((rc = ensure(h, h->m_fo, (size_t)(n_frames + 1) * sizeof(int))) != LF_OK) return rc;
+        dev.frame_offset = static_cast<int32_t*>(h->m_fo.p);
+        dev.color = nullptr; dev.pixels_normalized = nullptr; dev.normals = nullptr; dev.ground = nullptr;
+        if (out->color) { if ((rc = ensure(h, h->m_color, max_segs)) != LF_OK) return rc; dev.color = static_cast<uint8_t*>(h->m_color.p); }
+        if (out->pixels_normalized) { if ((rc = ensure(h, h->m_pn, max_segs * 16)) != LF_OK) return rc; dev.pixels_normalized = static_cast<float*>(h->m_pn.p); }
+        if (out->normals) { if ((rc = ensure(h, h->m_nm, max_segs * 8)) != LF_OK) return rc; dev.normals = static_cast<float*>(h->m_nm.p); }
+        if (out->ground) { if ((rc = ensure(h, h->m_gr, max_segs * 32)) != LF_OK) return rc; dev.ground = static_cast<double*>(h->m_gr.p); }
+    }
+    const int cap = out->capacity;
+    launch_msg_read(n_frames, cap, d_body, static_cast<const long long*>(h->m_boff.p), dev.frame_offset, static_cast<int*>(h->m_bad.p),
+                    dev.color, dev.pixels_normalized, dev.normals, dev.ground, s);
+    LF_HIP_CHECK(h, hipGetLastError());
+    int bad = 0, total = 0;
+    LF_HIP_CHECK(h, hipMemcpyAsync(&bad, h->m_bad.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(&total, dev.frame_offset + n_frames, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    if (n_segments) *n_segments = total;
+    if (bad) { lf_set_error(h, LF_ERR_DECODE, "a SegmentList body's count does not match its length"); return LF_ERR_DECODE; }
+    if (total > cap) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, cap); return LF_ERR_CAPACITY; }
+    if (!out_on_device) {
+        const size_t n = (size_t)total;
+        LF_HIP_CHECK(h, hipMemcpyAsync(out->frame_offset, dev.frame_offset, (size_t)(n_frames + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+        if (out->color && n) LF_HIP_CHECK(h, hipMemcpyAsync(out->color, dev.color, n, hipMemcpyDeviceToHost, s));
+        if (out->pixels_normalized && n) LF_HIP_CHECK(h, hipMemcpyAsync(out->pixels_normalized, dev.pixels_normalized, n * 16, hipMemcpyDeviceToHost, s));
+        if (out->normals && n) LF_HIP_CHECK(h, hipMemcpyAsync(out->normals, dev.normals, n * 8, hipMemcpyDeviceToHost, s));
+        if (out->ground && n) LF_HIP_CHECK(h, hipMemcpyAsync(out->ground, dev.ground, n * 32, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
     }
     return LF_OK;
 }
