@@ -6,13 +6,13 @@
 // bitops_custom.hpp:83-96: the exact Hamming nearest neighbour; candidates farther than
 // D = 128 are never reported (:721).  The reference's multi-index hash is a CPU
 // pointer-chasing structure rebuilt on every call; on MI355X the N x M distance matrix is
-// one dense int8 contraction: bits -> +-1 bytes, dot = 256 - 2*hamming, exactly.
+// one dense int8 contraction: bits -> +-64 bytes, dot / 4096 = 256 - 2*hamming, exactly.
 //
-// k_assoc_pack : 32-byte codes -> 256 int8 (+1 for bit 0, -1 for bit 1), zero padded rows.
-// k_assoc      : 128 queries per workgroup (4 waves x 32 rows, A fragments resident in
-//   VGPRs), map streamed through LDS in 64-entry tiles (row stride 272 B: conflict-free
-//   ds_read_b128), v_mfma_i32_32x32x32_i8 over K = 256.  Epilogue per lane:
-//   packed = (256 - dot) << 21 | map_index, running min per accumulator register -- no
+// k_assoc_pack : 32-byte codes -> 256 int8 (+64 for bit 0, -64 for bit 1), zero padded rows.
+// k_assoc      : 256 queries per workgroup (4 waves x 2 x 32 rows, A fragments resident in
+//   VGPRs; a B fragment read from LDS feeds two MFMAs), map streamed through LDS in 64-entry tiles by LDS-DMA
+//   (double buffered, source-swizzled: conflict-free ds_read_b128), v_mfma_i32_32x32x32_i8 over K = 256 plus one step that folds the column-block number into
+//   the accumulator, so the running arg-max is one v_max3 per register pair (see the kernel) -- no
 //   cross-lane traffic until the end; ties resolve to the lowest map index.  Map chunks are
 //   spread over gridDim.y and merged with atomicMin on the packed word (order free).
 //   Algorithmic ops: 2*N*M*256 int8.
@@ -25,9 +25,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int AQ = 128;        // queries per workgroup
+constexpr int QB = 2;          // 32-query row blocks per wave
+constexpr int AQ = 128 * QB;   // queries per workgroup (4 waves)
 constexpr int AM = 64;         // map entries per LDS tile
-constexpr int LROW = 272;      // LDS row stride (256 + 16 pad)
 
 __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, int n, int n_pad, int8_t* __restrict__ out)
 {
@@ -39,72 +39,125 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, int n, int n_pad
     uint32_t lo = 0, hi = 0;
     if (row < (size_t)n) {
         uint32_t b = codes[t];
-        // nibble -> 4 bytes of 0/1, then 0 -> 0x01 (+1), 1 -> 0xFF (-1)
+        // nibble -> 4 bytes of 0/1, then 0 -> 0x40 (+64), 1 -> 0xC0 (-64)
         uint32_t w0 = ((b & 15u) * 0x00204081u) & 0x01010101u;
         uint32_t w1 = ((b >> 4) * 0x00204081u) & 0x01010101u;
-        lo = (w0 * 0xFEu) ^ 0x01010101u;
-        hi = (w1 * 0xFEu) ^ 0x01010101u;
+        lo = (w0 << 7) | 0x40404040u;
+        hi = (w1 << 7) | 0x40404040u;
     }
     uint2* o = reinterpret_cast<uint2*>(out + t * 8);
     *o = make_uint2(lo, hi);
 }
 
-__global__ __launch_bounds__(256) void k_assoc(const int8_t* __restrict__ qx, int nq, const int8_t* __restrict__ mx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, int nq, const int8_t* __restrict__ mx,
                                                int nm, int nm_pad, int m_chunk, unsigned int* __restrict__ best)
 {
-    __shared__ __attribute__((aligned(16))) int8_t tile[AM * LROW];
+    __shared__ __attribute__((aligned(1024))) int8_t tile[2 * AM * 256];     // double buffered map tile, linear rows
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = blockIdx.x * AQ + wave * 32;
+    const int q0 = blockIdx.x * AQ + wave * (32 * QB);
     const int r32 = lane & 31, half = lane >> 5;
-    v4i A[8];
+    // QB row blocks of 32 queries per wave: every B fragment read from LDS feeds QB MFMAs
+    v4i A[QB][8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-        A[s] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + r32) * 256 + 32 * s + 16 * half);
-    int running[16];
+    for (int b = 0; b < QB; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) running[r] = 0x7fffffff;
+        for (int s = 0; s < 8; ++s)
+            A[b][s] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + 32 * b + r32) * 256 + 32 * s + 16 * half);
+    // Arg-max inside the matrix core.  Codes are +-64 bytes, so a chain of 8 MFMAs leaves 4096 * dot in the
+    // accumulator; a NINTH step multiplies the constant row fragment [64, 1, 0, ...] with the column fragment
+    // [-(t >> 6), -(t & 63), 0, ...], which subtracts t, the running number of the 32-column block inside this
+    // workgroup's map chunk.  key = 4096 * dot - t orders candidates by distance, then by column block, so the
+    // whole epilogue is ONE v_max3 per pair of accumulator registers: no zeroing (the chain starts from the
+    // inline constant 0), no packing, no select.  dot and t are recovered from the key at the very end.
+    v4i AX;
+    AX[0] = half == 0 ? 0x00000140 : 0;      // bytes: 64, 1, 0, 0
+    AX[1] = AX[2] = AX[3] = 0;
+    int running[QB][16];
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) running[b][r] = (int)0x80000000;
     const int m_begin = blockIdx.y * m_chunk;
     const int m_end = min(nm_pad, m_begin + m_chunk);
-    for (int m0 = m_begin; m0 < m_end; m0 += AM) {
-        __syncthreads();
+    const int n_tiles = (m_end - m_begin) / AM;
+    // Map tiles go global -> LDS directly (global_load_lds, no staging registers: this kernel lives at the
+    // register cap), one tile ahead into the other buffer, so a tile's HBM/L2 latency hides behind the MFMAs of
+    // the tile before it; one barrier per tile.  An LDS-DMA instruction writes 64 lanes x 16 B contiguously, so
+    // the LDS image is linear (4 rows of 256 B per instruction) and the bank-conflict-free layout comes from
+    // swizzling the SOURCE: 16-byte chunk c of row r is stored at chunk position c ^ (r & 15).
+    auto glds_tile = [&](int k, int buf) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-            int e = pass * 256 + threadIdx.x;       // 16-byte element index, 1024 per tile
-            int row = e >> 4, c16 = e & 15;
-            v4i v = *reinterpret_cast<const v4i*>(mx + (size_t)(m0 + row) * 256 + 16 * c16);
-            *reinterpret_cast<v4i*>(tile + row * LROW + 16 * c16) = v;
+            const int piece = pass * 4 + wave;                // 1 KB piece of the 16 KB tile
+            const int e = piece * 64 + lane, row = e >> 4, pos = e & 15;
+            const int8_t* src = mx + (size_t)(m_begin + k * AM + row) * 256 + 16 * (pos ^ (row & 15));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(tile + buf * (AM * 256) + piece * 1024),
+                                             16, 0, 0);
         }
-        __syncthreads();
+    };
+    if (n_tiles > 0) {
+        glds_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int k = 0; k < n_tiles; ++k) {
+        const int8_t* cur = tile + (k & 1) * (AM * 256);
+        if (k + 1 < n_tiles) glds_tile(k + 1, (k + 1) & 1);     // every wave left that buffer at the last barrier
+        const int t = 2 * k;                                      // 32-column block counter
+        v4i Bf[2][8];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            v16i acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0;
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                v4i B = *reinterpret_cast<const v4i*>(tile + (cb * 32 + r32) * LROW + 32 * s + 16 * half);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[s], B, acc, 0, 0, 0);
+                const int row = cb * 32 + r32, c = 2 * s + half;
+                Bf[cb][s] = *reinterpret_cast<const v4i*>(cur + row * 256 + ((c ^ (row & 15)) << 4));
             }
-            const int col = m0 + cb * 32 + r32;
-            const bool valid = col < nm;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int v = valid ? (((256 - acc[r]) << 21) | col) : 0x7fffffff;
-                running[r] = min(running[r], v);
+        for (int cb = 0; cb < 2; ++cb) {
+            const int tt = t + cb;
+            v4i BX;
+            BX[0] = half == 0 ? (((-(tt >> 6)) & 0xff) | (((-(tt & 63)) & 0xff) << 8)) : 0;
+            BX[1] = BX[2] = BX[3] = 0;
+            v16i acc[QB];
+#pragma unroll
+            for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX, BX, zero, 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[cb][s], acc[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) running[b][r] = max(running[b][r], acc[b][r]);
+        }
+        // the next tile has landed (this wave's pieces) and every wave is done with the current one
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // key -> (distance, column): dot = ceil(key / 4096), t = 4096 * dot - key; this lane's column inside block t
+    // is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
+    // column can only have displaced candidates with a negative dot, which are beyond 128 and never reported.
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = running[b][r];
+            int v = 0x7fffffff;
+            if (key != (int)0x80000000) {
+                const int dot4096 = (key + 4095) & ~4095;
+                const int col = m_begin + 32 * (dot4096 - key) + r32;
+                if (col < nm) v = (((256 << 12) - dot4096) << 9) | col;      // (256 - dot) << 21 | col
+            }
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
+            if (r32 == 0) {
+                int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                int q = q0 + 32 * b + row;
+                if (q < nq) atomicMin(best + q, (unsigned int)v);
             }
         }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        int v = running[r];
-#pragma unroll
-        for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-        if (r32 == 0) {
-            int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            int q = q0 + row;
-            if (q < nq) atomicMin(best + q, (unsigned int)v);
-        }
-    }
 }
 
 __global__ void k_assoc_finish(const unsigned int* __restrict__ best, int nq, int32_t* __restrict__ idx,
@@ -132,9 +185,12 @@ void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx
     hipLaunchKernelGGL(k_assoc_pack, dim3(((size_t)nm_pad * 32 + 255) / 256), dim3(256), 0, s, m, nm, nm_pad, mx);
     hipLaunchKernelGGL(k_fill_u32, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, 0x7fffffffu);
     const int qblocks = nq_pad / AQ;
-    // enough workgroups to cover the chip a few times over
-    int splits = (2048 + qblocks - 1) / qblocks;
+    // 2 workgroups are resident per CU (234 VGPRs): split the map so that the grid is just under two full
+    // rounds of the 512 slots -- long chunks amortise the A-fragment loads and the final cross-lane reduction
+    int splits = (2 * 512) / qblocks;
     const int tiles = nm_pad / AM;
+    const int min_splits = (nm_pad + (4096 * 32) - 1) / (4096 * 32);     // the in-accumulator block counter has 12 bits
+    if (splits < min_splits) splits = min_splits;
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     const int m_chunk = (tiles + splits - 1) / splits * AM;

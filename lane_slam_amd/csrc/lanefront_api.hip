@@ -694,7 +694,7 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
         } else { memcpy(idx, hi.data(), nq * sizeof(int32_t)); memcpy(dist, hd.data(), nq * sizeof(float)); }
         return LF_OK;
     }
-    const size_t nq_pad = ((size_t)nq + 127) / 128 * 128, nm_pad = ((size_t)nm + 63) / 64 * 64;
+    const size_t nq_pad = ((size_t)nq + 255) / 256 * 256, nm_pad = ((size_t)nm + 63) / 64 * 64;   // k_assoc.hip AQ, AM
     int rc;
     if ((rc = ensure(h, h->a_qx, nq_pad * 256)) || (rc = ensure(h, h->a_mx, nm_pad * 256)) || (rc = ensure(h, h->a_best, (size_t)nq * 8))) return rc;
     const uint8_t *dq = query32, *dmp = map32;
