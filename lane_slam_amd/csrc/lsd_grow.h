@@ -326,11 +326,16 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
 {
     const int lane = lane_id();
     double x = 0, y = 0, sum = 0;
+    // points and weights of the first 64 region points stay in lane registers for the second pass
+    // (most regions are shorter than that: one row search + one trip to the magnitudes instead of two)
+    uint32_t pk0 = 0u;
+    double w0 = 0.0;
     for (int base = 0; base < reg_size; base += LFG_NL) {
         const int i = base + lane;
         const bool v = i < reg_size;
         const uint32_t pk = v ? reg_get(c, i) : 0u;
         const double w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
+        if (base == 0) { pk0 = pk; w0 = w; }
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
@@ -347,8 +352,12 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
     for (int base = 0; base < reg_size; base += LFG_NL) {
         const int i = base + lane;
         const bool v = i < reg_size;
-        const uint32_t pk = v ? reg_get(c, i) : 0u;
-        const double w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
+        uint32_t pk = pk0;
+        double w = w0;
+        if (base != 0) {
+            pk = v ? reg_get(c, i) : 0u;
+            w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
+        }
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
