@@ -83,8 +83,15 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + region-list head.
     const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4;
-    const size_t budget = LFG_LDS_KB * 1024;
+    // LFG_LDS_KB serves the 640x480 geometries (a few thousand defined pixels per problem).  Larger LSD images
+    // (1080p: 1536x576) have proportionally more defined pixels and far fewer problems per batch, so latency
+    // matters more than residency: grow the slice with the image (~3 % of the pixels defined), up to 64 KB.
+    size_t budget = LFG_LDS_KB * 1024;
     int reg_lds = LFG_REG_LDS;
+    {
+        const size_t want = fixed + (size_t)reg_lds * 4 + 8 + (size_t)((double)Ps * 0.03 * 17.0 / 8.0);
+        if (want > budget) budget = want < (size_t)64 * 1024 ? want : (size_t)64 * 1024;
+    }
     long long left = (long long)budget - (long long)fixed - (long long)reg_lds * 4 - 8;
     int def_lds = left > 0 ? (int)(left * 8 / 17) : 0;         // 2 B + 1/8 B per entry
     def_lds &= ~31;
