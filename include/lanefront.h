@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 1
+#define LF_ABI_VERSION 2   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages */
 
 typedef enum lf_status {
     LF_OK = 0,
@@ -138,7 +138,7 @@ int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int fram
 
 /* Pipelined form: lf_process_batch_async queues the whole batch on the handle's HIP stream and
  * returns at once (device outputs only); lf_wait blocks until it is done and returns the
- * segment count.  Two handles used alternately keep two independent batches in flight, which
+ * segment count.  Several handles used in turn keep as many independent batches in flight, which
  * lets one batch's latency-bound LSD region growing overlap the next batch's streaming
  * kernels.  One batch in flight per handle. */
 int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
