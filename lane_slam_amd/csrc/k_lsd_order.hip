@@ -12,18 +12,20 @@
 //       can never seed a region, so only defined pixels are listed.
 // k_lsd_grow works entirely in that index space (tens of KB per problem, cache resident).
 //
-// Integer work, exact and deterministic: (1) LSD radix sort of (address << 32 | record) on the
-// 20-bit address, five 4-bit passes -- addresses are unique, so the result does not depend on the
-// order in which tiles appended their records; (2) gather + row starts + bins; (3) stable LSD radix
-// sort of the seeds on the 10-bit bin key, three 4-bit passes.  Each lane owns a contiguous run of
-// items, per-lane bucket counters live in a [16][512] LDS matrix and one wave scans each bucket
-// row, so no atomics are needed.
+// Integer work, exact and deterministic.  Problems of up to LDS_ITEMS defined pixels stay in LDS: (1) counting
+// sort on the image row with atomic cursors + rank among row mates (addresses are unique, so the result does
+// not depend on the order in which tiles appended their records); (2) gather + row starts + bins; (3) two
+// stable 5-bit counting passes over the 10-bit bin key, ranks from wave ballots.  Larger problems take the
+// same three steps as LSD radix sorts with the items in HBM (five + three 4-bit passes; each lane owns a
+// contiguous run of items, per-lane bucket counters live in a [16][512] LDS matrix and one wave scans each
+// bucket row, so no atomics are needed).
 #include "common.h"
 
 namespace lf {
 
 constexpr int OT = 512;          // threads
 constexpr int NB = 16;           // buckets per pass (4-bit digits; [16][512] u32 = 32 KB LDS)
+constexpr int LDS_ITEMS = 8192;  // problems up to this many defined pixels are ordered entirely in LDS (2 x 32 KB, dynamic)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {
@@ -36,7 +38,7 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 }
 
 template <typename T>
-__device__ void radix_pass(const T* __restrict__ src, T* __restrict__ dst, int n, int shift,
+__device__ __forceinline__ void radix_pass(const T* __restrict__ src, T* __restrict__ dst, int n, int shift,
                            uint32_t* cnt /*[NB][OT]*/, int* tot /*[NB]*/, int* base /*[NB]*/)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -73,6 +75,60 @@ __device__ void radix_pass(const T* __restrict__ src, T* __restrict__ dst, int n
     __syncthreads();
 }
 
+// One STABLE 5-bit counting pass over n <= LDS_ITEMS items held in LDS, ranks from wave ballots.
+// Wave w owns the contiguous run [w * C, (w + 1) * C); in every 64-item step a lane's rank among the
+// lanes with the same digit comes from five ballots, and the wave's running per-digit count lives in
+// LDS (wrun).  After a barrier one wave turns the [wave][digit] counts into scatter bases.
+template <typename Dst>
+__device__ __forceinline__ void stable_pass5(const uint32_t* src, Dst* dst, int n, int shift,
+                                             uint32_t* wrun /*[OT/64][32]*/, uint32_t* wbase /*[OT/64][32]*/)
+{
+    constexpr int W = OT / 64, MAXSTEP = LDS_ITEMS / OT;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int C = ((n + W - 1) / W + 63) & ~63;                  // whole 64-item steps per wave
+    const int start = w * C, end = min(n, start + C);
+    if (lane < 32) wrun[w * 32 + lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    uint32_t item[MAXSTEP], lrank[MAXSTEP];
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int st = 0; st < MAXSTEP; ++st) {
+        const int i = start + st * 64 + lane;
+        const bool valid = st * 64 < C && i < end;
+        const uint32_t it = valid ? src[i] : 0u;
+        const uint32_t d = (it >> shift) & 31u;
+        unsigned long long mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const unsigned long long bal = __ballot((d >> b) & 1u);
+            mask &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        item[st] = it;
+        lrank[st] = 0;
+        if (valid) {
+            lrank[st] = wrun[w * 32 + d] + (uint32_t)__popcll(mask & lt);
+            if ((mask >> lane) >> 1 == 0ull) wrun[w * 32 + d] += (uint32_t)__popcll(mask);    // last lane of the group
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    if (t < 32) {
+        uint32_t tot = 0;
+        for (int k = 0; k < W; ++k) tot += wrun[k * 32 + t];
+        uint32_t inc = (uint32_t)wave_incl_scan((int)tot, t);
+        uint32_t run = inc - tot;
+        for (int k = 0; k < W; ++k) { wbase[k * 32 + t] = run; run += wrun[k * 32 + t]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int st = 0; st < MAXSTEP; ++st) {
+        const int i = start + st * 64 + lane;
+        if (st * 64 < C && i < end) dst[wbase[w * 32 + ((item[st] >> shift) & 31u)] + lrank[st]] = item[st];
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* __restrict__ r_addr,
                                                   const float* __restrict__ r_deg, const double* __restrict__ r_mod,
                                                   const double* __restrict__ r_cs, const double* __restrict__ r_sn,
@@ -85,7 +141,12 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
                                                   double* __restrict__ c_cs, double* __restrict__ c_sn,
                                                   int* __restrict__ row_start)
 {
-    __shared__ uint32_t cnt[NB * OT];
+    // dynamic LDS: [LA LDS_ITEMS][LB LDS_ITEMS][row tables 2 x (Hs + 2)][wave tables 2 x 256]; the HBM path reuses the
+    // front of it as its [16][512] counter matrix
+    extern __shared__ uint32_t dyn_lds[];
+    uint32_t* LA = dyn_lds;
+    uint32_t* LB = dyn_lds + LDS_ITEMS;
+    uint32_t* cnt = dyn_lds;
     __shared__ int tot[NB];
     __shared__ int base[NB];
     const int pc = blockIdx.x;
@@ -103,6 +164,71 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
         for (int y = t; y <= p.Hs; y += OT) RS[y] = 0;
         return;
     }
+    const int idx_bits = __clz((int)(Ps - 1));      // 32 - (bits of the largest pixel address): room for the record number
+    const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
+    const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
+    if (n <= LDS_ITEMS && n <= (1 << idx_bits) && p.n_bins <= 1024) {
+        // Typical problem (a few thousand defined pixels): two counting sorts in LDS.  Keys are unique
+        // (addresses), so the raster sort need not be stable: items are dropped into their image row with an
+        // LDS atomic cursor in whatever order they arrive,
+        // and each item's final place is the row start plus the number of row mates to its left (rows hold tens of
+        // entries).  The seeds then take two stable ballot-ranked passes over the bin key.
+        uint32_t* rowS = dyn_lds + 2 * LDS_ITEMS;   // [Hs + 1] first entry of every row (exclusive scan)
+        uint32_t* rowC = rowS + (p.Hs + 2);          // [Hs + 1] histogram, then scatter cursor
+        const uint32_t idx_mask = (1u << idx_bits) - 1u;
+        for (int y = t; y <= p.Hs; y += OT) rowC[y] = 0;
+        __syncthreads();
+        for (int i = t; i < n; i += OT) {
+            const uint32_t addr = r_addr[o + i];
+            LA[i] = (addr << idx_bits) | (uint32_t)i;   // address above, record number below
+            atomicAdd(&rowC[addr / (uint32_t)p.Ws], 1u);
+        }
+        __syncthreads();
+        if (t < 64) {                                // exclusive scan over the rows, one wave
+            uint32_t carry = 0;
+            for (int y0 = 0; y0 <= p.Hs; y0 += 64) {
+                const int y = y0 + t;
+                const uint32_t v = y < p.Hs ? rowC[y] : 0u;
+                const uint32_t inc = (uint32_t)wave_incl_scan((int)v, t);
+                if (y <= p.Hs) { rowS[y] = carry + inc - v; RS[y] = (int)(carry + inc - v); }
+                carry += (uint32_t)__shfl((int)inc, 63);
+            }
+        }
+        __syncthreads();
+        for (int y = t; y <= p.Hs; y += OT) rowC[y] = rowS[y];
+        __syncthreads();
+        for (int i = t; i < n; i += OT) {
+            const uint32_t it = LA[i];
+            const uint32_t y = (it >> idx_bits) / (uint32_t)p.Ws;
+            LB[atomicAdd(&rowC[y], 1u)] = it;
+        }
+        __syncthreads();
+        for (int j = t; j < n; j += OT) {
+            const uint32_t it = LB[j];
+            const uint32_t addr = it >> idx_bits, ri = it & idx_mask;
+            const int y = (int)(addr / (uint32_t)p.Ws), x = (int)(addr - (uint32_t)y * (uint32_t)p.Ws);
+            const uint32_t s0 = rowS[y], s1 = rowS[y + 1];
+            uint32_t e = s0;
+            for (uint32_t k = s0; k < s1; ++k) e += LB[k] < it ? 1u : 0u;                // row mates to the left
+            const double m = r_mod[o + ri];
+            c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
+            c_deg[o + e] = r_deg[o + ri];
+            c_mod[o + e] = m;
+            c_cs[o + e] = r_cs[o + ri];
+            c_sn[o + e] = r_sn[o + ri];
+            const uint32_t key = (uint32_t)((p.n_bins - 1) - (int)(m * bin_coef));
+            LA[e] = (key << 20) | e;
+        }
+        __syncthreads();
+        // seeds: stable by construction (LA is in raster order), two 5-bit passes over the 10-bit bin key.
+        // The bins of a binary edge image are few and crowded, so a rank-among-bin-mates loop would be quadratic.
+        uint32_t* wrun = rowC + (p.Hs + 2);
+        uint32_t* wbase = wrun + (OT / 64) * 32;
+        stable_pass5(LA, LB, n, 20, wrun, wbase);
+        stable_pass5(LB, A, n, 25, wrun, wbase);                  // k_lsd_grow reads the seeds from order_a
+        return;
+    }
+    // ---- large problems: same algorithm with the items in HBM
     // (1) raster order: sort (address, record index) by address
     for (int i = t; i < n; i += OT) X[i] = ((unsigned long long)r_addr[o + i] << 32) | (unsigned int)i;
     __syncthreads();
@@ -112,8 +238,6 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
     radix_pass(Y, X, n, 44, cnt, tot, base);
     radix_pass(X, Y, n, 48, cnt, tot, base);                 // sorted by address in Y
     // (2) gather into the compact arrays, row starts, seed items
-    const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
-    const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
     for (int e = t; e < n; e += OT) {
         const unsigned long long it = Y[e];
         const uint32_t addr = (uint32_t)(it >> 32), ri = (uint32_t)it;
@@ -145,7 +269,14 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
                       int* norder, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs, double* c_sn,
                       int* row_start, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_order, dim3(n_frames * 3), dim3(OT), 0, s, p, r_addr, r_deg, r_mod, r_cs, r_sn, n_rec, maxgrad,
+    const size_t lds = ((size_t)2 * LDS_ITEMS + 2 * (size_t)(p.Hs + 2) + 2 * (OT / 64) * 32) * sizeof(uint32_t);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {   // more than 64 KB of dynamic LDS needs the opt-in (a refusal is not fatal here: the launch says so)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_order), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            (void)hipGetLastError();
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(k_lsd_order, dim3(n_frames * 3), dim3(OT), lds, s, p, r_addr, r_deg, r_mod, r_cs, r_sn, n_rec, maxgrad,
                        sort_a, sort_b, order_a, order_b, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start);
 }
 
