@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--quality", type=int, default=75)
+ap.add_argument("--feeders", type=int, default=1, help="host threads that each drive their own handles (ctypes releases the GIL inside the library)")
 args = ap.parse_args()
 B, D = args.batch, args.depth
 torch.cuda.init()
@@ -49,18 +50,25 @@ for nt in [int(t) for t in args.threads.split(",")]:
     fes[0].synchronize()
     dt = time.perf_counter() - t0
     dec = B * args.steps / dt
-    # decode + front end, D handles in flight
-    def run(n):
+    # decode + front end, D handles in flight, split over --feeders host threads
+    import threading
+    F = max(1, min(args.feeders, D))
+    def run(n, fi=0):
+        mine = [sl for sl in range(D) if sl % F == fi]
         infl = []
         for k in range(n):
-            sl = k % D
-            if len(infl) == D: fes[infl.pop(0)].wait()
-            fes[sl].decode_jpeg_batch(streams, n_threads=nt, device_ptr=bufs[sl])
+            sl = mine[k % len(mine)]
+            if len(infl) == len(mine): fes[infl.pop(0)].wait()
+            fes[sl].decode_jpeg_batch(streams, n_threads=max(1, nt // F), device_ptr=bufs[sl])
             fes[sl].submit_device(bufs[sl], B, ptrs[sl], cap, describe=True)
             infl.append(sl)
         while infl: fes[infl.pop(0)].wait()
-    run(D)
-    t0 = time.perf_counter(); run(args.steps); dt = time.perf_counter() - t0
+    def run_all(n):
+        th = [threading.Thread(target=run, args=(n // F, fi)) for fi in range(F)]
+        for x in th: x.start()
+        for x in th: x.join()
+    run_all(D)
+    t0 = time.perf_counter(); run_all(args.steps); dt = time.perf_counter() - t0
     print("threads %3d: decode %8.0f frames/s   decode + front end %8.0f frames/s" % (nt, dec, B * args.steps / dt))
 # device time of the ingest kernels (HIP events on the handle's stream), one batch in flight
 fes[0].reset_timing(); fes[0].set_profiling(True)
