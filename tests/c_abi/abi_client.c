@@ -1,0 +1,101 @@
+/* A plain-C client of include/lanefront.h: what a non-Python integrator links against.
+ * Reads a config blob and raw frames written by tests/test_c_abi.py, runs the batch entry point with host
+ * pointers, associates the codes against themselves reversed, serialises the filtered SegmentList bodies and
+ * writes everything back for the test to compare with the Python binding and the oracle.
+ *
+ *   abi_client <config.bin> <frames.bin> <n_frames> <out.bin>
+ *
+ * Compiled by gcc (C11), no HIP headers: only the C ABI.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/lanefront.h"
+
+static void die(const char* what, lf_handle* h, int rc)
+{
+    fprintf(stderr, "%s failed: %d (%s)\n", what, rc, h ? lf_last_error(h) : "no handle");
+    exit(2);
+}
+
+static void* xread(const char* path, size_t bytes)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) { perror(path); exit(2); }
+    void* p = malloc(bytes);
+    if (fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "%s: short read\n", path); exit(2); }
+    fclose(f);
+    return p;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 5) { fprintf(stderr, "usage: abi_client config.bin frames.bin n_frames out.bin\n"); return 2; }
+    if (lf_abi_version() != LF_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 2; }
+    lf_config* cfg = (lf_config*)xread(argv[1], sizeof(lf_config));
+    const int n = atoi(argv[3]);
+    const size_t frame_bytes = (size_t)cfg->in_rows * cfg->in_cols * 3;
+    uint8_t* frames = (uint8_t*)xread(argv[2], frame_bytes * (size_t)n);
+    const int cap_lines = 512, cap = n * 3 * cap_lines;
+
+    lf_handle* h = NULL;
+    int rc = lf_create(cfg, 0, n, cap_lines, &h);
+    if (rc != LF_OK) die("lf_create", h, rc);
+
+    lf_segments s;
+    memset(&s, 0, sizeof(s));
+    s.capacity = cap;
+    s.frame_offset = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+    s.lines = (float*)malloc(sizeof(float) * 4 * (size_t)cap);
+    s.normals = (float*)malloc(sizeof(float) * 2 * (size_t)cap);
+    s.color = (uint8_t*)malloc((size_t)cap);
+    s.pixels_normalized = (float*)malloc(sizeof(float) * 4 * (size_t)cap);
+    s.ground = (double*)malloc(sizeof(double) * 4 * (size_t)cap);
+    s.keep = (uint8_t*)malloc((size_t)cap);
+    s.code = (uint8_t*)malloc(32 * (size_t)cap);
+    int total = 0;
+    rc = lf_process_batch(h, frames, n, 0, &s, 0, 1, &total);
+    if (rc != LF_OK) die("lf_process_batch", h, rc);
+
+    /* association of the codes against the same codes in reverse order */
+    uint8_t* rev = (uint8_t*)malloc(32 * (size_t)(total > 0 ? total : 1));
+    for (int i = 0; i < total; ++i) memcpy(rev + 32 * (size_t)i, s.code + 32 * (size_t)(total - 1 - i), 32);
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    float* dist = (float*)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
+    if (total > 0) {
+        rc = lf_associate(h, s.code, total, rev, total, idx, dist, 0);
+        if (rc != LF_OK) die("lf_associate", h, rc);
+    }
+
+    /* SegmentList bodies line_sanity_node would publish */
+    const size_t body_cap = 4 * (size_t)n + 73 * (size_t)total;
+    uint8_t* body = (uint8_t*)malloc(body_cap ? body_cap : 1);
+    int64_t* boff = (int64_t*)calloc((size_t)n + 1, sizeof(int64_t));
+    rc = lf_serialize_segments(h, &s, 0, n, LF_MSG_FILTERED, body, body_cap, 0, boff);
+    if (rc != LF_OK) die("lf_serialize_segments", h, rc);
+
+    /* error path: too small a capacity must be reported, not overrun */
+    lf_segments tiny = s;
+    tiny.capacity = total > 1 ? total - 1 : 0;
+    int t2 = 0;
+    const int rc_small = total > 1 ? lf_process_batch(h, frames, n, 0, &tiny, 0, 0, &t2) : LF_ERR_CAPACITY;
+
+    FILE* f = fopen(argv[4], "wb");
+    if (!f) { perror(argv[4]); return 2; }
+    int32_t head[4] = { total, rc_small, (int32_t)boff[n], LF_N_STAGES };
+    fwrite(head, sizeof(head), 1, f);
+    fwrite(s.frame_offset, sizeof(int32_t), (size_t)n + 1, f);
+    fwrite(s.lines, sizeof(float) * 4, (size_t)total, f);
+    fwrite(s.ground, sizeof(double) * 4, (size_t)total, f);
+    fwrite(s.keep, 1, (size_t)total, f);
+    fwrite(s.code, 32, (size_t)total, f);
+    fwrite(idx, sizeof(int32_t), (size_t)total, f);
+    fwrite(dist, sizeof(float), (size_t)total, f);
+    fwrite(boff, sizeof(int64_t), (size_t)n + 1, f);
+    fwrite(body, 1, (size_t)boff[n], f);
+    fclose(f);
+    lf_destroy(h);
+    printf("abi_client: %d frames, %d segments, %lld body bytes\n", n, total, (long long)boff[n]);
+    return 0;
+}

@@ -1,0 +1,88 @@
+"""The C ABI from C: tests/c_abi/abi_client.c (gcc, C11, only include/lanefront.h) linked against
+liblanefront.so.  CPU part: it compiles and links against every symbol it uses.  GPU part: it runs the batch path,
+the associator and the SegmentList serialiser with host pointers, and its output equals the Python binding's and
+the oracle's."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from lane_slam_amd import _lib, default_config, synth
+from lane_slam_amd.config import LfConfig, fill_struct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def build_client():
+    exe = os.path.join(HERE, "hostsim", "_build", "abi_client")
+    src = os.path.join(HERE, "c_abi", "abi_client.c")
+    so = os.path.join(ROOT, "lane_slam_amd", "liblanefront.so")
+    deps = [src, os.path.join(ROOT, "include", "lanefront.h"), so]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Wextra", "-Werror", "-o", exe, src,
+                               "-L" + os.path.dirname(so), "-l:liblanefront.so", "-Wl,-rpath," + os.path.dirname(so),
+                               "-Wl,--allow-shlib-undefined"])
+    return exe
+
+
+def test_c_client_compiles_and_links():
+    exe = build_client()
+    assert os.access(exe, os.X_OK)
+    # usage error path needs no GPU
+    p = subprocess.run([exe], capture_output=True)
+    assert p.returncode == 2 and b"usage" in p.stderr
+
+
+@pytest.mark.gpu
+def test_c_client_matches_python_binding_and_oracle(tmp_path):
+    from lane_slam_amd import FrontEnd
+    from lane_slam_amd import segment_msgs as sm
+    from oracle.oracle import Oracle
+    exe = build_client()
+    cfg = default_config("parity")
+    n = 6
+    frames = synth.make_batch(n, 500)
+    c = LfConfig()
+    fill_struct(c, cfg)
+    (tmp_path / "cfg.bin").write_bytes(bytes(c))
+    (tmp_path / "frames.bin").write_bytes(frames.tobytes())
+    p = subprocess.run([exe, str(tmp_path / "cfg.bin"), str(tmp_path / "frames.bin"), str(n), str(tmp_path / "out.bin")],
+                       capture_output=True)
+    assert p.returncode == 0, p.stderr.decode()
+    raw = (tmp_path / "out.bin").read_bytes()
+    total, rc_small, body_bytes, n_stages = struct.unpack_from("<4i", raw, 0)
+    assert rc_small == -2 and n_stages == _lib.LF_N_STAGES          # LF_ERR_CAPACITY
+    pos = 16
+
+    def take(dtype, count):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype, count=count, offset=pos)
+        pos += a.nbytes
+        return a
+
+    fo = take(np.int32, n + 1)
+    lines = take(np.float32, total * 4).reshape(-1, 4)
+    ground = take(np.float64, total * 4).reshape(-1, 4)
+    keep = take(np.uint8, total)
+    code = take(np.uint8, total * 32).reshape(-1, 32)
+    idx = take(np.int32, total)
+    dist = take(np.float32, total)
+    boff = take(np.int64, n + 1)
+    body = take(np.uint8, body_bytes)
+    assert pos == len(raw) and total > 20
+    fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=512)
+    seg = fe.process_batch(frames)
+    assert seg.n == total and np.array_equal(fo, seg.frame_offset)
+    assert np.array_equal(lines, seg.lines) and np.array_equal(ground, seg.ground)
+    assert np.array_equal(keep, seg.keep) and np.array_equal(code, seg.code)
+    o = Oracle(cfg)
+    oi, od = o.match(code, code[::-1].copy())
+    assert np.array_equal(idx, oi) and np.array_equal(dist, od)
+    ref_body, ref_off = sm.serialize_segments(fe, seg, sm.FILTERED)
+    assert np.array_equal(boff, ref_off) and np.array_equal(body, ref_body)
+    r0 = o.process_frame(frames[0])
+    assert np.array_equal(lines[fo[0]:fo[1]], r0["lines"]) and np.array_equal(keep[fo[0]:fo[1]], r0["keep"])
