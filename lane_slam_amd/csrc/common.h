@@ -108,9 +108,10 @@ void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,
                      const int* seg_offset, const uint8_t* masks, lf_segments out, int* seg_frame,
                      double* normals64, float* centers, hipStream_t s);
-void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s);
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, uint32_t* dxy, hipStream_t s);
+void launch_lbd_split_debug(size_t n, const uint32_t* dxy, int16_t* dx, int16_t* dy, hipStream_t s);
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
-                const int16_t* dx, const int16_t* dy, const float* gauss_g, const float* gauss_l,
+                const uint32_t* dxy, const float* gauss_g, const float* gauss_l,
                 float* desc, uint8_t* code, hipStream_t s);
 void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* mx,
                   unsigned int* best, int32_t* idx, float* dist, hipStream_t s);

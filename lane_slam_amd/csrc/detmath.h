@@ -334,5 +334,16 @@ LF_HD double round_half_away(double v)
     return f;
 }
 
+// the same for a float argument, in float arithmetic: trunc and the remainder are exact for every finite
+// float (|v| >= 2^23 has no fraction), so this equals round_half_away((double)v) without the f64 -> i64 round trip
+LF_HD float round_half_away_f(float v)
+{
+    const float f = __builtin_truncf(v);
+    const float d = v - f;
+    if (d >= 0.5f) return f + 1.0f;
+    if (d <= -0.5f) return f - 1.0f;
+    return f;
+}
+
 }  // namespace dm
 }  // namespace lf

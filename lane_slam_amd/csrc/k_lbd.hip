@@ -30,7 +30,7 @@ __device__ __forceinline__ int refl101(int p, int n)
 // Four horizontally adjacent outputs per lane in every phase: the LDS tiles are read as dwords /
 // 16-byte vectors with sliding windows instead of one byte (or int) per tap.
 __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t* __restrict__ bgr,
-                                                  int16_t* __restrict__ dxo, int16_t* __restrict__ dyo)
+                                                  uint32_t* __restrict__ dxyo)
 {
     constexpr int GW = 72, GH = LT_H + 6;            // gray tile: 70 columns used (x0-3 .. x0+66), rows padded to dwords
     constexpr int RW = 68, RG = RW / 4;              // row-filtered: 66 columns used (x0-1 .. x0+64)
@@ -111,22 +111,23 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t*
                 vy[k] = (r[2][k] - r[0][k]) + 2 * (r[2][k + 1] - r[0][k + 1]) + (r[2][k + 2] - r[0][k + 2]);
             }
             const size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
+            // dx and dy of a pixel share one dword (dx low, dy high): the descriptor kernel fetches both with one gather
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)(uint16_t)vx[k] | ((uint32_t)(uint16_t)vy[k] << 16);
             if (gx + 3 < W && (W & 3) == 0) {
-                *reinterpret_cast<uint2*>(dxo + o) = make_uint2((uint32_t)(uint16_t)vx[0] | ((uint32_t)(uint16_t)vx[1] << 16),
-                                                                (uint32_t)(uint16_t)vx[2] | ((uint32_t)(uint16_t)vx[3] << 16));
-                *reinterpret_cast<uint2*>(dyo + o) = make_uint2((uint32_t)(uint16_t)vy[0] | ((uint32_t)(uint16_t)vy[1] << 16),
-                                                                (uint32_t)(uint16_t)vy[2] | ((uint32_t)(uint16_t)vy[3] << 16));
+                *reinterpret_cast<uint4*>(dxyo + o) = make_uint4(w[0], w[1], w[2], w[3]);
             } else {
-                for (int k = 0; k < 4 && gx + k < W; ++k) { dxo[o + k] = (int16_t)vx[k]; dyo[o + k] = (int16_t)vy[k]; }
+                for (int k = 0; k < 4 && gx + k < W; ++k) dxyo[o + k] = w[k];
             }
         }
     }
 }
 
-void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, int16_t* dx, int16_t* dy, hipStream_t s)
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, uint32_t* dxy, hipStream_t s)
 {
     dim3 grid((W + LT_W - 1) / LT_W, (Hc + LT_H - 1) / LT_H, n_frames);
-    hipLaunchKernelGGL(k_lbd_grad, grid, dim3(64, 4), 0, s, Hc, W, bgr, dx, dy);
+    hipLaunchKernelGGL(k_lbd_grad, grid, dim3(64, 4), 0, s, Hc, W, bgr, dxy);
 }
 
 __constant__ int c_comb[32][2] = {
@@ -134,10 +135,11 @@ __constant__ int c_comb[32][2] = {
     {2,8},{3,4},{3,5},{3,6},{3,7},{3,8},{4,5},{4,6},{4,7},{4,8},{5,6},{5,7},{5,8},{6,7},{6,8},{7,8} };
 
 constexpr int NBANDS = 9, WBAND = 7, LSP_H = 63;
+constexpr int LBD_STEPS = 8;      // support-region columns fetched per round trip
 
 __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restrict__ n_seg_ptr,
                                              const float* __restrict__ lines, const int* __restrict__ seg_frame,
-                                             const int16_t* __restrict__ dxi, const int16_t* __restrict__ dyi,
+                                             const uint32_t* __restrict__ dxyi,
                                              const float* __restrict__ gauss_g /*63*/, const float* __restrict__ gauss_l /*21*/,
                                              float* __restrict__ desc, uint8_t* __restrict__ code)
 {
@@ -150,8 +152,7 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int f = seg_frame[seg];
-    const int16_t* pdx = dxi + (size_t)f * Hc * W;
-    const int16_t* pdy = dyi + (size_t)f * Hc * W;
+    const uint32_t* pdxy = dxyi + (size_t)f * Hc * W;
     // KeyLine fields (LSDDetector_custom.cpp:73-102,169-197), octave 0
     float e0 = lines[4 * (size_t)seg], e1 = lines[4 * (size_t)seg + 1], e2 = lines[4 * (size_t)seg + 2], e3 = lines[4 * (size_t)seg + 3];
     if (e0 < 0) e0 = 0;
@@ -183,25 +184,26 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
         for (int hh = 0; hh < lane; ++hh) { sCorX0 -= dL1; sCorY0 += dL0; }
         float sCorX = sCorX0, sCorY = sCorY0;
         float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
-        // coordinates never depend on the gathered data: 4 steps of addresses first, 8 loads in flight
-        for (int w0 = 0; w0 < lengthOfLSP; w0 += 4) {
-            int dxv[4], dyv[4];
+        // coordinates never depend on the gathered data: LBD_STEPS steps of addresses first, 2 * LBD_STEPS loads
+        // in flight per lane (the longest segment of a batch sets the kernel's duration: fewer, fuller round trips)
+        for (int w0 = 0; w0 < lengthOfLSP; w0 += LBD_STEPS) {
+            uint32_t dxyv[LBD_STEPS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int tx = (int)dm::round_half_away((double)sCorX);
+            for (int u = 0; u < LBD_STEPS; ++u) {
+                int tx = (int)dm::round_half_away_f(sCorX);
                 int xCor = tx < 0 ? 0 : (tx > imageWidth ? imageWidth : tx);
-                int ty = (int)dm::round_half_away((double)sCorY);
+                int ty = (int)dm::round_half_away_f(sCorY);
                 int yCor = ty < 0 ? 0 : (ty > imageHeight ? imageHeight : ty);
-                dxv[u] = pdx[yCor * W + xCor];
-                dyv[u] = pdy[yCor * W + xCor];
+                dxyv[u] = pdxy[yCor * W + xCor];
                 sCorX += dL0;
                 sCorY += dL1;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LBD_STEPS; ++u) {
                 if (w0 + u >= lengthOfLSP) break;
-                float gDL = (float)dxv[u] * dL0 + (float)dyv[u] * dL1;
-                float gDO = (float)dxv[u] * dO0 + (float)dyv[u] * dO1;
+                const float gx_ = (float)(int)(int16_t)(dxyv[u] & 0xffffu), gy_ = (float)((int)dxyv[u] >> 16);
+                float gDL = gx_ * dL0 + gy_ * dL1;
+                float gDO = gx_ * dO0 + gy_ * dO1;
                 if (gDL > 0) pgdL += gDL; else ngdL -= gDL;
                 if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
             }
@@ -293,14 +295,29 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
 }
 
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
-                const int16_t* dx, const int16_t* dy, const float* gauss_g, const float* gauss_l,
+                const uint32_t* dxy, const float* gauss_g, const float* gauss_l,
                 float* desc, uint8_t* code, hipStream_t s)
 {
     if (n_seg_cap <= 0) return;
     int blocks = (n_seg_cap + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_lbd, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dx, dy,
+    hipLaunchKernelGGL(k_lbd, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
                        gauss_g, gauss_l, desc, code);
+}
+
+// Debug only: the two s16 planes tests compare with the oracle's Sobel output.
+__global__ void k_lbd_split_debug(size_t n, const uint32_t* __restrict__ dxy, int16_t* __restrict__ dx, int16_t* __restrict__ dy)
+{
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = dxy[i];
+    dx[i] = (int16_t)(v & 0xffffu);
+    dy[i] = (int16_t)(v >> 16);
+}
+
+void launch_lbd_split_debug(size_t n, const uint32_t* dxy, int16_t* dx, int16_t* dy, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lbd_split_debug, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, dxy, dx, dy);
 }
 
 }  // namespace lf

@@ -80,7 +80,8 @@ struct lf_handle {
     int *d_norder = nullptr, *d_counts = nullptr, *d_seg_offset = nullptr, *d_frame_offset = nullptr, *d_overflow = nullptr;
     float* d_slot_lines = nullptr;
     int* d_seg_frame = nullptr;
-    int16_t *d_dx = nullptr, *d_dy = nullptr;
+    uint32_t* d_dxy = nullptr;          // LBD gradients, dx | dy << 16 per pixel
+    DevBuf dbg_dx, dbg_dy;
     float *d_gauss_g = nullptr, *d_gauss_l = nullptr;
     int *d_xofs = nullptr, *d_y0 = nullptr, *d_y1 = nullptr;
     float *d_xa = nullptr, *d_yb = nullptr;
@@ -385,7 +386,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * Ps) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
-        dalloc(h, &h->d_dx, B * P) || dalloc(h, &h->d_dy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
+        dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
     h->out_capacity = (int)cap;
@@ -415,7 +416,7 @@ extern "C" void lf_destroy(lf_handle* h)
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
                      h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
-                     h->d_seg_frame, h->d_dx, h->d_dy, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
+                     h->d_seg_frame, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
                      h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
@@ -527,11 +528,11 @@ static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
                         h->d_normals64, h->d_centers, s);
     }
     if (describe) {
-        { StageTimer t(h, ST_LBD_GRAD); launch_lbd_grad(h->Hc, h->W, n, h->d_bgr, h->d_dx, h->d_dy, s); }
+        { StageTimer t(h, ST_LBD_GRAD); launch_lbd_grad(h->Hc, h->W, n, h->d_bgr, h->d_dxy, s); }
         {
             StageTimer t(h, ST_LBD);
             int cap = dev_out.capacity < n * 3 * h->cap_lines ? dev_out.capacity : n * 3 * h->cap_lines;
-            launch_lbd(h->Hc, h->W, cap, h->d_seg_offset + n * 3, dev_out.lines, h->d_seg_frame, h->d_dx, h->d_dy,
+            launch_lbd(h->Hc, h->W, cap, h->d_seg_offset + n * 3, dev_out.lines, h->d_seg_frame, h->d_dxy,
                        h->d_gauss_g, h->d_gauss_l, dev_out.desc, dev_out.code, s);
         }
     }
@@ -827,8 +828,17 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
     }
     case LF_BUF_LSD_ORDER: src = h->d_order_a; avail = n * 3 * h->Ps * sizeof(uint32_t); break;
     case LF_BUF_LSD_NORDER: src = h->d_norder; avail = n * 3 * sizeof(int); break;
-    case LF_BUF_LBD_DX: src = h->d_dx; avail = n * h->P * sizeof(int16_t); break;
-    case LF_BUF_LBD_DY: src = h->d_dy; avail = n * h->P * sizeof(int16_t); break;
+    case LF_BUF_LBD_DX:
+    case LF_BUF_LBD_DY: {
+        // the pipeline keeps dx and dy interleaved: split them for the caller
+        int rc = ensure(h, h->dbg_dx, n * h->P * sizeof(int16_t));
+        if (rc == LF_OK) rc = ensure(h, h->dbg_dy, n * h->P * sizeof(int16_t));
+        if (rc != LF_OK) return rc;
+        launch_lbd_split_debug(n * h->P, h->d_dxy, (int16_t*)h->dbg_dx.p, (int16_t*)h->dbg_dy.p, s);
+        src = buffer_id == LF_BUF_LBD_DX ? h->dbg_dx.p : h->dbg_dy.p;
+        avail = n * h->P * sizeof(int16_t);
+        break;
+    }
     case LF_BUF_LSD_COUNTS: src = h->d_counts; avail = n * 3 * sizeof(int); break;
     case LF_BUF_LSD_SCRATCH: src = h->d_reg; avail = n * 3 * h->Ps * sizeof(uint32_t); break;
     default: lf_set_error(h, LF_ERR_BAD_ARG, "unknown buffer id %d", buffer_id); return LF_ERR_BAD_ARG;
