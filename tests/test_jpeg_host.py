@@ -70,3 +70,13 @@ def test_host_decoder_refuses_bad_streams(host, vectors):
         b = bytearray(good)
         b[int(rng.integers(len(good) // 2, len(good) - 2))] ^= 1 << int(rng.integers(0, 8))
         assert _coefs(host, bytes(b))[0] in (0, LF_ERR_DECODE, LF_ERR_UNSUPPORTED)
+
+
+def test_host_decoder_builtin_tables(host, vectors):
+    """DHT-less streams: the product's copy of the Annex K tables gives the same coefficients as the stream's own."""
+    from test_oracle_jpeg import strip_dht
+    for name in ("lane_q75_420", "noise_q30_444", "gray"):
+        data = bytes(vectors["jpeg_" + name])
+        rc0, a, _, _ = _coefs(host, data)
+        rc1, b, _, _ = _coefs(host, strip_dht(data))
+        assert rc0 == 0 and rc1 == 0 and np.array_equal(a, b), name
