@@ -60,6 +60,7 @@ def main():
     add("lane_rst_420", encode(lane, quality=75, subsampling=2, restart_marker_blocks=5))
     add("lane_rst_444", encode(lane, quality=75, subsampling=0, restart_marker_rows=1))
     add("gray", encode(lane[..., 1].copy(), quality=80))
+    add("lane_rgb_444", encode(lane, quality=80, keep_rgb=True))         # Adobe marker, transform 0: components are R, G, B
     add("tiny_3x5_420", encode(noise[:3, :5].copy(), quality=75, subsampling=2))
     add("tiny_1x1_420", encode(noise[:1, :1].copy(), quality=75, subsampling=2))
     add("narrow_9x4_422", encode(noise[:9, :4].copy(), quality=75, subsampling=1))
