@@ -35,6 +35,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+INT8_MFMA_PEAK_POPS = 5.0     # dense int8 MFMA, MI355X_MICROARCH.md (2x the ~2.5 PF bf16 rate)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -239,6 +240,14 @@ def main():
             if name in sb and avg > 0:
                 e["algorithmic_bytes"] = sb[name] * B
                 e["GBps"] = round(sb[name] * B / (avg * 1e-3) / 1e9, 1)
+            if name == "assoc_mfma" and avg > 0 and seg_total[0] > 0:
+                # 2 * N * M * 256 int8 ops per call against the dense int8 MFMA peak (stage time
+                # includes the +-64 packing of queries and map and the final decode)
+                ops = 2.0 * seg_total[0] * M * 256
+                e["algorithmic_ops"] = ops
+                e["Pop_per_s"] = round(ops / (avg * 1e-3) / 1e15, 3)
+                e["mfma_peak_Pop_per_s"] = INT8_MFMA_PEAK_POPS
+                e["frac_of_mfma_peak"] = round(ops / (avg * 1e-3) / 1e15 / INT8_MFMA_PEAK_POPS, 3)
             kernels.append(e)
         streaming = [k for k in kernels if "GBps" in k]
         # dominant streaming kernel = the one that has to move the most bytes
