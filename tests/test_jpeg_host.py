@@ -80,3 +80,17 @@ def test_host_decoder_builtin_tables(host, vectors):
         rc0, a, _, _ = _coefs(host, data)
         rc1, b, _, _ = _coefs(host, strip_dht(data))
         assert rc0 == 0 and rc1 == 0 and np.array_equal(a, b), name
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/anti_instagram/annotation-tool/images"),
+                    reason="the reference checkout (real camera JPEGs) is only present in the build container")
+def test_host_decoder_on_reference_camera_images(host):
+    """The product's entropy decoder on the reference's 173 real camera frames: coefficients equal the oracle's
+    (which equals libjpeg-turbo on these files, tests/test_oracle_jpeg.py)."""
+    import glob
+    from oracle.oracle import jpeg_coefficients
+    files = sorted(glob.glob("/root/reference/src/anti_instagram/annotation-tool/images/*.jpg"))[::4]
+    for f in files:
+        data = open(f, "rb").read()
+        rc, dense, _, _ = _coefs(host, data)
+        assert rc == 0 and np.array_equal(dense, jpeg_coefficients(data)), os.path.basename(f)
