@@ -12,6 +12,8 @@ What is imported from /root/reference (Python 3 can execute these files as they 
         LineSanityNode.processSegmentList / fancyFilters                     (a-8)
   * src/anti_instagram/include/anti_instagram/scale_and_shift.py
         scaleandshift2                                                       (a-1)
+  * src/ground_projection/include/ground_projection/GroundProjection.py (Python 2: converted in memory by lib2to3)
+        GroundProjection.vector2pixel / pixel2ground with rectifyPoint = identity   (a-7 minus undistortPoints)
 The modules `rospy`, `cv2`, `*_msgs.msg` they import at file scope are absent from this
 image; they are replaced by empty name-only stubs (no arithmetic) so the import
 statements succeed.  Message classes are plain attribute holders with the constants of
@@ -186,8 +188,59 @@ def golden_scaleandshift():
     print("scaleandshift:", outs.shape, outs.dtype)
 
 
+def golden_ground_projection():
+    """GroundProjection.vector2pixel + pixel2ground (a-7 without the undistortion).  The file is Python 2
+    (`print ob`), so it is converted IN MEMORY with lib2to3 and executed; nothing of it is stored.  The
+    instance is built without __init__ (which needs ROS parameter plumbing): H comes from the reference's own
+    default extrinsic calibration file, ci_ is a 640x480 CameraInfo holder, and pcm_.rectifyPoint -- which is
+    cv2.undistortPoints inside the absent third-party image_geometry package -- is replaced by the identity.
+    The vectors therefore pin the pixel scaling, the four clamps (including `v > ch-1 -> 0`), the always-on
+    rectification call, the homography product and the division; NOT undistortPoints itself."""
+    import yaml
+    from lib2to3.refactor import RefactoringTool, get_fixers_from_package
+    path = REF + "/ground_projection/include/ground_projection/GroundProjection.py"
+    src3 = str(RefactoringTool(get_fixers_from_package("lib2to3.fixes")).refactor_string(open(path).read() + "\n", path))
+
+    class _Pcm(object):
+        def rectifyPoint(self, uv):
+            return uv
+
+    _stub("image_geometry", PinholeCameraModel=_Pcm)
+    du = _stub("duckietown_utils", logger=None, get_duckiefleet_root=lambda: "")
+    du.__path__ = []
+    _stub("duckietown_utils.path_utils", get_ros_package_path=lambda *a: "")
+    _stub("duckietown_utils.yaml_wrap", yaml_load_file=lambda *a: None, yaml_write_to_file=lambda *a: None)
+    sys.modules["sensor_msgs.msg"].CameraInfo = _Obj
+    sys.modules["duckietown_msgs.msg"].Pixel = _Obj
+    mod = types.ModuleType("ref_ground_projection")
+    exec(compile(src3, path, "exec"), mod.__dict__)
+    gp = object.__new__(mod.GroundProjection)
+    gp.rectified_input = False
+    ext = yaml.safe_load(open(REF + "/duckietown/include/calibrations/camera_extrinsic/default.yaml"))
+    gp.H = np.array(ext["homography"], np.float64).reshape(3, 3)
+    gp.ci_ = _Obj(width=640, height=480)
+    gp.pcm_ = _Pcm()
+    rng = np.random.default_rng(31)
+    n = 400
+    vec = rng.uniform(-0.15, 1.15, (n, 2)).astype(np.float32)          # message fields are float32
+    vec[0] = [0.0, 0.0]; vec[1] = [1.0, 1.0]; vec[2] = [0.5, 479.0 / 480.0]; vec[3] = [0.5, 479.5 / 480.0]
+    vec[4] = [639.0 / 640.0, 0.25]; vec[5] = [639.5 / 640.0, 0.25]; vec[6] = [-0.001, -0.001]
+    out = np.empty((n, 3), np.float64)
+    pix = np.empty((n, 2), np.float64)
+    for i in range(n):
+        v = _Obj(x=float(vec[i, 0]), y=float(vec[i, 1]))
+        px = gp.vector2pixel(v)
+        pix[i] = [px.u, px.v]
+        g = gp.vector2ground(v)
+        out[i] = [g.x, g.y, g.z]
+    np.savez_compressed(os.path.join(OUT, "ground_projection.npz"), vec=vec, pixel=pix, ground=out, H=gp.H,
+                        cam=np.array([640, 480], np.int32))
+    print("ground_projection:", n, "points; clamp quirk example", pix[3], out[3])
+
+
 if __name__ == "__main__":
     install_stubs()
+    golden_ground_projection()
     golden_find_normal()
     golden_line_sanity()
     golden_scaleandshift()

@@ -55,3 +55,35 @@ def test_scaleandshift_matches_reference(golden_dir):
         # convertScaleAbs: saturate_u8(round_half_even(|x|))
         expect = np.clip(np.rint(np.abs(ref_f32.astype(np.float64))), 0, 255).astype(np.uint8)
         assert np.array_equal(out, expect)
+
+
+def test_ground_projection_matches_reference(golden_dir):
+    """GroundProjection.vector2pixel + pixel2ground run from the reference (in-memory lib2to3 conversion,
+    rectifyPoint replaced by the identity because image_geometry / cv2 are absent): pixel scaling, the four
+    clamps with the `v > ch-1 -> 0` quirk, the homography of the reference's default calibration and the
+    division.  The oracle is given K = I, D = 0, R = I, P = [I | 0], for which its always-on rectification is
+    exactly the identity too."""
+    import copy
+    from lane_slam_amd.config import default_config
+    from oracle.oracle import Oracle
+    g = np.load(os.path.join(golden_dir, "ground_projection.npz"))
+    cfg = copy.deepcopy(default_config("parity"))
+    assert np.allclose(cfg["H"], g["H"].reshape(-1), rtol=0, atol=0)          # same calibration constants as the reference file
+    assert list(cfg["cam_size"]) == [int(g["cam"][1]), int(g["cam"][0])]
+    cfg["K"] = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+    cfg["D"] = [0.0] * 5
+    cfg["R"] = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+    cfg["P"] = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+    o = Oracle(cfg)
+    vec = g["vec"]
+    n = vec.shape[0] // 2
+    pn = np.concatenate([vec[:n], vec[n:2 * n]], axis=1)                     # two endpoints per segment
+    got = o.ground_project(pn)
+    ref = np.concatenate([g["ground"][:n, :2], g["ground"][n:2 * n, :2]], axis=1)
+    assert not g["ground"][:, 2].any()                                        # point.z = 0.0
+    # numpy's dot may fuse / reorder the three multiply-adds (a few ulp, amplified near the horizon where z -> 0);
+    # everything else is the same IEEE sequence
+    assert np.allclose(got, ref, rtol=1e-13, atol=1e-16)
+    assert np.median(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)) < 1e-15
+    # the clamp quirk rows of the fixture really exercise it
+    assert g["pixel"][3, 1] == 0.0 and g["pixel"][2, 1] == 479.0 and g["pixel"][5, 0] == 639.0 and g["pixel"][6].tolist() == [0.0, 0.0]
