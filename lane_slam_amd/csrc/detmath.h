@@ -286,16 +286,14 @@ LF_HD float fast_atan2_deg(float y, float x)
                 p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
     const float eps = (float)2.2204460492503131e-16;
     float ax = x < 0 ? -x : x, ay = y < 0 ? -y : y;
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + eps);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + eps);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    // OpenCV divides the smaller magnitude by the larger (+ eps) in either branch: one division, selected
+    // operands -- identical values, half the divide sequences in the region-growing accept chain
+    const bool steep = !(ax >= ay);
+    const float num = steep ? ax : ay, den = (steep ? ay : ax) + eps;
+    const float c = num / den;
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (steep) a = 90.f - a;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
