@@ -304,6 +304,26 @@ def main():
                 "sample": "%d of the %d frames of one step (same synthetic frames, same config, same %d-code map), "
                           "oracle/liblforacle.so single thread, %.1f s" % (nf, B, M, cdt),
                 "host_cpus": os.cpu_count()}
+            # the same port on many host cores at once (frames are independent; ctypes releases the GIL):
+            # BASELINE.md section 3 asks for both the single-thread and the all-cores figure
+            from concurrent.futures import ThreadPoolExecutor
+            T = max(1, min(64, (os.cpu_count() or 1) // 2))
+            per = 8 if args.geometry == "fullres" else 80
+            oracles = [Oracle(cfg) for _ in range(T)]
+
+            def work(t):
+                for k in range(per):
+                    r = oracles[t].process_frame(host[(t * per + k) % B], cap=3 * args.cap)
+                    if r["n"]:
+                        oracles[t].match(r["code"], mc)
+
+            t2 = time.perf_counter()
+            with ThreadPoolExecutor(T) as ex:
+                list(ex.map(work, range(T)))
+            mdt = time.perf_counter() - t2
+            result["cpu_baseline_threads"] = {
+                "value": round(T * per / mdt, 1), "unit": "frames/s", "cores": T, "kind": "port",
+                "sample": "%d threads x %d frames of the same step, one oracle instance per thread, %.1f s" % (T, per, mdt)}
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
