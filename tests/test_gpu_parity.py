@@ -475,3 +475,22 @@ def test_configuration_variants(variant):
         total += s.n
     assert total > 5
     fe.close()
+
+
+@pytest.mark.gpu
+def test_associate_large_map_and_many_ties():
+    """Maps beyond 4096 column blocks per workgroup chunk (the in-accumulator block counter has 12 bits, so the
+    launcher must split them) and heavy duplication: ties must resolve to the lowest map index everywhere."""
+    from oracle.oracle import Oracle
+    o = Oracle(default_config("parity"))
+    fe = FrontEnd(default_config("parity"))
+    rng = np.random.default_rng(23)
+    nm, nq = 150001, 260
+    base = rng.integers(0, 256, (500, 32), dtype=np.uint8)
+    m = base[rng.integers(0, 500, nm)]                      # every code occurs ~300 times
+    q = base[rng.integers(0, 500, nq)].copy()
+    q[::3, 5] ^= 0x11                                        # a third of the queries two bits away
+    idx, dist = fe.associate(q, m)
+    oi, od = o.match(q, m)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert (dist <= 2).all() and (np.diff(np.sort(idx)) >= 0).all()
