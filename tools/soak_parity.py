@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--parity", type=int, default=2000)
 ap.add_argument("--fullres", type=int, default=200)
 ap.add_argument("--clutter", type=int, default=100)
+ap.add_argument("--seed", type=int, default=0, help="offset added to every frame seed")
 args = ap.parse_args()
 KEYS = ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "code")
 
@@ -64,8 +65,8 @@ def clutter(frames, seed):
 
 
 bad = 0
-bad += check("parity", args.parity, 100000)
-bad += check("fullres", args.fullres, 200000)
-bad += check("fullres", args.clutter, 300000, clutter)
+bad += check("parity", args.parity, 100000 + args.seed)
+bad += check("fullres", args.fullres, 200000 + args.seed)
+bad += check("fullres", args.clutter, 300000 + args.seed, clutter)
 print("soak:", "OK" if bad == 0 else "%d MISMATCHING FRAMES" % bad)
 sys.exit(1 if bad else 0)
