@@ -138,11 +138,17 @@ def main():
     counts_local = torch.zeros(1, dtype=torch.int32, device=dev)
     counts_all = torch.zeros(world, dtype=torch.int32, device=dev)
     seg_total = [0]
+    # the handles' own HIP streams, wrapped so that torch events can order work across them
+    exts = [torch.cuda.ExternalStream(f.stream_ptr(), device=dev) for f in fes]
+    events = [tuple(torch.cuda.Event() for _ in range(3)) for _ in range(D)]
+    host_ms = {"wait": 0.0, "merge": 0.0, "assoc": 0.0, "map": 0.0, "n": 0}
 
     def finish(slot):
         """Complete the batch queued on `slot`: merge segment lists across ranks, associate, update the map."""
         f, out = fes[slot], outs[slot]
+        h0 = time.perf_counter()
         total = f.wait()
+        h1 = time.perf_counter()
         seg_total[0] = total
         n = min(total, G)
         if world > 1:
@@ -162,16 +168,29 @@ def main():
             src = gathered.view(world, G, 34)[:, : roll // world, :32]
         else:
             src = out["code"][: roll].view(1, -1, 32)[:, : roll]
-        # association: this rank's segments against the replicated map as it stood before this batch
-        torch.cuda.current_stream().synchronize()
+        # Association: this rank's segments against the replicated map as it stood before this batch; then the map
+        # update.  The association runs on the handle's own stream, the merge and the map on torch's: they are
+        # ordered with events, not host synchronisation, so the host goes straight back to queueing the next batch
+        # (with host syncs here the freed handle sat idle for ~1.4 ms per step behind a saturated GPU).
+        cur = torch.cuda.current_stream()
+        ev_a, ev_b, ev_c = events[slot]
+        ev_a.record(cur)
+        exts[slot].wait_event(ev_a)                 # after the merge and every earlier map update
+        h2 = time.perf_counter()
         if total > 0:
             f.associate_device(out["code"].data_ptr(), total, map_codes.data_ptr(), M, a_idx[slot].data_ptr(),
                                a_dist[slot].data_ptr())
-            f.synchronize()
+        ev_b.record(exts[slot])
+        cur.wait_event(ev_b)                        # the map changes only after this batch has been matched
+        h3 = time.perf_counter()
         # map update, rank-major / frame-minor so every rank holds the same map
         k = src.shape[1]
         map_codes[args.map: args.map + world * k] = src.reshape(-1, 32)
-        torch.cuda.current_stream().synchronize()
+        ev_c.record(cur)
+        exts[slot].wait_event(ev_c)                 # the handle's next batch may overwrite `out` only after it was read
+        h4 = time.perf_counter()
+        host_ms["wait"] += h1 - h0; host_ms["merge"] += h2 - h1; host_ms["assoc"] += h3 - h2; host_ms["map"] += h4 - h3
+        host_ms["n"] += 1
 
     def run(steps):
         inflight = []
@@ -194,10 +213,13 @@ def main():
     for f in fes:
         f.reset_timing()
         f.set_profiling(True)
+    for k_ in ("wait", "merge", "assoc", "map", "n"):
+        host_ms[k_] = 0
     t0 = time.perf_counter()
     run(args.steps)
     sync_all()
     dt = time.perf_counter() - t0
+    host_profile = {k_: round(1e3 * v / max(host_ms["n"], 1), 3) for k_, v in host_ms.items() if k_ != "n"}
     for f in fes:
         f.set_profiling(False)
     if world > 1:
@@ -277,7 +299,7 @@ def main():
                                    "Hamming association vs %d-code live map" % (B, args.geometry, fe.cols, fe.rows,
                                                                                  fe.lsd_cols, fe.lsd_rows, M),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0],
-                       "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                       "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, all-gather of segment blocks" % world},
             "roofline": roofline,
             "kernels": kernels,

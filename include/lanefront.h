@@ -109,6 +109,9 @@ void lf_destroy(lf_handle* h);
 const char* lf_last_error(const lf_handle* h);
 /* wait for all work queued on the handle's HIP stream */
 int lf_synchronize(lf_handle* h);
+/* the handle's HIP stream (a hipStream_t) for callers that order their own device work against the handle's with
+ * events instead of host synchronisation (e.g. torch.cuda.ExternalStream); the stream stays owned by the handle */
+int lf_get_stream(lf_handle* h, void** hip_stream);
 
 /* ---- plugin path: replaces LineDetectorLSD (line_detector_lsd.py:11-142) ---
  * lf_set_image  <-> LineDetectorLSD.setImage(bgr)      (:135-139)

@@ -17,7 +17,7 @@ LF_MSG_DETECTOR, LF_MSG_GROUND, LF_MSG_FILTERED = 0, 1, 2
 
 # every symbol include/lanefront.h declares
 EXPORTS = (
-    "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize",
+    "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize", "lf_get_stream",
     "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
     "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
@@ -56,6 +56,8 @@ def load():
     lib.lf_last_error.argtypes = [vp]
     lib.lf_last_error.restype = ctypes.c_char_p
     lib.lf_synchronize.argtypes = [vp]
+    lib.lf_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.lf_get_stream.restype = ci
     lib.lf_set_image.argtypes = [vp, vp, ci, ci, ci]
     lib.lf_detect_lines.argtypes = [vp, ci, vp, vp, vp, vp, ci, ctypes.POINTER(ci)]
     lib.lf_process_batch.argtypes = [vp, vp, ci, ci, ctypes.POINTER(LfSegments), ci, ci, ctypes.POINTER(ci)]

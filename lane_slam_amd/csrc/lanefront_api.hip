@@ -404,6 +404,14 @@ static int alloc_buffers(lf_handle* h)
 
 extern "C" int lf_abi_version(void) { return LF_ABI_VERSION; }
 
+extern "C" int lf_get_stream(lf_handle* h, void** hip_stream)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!hip_stream) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_get_stream: null argument"); return LF_ERR_BAD_ARG; }
+    *hip_stream = static_cast<void*>(h->stream);
+    return LF_OK;
+}
+
 extern "C" const char* lf_last_error(const lf_handle* h) { return h ? h->err : g_create_err; }
 
 extern "C" const char* lf_stage_name(int stage) { return (stage >= 0 && stage < LF_N_STAGES) ? kStageNames[stage] : "?"; }

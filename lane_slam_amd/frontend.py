@@ -86,6 +86,12 @@ class FrontEnd(object):
     def synchronize(self):
         self._check(self.lib.lf_synchronize(self.h))
 
+    def stream_ptr(self):
+        """The handle's hipStream_t as an integer (for torch.cuda.ExternalStream and event-based ordering)."""
+        p = ctypes.c_void_p()
+        self._check(self.lib.lf_get_stream(self.h, ctypes.byref(p)))
+        return p.value or 0
+
     # ------------------------------------------------------------------ host arrays
     def process_batch(self, frames, describe=True, n_frames=None):
         """frames: uint8 (n, in_rows, in_cols, 3) BGR on the host -- or, with n_frames given, the device
