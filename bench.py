@@ -27,8 +27,8 @@ import time
 
 # Six batches are kept in flight on six HIP streams (plus torch's); ROCclr maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Must be
-# set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# set before the HIP runtime initialises.  16 leaves room for the collective library's own streams at N > 1.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 
