@@ -126,8 +126,11 @@ def main():
     ptrs = [{k: v.data_ptr() for k, v in o.items()} for o in outs]
     # live map: M random codes (seed 1234, identical on every rank) + a rolling region that
     # receives the segments all ranks produced (append-only map, show_map.py:28-42)
-    G = 64 * 1024                                   # gathered segments per rank (padded block)
-    roll = min(G, 16384) * world
+    G = 16 * 1024                                   # gathered segments per rank (fixed-capacity block; a step's
+                                                    # ~11 k segments fit, a longer list contributes its first G)
+    # The rolling region has a FIXED total size: every rank contributes roll / world of its newest segments per
+    # step, so the map -- and with it the association work per GPU -- is the same at every N (weak scaling).
+    roll = (min(G, 16384) // world) * world
     map_codes = torch.from_numpy(np.concatenate([synth.random_codes(args.map, 1234),
                                                  synth.random_codes(roll, 4321)])).to(dev)
     M = map_codes.shape[0]
