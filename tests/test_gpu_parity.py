@@ -7,7 +7,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from lane_slam_amd import FrontEnd, LineDetectorHIP, default_config, synth
+from lane_slam_amd import FrontEnd, LanefrontError, LineDetectorHIP, default_config, synth
 from lane_slam_amd import _lib
 from lane_slam_amd.config import DEFAULT_DETECTOR_CONFIGURATION
 
@@ -494,3 +494,14 @@ def test_associate_large_map_and_many_ties():
     oi, od = o.match(q, m)
     assert np.array_equal(dist, od) and np.array_equal(idx, oi)
     assert (dist <= 2).all() and (np.diff(np.sort(idx)) >= 0).all()
+
+
+@pytest.mark.gpu
+def test_stream_handle_and_async_errors():
+    fe = FrontEnd(default_config("parity"), max_frames=2, max_lines_per_color=64)
+    assert fe.stream_ptr() != 0
+    other = FrontEnd(default_config("parity"), max_frames=2, max_lines_per_color=64)
+    assert other.stream_ptr() != fe.stream_ptr()            # one stream per handle
+    assert fe.wait() == 0                                    # nothing queued: not an error
+    with pytest.raises(LanefrontError):
+        fe.submit_device(0, 1, {}, 0)                        # null frames
