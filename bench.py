@@ -291,7 +291,11 @@ def main():
                         "measured": "HIP events on the launch stream, %d single-batch steps run right after the "
                                     "timed region (per-kernel times inside the overlapped region are in "
                                     "kernels_timed_region)" % solo_steps,
-                        "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None}
+                        "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
+                        "note": "dominant STREAMING kernel (most algorithmic bytes).  The longest kernel by time, lsd_grow "
+                                "(sequential-semantics LSD region growing, one wave per problem), is latency / issue bound and "
+                                "has no bandwidth or MFMA roofline (SURVEY 8d: report time); its time is in `kernels`, its "
+                                "instruction profile in DESIGN.md section 9"}
         result = {
             "metric": "frames/sec (640x480) detect->descript->project->sanity->associate",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
