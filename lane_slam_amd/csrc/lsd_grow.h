@@ -18,7 +18,7 @@
 //     integer / min-max reductions across lanes (exact, order free).
 // Per-pixel data are addressed by COMPACT index (raster rank among defined pixels); LDS holds
 // the row starts, the sorted x lists, one USED bit per defined pixel and the head of the region list
-// (~16 KB for a 512x256 problem), so many problems are resident per CU.
+// (13 KB for a 512x256 problem), so twelve problems are resident per CU.
 //
 // The same source compiles for the host (LF_HOST_SIM, one lane) so the control flow can be
 // checked against the oracle without a GPU (tests/hostsim); that build is a test harness,
