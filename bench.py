@@ -56,8 +56,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity"])
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (0: 256, or 32 for --geometry hd)")
+    ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity", "hd"],
+                    help="fullres / parity: BASELINE configs[1] (640x480 input); hd: configs[4]'s 1920x1080 frames "
+                         "(img_size [1080,1920], top_cutoff 360) -- an optional stress mode, not the headline")
     ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames per rank (tiled to --batch)")
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
@@ -91,9 +93,11 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    B = args.batch
+    hd = args.geometry == "hd"
+    B = args.batch or (32 if hd else 256)
     D = max(1, args.depth)
-    cfg = default_config(args.geometry)
+    in_rows, in_cols = (1080, 1920) if hd else (480, 640)
+    cfg = default_config("fullres", in_size=(in_rows, in_cols)) if hd else default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
     # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers)
     fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D)]
@@ -102,7 +106,7 @@ def main():
 
     # ---- synthetic input, resident in HBM before the timed region
     uniq = min(args.unique, B)
-    host = synth.make_batch(uniq, seed0=10000 * rank)
+    host = synth.make_batch(uniq, seed0=10000 * rank, rows=in_rows, cols=in_cols)
     reps = (B + uniq - 1) // uniq
     host = np.ascontiguousarray(np.tile(host, (reps, 1, 1, 1))[:B])
     frames = torch.from_numpy(host).to(dev)
@@ -297,14 +301,14 @@ def main():
                                 "has no bandwidth or MFMA roofline (SURVEY 8d: report time); its time is in `kernels`, its "
                                 "instruction profile in DESIGN.md section 9"}
         result = {
-            "metric": "frames/sec (640x480) detect->descript->project->sanity->associate",
+            "metric": "frames/sec (%dx%d) detect->descript->project->sanity->associate" % (in_cols, in_rows),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (i8 MFMA for association)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d-frame batch per GPU of 640x480 synthetic lane frames, "
-                                   "%s geometry (working image %dx%d, LSD image %dx%d), LSD+LBD+project+sanity, "
-                                   "Hamming association vs %d-code live map" % (B, args.geometry, fe.cols, fe.rows,
-                                                                                 fe.lsd_cols, fe.lsd_rows, M),
+            "config": {"workload": "%s%d-frame batch per GPU of %dx%d synthetic lane frames, %s geometry (working image %dx%d, "
+                                   "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs %d-code live map"
+                                   % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",
+                                      B, in_cols, in_rows, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0],
                        "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, all-gather of segment blocks" % world},
@@ -317,7 +321,7 @@ def main():
         if world == 1 and args.cpu_frames >= 0:
             from oracle.oracle import Oracle
             o = Oracle(cfg)
-            nf = args.cpu_frames or (160 if args.geometry == "fullres" else 1500)
+            nf = args.cpu_frames or (160 if args.geometry == "fullres" else (24 if hd else 1500))
             nf = min(nf, B)
             mc = map_codes.cpu().numpy()
             t1 = time.perf_counter()
@@ -337,7 +341,7 @@ def main():
             # BASELINE.md section 3 asks for both the single-thread and the all-cores figure
             from concurrent.futures import ThreadPoolExecutor
             T = max(1, min(64, (os.cpu_count() or 1) // 2))
-            per = 8 if args.geometry == "fullres" else 80
+            per = 8 if args.geometry == "fullres" else (1 if hd else 80)
             oracles = [Oracle(cfg) for _ in range(T)]
 
             def work(t):
