@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (0: 256, or 32 for --geometry hd)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (0: 256, or 128 for --geometry hd)")
     ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity", "hd"],
                     help="fullres / parity: BASELINE configs[1] (640x480 input); hd: configs[4]'s 1920x1080 frames "
                          "(img_size [1080,1920], top_cutoff 360) -- an optional stress mode, not the headline")
@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
-    ap.add_argument("--depth", type=int, default=6, help="independent batches in flight (handles/streams)")
+    ap.add_argument("--depth", type=int, default=0, help="independent batches in flight (handles/streams); 0: 6, or 3 for --geometry hd")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     args = ap.parse_args()
@@ -94,8 +94,8 @@ def main():
             dist.init_process_group("gloo")
 
     hd = args.geometry == "hd"
-    B = args.batch or (32 if hd else 256)
-    D = max(1, args.depth)
+    B = args.batch or (128 if hd else 256)
+    D = args.depth if args.depth > 0 else (3 if hd else 6)
     in_rows, in_cols = (1080, 1920) if hd else (480, 640)
     cfg = default_config("fullres", in_size=(in_rows, in_cols)) if hd else default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
