@@ -908,6 +908,12 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
         return LF_ERR_BAD_ARG;
     }
     if (n_frames > 65535) { lf_set_error(h, LF_ERR_CAPACITY, "lf_jpeg_decode_batch: at most 65535 frames per call"); return LF_ERR_CAPACITY; }
+    if (frames_on_device && frames == h->d_frames &&
+        (size_t)n_frames * rows * cols * 3 > (size_t)h->max_frames * h->cfg.in_rows * h->cfg.in_cols * 3) {
+        lf_set_error(h, LF_ERR_CAPACITY, "lf_jpeg_decode_batch: %d frames of %dx%d do not fit the handle's frame buffer (%d of %dx%d)",
+                     n_frames, rows, cols, h->max_frames, h->cfg.in_rows, h->cfg.in_cols);
+        return LF_ERR_CAPACITY;
+    }
     LF_HIP_CHECK(h, hipSetDevice(h->device));
     if (!h->jpeg) {
         h->jpeg = new (std::nothrow) JpegState();

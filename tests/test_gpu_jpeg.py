@@ -100,3 +100,14 @@ def test_camera_sized_batch_against_oracle_and_pillow():
     assert b.n == a.n and a.n > 0
     for k in ("frame_offset", "lines", "normals", "color", "ground", "keep", "desc", "code"):
         assert np.array_equal(getattr(a, k), getattr(b, k)), k
+
+
+def test_decode_into_the_handle_buffer_is_bounds_checked(vectors):
+    from lane_slam_amd import LanefrontError
+    fe2 = FrontEnd(default_config("parity"), max_frames=2, max_lines_per_color=16)
+    dev, nbytes = fe2.frames_buffer()
+    assert nbytes == 2 * 480 * 640 * 3
+    data = bytes(vectors["jpeg_full_640x480_420"])
+    assert not fe2.decode_jpeg_batch([data, data], device_ptr=dev).any()
+    with pytest.raises(LanefrontError):
+        fe2.decode_jpeg_batch([data, data, data], device_ptr=dev)       # three frames into a two-frame buffer
