@@ -86,8 +86,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LF_FORCE_COLLECTIVES=1 runs the N > 1 code path (process group, all-gathers, rank-major merge) with a single
+    # rank: a dry run of the RCCL calls on one GPU, never a headline configuration
+    multi = world > 1 or bool(os.environ.get("LF_FORCE_COLLECTIVES"))
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -158,7 +165,7 @@ def main():
         h1 = time.perf_counter()
         seg_total[0] = total
         n = min(total, G)
-        if world > 1:
+        if multi:
             block[:n, :32] = out["code"][:n]
             block[:n, 32] = out["keep"][:n]
             block[:n, 33] = out["color"][:n]
@@ -211,7 +218,7 @@ def main():
             finish(inflight.pop(0))
 
     def sync_all():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -229,7 +236,7 @@ def main():
     host_profile = {k_: round(1e3 * v / max(host_ms["n"], 1), 3) for k_, v in host_ms.items() if k_ != "n"}
     for f in fes:
         f.set_profiling(False)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -357,12 +364,21 @@ def main():
             result["cpu_baseline_threads"] = {
                 "value": round(T * per / mdt, 1), "unit": "frames/s", "cores": T, "kind": "port",
                 "sample": "%d threads x %d frames of the same step, one oracle instance per thread, %.1f s" % (T, per, mdt)}
-        print(json.dumps(result))
-    if world > 1:
+    # The JSON line is the LAST thing on stdout: libraries that log through C stdio (RCCL prints its version banner
+    # under NCCL_DEBUG=VERSION, buffered until exit when stdout is a pipe) are flushed on every rank first.
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if multi:
         dist.barrier()
-        dist.destroy_process_group()
     for f in fes:
         f.close()
+    if multi:
+        dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(result))
+        sys.stdout.flush()
     return result
 
 
