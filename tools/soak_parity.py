@@ -15,25 +15,27 @@ ap.add_argument("--parity", type=int, default=2000)
 ap.add_argument("--fullres", type=int, default=200)
 ap.add_argument("--clutter", type=int, default=100)
 ap.add_argument("--seed", type=int, default=0, help="offset added to every frame seed")
+ap.add_argument("--hd", type=int, default=0, help="1920x1080 frames (img_size [1080,1920], top_cutoff 360)")
 args = ap.parse_args()
 KEYS = ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "code")
 
 
 def check(geom, n, seed0, mutate=None):
-    cfg = default_config(geom)
+    hd = geom == "hd"
+    cfg = default_config("fullres", in_size=(1080, 1920)) if hd else default_config(geom)
     o = Oracle(cfg)
-    B = 64
-    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=2048)
+    B = 16 if hd else 64
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=4096)
     bad = segs = 0
     t0 = time.time()
     for b0 in range(0, n, B):
         nb = min(B, n - b0)
-        frames = synth.make_batch(nb, seed0 + b0)
+        frames = synth.make_batch(nb, seed0 + b0, rows=1080, cols=1920) if hd else synth.make_batch(nb, seed0 + b0)
         if mutate is not None:
             frames = mutate(frames, seed0 + b0)
         seg = fe.process_batch(frames)
         for f in range(nb):
-            r = o.process_frame(frames[f], cap=8192)
+            r = o.process_frame(frames[f], cap=16384)
             s = seg.frame(f)
             ok = s.n == r["n"] and all(np.array_equal(getattr(s, k), r[k]) for k in KEYS)
             ok = ok and np.allclose(s.desc, r["desc"], rtol=0, atol=1e-6)
@@ -68,5 +70,7 @@ bad = 0
 bad += check("parity", args.parity, 100000 + args.seed)
 bad += check("fullres", args.fullres, 200000 + args.seed)
 bad += check("fullres", args.clutter, 300000 + args.seed, clutter)
+if args.hd:
+    bad += check("hd", args.hd, 400000 + args.seed)
 print("soak:", "OK" if bad == 0 else "%d MISMATCHING FRAMES" % bad)
 sys.exit(1 if bad else 0)
