@@ -11,7 +11,8 @@
 //   IS the 64-pixel bit-plane word pair.  Output: `weak` (m > low and local max) and
 //   `strong` (also m > high) bit planes, 1 bit per pixel -- 8x fewer bytes than u8 maps.
 //   Algorithmic bytes per pixel: 3 read (moved as one BGRX dword), 2/8 written.
-// k_hysteresis: one workgroup per frame, both bit planes resident in LDS; Jacobi sweeps of
+// k_hysteresis: one workgroup per frame, both bit planes resident in LDS (k_hysteresis_strips: strip by strip
+//   for frames that are too large); Jacobi sweeps of
 //   "strong |= weak & dilate3x3(strong)" with an exact in-word run fill (carry trick) until
 //   a sweep changes nothing.  The fixpoint is unique, so the result does not depend on
 //   sweep order (== the reference's stack-based flood fill).
@@ -170,46 +171,84 @@ __global__ __launch_bounds__(1024) void k_hysteresis(CannyParams p, uint32_t* __
     for (int i = threadIdx.x; i < nw; i += blockDim.x) gs[i] = S[i];
 }
 
-// Fallback for working images whose two bit planes do not fit one CU's LDS (e.g. 1920x720):
-// the same Jacobi iteration by one workgroup per frame, on the planes in HBM/L2.  Strong bits
-// only ever get set, and every word is written by exactly one lane per sweep, so a sweep that
-// reads a neighbour's freshly written word merely converges faster (Gauss-Seidel); the fixpoint
-// is the same unique one.
-__global__ __launch_bounds__(1024) void k_hysteresis_global(CannyParams p, uint32_t* strong,
+// Working images whose two bit planes do not fit one workgroup's LDS (e.g. 1920x720: 2 x 173 KB): one workgroup
+// per frame sweeps the frame in horizontal STRIPS.  A strip (its weak rows, its strong rows and one strong halo row
+// above and below, which stay fixed) is brought into LDS, iterated to its local fixpoint exactly as k_hysteresis
+// does, and written back; strips are visited top to bottom, then bottom to top, until a whole down + up cycle
+// changes nothing.  Strong bits only ever get set and the fixpoint is unique, so the visiting order is free;
+// a chain of weak pixels crosses any number of strips in one pass in its direction of travel.
+__global__ __launch_bounds__(1024) void k_hysteresis_strips(CannyParams p, int strip_rows, uint32_t* __restrict__ strong,
                                                              const uint32_t* __restrict__ weak)
 {
-    const int nw = p.Hc * p.Ww;
+    extern __shared__ uint32_t lds[];
+    const int Ww = p.Ww, Hc = p.Hc;
     const int f = blockIdx.x;
-    volatile uint32_t* S = strong + (size_t)f * nw;
-    const uint32_t* Wk = weak + (size_t)f * nw;
-    const int Ww = p.Ww;
-    for (int iter = 0; iter < (1 << 20); ++iter) {
-        int changed = 0;
-        for (int i = threadIdx.x; i < nw; i += 1024) {
-            const uint32_t w = Wk[i];
-            if (!w) continue;
-            const int y = i / Ww, x = i - y * Ww;
-            const uint32_t cur = S[i];
-            if ((cur & w) == w) continue;                  // nothing left to gain in this word
-            uint32_t acc = 0;
+    uint32_t* gs = strong + (size_t)f * Hc * Ww;
+    const uint32_t* gw = weak + (size_t)f * Hc * Ww;
+    uint32_t* S = lds;                                   // [(strip_rows + 2)][Ww], row 0 / last = halo
+    uint32_t* Wk = lds + (size_t)(strip_rows + 2) * Ww;  // [strip_rows][Ww]
+    const int n_strips = (Hc + strip_rows - 1) / strip_rows;
+    for (int cycle = 0; cycle < 65536; ++cycle) {
+        int cycle_changed = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int k = 0; k < n_strips; ++k) {
+                const int st = pass == 0 ? k : n_strips - 1 - k;
+                const int r0 = st * strip_rows, nr = min(strip_rows, Hc - r0);
+                const int nw = nr * Ww;
+                __syncthreads();
+                for (int i = threadIdx.x; i < (nr + 2) * Ww; i += 1024) {
+                    const int ry = i / Ww - 1 + r0;                       // image row of this LDS row
+                    S[i] = (ry >= 0 && ry < Hc) ? gs[(size_t)ry * Ww + (i % Ww)] : 0u;
+                }
+                for (int i = threadIdx.x; i < nw; i += 1024) Wk[i] = gw[(size_t)r0 * Ww + i];
+                __syncthreads();
+                int strip_changed = 0;
+                for (int iter = 0; iter < 65536; ++iter) {
+                    int changed = 0;
+                    uint32_t upd[8];
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int yy = y + dy;
-                if (yy < 0 || yy >= p.Hc) continue;
-                volatile uint32_t* row = S + yy * Ww;
-                const uint32_t c = row[x];
-                const uint32_t l = x > 0 ? row[x - 1] : 0u;
-                const uint32_t r = x + 1 < Ww ? row[x + 1] : 0u;
-                acc |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+                    for (int cnt = 0; cnt < 8; ++cnt) {
+                        const int i = threadIdx.x + cnt * 1024;
+                        upd[cnt] = 0;
+                        if (i >= nw) continue;
+                        const int y = i / Ww, x = i - y * Ww;
+                        const uint32_t w = Wk[i];
+                        const uint32_t cur = S[(y + 1) * Ww + x];
+                        uint32_t acc = 0;
+                        if (w) {
+#pragma unroll
+                            for (int dy = 0; dy <= 2; ++dy) {                  // LDS rows y .. y+2 = image rows y-1 .. y+1
+                                const uint32_t* row = S + (y + dy) * Ww;
+                                const uint32_t c = row[x];
+                                const uint32_t l = x > 0 ? row[x - 1] : 0u;
+                                const uint32_t r = x + 1 < Ww ? row[x + 1] : 0u;
+                                acc |= c | (c << 1) | (c >> 1) | (l >> 31) | (r << 31);
+                            }
+                            uint32_t sfill = acc & w;
+                            sfill = fill_up(w, sfill);
+                            sfill = __brev(fill_up(__brev(w), __brev(sfill)));
+                            acc = sfill;
+                        }
+                        upd[cnt] = acc | cur;
+                        changed |= (upd[cnt] != cur);
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int cnt = 0; cnt < 8; ++cnt) {
+                        const int i = threadIdx.x + cnt * 1024;
+                        if (i < nw) { const int y = i / Ww, x = i - y * Ww; S[(y + 1) * Ww + x] = upd[cnt]; }
+                    }
+                    if (!__syncthreads_or(changed)) break;
+                    strip_changed = 1;
+                }
+                if (strip_changed) {
+                    for (int i = threadIdx.x; i < nw; i += 1024) gs[(size_t)r0 * Ww + i] = S[Ww + i];
+                    cycle_changed = 1;
+                }
+                __threadfence_block();
             }
-            uint32_t s = acc & w;
-            s = fill_up(w, s);
-            s = __brev(fill_up(__brev(w), __brev(s)));
-            const uint32_t nv = s | cur;
-            if (nv != cur) { S[i] = nv; changed = 1; }
         }
-        __threadfence_block();
-        if (!__syncthreads_or(changed)) break;
+        if (!__syncthreads_or(cycle_changed)) break;
     }
 }
 
@@ -220,7 +259,13 @@ int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, cons
     if (lds <= 64 * 1024 && nw <= 8 * 1024) {
         hipLaunchKernelGGL(k_hysteresis, dim3(n_frames), dim3(1024), lds, s, p, strong, weak);
     } else {
-        hipLaunchKernelGGL(k_hysteresis_global, dim3(n_frames), dim3(1024), 0, s, p, strong, weak);
+        // strips of at most 8192 words (8 per thread) and 60 KB of LDS for the three row sets
+        int rows = 8192 / p.Ww;
+        const int by_lds = (int)((60 * 1024 / sizeof(uint32_t)) / (2 * (size_t)p.Ww)) - 1;
+        if (rows > by_lds) rows = by_lds;
+        if (rows < 1) return -1;
+        const size_t slds = ((size_t)(rows + 2) + rows) * p.Ww * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_hysteresis_strips, dim3(n_frames), dim3(1024), slds, s, p, rows, strong, weak);
     }
     return 0;
 }
