@@ -505,3 +505,33 @@ def test_stream_handle_and_async_errors():
     assert fe.wait() == 0                                    # nothing queued: not an error
     with pytest.raises(LanefrontError):
         fe.submit_device(0, 1, {}, 0)                        # null frames
+
+
+@pytest.mark.gpu
+def test_hysteresis_strips_follow_a_serpentine_weak_chain():
+    """1920x1080: a low-contrast zig-zag bar (weak edges only) that climbs and descends the whole working image
+    several times; only its first few pixels have high contrast (the only strong edges).  Hysteresis has to carry the
+    strong label along the chain across every LDS strip, in both directions, repeatedly."""
+    from oracle.oracle import Oracle
+    cfg = default_config("fullres", in_size=(1080, 1920))
+    o = Oracle(cfg)
+    fe = FrontEnd(cfg, max_frames=1, max_lines_per_color=4096)
+    frame = np.full((1080, 1920, 3), 70, np.uint8)
+    top, bot = 390, 1050
+    mid, amp = (top + bot) / 2.0, (bot - top) / 2.0
+    for t in np.linspace(0.0, 1.0, 40000):                    # a sine wave, five periods across the frame
+        cx = 60 + t * 1760
+        cy = mid + amp * np.cos(2 * np.pi * 5 * t)
+        # +26 grey levels: weak edges only -- except the first 18 px of the band, the only strong edges of the frame
+        frame[int(round(cy)) - 2:int(round(cy)) + 3, int(round(cx)) - 2:int(round(cx)) + 3] = 230 if t < 0.01 else 96
+    fe.process_batch(frame[None])
+    edges = fe.fetch(_lib.LF_BUF_EDGES, 1)[0]
+    work = o.preprocess(frame)
+    ref = o.canny(work)
+    assert np.array_equal(edges, ref)
+    # the chain really is promoted end to end (not only near the seed), i.e. hysteresis did the work
+    cols = np.nonzero(ref.any(axis=0))[0]
+    assert cols.min() < 100 and cols.max() > 1700 and ref.sum() // 255 > 10000
+    head = frame.copy()
+    head[:, 100:] = 70                                        # the strong head alone: a few hundred edge pixels
+    assert o.canny(o.preprocess(head)).sum() // 255 < 400
