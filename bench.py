@@ -331,14 +331,33 @@ def main():
             nf = args.cpu_frames or (160 if args.geometry == "fullres" else (24 if hd else 1500))
             nf = min(nf, B)
             mc = map_codes.cpu().numpy()
-            t1 = time.perf_counter()
+            # parity gate of this very run: the GPU output of the last batch on handle 0,
+            # frame by frame, against what the oracle computes for the same frames while it is being timed
+            g_fo = outs[0]["frame_offset"].cpu().numpy()
+            g_n = int(g_fo[-1])
+            g = {k_: outs[0][k_][:g_n].cpu().numpy() for k_ in ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "code")}
+            g_desc = outs[0]["desc"][:g_n].cpu().numpy()
+            gate_ok, gate_frames, gate_desc_err = True, 0, 0.0
+            cdt = 0.0
             nseg = 0
             for f in range(nf):
+                t1 = time.perf_counter()
                 r = o.process_frame(host[f], cap=3 * args.cap)
                 nseg += r["n"]
                 if r["n"]:
                     o.match(r["code"], mc)
-            cdt = time.perf_counter() - t1
+                cdt += time.perf_counter() - t1            # the comparison below is not part of the baseline
+                a_, b_ = int(g_fo[f]), int(g_fo[f + 1])
+                same = (b_ - a_) == r["n"] and all(np.array_equal(g[k_][a_:b_], r[k_]) for k_ in g)
+                if same and r["n"]:
+                    gate_desc_err = max(gate_desc_err, float(np.abs(g_desc[a_:b_] - r["desc"]).max()))
+                gate_ok = gate_ok and same
+                gate_frames += 1
+            result["parity_gate"] = {
+                "frames": gate_frames, "identical": bool(gate_ok and gate_desc_err <= 1e-4),
+                "fields_bit_exact": ["lines", "normals", "color", "pixels_normalized", "ground", "keep", "code"],
+                "descriptor_max_abs_diff": gate_desc_err, "descriptor_tolerance": 1e-4,
+                "what": "GPU output of the run's last batch vs the oracle on the same frames"}
             result["cpu_baseline"] = {
                 "value": round(nf / cdt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
                 "sample": "%d of the %d frames of one step (same synthetic frames, same config, same %d-code map), "
