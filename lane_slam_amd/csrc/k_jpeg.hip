@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(JpegGeom g, const jpeg::Frame
     const int t = threadIdx.x, lb = t >> 3, k = t & 7;
     const int b = blockIdx.x * kBlocksPerWg + lb;
     const int nblocks = H->valid ? H->nblocks : 0;
-    if (blockIdx.x * kBlocksPerWg >= nblocks) return;          // whole workgroup beyond this frame's scan
+    if ((int)blockIdx.x * kBlocksPerWg >= nblocks) return;     // whole workgroup beyond this frame's scan
     const bool act = b < nblocks;
     int32_t* w = ws + lb * kBlockStride;
 #pragma unroll
