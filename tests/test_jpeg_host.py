@@ -94,3 +94,27 @@ def test_host_decoder_on_reference_camera_images(host):
         data = open(f, "rb").read()
         rc, dense, _, _ = _coefs(host, data)
         assert rc == 0 and np.array_equal(dense, jpeg_coefficients(data)), os.path.basename(f)
+
+
+def test_decoders_survive_hostile_input_under_sanitizers(vectors, tmp_path):
+    """AddressSanitizer + UBSan build of the product's host decoder and the oracle's (tests/hostsim/jpeg_fuzz.cpp):
+    truncations, bit flips, byte splices and deletions of the golden streams.  No memory error, no undefined
+    behaviour, and whenever both accept a mutated stream they agree on every coefficient."""
+    exe = os.path.join(HERE, "hostsim", "_build", "jpeg_fuzz")
+    srcs = [os.path.join(HERE, "hostsim", "jpeg_fuzz.cpp"), os.path.join(HERE, "..", "oracle", "lf_oracle_jpeg.c"),
+            os.path.join(HERE, "..", "lane_slam_amd", "csrc", "jpeg_entropy.cpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        obj = os.path.join(os.path.dirname(exe), "lf_oracle_jpeg_asan.o")
+        san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g", "-O1"]
+        subprocess.check_call(["gcc", "-std=c11", "-c", "-I" + os.path.join(HERE, "..", "oracle"), srcs[1], "-o", obj] + san)
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", srcs[0], obj, "-o", exe] + san)
+    files = []
+    for name in ("lane_q75_420", "noise_q30_444", "smooth_q95_422", "gray", "lane_rst_420", "noise_opt_420", "tiny_3x5_420", "lane_rgb_444"):
+        p = tmp_path / (name + ".jpg")
+        p.write_bytes(bytes(vectors["jpeg_" + name]))
+        files.append(str(p))
+    out = subprocess.run([exe] + files + ["--iters", "250"], capture_output=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0, (out.stdout + out.stderr).decode()[-2000:]
+    assert b"identical coefficients" in out.stdout
