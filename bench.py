@@ -29,6 +29,9 @@ import time
 # GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Must be
 # set before the HIP runtime initialises.  16 leaves room for the collective library's own streams at N > 1.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# dmabuf IPC (the only kind the pool's host driver supports) -- read when HSA initialises, so it is set here, before
+# any torch GPU call, not next to init_process_group
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 
@@ -90,7 +93,6 @@ def main():
     # rank: a dry run of the RCCL calls on one GPU, never a headline configuration
     multi = world > 1 or bool(os.environ.get("LF_FORCE_COLLECTIVES"))
     if multi:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")

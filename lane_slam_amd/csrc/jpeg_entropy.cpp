@@ -3,6 +3,7 @@
 #include "jpeg_entropy.h"
 
 #include <cstring>
+#include <exception>
 
 #include "../../include/lanefront.h"
 
@@ -288,7 +289,7 @@ int peek(const uint8_t* data, size_t size, int* rows, int* cols, int* ncomp, int
     return LF_OK;
 }
 
-int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out)
+static int decode_coefficients_impl(const uint8_t* data, size_t size, FrameCoefs& out, int expect_rows, int expect_cols)
 {
     out.n_entries = 0;
     out.hdr.valid = 0;
@@ -299,6 +300,12 @@ int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out)
     if (rc != LF_OK) { out.status = rc; return rc; }
     out.rows = j.rows;
     out.cols = j.cols;
+    // A stream of another size than the caller declared is refused HERE, before anything is sized from the
+    // stream's own (untrusted) SOF fields.
+    if (expect_rows > 0 && expect_cols > 0 && (j.rows != expect_rows || j.cols != expect_cols)) {
+        out.status = LF_ERR_BAD_ARG;
+        return out.status;
+    }
     FrameHeader& h = out.hdr;
     h.ncomp = j.ncomp;
     h.hmax = j.hmax;
@@ -310,6 +317,12 @@ int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out)
     const int bpm = j.ncomp == 1 ? 1 : luma_blocks + 2;
     const long nblocks = (long)h.mcux * h.mcuy * bpm;
     if (nblocks > (1L << 24)) { out.status = LF_ERR_UNSUPPORTED; return out.status; }
+    // Every block costs at least two bits of entropy data (a DC code and an EOB or AC code of >= 1 bit each) and
+    // every coefficient at least two (a code and >= 1 magnitude bit): a stream too short for its declared size
+    // cannot decode, so nothing is allocated beyond what the stream's own length can fill.
+    const size_t scan_len = (size_t)(j.end - j.scan);
+    const size_t max_units = 4 * scan_len + 64;
+    if ((size_t)nblocks > max_units) { out.status = LF_ERR_DECODE; return out.status; }
     h.nblocks = (int32_t)nblocks;
     for (int c = 0; c < 3; ++c)
         std::memcpy(h.qt[c], j.qt[j.comp[c < j.ncomp ? c : 0].tq], sizeof(h.qt[c]));
@@ -343,13 +356,16 @@ int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out)
             const HuffTable& tdc = j.dc[j.comp[c].td];
             const HuffTable& tac = j.ac[j.comp[c].ta];
             if (ne + 64 > cap) {
-                cap = cap ? cap * 2 : (size_t)nblocks * 8 + 64;
+                size_t want = cap ? cap * 2 : (size_t)nblocks * 8 + 64;
+                if (want > max_units + 64) want = max_units + 64;
+                if (want < ne + 64) { rc = LF_ERR_DECODE; break; }      // more coefficients than the stream has bits for
+                cap = want;
                 out.entries.resize(cap);
                 ent = out.entries.data();
             }
             int s = decode_symbol(br, tdc);
             if (s < 0 || s > 11) { rc = LF_ERR_DECODE; break; }
-            if (s) pred[c] += receive_extend(br, s);
+            if (s) pred[c] = (int)((unsigned)pred[c] + (unsigned)receive_extend(br, s));   // wraps, never UB (hostile streams)
             if (pred[c]) ent[ne++] = (uint32_t)(uint16_t)(int16_t)pred[c];
             for (int k = 1; k < 64;) {
                 const int rs = decode_symbol(br, tac);
@@ -380,6 +396,20 @@ int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out)
     h.valid = 1;
     out.status = LF_OK;
     return LF_OK;
+}
+
+int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out, int expect_rows, int expect_cols)
+{
+    // never let an exception cross into a worker thread or the C ABI
+    try {
+        return decode_coefficients_impl(data, size, out, expect_rows, expect_cols);
+    } catch (const std::exception&) {
+        out.n_entries = 0;
+        out.hdr.valid = 0;
+        out.hdr.nblocks = 0;
+        out.status = LF_ERR_CAPACITY;      // out of host memory
+        return out.status;
+    }
 }
 
 WorkerPool::~WorkerPool()

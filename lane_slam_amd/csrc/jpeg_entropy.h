@@ -46,8 +46,11 @@ struct FrameCoefs {
 int peek(const uint8_t* data, size_t size, int* rows, int* cols, int* ncomp, int* hmax, int* vmax);
 
 // Parse and entropy-decode one stream.  Returns the frame's lf_status (also stored in out.status);
-// on failure out.hdr.valid = 0 and the coefficient lists are empty.
-int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out);
+// on failure out.hdr.valid = 0 and the coefficient lists are empty.  expect_rows / expect_cols > 0: a stream of
+// any other size is refused (LF_ERR_BAD_ARG) right after its headers, before any buffer is sized from them.
+// Host allocations are bounded by the stream's length; allocation failure is a status (LF_ERR_CAPACITY), never
+// an exception.
+int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out, int expect_rows = 0, int expect_cols = 0);
 
 // Persistent host threads for the per-frame work (entropy decoding, packing the staging buffer):
 // run(n, job) executes job(worker) on n workers and returns when all are done.  Threads are created

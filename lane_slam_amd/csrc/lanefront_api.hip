@@ -58,6 +58,7 @@ struct lf_handle {
     int max_nsx = 0, max_nsy = 0;
     // device buffers
     uint8_t *d_frames = nullptr, *d_masks = nullptr, *d_edges_u8 = nullptr;
+    size_t frames_bytes = 0;            // allocation behind d_frames
     uint32_t* d_bgr = nullptr;          // corrected working image, BGRX dword per pixel
     DevBuf dbg_bgr;
     uint32_t *d_strong = nullptr, *d_weak = nullptr, *d_maskbits = nullptr;
@@ -235,6 +236,11 @@ static int build_params(lf_handle* h)
     else { L.Ws = h->W; L.Hs = h->Hc; }
     h->Hs = L.Hs; h->Ws = L.Ws; h->Ps = (size_t)L.Hs * L.Ws;
     if (h->Ps >= (1u << 20) || L.Ws > 65535 || L.Hs > 65535) { lf_set_error(h, LF_ERR_UNSUPPORTED, "scaled LSD image too large"); return LF_ERR_UNSUPPORTED; }
+    // LDS limits of the two LDS-resident stages, checked once here so that an unsupported geometry fails at
+    // lf_create instead of as a launch error later: region growing keeps the row-start table of its problem in
+    // LDS (k_lsd_grow.hip), canny hysteresis sweeps strips of >= 1 row + 2 halo rows (k_canny.hip)
+    if ((size_t)((L.Hs + 2) & ~1) * 4 + 512 * 4 + 1024 > 64 * 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "scaled LSD image has %d rows: the row table exceeds the LDS of one problem", L.Hs); return LF_ERR_UNSUPPORTED; }
+    if ((size_t)h->Hc * h->Ww > 8 * 1024 && (8192 / h->Ww < 1 || (int)((60 * 1024 / 4) / (2 * (size_t)h->Ww)) - 1 < 1)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols %d: one row of the edge bit planes exceeds the hysteresis strip budget", h->W); return LF_ERR_UNSUPPORTED; }
     if (c.lsd_n_bins < 2 || c.lsd_n_bins > 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_n_bins must be in [2,1024]"); return LF_ERR_UNSUPPORTED; }
     if (L.scaled) {
         const double sigma = (c.lsd_scale < 1) ? (c.lsd_sigma_scale / c.lsd_scale) : c.lsd_sigma_scale;
@@ -376,7 +382,10 @@ static int alloc_buffers(lf_handle* h)
     const size_t in_px = (size_t)h->cfg.in_rows * h->cfg.in_cols;
     const size_t nprob = B * 3;
     const size_t cap = nprob * (size_t)h->cap_lines;
-    if (dalloc(h, &h->d_frames, B * in_px * 3) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_masks, nprob * P) ||
+    // the plugin path (lf_set_image) stages one WORKING image here, which is larger than an input frame when
+    // img_size > in_size
+    h->frames_bytes = B * in_px * 3 > P * 3 ? B * in_px * 3 : P * 3;
+    if (dalloc(h, &h->d_frames, h->frames_bytes) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_masks, nprob * P) ||
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) || dalloc(h, &h->d_maskbits, nprob * h->Hc * h->Ww) ||
         dalloc(h, &h->d_raddr, nprob * Ps) || dalloc(h, &h->d_rdeg, nprob * Ps) || dalloc(h, &h->d_rmod, nprob * Ps) ||
         dalloc(h, &h->d_rcs, nprob * Ps) || dalloc(h, &h->d_rsn, nprob * Ps) || dalloc(h, &h->d_nrec, nprob) ||
@@ -509,7 +518,10 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     { StageTimer t(h, ST_CANNY); launch_canny(h->canny, h->d_bgr, n, h->d_strong, h->d_weak, s); }
     {
         StageTimer t(h, ST_HYST);
-        (void)launch_hysteresis(h->canny, n, h->d_strong, h->d_weak, s);
+        if (launch_hysteresis(h->canny, n, h->d_strong, h->d_weak, s) != 0) {
+            lf_set_error(h, LF_ERR_UNSUPPORTED, "canny hysteresis: a %dx%d working image does not fit the LDS-resident strips", h->Hc, h->W);
+            return LF_ERR_UNSUPPORTED;
+        }
     }
     {
         StageTimer t(h, ST_LSD_GRAD);
@@ -894,7 +906,7 @@ extern "C" int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* byte
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
     if (device_ptr) *device_ptr = h->d_frames;
-    if (bytes) *bytes = (size_t)h->max_frames * h->cfg.in_rows * h->cfg.in_cols * 3;
+    if (bytes) *bytes = h->frames_bytes;
     return LF_OK;
 }
 
@@ -909,7 +921,7 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
     }
     if (n_frames > 65535) { lf_set_error(h, LF_ERR_CAPACITY, "lf_jpeg_decode_batch: at most 65535 frames per call"); return LF_ERR_CAPACITY; }
     if (frames_on_device && frames == h->d_frames &&
-        (size_t)n_frames * rows * cols * 3 > (size_t)h->max_frames * h->cfg.in_rows * h->cfg.in_cols * 3) {
+        (size_t)n_frames * rows * cols * 3 > h->frames_bytes) {
         lf_set_error(h, LF_ERR_CAPACITY, "lf_jpeg_decode_batch: %d frames of %dx%d do not fit the handle's frame buffer (%d of %dx%d)",
                      n_frames, rows, cols, h->max_frames, h->cfg.in_rows, h->cfg.in_cols);
         return LF_ERR_CAPACITY;
@@ -940,11 +952,10 @@ extern "C" int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, co
                 if (i >= n_frames) break;
                 lf::jpeg::FrameCoefs& fc = J.frames[(size_t)i];
                 if (!jpeg[i]) { fc.status = LF_ERR_BAD_ARG; fc.hdr.valid = 0; fc.hdr.nblocks = 0; fc.n_entries = 0; continue; }
-                int rc = lf::jpeg::decode_coefficients(jpeg[i], jpeg_size[i], fc);
-                if (rc == LF_OK && (fc.rows != rows || fc.cols != cols)) {
-                    fc.status = LF_ERR_BAD_ARG;          // decodable, but not the size the batch was declared with
-                    fc.hdr.valid = 0; fc.hdr.nblocks = 0; fc.n_entries = 0;
-                }
+                // a stream of another size than the batch was declared with is refused right after its headers
+                // (LF_ERR_BAD_ARG), before any host buffer is sized from the stream's own fields
+                (void)lf::jpeg::decode_coefficients(jpeg[i], jpeg_size[i], fc, rows, cols);
+                if (fc.status != LF_OK) { fc.hdr.valid = 0; fc.hdr.nblocks = 0; fc.n_entries = 0; }
             }
         });
     }

@@ -29,3 +29,12 @@ extern "C" int hs_jpeg_coefficients(const uint8_t* d, size_t n, int16_t* dense, 
     }
     return 0;
 }
+
+// decode with a declared size; reports how much host memory the decoder sized from the stream (entries + block table)
+extern "C" int hs_jpeg_decode_expect(const uint8_t* d, size_t n, int expect_rows, int expect_cols, long* alloc_bytes)
+{
+    lf::jpeg::FrameCoefs fc;
+    const int rc = lf::jpeg::decode_coefficients(d, n, fc, expect_rows, expect_cols);
+    *alloc_bytes = (long)(fc.entries.capacity() * 4 + fc.block_end.capacity() * 4);
+    return rc;
+}

@@ -72,6 +72,27 @@ def test_host_decoder_refuses_bad_streams(host, vectors):
         assert _coefs(host, bytes(b))[0] in (0, LF_ERR_DECODE, LF_ERR_UNSUPPORTED)
 
 
+def test_host_decoder_bounds_allocation_by_the_stream(host, vectors):
+    """A tiny stream whose SOF declares 8192x8192 must not make the decoder allocate for 8192x8192: with
+    the batch's declared size it is refused right after its headers, without it by the stream-length bound."""
+    data = bytearray(bytes(vectors["jpeg_lane_q75_420"]))
+    i = data.find(b"\xff\xc0")
+    assert i > 0
+    rows0, cols0 = (data[i + 5] << 8) | data[i + 6], (data[i + 7] << 8) | data[i + 8]
+    data[i + 5:i + 9] = bytes([0x20, 0x00, 0x20, 0x00])          # 8192 x 8192
+    buf = np.frombuffer(bytes(data), np.uint8)
+    host.hs_jpeg_decode_expect.restype = ctypes.c_int
+    alloc = ctypes.c_long()
+    rc = host.hs_jpeg_decode_expect(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.size), rows0, cols0, ctypes.byref(alloc))
+    assert rc == -1 and alloc.value == 0                         # LF_ERR_BAD_ARG, nothing sized from the stream
+    rc = host.hs_jpeg_decode_expect(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.size), 0, 0, ctypes.byref(alloc))
+    assert rc == -6 and alloc.value <= 64 * buf.size + 4096      # LF_ERR_DECODE; at most a small multiple of the stream
+    # the genuine stream still decodes when its size is declared
+    good = np.frombuffer(bytes(vectors["jpeg_lane_q75_420"]), np.uint8)
+    rc = host.hs_jpeg_decode_expect(good.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(good.size), rows0, cols0, ctypes.byref(alloc))
+    assert rc == 0
+
+
 def test_host_decoder_builtin_tables(host, vectors):
     """DHT-less streams: the product's copy of the Annex K tables gives the same coefficients as the stream's own."""
     from test_oracle_jpeg import strip_dht
