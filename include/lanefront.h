@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 2   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages */
+#define LF_ABI_VERSION 3   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages; 3: live map (lf_map_*) */
 
 typedef enum lf_status {
     LF_OK = 0,
@@ -159,6 +159,95 @@ int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* ma
 /* float LBD (72-d, unit norm) Euclidean nearest neighbour on fp32 MFMA */
 int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
                        int32_t* idx, float* dist, int on_device);
+
+/* ---- live map + associator (SURVEY a-11, 8f-3) ------------------------------------------------
+ * What the package offers in place of the reference's line_associator node, which is an unfinished stub
+ * (src/line_associator/src/line_associator_node.py:12-86), and of show_map's append-only segment store
+ * (src/show_map/src/show_map.py:28-42).  The matching itself keeps BinaryDescriptorMatcher::match semantics
+ * (a-10 above); everything else in this section is this package's OWN contract -- no reference behaviour exists
+ * to match -- and oracle/lf_oracle_map.c is its sequential statement.
+ *
+ * A map lives on one device: per entry the 32-byte code, colour, the two ground endpoints (x0 y0 x1 y1, map
+ * frame, metres), hits, last_seen (step number), plus the int8 operands of the MFMA associator, which are
+ * re-packed only for the rows an update touches.  All map work runs on the map's own HIP stream, in call order.
+ *
+ *   color_gating    0: a query may match any entry (a-10).  1: only entries of its own colour (Segment.color);
+ *                   entries / queries with colour >= 3 match every colour.  Costs nothing: the test rides in
+ *                   the matrix core (k_assoc.hip).
+ *   max_distance    matches farther than this many bits are "no match" (<= 128; the reference's D = 128)
+ *   kept_only       1: only segments line_sanity keeps (keep == 1) enter the map (show_map subscribes to the
+ *                   filtered list, show_map_complete.launch:37)
+ *   policy          LF_MAP_APPEND: every eligible segment is appended (show_map.py:41).
+ *                   LF_MAP_MERGE: an eligible segment whose match is within merge_distance REFRESHES that
+ *                   entry (code, colour, endpoints <- the segment's; hits += 1; last_seen = step; when several
+ *                   segments of one update hit the same entry the last in SegmentList order wins); the others
+ *                   are appended.
+ *   when_full       LF_MAP_RING: appends wrap around and overwrite the oldest entries.
+ *                   LF_MAP_FULL_ERROR: what does not fit is dropped and the next call that synchronises with
+ *                   the map returns LF_ERR_CAPACITY.
+ * One update consumes BLOCKS: [1 + rows][LF_BLOCK_ROW_BYTES] bytes each, row 0 = header
+ * {u32 magic "LFBK", u32 count, i32 step, u32 n_frames}, then per segment, SegmentList order:
+ *   0..31 code | 32..63 f64 x0 y0 x1 y1 in the MAP frame | 64 i32 idx | 68 f32 dist | 72 colour | 73 keep | 0-pad
+ * (idx / dist = the segment's association result against the map as it stood BEFORE this update).  A block is
+ * what ranks exchange with ONE all-gather per step; blocks are applied in the order given, so
+ * replicas that see the same blocks hold the same map, and a single GPU applies its own block the same way.
+ *
+ * Map frame: odometry publishes map -> duck as (x, y, theta) (src/odometry/src/odometry.py:110-120);
+ * lf_map_pack_block moves each segment's ground endpoints with ITS FRAME's pose:
+ *   X = x + (cos(theta) * px - sin(theta) * py),  Y = y + (sin(theta) * px + cos(theta) * py)   (f64, unfused)
+ * pose NULL = leave the points in the robot frame, as show_map.py does.
+ */
+typedef struct lf_map lf_map;
+#define LF_MAP_APPEND 0
+#define LF_MAP_MERGE 1
+#define LF_MAP_RING 0
+#define LF_MAP_FULL_ERROR 1
+#define LF_BLOCK_ROW_BYTES 80
+typedef struct lf_map_config {
+    int32_t capacity;          /* entries, 64 .. 2^21 */
+    int32_t color_gating;
+    int32_t max_distance;      /* 0 .. 128 */
+    int32_t policy;            /* LF_MAP_APPEND | LF_MAP_MERGE */
+    int32_t kept_only;
+    int32_t merge_distance;    /* MERGE: 0 .. max_distance */
+    int32_t when_full;         /* LF_MAP_RING | LF_MAP_FULL_ERROR */
+} lf_map_config;
+
+int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** out);
+void lf_map_destroy(lf_map* m);
+const char* lf_map_last_error(const lf_map* m);      /* m == NULL: the last lf_map_create failure */
+int lf_map_get_stream(lf_map* m, void** hip_stream);
+int lf_map_synchronize(lf_map* m);
+/* append n entries as they are (color NULL: 255 = matches every colour; ground NULL: zeros); hits 1, last_seen -1 */
+int lf_map_seed(lf_map* m, const uint8_t* code32, const uint8_t* color, const double* ground4, int n, int on_device);
+/* entries in use, ring head, lifetime counters; waits for the map's stream; LF_ERR_CAPACITY if an update overflowed */
+int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_t* total_refreshed);
+/* Nearest map entry of n queries (a-10 semantics + the map's gating / max_distance).  color may be NULL when
+ * gating is off.  h: the handle whose stream produced the query arrays (the map's stream waits for it, and the
+ * handle's next batch waits until the map has read them), or NULL when the caller has ordered that itself.
+ * on_device applies to all four arrays; with host arrays the call returns when idx / dist are in place. */
+int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, const uint8_t* color, int n,
+                     int32_t* idx, float* dist, int on_device);
+/* Device arrays of `segs` (frame_offset, code, color, keep, ground; capacity ignored) + idx / dist -> one block in
+ * device memory (block_rows >= n + 1 rows, else LF_ERR_CAPACITY -- never truncated).  frame_pose: host
+ * [n_frames][3] = x, y, theta per frame, or NULL. */
+int lf_map_pack_block(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const int32_t* idx,
+                      const float* dist, const double* frame_pose, int step, uint8_t* block, int block_rows);
+/* apply n_blocks consecutive blocks of block_rows rows each (device memory), in order */
+int lf_map_update(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows);
+/* single-GPU convenience: lf_map_associate + lf_map_pack_block + lf_map_update; idx / dist device arrays [n] */
+int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const double* frame_pose,
+                int step, int32_t* idx, float* dist);
+/* copy entries [first, first + n) to host arrays (NULL arrays are skipped); waits for the map's stream */
+int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,
+                 int32_t* last_seen);
+
+/* per-stage timing with HIP events on the map's stream: 0 query packing, 1 association (MFMA), 2 block packing,
+ * 3 map update.  lf_map_get_timing returns what accumulated since the previous call and resets it. */
+#define LF_MAP_N_STAGES 4
+int lf_map_set_profiling(lf_map* m, int enabled);
+int lf_map_get_timing(lf_map* m, double* ms_per_stage, int32_t* launches_per_stage, int n);
+const char* lf_map_stage_name(int stage);
 
 /* ---- host ingest: replaces duckietown_utils.jpg.image_cv_from_jpg ---------------
  * = cv2.imdecode(np.fromstring(data, np.uint8), cv2.IMREAD_COLOR)

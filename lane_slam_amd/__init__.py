@@ -3,6 +3,8 @@ ground-project, sanity-filter, associate) behind a C ABI (include/lanefront.h).
 
 The package is a thin host-side mirror of the reference's interfaces for this path:
   LineDetectorHIP  <->  line_detector.LineDetectorLSD (LineDetectorInterface plugin)
+  LineAssociator   <->  line_associator node (a stub in the reference) + show_map's segment store: device-resident
+                        live map, MFMA Hamming association, colour gating, append / merge updates (lf_map_*)
   FrontEnd         <->  batch form of line_detector_node / ground_projection_node /
                         line_sanity_node callbacks + BinaryDescriptor / BinaryDescriptorMatcher
 There is no CPU fallback: importing works anywhere, but creating a detector without the
@@ -10,7 +12,8 @@ HIP library or without a GPU raises.
 """
 from .config import (COLOR_NAMES, DEFAULT_DETECTOR_CONFIGURATION, RED, WHITE, YELLOW, default_config)
 from .frontend import FrontEnd, LanefrontError, Segments
+from .line_associator import LineAssociator
 from .line_detector_hip import Detections, LineDetectorHIP, LineDetectorInterface
 
-__all__ = ["FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorInterface", "Detections",
+__all__ = ["LineAssociator", "FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorInterface", "Detections",
            "default_config", "DEFAULT_DETECTOR_CONFIGURATION", "WHITE", "YELLOW", "RED", "COLOR_NAMES"]

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("LANEFRONT_LIBRARY") or os.path.join(_HERE, "liblanefront.so")
 
 LF_N_STAGES = 13
+LF_MAP_N_STAGES = 4
 LF_MSG_DETECTOR, LF_MSG_GROUND, LF_MSG_FILTERED = 0, 1, 2
 (LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,
  LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS, LF_BUF_LSD_SCRATCH) = range(11)
@@ -21,6 +22,9 @@ EXPORTS = (
     "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
     "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
+    "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
+    "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_fetch",
+    "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
 )
 
 
@@ -32,6 +36,12 @@ class LfSegments(ctypes.Structure):
         ("pixels_normalized", ctypes.c_void_p), ("ground", ctypes.c_void_p), ("keep", ctypes.c_void_p),
         ("desc", ctypes.c_void_p), ("code", ctypes.c_void_p),
     ]
+
+
+class LfMapConfig(ctypes.Structure):
+    """ctypes mirror of `lf_map_config` (include/lanefront.h)."""
+    _fields_ = [(k, ctypes.c_int32) for k in ("capacity", "color_gating", "max_distance", "policy", "kept_only",
+                                              "merge_distance", "when_full")]
 
 
 _lib = None
@@ -91,6 +101,30 @@ def load():
     lib.lf_reset_timing.argtypes = [vp]
     lib.lf_stage_name.argtypes = [ci]
     lib.lf_stage_name.restype = ctypes.c_char_p
+    i64p = ctypes.POINTER(ctypes.c_int64)
+    lib.lf_map_create.argtypes = [ci, ctypes.POINTER(LfMapConfig), ctypes.POINTER(vp)]
+    lib.lf_map_destroy.argtypes = [vp]
+    lib.lf_map_destroy.restype = None
+    lib.lf_map_last_error.argtypes = [vp]
+    lib.lf_map_last_error.restype = ctypes.c_char_p
+    lib.lf_map_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.lf_map_synchronize.argtypes = [vp]
+    lib.lf_map_seed.argtypes = [vp, vp, vp, vp, ci, ci]
+    lib.lf_map_size.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), i64p, i64p]
+    lib.lf_map_associate.argtypes = [vp, vp, vp, vp, ci, vp, vp, ci]
+    lib.lf_map_pack_block.argtypes = [vp, vp, ctypes.POINTER(LfSegments), ci, ci, vp, vp, vp, ci, vp, ci]
+    lib.lf_map_update.argtypes = [vp, vp, ci, ci]
+    lib.lf_map_step.argtypes = [vp, vp, ctypes.POINTER(LfSegments), ci, ci, vp, ci, vp, vp]
+    lib.lf_map_fetch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
+    lib.lf_map_set_profiling.argtypes = [vp, ci]
+    lib.lf_map_set_profiling.restype = ci
+    lib.lf_map_get_timing.argtypes = [vp, vp, vp, ci]
+    lib.lf_map_get_timing.restype = ci
+    lib.lf_map_stage_name.argtypes = [ci]
+    lib.lf_map_stage_name.restype = ctypes.c_char_p
+    for f in ("lf_map_create", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size", "lf_map_associate",
+              "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_fetch"):
+        getattr(lib, f).restype = ci
     for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate",
               "lf_associate_float", "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",

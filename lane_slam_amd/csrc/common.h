@@ -113,8 +113,31 @@ void launch_lbd_split_debug(size_t n, const uint32_t* dxy, int16_t* dx, int16_t*
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
                 const uint32_t* dxy, const float* gauss_g, const float* gauss_l,
                 float* desc, uint8_t* code, hipStream_t s);
-void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* mx,
+// ---- associator (k_assoc.hip): packed operands = [rows][256] int8 code bytes + [rows][32] int8 ninth-step operand
+size_t assoc_rows_padded_q(int nq);
+size_t assoc_rows_padded_m(int nm);
+void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
+                       int8_t* cx, hipStream_t s);
+void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
+                       int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
+void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,
                   unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
+void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);
+// ---- live map (k_map.hip)
+struct MapDevice {
+    int capacity, policy, kept_only, merge_distance, when_full;
+    uint8_t* code; uint8_t* color; double* ground; int* hits; int* last_seen; int* winner;
+    int8_t* mx; int8_t* mcx;
+    int* state;                    // [0] size [1] head [2] overflow [3] n_app [4] n_ref [5] old head [6] old size [7] step
+    unsigned long long* totals;    // [0] appended [1] refreshed
+};
+void launch_fill_i32(int* p, size_t n, int v, hipStream_t s);
+void launch_map_pack_block(int n, int n_frames, const int* frame_offset, const uint8_t* code, const uint8_t* color,
+                           const uint8_t* keep, const double* ground, const int32_t* idx, const float* dist,
+                           const double* pose4, int step, uint8_t* block, hipStream_t s);
+void launch_map_seed_block(int n, const uint8_t* code, const uint8_t* color, const double* ground, uint8_t* block, hipStream_t s);
+void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks, int block_rows, int force_append, int* act,
+                       hipStream_t s);
 void launch_assoc_float(const float* q, int nq, const float* m, int nm, float* qn, float* mn,
                         unsigned long long* best, int32_t* idx, float* dist, hipStream_t s);
 // ---- JPEG ingest (k_jpeg.hip)

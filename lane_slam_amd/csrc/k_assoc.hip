@@ -6,15 +6,24 @@
 // bitops_custom.hpp:83-96: the exact Hamming nearest neighbour; candidates farther than
 // D = 128 are never reported (:721).  The reference's multi-index hash is a CPU
 // pointer-chasing structure rebuilt on every call; on MI355X the N x M distance matrix is
-// one dense int8 contraction: bits -> +-64 bytes, dot / 4096 = 256 - 2*hamming, exactly.
+// one dense int8 contraction: query bits -> +-32, map bits -> +-16, so dot / 512 = 256 - 2*hamming,
+// exactly.
 //
-// k_assoc_pack : 32-byte codes -> 256 int8 (+64 for bit 0, -64 for bit 1), zero padded rows.
-// k_assoc      : 256 queries per workgroup (4 waves x 2 x 32 rows, A fragments resident in
-//   VGPRs; a B fragment read from LDS feeds two MFMAs), map streamed through LDS in 64-entry tiles by LDS-DMA
-//   (double buffered, source-swizzled: conflict-free ds_read_b128), v_mfma_i32_32x32x32_i8 over K = 256 plus one step that folds the column-block number into
-//   the accumulator, so the running arg-max is one v_max3 per register pair (see the kernel) -- no
-//   cross-lane traffic until the end; ties resolve to the lowest map index.  Map chunks are
-//   spread over gridDim.y and merged with atomicMin on the packed word (order free).
+// Packed operands (kept by the live map across calls, k_map.hip packs only the rows that change):
+//   qx / mx   [rows][256] int8   the code, one byte per bit
+//   qcx / mcx [rows][32]  int8   the operands of a NINTH MFMA step (K = 32) that folds two more terms into
+//                                the accumulator:
+//        k = 0, 1      query [16, 1]  x  map [-(t >> 4), -(t & 15)]  = -t, the number of the 32-column block inside
+//                      the workgroup's map chunk (written by the kernel, the bytes are zero in memory)
+//        k = 2 .. 31   three groups of ten, one per colour: query 127 in the group of ITS colour (only when colour
+//                      gating is on), map -127 in the groups of the OTHER colours -> -161 290 when the colours
+//                      differ, which is below every candidate within distance 128 (key >= -511)
+//   key = 512 * dot - t - penalty orders candidates by distance, then by column block, so the running arg-max is
+//   ONE v_max per accumulator register and colour gating (SURVEY a-11) costs nothing: it rides in the matrix core.
+// k_assoc      : 256 queries per workgroup (4 waves x 2 x 32 rows, A fragments resident in VGPRs; a B fragment
+//   read from LDS feeds two MFMAs), map streamed through LDS in 64-entry tiles by LDS-DMA (double buffered,
+//   source-swizzled: conflict-free ds_read_b128), v_mfma_i32_32x32x32_i8 over K = 256 + 32; ties resolve to the
+//   lowest map index.  Map chunks are spread over gridDim.y and merged with atomicMin on the packed word.
 //   Algorithmic ops: 2*N*M*256 int8.
 // k_assoc_float: 72-d float LBD, Euclidean, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 #include "common.h"
@@ -28,50 +37,70 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int QB = 2;          // 32-query row blocks per wave
 constexpr int AQ = 128 * QB;   // queries per workgroup (4 waves)
 constexpr int AM = 64;         // map entries per LDS tile
+constexpr int kMaxBlocksPerChunk = 512;   // the in-accumulator block counter t has 9 bits
 
-__global__ void k_assoc_pack(const uint8_t* __restrict__ codes, int n, int n_pad, int8_t* __restrict__ out)
+// one thread per (row, code byte): 8 int8 = 2 dwords; thread 0 of a row also writes the row's ninth-step operand.
+// side 0: query (+-32, [16, 1] counter weights, +127 in the own colour's group when gating)
+// side 1: map   (+-16, zero counter bytes, -127 in the other colours' groups; colour >= 3 matches every colour)
+__global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ colors, int side, int gating,
+                             int n, int n_pad, int8_t* __restrict__ out, int8_t* __restrict__ outc)
 {
-    // one thread per (row, byte): 8 int8 = 2 dwords
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t total = (size_t)n_pad * 32;
     if (t >= total) return;
     size_t row = t >> 5;
     uint32_t lo = 0, hi = 0;
-    if (row < (size_t)n) {
+    const bool live = row < (size_t)n;
+    if (live) {
         uint32_t b = codes[t];
-        // nibble -> 4 bytes of 0/1, then 0 -> 0x40 (+64), 1 -> 0xC0 (-64)
+        // nibble -> 4 bytes of 0/1, then 0 -> +mag, 1 -> -mag
         uint32_t w0 = ((b & 15u) * 0x00204081u) & 0x01010101u;
         uint32_t w1 = ((b >> 4) * 0x00204081u) & 0x01010101u;
-        lo = (w0 << 7) | 0x40404040u;
-        hi = (w1 << 7) | 0x40404040u;
+        if (side == 0) { lo = (w0 * 0xC0u) ^ 0x20202020u; hi = (w1 * 0xC0u) ^ 0x20202020u; }
+        else { lo = (w0 * 0xE0u) ^ 0x10101010u; hi = (w1 * 0xE0u) ^ 0x10101010u; }
     }
-    uint2* o = reinterpret_cast<uint2*>(out + t * 8);
-    *o = make_uint2(lo, hi);
+    *reinterpret_cast<uint2*>(out + t * 8) = make_uint2(lo, hi);
+    if ((t & 31) == 0) {
+        uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (live) {
+            const int c = colors ? colors[row] : 255;
+            uint8_t* wb = reinterpret_cast<uint8_t*>(w);
+            if (side == 0) {
+                wb[0] = 16; wb[1] = 1;
+                if (gating && c < 3) for (int k = 0; k < 10; ++k) wb[2 + 10 * c + k] = 127;
+            } else if (c < 3) {
+                for (int g = 0; g < 3; ++g)
+                    if (g != c) for (int k = 0; k < 10; ++k) wb[2 + 10 * g + k] = (uint8_t)(-127);
+            }
+        }
+        uint4* o = reinterpret_cast<uint4*>(outc + row * 32);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, int nq, const int8_t* __restrict__ mx,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                                int nm, int nm_pad, int m_chunk, unsigned int* __restrict__ best)
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[2 * AM * 256];     // double buffered map tile, linear rows
+    __shared__ __attribute__((aligned(1024))) int8_t ctile[2 * AM * 32];     // the tiles' ninth-step operands
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q0 = blockIdx.x * AQ + wave * (32 * QB);
     const int r32 = lane & 31, half = lane >> 5;
     // QB row blocks of 32 queries per wave: every B fragment read from LDS feeds QB MFMAs
-    v4i A[QB][8];
+    v4i A[QB][8], AX[QB];
 #pragma unroll
-    for (int b = 0; b < QB; ++b)
+    for (int b = 0; b < QB; ++b) {
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             A[b][s] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + 32 * b + r32) * 256 + 32 * s + 16 * half);
-    // Arg-max inside the matrix core.  Codes are +-64 bytes, so a chain of 8 MFMAs leaves 4096 * dot in the
-    // accumulator; a NINTH step multiplies the constant row fragment [64, 1, 0, ...] with the column fragment
-    // [-(t >> 6), -(t & 63), 0, ...], which subtracts t, the running number of the 32-column block inside this
-    // workgroup's map chunk.  key = 4096 * dot - t orders candidates by distance, then by column block, so the
-    // whole epilogue is ONE v_max3 per pair of accumulator registers: no zeroing (the chain starts from the
-    // inline constant 0), no packing, no select.  dot and t are recovered from the key at the very end.
-    v4i AX;
-    AX[0] = half == 0 ? 0x00000140 : 0;      // bytes: 64, 1, 0, 0
-    AX[1] = AX[2] = AX[3] = 0;
+        AX[b] = *reinterpret_cast<const v4i*>(qcx + (size_t)(q0 + 32 * b + r32) * 32 + 16 * half);
+    }
+    // Arg-max inside the matrix core (see the header): after the chain of 9 MFMAs the accumulator holds
+    // key = 512 * dot - t - colour penalty, so the whole epilogue is ONE v_max per accumulator register: no zeroing
+    // (the chain starts from the inline constant 0), no packing, no select.  dot and t are recovered from the key at
+    // the very end.
     int running[QB][16];
 #pragma unroll
     for (int b = 0; b < QB; ++b)
@@ -80,11 +109,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int m_begin = blockIdx.y * m_chunk;
     const int m_end = min(nm_pad, m_begin + m_chunk);
     const int n_tiles = (m_end - m_begin) / AM;
+    const unsigned tmask = half == 0 ? 0xffffu : 0u;          // the counter bytes live in k = 0, 1 (lanes 0..31)
     // Map tiles go global -> LDS directly (global_load_lds, no staging registers: this kernel lives at the
     // register cap), one tile ahead into the other buffer, so a tile's HBM/L2 latency hides behind the MFMAs of
     // the tile before it; one barrier per tile.  An LDS-DMA instruction writes 64 lanes x 16 B contiguously, so
     // the LDS image is linear (4 rows of 256 B per instruction) and the bank-conflict-free layout comes from
-    // swizzling the SOURCE: 16-byte chunk c of row r is stored at chunk position c ^ (r & 15).
+    // swizzling the SOURCE: 16-byte chunk c of row r is stored at chunk position c ^ (r & 15).  The 32-byte
+    // ninth-step rows are read 16 B per lane, 64 lanes contiguous: linear as they are.
     auto glds_tile = [&](int k, int buf) {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
@@ -93,6 +124,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int8_t* src = mx + (size_t)(m_begin + k * AM + row) * 256 + 16 * (pos ^ (row & 15));
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(tile + buf * (AM * 256) + piece * 1024),
+                                             16, 0, 0);
+        }
+        if (wave < 2) {
+            const int8_t* src = mcx + (size_t)(m_begin + k * AM) * 32 + (size_t)(wave * 64 + lane) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ctile + buf * (AM * 32) + wave * 1024),
                                              16, 0, 0);
         }
     };
@@ -104,25 +141,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     for (int k = 0; k < n_tiles; ++k) {
         const int8_t* cur = tile + (k & 1) * (AM * 256);
+        const int8_t* curc = ctile + (k & 1) * (AM * 32);
         if (k + 1 < n_tiles) glds_tile(k + 1, (k + 1) & 1);     // every wave left that buffer at the last barrier
         const int t = 2 * k;                                      // 32-column block counter
-        v4i Bf[2][8];
+        v4i Bf[2][8], BX[2];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const int row = cb * 32 + r32, c = 2 * s + half;
                 Bf[cb][s] = *reinterpret_cast<const v4i*>(cur + row * 256 + ((c ^ (row & 15)) << 4));
             }
+            BX[cb] = *reinterpret_cast<const v4i*>(curc + (cb * 32 + r32) * 32 + 16 * half);
+        }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const int tt = t + cb;
-            v4i BX;
-            BX[0] = half == 0 ? (((-(tt >> 6)) & 0xff) | (((-(tt & 63)) & 0xff) << 8)) : 0;
-            BX[1] = BX[2] = BX[3] = 0;
+            const unsigned tbytes = ((unsigned)(-(tt >> 4)) & 0xffu) | (((unsigned)(-(tt & 15)) & 0xffu) << 8);
+            BX[cb][0] |= (int)(tbytes & tmask);
             v16i acc[QB];
 #pragma unroll
-            for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX, BX, zero, 0, 0, 0);
+            for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX[b], BX[cb], zero, 0, 0, 0);
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -136,19 +175,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    // key -> (distance, column): dot = ceil(key / 4096), t = 4096 * dot - key; this lane's column inside block t
-    // is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
-    // column can only have displaced candidates with a negative dot, which are beyond 128 and never reported.
+    // key -> (distance, column): 512 * dot = ceil(key / 512) * 512, t = 512 * dot - key; this lane's column inside
+    // block t is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
+    // column can only have displaced candidates with a negative dot, which are beyond 128 and never reported.  A
+    // candidate of another colour (gating) decodes to a distance beyond 128 and is dropped by k_assoc_finish.
 #pragma unroll
     for (int b = 0; b < QB; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = running[b][r];
             int v = 0x7fffffff;
-            if (key != (int)0x80000000) {
-                const int dot4096 = (key + 4095) & ~4095;
-                const int col = m_begin + 32 * (dot4096 - key) + r32;
-                if (col < nm) v = (((256 << 12) - dot4096) << 9) | col;      // (256 - dot) << 21 | col
+            if (key != (int)0x80000000) {                             // this lane saw at least one column block
+                const int dot512 = (key + 511) & ~511;
+                const int col = m_begin + 32 * (dot512 - key) + r32;
+                if (col < nm) v = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
             }
 #pragma unroll
             for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
@@ -160,14 +200,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 }
 
-__global__ void k_assoc_finish(const unsigned int* __restrict__ best, int nq, int32_t* __restrict__ idx,
+__global__ void k_assoc_finish(const unsigned int* __restrict__ best, int nq, int max_distance, int32_t* __restrict__ idx,
                                float* __restrict__ dist)
 {
     int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     unsigned int v = best[q];
     int ham = (int)(v >> 22);
-    if (v == 0x7fffffffu || ham > 128) { idx[q] = -1; dist[q] = -1.f; }
+    if (v == 0x7fffffffu || ham > max_distance) { idx[q] = -1; dist[q] = -1.f; }
     else { idx[q] = (int)(v & 0x1fffffu); dist[q] = (float)ham; }
 }
 
@@ -177,26 +217,56 @@ __global__ void k_fill_u32(unsigned int* p, int n, unsigned int v)
     if (i < n) p[i] = v;
 }
 
-void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* mx,
-                  unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+__global__ void k_fill_nomatch(int n, int32_t* idx, float* dist)
 {
-    const int nq_pad = (nq + AQ - 1) / AQ * AQ, nm_pad = (nm + AM - 1) / AM * AM;
-    hipLaunchKernelGGL(k_assoc_pack, dim3(((size_t)nq_pad * 32 + 255) / 256), dim3(256), 0, s, q, nq, nq_pad, qx);
-    hipLaunchKernelGGL(k_assoc_pack, dim3(((size_t)nm_pad * 32 + 255) / 256), dim3(256), 0, s, m, nm, nm_pad, mx);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { idx[i] = -1; dist[i] = -1.f; }
+}
+
+void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s)
+{
+    if (nq > 0) hipLaunchKernelGGL(k_fill_nomatch, dim3((nq + 255) / 256), dim3(256), 0, s, nq, idx, dist);
+}
+
+size_t assoc_rows_padded_q(int nq) { return ((size_t)nq + AQ - 1) / AQ * AQ; }
+size_t assoc_rows_padded_m(int nm) { return ((size_t)nm + AM - 1) / AM * AM; }
+
+void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
+                       int8_t* cx, hipStream_t s)
+{
+    if (n_pad <= 0) return;
+    hipLaunchKernelGGL(k_assoc_pack, dim3(((size_t)n_pad * 32 + 255) / 256), dim3(256), 0, s, codes, colors, side, gating, n,
+                       n_pad, x, cx);
+}
+
+// association of packed queries against a packed map (the live map keeps its side packed across calls;
+// lf_associate packs its caller's raw map first)
+void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
+                       int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+{
+    const int nq_pad = (int)assoc_rows_padded_q(nq), nm_pad = (int)assoc_rows_padded_m(nm);
     hipLaunchKernelGGL(k_fill_u32, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, 0x7fffffffu);
     const int qblocks = nq_pad / AQ;
-    // 2 workgroups are resident per CU (234 VGPRs): split the map so that the grid is just under two full
-    // rounds of the 512 slots -- long chunks amortise the A-fragment loads and the final cross-lane reduction
+    // 2 workgroups are resident per CU: split the map so that the grid is just under two full rounds of the 512
+    // slots -- long chunks amortise the A-fragment loads and the final cross-lane reduction
     int splits = (2 * 512) / qblocks;
     const int tiles = nm_pad / AM;
-    const int min_splits = (nm_pad + (4096 * 32) - 1) / (4096 * 32);     // the in-accumulator block counter has 12 bits
+    const int min_splits = (nm_pad + (kMaxBlocksPerChunk * 32) - 1) / (kMaxBlocksPerChunk * 32);
     if (splits < min_splits) splits = min_splits;
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
     const int m_chunk = (tiles + splits - 1) / splits * AM;
     splits = (nm_pad + m_chunk - 1) / m_chunk;
-    hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, nq, mx, nm, nm_pad, m_chunk, best);
-    hipLaunchKernelGGL(k_assoc_finish, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, idx, dist);
+    hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_pad, m_chunk, best);
+    hipLaunchKernelGGL(k_assoc_finish, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, max_distance, idx, dist);
+}
+
+void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,
+                  unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+{
+    launch_assoc_pack(m, nullptr, 1, 0, nm, (int)assoc_rows_padded_m(nm), mx, mcx, s);
+    launch_assoc_pack(q, nullptr, 0, 0, nq, (int)assoc_rows_padded_q(nq), qx, qcx, s);
+    launch_assoc_core(qx, qcx, nq, mx, mcx, nm, 128, best, idx, dist, s);
 }
 
 // ---------------------------------------------------------------- float LBD (72-d)

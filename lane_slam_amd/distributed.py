@@ -1,89 +1,95 @@
-"""Multi-GPU merge of per-rank segment lists.
+"""Multi-GPU association against a replicated live map.
 
-Frames shard across ranks as independent batches (no data-path collective for detect ->
-describe -> project -> sanity).  The only exchange is ONE all-gather per step of fixed-capacity
-segment blocks, so that every rank can append the same segments, in the same order, to its
-replica of the live map before the next association (the reference's map is an append-only
-list, src/show_map/src/show_map.py:28-42).  Association itself needs no collective: the map
-is replicated and each rank matches only its own frames' descriptors.
+Frames shard across ranks as independent batches: detect -> describe -> project -> sanity need no collective, and
+neither does association (the map is replicated, every rank matches only its own frames' descriptors).  The one
+exchange per step is ONE all-gather of fixed-capacity segment BLOCKS (include/lanefront.h, "live map": header row
+with the count, then 80 bytes per segment: code, ground endpoints in the map frame, association result, colour,
+keep), after which every rank applies the same blocks in rank order to its replica, so the replicas -- and with
+frames dealt to ranks in contiguous chunks, the single-GPU map -- stay identical, entry for entry.
 
-Block layout (uint8, one row per segment, padded to `capacity` rows):
-    bytes 0..31  binary LBD code      byte 32  keep flag      byte 33  colour
-The segment count travels in a separate tiny all-gather.  Works on any torch.distributed
-backend: "nccl" (= RCCL over xGMI on MI355X) for device tensors, "gloo" for the CPU tests.
+`ShardedAssociator.step` is the whole per-step protocol; bench.py and the world-size-2 gloo test both call it.  The
+map behind it is anything with LineAssociator's device interface (associate_device / pack_block_device /
+update_device / stream_ptr): lane_slam_amd.LineAssociator on an MI355X, or the oracle-backed stand-in the CPU test
+uses.  A single rank skips the collective and applies its own block through the same calls.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
-BLOCK_COLS = 34
+BLOCK_ROW_BYTES = 80
+BLOCK_MAGIC = 0x4B42464C          # "LFBK"
+
+# numpy view of a block's segment rows / header row (an independent statement of the layout in lanefront.h)
+ROW_DTYPE = np.dtype({"names": ["code", "ground", "idx", "dist", "color", "keep", "pad"],
+                      "formats": [("u1", 32), ("<f8", 4), "<i4", "<f4", "u1", "u1", ("u1", 6)],
+                      "offsets": [0, 32, 64, 68, 72, 73, 74], "itemsize": BLOCK_ROW_BYTES})
+HEADER_DTYPE = np.dtype({"names": ["magic", "count", "step", "n_frames"], "formats": ["<u4", "<u4", "<i4", "<u4"],
+                         "offsets": [0, 4, 8, 12], "itemsize": BLOCK_ROW_BYTES})
 
 
-def pack_block(block, code, keep, color, n):
-    """Write the first n segments into the padded block (in place); rows >= n are left as they are."""
-    n = min(int(n), block.shape[0])
-    block[:n, :32] = code[:n]
-    block[:n, 32] = keep[:n]
-    block[:n, 33] = color[:n]
-    return n
+def block_header(block_bytes):
+    """(count, step, n_frames) of a block given as a uint8 numpy array."""
+    h = np.frombuffer(block_bytes[:BLOCK_ROW_BYTES].tobytes(), HEADER_DTYPE)[0]
+    if int(h["magic"]) != BLOCK_MAGIC:
+        raise ValueError("not a segment block (bad magic)")
+    return int(h["count"]), int(h["step"]), int(h["n_frames"])
 
 
-def all_gather_blocks(block, n, gathered=None, counts=None):
-    """All-gather one padded block per rank.  Returns (gathered [world, capacity, 34], counts [world])."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    cap = block.shape[0]
-    if gathered is None:
-        gathered = torch.empty(world * cap, BLOCK_COLS, dtype=torch.uint8, device=block.device)
-    if counts is None:
-        counts = torch.empty(world, dtype=torch.int32, device=block.device)
-    mine = torch.tensor([n], dtype=torch.int32, device=block.device)
-    if world == 1:
-        gathered.view(1, cap, BLOCK_COLS)[0].copy_(block)
-        counts[0] = n
-    else:
-        dist.all_gather_into_tensor(counts, mine)
-        dist.all_gather_into_tensor(gathered, block)
-    return gathered.view(world, cap, BLOCK_COLS), counts
+def block_rows(block_bytes):
+    """Structured view (ROW_DTYPE) of a block's valid segment rows."""
+    count = block_header(block_bytes)[0]
+    return np.frombuffer(block_bytes.tobytes(), ROW_DTYPE, count=count, offset=BLOCK_ROW_BYTES)
 
 
-def merged_codes(gathered, counts, kept_only=True):
-    """Concatenate the valid rows rank-major / segment-minor: identical on every rank, and equal to
-    the single-GPU order when frames were dealt to ranks in contiguous chunks."""
-    out = []
-    for r in range(gathered.shape[0]):
-        n = int(counts[r])
-        rows = gathered[r, :n]
-        if kept_only:
-            rows = rows[rows[:, 32] != 0]
-        out.append(rows[:, :32])
-    return torch.cat(out, dim=0) if out else gathered.new_zeros((0, 32))
+class ShardedAssociator(object):
+    """One rank's replica of the live map plus the per-step exchange.
 
+    amap            LineAssociator (or an object with its device interface)
+    block_segments  capacity of one rank's block; a step with more segments raises (never truncates)
+    device          torch device of the segment arrays and blocks
+    backend         "nccl" (= RCCL over xGMI, device buffers), "gloo" (CPU tensors; with a CUDA device the blocks are
+                    staged through the host -- dry runs only)
+    """
 
-class LiveMap(object):
-    """Append-only code map with fixed capacity (oldest entries are overwritten once full)."""
+    def __init__(self, amap, block_segments, device="cpu", backend="nccl", force_collective=False):
+        self.map = amap
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.collective = self.world > 1 or (force_collective and dist.is_initialized())
+        self.rows = int(block_segments) + 1
+        self.device = torch.device(device)
+        self.backend = backend
+        nbytes = self.rows * BLOCK_ROW_BYTES
+        self.block = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.gathered = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=self.device) if self.collective else self.block
+        self.cuda = self.device.type == "cuda"
+        self.ext = torch.cuda.ExternalStream(amap.stream_ptr(), device=self.device) if self.cuda else None
 
-    def __init__(self, capacity, device="cpu", initial=None):
-        self.codes = torch.zeros(capacity, 32, dtype=torch.uint8, device=device)
-        self.size = 0
-        self.head = 0
-        if initial is not None:
-            self.append(initial)
+    def step(self, fe, out, n, n_frames, idx, dist_out, poses=None, step=0):
+        """Associate the n segments of this rank's batch, exchange blocks, update the replica.
 
-    def append(self, codes):
-        cap = self.codes.shape[0]
-        n = codes.shape[0]
-        if n >= cap:
-            self.codes.copy_(codes[-cap:])
-            self.size, self.head = cap, 0
-            return
-        end = self.head + n
-        if end <= cap:
-            self.codes[self.head:end] = codes
-        else:
-            k = cap - self.head
-            self.codes[self.head:] = codes[:k]
-            self.codes[: end - cap] = codes[k:]
-        self.head = end % cap
-        self.size = min(cap, self.size + n)
-
-    def view(self):
-        return self.codes[: self.size]
+        fe       the FrontEnd whose stream produced `out` (None: the caller has ordered that)
+        out      dict of tensors: frame_offset, code, color, keep, ground (device resident)
+        idx, dist_out   int32 / float32 tensors [>= n] receiving this rank's association results
+        poses    (n_frames, 3) map -> duck pose per frame, or None
+        """
+        m = self.map
+        ptrs = {k: out[k].data_ptr() for k in ("frame_offset", "code", "color", "keep", "ground")}
+        if n > 0:
+            m.associate_device(fe, ptrs["code"], ptrs["color"], n, idx.data_ptr(), dist_out.data_ptr())
+        # raises LanefrontError(LF_ERR_CAPACITY) when n does not fit the block: fail loudly, never truncate
+        m.pack_block_device(fe, ptrs, n, n_frames, idx.data_ptr(), dist_out.data_ptr(), poses, step, self.block.data_ptr(),
+                            self.rows)
+        if self.collective:
+            if self.cuda:
+                torch.cuda.current_stream(self.device).wait_stream(self.ext)      # the block is complete
+            if self.cuda and self.backend == "gloo":
+                hb = self.block.cpu()
+                hg = torch.empty(self.gathered.shape, dtype=torch.uint8)
+                dist.all_gather_into_tensor(hg, hb)
+                self.gathered.copy_(hg)
+            else:
+                dist.all_gather_into_tensor(self.gathered, self.block)             # the step's ONE collective
+            if self.cuda:
+                self.ext.wait_stream(torch.cuda.current_stream(self.device))
+        m.update_device(self.gathered.data_ptr(), self.world if self.collective else 1, self.rows)

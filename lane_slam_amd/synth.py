@@ -71,9 +71,19 @@ def make_frame(seed, rows=480, cols=640, H=None):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def make_batch(n, seed0=0, rows=480, cols=640):
-    """(n, rows, cols, 3) uint8, seeds seed0 .. seed0+n-1."""
+def make_batch(n, seed0=0, rows=480, cols=640, threads=1):
+    """(n, rows, cols, 3) uint8, seeds seed0 .. seed0+n-1 (frame i depends on its seed only; threads > 1 just
+    renders several frames at once)."""
     out = np.empty((n, rows, cols, 3), dtype=np.uint8)
+    if n and threads > 1:
+        make_frame(seed0, rows, cols)          # fill the ground-coordinate cache before the threads start
+        from concurrent.futures import ThreadPoolExecutor
+
+        def work(i):
+            out[i] = make_frame(seed0 + i, rows, cols)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, range(n)))
+        return out
     for i in range(n):
         out[i] = make_frame(seed0 + i, rows, cols)
     return out

@@ -114,6 +114,31 @@ void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
 /* float-descriptor L2 NN (72-d) */
 void lfo_match_float(const float* q72, int nq, const float* t72, int nt, int32_t* idx, float* dist);
 
+/* ---- live map + associator (lf_oracle_map.c): the build's own contract, see that file's header ---- */
+#define LFO_MAP_APPEND 0
+#define LFO_MAP_MERGE 1
+#define LFO_MAP_RING 0
+#define LFO_MAP_FULL_ERROR 1
+typedef struct lfo_map_config {
+    int32_t capacity, color_gating, max_distance, policy, kept_only, merge_distance, when_full;
+} lfo_map_config;
+typedef struct lfo_map lfo_map;
+lfo_map* lfo_map_create(const lfo_map_config* cfg);
+void lfo_map_destroy(lfo_map* m);
+void lfo_map_state(const lfo_map* m, int32_t* size, int32_t* head, int32_t* overflow, long long* total_appended,
+                   long long* total_refreshed);
+const uint8_t* lfo_map_codes(const lfo_map* m);
+const uint8_t* lfo_map_colors(const lfo_map* m);
+const double* lfo_map_ground(const lfo_map* m);
+const int32_t* lfo_map_hits(const lfo_map* m);
+const int32_t* lfo_map_last_seen(const lfo_map* m);
+void lfo_map_seed(lfo_map* m, const uint8_t* code32, const uint8_t* color, const double* ground4, int n);
+void lfo_map_associate(const lfo_map* m, const uint8_t* code32, const uint8_t* color, int n, int32_t* idx, float* dist);
+void lfo_map_to_map_frame(const double* ground4, int n, const int32_t* frame_offset, int n_frames, const double* pose3,
+                          double* out4);
+void lfo_map_update(lfo_map* m, const uint8_t* code32, const uint8_t* color, const uint8_t* keep, const double* ground4,
+                    const int32_t* idx, const float* dist, int n, int step);
+
 /* ---- whole frame (lf_oracle_frame.c) ---- */
 typedef struct lfo_frame_out {
     int32_t n;                  /* segments, order white, yellow, red */

@@ -338,3 +338,95 @@ def jpeg_coefficients(data):
 def detmath_lib():
     build()
     return ctypes.CDLL(_SO)
+
+
+class LfoMapConfig(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("capacity", "color_gating", "max_distance", "policy", "kept_only",
+                                              "merge_distance", "when_full")]
+
+
+class OracleMap(object):
+    """Sequential statement of the live map + associator contract (oracle/lf_oracle_map.c).  Same keyword arguments as
+    lane_slam_amd.LineAssociator."""
+
+    def __init__(self, capacity=65536, color_gating=False, max_distance=128, policy="append", kept_only=True,
+                 merge_distance=0, when_full="ring"):
+        build()
+        self.lib = ctypes.CDLL(_SO)
+        self.lib.lfo_map_create.restype = ctypes.c_void_p
+        for f in ("lfo_map_codes", "lfo_map_colors", "lfo_map_ground", "lfo_map_hits", "lfo_map_last_seen"):
+            getattr(self.lib, f).restype = ctypes.c_void_p
+            getattr(self.lib, f).argtypes = [ctypes.c_void_p]
+        c = LfoMapConfig(int(capacity), int(bool(color_gating)), int(max_distance), {"append": 0, "merge": 1}[policy],
+                         int(bool(kept_only)), int(merge_distance), {"ring": 0, "error": 1}[when_full])
+        self.capacity = int(capacity)
+        self.m = ctypes.c_void_p(self.lib.lfo_map_create(ctypes.byref(c)))
+
+    def __del__(self):
+        try:
+            if self.m:
+                self.lib.lfo_map_destroy(self.m)
+                self.m = None
+        except Exception:
+            pass
+
+    def state(self):
+        size, head, ovf = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        ta, tr = ctypes.c_longlong(), ctypes.c_longlong()
+        self.lib.lfo_map_state(self.m, ctypes.byref(size), ctypes.byref(head), ctypes.byref(ovf), ctypes.byref(ta), ctypes.byref(tr))
+        return {"size": size.value, "head": head.value, "overflow": ovf.value, "total_appended": ta.value,
+                "total_refreshed": tr.value}
+
+    def seed(self, codes, colors=None, ground=None):
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(-1, 32)
+        colors = None if colors is None else np.ascontiguousarray(colors, np.uint8)
+        ground = None if ground is None else np.ascontiguousarray(ground, np.float64).reshape(-1, 4)
+        self.lib.lfo_map_seed(self.m, _p(codes), None if colors is None else _p(colors),
+                              None if ground is None else _p(ground), codes.shape[0])
+
+    def associate(self, codes, colors=None):
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(-1, 32)
+        colors = None if colors is None else np.ascontiguousarray(colors, np.uint8)
+        n = codes.shape[0]
+        idx, dist = np.empty(n, np.int32), np.empty(n, np.float32)
+        self.lib.lfo_map_associate(self.m, _p(codes), None if colors is None else _p(colors), n, _p(idx), _p(dist))
+        return idx, dist
+
+    def to_map_frame(self, ground, frame_offset, poses):
+        ground = np.ascontiguousarray(ground, np.float64).reshape(-1, 4)
+        fo = np.ascontiguousarray(frame_offset, np.int32)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 3)
+        out = ground.copy()
+        self.lib.lfo_map_to_map_frame(_p(ground), ground.shape[0], _p(fo), poses.shape[0], _p(poses), _p(out))
+        return out
+
+    def update(self, codes, colors, keep, ground, idx, dist, step):
+        codes = np.ascontiguousarray(codes, np.uint8).reshape(-1, 32)
+        n = codes.shape[0]
+        colors = None if colors is None else np.ascontiguousarray(colors, np.uint8)
+        keep = None if keep is None else np.ascontiguousarray(keep, np.uint8)
+        ground = None if ground is None else np.ascontiguousarray(ground, np.float64).reshape(-1, 4)
+        idx = np.ascontiguousarray(idx, np.int32)
+        dist = np.ascontiguousarray(dist, np.float32)
+        self.lib.lfo_map_update(self.m, _p(codes), None if colors is None else _p(colors), None if keep is None else _p(keep),
+                                None if ground is None else _p(ground), _p(idx), _p(dist), n, int(step))
+
+    def step(self, codes, colors, keep, ground, step, frame_offset=None, poses=None):
+        """associate + (pose transform) + update; returns (idx, dist)."""
+        idx, dist = self.associate(codes, colors)
+        g = ground
+        if poses is not None and ground is not None:
+            g = self.to_map_frame(ground, frame_offset, poses)
+        self.update(codes, colors, keep, g, idx, dist, step)
+        return idx, dist
+
+    def fetch(self):
+        n = self.capacity
+
+        def arr(fn, dt, cols):
+            p = getattr(self.lib, fn)(self.m)
+            a = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(dt)), shape=(n * cols,))
+            return a.reshape((n, cols) if cols > 1 else (n,)).copy()
+        return {"code": arr("lfo_map_codes", ctypes.c_uint8, 32), "color": arr("lfo_map_colors", ctypes.c_uint8, 1),
+                "ground": arr("lfo_map_ground", ctypes.c_double, 4), "hits": arr("lfo_map_hits", ctypes.c_int32, 1),
+                "last_seen": arr("lfo_map_last_seen", ctypes.c_int32, 1)}
