@@ -8,16 +8,19 @@ associate on MI355X (BASELINE.json metric), one process per GPU.
 
 A step = one pass of the whole hot path over one batch of 256 synthetic 640x480 BGR frames
 per GPU, already resident in HBM (BASELINE.json configs[1], full-res geometry: img_size
-[480,640], top_cutoff 160 -> 640x320 working image), followed by association of the step's
-descriptors against a live map of 50 000 codes.  With N > 1 GPUs frames shard across ranks
-(weak scaling, 256 frames per GPU per step) and the per-rank segment blocks are merged with
-one RCCL all-gather before the map is updated; association itself needs no collective (the
-map is replicated, queries stay local).
+[480,640], top_cutoff 160 -> 640x320 working image): detect -> describe -> project -> sanity, then the
+package's associator (lane_slam_amd.LineAssociator / lf_map_*): Hamming association of the step's descriptors
+against a device-resident live map of 66 384 entries, and the map update with the kept segments.  With N > 1 GPUs
+frames shard across ranks (weak scaling, 256 frames per GPU per step); the per-rank segment blocks are merged with
+ONE RCCL all-gather per step (lane_slam_amd.distributed.ShardedAssociator, the class the gloo test covers) and every
+rank applies the same blocks to its map replica; association itself needs no collective.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant streaming kernel with live
-HIP-event timings from the library's own stream; `cpu_baseline` times the CPU oracle
-(oracle/, a single-threaded restatement of the reference path) on a bounded sample of the
-same workload on the GPU box's host.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant streaming kernel with live HIP-event timings from
+the library's own stream; `cpu_baseline` times the CPU oracle (oracle/, a single-threaded restatement of the
+reference path) on a bounded sample of the same workload on the GPU box's host.  `secondary` holds numbers that
+never replace `value`: the BASELINE configs[2] stream replay (host-resident frames, per-batch H2D, growing map), the
+JPEG-ingest rate, the single-frame plugin latency at the reference's own operating point, the configs[4] associator
+stress.
 """
 import argparse
 import json
@@ -25,7 +28,7 @@ import os
 import sys
 import time
 
-# Six batches are kept in flight on six HIP streams (plus torch's); ROCclr maps streams onto
+# Six batches are kept in flight on six HIP streams (plus the map's and torch's); ROCclr maps streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a queue serialise.  Must be
 # set before the HIP runtime initialises.  16 leaves room for the collective library's own streams at N > 1.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
@@ -40,17 +43,31 @@ sys.path.insert(0, ROOT)
 
 INT8_MFMA_PEAK_POPS = 5.0     # dense int8 MFMA, MI355X_MICROARCH.md (2x the ~2.5 PF bf16 rate)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+MAP_ROLL = 16384               # live map = --map seeded codes + this many more entries, kept full (ring)
 
 
-def stage_bytes(P, Ps, resize):
-    """ALGORITHMIC HBM bytes per frame of each streaming kernel.  The LSD stages are
-    not listed: their traffic is proportional to the number of edge pixels (sparse records), they are
+def stage_bytes(P):
+    """ALGORITHMIC HBM bytes per frame of each streaming kernel, SURVEY.md section 8(d) (P = working pixels).  The LSD
+    stages are not listed: their traffic is proportional to the number of edge pixels (sparse records), they are
     latency / issue bound and are reported as time only."""
     return {
-        "pre(resize+correct+hsv+masks+dilate)": 3 * P + 3 * P + 3 * P + 3 * (P // 8),
-        "canny_nms": 3 * P + 2 * (P // 8),
-        "canny_hysteresis": 3 * (P // 8),
-        "lbd_gray_blur_sobel": 3 * P + 4 * P,
+        "pre(resize+correct+hsv+masks+dilate)": 3 * P + 3 * P + 3 * P,      # K_pre: read 3P, write 3P + 3P
+        "canny_nms": 3 * P + P,                                              # K_canny_grad: read 3P, write P
+        "lbd_gray_blur_sobel": P + 4 * P,                                    # K_sobel_lbd: read P (gray), write 4P
+    }
+
+
+def alloc_out(torch, dev, B, cap):
+    return {
+        "frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev),
+        "lines": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+        "normals": torch.zeros(cap, 2, dtype=torch.float32, device=dev),
+        "color": torch.zeros(cap, dtype=torch.uint8, device=dev),
+        "pixels_normalized": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
+        "ground": torch.zeros(cap, 4, dtype=torch.float64, device=dev),
+        "keep": torch.zeros(cap, dtype=torch.uint8, device=dev),
+        "desc": torch.zeros(cap, 72, dtype=torch.float32, device=dev),
+        "code": torch.zeros(cap, 32, dtype=torch.uint8, device=dev),
     }
 
 
@@ -63,19 +80,25 @@ def main():
     ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity", "hd"],
                     help="fullres / parity: BASELINE configs[1] (640x480 input); hd: configs[4]'s 1920x1080 frames "
                          "(img_size [1080,1920], top_cutoff 360) -- an optional stress mode, not the headline")
-    ap.add_argument("--map", type=int, default=50000, help="live-map size (codes)")
-    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic frames per rank (tiled to --batch)")
+    ap.add_argument("--map", type=int, default=50000, help="seeded live-map codes (the map holds these + 16384 more entries)")
+    ap.add_argument("--unique", type=int, default=256, help="distinct synthetic frames per rank (tiled to --batch)")
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
     ap.add_argument("--depth", type=int, default=0, help="independent batches in flight (handles/streams); 0: 6, or 3 for --geometry hd")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
+    ap.add_argument("--secondary", default="auto", choices=["auto", "all", "none"],
+                    help="secondary measurements (stream replay, JPEG ingest, plugin latency, associator stress): auto = all at "
+                         "N = 1 with the default geometry, none otherwise")
+    ap.add_argument("--stream-frames", type=int, default=1024, help="frames of the configs[2] stream (replayed --stream-laps times)")
+    ap.add_argument("--stream-laps", type=int, default=4)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from lane_slam_amd import FrontEnd, default_config, synth
+    from lane_slam_amd import FrontEnd, LineAssociator, default_config, synth
+    from lane_slam_amd.distributed import ShardedAssociator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -89,9 +112,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # LF_FORCE_COLLECTIVES=1 runs the N > 1 code path (process group, all-gathers, rank-major merge) with a single
+    # LF_FORCE_COLLECTIVES=1 runs the N > 1 code path (process group, all-gather, block merge) with a single
     # rank: a dry run of the RCCL calls on one GPU, never a headline configuration
-    multi = world > 1 or bool(os.environ.get("LF_FORCE_COLLECTIVES"))
+    force = bool(os.environ.get("LF_FORCE_COLLECTIVES"))
+    multi = world > 1 or force
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -111,101 +135,53 @@ def main():
     # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers)
     fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D)]
     fe = fes[0]
-    P, Ps = fe.rows * fe.cols, fe.lsd_rows * fe.lsd_cols
+    P = fe.rows * fe.cols
 
     # ---- synthetic input, resident in HBM before the timed region
     uniq = min(args.unique, B)
-    host = synth.make_batch(uniq, seed0=10000 * rank, rows=in_rows, cols=in_cols)
+    host_threads = max(1, min(32, (os.cpu_count() or 2) // 2))
+    host = synth.make_batch(uniq, seed0=10000 * rank, rows=in_rows, cols=in_cols, threads=host_threads)
     reps = (B + uniq - 1) // uniq
     host = np.ascontiguousarray(np.tile(host, (reps, 1, 1, 1))[:B])
     frames = torch.from_numpy(host).to(dev)
 
     cap = B * 3 * args.cap
-
-    def alloc_out():
-        return {
-            "frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev),
-            "lines": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
-            "normals": torch.zeros(cap, 2, dtype=torch.float32, device=dev),
-            "color": torch.zeros(cap, dtype=torch.uint8, device=dev),
-            "pixels_normalized": torch.zeros(cap, 4, dtype=torch.float32, device=dev),
-            "ground": torch.zeros(cap, 4, dtype=torch.float64, device=dev),
-            "keep": torch.zeros(cap, dtype=torch.uint8, device=dev),
-            "desc": torch.zeros(cap, 72, dtype=torch.float32, device=dev),
-            "code": torch.zeros(cap, 32, dtype=torch.uint8, device=dev),
-        }
-
-    outs = [alloc_out() for _ in range(D)]
+    outs = [alloc_out(torch, dev, B, cap) for _ in range(D)]
     ptrs = [{k: v.data_ptr() for k, v in o.items()} for o in outs]
-    # live map: M random codes (seed 1234, identical on every rank) + a rolling region that
-    # receives the segments all ranks produced (append-only map, show_map.py:28-42)
-    G = 16 * 1024                                   # gathered segments per rank (fixed-capacity block; a step's
-                                                    # ~11 k segments fit, a longer list contributes its first G)
-    # The rolling region has a FIXED total size: every rank contributes roll / world of its newest segments per
-    # step, so the map -- and with it the association work per GPU -- is the same at every N (weak scaling).
-    roll = (min(G, 16384) // world) * world
-    map_codes = torch.from_numpy(np.concatenate([synth.random_codes(args.map, 1234),
-                                                 synth.random_codes(roll, 4321)])).to(dev)
-    M = map_codes.shape[0]
     a_idx = [torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(D)]
     a_dist = [torch.zeros(cap, dtype=torch.float32, device=dev) for _ in range(D)]
-    block = torch.zeros(G, 34, dtype=torch.uint8, device=dev)          # code(32) + keep + colour per segment
-    gathered = torch.zeros(world * G, 34, dtype=torch.uint8, device=dev)
-    counts_local = torch.zeros(1, dtype=torch.int32, device=dev)
-    counts_all = torch.zeros(world, dtype=torch.int32, device=dev)
+
+    # ---- the live map: the package's associator component.  Seeded FULL (--map + 16384 random codes, seed 1234,
+    # identical on every rank) and kept full by the ring, so the association work per GPU is the same at every N
+    # and in every step (weak scaling); the kept segments of every rank's batch enter it each step
+    # (append-only like show_map.py:28-42, oldest entries overwritten).
+    M = args.map + MAP_ROLL
+    amap = LineAssociator(capacity=M, color_gating=False, max_distance=128, policy="append", kept_only=True,
+                          when_full="ring", device=local_rank)
+    amap.seed(synth.random_codes(M, 1234))
+    G = 16 * 1024                                    # segments per rank block; a batch with more raises (never truncates)
+    sharded = ShardedAssociator(amap, block_segments=G, device=dev, backend=args.backend, force_collective=force)
     seg_total = [0]
-    # the handles' own HIP streams, wrapped so that torch events can order work across them
-    exts = [torch.cuda.ExternalStream(f.stream_ptr(), device=dev) for f in fes]
-    events = [tuple(torch.cuda.Event() for _ in range(3)) for _ in range(D)]
-    host_ms = {"wait": 0.0, "merge": 0.0, "assoc": 0.0, "map": 0.0, "n": 0}
+    host_ms = {"wait": 0.0, "associate+exchange+update": 0.0, "n": 0}
+    step_no = [0]
+    # per-frame odometry poses (map -> duck, odometry.py:110-120): a gentle arc, the same for every batch
+    poses = np.column_stack([0.01 * np.arange(B), 0.3 * np.sin(0.02 * np.arange(B)), 0.002 * np.arange(B)])
 
     def finish(slot):
-        """Complete the batch queued on `slot`: merge segment lists across ranks, associate, update the map."""
-        f, out = fes[slot], outs[slot]
+        """Complete the batch queued on `slot`: associate against the map replica, exchange segment blocks (N > 1),
+        update the map.  The only host synchronisations are lf_wait (the batch's segment count) and the map's
+        size mirror of the PREVIOUS update; everything else is queued on the map's stream and ordered against the
+        handle's stream with events inside the library."""
+        f = fes[slot]
         h0 = time.perf_counter()
         total = f.wait()
         h1 = time.perf_counter()
         seg_total[0] = total
-        n = min(total, G)
-        if multi:
-            block[:n, :32] = out["code"][:n]
-            block[:n, 32] = out["keep"][:n]
-            block[:n, 33] = out["color"][:n]
-            counts_local[0] = n
-            if args.backend == "nccl":           # RCCL over xGMI, device buffers
-                dist.all_gather_into_tensor(counts_all, counts_local)
-                dist.all_gather_into_tensor(gathered, block)
-            else:                                # gloo dry run: stage through the host
-                hc, hb = counts_all.cpu(), gathered.cpu()
-                dist.all_gather_into_tensor(hc, counts_local.cpu())
-                dist.all_gather_into_tensor(hb, block.cpu())
-                counts_all.copy_(hc)
-                gathered.copy_(hb)
-            src = gathered.view(world, G, 34)[:, : roll // world, :32]
-        else:
-            src = out["code"][: roll].view(1, -1, 32)[:, : roll]
-        # Association: this rank's segments against the replicated map as it stood before this batch; then the map
-        # update.  The association runs on the handle's own stream, the merge and the map on torch's: they are
-        # ordered with events, not host synchronisation, so the host goes straight back to queueing the next batch
-        # (with host syncs here the freed handle sat idle for ~1.4 ms per step behind a saturated GPU).
-        cur = torch.cuda.current_stream()
-        ev_a, ev_b, ev_c = events[slot]
-        ev_a.record(cur)
-        exts[slot].wait_event(ev_a)                 # after the merge and every earlier map update
+        sharded.step(f, outs[slot], total, B, a_idx[slot], a_dist[slot], poses=poses, step=step_no[0])
+        step_no[0] += 1
         h2 = time.perf_counter()
-        if total > 0:
-            f.associate_device(out["code"].data_ptr(), total, map_codes.data_ptr(), M, a_idx[slot].data_ptr(),
-                               a_dist[slot].data_ptr())
-        ev_b.record(exts[slot])
-        cur.wait_event(ev_b)                        # the map changes only after this batch has been matched
-        h3 = time.perf_counter()
-        # map update, rank-major / frame-minor so every rank holds the same map
-        k = src.shape[1]
-        map_codes[args.map: args.map + world * k] = src.reshape(-1, 32)
-        ev_c.record(cur)
-        exts[slot].wait_event(ev_c)                 # the handle's next batch may overwrite `out` only after it was read
-        h4 = time.perf_counter()
-        host_ms["wait"] += h1 - h0; host_ms["merge"] += h2 - h1; host_ms["assoc"] += h3 - h2; host_ms["map"] += h4 - h3
+        host_ms["wait"] += h1 - h0
+        host_ms["associate+exchange+update"] += h2 - h1
         host_ms["n"] += 1
 
     def run(steps):
@@ -220,6 +196,7 @@ def main():
             finish(inflight.pop(0))
 
     def sync_all():
+        amap.synchronize()
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
@@ -229,7 +206,9 @@ def main():
     for f in fes:
         f.reset_timing()
         f.set_profiling(True)
-    for k_ in ("wait", "merge", "assoc", "map", "n"):
+    amap.timing()
+    amap.set_profiling(True)
+    for k_ in host_ms:
         host_ms[k_] = 0
     t0 = time.perf_counter()
     run(args.steps)
@@ -242,12 +221,15 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
     def collect():
         t_ = {}
         for f in fes:
             for name, (ms, launches) in f.timing().items():
                 a0, b0 = t_.get(name, (0.0, 0))
                 t_[name] = (a0 + ms, b0 + launches)
+        for name, (ms, launches) in amap.timing().items():
+            t_[name] = (ms, launches)
         return t_
 
     timing_overlapped = collect()       # event durations inside the timed region (batches overlap -> kernels share the GPU)
@@ -260,15 +242,18 @@ def main():
     for _ in range(solo_steps):
         fes[0].submit_device(frames.data_ptr(), B, ptrs[0], cap, describe=True)
         finish(0)
+        amap.synchronize()
     sync_all()
     fes[0].set_profiling(False)
+    amap.set_profiling(False)
     timing = collect()
+    map_state = amap.state()
 
     result = None
     if rank == 0:
         frames_total = world * B * args.steps
         value = frames_total / dt
-        sb = stage_bytes(P, Ps, cfg["img_size"] != cfg["in_size"])
+        sb = stage_bytes(P)
         kernels = []
         for name, (ms, launches) in timing.items():
             if launches == 0:
@@ -278,9 +263,10 @@ def main():
             if name in sb and avg > 0:
                 e["algorithmic_bytes"] = sb[name] * B
                 e["GBps"] = round(sb[name] * B / (avg * 1e-3) / 1e9, 1)
+                e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
             if name == "assoc_mfma" and avg > 0 and seg_total[0] > 0:
-                # 2 * N * M * 256 int8 ops per call against the dense int8 MFMA peak (stage time
-                # includes the +-64 packing of queries and map and the final decode)
+                # 2 * N * M * 256 int8 ops per call against the dense int8 MFMA peak (the kernel, its
+                # best-slot fill and the final decode; the map's operands stay packed across calls)
                 ops = 2.0 * seg_total[0] * M * 256
                 e["algorithmic_ops"] = ops
                 e["Pop_per_s"] = round(ops / (avg * 1e-3) / 1e15, 3)
@@ -293,7 +279,7 @@ def main():
         roofline = None
         if dom:
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj["workload"] == {"batch": B, "geometry": args.geometry}:
@@ -304,23 +290,22 @@ def main():
                         "measured": "HIP events on the launch stream, %d single-batch steps run right after the "
                                     "timed region (per-kernel times inside the overlapped region are in "
                                     "kernels_timed_region)" % solo_steps,
-                        "traffic_source": "profiles/r01_traffic.json (rocprofv3 PMC, FETCH_SIZE x2 + WRITE_SIZE)" if traffic else None,
-                        "note": "dominant STREAMING kernel (most algorithmic bytes).  The longest kernel by time, lsd_grow "
-                                "(sequential-semantics LSD region growing, one wave per problem), is latency / issue bound and "
-                                "has no bandwidth or MFMA roofline (SURVEY 8d: report time); its time is in `kernels`, its "
-                                "instruction profile in DESIGN.md section 9"}
+                        "traffic_source": "profiles/r02_traffic.json (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes)" if traffic else None,
+                        "note": "dominant STREAMING kernel (most algorithmic bytes, SURVEY 8d).  The longest kernel by time, lsd_grow "
+                                "(sequential-semantics LSD region growing), is latency / issue bound and "
+                                "has no bandwidth or MFMA roofline (SURVEY 8d: report time); its time is in `kernels`"}
         result = {
             "metric": "frames/sec (%dx%d) detect->descript->project->sanity->associate" % (in_cols, in_rows),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (i8 MFMA for association)", "data": "synthetic",
-            "config": {"workload": "%s%d-frame batch per GPU of %dx%d synthetic lane frames, %s geometry (working image %dx%d, "
-                                   "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs %d-code live map"
+            "config": {"workload": "%s%d-frame batch per GPU of %dx%d synthetic lane frames (%d distinct), %s geometry (working image %dx%d, "
+                                   "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs the %d-entry live map + map update"
                                    % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",
-                                      B, in_cols, in_rows, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M),
-                       "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0],
+                                      B, in_cols, in_rows, uniq, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M),
+                       "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0], "live_map": map_state,
                        "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
-                       "parallelism": "frame-sharded x%d, all-gather of segment blocks" % world},
+                       "parallelism": "frame-sharded x%d, one all-gather of segment blocks per step, replicated map" % world},
             "roofline": roofline,
             "kernels": kernels,
             "kernels_timed_region": [{"stage": n, "avg_ms": round(ms / max(l, 1), 4), "launches": l}
@@ -332,7 +317,7 @@ def main():
             o = Oracle(cfg)
             nf = args.cpu_frames or (160 if args.geometry == "fullres" else (24 if hd else 1500))
             nf = min(nf, B)
-            mc = map_codes.cpu().numpy()
+            mc = amap.fetch(0, M)["code"]
             # parity gate of this very run: the GPU output of the last batch on handle 0,
             # frame by frame, against what the oracle computes for the same frames while it is being timed
             g_fo = outs[0]["frame_offset"].cpu().numpy()
@@ -341,11 +326,9 @@ def main():
             g_desc = outs[0]["desc"][:g_n].cpu().numpy()
             gate_ok, gate_frames, gate_desc_err = True, 0, 0.0
             cdt = 0.0
-            nseg = 0
             for f in range(nf):
                 t1 = time.perf_counter()
                 r = o.process_frame(host[f], cap=3 * args.cap)
-                nseg += r["n"]
                 if r["n"]:
                     o.match(r["code"], mc)
                 cdt += time.perf_counter() - t1            # the comparison below is not part of the baseline
@@ -385,6 +368,9 @@ def main():
             result["cpu_baseline_threads"] = {
                 "value": round(T * per / mdt, 1), "unit": "frames/s", "cores": T, "kind": "port",
                 "sample": "%d threads x %d frames of the same step, one oracle instance per thread, %.1f s" % (T, per, mdt)}
+        do_secondary = args.secondary == "all" or (args.secondary == "auto" and world == 1 and not force and args.geometry == "fullres")
+        if do_secondary:
+            result["secondary"] = secondary(args, torch, dev, local_rank, fes, ptrs, a_idx, a_dist, host, B, D, cap)
     # The JSON line is the LAST thing on stdout: libraries that log through C stdio (RCCL prints its version banner
     # under NCCL_DEBUG=VERSION, buffered until exit when stdout is a pipe) are flushed on every rank first.
     import ctypes
@@ -392,6 +378,7 @@ def main():
     ctypes.CDLL(None).fflush(None)
     if multi:
         dist.barrier()
+    amap.close()
     for f in fes:
         f.close()
     if multi:
@@ -401,6 +388,170 @@ def main():
         print(json.dumps(result))
         sys.stdout.flush()
     return result
+
+
+def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D, cap):
+    """Measurements that never replace `value` (VERDICT r1 #5).  Each is bounded to a few seconds."""
+    from lane_slam_amd import LineAssociator, LineDetectorHIP, synth
+    from lane_slam_amd.config import DEFAULT_DETECTOR_CONFIGURATION
+    sec = {}
+
+    # ---- BASELINE configs[2]: streaming replay.  Frames live in PINNED HOST memory and every batch pays its own
+    # H2D copy on its handle's stream (D batches in flight = multi-buffered H2D); distinct frames; the map starts
+    # EMPTY and grows by the kept segments (append-only, show_map.py:28-42), with per-frame poses.
+    n_stream = max(B, (args.stream_frames // B) * B)
+    laps = max(1, args.stream_laps)
+    uniq = host.shape[0]
+    pinned = torch.empty((n_stream,) + host.shape[1:], dtype=torch.uint8).pin_memory()
+    pn = pinned.numpy()
+    for j in range(n_stream):
+        # the `uniq` rendered frames, shifted sideways by 9 px per pass: cheap, and every frame of the stream differs
+        pn[j] = np.roll(host[j % uniq], 9 * (j // uniq), axis=1)
+    frame_bytes = host[0].nbytes
+    segs = [0]
+
+    def stream_pass(smap, lap):
+        inflight = []
+
+        def complete():
+            s0, k0 = inflight.pop(0)
+            n = fes[s0].wait()
+            segs[0] += n
+            t = np.arange(k0 * B, (k0 + 1) * B, dtype=np.float64) + lap * n_stream
+            pose = np.column_stack([0.01 * t, 0.3 * np.sin(0.02 * t), 0.002 * t])
+            smap.step_device(fes[s0], ptrs[s0], n, B, a_idx[s0].data_ptr(), a_dist[s0].data_ptr(), poses=pose, step=lap * 1000 + k0)
+        for k in range(n_stream // B):
+            slot = k % D
+            if len(inflight) == D:
+                complete()
+            fes[slot].submit_host(pinned.data_ptr() + k * B * frame_bytes, B, ptrs[slot], cap, describe=True)
+            inflight.append((slot, k))
+        while inflight:
+            complete()
+
+    def new_map():
+        return LineAssociator(capacity=1 << 18, color_gating=False, max_distance=128, policy="append", kept_only=True,
+                              when_full="ring", device=device_id)
+    smap = new_map()
+    stream_pass(smap, 0)                             # warm-up lap (allocations, first touch of the pinned pages)
+    smap.synchronize()
+    torch.cuda.synchronize()
+    smap.close()
+    smap = new_map()
+    segs[0] = 0
+    t0 = time.perf_counter()
+    for lap in range(laps):
+        stream_pass(smap, lap)
+    smap.synchronize()
+    torch.cuda.synchronize()
+    sdt = time.perf_counter() - t0
+    st = smap.state()
+    smap.close()
+    sec["stream_configs2"] = {
+        "value": round(laps * n_stream / sdt, 1), "unit": "frames/s",
+        "what": "BASELINE configs[2]: %d-frame stream x %d laps, frames in pinned host memory, one async H2D copy per %d-frame batch "
+                "on its handle's stream (%d batches in flight), detect->describe->project->sanity->associate->map update, map "
+                "growing from empty by the kept segments (append, per-frame poses)" % (n_stream, laps, B, D),
+        "frames": laps * n_stream, "distinct_frames_per_lap": n_stream, "seconds": round(sdt, 4),
+        "h2d_GBps": round(laps * n_stream * frame_bytes / sdt / 1e9, 2), "segments": segs[0], "map_final": st}
+
+    # ---- JPEG ingest (8f-1): CompressedImage streams -> host Huffman decode -> GPU IDCT/colour -> the same path
+    try:
+        import io
+        from PIL import Image
+        streams = []
+        for i in range(min(uniq, 64)):
+            b = io.BytesIO()
+            Image.fromarray(host[i][..., ::-1].copy()).save(b, "JPEG", quality=80, subsampling=2)
+            streams.append(b.getvalue())
+        msgs = [streams[i % len(streams)] for i in range(B)]
+        bufs = [fe.frames_buffer()[0] for fe in fes]
+        nthreads = max(1, min(64, (os.cpu_count() or 2) // 2))
+
+        def jpeg_pass(nb):
+            inflight = []
+            for k in range(nb):
+                slot = k % D
+                if len(inflight) == D:
+                    fes[inflight.pop(0)].wait()
+                fes[slot].decode_jpeg_batch(msgs, n_threads=nthreads, device_ptr=bufs[slot])
+                fes[slot].submit_device(bufs[slot], B, ptrs[slot], cap, describe=True)
+                inflight.append(slot)
+            while inflight:
+                fes[inflight.pop(0)].wait()
+        jpeg_pass(D)
+        torch.cuda.synchronize()
+        nb = 2 * D
+        t0 = time.perf_counter()
+        jpeg_pass(nb)
+        torch.cuda.synchronize()
+        jdt = time.perf_counter() - t0
+        sec["jpeg_ingest"] = {"value": round(nb * B / jdt, 1), "unit": "frames/s", "host_threads": nthreads,
+                              "what": "JPEG streams (quality 80, 4:2:0, %.0f kB each) -> lf_jpeg_decode_batch -> detect->describe->project->sanity, "
+                                      "%d batches in flight; entropy decoding on %d host threads of a shared box"
+                                      % (np.mean([len(s) for s in streams]) / 1e3, D, nthreads)}
+    except Exception as e:                                       # Pillow missing or similar: say so, do not fail the bench
+        sec["jpeg_ingest"] = {"error": repr(e)}
+
+    # ---- the drop-in operating point: ONE 160x120 frame through the plugin interface (default.yaml:1-2),
+    # setImage + three detectLines, host arrays in and out
+    det = LineDetectorHIP(dict(DEFAULT_DETECTOR_CONFIGURATION), device=device_id)
+    small = [np.ascontiguousarray(host[i % uniq][::4, ::4][40:]) for i in range(32)]          # 80x160 working images
+    for img in small[:4]:
+        det.setImage(img)
+        [det.detectLines(c) for c in ("white", "yellow", "red")]
+    lat = []
+    for i in range(200):
+        t0 = time.perf_counter()
+        det.setImage(small[i % 32])
+        for c in ("white", "yellow", "red"):
+            det.detectLines(c)
+        lat.append(time.perf_counter() - t0)
+    lat = np.sort(np.array(lat)) * 1e3
+    sec["plugin_latency_160x120"] = {"median_ms": round(float(lat[100]), 3), "p90_ms": round(float(lat[180]), 3), "min_ms": round(float(lat[0]), 3),
+                                     "what": "LineDetectorHIP.setImage + 3 x detectLines on one 160x80 working image (img_size [120,160], "
+                                             "top_cutoff 40), host numpy in/out, 200 frames"}
+
+    # ---- BASELINE configs[4]: associator stress, N queries x 50 000-code map (5 % planted neighbours within 40 bits)
+    stress = []
+    rng = np.random.default_rng(1234)
+    mcodes = synth.random_codes(50000, 1234)
+    am = LineAssociator(capacity=50048, color_gating=False, kept_only=False, device=device_id)
+    am.seed(mcodes)
+    for nq in (4096, 16384):
+        q = synth.random_codes(nq, 99)
+        planted = rng.choice(nq, nq // 20, replace=False)
+        for i in planted:
+            src = mcodes[rng.integers(0, 50000)].copy()
+            for b in rng.choice(256, size=int(rng.integers(0, 41)), replace=False):
+                src[b >> 3] ^= np.uint8(1 << (b & 7))
+            q[i] = src
+        dq = torch.from_numpy(q).to(dev)
+        di = torch.zeros(nq, dtype=torch.int32, device=dev)
+        dd = torch.zeros(nq, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            am.associate_device(None, dq.data_ptr(), None, nq, di.data_ptr(), dd.data_ptr())
+        am.synchronize()
+        am.timing()
+        am.set_profiling(True)
+        for _ in range(20):
+            am.associate_device(None, dq.data_ptr(), None, nq, di.data_ptr(), dd.data_ptr())
+        am.synchronize()
+        tm = am.timing()
+        am.set_profiling(False)
+        ms_core = tm["assoc_mfma"][0] / max(tm["assoc_mfma"][1], 1)
+        ms_pack = tm["assoc_pack_queries"][0] / max(tm["assoc_pack_queries"][1], 1)
+        ops = 2.0 * nq * 50000 * 256
+        stress.append({"N": nq, "M": 50000, "assoc_ms": round(ms_core, 4), "query_pack_ms": round(ms_pack, 4),
+                       "Pop_per_s": round(ops / (ms_core * 1e-3) / 1e15, 3),
+                       "frac_of_int8_mfma_peak": round(ops / (ms_core * 1e-3) / 1e15 / INT8_MFMA_PEAK_POPS, 3),
+                       "matched_within_128": int((di >= 0).sum().item())})
+    am.close()
+    sec["assoc_stress_configs4"] = {"rows": stress, "peak_Pop_per_s": INT8_MFMA_PEAK_POPS,
+                                    "what": "lf_map_associate on a 50 000-code map kept packed on the device; ops = 2*N*M*256 (SURVEY 8d); "
+                                            "assoc_ms = best-slot fill + MFMA kernel + decode, HIP events on the map's stream, 20 calls"}
+    return sec
 
 
 if __name__ == "__main__":

@@ -119,7 +119,7 @@ size_t assoc_rows_padded_m(int nm);
 void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
                        int8_t* cx, hipStream_t s);
 void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
-                       int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
+                       const int* nm_dev, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,
                   unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);

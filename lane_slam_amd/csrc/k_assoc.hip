@@ -81,8 +81,13 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* _
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
-                                               int nm, int nm_pad, int m_chunk, unsigned int* __restrict__ best)
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
+                                               unsigned int* __restrict__ best)
 {
+    // nm_bound sized the grid on the host; when the exact size is only known on the device (the live map's size
+    // after an update still in flight) it is read here.  Rows in [size, bound) are all-zero operands and are dropped
+    // below exactly like padding rows, so the result does not depend on how loose the bound was.
+    const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
     __shared__ __attribute__((aligned(1024))) int8_t tile[2 * AM * 256];     // double buffered map tile, linear rows
     __shared__ __attribute__((aligned(1024))) int8_t ctile[2 * AM * 32];     // the tiles' ninth-step operands
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -242,7 +247,7 @@ void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, in
 // association of packed queries against a packed map (the live map keeps its side packed across calls;
 // lf_associate packs its caller's raw map first)
 void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
-                       int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+                       const int* nm_dev, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
 {
     const int nq_pad = (int)assoc_rows_padded_q(nq), nm_pad = (int)assoc_rows_padded_m(nm);
     hipLaunchKernelGGL(k_fill_u32, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, 0x7fffffffu);
@@ -257,7 +262,7 @@ void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t
     if (splits < 1) splits = 1;
     const int m_chunk = (tiles + splits - 1) / splits * AM;
     splits = (nm_pad + m_chunk - 1) / m_chunk;
-    hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_pad, m_chunk, best);
+    hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
     hipLaunchKernelGGL(k_assoc_finish, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, max_distance, idx, dist);
 }
 
@@ -266,7 +271,7 @@ void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx
 {
     launch_assoc_pack(m, nullptr, 1, 0, nm, (int)assoc_rows_padded_m(nm), mx, mcx, s);
     launch_assoc_pack(q, nullptr, 0, 0, nq, (int)assoc_rows_padded_q(nq), qx, qcx, s);
-    launch_assoc_core(qx, qcx, nq, mx, mcx, nm, 128, best, idx, dist, s);
+    launch_assoc_core(qx, qcx, nq, mx, mcx, nm, nullptr, 128, best, idx, dist, s);
 }
 
 // ---------------------------------------------------------------- float LBD (72-d)

@@ -262,8 +262,9 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
         tempM += v[0] * v[0]; tempM += v[1] * v[1]; tempM += v[2] * v[2]; tempM += v[3] * v[3];
         tempS += v[4] * v[4]; tempS += v[5] * v[5]; tempS += v[6] * v[6]; tempS += v[7] * v[7];
     }
-    tempM = (float)(1 / dm::dsqrt((double)tempM));
-    tempS = (float)(1 / dm::dsqrt((double)tempS));
+    // binary_descriptor_custom.cpp:1301-1302: std::sqrt(float), then a float division -- two float roundings
+    tempM = dm::fdiv(1.f, dm::fsqrt(tempM));
+    tempS = dm::fdiv(1.f, dm::fsqrt(tempS));
     __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < 72; e += 64) {
         float v = D[e] * (((e & 7) < 4) ? tempM : tempS);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     float temp = 0;
     for (int i = 0; i < 72; ++i) temp += D[i] * D[i];
-    temp = (float)(1 / dm::dsqrt((double)temp));
+    temp = dm::fdiv(1.f, dm::fsqrt(temp));          // :1337
     __builtin_amdgcn_wave_barrier();
     for (int e = lane; e < 72; e += 64) {
         float v = D[e] * temp;

@@ -24,6 +24,7 @@ struct lf_map {
     int* h_state = nullptr;                  // pinned: [0..7] state, then 2 x u64 totals at +8 ints
     hipEvent_t ev_state = nullptr, ev_in = nullptr, ev_out = nullptr;
     bool state_pending = false;
+    long long rows_in_flight = 0;            // rows handed to updates whose state copy has not been seen yet
     Buf qx, qcx, best, act, own_block, pose, q_in, c_in, idx_out, dist_out, seed_code, seed_color, seed_ground;
     std::vector<double> h_pose;
     // per-stage timing with HIP events on the map's stream (resolved by lf_map_get_timing)
@@ -87,12 +88,14 @@ static int grow(lf_map* m, Buf& b, size_t bytes)
     return LF_OK;
 }
 
-// make the host mirror current: wait for the copy queued behind the last update
-static int refresh_state(lf_map* m)
+// make the host mirror current: wait for the copy queued behind the last update (block = false: only look)
+static int refresh_state(lf_map* m, bool block = true)
 {
     if (m->state_pending) {
-        MAP_HIP(m, hipEventSynchronize(m->ev_state));
+        if (block) MAP_HIP(m, hipEventSynchronize(m->ev_state));
+        else if (hipEventQuery(m->ev_state) != hipSuccess) return LF_OK;          // still in flight: the mirror is stale
         m->state_pending = false;
+        m->rows_in_flight = 0;
     }
     if (m->h_state[2] & 2) { map_error(m, "lf_map_update was given a block with a bad header (magic / count)"); return LF_ERR_BAD_ARG; }
     if (m->h_state[2] & 1) { map_error(m, "the map is full (capacity %d, LF_MAP_FULL_ERROR): segments were dropped", m->cfg.capacity); return LF_ERR_CAPACITY; }
@@ -259,7 +262,8 @@ extern "C" int lf_map_synchronize(lf_map* m)
     return LF_OK;
 }
 
-static int update_blocks(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows, int force_append)
+// rows_hint: how many segment rows the blocks really hold when the host knows it (-1: assume they are full)
+static int update_blocks(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows, int force_append, long long rows_hint = -1)
 {
     int rc;
     const size_t rows = (size_t)n_blocks * (size_t)(block_rows - 1);
@@ -270,6 +274,7 @@ static int update_blocks(lf_map* m, const uint8_t* blocks, int n_blocks, int blo
         launch_map_update(m->d, blocks, n_blocks, block_rows, force_append, static_cast<int*>(m->act.p), m->stream);
     }
     MAP_HIP(m, hipGetLastError());
+    m->rows_in_flight += rows_hint >= 0 ? rows_hint : (long long)rows;
     return queue_state_copy(m);
 }
 
@@ -308,7 +313,7 @@ extern "C" int lf_map_seed(lf_map* m, const uint8_t* code32, const uint8_t* colo
     }
     if ((rc = grow(m, m->own_block, (size_t)(n + 1) * LF_BLOCK_ROW_BYTES)) != LF_OK) return rc;
     launch_map_seed_block(n, dcode, dcolor, dground, static_cast<uint8_t*>(m->own_block.p), m->stream);
-    rc = update_blocks(m, static_cast<const uint8_t*>(m->own_block.p), 1, n + 1, 1);
+    rc = update_blocks(m, static_cast<const uint8_t*>(m->own_block.p), 1, n + 1, 1, n);
     if (rc != LF_OK) return rc;
     if (!on_device) MAP_HIP(m, hipStreamSynchronize(m->stream));     // the host arrays may be reused on return
     return LF_OK;
@@ -336,8 +341,14 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
     if (n == 0) return LF_OK;
     MAP_HIP(m, hipSetDevice(m->device));
     int rc;
-    if ((rc = refresh_state(m)) != LF_OK) return rc;
-    const int size = m->h_state[0];
+    // The map's size after the last update is needed to size the grid.  The host does not wait for that update:
+    // when its state copy has not landed yet, an upper bound (last size seen + the rows handed over since) sizes
+    // the grid and the kernel reads the exact size on the device; rows past it hold all-zero operands, so the
+    // result is the same.  (An overflow / bad-block flag is then reported one call later.)
+    if ((rc = refresh_state(m, false)) != LF_OK) return rc;
+    long long bound = (long long)m->h_state[0] + (m->state_pending ? m->rows_in_flight : 0);
+    if (bound > m->cfg.capacity) bound = m->cfg.capacity;
+    const int size = (int)bound;
     if ((rc = after_handle(m, h)) != LF_OK) return rc;
     hipStream_t s = m->stream;
     const uint8_t *dq = code32, *dc = color;
@@ -367,7 +378,7 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
         {
             MapTimer t(m, 1);
             launch_assoc_core(static_cast<const int8_t*>(m->qx.p), static_cast<const int8_t*>(m->qcx.p), n, m->d.mx, m->d.mcx, size,
-                              m->cfg.max_distance, static_cast<unsigned int*>(m->best.p), didx, ddist, s);
+                              m->d.state, m->cfg.max_distance, static_cast<unsigned int*>(m->best.p), didx, ddist, s);
         }
     }
     MAP_HIP(m, hipGetLastError());
@@ -428,7 +439,8 @@ extern "C" int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int
     MAP_HIP(m, hipSetDevice(m->device));
     if ((rc = grow(m, m->own_block, (size_t)(n + 1) * LF_BLOCK_ROW_BYTES)) != LF_OK) return rc;
     if ((rc = lf_map_pack_block(m, h, segs, n, n_frames, idx, dist, frame_pose, step, static_cast<uint8_t*>(m->own_block.p), n + 1)) != LF_OK) return rc;
-    return lf_map_update(m, static_cast<const uint8_t*>(m->own_block.p), 1, n + 1);
+    if (n == 0) return LF_OK;
+    return update_blocks(m, static_cast<const uint8_t*>(m->own_block.p), 1, n + 1, 0, n);
 }
 
 extern "C" int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,

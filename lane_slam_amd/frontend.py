@@ -159,6 +159,17 @@ class FrontEnd(object):
         self._check(self.lib.lf_process_batch_async(self.h, ctypes.c_void_p(int(frames_ptr)), int(n_frames), 1,
                                                     ctypes.byref(s), int(bool(describe))))
 
+    def submit_host(self, frames_host_ptr, n_frames, out_ptrs, capacity, describe=True):
+        """Like submit_device, but the frames are in HOST memory (pinned, for the copy to be asynchronous): the H2D copy
+        into the handle's staging buffer is queued on the handle's stream in front of the kernels.  The host block must
+        stay valid until wait() returns."""
+        s = _lib.LfSegments()
+        s.capacity = int(capacity)
+        for k, v in out_ptrs.items():
+            setattr(s, k, int(v))
+        self._check(self.lib.lf_process_batch_async(self.h, ctypes.c_void_p(int(frames_host_ptr)), int(n_frames), 0,
+                                                    ctypes.byref(s), int(bool(describe))))
+
     def wait(self):
         """Block until the queued batch is complete; returns its segment count."""
         total = ctypes.c_int()

@@ -99,6 +99,12 @@ void lfo_lbd(const int16_t* pdx, const int16_t* pdy, int rows, int cols,
         const float lineMiddlePointX = (float)(0.5 * (sX + eX));
         const float lineMiddlePointY = (float)(0.5 * (sY + eY));
         float dL[2], dO[2];
+        /* :1130-1131 `dL[0] = cos( pSingleLine->direction )`, direction a float (descriptor_custom.hpp:396).  Unlike
+         * sqrt, cos / sin are NOT among cvstd.hpp's using-declarations, so inside namespace cv::line_descriptor the
+         * unqualified name resolves to the global ::cos(double) of <math.h> that <cmath> (precomp_custom.hpp:62)
+         * drags in: the float is promoted, the cosine is a double and is rounded once into the float dL (checked with
+         * g++ 11 / libstdc++ on the same include list: decltype(cos(float)) is double there, decltype(sqrt(float))
+         * float once `using std::sqrt` is in scope). */
         dL[0] = (float)lfo_cos((double)angle[li]);
         dL[1] = (float)lfo_sin((double)angle[li]);
         dO[0] = -dL[1];
@@ -175,8 +181,12 @@ void lfo_lbd(const int16_t* pdx, const int16_t* pdy, int rows, int cols,
             tempM += v[0] * v[0]; tempM += v[1] * v[1]; tempM += v[2] * v[2]; tempM += v[3] * v[3];
             tempS += v[4] * v[4]; tempS += v[5] * v[5]; tempS += v[6] * v[6]; tempS += v[7] * v[7];
         }
-        tempM = (float)(1 / sqrt((double)tempM));
-        tempS = (float)(1 / sqrt((double)tempS));
+        /* :1301-1302 `tempM = 1 / sqrt( tempM )` with float tempM inside namespace cv: cvstd.hpp's `using std::sqrt`
+         * makes this std::sqrt(float), and int / float is a float division -- TWO float roundings (sqrt, then the
+         * quotient), not one rounding of a double quotient.  A float sqrt / quotient computed in double and rounded
+         * once more is the correctly rounded float result (53 >= 2*24 + 2). */
+        tempM = (float)(1.0 / (double)(float)sqrt((double)tempM));
+        tempS = (float)(1.0 / (double)(float)sqrt((double)tempS));
         for (int b = 0; b < NUM_OF_BANDS; ++b) {
             float* v = desVec + 8 * b;
             v[0] = v[0] * tempM; v[1] = v[1] * tempM; v[2] = v[2] * tempM; v[3] = v[3] * tempM;
@@ -185,7 +195,7 @@ void lfo_lbd(const int16_t* pdx, const int16_t* pdy, int rows, int cols,
         for (int i = 0; i < 72; ++i) if ((double)desVec[i] > 0.4) desVec[i] = (float)0.4;
         float temp = 0;
         for (int i = 0; i < 72; ++i) temp += desVec[i] * desVec[i];
-        temp = (float)(1 / sqrt((double)temp));
+        temp = (float)(1.0 / (double)(float)sqrt((double)temp));          /* :1337, same two roundings */
         for (int i = 0; i < 72; ++i) desVec[i] = desVec[i] * temp;
         /* :653-667 + :401-412 */
         uint8_t* code = code32 + (size_t)32 * li;

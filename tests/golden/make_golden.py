@@ -14,6 +14,13 @@ What is imported from /root/reference (Python 3 can execute these files as they 
         scaleandshift2                                                       (a-1)
   * src/ground_projection/include/ground_projection/GroundProjection.py (Python 2: converted in memory by lib2to3)
         GroundProjection.vector2pixel / pixel2ground with rectifyPoint = identity   (a-7 minus undistortPoints)
+  * src/line_detector/src/line_detector_node.py
+        LineDetectorNode.processImage_ / toSegmentMsg with a FAKE detector plugin that returns fixed lines and
+        normals: the normalisation arithmetic, the colour order, the empty-list rule               (a-6)
+  * src/ground_projection/src/ground_projection_node.py
+        GroundProjectionNode.lineseglist_cb: which fields travel on, in which order                 (a-7 glue)
+  * src/duckietown_msgs/msg/{SegmentList,Segment,Vector2D}.msg
+        parsed here to serialise the messages the two nodes built -> the ROS 1 wire bytes           (f-2)
 The modules `rospy`, `cv2`, `*_msgs.msg` they import at file scope are absent from this
 image; they are replaced by empty name-only stubs (no arithmetic) so the import
 statements succeed.  Message classes are plain attribute holders with the constants of
@@ -48,12 +55,22 @@ class Segment(object):
 
     def __init__(self):
         self.color = 0
+        self.pixels_normalized = [_Obj(x=0.0, y=0.0), _Obj(x=0.0, y=0.0)]
+        self.normal = _Obj(x=0.0, y=0.0)
         self.points = [_Obj(x=0.0, y=0.0, z=0.0), _Obj(x=0.0, y=0.0, z=0.0)]
+
+
+class _Stamp(object):
+    def __init__(self, secs=0, nsecs=0):
+        self.secs, self.nsecs = secs, nsecs
+
+    def to_sec(self):
+        return self.secs + 1e-9 * self.nsecs
 
 
 class SegmentList(object):
     def __init__(self):
-        self.header = None
+        self.header = _Obj(seq=0, stamp=_Stamp(), frame_id="")
         self.segments = []
 
 
@@ -238,7 +255,205 @@ def golden_ground_projection():
     print("ground_projection:", n, "points; clamp quirk example", pix[3], out[3])
 
 
+# ---------------------------------------------------------------------------------------------------------
+# ROS 1 wire format from the reference's own .msg files.  std_msgs/Header and geometry_msgs/Point are not in the
+# reference's tree (ROS packages); their public definitions are written out here.  Serialisation rules (public,
+# wiki.ros.org/msg): little endian, fields in declaration order, constants skipped, fixed arrays back to back,
+# variable arrays and strings behind a uint32 length, `time` = uint32 secs + uint32 nsecs.
+_PUBLIC_DEFS = {
+    "std_msgs/Header": "uint32 seq\ntime stamp\nstring frame_id\n",
+    "geometry_msgs/Point": "float64 x\nfloat64 y\nfloat64 z\n",
+}
+_BUILTIN = {"uint8": "<B", "int8": "<b", "uint16": "<H", "int16": "<h", "uint32": "<I", "int32": "<i", "float32": "<f",
+            "float64": "<d", "bool": "<B"}
+
+
+def _msg_fields(type_name):
+    if type_name in _PUBLIC_DEFS:
+        text = _PUBLIC_DEFS[type_name]
+    else:
+        pkg, name = type_name.split("/")
+        text = open(os.path.join(REF, pkg, "msg", name + ".msg")).read()
+    fields = []
+    for line in text.splitlines():
+        line = line.split("#")[0].strip()
+        if not line or "=" in line:
+            continue
+        t, n = line.split()
+        fields.append((t, n))
+    return fields
+
+
+def ros_serialize(obj, type_name, pkg="duckietown_msgs"):
+    import struct
+    base, arr = type_name, None
+    if type_name.endswith("]"):
+        base, rest = type_name.split("[")
+        arr = rest[:-1]
+    if arr is not None:
+        out = b"" if arr else struct.pack("<I", len(obj))
+        if arr:
+            assert len(obj) == int(arr)
+        return out + b"".join(ros_serialize(v, base, pkg) for v in obj)
+    if base in _BUILTIN:
+        return struct.pack(_BUILTIN[base], obj)
+    if base == "string":
+        b = obj.encode()
+        return struct.pack("<I", len(b)) + b
+    if base == "time":
+        return struct.pack("<II", obj.secs, obj.nsecs)
+    if base == "Header":
+        base = "std_msgs/Header"
+    if "/" not in base:
+        base = pkg + "/" + base
+    return b"".join(ros_serialize(getattr(obj, n), t, base.split("/")[0]) for t, n in _msg_fields(base))
+
+
+def golden_node_pipeline():
+    """The reference's own node code around a-6 / a-7, executed here with a fake detector plugin:
+    LineDetectorNode.processImage_ + toSegmentMsg (line_detector_node.py:141-213,251-265) and
+    GroundProjectionNode.lineseglist_cb (ground_projection_node.py:55-65), and the messages they build serialised
+    with the field order of the reference's .msg files.  cv2.convertScaleAbs / drawLines / cv_bridge are name-only
+    stubs: the fake detector never looks at the image, so no arithmetic of theirs reaches the fixture."""
+    import time
+    import yaml
+    from lib2to3.refactor import RefactoringTool, get_fixers_from_package
+    if not hasattr(time, "clock"):
+        time.clock = time.process_time                 # timekeeper.py:20 (Python 2 API), timing only
+    rospy = sys.modules["rospy"]
+    rospy.get_time = time.time
+    sys.modules["cv2"].convertScaleAbs = lambda img: img
+    _stub("cv_bridge", CvBridge=_Obj, CvBridgeError=Exception)
+    ai = _stub("anti_instagram")
+    ai.__path__ = []
+    _stub("anti_instagram.AntiInstagram", AntiInstagram=_Obj)
+    du = _stub("duckietown_utils", logger=None, get_duckiefleet_root=lambda: "")
+    du.__path__ = []
+    _stub("duckietown_utils.instantiate_utils", instantiate=lambda *a: None)
+    _stub("duckietown_utils.jpg", image_cv_from_jpg=lambda data: data)       # the "decoded" image is handed over as is
+    load_file("duckietown_utils.parameters", REF + "/duckietown/include/duckietown_utils/parameters.py")
+    if REF + "/line_detector/include" not in sys.path:
+        sys.path.insert(0, REF + "/line_detector/include")
+    _stub("line_detector.line_detector_plot", color_segment=lambda *a: None, drawLines=lambda *a: None)
+    from line_detector.line_detector_interface import Detections
+    node_mod = load_file("ref_line_detector_node", REF + "/line_detector/src/line_detector_node.py")
+
+    class FakeDetector(object):
+        def __init__(self, per_color):
+            self.per_color = per_color
+
+        def setImage(self, bgr):
+            self.shape = bgr.shape
+
+        def detectLines(self, color):
+            lines, normals = self.per_color[color]
+            if len(lines) == 0:
+                return Detections(lines=[], normals=[], area=None, centers=[])       # line_detector_lsd.py:68-71
+            return Detections(lines=lines.copy(), normals=normals.copy(), area=None, centers=None)
+
+    class Capture(object):
+        def publish(self, msg):
+            self.msg = msg
+
+    # ground projection node around the converted GroundProjection class (see golden_ground_projection)
+    path = REF + "/ground_projection/include/ground_projection/GroundProjection.py"
+    src3 = str(RefactoringTool(get_fixers_from_package("lib2to3.fixes")).refactor_string(open(path).read() + "\n", path))
+
+    class _Pcm(object):
+        def rectifyPoint(self, uv):
+            return uv
+
+    _stub("image_geometry", PinholeCameraModel=_Pcm)
+    _stub("duckietown_utils.path_utils", get_ros_package_path=lambda *a: "")
+    _stub("duckietown_utils.yaml_wrap", yaml_load_file=lambda *a: None, yaml_write_to_file=lambda *a: None)
+    sys.modules["sensor_msgs.msg"].CameraInfo = _Obj
+    sys.modules["duckietown_msgs.msg"].Pixel = _Obj
+    gpkg = _stub("ground_projection")
+    gpkg.__path__ = []
+    _stub("ground_projection.srv", **{k: _Obj for k in ("EstimateHomography", "EstimateHomographyResponse", "GetGroundCoord",
+                                                        "GetGroundCoordResponse", "GetImageCoord", "GetImageCoordResponse")})
+    gmod = types.ModuleType("ground_projection.GroundProjection")
+    sys.modules["ground_projection.GroundProjection"] = gmod
+    exec(compile(src3, path, "exec"), gmod.__dict__)
+    gp = object.__new__(gmod.GroundProjection)
+    gp.rectified_input = False
+    ext = yaml.safe_load(open(REF + "/duckietown/include/calibrations/camera_extrinsic/default.yaml"))
+    gp.H = np.array(ext["homography"], np.float64).reshape(3, 3)
+    gp.ci_ = _Obj(width=640, height=480)
+    gp.pcm_ = _Pcm()
+    gnode_mod = load_file("ref_ground_projection_node", REF + "/ground_projection/src/ground_projection_node.py")
+    gnode = object.__new__(gnode_mod.GroundProjectionNode)
+    gnode.gp = gp
+    gnode.pub_lineseglist_ = Capture()
+
+    rng = np.random.default_rng(4242)
+    cases = {}
+    geoms = [((120, 160), 40, (37, 0, 5)), ((480, 640), 160, (60, 33, 0)), ((200, 300), 7, (9, 11, 4)), ((120, 160), 40, (0, 0, 0))]
+    for ci, (size, cut, counts) in enumerate(geoms):
+        H, W = size
+        per = {}
+        for color, n in zip(("white", "yellow", "red"), counts):
+            lines = np.empty((n, 4), np.float32)
+            lines[:, 0::2] = rng.uniform(-2, W + 2, (n, 2)).astype(np.float32)
+            lines[:, 1::2] = rng.uniform(-2, H - cut + 2, (n, 2)).astype(np.float32)
+            if n > 2:
+                lines[0] = [0.0, 0.0, W - 1.0, H - cut - 1.0]
+                lines[1] = [0.5, 1.25, 100.625, 33.3125]
+            th = rng.uniform(-np.pi, np.pi, n)
+            # LineDetectorLSD hands over float64 normals whose values are float32 products (line_detector_lsd.py:118-123)
+            normals = np.column_stack([np.cos(th), np.sin(th)]).astype(np.float32).astype(np.float64)
+            per[color] = (lines, normals)
+        node = object.__new__(node_mod.LineDetectorNode)
+        node.node_name = "LineDetectorNode"
+        node.stats = node_mod.Stats()
+        node.intermittent_interval, node.intermittent_counter = 100, 5
+        node.image_size, node.top_cutoff = [H, W], cut
+        node.ai = _Obj(applyTransform=lambda img: img)
+        node.detector = FakeDetector(per)
+        node.pub_lines, node.pub_image = Capture(), Capture()
+        node.bridge = _Obj(cv2_to_imgmsg=lambda img, enc: _Obj(header=_Obj(stamp=None)))
+        node.verbose = False
+        img_msg = _Obj(data=np.zeros((H, W, 3), np.uint8), header=_Obj(stamp=_Stamp(1234, 5678)))
+        node.processImage_(img_msg)
+        sl = node.pub_lines.msg
+        sl.header.seq, sl.header.frame_id = 7, "cam"
+        n = len(sl.segments)
+        assert n == sum(counts)
+        cases["geom%d" % ci] = np.array([H, W, cut], np.int32)
+        for color in ("white", "yellow", "red"):
+            cases["lines_%s%d" % (color, ci)] = per[color][0]
+            cases["normals_%s%d" % (color, ci)] = per[color][1]
+        cases["det_color%d" % ci] = np.array([s.color for s in sl.segments], np.uint8)
+        cases["det_pn64_%d" % ci] = np.array([[s.pixels_normalized[0].x, s.pixels_normalized[0].y, s.pixels_normalized[1].x,
+                                               s.pixels_normalized[1].y] for s in sl.segments], np.float64).reshape(n, 4)
+        cases["det_normal64_%d" % ci] = np.array([[s.normal.x, s.normal.y] for s in sl.segments], np.float64).reshape(n, 2)
+        cases["det_wire%d" % ci] = np.frombuffer(ros_serialize(sl, "duckietown_msgs/SegmentList"), np.uint8)
+        # what ground_projection_node receives is the message after the wire: float32 fields
+        rx = SegmentList()
+        rx.header = sl.header
+        for s in sl.segments:
+            t = Segment()
+            t.color = s.color
+            for e in range(2):
+                t.pixels_normalized[e].x = float(np.float32(s.pixels_normalized[e].x))
+                t.pixels_normalized[e].y = float(np.float32(s.pixels_normalized[e].y))
+            t.normal.x, t.normal.y = float(np.float32(s.normal.x)), float(np.float32(s.normal.y))
+            rx.segments.append(t)
+        gnode.lineseglist_cb(rx)
+        gl = gnode.pub_lineseglist_.msg
+        assert len(gl.segments) == n
+        cases["gp_color%d" % ci] = np.array([s.color for s in gl.segments], np.uint8)
+        cases["gp_points%d" % ci] = np.array([[s.points[0].x, s.points[0].y, s.points[0].z, s.points[1].x, s.points[1].y, s.points[1].z]
+                                              for s in gl.segments], np.float64).reshape(n, 6)
+        cases["gp_wire%d" % ci] = np.frombuffer(ros_serialize(gl, "duckietown_msgs/SegmentList"), np.uint8)
+    cases["n_cases"] = np.int32(len(geoms))
+    np.savez_compressed(os.path.join(OUT, "node_pipeline.npz"), **cases)
+    print("node_pipeline:", [int(cases["det_wire%d" % i].size) for i in range(len(geoms))], "wire bytes")
+
+
 if __name__ == "__main__":
+    install_stubs()
+    golden_node_pipeline()
     install_stubs()
     golden_ground_projection()
     golden_find_normal()

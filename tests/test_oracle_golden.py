@@ -88,3 +88,88 @@ def test_ground_projection_matches_reference(golden_dir):
     # the clamp quirk rows of the fixture really exercise it
     assert g["pixel"][3, 1] == 0.0 and 478.9 < g["pixel"][2, 1] <= 479.0          # v just above ch-1 -> 0, just below -> kept
     assert g["pixel"][5, 0] == 639.0 and g["pixel"][6].tolist() == [0.0, 0.0]        # u clamps to cw-1, negatives to 0
+
+
+def _node_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "node_pipeline.npz"))
+    for ci in range(int(g["n_cases"])):
+        yield ci, g
+
+
+def test_normalisation_matches_reference_node(golden_dir):
+    """a-6: LineDetectorNode.processImage_ + toSegmentMsg run from the reference with a fake detector plugin
+    (line_detector_node.py:190-205,251-265).  The oracle's normalisation must give exactly the float32 the message
+    fields take on the wire, in the reference's segment order (white, yellow, red; empty colours skipped)."""
+    import copy
+    from lane_slam_amd.config import default_config
+    from oracle.oracle import Oracle
+    for ci, g in _node_cases(golden_dir):
+        H, W, cut = (int(v) for v in g["geom%d" % ci])
+        cfg = copy.deepcopy(default_config("parity"))
+        cfg["in_size"], cfg["img_size"], cfg["top_cutoff"] = [H, W], [H, W], cut
+        o = Oracle(cfg)
+        pn, nm, col = [], [], []
+        for code, color in enumerate(("white", "yellow", "red")):
+            lines = g["lines_%s%d" % (color, ci)]
+            if len(lines):
+                pn.append(o.normalize_lines(lines))
+                nm.append(g["normals_%s%d" % (color, ci)].astype(np.float32))
+                col.append(np.full(len(lines), code, np.uint8))
+        if not pn:
+            assert g["det_color%d" % ci].size == 0
+            continue
+        pn, nm, col = np.concatenate(pn), np.concatenate(nm), np.concatenate(col)
+        assert np.array_equal(col, g["det_color%d" % ci])
+        assert np.array_equal(pn, g["det_pn64_%d" % ci].astype(np.float32))            # bit-exact float32
+        assert np.array_equal(nm, g["det_normal64_%d" % ci].astype(np.float32))
+        # the float64 the reference computed is (float64(x) + cut) * (1 / size): not x / size
+        x = g["lines_white%d" % ci]
+        if len(x):
+            assert np.array_equal(g["det_pn64_%d" % ci][: len(x), 0], x[:, 0].astype(np.float64) * (1.0 / W))
+
+
+def test_segment_wire_helpers_match_reference_msg_files(golden_dir):
+    """f-2: the bytes of the SegmentList messages the reference's nodes built, serialised in the generator with the
+    field order parsed from the reference's own .msg files (SegmentList.msg, Segment.msg, Vector2D.msg).  The
+    package's wire helpers (header_bytes, SEGMENT_DTYPE, split_segment_list) must describe exactly those bytes, for
+    the detector stage (pixels_normalized + normal, points zero) and the ground stage (points, the rest dropped:
+    ground_projection_node.py:59-63)."""
+    import struct
+    from lane_slam_amd import segment_msgs as sm
+    hdr = sm.header_bytes(7, 1234, 5678, "cam")
+    for ci, g in _node_cases(golden_dir):
+        n = g["det_color%d" % ci].size
+        rec = np.zeros(n, sm.SEGMENT_DTYPE)
+        rec["color"] = g["det_color%d" % ci]
+        rec["pixels_normalized"] = g["det_pn64_%d" % ci].astype(np.float32).reshape(n, 2, 2)
+        rec["normal"] = g["det_normal64_%d" % ci].astype(np.float32)
+        assert g["det_wire%d" % ci].tobytes() == hdr + struct.pack("<I", n) + rec.tobytes()
+        seq, secs, nsecs, fid, body, view = sm.split_segment_list(g["det_wire%d" % ci].tobytes())
+        assert (seq, secs, nsecs, fid) == (7, 1234, 5678, "cam") and not view["points"].any()
+        rec = np.zeros(n, sm.SEGMENT_DTYPE)
+        rec["color"] = g["gp_color%d" % ci]
+        rec["points"] = g["gp_points%d" % ci].reshape(n, 2, 3)
+        assert g["gp_wire%d" % ci].tobytes() == hdr + struct.pack("<I", n) + rec.tobytes()
+        assert np.array_equal(g["gp_color%d" % ci], g["det_color%d" % ci])             # colour travels on, order kept
+        assert not g["gp_points%d" % ci][:, [2, 5]].any()                             # z = 0
+
+
+def test_ground_stage_of_the_node_matches_oracle(golden_dir):
+    """lineseglist_cb (ground_projection_node.py:55-65) on the float32 message fields: the oracle's projection of the
+    same float32 endpoints (rectification = identity on both sides, see test_ground_projection_matches_reference)."""
+    import copy
+    from lane_slam_amd.config import default_config
+    from oracle.oracle import Oracle
+    cfg = copy.deepcopy(default_config("parity"))
+    cfg["K"] = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+    cfg["D"] = [0.0] * 5
+    cfg["R"] = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+    cfg["P"] = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+    o = Oracle(cfg)
+    for ci, g in _node_cases(golden_dir):
+        n = g["det_color%d" % ci].size
+        if not n:
+            continue
+        got = o.ground_project(g["det_pn64_%d" % ci].astype(np.float32))
+        ref = g["gp_points%d" % ci][:, [0, 1, 3, 4]]
+        assert np.allclose(got, ref, rtol=1e-13, atol=1e-16)

@@ -71,6 +71,26 @@ def test_gpu_bodies_match_the_wire_format_and_round_trip():
                 assert np.array_equal(pn, seg.pixels_normalized) and np.array_equal(nm, seg.normals) and not gr.any()
             else:
                 assert np.array_equal(gr, seg.ground) and not pn.any() and not nm.any()
+    # the reference's own nodes' messages (tests/golden/node_pipeline.npz: processImage_ / lineseglist_cb run from the
+    # reference, serialised with the field order of its .msg files): lf_serialize_segments must write those bytes
+    import os
+    from lane_slam_amd.frontend import Segments
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "node_pipeline.npz"))
+    hdr_len = len(sm.header_bytes(7, 1234, 5678, "cam"))
+    for ci in range(int(g["n_cases"])):
+        k = int(g["det_color%d" % ci].size)
+        s2 = Segments()
+        s2.n = k
+        s2.frame_offset = np.array([0, k], np.int32)
+        s2.color = g["det_color%d" % ci]
+        s2.pixels_normalized = g["det_pn64_%d" % ci].astype(np.float32).reshape(k, 4)
+        s2.normals = g["det_normal64_%d" % ci].astype(np.float32).reshape(k, 2)
+        s2.ground = np.ascontiguousarray(g["gp_points%d" % ci].reshape(k, 6)[:, [0, 1, 3, 4]])
+        s2.keep = np.ones(k, np.uint8)
+        body, off = sm.serialize_segments(fe, s2, sm.DETECTOR)
+        assert body.tobytes() == g["det_wire%d" % ci].tobytes()[hdr_len:], ci
+        body, off = sm.serialize_segments(fe, s2, sm.GROUND)
+        assert body.tobytes() == g["gp_wire%d" % ci].tobytes()[hdr_len:], ci
     # a whole message, read back the way a subscriber would
     bodies, off = sm.serialize_segments(fe, seg, sm.GROUND)
     msg = sm.segment_list_message(sm.header_bytes(3, 10, 20, "cam"), bodies[off[2]:off[3]])
