@@ -251,6 +251,10 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         if (w_e >= 0) { w_deg = c.deg[w_e]; w_cs = c.cs[w_e]; w_sn = c.sn[w_e]; }
     }
     LFG_T1(c, 16)
+    const float precf = (float)prec;
+    const float EPSF = 0.0043633f;                        // 0.25 degree
+    const bool bulk_ok = precf < 0.7f && precf > 4.f * EPSF;
+    const float tn_cone = 0.5f * (precf - EPSF), tf_cone = precf + 0.5f * (precf - EPSF) + EPSF;
     for (int i = 0; i < n;) {
         const int m = n - i < 7 ? n - i : 7;
         const bool lv = slot < m;
@@ -273,24 +277,107 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
         const double a = (double)dg * DEG2RAD;
         LFG_T1(c, 13)
+        // The reference tests the candidates one by one, in lane order, each against the running region angle,
+        // which moves with every accepted pixel.  Most decisions do not depend on that order: the running angle
+        // can only move a little while a handful of nearly parallel unit vectors join a sum of many, so a
+        // candidate well inside the tolerance is accepted and one well outside is rejected WHATEVER the order.
+        // Per span (cursor .. first undecided lane) the candidates are therefore split three ways against the
+        // angle R at the span's start, with d = |angle - R| folded to [0, pi]:
+        //   near  d <= Tn        accepted, all at once (list slots by prefix count, USED bits by per-lane atomics,
+        //                        the two float sums by a short ordered chain -- no arc tangent per pixel)
+        //   far   d >  Tf        rejected
+        //   mid   otherwise      undecided: the span ends here, the lane gets the reference's own comparison
+        //                        under the exact angle of that moment, and the rest is classified afresh.
+        // Two valid (Tn, Tf) pairs, the wider near band is taken (EPS covers fastAtan2's 0.011 degree error, the
+        // float sums and this float classification, with a margin of 20x):
+        //   cone       Tn = (prec - EPS) / 2, Tf = prec + Tn + EPS: while only near lanes join, the sum stays
+        //              inside the cone R +- Tn (a cone narrower than pi is closed under addition), so a near lane is
+        //              at most 2 Tn + EPS = prec away from any intermediate angle, a far lane more than prec;
+        //   magnitude  delta = (pi/2) m / max(|sumdx|, |sumdy|) >= asin(m / |S|) bounds how far m unit vectors can
+        //              turn the sum S: Tn = prec - delta - EPS, Tf = prec + delta + EPS, m = candidates within prec.
+        // Duplicates (the same pixel offered by several frontier points of this batch) keep the reference's rule
+        // "first offer wins": inside a span the near lanes are walked in order and every new pixel strikes its later
+        // offers; across spans the USED bits decide, re-read after every bulk accept.
+        const float af = (float)a;
+        const uint32_t key = ((uint32_t)yy << 16) | (uint32_t)xx;
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
-            if ((__ballot(cand) & later) == 0ull) break;  // nobody left to test: skip the f64 alignment pass
-            const unsigned long long hit = __ballot(cand && aligned_val(a, reg_angle, prec)) & later;
-            if (hit == 0ull) break;
-            const int L = __builtin_ctzll(hit);
-            const int eL = rl_i(e, L);
-            const int ay = rl_i(yy, L), ax = rl_i(xx, L);
-            used_set(c, eL);
-            reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
-            ++n;
-            sumdx = (float)((double)sumdx + rl_d(ck, L));
-            sumdy = (float)((double)sumdy + rl_d(sk, L));
-            reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
-            if (e == eL) cand = false;                    // the same pixel seen from a later point is now USED
+            const unsigned long long cb = __ballot(cand) & later;
+            if (cb == 0ull) break;                        // nobody left to test
+            float ad = af - (float)reg_angle;
+            ad = ad < 0.f ? -ad : ad;
+            if (ad > 3.14159265f) ad = 6.28318531f - ad;
+            bool is_near = false, is_mid = true;          // everything undecided = the reference's loop, lane by lane
+            if (bulk_ok) {
+                // division free: ad <= prec - EPS - (pi/2) m / smax  <=>  (ad - prec + EPS) smax + (pi/2) m <= 0
+                const float hm = 1.5707964f * (float)__popcll(__ballot(cand && ad <= precf) & later);
+                const float sx_ = sumdx < 0.f ? -sumdx : sumdx, sy_ = sumdy < 0.f ? -sumdy : sumdy;
+                const float smax = sx_ > sy_ ? sx_ : sy_;
+                if ((precf - EPSF - tn_cone) * smax > hm) {            // the magnitude pair has the wider near band
+                    is_near = (ad - precf + EPSF) * smax + hm <= 0.f;
+                    is_mid = !is_near && !((ad - precf - EPSF) * smax - hm > 0.f);
+                } else {
+                    is_near = ad <= tn_cone;
+                    is_mid = !is_near && ad <= tf_cone;
+                }
+            }
+            const unsigned long long maskM = __ballot(cand && is_mid) & later;
+            const int L = maskM ? __builtin_ctzll(maskM) : 64;
+            const unsigned long long span = later & (L >= 64 ? ~0ull : ((1ull << L) - 1ull));
+            const unsigned long long maskN = __ballot(cand && is_near) & span;
+            if (maskN != 0ull) {
+                // first offer wins inside the span: walk the near lanes in order, each new pixel strikes its later offers
+                unsigned long long maskA = maskN;
+                if (maskN & (maskN - 1ull)) {
+                    for (unsigned long long mm = maskN; mm != 0ull;) {
+                        const int j = __builtin_ctzll(mm);
+                        const unsigned long long same = __ballot(key == (uint32_t)rl_i((int)key, j)) & mm & ~(1ull << j);
+                        maskA &= ~same;
+                        mm &= ~(same | (1ull << j));
+                    }
+                }
+                const bool acc = (maskA >> lane) & 1ull;
+                // region-list slot = n + number of accepted lanes below me
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(maskA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)maskA, 0u));
+                if (acc) {
+                    const int pos = n + below;
+                    if (pos < c.reg_lds) c.lreg[pos] = key; else c.greg[pos] = key;
+                    if (e < c.used_lds) atomicOr(&c.usedc[e >> 5], 1u << (e & 31)); else atomicOr(&c.gused[e >> 5], 1u << (e & 31));
+                }
+                n += __popcll(maskA);
+                // the float sums take the accepted vectors in list order: (float)((double)sum + cos), one by one
+                for (unsigned long long mm = maskA; mm != 0ull; mm &= mm - 1ull) {
+                    const int j = __builtin_ctzll(mm);
+                    sumdx = (float)((double)sumdx + rl_d(ck, j));
+                    sumdy = (float)((double)sumdy + rl_d(sk, j));
+                }
+                reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+                added = true;
+                LFG_CNT(c, 18, __popcll(maskA))
+            }
+            if (L >= 64) break;
+            if (maskN != 0ull) {
+                // later offers of the pixels just accepted are no longer candidates
+                mem_fence();
+                cand = cand && !used_get(c, e);
+            }
+            // the undecided lane: the reference's comparison under the angle of this moment
+            const bool hitL = (__ballot(cand && aligned_val(a, reg_angle, prec)) >> L) & 1ull;
+            if (hitL) {
+                const int eL = rl_i(e, L);
+                const int ay = rl_i(yy, L), ax = rl_i(xx, L);
+                used_set(c, eL);
+                reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
+                ++n;
+                sumdx = (float)((double)sumdx + rl_d(ck, L));
+                sumdy = (float)((double)sumdy + rl_d(sk, L));
+                reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
+                if (e == eL) cand = false;                // the same pixel seen from a later point is now USED
+                added = true;
+                LFG_CNT(c, 19, 1)
+            }
             later = L >= 63 ? 0ull : (~0ull << (L + 1));
-            added = true;
         }
         if (added) mem_fence();
         LFG_T1(c, 14)

@@ -17,7 +17,7 @@ scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
 Ps = scr.shape[2]
 d = scr[:, :, Ps - 64:].copy().view(np.uint64).reshape(n * 3, 32)[:, :27].astype(np.float64)
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
-         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters"] + ["-"] * 6 + ["total", "n_order", "n_lines"]
+         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc"] + ["-"] * 4 + ["total", "n_order", "n_lines"]
 CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
 raw7 = scr[:, :, Ps - 64:].copy().view(np.uint64).reshape(n * 3, 32)[:, 7]
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
