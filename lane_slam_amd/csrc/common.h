@@ -11,6 +11,8 @@ namespace lf {
 constexpr int kMaxKsize = 9;        // dilation structuring element
 constexpr int kMaxGaussTaps = 15;   // LSD Gaussian
 constexpr float kNotDef = -1024.0f; // LSD NOTDEF marker (angle plane, degrees)
+constexpr int kLabelItems = 8192;   // problems up to this many defined pixels are split into connected components
+constexpr int kCompCap = 1024;      // component list entries per problem (more eligible components: one component)
 
 enum Stage {
     ST_PRE = 0, ST_CANNY, ST_HYST, ST_LSD_GRAD, ST_LSD_ORDER, ST_LSD_GROW, ST_SEGMENTS,
@@ -100,9 +102,13 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
                       int* row_start, hipStream_t s);
 void launch_lsd_dense_debug(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const float* c_deg,
                             const double* c_mod, float* ang, double* mod, hipStream_t s);
+void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, hipStream_t s);
+size_t lsd_grow_reg_stride(const LsdParams& p);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
-                     const int* row_start, uint32_t* reg, uint32_t* gused, float* lines, int* counts, hipStream_t s);
+                     const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
+                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, hipStream_t s);
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,

@@ -19,33 +19,43 @@ namespace lf {
 #define LFG_REG_LDS 512
 #endif
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
+constexpr int GROW_WAVES = 4;        // waves per problem: components of the defined-pixel graph are handed out among them
+
+__global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
                                                  const double* __restrict__ c_cs, const double* __restrict__ c_sn,
-                                                 const int* __restrict__ row_start, uint32_t* reg, uint32_t* gused,
-                                                 float* lines, int* counts, int reg_lds, int def_lds)
+                                                 const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
+                                                 const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
+                                                 int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds)
 {
     extern __shared__ uint32_t lds[];
+    __shared__ int next_comp, line_count;
     const int pc = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    // LDS carve: [row starts] [USED bits] [region list] [x lists (u16)]
+    // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
     int* rows = reinterpret_cast<int*>(lds);
     uint32_t* usedc = lds + ((p.Hs + 2) & ~1);
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
-    uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + reg_lds);
+    uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_WAVES * reg_lds);
     const int n_def = norder[pc];
     const uint32_t* gxy = c_xy + (size_t)pc * Ps;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
-    for (int i = lane; i <= p.Hs; i += 64) rows[i] = grs[i];
-    for (int i = lane; i <= ((def_lds + 31) >> 5); i += 64) usedc[i] = 0u;
-    for (int i = lane; i < n_def && i < def_lds; i += 64) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
+    for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
+    for (int i = tid; i <= ((def_lds + 31) >> 5); i += 64 * GROW_WAVES) usedc[i] = 0u;
+    for (int i = tid; i < n_def && i < def_lds; i += 64 * GROW_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
     uint32_t* gu = gused + (size_t)pc * ((Ps + 31) / 32);
     if (n_def > def_lds)
-        for (int i = lane; i < (n_def + 31) / 32; i += 64) gu[i] = 0u;
+        for (int i = tid; i < (n_def + 31) / 32; i += 64 * GROW_WAVES) gu[i] = 0u;
+    if (tid == 0) { next_comp = 0; line_count = 0; }
     __threadfence_block();
     __syncthreads();
+    const int n_comp = comp_count[pc];
+    const uint16_t* clist = comp_list + (size_t)pc * comp_cap;
+    float* tl = tmp_lines + (size_t)pc * p.cap_lines * 4;
+    int* tt = tmp_tags + (size_t)pc * p.cap_lines;
     grow::Ctx c;
     c.W = p.Ws; c.H = p.Hs;
     c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
@@ -54,51 +64,92 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LFG_WAVES)))
     c.cs = c_cs + (size_t)pc * Ps;
     c.sn = c_sn + (size_t)pc * Ps;
     c.usedc = usedc; c.gused = gu; c.used_lds = def_lds;
-    c.lreg = lreg; c.greg = reg + (size_t)pc * Ps; c.reg_lds = reg_lds;
+    // every wave has its own region list: reg_lds entries in LDS, the rest in its slice of the problem's scratch.
+    // Problems too large for k_lsd_label's LDS (> kLabelItems defined pixels) come as ONE component: wave 0 takes it
+    // with the whole scratch, the other waves have nothing to do.
+    const bool single = n_def > kLabelItems;
+    c.lreg = lreg + wave * reg_lds; c.reg_lds = reg_lds;
+    c.greg = reg + (size_t)pc * reg_stride + (single ? (size_t)0 : (size_t)wave * kLabelItems);
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
     c.min_reg_size = p.min_reg_size; c.refine = p.refine;
+    c.label = c_label + (size_t)pc * Ps;
+    c.tags = tt; c.line_count = &line_count;
 #ifdef LFG_STAMPS
     for (int k = 0; k < 24; ++k) c.stamps[k] = 0;
     unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
-    int n = grow::detect(c, order + (size_t)pc * Ps, n_def, lines + (size_t)pc * p.cap_lines * 4, p.cap_lines);
-    if (lane == 0) counts[pc] = n;     // may exceed cap_lines: the host reports LF_ERR_CAPACITY
+    // components largest first (k_lsd_label sorted them), next one to whichever wave is free
+    for (;;) {
+        if (single && wave != 0) break;
+        int k = 0;
+        if (lane == 0) k = atomicAdd(&next_comp, 1);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= n_comp) break;
+        c.root = (int)clist[k];
+        (void)grow::detect(c, order + (size_t)pc * Ps, n_def, tl, p.cap_lines);
+    }
 #ifdef LFG_STAMPS
     if (lane == 0) {
-        // diagnostic: park the phase totals in the (otherwise unused) tail of this problem's region scratch
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reg + (size_t)pc * Ps + Ps - 64);
+        // diagnostic: park the phase totals of every wave in the (otherwise unused) tail of the region scratch
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reg + (size_t)pc * reg_stride + reg_stride - 64 * GROW_WAVES) + 32 * wave;   // 32 u64 per wave
         for (int k = 0; k < 24; ++k) dbg[k] = c.stamps[k];
         dbg[24] = __builtin_readcyclecounter() - tb0;
         dbg[25] = (unsigned long long)norder[pc];
-        dbg[26] = (unsigned long long)n;
+        dbg[26] = (unsigned long long)n_comp;
     }
 #endif
+    // back into the sequential order: a line's place is the number of lines whose seed comes earlier in the seed list
+    __threadfence_block();
+    __syncthreads();
+    const int total = line_count;
+    const int n = total < p.cap_lines ? total : p.cap_lines;
+    float* out = lines + (size_t)pc * p.cap_lines * 4;
+    for (int i = tid; i < n; i += 64 * GROW_WAVES) {
+        const int ti = tt[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += tt[j] < ti ? 1 : 0;
+        const float4 v = *reinterpret_cast<const float4*>(tl + 4 * i);
+        *reinterpret_cast<float4*>(out + 4 * rank) = v;
+    }
+    if (tid == 0) counts[pc] = total;     // may exceed cap_lines: the host reports LF_ERR_CAPACITY
+}
+
+size_t lsd_grow_reg_stride(const LsdParams& p)
+{
+    // region scratch per problem: the whole scaled image for a single-component problem (one wave), or one
+    // slice per wave -- components come from k_lsd_label only for problems of <= 8192 defined pixels
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t need = (size_t)GROW_WAVES * kLabelItems;
+    return Ps > need ? Ps : need;
 }
 
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
-                     const int* row_start, uint32_t* reg, uint32_t* gused, float* lines, int* counts, hipStream_t s)
+                     const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
+                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, hipStream_t s)
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + region-list head.
+    // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.
     const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4;
     // LFG_LDS_KB serves the 640x480 geometries (a few thousand defined pixels per problem).  Larger LSD images
     // (1080p: 1536x576) have proportionally more defined pixels and far fewer problems per batch, so latency
     // matters more than residency: grow the slice with the image (~3 % of the pixels defined), up to 64 KB.
-    size_t budget = LFG_LDS_KB * 1024;
     int reg_lds = LFG_REG_LDS;
+    const size_t regs = (size_t)GROW_WAVES * reg_lds * 4;
+    size_t budget = LFG_LDS_KB * 1024 + regs - (size_t)reg_lds * 4;
     {
-        const size_t want = fixed + (size_t)reg_lds * 4 + 8 + (size_t)((double)Ps * 0.03 * 17.0 / 8.0);
+        const size_t want = fixed + regs + 8 + (size_t)((double)Ps * 0.03 * 17.0 / 8.0);
         if (want > budget) budget = want < (size_t)64 * 1024 ? want : (size_t)64 * 1024;
     }
-    long long left = (long long)budget - (long long)fixed - (long long)reg_lds * 4 - 8;
+    long long left = (long long)budget - (long long)fixed - (long long)regs - 8;
     int def_lds = left > 0 ? (int)(left * 8 / 17) : 0;         // 2 B + 1/8 B per entry
     def_lds &= ~31;
     if ((size_t)def_lds > Ps) def_lds = (int)((Ps + 31) & ~(size_t)31);
-    const size_t lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + (size_t)reg_lds * 4 + (size_t)def_lds * 2 + 8;
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
-                       c_sn, row_start, reg, gused, lines, counts, reg_lds, def_lds);
+    const size_t lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
+                       c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
+                       tmp_tags, lines, counts, reg_lds, def_lds);
 }
 
 }  // namespace lf

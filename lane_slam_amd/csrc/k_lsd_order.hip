@@ -280,6 +280,133 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
                        sort_a, sort_b, order_a, order_b, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K_lsd_label: connected components of a problem's defined pixels (8-adjacency), one workgroup per problem.
+//
+// LSD's region growing moves along 8-adjacent pixels with a defined gradient and looks at nothing but their USED
+// flags (OpenCV lsd.cpp region_grow, restated in lsd_grow.h), so the components of that graph are independent
+// sub-problems: growing them in any order, or at the same time, gives the sequential result as long as each keeps
+// its own seeds in the global seed order.  k_lsd_grow hands the components of a problem to its waves, largest first.
+// A component with fewer pixels than the smallest acceptable region can never yield a segment and is not listed.
+//
+// Union-find in LDS over the compact entries (lock-free: a root is only ever re-parented to a SMALLER index with
+// atomicMin, path halving uses the same atomic, so every write moves a node closer to its final root): each entry is
+// united with its left neighbour and its up-left / up / up-right neighbours (found in the row lists).  The label of a
+// component is its first entry in raster order.
+//   c_label[e]      root of entry e                     (u16; problems of more than kLabelItems entries: all 0)
+//   comp_list[k]    roots of the components with >= min_reg_size pixels, by size descending, root ascending
+//   comp_count      how many
+__device__ __forceinline__ uint32_t uf_find(volatile uint32_t* P, uint32_t x)
+{
+    uint32_t p = P[x];
+    while (p != x) {
+        const uint32_t g = P[p];
+        if (g != p) atomicMin(const_cast<uint32_t*>(&P[x]), g);      // path halving
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void uf_unite(volatile uint32_t* P, uint32_t a, uint32_t b)
+{
+    for (;;) {
+        a = uf_find(P, a);
+        b = uf_find(P, b);
+        if (a == b) return;
+        if (a < b) { const uint32_t t = a; a = b; b = t; }            // a > b: hang a below b
+        const uint32_t old = atomicMin(const_cast<uint32_t*>(&P[a]), b);
+        if (old == a) return;                                          // a was still a root: done
+        a = old;                                                       // somebody re-parented a meanwhile: go on from there
+    }
+}
+
+constexpr int LT = 512;
+
+__global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+                                                  const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
+                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count)
+{
+    extern __shared__ uint32_t dyn_lds[];
+    uint32_t* parent = dyn_lds;                               // [kLabelItems]
+    uint32_t* csize = dyn_lds + kLabelItems;                  // [kLabelItems]
+    uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + 2 * kLabelItems);   // [kLabelItems]
+    __shared__ uint16_t roots[kCompCap];
+    __shared__ int n_roots;
+    const int pc = blockIdx.x, t = threadIdx.x;
+    const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps;
+    const int n = norder[pc];
+    uint16_t* lab = c_label + o;
+    uint16_t* list = comp_list + (size_t)pc * kCompCap;
+    if (n == 0) { if (t == 0) comp_count[pc] = 0; return; }
+    if (n > kLabelItems) {
+        // too large for the LDS tables (1080p problems): one component = the whole problem, as before
+        for (int e = t; e < n; e += LT) lab[e] = 0;
+        if (t == 0) { list[0] = 0; comp_count[pc] = 1; }
+        return;
+    }
+    const int* rs = row_start + (size_t)pc * (p.Hs + 1);
+    for (int e = t; e < n; e += LT) { parent[e] = (uint32_t)e; csize[e] = 0u; xs[e] = (uint16_t)(c_xy[o + e] & 0xffffu); }
+    if (t == 0) n_roots = 0;
+    __syncthreads();
+    for (int e = t; e < n; e += LT) {
+        const uint32_t xy = c_xy[o + e];
+        const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+        if (e > rs[y] && (int)xs[e - 1] == x - 1) uf_unite(parent, (uint32_t)e, (uint32_t)(e - 1));
+        if (y > 0) {
+            int lo = rs[y - 1];
+            const int end = rs[y];
+            int hi = end;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)xs[mid] < x - 1) lo = mid + 1; else hi = mid; }
+            for (int k = lo; k < end && k < lo + 3 && (int)xs[k] <= x + 1; ++k) uf_unite(parent, (uint32_t)e, (uint32_t)k);
+        }
+    }
+    __syncthreads();
+    for (int e = t; e < n; e += LT) {
+        const uint32_t r = uf_find(parent, (uint32_t)e);
+        lab[e] = (uint16_t)r;
+        atomicAdd(&csize[r], 1u);
+    }
+    __syncthreads();
+    const uint32_t minsz = p.min_reg_size > 1 ? (uint32_t)p.min_reg_size : 1u;
+    for (int e = t; e < n; e += LT)
+        if (csize[e] >= minsz) {                       // only roots have a count
+            const int k = atomicAdd(&n_roots, 1);
+            if (k < kCompCap) roots[k] = (uint16_t)e;
+        }
+    __syncthreads();
+    const int C = n_roots;
+    if (C > kCompCap) {
+        // more eligible components than the list holds (tiny min_reg_size): fall back to one component
+        for (int e = t; e < n; e += LT) lab[e] = 0;
+        if (t == 0) { list[0] = 0; comp_count[pc] = 1; }
+        return;
+    }
+    for (int i = t; i < C; i += LT) {
+        const uint32_t ri = roots[i], si = csize[ri];
+        int rank = 0;
+        for (int j = 0; j < C; ++j) {
+            const uint32_t rj = roots[j], sj = csize[rj];
+            rank += (sj > si || (sj == si && rj < ri)) ? 1 : 0;
+        }
+        list[rank] = (uint16_t)ri;
+    }
+    if (t == 0) comp_count[pc] = C;
+}
+
+void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, hipStream_t s)
+{
+    const size_t lds = (size_t)kLabelItems * (4 + 4 + 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count);
+}
+
 // Debug only: dense angle / magnitude planes rebuilt from the compact arrays (NOTDEF / 0 elsewhere).
 __global__ void k_lsd_dense_debug(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                   const float* __restrict__ c_deg, const double* __restrict__ c_mod,

@@ -49,7 +49,7 @@ constexpr double NOTDEF_D = -1024.0;
 
 // ------------------------------------------------------------------ wave primitives
 #ifndef LF_HOST_SIM
-LFG_DEV int lane_id() { return (int)threadIdx.x; }
+LFG_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 LFG_DEV int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 LFG_DEV float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 LFG_DEV double rl_d(double v, int src)
@@ -129,6 +129,15 @@ struct Ctx {
     int reg_lds;
     double log_nt, log_eps, density_th, prec, p, scale;
     int min_reg_size, refine;
+    // Connected components (k_lsd_label): region growing only ever moves along 8-adjacent DEFINED pixels and the
+    // USED flags of other components are never consulted, so every connected component of the defined-pixel graph is
+    // an independent sub-problem whose seeds are the global seed list restricted to it.  A wave works on ONE component
+    // (label == root), several waves of a workgroup share the problem; lines carry their seed's position in the
+    // global list (tag) and are put back into the sequential order afterwards.  label == nullptr: the whole problem.
+    const uint16_t* label;    // HBM  component root of every entry
+    int root;
+    int* tags;                // seed position of every emitted line (HBM), or nullptr
+    int* line_count;          // shared line counter (GPU: LDS, bumped atomically by the workgroup's waves)
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
     mutable unsigned long long stamps[24];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
                                             // 8 seed fetch, 9 regions, 10 region points, 11 grow batches
@@ -929,8 +938,8 @@ LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 }
 
 // ------------------------------------------------------------------ main loop (flsd)
-// order: sorted seed items ((1023-bin) << 20 | compact entry e); returns the number of lines found
-// (may exceed cap; only the first cap are stored).
+// order: sorted seed items ((1023-bin) << 20 | compact entry e); returns the number of lines this call found.
+// Lines go to slot atomicAdd(*c.line_count) while that is below cap, with their seed's position in `order` as tag.
 LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* lines, int cap)
 {
     int n_lines = 0;
@@ -943,9 +952,11 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
     // test per seed.
     for (int base = 0; base < n_order; base += LFG_NL) {
         LFG_T1(c, 0)
-        const bool sv = base + lane_id() < n_order;
+        bool sv = base + lane_id() < n_order;
         const uint32_t seed_items = sv ? order[base + lane_id()] : 0u;
         const int my_e = (int)(seed_items & 0xfffffu);
+        if (sv && c.label) sv = (int)c.label[my_e] == c.root;          // seeds of other components are not ours
+        if (__ballot(sv) == 0ull) continue;
         const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;
         LFG_T1(c, 8)
         unsigned long long pending = ~0ull;
@@ -957,13 +968,16 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         pending = sl >= 63 ? 0ull : (~0ull << (sl + 1));
         const int se = rl_i(my_e, sl);
         const uint32_t sxy = (uint32_t)rl_i((int)seed_xy, sl);
+        const int tag = base + sl;
         LFG_T1(c, 0)
 #else
     for (int i = 0; i < n_order; ++i) {
       {
         const int se = (int)(order[i] & 0xfffffu);
+        if (c.label && (int)c.label[se] != c.root) continue;
         if (used_get(c, se)) continue;
         const uint32_t sxy = c.gxy[se];
+        const int tag = i;
 #endif
         int reg_size;
         double reg_angle;
@@ -989,12 +1003,29 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         if (c.scale != 1) {
             rec.x1 /= c.scale; rec.y1 /= c.scale; rec.x2 /= c.scale; rec.y2 /= c.scale;
         }
-        if (n_lines < cap && lane_id() == 0) {
-            lines[4 * n_lines + 0] = (float)rec.x1;
-            lines[4 * n_lines + 1] = (float)rec.y1;
-            lines[4 * n_lines + 2] = (float)rec.x2;
-            lines[4 * n_lines + 3] = (float)rec.y2;
+#ifndef LF_HOST_SIM
+        if (lane_id() == 0) {
+            const int slot = atomicAdd(c.line_count, 1);          // any order: the tags restore the sequential one
+            if (slot < cap) {
+                lines[4 * slot + 0] = (float)rec.x1;
+                lines[4 * slot + 1] = (float)rec.y1;
+                lines[4 * slot + 2] = (float)rec.x2;
+                lines[4 * slot + 3] = (float)rec.y2;
+                c.tags[slot] = tag;
+            }
         }
+#else
+        {
+            const int slot = c.line_count ? (*c.line_count)++ : n_lines;
+            if (slot < cap) {
+                lines[4 * slot + 0] = (float)rec.x1;
+                lines[4 * slot + 1] = (float)rec.y1;
+                lines[4 * slot + 2] = (float)rec.x2;
+                lines[4 * slot + 3] = (float)rec.y2;
+                if (c.tags) c.tags[slot] = tag;
+            }
+        }
+#endif
         ++n_lines;
         LFG_T1(c, 6)
       }

@@ -12,9 +12,12 @@
 
 using namespace lf;
 
-extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, double prec, double p, double log_nt,
-                             double log_eps, double density_th, double scale, int min_reg_size, int refine,
-                             int n_bins, float* lines, int cap, int reg_lds)
+// by_components != 0: the problem is split into the connected components of its defined pixels (8-adjacency, host
+// BFS here; k_lsd_label on the device), every component of at least min_reg_size pixels is grown on its own --
+// largest first, as k_lsd_grow hands them out -- and the lines are put back in seed order by their tags.
+extern "C" int hs_lsd_detect_ex(const double* scaled, int H, int W, double rho, double prec, double p, double log_nt,
+                                double log_eps, double density_th, double scale, int min_reg_size, int refine,
+                                int n_bins, float* lines, int cap, int reg_lds, int by_components, int* n_components)
 {
     const size_t Ps = (size_t)H * W;
     std::vector<float> ang(Ps, grow::NOTDEF_F);
@@ -70,7 +73,59 @@ extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, dou
     c.lreg = lreg.data(); c.greg = greg.data(); c.reg_lds = reg_lds;
     c.log_nt = log_nt; c.log_eps = log_eps; c.density_th = density_th; c.prec = prec; c.p = p; c.scale = scale;
     c.min_reg_size = min_reg_size; c.refine = refine;
-    return grow::detect(c, order.data(), (int)order.size(), lines, cap);
+    c.label = nullptr; c.root = 0; c.tags = nullptr; c.line_count = nullptr;
+    if (n_components) *n_components = 0;
+    if (!by_components) return grow::detect(c, order.data(), (int)order.size(), lines, cap);
+    // connected components: label = first entry (raster order) of the component
+    std::vector<uint16_t> label(n_def, 0xffff);
+    std::vector<std::pair<int, int>> comps;      // (size, root)
+    auto entry_at = [&](int x, int y) -> int {
+        if (x < 0 || x >= W || y < 0 || y >= H) return -1;
+        for (int e = rows[y]; e < rows[y + 1]; ++e) if ((int)xs[e] == x) return e;
+        return -1;
+    };
+    for (int e0 = 0; e0 < n_def; ++e0) {
+        if (label[e0] != 0xffff) continue;
+        std::vector<int> stack(1, e0);
+        label[e0] = (uint16_t)e0;
+        int size = 0;
+        while (!stack.empty()) {
+            const int e = stack.back(); stack.pop_back(); ++size;
+            const int x = (int)(gxy[e] & 0xffffu), y = (int)(gxy[e] >> 16);
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int q = entry_at(x + dx, y + dy);
+                    if (q >= 0 && label[q] == 0xffff) { label[q] = (uint16_t)e0; stack.push_back(q); }
+                }
+        }
+        if (size >= (min_reg_size > 1 ? min_reg_size : 1)) comps.push_back(std::make_pair(size, e0));
+    }
+    std::sort(comps.begin(), comps.end(), [](const std::pair<int, int>& u, const std::pair<int, int>& v) {
+        return u.first != v.first ? u.first > v.first : u.second < v.second; });
+    if (n_components) *n_components = (int)comps.size();
+    std::vector<float> tl((size_t)cap * 4);
+    std::vector<int> tags(cap);
+    int count = 0;
+    c.label = label.data(); c.tags = tags.data(); c.line_count = &count;
+    for (size_t k = 0; k < comps.size(); ++k) {
+        c.root = comps[k].second;
+        (void)grow::detect(c, order.data(), (int)order.size(), tl.data(), cap);
+    }
+    const int n = count < cap ? count : cap;
+    for (int i = 0; i < n; ++i) {
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += tags[j] < tags[i] ? 1 : 0;
+        for (int k = 0; k < 4; ++k) lines[4 * rank + k] = tl[4 * (size_t)i + k];
+    }
+    return count;
+}
+
+extern "C" int hs_lsd_detect(const double* scaled, int H, int W, double rho, double prec, double p, double log_nt,
+                             double log_eps, double density_th, double scale, int min_reg_size, int refine,
+                             int n_bins, float* lines, int cap, int reg_lds)
+{
+    return hs_lsd_detect_ex(scaled, H, W, rho, prec, p, log_nt, log_eps, density_th, scale, min_reg_size, refine, n_bins, lines,
+                            cap, reg_lds, 0, nullptr);
 }
 
 // host parameters exactly as the product computes them (lanefront_api.hip make_lsd_params)

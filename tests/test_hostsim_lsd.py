@@ -24,10 +24,11 @@ def hostsim():
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.hs_lsd_detect.restype = ctypes.c_int
+    lib.hs_lsd_detect_ex.restype = ctypes.c_int
     return lib
 
 
-def _run(hs, o, ec, reg_lds):
+def _run(hs, o, ec, reg_lds, by_components=False, n_components=None):
     P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
     scaled = o.lsd_scaled_image(ec)
     H, W = scaled.shape
@@ -37,9 +38,12 @@ def _run(hs, o, ec, reg_lds):
     hs.hs_lsd_params(ctypes.c_double(lsd["ang_th"]), ctypes.c_double(lsd["quant"]), H, W, ctypes.byref(rho),
                      ctypes.byref(prec), ctypes.byref(p), ctypes.byref(lognt), ctypes.byref(mrs))
     lines = np.zeros((4096, 4), np.float32)
-    n = hs.hs_lsd_detect(P(scaled), H, W, rho, prec, p, lognt, ctypes.c_double(lsd["log_eps"]),
-                         ctypes.c_double(lsd["density_th"]), ctypes.c_double(lsd["scale"]), mrs, lsd["refine"],
-                         lsd["n_bins"], P(lines), 4096, reg_lds)
+    nc = ctypes.c_int()
+    n = hs.hs_lsd_detect_ex(P(scaled), H, W, rho, prec, p, lognt, ctypes.c_double(lsd["log_eps"]),
+                            ctypes.c_double(lsd["density_th"]), ctypes.c_double(lsd["scale"]), mrs, lsd["refine"],
+                            lsd["n_bins"], P(lines), 4096, reg_lds, int(by_components), ctypes.byref(nc))
+    if n_components is not None:
+        n_components.append(nc.value)
     return lines[:n]
 
 
@@ -58,6 +62,40 @@ def test_product_lsd_logic_matches_oracle(hostsim, oracle_parity):
                 assert got.shape == ref.shape and np.array_equal(got, ref), (seed, c, reg_lds)
             total += len(ref)
     assert total > 50
+
+
+def test_connected_components_are_independent_subproblems(hostsim, oracle_parity, oracle_fullres):
+    """What k_lsd_label / k_lsd_grow rely on: growing every connected component of the defined pixels on its own
+    (largest first, its seeds in global order) and merging the lines by seed position reproduces the sequential
+    detector bit for bit -- on lane frames (a few components each) and on clutter (dozens, most of them too small to
+    matter)."""
+    ncs = []
+    for o, seeds in ((oracle_parity, range(6)), (oracle_fullres, range(2))):
+        for seed in seeds:
+            bgr = o.preprocess(synth.make_frame(seed))
+            bw = o.color_masks(o.bgr2hsv(bgr))
+            edges = o.canny(bgr)
+            for c in range(3):
+                ec = o.dilate(bw[c]) & edges
+                ref = o.lsd(ec)
+                got = _run(hostsim, o, ec, 64, by_components=True, n_components=ncs)
+                assert got.shape == ref.shape and np.array_equal(got, ref), (seed, c)
+    rng = np.random.default_rng(5)
+    o = oracle_parity
+    for t in range(4):
+        img = np.zeros((80, 160), np.uint8)
+        for _ in range(25):
+            y, x = rng.integers(0, 80), rng.integers(0, 160)
+            dy, dx = rng.integers(-6, 7), rng.integers(-25, 26)
+            for s in np.linspace(0, 1, 60):
+                yy, xx = int(y + s * dy + rng.normal(0, 0.6)), int(x + s * dx + rng.normal(0, 0.6))
+                if 0 <= yy < 80 and 0 <= xx < 160:
+                    img[yy, xx] = 255
+        img[rng.random(img.shape) < 0.02] = 255
+        ref = o.lsd(img)
+        got = _run(hostsim, o, img, 64, by_components=True, n_components=ncs)
+        assert got.shape == ref.shape and np.array_equal(got, ref), t
+    assert max(ncs) >= 3 and len(set(ncs)) > 2
 
 
 def test_product_lsd_logic_on_clutter(hostsim, oracle_parity):

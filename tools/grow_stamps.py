@@ -15,11 +15,17 @@ fe.process_batch(frames)
 seg = fe.process_batch(frames)
 scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
 Ps = scr.shape[2]
-d = scr[:, :, Ps - 64:].copy().view(np.uint64).reshape(n * 3, 32)[:, :27].astype(np.float64)
+# four waves per problem, 32 u64 each, in the last 256 words of the problem's region scratch
+raw = scr[:, :, Ps - 256:].copy().view(np.uint64).reshape(n * 3, 4, 32)
+tot_w = raw[:, :, 24].astype(np.float64)
+print("wave totals (kcycles): slowest wave mean %.0f max %.0f | sum over waves mean %.0f | components mean %.1f" % (
+    tot_w.max(1).mean() / 1e3, tot_w.max() / 1e3, tot_w.sum(1).mean() / 1e3, raw[:, 0, 26].mean()))
+slow = tot_w.argmax(1)
+d = raw[np.arange(n * 3), slow][:, :27].astype(np.float64)          # the slowest wave of every problem
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
-         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc"] + ["-"] * 4 + ["total", "n_order", "n_lines"]
+         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc"] + ["-"] * 4 + ["total", "n_order", "n_comp"]
 CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
-raw7 = scr[:, :, Ps - 64:].copy().view(np.uint64).reshape(n * 3, 32)[:, 7]
+raw7 = raw[:, :, 7].sum(1)
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
 order = np.argsort(d[:, 24])
 print("problems", n * 3, "segments", seg.n)
