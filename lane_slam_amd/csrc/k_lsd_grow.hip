@@ -19,7 +19,10 @@ namespace lf {
 #define LFG_REG_LDS 512
 #endif
 
-constexpr int GROW_WAVES = 4;        // waves per problem: components of the defined-pixel graph are handed out among them
+#ifndef LFG_GROW_WAVES
+#define LFG_GROW_WAVES 3
+#endif
+constexpr int GROW_WAVES = LFG_GROW_WAVES;   // waves per problem: components of the defined-pixel graph are handed out among them
 
 __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
                                                  float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds)
 {
     extern __shared__ uint32_t lds[];
-    __shared__ int next_comp, line_count;
+    __shared__ int next_comp, line_count, waves_done;
     const int pc = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     uint32_t* gu = gused + (size_t)pc * ((Ps + 31) / 32);
     if (n_def > def_lds)
         for (int i = tid; i < (n_def + 31) / 32; i += 64 * GROW_WAVES) gu[i] = 0u;
-    if (tid == 0) { next_comp = 0; line_count = 0; }
+    if (tid == 0) { next_comp = 0; line_count = 0; waves_done = 0; }
     __threadfence_block();
     __syncthreads();
     const int n_comp = comp_count[pc];
@@ -99,20 +102,26 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
         dbg[26] = (unsigned long long)n_comp;
     }
 #endif
-    // back into the sequential order: a line's place is the number of lines whose seed comes earlier in the seed list
+    // A wave that has run out of components leaves at once (a wave parked at a barrier would keep its registers and
+    // with them a wave slot of its SIMD); the LAST wave to finish puts the lines back into the sequential order: a
+    // line's place is the number of lines whose seed comes earlier in the seed list.
     __threadfence_block();
-    __syncthreads();
-    const int total = line_count;
+    int done = 0;
+    if (lane == 0) done = atomicAdd(&waves_done, 1);
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != GROW_WAVES - 1) return;
+    __threadfence_block();
+    const int total = *(volatile int*)&line_count;
     const int n = total < p.cap_lines ? total : p.cap_lines;
     float* out = lines + (size_t)pc * p.cap_lines * 4;
-    for (int i = tid; i < n; i += 64 * GROW_WAVES) {
+    for (int i = lane; i < n; i += 64) {
         const int ti = tt[i];
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += tt[j] < ti ? 1 : 0;
         const float4 v = *reinterpret_cast<const float4*>(tl + 4 * i);
         *reinterpret_cast<float4*>(out + 4 * rank) = v;
     }
-    if (tid == 0) counts[pc] = total;     // may exceed cap_lines: the host reports LF_ERR_CAPACITY
+    if (lane == 0) counts[pc] = total;     // may exceed cap_lines: the host reports LF_ERR_CAPACITY
 }
 
 size_t lsd_grow_reg_stride(const LsdParams& p)
