@@ -324,6 +324,9 @@ int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes);
  * which = 0 exp 1 log 2 sin 3 cos 4 atan 5 asin 6 log10 7 sinh_small 8 atan2(a,b) 9 pow(a,b)
  *         10 sqrt 11 a/b 12 fastAtan2(float a, float b) 13 sqrtf 14 float a/b */
 int lf_debug_detmath(lf_handle* h, int which, const double* a, const double* b_or_null, double* y, int n);
+/* counter calibration: stream `bytes` of a scratch buffer `reps` times with `width` (4 / 8 / 12 / 16) bytes per lane
+ * per access (write != 0: stores, 4 or 16); run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` (tools/fetch_probe.py) */
+int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps);
 /* LSD stages alone on a binary image of the handle's working size (non-zero = edge pixel, colour
  * mask forced to all ones); host pointers; lines before normal-based endpoint ordering */
 int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out);

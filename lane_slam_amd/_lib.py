@@ -21,7 +21,7 @@ EXPORTS = (
     "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize", "lf_get_stream",
     "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
     "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
-    "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
+    "lf_debug_fetch", "lf_debug_detmath", "lf_debug_probe", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
     "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
     "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
@@ -93,6 +93,8 @@ def load():
     lib.lf_debug_fetch.argtypes = [vp, ci, vp, ctypes.c_size_t]
     lib.lf_debug_detmath.argtypes = [vp, ci, vp, vp, vp, ci]
     lib.lf_debug_detmath.restype = ci
+    lib.lf_debug_probe.argtypes = [vp, ci, ci, ctypes.c_size_t, ci]
+    lib.lf_debug_probe.restype = ci
     lib.lf_debug_lsd_binary.argtypes = [vp, vp, ci, ci, vp, ci, ctypes.POINTER(ci)]
     lib.lf_debug_lsd_binary.restype = ci
     lib.lf_lsd_size.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]

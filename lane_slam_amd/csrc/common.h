@@ -84,7 +84,7 @@ extern "C" void lf_set_error(lf_handle* h, int code, const char* fmt, ...);
 
 // kernel launchers (one per translation unit)
 namespace lf {
-void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* masks,
+void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* gray,
                 uint32_t* maskbits, const int* sdiv, const int* hdiv, hipStream_t s);
 void launch_canny(const CannyParams& p, const uint32_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
                   hipStream_t s);
@@ -112,9 +112,9 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,
-                     const int* seg_offset, const uint8_t* masks, lf_segments out, int* seg_frame,
+                     const int* seg_offset, const uint32_t* maskbits, int Ww, lf_segments out, int* seg_frame,
                      double* normals64, float* centers, hipStream_t s);
-void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, uint32_t* dxy, hipStream_t s);
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* gray, uint32_t* dxy, hipStream_t s);
 void launch_lbd_split_debug(size_t n, const uint32_t* dxy, int16_t* dx, int16_t* dy, hipStream_t s);
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
                 const uint32_t* dxy, const float* gauss_g, const float* gauss_l,

@@ -31,7 +31,66 @@ __global__ void k_detmath(int which, const double* __restrict__ a, const double*
     y[i] = r;
 }
 
+// Calibration probes for the FETCH_SIZE / WRITE_SIZE counters (MI355X_MICROARCH.md: "other access widths are
+// uncalibrated: calibrate on a known byte count in your own access pattern").  Each kernel streams a buffer of known
+// size once with one of the access shapes the pipeline's kernels use; tools/fetch_probe.py compares the counters of a
+// `rocprofv3 --pmc` pass with the byte count.
+template <int W>      // bytes per lane per access: 4 (dword), 8, 12 (three dwords, k_pre's source rows), 16
+__global__ void k_probe_read(const uint32_t* __restrict__ src, size_t n_words, uint32_t* __restrict__ sink)
+{
+    constexpr int D = W / 4;
+    uint32_t acc = 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * D;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * D; i + D <= n_words; i += stride) {
+        if (D == 1) acc ^= src[i];
+        else if (D == 2) { const uint2 v = *reinterpret_cast<const uint2*>(src + i); acc ^= v.x ^ v.y; }
+        else if (D == 3) { acc ^= src[i] ^ src[i + 1] ^ src[i + 2]; }
+        else { const uint4 v = *reinterpret_cast<const uint4*>(src + i); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;          // keeps the loads alive, practically never taken
+}
+
+template <int W>
+__global__ void k_probe_write(uint32_t* __restrict__ dst, size_t n_words)
+{
+    constexpr int D = W / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * D;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * D; i + D <= n_words; i += stride) {
+        if (D == 1) dst[i] = (uint32_t)i;
+        else *reinterpret_cast<uint4*>(dst + i) = make_uint4((uint32_t)i, 1u, 2u, 3u);
+    }
+}
+
 }  // namespace lf
+
+// stream `bytes` of a scratch buffer `reps` times with the given access shape (width 4 / 8 / 12 / 16 bytes per lane;
+// write != 0: stores, widths 4 and 16 only).  Diagnostic entry for tools/fetch_probe.py.
+extern "C" int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps)
+{
+    if (!h || bytes < 4096 || reps < 1) return LF_ERR_BAD_ARG;
+    uint32_t *buf = nullptr, *sink = nullptr;
+    if (hipMalloc((void**)&buf, bytes) != hipSuccess || hipMalloc((void**)&sink, 256) != hipSuccess) {
+        if (buf) (void)hipFree(buf);
+        lf_set_error(h, LF_ERR_HIP, "lf_debug_probe: hipMalloc failed");
+        return LF_ERR_HIP;
+    }
+    (void)hipMemset(buf, 1, bytes);
+    const size_t nw = bytes / 4;
+    const dim3 grid(256 * 16), block(256);
+    for (int r = 0; r < reps; ++r) {
+        if (write) {
+            if (width == 4) hipLaunchKernelGGL(lf::k_probe_write<4>, grid, block, 0, 0, buf, nw);
+            else hipLaunchKernelGGL(lf::k_probe_write<16>, grid, block, 0, 0, buf, nw);
+        } else if (width == 4) hipLaunchKernelGGL(lf::k_probe_read<4>, grid, block, 0, 0, buf, nw, sink);
+        else if (width == 8) hipLaunchKernelGGL(lf::k_probe_read<8>, grid, block, 0, 0, buf, nw, sink);
+        else if (width == 12) hipLaunchKernelGGL(lf::k_probe_read<12>, grid, block, 0, 0, buf, nw, sink);
+        else hipLaunchKernelGGL(lf::k_probe_read<16>, grid, block, 0, 0, buf, nw, sink);
+    }
+    const hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(buf); (void)hipFree(sink);
+    if (e != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "lf_debug_probe: %s", hipGetErrorString(e)); return LF_ERR_HIP; }
+    return LF_OK;
+}
 
 extern "C" int lf_debug_detmath(lf_handle* h, int which, const double* a, const double* b, double* y, int n)
 {

@@ -6,9 +6,9 @@
 //     :1026-1372 computeLBD   :401-412,653-667 binary code   :74-107 pair table
 //   /root/reference/src/line_descriptor/src/LSDDetector_custom.cpp:73-102,169-197 KeyLine fields
 //
-// k_lbd_grad: 64x16 tile per workgroup; gray (+3 halo, BORDER_REFLECT_101) -> LDS, 5x5
+// k_lbd_grad: 64x16 tile per workgroup; gray plane written by k_pre (+3 halo, BORDER_REFLECT_101) -> LDS, 5x5
 //   fixed-point Gaussian {14,63,103,63,14}/256 twice -> LDS, Sobel -> s16 dx,dy.  Integer exact.
-//   Algorithmic bytes per pixel: 3 read, 4 written.
+//   Algorithmic bytes per pixel (SURVEY 8d K_sobel_lbd): 1 read (gray), 4 written.
 // k_lbd: ONE WAVE PER SEGMENT.  Lane r (< 63) walks row r of the 63 x len support region
 //   with the reference's running float coordinates (rounded per step, clamped), gathering
 //   s16 gradients; the per-row sums are scaled by the global Gaussian, staged in LDS, and
@@ -29,7 +29,7 @@ __device__ __forceinline__ int refl101(int p, int n)
 
 // Four horizontally adjacent outputs per lane in every phase: the LDS tiles are read as dwords /
 // 16-byte vectors with sliding windows instead of one byte (or int) per tap.
-__global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t* __restrict__ bgr,
+__global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* __restrict__ gray_in,
                                                   uint32_t* __restrict__ dxyo)
 {
     constexpr int GW = 72, GH = LT_H + 6;            // gray tile: 70 columns used (x0-3 .. x0+66), rows padded to dwords
@@ -40,18 +40,21 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t*
     __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
     const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H, f = blockIdx.z;
     const int tid = threadIdx.y * 64 + threadIdx.x;
-    const uint32_t* img = bgr + (size_t)f * Hc * W;
-    // gray (BGR2GRAY fixed point), 4 pixels per lane -> one dword store
+    const uint8_t* img = gray_in + (size_t)f * Hc * W;
+    // gray tile from k_pre's 1 byte/pixel plane (BGR2GRAY is done there), 4 pixels per lane -> one dword store.
+    // The tile starts at x0 - 3: interior groups take the two aligned dwords around their four bytes and shift,
+    // groups that touch the image border reflect byte by byte (BORDER_REFLECT_101).
     for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
         const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
         const int gy = refl101(y0 + ty - 3, Hc);
+        const int xa = x0 + 4 * g - 4;                   // aligned dword below the group (W is a multiple of 32)
         uint32_t packed = 0;
+        if (xa >= 0 && xa + 7 < W) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(img + (size_t)gy * W + xa);
+            packed = (q[0] >> 8) | (q[1] << 24);         // bytes xa+1 .. xa+4 = x0 + 4g - 3 .. x0 + 4g
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int gx = refl101(x0 + 4 * g + k - 3, W);
-            const uint32_t q = img[(size_t)gy * W + gx];
-            const uint32_t v = ((q & 255u) * 1868 + ((q >> 8) & 255u) * 9617 + ((q >> 16) & 255u) * 4899 + (1 << 13)) >> 14;
-            packed |= (v & 255u) << (8 * k);
+            for (int k = 0; k < 4; ++k) packed |= (uint32_t)img[(size_t)gy * W + refl101(x0 + 4 * g + k - 3, W)] << (8 * k);
         }
         *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = packed;
     }
@@ -124,10 +127,10 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint32_t*
     }
 }
 
-void launch_lbd_grad(int Hc, int W, int n_frames, const uint32_t* bgr, uint32_t* dxy, hipStream_t s)
+void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* gray, uint32_t* dxy, hipStream_t s)
 {
     dim3 grid((W + LT_W - 1) / LT_W, (Hc + LT_H - 1) / LT_H, n_frames);
-    hipLaunchKernelGGL(k_lbd_grad, grid, dim3(64, 4), 0, s, Hc, W, bgr, dxy);
+    hipLaunchKernelGGL(k_lbd_grad, grid, dim3(64, 4), 0, s, Hc, W, gray, dxy);
 }
 
 __constant__ int c_comb[32][2] = {

@@ -9,10 +9,12 @@
 // tile plus its dilation halo to packed (b,g,r,maskbits) words in LDS (HSV is computed
 // once per pixel, never written to HBM).  Phase 2: each lane owns 4 adjacent pixels,
 // ORs the structuring element over the LDS mask bits and writes 16 B of corrected BGRX (one dword
-// per pixel, so the Canny and LBD stencils load whole pixels)
-// and 4 B per colour plane -- dword stores, fully coalesced -- plus a 1-bit-per-pixel copy of the
-// masks (8 lanes OR their nibbles into one word) that the LSD stage ANDs with the edge bit plane.
-// Algorithmic bytes per working pixel: 3 read + 3 (bgr) + 3 (masks) + 3/8 (mask bits) written.
+// per pixel, so the Canny stencil loads whole pixels), 4 B of gray (BGR2GRAY, 1 byte per pixel: what the LBD
+// gradient stage reads) and the three dilated colour masks as BIT PLANES, 1 bit per pixel (8 lanes OR their
+// nibbles into one word): the LSD stage ANDs them with the edge bit plane, _findNormal tests single bits, and the
+// 0/255 byte form the reference's `Detections.area` wants is expanded from them on demand (k_edges_u8).
+// Algorithmic bytes per working pixel: 3 read + 3 + 3 written; moved: 3 read + 4 (BGRX) + 1 (gray) +
+// 3/8 (mask bits) written.
 #include "common.h"
 
 namespace lf {
@@ -53,7 +55,7 @@ __device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const 
 }
 
 __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t* __restrict__ frames,
-                                                      uint32_t* __restrict__ bgrx_out, uint8_t* __restrict__ masks,
+                                                      uint32_t* __restrict__ bgrx_out, uint8_t* __restrict__ gray_out,
                                                       uint32_t* __restrict__ maskbits, const int* __restrict__ sdiv_g,
                                                       const int* __restrict__ hdiv_g)
 {
@@ -137,7 +139,6 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
         const int gx = x0 + lx, gy = y0 + ly;
         const bool valid = ly < TH && gx < p.W && gy < p.Hc;
         uint32_t px[4] = {0, 0, 0, 0};
-        uint32_t m[3] = {0, 0, 0};
         uint32_t nib[3] = {0, 0, 0};
         if (valid) {
             const uint32_t* ctr = tile + (ly + r) * tw + XO + lx;
@@ -164,9 +165,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                 }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const uint32_t on = (bits >> c) & 1u;
-                    m[c] |= (on ? 0xFFu : 0u) << (8 * k);
-                    nib[c] |= on << k;
+                    nib[c] |= ((bits >> c) & 1u) << k;
                 }
             }
         }
@@ -190,18 +189,23 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
         const size_t pix = (size_t)gy * p.W + gx;
         *reinterpret_cast<uint4*>(bgrx_out + (size_t)f * P + pix) =
             make_uint4(px[0] & 0xFFFFFFu, px[1] & 0xFFFFFFu, px[2] & 0xFFFFFFu, px[3] & 0xFFFFFFu);
-        uint8_t* mo = masks + (size_t)f * 3 * P + pix;
-        *reinterpret_cast<uint32_t*>(mo) = m[0];
-        *reinterpret_cast<uint32_t*>(mo + P) = m[1];
-        *reinterpret_cast<uint32_t*>(mo + 2 * P) = m[2];
+        // BGR2GRAY (fixed point, as cvtColor) of the same four pixels: the 1 byte/pixel plane the LBD gradient stage
+        // reads instead of the 4 byte/pixel working image (binary_descriptor_custom.cpp:350-398 works on gray)
+        uint32_t gq = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t q = px[k];
+            gq |= ((((q & 255u) * 1868u + ((q >> 8) & 255u) * 9617u + ((q >> 16) & 255u) * 4899u + (1u << 13)) >> 14) & 255u) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(gray_out + (size_t)f * P + pix) = gq;
     }
 }
 
-void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* masks,
+void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* gray,
                 uint32_t* maskbits, const int* sdiv, const int* hdiv, hipStream_t s)
 {
     dim3 grid((p.W + TW - 1) / TW, (p.Hc + TH - 1) / TH, n_frames);
-    hipLaunchKernelGGL(k_pre, grid, dim3(PRE_THREADS), 0, s, p, frames, bgr, masks, maskbits, sdiv, hdiv);
+    hipLaunchKernelGGL(k_pre, grid, dim3(PRE_THREADS), 0, s, p, frames, bgr, gray, maskbits, sdiv, hdiv);
 }
 
 }  // namespace lf

@@ -93,7 +93,7 @@ __device__ void ground_point(const SegParams& p, double vx, double vy, double& g
 
 __global__ void k_segments(SegParams p, int n_frames, const float* __restrict__ slot_lines,
                            const int* __restrict__ counts, const int* __restrict__ seg_offset,
-                           const uint8_t* __restrict__ masks, lf_segments out, int* __restrict__ seg_frame,
+                           const uint32_t* __restrict__ maskbits, int Ww, lf_segments out, int* __restrict__ seg_frame,
                            double* __restrict__ normals64, float* __restrict__ centers)
 {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;      // [pc][cap]
@@ -117,8 +117,11 @@ __global__ void k_segments(SegParams p, int n_frames, const float* __restrict__ 
     int x4 = (int)(cx + 3.f * dx), y4 = (int)(cy + 3.f * dy);
     x3 = check_bounds(x3, p.W); y3 = check_bounds(y3, p.Hc);
     x4 = check_bounds(x4, p.W); y4 = check_bounds(y4, p.Hc);
-    const uint8_t* bw = masks + (size_t)pc * p.Hc * p.W;
-    const int sign = (bw[(size_t)y3 * p.W + x3] > 0 && bw[(size_t)y4 * p.W + x4] == 0) ? 1 : -1;
+    // bw = the dilated colour mask, kept as a bit plane (k_pre)
+    const uint32_t* bw = maskbits + (size_t)pc * p.Hc * Ww;
+    const bool on3 = (bw[(size_t)y3 * Ww + (x3 >> 5)] >> (x3 & 31)) & 1u;
+    const bool on4 = (bw[(size_t)y4 * Ww + (x4 >> 5)] >> (x4 & 31)) & 1u;
+    const int sign = (on3 && !on4) ? 1 : -1;
     const double nx = (double)dx * sign, ny = (double)dy * sign;
     const double flag = (double)(x2 - x1) * ny - (double)(y2 - y1) * nx;
     if (flag > 0) { float tx = x1, ty = y1; x1 = x2; y1 = y2; x2 = tx; y2 = ty; }
@@ -172,12 +175,12 @@ __global__ void k_segments(SegParams p, int n_frames, const float* __restrict__ 
 }
 
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,
-                     const int* seg_offset, const uint8_t* masks, lf_segments out, int* seg_frame,
+                     const int* seg_offset, const uint32_t* maskbits, int Ww, lf_segments out, int* seg_frame,
                      double* normals64, float* centers, hipStream_t s)
 {
     const int total = n_frames * 3 * p.cap_lines;
     hipLaunchKernelGGL(k_segments, dim3((total + 255) / 256), dim3(256), 0, s, p, n_frames, slot_lines, counts,
-                       seg_offset, masks, out, seg_frame, normals64, centers);
+                       seg_offset, maskbits, Ww, out, seg_frame, normals64, centers);
 }
 
 }  // namespace lf

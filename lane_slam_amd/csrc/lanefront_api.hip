@@ -57,9 +57,11 @@ struct lf_handle {
     ResizeTables rt;
     int max_nsx = 0, max_nsy = 0;
     // device buffers
-    uint8_t *d_frames = nullptr, *d_masks = nullptr, *d_edges_u8 = nullptr;
+    uint8_t *d_frames = nullptr, *d_edges_u8 = nullptr;
+    DevBuf dbg_masks;                   // 0/255 byte form of the colour masks, expanded from the bit planes on demand
     size_t frames_bytes = 0;            // allocation behind d_frames
     uint32_t* d_bgr = nullptr;          // corrected working image, BGRX dword per pixel
+    uint8_t* d_gray = nullptr;          // BGR2GRAY of it, 1 byte per pixel (read by the LBD gradient stage)
     DevBuf dbg_bgr;
     uint32_t *d_strong = nullptr, *d_weak = nullptr, *d_maskbits = nullptr;
     int *d_sdiv = nullptr, *d_hdiv = nullptr;
@@ -389,7 +391,7 @@ static int alloc_buffers(lf_handle* h)
     // the plugin path (lf_set_image) stages one WORKING image here, which is larger than an input frame when
     // img_size > in_size
     h->frames_bytes = B * in_px * 3 > P * 3 ? B * in_px * 3 : P * 3;
-    if (dalloc(h, &h->d_frames, h->frames_bytes) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_masks, nprob * P) ||
+    if (dalloc(h, &h->d_frames, h->frames_bytes) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_gray, B * P) || 
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) || dalloc(h, &h->d_maskbits, nprob * h->Hc * h->Ww) ||
         dalloc(h, &h->d_raddr, nprob * Ps) || dalloc(h, &h->d_rdeg, nprob * Ps) || dalloc(h, &h->d_rmod, nprob * Ps) ||
         dalloc(h, &h->d_rcs, nprob * Ps) || dalloc(h, &h->d_rsn, nprob * Ps) || dalloc(h, &h->d_nrec, nprob) ||
@@ -436,7 +438,7 @@ extern "C" void lf_destroy(lf_handle* h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = { h->d_frames, h->d_bgr, h->d_masks, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
+    void* ptrs[] = { h->d_frames, h->d_bgr, h->d_gray, h->dbg_masks.p, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
                      h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
@@ -520,7 +522,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         for (int i = 0; i < 3; ++i) { pp.ai_scale[i] = 1.f; pp.ai_shift[i] = 0.f; }
         pp.identity_ai = 1;
     }
-    { StageTimer t(h, ST_PRE); launch_pre(pp, d_frames, n, h->d_bgr, h->d_masks, h->d_maskbits, h->d_sdiv, h->d_hdiv, s); }
+    { StageTimer t(h, ST_PRE); launch_pre(pp, d_frames, n, h->d_bgr, h->d_gray, h->d_maskbits, h->d_sdiv, h->d_hdiv, s); }
     { StageTimer t(h, ST_CANNY); launch_canny(h->canny, h->d_bgr, n, h->d_strong, h->d_weak, s); }
     {
         StageTimer t(h, ST_HYST);
@@ -559,11 +561,11 @@ static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_overflow, 0, sizeof(int), s));
         launch_seg_offsets(n, h->cap_lines, h->d_counts, h->d_seg_offset, dev_out.frame_offset ? dev_out.frame_offset : h->d_frame_offset,
                            h->d_overflow, s);
-        launch_segments(h->seg, n, h->d_slot_lines, h->d_counts, h->d_seg_offset, h->d_masks, dev_out, h->d_seg_frame,
+        launch_segments(h->seg, n, h->d_slot_lines, h->d_counts, h->d_seg_offset, h->d_maskbits, h->Ww, dev_out, h->d_seg_frame,
                         h->d_normals64, h->d_centers, s);
     }
     if (describe) {
-        { StageTimer t(h, ST_LBD_GRAD); launch_lbd_grad(h->Hc, h->W, n, h->d_bgr, h->d_dxy, s); }
+        { StageTimer t(h, ST_LBD_GRAD); launch_lbd_grad(h->Hc, h->W, n, h->d_gray, h->d_dxy, s); }
         {
             StageTimer t(h, ST_LBD);
             int cap = dev_out.capacity < n * 3 * h->cap_lines ? dev_out.capacity : n * 3 * h->cap_lines;
@@ -679,6 +681,10 @@ extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols
     dev.desc = nullptr; dev.code = nullptr;
     rc = run_segments(h, 1, dev, false);
     if (rc != LF_OK) return rc;
+    // Detections.area = the dilated colour mask as 0/255 bytes (line_detector_lsd.py:127-133): expanded once for the
+    // three colours from the bit planes
+    if ((rc = ensure(h, h->dbg_masks, 3 * h->P)) != LF_OK) return rc;
+    launch_edges_u8(h->canny, 3, h->d_maskbits, (uint8_t*)h->dbg_masks.p, s);
     h->h_counts.resize(3); h->h_seg_offset.resize(4);
     LF_HIP_CHECK(h, hipMemcpyAsync(h->h_counts.data(), h->d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipMemcpyAsync(h->h_seg_offset.data(), h->d_seg_offset, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -705,7 +711,7 @@ extern "C" int lf_detect_lines(lf_handle* h, int color, float* lines4, double* n
         if (normals2) LF_HIP_CHECK(h, hipMemcpyAsync(normals2, h->d_normals64 + off * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, s));
         if (centers2) LF_HIP_CHECK(h, hipMemcpyAsync(centers2, h->d_centers + off * 2, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, s));
     }
-    if (area_or_null) LF_HIP_CHECK(h, hipMemcpyAsync(area_or_null, h->d_masks + (size_t)color * h->P, h->P, hipMemcpyDeviceToHost, s));
+    if (area_or_null) LF_HIP_CHECK(h, hipMemcpyAsync(area_or_null, static_cast<uint8_t*>(h->dbg_masks.p) + (size_t)color * h->P, h->P, hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipStreamSynchronize(s));
     *n_out = n;
     return LF_OK;
@@ -850,7 +856,12 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
         launch_bgrx_to_bgr((int)(n * h->P), h->d_bgr, (uint8_t*)h->dbg_bgr.p, s);
         src = h->dbg_bgr.p; avail = n * h->P * 3; break;
     }
-    case LF_BUF_MASKS: src = h->d_masks; avail = n * 3 * h->P; break;
+    case LF_BUF_MASKS: {
+        int rc = ensure(h, h->dbg_masks, n * 3 * h->P);
+        if (rc != LF_OK) return rc;
+        launch_edges_u8(h->canny, (int)(n * 3), h->d_maskbits, (uint8_t*)h->dbg_masks.p, s);     // same bit-plane layout as the edge map
+        src = h->dbg_masks.p; avail = n * 3 * h->P; break;
+    }
     case LF_BUF_EDGES:
         launch_edges_u8(h->canny, (int)n, h->d_strong, h->d_edges_u8, s);
         src = h->d_edges_u8; avail = n * h->P; break;
