@@ -70,6 +70,23 @@ struct ResizeTables {
 
 }  // namespace lf
 
+#ifdef __HIPCC__
+// XCD-aware tile order for the streaming stencil kernels.  Workgroups are dealt to the 8 XCDs round robin by their
+// linear id, and every XCD has its own L2: with the natural order the tiles that share halo rows / 128-byte lines sit
+// on different XCDs and each L2 fetches its own copy.  This maps linear id b to tile (b % 8) * (N / 8) + b / 8, so one
+// XCD walks a contiguous eighth of the tiles (whole frames at the bench's sizes) and shared lines hit in its L2.
+__device__ __forceinline__ void lf_xcd_tile(int& bx, int& by, int& bz)
+{
+    const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
+    unsigned b = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
+    if ((total & 7u) == 0u) b = (b & 7u) * (total >> 3) + (b >> 3);
+    bx = (int)(b % nx);
+    const unsigned r = b / nx;
+    by = (int)(r % ny);
+    bz = (int)(r / ny);
+}
+#endif
+
 #define LF_HIP_CHECK(h, expr)                                                              \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \

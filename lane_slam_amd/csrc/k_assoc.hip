@@ -26,6 +26,7 @@
 //   lowest map index.  Map chunks are spread over gridDim.y and merged with atomicMin on the packed word.
 //   Algorithmic ops: 2*N*M*256 int8.
 // k_assoc_float: 72-d float LBD, Euclidean, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+#include <cstdlib>
 #include "common.h"
 
 namespace lf {
@@ -34,8 +35,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int QB = 2;          // 32-query row blocks per wave
-constexpr int AQ = 128 * QB;   // queries per workgroup (4 waves)
+constexpr int AQ = 512;        // query rows are padded to this (both kernel shapes divide it)
 constexpr int AM = 64;         // map entries per LDS tile
 constexpr int kMaxBlocksPerChunk = 512;   // the in-accumulator block counter t has 9 bits
 
@@ -79,19 +79,23 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* _
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
-                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
-                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
-                                               unsigned int* __restrict__ best)
+// QB = 32-query row blocks per wave.  Two shapes:
+//   QB = 2  256 queries per workgroup, 234 VGPRs, two workgroups per CU (small query counts: more workgroups)
+//   QB = 4  512 queries per workgroup, one wave per SIMD with the whole register file: every B fragment read from LDS
+//           feeds FOUR MFMAs (half the LDS reads and half the LDS-DMA traffic per MFMA, 72 MFMAs between barriers),
+//           and a wave never shares its matrix core with a wave of another workgroup whose barrier phase differs
+template <int QB>
+__device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+                                           const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
+                                           int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
+                                           unsigned int* __restrict__ best, int8_t* tile, int8_t* ctile)
 {
     // nm_bound sized the grid on the host; when the exact size is only known on the device (the live map's size
     // after an update still in flight) it is read here.  Rows in [size, bound) are all-zero operands and are dropped
     // below exactly like padding rows, so the result does not depend on how loose the bound was.
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
-    __shared__ __attribute__((aligned(1024))) int8_t tile[2 * AM * 256];     // double buffered map tile, linear rows
-    __shared__ __attribute__((aligned(1024))) int8_t ctile[2 * AM * 32];     // the tiles' ninth-step operands
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q0 = blockIdx.x * AQ + wave * (32 * QB);
+    const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
     const int r32 = lane & 31, half = lane >> 5;
     // QB row blocks of 32 queries per wave: every B fragment read from LDS feeds QB MFMAs
     v4i A[QB][8], AX[QB];
@@ -138,16 +142,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                              16, 0, 0);
         }
     };
+    // Three buffers, two tiles ahead: with every CU streaming the map through L2 at once a tile takes longer to land
+    // than the 36 MFMAs of one tile last, so the tile needed next was issued TWO tiles ago and the wait at the end of
+    // a tile leaves only the newest tile's pieces (4 per wave, 5 for waves 0 and 1) outstanding.
     if (n_tiles > 0) {
         glds_tile(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (n_tiles > 1) glds_tile(1, 1);
+        if (n_tiles > 1) { if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
     const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    int bcur = 0;
     for (int k = 0; k < n_tiles; ++k) {
-        const int8_t* cur = tile + (k & 1) * (AM * 256);
-        const int8_t* curc = ctile + (k & 1) * (AM * 32);
-        if (k + 1 < n_tiles) glds_tile(k + 1, (k + 1) & 1);     // every wave left that buffer at the last barrier
+        const int8_t* cur = tile + bcur * (AM * 256);
+        const int8_t* curc = ctile + bcur * (AM * 32);
+        const int bnext2 = bcur == 0 ? 2 : bcur - 1;              // (bcur + 2) % 3: the buffer every wave left at the last barrier
+        if (k + 2 < n_tiles) glds_tile(k + 2, bnext2);
         const int t = 2 * k;                                      // 32-column block counter
         v4i Bf[2][8], BX[2];
 #pragma unroll
@@ -176,9 +187,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) running[b][r] = max(running[b][r], acc[b][r]);
         }
-        // the next tile has landed (this wave's pieces) and every wave is done with the current one
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // the next tile has landed (this wave's pieces; the one after it may still be in flight) and every wave is done
+        // with the current one
+        if (k + 2 < n_tiles) { if (wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        bcur = bcur == 2 ? 0 : bcur + 1;
     }
     // key -> (distance, column): 512 * dot = ceil(key / 512) * 512, t = 512 * dot - key; this lane's column inside
     // block t is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
@@ -203,6 +217,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (q < nq) atomicMin(best + q, (unsigned int)v);
             }
         }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
+                                               unsigned int* __restrict__ best)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];     // triple buffered map tile, linear rows
+    __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];     // the tiles' ninth-step operands
+    assoc_body<2>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_assoc4(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
+                                               unsigned int* __restrict__ best)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];
+    __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];
+    assoc_body<4>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
 }
 
 __global__ void k_assoc_finish(const unsigned int* __restrict__ best, int nq, int max_distance, int32_t* __restrict__ idx,
@@ -251,18 +285,38 @@ void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t
 {
     const int nq_pad = (int)assoc_rows_padded_q(nq), nm_pad = (int)assoc_rows_padded_m(nm);
     hipLaunchKernelGGL(k_fill_u32, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, 0x7fffffffu);
-    const int qblocks = nq_pad / AQ;
-    // 2 workgroups are resident per CU: split the map so that the grid is just under two full rounds of the 512
-    // slots -- long chunks amortise the A-fragment loads and the final cross-lane reduction
-    int splits = (2 * 512) / qblocks;
     const int tiles = nm_pad / AM;
     const int min_splits = (nm_pad + (kMaxBlocksPerChunk * 32) - 1) / (kMaxBlocksPerChunk * 32);
-    if (splits < min_splits) splits = min_splits;
-    if (splits > tiles) splits = tiles;
-    if (splits < 1) splits = 1;
-    const int m_chunk = (tiles + splits - 1) / splits * AM;
-    splits = (nm_pad + m_chunk - 1) / m_chunk;
-    hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
+    // Shape: 512-query workgroups (one per CU, QB = 4) once there are enough queries to give every CU a chunk of at
+    // least 16 tiles; below that the 256-query shape, two workgroups per CU.
+    const int qb4 = (nq_pad + 511) / 512;
+    int sp4 = 256 / qb4;
+    if (sp4 < 1) sp4 = 1;
+    // measured on MI355X: the 512-query shape is SLOWER (34 % vs 40 % of the int8 peak at 16 k x 50 k): with one wave per
+    // SIMD nothing covers a wave's LDS reads and barrier waits.  Kept for experiments (LF_ASSOC_QB4=1), not used.
+    static const bool allow_big = getenv("LF_ASSOC_QB4") != nullptr;
+    const bool big = allow_big && qb4 >= 4 && tiles / sp4 >= 16;
+    if (big) {
+        // one round of (at most) 256 workgroups; more query blocks than CUs: whole rounds
+        int splits = sp4;
+        if (splits < min_splits) splits = min_splits;
+        if (splits > tiles) splits = tiles;
+        const int m_chunk = (tiles + splits - 1) / splits * AM;
+        splits = (nm_pad + m_chunk - 1) / m_chunk;
+        hipLaunchKernelGGL(k_assoc4, dim3(qb4, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
+    } else {
+        const int qblocks = nq_pad / 256;
+        // 2 workgroups are resident per CU: split the map so that the grid is just under two full rounds of the 512
+        // slots -- long chunks amortise the A-fragment loads and the final cross-lane reduction
+        static const int slots = getenv("LF_ASSOC_SLOTS") ? atoi(getenv("LF_ASSOC_SLOTS")) : 512;   // one round of two workgroups per CU (measured best: 512 > 1024 > 768)
+        int splits = slots / qblocks;
+        if (splits < min_splits) splits = min_splits;
+        if (splits > tiles) splits = tiles;
+        if (splits < 1) splits = 1;
+        const int m_chunk = (tiles + splits - 1) / splits * AM;
+        splits = (nm_pad + m_chunk - 1) / m_chunk;
+        hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
+    }
     hipLaunchKernelGGL(k_assoc_finish, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, max_distance, idx, dist);
 }
 

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint32_t
     __shared__ uint32_t px[(CT_H + 4) * (CT_W + 4)];
     __shared__ int mag[(CT_H + 2) * (CT_W + 2)];
     __shared__ int gxy[(CT_H + 2) * (CT_W + 2)];
-    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H, f = blockIdx.z;
+    int tbx, tby, f;
+    lf_xcd_tile(tbx, tby, f);
+    const int x0 = tbx * CT_W, y0 = tby * CT_H;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint32_t* img = bgr + (size_t)f * p.Hc * p.W;
     constexpr int PW = CT_W + 4, PH = CT_H + 4, MW = CT_W + 2, MH = CT_H + 2;

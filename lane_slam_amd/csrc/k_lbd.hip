@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* 
     __shared__ __attribute__((aligned(16))) uint8_t gray[GH * GW];
     __shared__ __attribute__((aligned(16))) int rowf[GH * RW];
     __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
-    const int x0 = blockIdx.x * LT_W, y0 = blockIdx.y * LT_H, f = blockIdx.z;
+    int tbx, tby, f;
+    lf_xcd_tile(tbx, tby, f);
+    const int x0 = tbx * LT_W, y0 = tby * LT_H;
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint8_t* img = gray_in + (size_t)f * Hc * W;
     // gray tile from k_pre's 1 byte/pixel plane (BGR2GRAY is done there), 4 pixels per lane -> one dword store.

@@ -290,8 +290,9 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
 // A component with fewer pixels than the smallest acceptable region can never yield a segment and is not listed.
 //
 // Union-find in LDS over the compact entries (lock-free: a root is only ever re-parented to a SMALLER index with
-// atomicMin, path halving uses the same atomic, so every write moves a node closer to its final root): each entry is
-// united with its left neighbour and its up-left / up / up-right neighbours (found in the row lists).  The label of a
+// atomicMin, path halving uses the same atomic, so every write moves a node closer to its final root): horizontal runs
+// of consecutive pixels are linked to their first entry up front, then each entry is united with its up-left / up /
+// up-right neighbours (found in the row lists).  The label of a
 // component is its first entry in raster order.
 //   c_label[e]      root of entry e                     (u16; problems of more than kLabelItems entries: all 0)
 //   comp_list[k]    roots of the components with >= min_reg_size pixels, by size descending, root ascending
@@ -328,9 +329,10 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
                                                   uint16_t* __restrict__ comp_list, int* __restrict__ comp_count)
 {
     extern __shared__ uint32_t dyn_lds[];
+    // 48 KB: three workgroups per CU, i.e. all 768 problems of a 256-frame batch are resident at once
     uint32_t* parent = dyn_lds;                               // [kLabelItems]
-    uint32_t* csize = dyn_lds + kLabelItems;                  // [kLabelItems]
-    uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + 2 * kLabelItems);   // [kLabelItems]
+    uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + kLabelItems);        // [kLabelItems], the union phase's x lists ...
+    uint32_t* csize2 = dyn_lds + kLabelItems;                 // ... then the component sizes, two u16 counters per word
     __shared__ uint16_t roots[kCompCap];
     __shared__ int n_roots;
     const int pc = blockIdx.x, t = threadIdx.x;
@@ -346,13 +348,23 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
         return;
     }
     const int* rs = row_start + (size_t)pc * (p.Hs + 1);
-    for (int e = t; e < n; e += LT) { parent[e] = (uint32_t)e; csize[e] = 0u; xs[e] = (uint16_t)(c_xy[o + e] & 0xffffu); }
+    for (int e = t; e < n; e += LT) xs[e] = (uint16_t)(c_xy[o + e] & 0xffffu);
     if (t == 0) n_roots = 0;
+    __syncthreads();
+    // horizontal runs first, without atomics: every entry starts as a child of the first entry of its run of
+    // consecutive x (a forest of depth one whose roots are the smallest indices), so the union phase below only has
+    // to stitch runs of adjacent rows together
+    for (int e = t; e < n; e += LT) {
+        const int y = (int)(c_xy[o + e] >> 16);
+        const int first = rs[y];
+        int h = e;
+        while (h > first && (int)xs[h - 1] + 1 == (int)xs[h]) --h;
+        parent[e] = (uint32_t)h;
+    }
     __syncthreads();
     for (int e = t; e < n; e += LT) {
         const uint32_t xy = c_xy[o + e];
         const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-        if (e > rs[y] && (int)xs[e - 1] == x - 1) uf_unite(parent, (uint32_t)e, (uint32_t)(e - 1));
         if (y > 0) {
             int lo = rs[y - 1];
             const int end = rs[y];
@@ -362,15 +374,18 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
         }
     }
     __syncthreads();
+    for (int i = t; i < (n + 1) / 2; i += LT) csize2[i] = 0u;     // the x lists are no longer needed
+    __syncthreads();
     for (int e = t; e < n; e += LT) {
         const uint32_t r = uf_find(parent, (uint32_t)e);
         lab[e] = (uint16_t)r;
-        atomicAdd(&csize[r], 1u);
+        atomicAdd(&csize2[r >> 1], 1u << (16 * (r & 1u)));        // counts stay below 2^16 (n <= 8192): no carry between the halves
     }
     __syncthreads();
+    auto csize = [&](uint32_t r) -> uint32_t { return (csize2[r >> 1] >> (16 * (r & 1u))) & 0xffffu; };
     const uint32_t minsz = p.min_reg_size > 1 ? (uint32_t)p.min_reg_size : 1u;
     for (int e = t; e < n; e += LT)
-        if (csize[e] >= minsz) {                       // only roots have a count
+        if (csize((uint32_t)e) >= minsz) {                       // only roots have a count
             const int k = atomicAdd(&n_roots, 1);
             if (k < kCompCap) roots[k] = (uint16_t)e;
         }
@@ -383,10 +398,10 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
         return;
     }
     for (int i = t; i < C; i += LT) {
-        const uint32_t ri = roots[i], si = csize[ri];
+        const uint32_t ri = roots[i], si = csize(ri);
         int rank = 0;
         for (int j = 0; j < C; ++j) {
-            const uint32_t rj = roots[j], sj = csize[rj];
+            const uint32_t rj = roots[j], sj = csize(rj);
             rank += (sj > si || (sj == si && rj < ri)) ? 1 : 0;
         }
         list[rank] = (uint16_t)ri;
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
 void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
                       uint16_t* c_label, uint16_t* comp_list, int* comp_count, hipStream_t s)
 {
-    const size_t lds = (size_t)kLabelItems * (4 + 4 + 2);
+    const size_t lds = (size_t)kLabelItems * (4 + 2);
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

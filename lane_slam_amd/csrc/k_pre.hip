@@ -66,7 +66,9 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
     __shared__ uint8_t boxes[3 * 256];           // boxes[ch*256 + value] bit k: lo[k][ch] <= value <= hi[k][ch]
     const int r = p.r;
     const int th = TH + 2 * r;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
+    int tbx, tby, f;
+    lf_xcd_tile(tbx, tby, f);
+    const int x0 = tbx * TW, y0 = tby * TH;
     const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
     sdiv[threadIdx.x] = sdiv_g[threadIdx.x];
     hdiv[threadIdx.x] = hdiv_g[threadIdx.x];

@@ -1,35 +1,45 @@
 #!/usr/bin/env python3
 """Associator stress (BASELINE configs[4]): exact Hamming nearest neighbour of N 256-bit query codes in an M-code
-map on the int8 MFMA path, device resident; reports time and 2*N*M*256 ops/s against the dense int8 peak.
+live map (lane_slam_amd.LineAssociator: the map's int8 operands stay packed on the device), int8 MFMA path; reports the
+per-call time of the association (HIP events on the map's stream) and 2*N*M*256 ops/s against the dense int8 peak.
 
-    python tools/assoc_rate.py [--pairs 4096x50000,16384x50000,65536x50000,65536x262144]
+    python tools/assoc_rate.py [--pairs 4096x50000,16384x50000,65536x50000,65536x262144] [--gating]
 """
-import argparse, os, sys, time
+import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lane_slam_amd import FrontEnd, default_config, synth
+from lane_slam_amd import LineAssociator, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", default="4096x50000,16384x50000,65536x50000,65536x262144")
+ap.add_argument("--gating", action="store_true", help="colour-gated association (same kernel, colour terms in the ninth MFMA step)")
+ap.add_argument("--reps", type=int, default=20)
 args = ap.parse_args()
 torch.cuda.init()
-fe = FrontEnd(default_config("parity"), max_frames=1, max_lines_per_color=16)
 PEAK = 5.0e15
 for pair in args.pairs.split(","):
     n, m = (int(v) for v in pair.split("x"))
+    am = LineAssociator(capacity=max(64, m), color_gating=args.gating, kept_only=False)
+    rng = np.random.default_rng(3)
+    am.seed(synth.random_codes(m, 2), rng.integers(0, 3, m).astype(np.uint8))
     q = torch.from_numpy(synth.random_codes(n, 1)).cuda()
-    mp = torch.from_numpy(synth.random_codes(m, 2)).cuda()
+    qc = torch.from_numpy(rng.integers(0, 3, n).astype(np.uint8)).cuda()
     idx = torch.zeros(n, dtype=torch.int32, device="cuda")
     dist = torch.zeros(n, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
     for _ in range(3):
-        fe.associate_device(q.data_ptr(), n, mp.data_ptr(), m, idx.data_ptr(), dist.data_ptr())
-    fe.synchronize()
-    t0 = time.perf_counter()
-    reps = 10
-    for _ in range(reps):
-        fe.associate_device(q.data_ptr(), n, mp.data_ptr(), m, idx.data_ptr(), dist.data_ptr())
-    fe.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+        am.associate_device(None, q.data_ptr(), qc.data_ptr(), n, idx.data_ptr(), dist.data_ptr())
+    am.synchronize()
+    am.timing()
+    am.set_profiling(True)
+    for _ in range(args.reps):
+        am.associate_device(None, q.data_ptr(), qc.data_ptr(), n, idx.data_ptr(), dist.data_ptr())
+    am.synchronize()
+    t = am.timing()
+    core = t["assoc_mfma"][0] / t["assoc_mfma"][1]
+    pack = t["assoc_pack_queries"][0] / t["assoc_pack_queries"][1]
     ops = 2.0 * n * m * 256
-    print("N=%6d M=%7d: %.3f ms  %.2f Pop/s  (%.0f %% of the dense int8 MFMA peak), incl. the +-64 packing of both sides" % (n, m, dt * 1e3, ops / dt / 1e15, 100 * ops / dt / PEAK))
+    print("N=%6d M=%7d%s: assoc %.4f ms (+ query pack %.4f ms)  %.2f Pop/s  (%.1f %% of the dense int8 MFMA peak)"
+          % (n, m, " gated" if args.gating else "", core, pack, ops / (core * 1e-3) / 1e15, 100 * ops / (core * 1e-3) / PEAK))
+    am.close()

@@ -1,12 +1,19 @@
+# One profiling round on the GPU box: bash tools/profile_round.sh <tag>   (results under gpurun_out/<tag>/)
 set -x
 R=$GRAFT_REPO_ROOT
-T=${1:-r1f}; mkdir -p $R/gpurun_out/$T
+T=${1:-r02a}; mkdir -p $R/gpurun_out/$T
 python -m pytest tests -m gpu -x -q > $R/gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?"
-python bench.py --steps 30 --warmup 6 > $R/gpurun_out/$T/bench_n1.json 2> $R/gpurun_out/$T/bench_n1.err
+python bench.py > $R/gpurun_out/$T/bench_n1.json 2> $R/gpurun_out/$T/bench_n1.err
+python tools/assoc_rate.py > $R/gpurun_out/$T/assoc_rate.txt 2>&1
+python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/d3 -- python3 $R/bench.py --steps 9 --warmup 3 --cpu-frames -1 > $R/gpurun_out/$T/bench_d3_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/d1 -- python3 $R/bench.py --steps 6 --warmup 2 --cpu-frames -1 --depth 1 > $R/gpurun_out/$T/bench_d1_rocprof.json 2>/dev/null
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$T/pw -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames -1 --depth 1 > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$T/pf -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-frames -1 --depth 1 > /dev/null 2>&1
-find $R/gpurun_out/$T -name "*.csv" | head -30
-tail -3 $R/gpurun_out/$T/pytest.log; cat $R/gpurun_out/$T/bench_n1.json
+B="--secondary none --cpu-frames -1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/d6 -- python3 $R/bench.py --steps 12 --warmup 4 $B > $R/gpurun_out/$T/bench_d6_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/d1 -- python3 $R/bench.py --steps 6 --warmup 2 $B --depth 1 > $R/gpurun_out/$T/bench_d1_rocprof.json 2>/dev/null
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$T/pw -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$T/pf -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/$T/pa -- python3 $R/tools/assoc_rate.py --pairs 16384x50000 --reps 5 > /dev/null 2>&1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/$T/pg -- python3 $R/tools/assoc_rate.py --pairs 16384x50000 --reps 5 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/as -- python3 $R/tools/assoc_rate.py --pairs 4096x50000,16384x50000 --reps 5 > /dev/null 2>&1
+find $R/gpurun_out/$T -name "*.csv" | head -40
+tail -3 $R/gpurun_out/$T/pytest.log; cat $R/gpurun_out/$T/assoc_rate.txt; tail -c 3000 $R/gpurun_out/$T/bench_n1.json
