@@ -16,6 +16,14 @@
  * (src/line_detector/src/line_detector_node.py:129-139).
  * There is no CPU fallback: without a HIP device lf_create fails with
  * LF_ERR_HIP.
+ *
+ * OpenCV version.  The reference calls cv2 for resize, convertScaleAbs, BGR2HSV, inRange, dilate, Canny, the line
+ * segment detector, GaussianBlur, Sobel, BGR2GRAY and (through image_geometry) undistortPoints without pinning a
+ * version (src/line_descriptor/CMakeLists.txt:17 `find_package(OpenCV 3 REQUIRED)`).  The arithmetic restated here is
+ * that of OpenCV 3.0 - 3.3 as ROS Kinetic / Melodic ship it (the f64 LSD with REFINE_ADV; 8-bit fixed-point HSV; the
+ * 5x5 sigma-1 8-bit Gaussian taps {14, 63, 103, 63, 14} / 256).  OpenCV >= 3.4.7 / 4.1.1 changed the 8-bit Gaussian
+ * taps, OpenCV >= 4.0 builds without the LSD; results against such a cv2 differ.  No real OpenCV exists in the build
+ * image, so these stages are "parity unpinned" (DESIGN.md section 2).
  */
 #ifndef LANEFRONT_H
 #define LANEFRONT_H

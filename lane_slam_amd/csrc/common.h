@@ -72,18 +72,25 @@ struct ResizeTables {
 
 #ifdef __HIPCC__
 // XCD-aware tile order for the streaming stencil kernels.  Workgroups are dealt to the 8 XCDs round robin by their
-// linear id, and every XCD has its own L2: with the natural order the tiles that share halo rows / 128-byte lines sit
-// on different XCDs and each L2 fetches its own copy.  This maps linear id b to tile (b % 8) * (N / 8) + b / 8, so one
-// XCD walks a contiguous eighth of the tiles (whole frames at the bench's sizes) and shared lines hit in its L2.
+// linear id, and every XCD has its own L2: in the natural order the tiles of one tile ROW -- which share the 128-byte
+// lines their left / right halos straddle (a 64-pixel row segment of a 1 byte/pixel plane is half a line) -- sit on
+// different XCDs and each L2 fetches its own copy.  Here the 8 XCDs take the 8 tile rows of a group of 8 * nx
+// consecutive ids, one whole row each: lines are shared inside an L2, while the chip as a whole still sweeps the frames
+// in order (handing each XCD a contiguous eighth of ALL tiles made the fetched bytes equal the algorithmic ones but
+// cost 3-10 % of kernel time).
 __device__ __forceinline__ void lf_xcd_tile(int& bx, int& by, int& bz)
 {
     const unsigned nx = gridDim.x, ny = gridDim.y, total = nx * ny * gridDim.z;
     unsigned b = blockIdx.x + nx * (blockIdx.y + ny * blockIdx.z);
-    if ((total & 7u) == 0u) b = (b & 7u) * (total >> 3) + (b >> 3);
+    const unsigned group = 8u * nx;
+    if (b < total / group * group) {
+        const unsigned g = b / group, r = b - g * group;
+        b = g * group + (r & 7u) * nx + (r >> 3);
+    }
     bx = (int)(b % nx);
-    const unsigned r = b / nx;
-    by = (int)(r % ny);
-    bz = (int)(r / ny);
+    const unsigned q = b / nx;
+    by = (int)(q % ny);
+    bz = (int)(q / ny);
 }
 #endif
 
@@ -142,7 +149,7 @@ size_t assoc_rows_padded_m(int nm);
 void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
                        int8_t* cx, hipStream_t s);
 void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
-                       const int* nm_dev, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
+                       const int* nm_dev, int gating, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,
                   unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);

@@ -84,7 +84,7 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* _
 //   QB = 4  512 queries per workgroup, one wave per SIMD with the whole register file: every B fragment read from LDS
 //           feeds FOUR MFMAs (half the LDS reads and half the LDS-DMA traffic per MFMA, 72 MFMAs between barriers),
 //           and a wave never shares its matrix core with a wave of another workgroup whose barrier phase differs
-template <int QB>
+template <int QB, bool GATED>
 __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
                                            const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                            int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
@@ -104,8 +104,12 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
 #pragma unroll
         for (int s = 0; s < 8; ++s)
             A[b][s] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + 32 * b + r32) * 256 + 32 * s + 16 * half);
-        AX[b] = *reinterpret_cast<const v4i*>(qcx + (size_t)(q0 + 32 * b + r32) * 32 + 16 * half);
+        if (GATED) AX[b] = *reinterpret_cast<const v4i*>(qcx + (size_t)(q0 + 32 * b + r32) * 32 + 16 * half);
     }
+    // Without colour gating the ninth MFMA step is not needed at all: the block counter enters as the chain's START
+    // value (the C operand of the first MFMA), a register set that is decremented once per block -- 16 vector adds
+    // that issue beside the MFMAs instead of one more MFMA per accumulator (8 instead of 9 matrix steps per block).
+    v16i negt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     // Arg-max inside the matrix core (see the header): after the chain of 9 MFMAs the accumulator holds
     // key = 512 * dot - t - colour penalty, so the whole epilogue is ONE v_max per accumulator register: no zeroing
     // (the chain starts from the inline constant 0), no packing, no select.  dot and t are recovered from the key at
@@ -135,7 +139,7 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
                                              (__attribute__((address_space(3))) void*)(tile + buf * (AM * 256) + piece * 1024),
                                              16, 0, 0);
         }
-        if (wave < 2) {
+        if (GATED && wave < 2) {
             const int8_t* src = mcx + (size_t)(m_begin + k * AM) * 32 + (size_t)(wave * 64 + lane) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(ctile + buf * (AM * 32) + wave * 1024),
@@ -148,7 +152,7 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
     if (n_tiles > 0) {
         glds_tile(0, 0);
         if (n_tiles > 1) glds_tile(1, 1);
-        if (n_tiles > 1) { if (wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        if (n_tiles > 1) { if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -168,20 +172,31 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
                 const int row = cb * 32 + r32, c = 2 * s + half;
                 Bf[cb][s] = *reinterpret_cast<const v4i*>(cur + row * 256 + ((c ^ (row & 15)) << 4));
             }
-            BX[cb] = *reinterpret_cast<const v4i*>(curc + (cb * 32 + r32) * 32 + 16 * half);
+            if (GATED) BX[cb] = *reinterpret_cast<const v4i*>(curc + (cb * 32 + r32) * 32 + 16 * half);
         }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            const int tt = t + cb;
-            const unsigned tbytes = ((unsigned)(-(tt >> 4)) & 0xffu) | (((unsigned)(-(tt & 15)) & 0xffu) << 8);
-            BX[cb][0] |= (int)(tbytes & tmask);
             v16i acc[QB];
+            if (GATED) {
+                const int tt = t + cb;
+                const unsigned tbytes = ((unsigned)(-(tt >> 4)) & 0xffu) | (((unsigned)(-(tt & 15)) & 0xffu) << 8);
+                BX[cb][0] |= (int)(tbytes & tmask);
 #pragma unroll
-            for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX[b], BX[cb], zero, 0, 0, 0);
+                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX[b], BX[cb], zero, 0, 0, 0);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+                for (int s = 0; s < 8; ++s)
 #pragma unroll
-                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[cb][s], acc[b], 0, 0, 0);
+                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[cb][s], acc[b], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][0], Bf[cb][0], negt, 0, 0, 0);
+#pragma unroll
+                for (int s = 1; s < 8; ++s)
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[cb][s], acc[b], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) negt[r] -= 1;
+            }
 #pragma unroll
             for (int b = 0; b < QB; ++b)
 #pragma unroll
@@ -189,7 +204,7 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
         }
         // the next tile has landed (this wave's pieces; the one after it may still be in flight) and every wave is done
         // with the current one
-        if (k + 2 < n_tiles) { if (wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
+        if (k + 2 < n_tiles) { if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         bcur = bcur == 2 ? 0 : bcur + 1;
@@ -226,7 +241,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];     // triple buffered map tile, linear rows
     __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];     // the tiles' ninth-step operands
-    assoc_body<2>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
+    assoc_body<2, true>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
+}
+
+// the same without colour gating: 8 MFMA steps per block, no ninth-step operands streamed
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_plain(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
+                                               unsigned int* __restrict__ best)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];
+    assoc_body<2, false>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, nullptr);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_assoc4(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
@@ -236,7 +261,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];
     __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];
-    assoc_body<4>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
+    assoc_body<4, true>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
 }
 
 __global__ void k_assoc_finish(const unsigned int* __restrict__ best, int nq, int max_distance, int32_t* __restrict__ idx,
@@ -281,7 +306,7 @@ void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, in
 // association of packed queries against a packed map (the live map keeps its side packed across calls;
 // lf_associate packs its caller's raw map first)
 void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
-                       const int* nm_dev, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+                       const int* nm_dev, int gating, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
 {
     const int nq_pad = (int)assoc_rows_padded_q(nq), nm_pad = (int)assoc_rows_padded_m(nm);
     hipLaunchKernelGGL(k_fill_u32, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, 0x7fffffffu);
@@ -315,7 +340,8 @@ void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t
         if (splits < 1) splits = 1;
         const int m_chunk = (tiles + splits - 1) / splits * AM;
         splits = (nm_pad + m_chunk - 1) / m_chunk;
-        hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
+        if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
+        else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
     }
     hipLaunchKernelGGL(k_assoc_finish, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, max_distance, idx, dist);
 }
@@ -325,7 +351,7 @@ void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx
 {
     launch_assoc_pack(m, nullptr, 1, 0, nm, (int)assoc_rows_padded_m(nm), mx, mcx, s);
     launch_assoc_pack(q, nullptr, 0, 0, nq, (int)assoc_rows_padded_q(nq), qx, qcx, s);
-    launch_assoc_core(qx, qcx, nq, mx, mcx, nm, nullptr, 128, best, idx, dist, s);
+    launch_assoc_core(qx, qcx, nq, mx, mcx, nm, nullptr, 0, 128, best, idx, dist, s);
 }
 
 // ---------------------------------------------------------------- float LBD (72-d)

@@ -378,7 +378,7 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
         {
             MapTimer t(m, 1);
             launch_assoc_core(static_cast<const int8_t*>(m->qx.p), static_cast<const int8_t*>(m->qcx.p), n, m->d.mx, m->d.mcx, size,
-                              m->d.state, m->cfg.max_distance, static_cast<unsigned int*>(m->best.p), didx, ddist, s);
+                              m->d.state, m->cfg.color_gating, m->cfg.max_distance, static_cast<unsigned int*>(m->best.p), didx, ddist, s);
         }
     }
     MAP_HIP(m, hipGetLastError());

@@ -347,6 +347,37 @@ def test_plugin_handles_changing_image_size():
         assert np.array_equal(d.lines, ol) and np.array_equal(d.normals, on)
 
 
+def test_set_image_on_an_upscaling_handle():
+    """lf_set_image takes the WORKING image (img_size - top_cutoff rows); on a handle whose working image is larger
+    than its input frames (img_size > in_size, nearest-neighbour upscaling) the staging buffer must still hold it
+    (it used to be sized from the input frame only and the copy ran past its end)."""
+    from oracle.oracle import Oracle
+    import ctypes
+    cfg = default_config("parity")
+    cfg["in_size"] = [120, 160]
+    cfg["img_size"] = [480, 640]
+    cfg["top_cutoff"] = 160
+    fe = FrontEnd(cfg, max_frames=1, max_lines_per_color=2048)
+    assert (fe.rows, fe.cols) == (320, 640)
+    o = Oracle(default_config("fullres"))
+    work = o.preprocess(synth.make_frame(11))                   # a 320 x 640 working image
+    fe._check(fe.lib.lf_set_image(fe.h, work.ctypes.data_as(ctypes.c_void_p), 320, 640, work.strides[0]))
+    lines = np.empty((2048, 4), np.float32)
+    n = ctypes.c_int()
+    area = np.empty((320, 640), np.uint8)
+    fe._check(fe.lib.lf_detect_lines(fe.h, 0, lines.ctypes.data_as(ctypes.c_void_p), None, None, area.ctypes.data_as(ctypes.c_void_p),
+                                     2048, ctypes.byref(n)))
+    bw = o.dilate(o.color_masks(o.bgr2hsv(work))[0])
+    ol, on, oc = o.find_normals(bw, o.lsd(bw & o.canny(work)))
+    assert np.array_equal(area, bw) and np.array_equal(lines[: n.value], ol) and n.value > 3
+    # and the batch path of the same handle upscales its 120 x 160 frames (nearest neighbour) like the oracle
+    small = np.ascontiguousarray(synth.make_frame(12)[::4, ::4])
+    seg = fe.process_batch(small[None])
+    r = Oracle(cfg).process_frame(small)
+    assert seg.n == r["n"] and np.array_equal(seg.lines, r["lines"]) and np.array_equal(seg.code, r["code"])
+    fe.close()
+
+
 def test_1080p_geometry_matches_oracle():
     """BASELINE config 5 geometry: 1920x1080 frames, img_size [1080,1920], top_cutoff 360 -> 1920x720
     working image (bit planes exceed one CU's LDS: HBM-resident hysteresis, whole-CU LSD problems)."""
