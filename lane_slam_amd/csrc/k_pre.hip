@@ -40,6 +40,11 @@ __device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const 
     }
     const int b = c[0], g = c[1], r = c[2];
     int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    // Every inRange box needs its V interval first: a pixel whose V (= max channel) lies in none of them is in no mask
+    // whatever its hue and saturation are, and those are the expensive part (two table divisions).  On road images most
+    // pixels are dark asphalt, so whole waves leave here.
+    const int in_v = boxes[512 + v];
+    if (in_v == 0) return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
     int diff = v - vmin;
     int vr = v == r ? -1 : 0;
     int vg = v == g ? -1 : 0;
@@ -49,7 +54,7 @@ __device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const 
     h += h < 0 ? 180 : 0;
     h = min(max(h, 0), 255);
     // inRange against the 4 HSV boxes: per-channel acceptance masks (bit k = box k) from LDS tables
-    const int in4 = boxes[h] & boxes[256 + s] & boxes[512 + v];
+    const int in4 = boxes[h] & boxes[256 + s] & in_v;
     const int bits = (in4 & 3) | (((in4 >> 2) | (in4 >> 3)) & 1) << 2;       // white, yellow, red = red1 | red2
     return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | ((uint32_t)bits << 24);
 }
@@ -66,9 +71,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
     __shared__ uint8_t boxes[3 * 256];           // boxes[ch*256 + value] bit k: lo[k][ch] <= value <= hi[k][ch]
     const int r = p.r;
     const int th = TH + 2 * r;
-    int tbx, tby, f;
-    lf_xcd_tile(tbx, tby, f);
-    const int x0 = tbx * TW, y0 = tby * TH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
     const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
     sdiv[threadIdx.x] = sdiv_g[threadIdx.x];
     hdiv[threadIdx.x] = hdiv_g[threadIdx.x];

@@ -542,7 +542,9 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         StageTimer t(h, ST_LSD_ORDER);
         launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, s);
     }
-    {
+    static const char* diag_skip = getenv("LF_DIAG_SKIP");     // diagnostic only (what-if timing, results are wrong): "grow"
+    if (diag_skip && strstr(diag_skip, "grow")) LF_HIP_CHECK(h, hipMemsetAsync(h->d_counts, 0, (size_t)n * 3 * sizeof(int), s));
+    else {
         StageTimer t(h, ST_LSD_GROW);
         launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,

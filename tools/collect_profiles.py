@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Copy the summaries of one tools/profile_round.sh run from gpurun_out/<tag>/ into profiles/<prefix>_* (tracked).
+usage: python tools/collect_profiles.py r02c r02_c"""
+import csv, glob, os, shutil, subprocess, sys
+tag, prefix = sys.argv[1], sys.argv[2]
+T = os.path.join("gpurun_out", tag)
+P = "profiles"
+
+def one(pattern):
+    f = glob.glob(os.path.join(T, pattern), recursive=True)
+    assert f, pattern
+    return f[0]
+
+shutil.copy(os.path.join(T, "bench_n1.json"), os.path.join(P, prefix + "_bench_n1.json"))
+shutil.copy(os.path.join(T, "bench_d6_rocprof.json"), os.path.join(P, prefix + "_bench_depth6_under_rocprof.json"))
+shutil.copy(os.path.join(T, "bench_d1_rocprof.json"), os.path.join(P, prefix + "_bench_depth1_under_rocprof.json"))
+shutil.copy(one("d6/**/*kernel_stats.csv"), os.path.join(P, prefix + "_kernel_stats_depth6.csv"))
+shutil.copy(one("d1/**/*kernel_stats.csv"), os.path.join(P, prefix + "_kernel_stats_depth1.csv"))
+shutil.copy(one("as/**/*kernel_stats.csv"), os.path.join(P, prefix + "_assoc_kernel_stats.csv"))
+with open(os.path.join(T, "assoc_rate.txt")) as f, open(os.path.join(P, prefix + "_assoc_rate.txt"), "w") as g:
+    g.writelines(l for l in f if "amdgpu.ids" not in l)
+
+def slim(src, dst):
+    """counter rows of the lanefront kernels only, the columns that matter"""
+    cols = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"]
+    with open(src) as f, open(dst, "w", newline="") as g:
+        w = csv.DictWriter(g, fieldnames=cols)
+        w.writeheader()
+        for r in csv.DictReader(f):
+            if "lf::" not in r["Kernel_Name"]:
+                continue
+            r2 = {k: r[k] for k in cols}
+            r2["Kernel_Name"] = r2["Kernel_Name"].split("(")[0]
+            w.writerow(r2)
+
+slim(one("pw/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_write_size.csv"))
+slim(one("pf/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_fetch_size.csv"))
+slim(one("pa/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_assoc_sq.csv"))
+slim(one("pg/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_assoc_grbm.csv"))
+with open(os.path.join(P, "r02_traffic.json"), "w") as g:
+    subprocess.check_call([sys.executable, "tools/pmc_traffic.py", os.path.join(P, prefix + "_pmc_write_size.csv"),
+                           os.path.join(P, prefix + "_pmc_fetch_size.csv"), prefix], stdout=g)
+print("collected", prefix)

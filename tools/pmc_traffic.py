@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Derive per-launch HBM traffic from two rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE; separate runs).
 
-usage: tools/pmc_traffic.py <pmc_write.csv> <pmc_fetch.csv> <tag> > profiles/r01_traffic.json
+usage: tools/pmc_traffic.py <pmc_write.csv> <pmc_fetch.csv> <tag> > profiles/r02_traffic.json
 
 Counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (the counter
 reports half the bytes of wide coalesced reads).  Output keys: kernel short names plus the stage
@@ -34,7 +34,7 @@ for a, k in alias.items():
 json.dump({"workload": {"batch": 256, "geometry": "fullres"},
            "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE in separate passes of `bench.py --steps 2 --warmup 1 "
                      "--cpu-frames -1 --depth 1` (profiles/%s_pmc_*.csv); counters are in KB; FETCH_SIZE doubled per "
-                     "MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads; calibrated for 16 B/lane "
-                     "streams only, so kernels using 4-byte loads may be over-counted on the read side); derived by "
-                     "tools/pmc_traffic.py" % tag,
+                     "MI355X_MICROARCH.md (gfx950 reports half the bytes of coalesced reads; the factor was calibrated on this "
+                     "pipeline's own access shapes -- 4, 8, 12 and 16 bytes per lane all read x2.000, profiles/r02_fetch_probe.json); "
+                     "derived by tools/pmc_traffic.py" % tag,
            "traffic_bytes_per_launch": tr}, sys.stdout, indent=1)
