@@ -246,6 +246,10 @@ int lf_map_update(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows
 /* single-GPU convenience: lf_map_associate + lf_map_pack_block + lf_map_update; idx / dist device arrays [n] */
 int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const double* frame_pose,
                 int step, int32_t* idx, float* dist);
+/* lf_map_step with HOST arrays in `segs` (frame_offset, code, color, keep, ground as lf_process_batch returns them with
+ * out_on_device = 0) and host idx / dist: upload, associate, update, download; returns when idx / dist are in place */
+int lf_map_step_host(lf_map* m, const lf_segments* segs, int n, int n_frames, const double* frame_pose, int step,
+                     int32_t* idx, float* dist);
 /* copy entries [first, first + n) to host arrays (NULL arrays are skipped); waits for the map's stream */
 int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,
                  int32_t* last_seen);

@@ -23,7 +23,7 @@ EXPORTS = (
     "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_probe", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
     "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
-    "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_fetch",
+    "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_step_host", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
 )
 
@@ -117,6 +117,8 @@ def load():
     lib.lf_map_pack_block.argtypes = [vp, vp, ctypes.POINTER(LfSegments), ci, ci, vp, vp, vp, ci, vp, ci]
     lib.lf_map_update.argtypes = [vp, vp, ci, ci]
     lib.lf_map_step.argtypes = [vp, vp, ctypes.POINTER(LfSegments), ci, ci, vp, ci, vp, vp]
+    lib.lf_map_step_host.argtypes = [vp, ctypes.POINTER(LfSegments), ci, ci, vp, ci, vp, vp]
+    lib.lf_map_step_host.restype = ci
     lib.lf_map_fetch.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp]
     lib.lf_map_set_profiling.argtypes = [vp, ci]
     lib.lf_map_set_profiling.restype = ci

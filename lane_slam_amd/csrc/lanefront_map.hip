@@ -26,6 +26,7 @@ struct lf_map {
     bool state_pending = false;
     long long rows_in_flight = 0;            // rows handed to updates whose state copy has not been seen yet
     Buf qx, qcx, best, act, own_block, pose, q_in, c_in, idx_out, dist_out, seed_code, seed_color, seed_ground;
+    Buf st_fo, st_code, st_color, st_keep, st_ground, st_idx, st_dist;     // staging of lf_map_step_host
     std::vector<double> h_pose;
     // per-stage timing with HIP events on the map's stream (resolved by lf_map_get_timing)
     struct Ev { hipEvent_t a, b; int st; };
@@ -172,7 +173,8 @@ extern "C" void lf_map_destroy(lf_map* m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     void* ptrs[] = { m->d.code, m->d.color, m->d.ground, m->d.hits, m->d.last_seen, m->d.winner, m->d.mx, m->d.mcx, m->d.state, m->d.totals };
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (Buf* b : { &m->qx, &m->qcx, &m->best, &m->act, &m->own_block, &m->pose, &m->q_in, &m->c_in, &m->idx_out, &m->dist_out, &m->seed_code, &m->seed_color, &m->seed_ground })
+    for (Buf* b : { &m->qx, &m->qcx, &m->best, &m->act, &m->own_block, &m->pose, &m->q_in, &m->c_in, &m->idx_out, &m->dist_out, &m->seed_code, &m->seed_color, &m->seed_ground,
+                     &m->st_fo, &m->st_code, &m->st_color, &m->st_keep, &m->st_ground, &m->st_idx, &m->st_dist })
         if (b->p) (void)hipFree(b->p);
     if (m->h_state) (void)hipHostFree(m->h_state);
     for (lf_map::Ev& e : m->ev_used) m->ev_free.push_back(e);
@@ -441,6 +443,44 @@ extern "C" int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int
     if ((rc = lf_map_pack_block(m, h, segs, n, n_frames, idx, dist, frame_pose, step, static_cast<uint8_t*>(m->own_block.p), n + 1)) != LF_OK) return rc;
     if (n == 0) return LF_OK;
     return update_blocks(m, static_cast<const uint8_t*>(m->own_block.p), 1, n + 1, 0, n);
+}
+
+// the same with HOST arrays (what lf_process_batch returns with out_on_device = 0): for per-frame callers such as a
+// ROS node, and for clients that link nothing but this C ABI
+extern "C" int lf_map_step_host(lf_map* m, const lf_segments* segs, int n, int n_frames, const double* frame_pose, int step,
+                                int32_t* idx, float* dist)
+{
+    if (!m) return LF_ERR_NOT_INITIALISED;
+    if (!segs || n < 0 || n_frames < 1 || (n > 0 && (!segs->code || !idx || !dist)) || !segs->frame_offset ||
+        (m->cfg.color_gating && n > 0 && !segs->color)) {
+        map_error(m, "lf_map_step_host: bad argument (frame_offset and code are required, color when gating is on)");
+        return LF_ERR_BAD_ARG;
+    }
+    MAP_HIP(m, hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    int rc;
+    const size_t c = (size_t)(n > 0 ? n : 1);
+    if ((rc = grow(m, m->st_fo, (size_t)(n_frames + 1) * 4)) || (rc = grow(m, m->st_code, c * 32)) || (rc = grow(m, m->st_color, c)) ||
+        (rc = grow(m, m->st_keep, c)) || (rc = grow(m, m->st_ground, c * 32)) || (rc = grow(m, m->st_idx, c * 4)) || (rc = grow(m, m->st_dist, c * 4))) return rc;
+    lf_segments d;
+    memset(&d, 0, sizeof(d));
+    MAP_HIP(m, hipMemcpyAsync(m->st_fo.p, segs->frame_offset, (size_t)(n_frames + 1) * 4, hipMemcpyHostToDevice, s));
+    d.frame_offset = static_cast<int32_t*>(m->st_fo.p);
+    if (n > 0) {
+        MAP_HIP(m, hipMemcpyAsync(m->st_code.p, segs->code, (size_t)n * 32, hipMemcpyHostToDevice, s));
+        d.code = static_cast<uint8_t*>(m->st_code.p);
+        if (segs->color) { MAP_HIP(m, hipMemcpyAsync(m->st_color.p, segs->color, (size_t)n, hipMemcpyHostToDevice, s)); d.color = static_cast<uint8_t*>(m->st_color.p); }
+        if (segs->keep) { MAP_HIP(m, hipMemcpyAsync(m->st_keep.p, segs->keep, (size_t)n, hipMemcpyHostToDevice, s)); d.keep = static_cast<uint8_t*>(m->st_keep.p); }
+        if (segs->ground) { MAP_HIP(m, hipMemcpyAsync(m->st_ground.p, segs->ground, (size_t)n * 32, hipMemcpyHostToDevice, s)); d.ground = static_cast<double*>(m->st_ground.p); }
+    }
+    rc = lf_map_step(m, nullptr, &d, n, n_frames, frame_pose, step, static_cast<int32_t*>(m->st_idx.p), static_cast<float*>(m->st_dist.p));
+    if (rc != LF_OK) return rc;
+    if (n > 0) {
+        MAP_HIP(m, hipMemcpyAsync(idx, m->st_idx.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        MAP_HIP(m, hipMemcpyAsync(dist, m->st_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    }
+    MAP_HIP(m, hipStreamSynchronize(s));
+    return LF_OK;
 }
 
 extern "C" int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,

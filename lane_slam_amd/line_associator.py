@@ -99,6 +99,24 @@ class LineAssociator(object):
                                               idx.ctypes.data, dist.ctypes.data, 0))
         return idx, dist
 
+    def step(self, seg, poses=None, step=0):
+        """Associate the segments of a host `Segments` block (FrontEnd.process_batch) against the map, then update the
+        map with them; returns (idx, dist).  poses: (n_frames, 3) map -> duck (x, y, theta) per frame, or None."""
+        n, n_frames = int(seg.n), len(seg.frame_offset) - 1
+        keep_alive, pp = self._poses(poses, n_frames)
+        s = _lib.LfSegments()
+        s.capacity = n
+        alive = []
+        for k in ("frame_offset", "code", "color", "keep", "ground"):
+            v = getattr(seg, k)
+            if v is not None:
+                a = np.ascontiguousarray(v)
+                alive.append(a)
+                setattr(s, k, a.ctypes.data)
+        idx, dist = np.empty(n, np.int32), np.empty(n, np.float32)
+        self._check(self.lib.lf_map_step_host(self.m, ctypes.byref(s), n, n_frames, pp, int(step), idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
     def fetch(self, first=0, n=None):
         n = self.capacity - first if n is None else n
         out = {"code": np.empty((n, 32), np.uint8), "color": np.empty(n, np.uint8), "ground": np.empty((n, 4), np.float64),

@@ -68,6 +68,29 @@ int main(int argc, char** argv)
         if (rc != LF_OK) die("lf_associate", h, rc);
     }
 
+    /* the associator component from plain C: two steps against a live map (append, then merge with colour gating off):
+     * the second step must match every kept segment of the first at distance 0 */
+    lf_map_config mc;
+    memset(&mc, 0, sizeof(mc));
+    mc.capacity = 4096; mc.max_distance = 128; mc.policy = LF_MAP_MERGE; mc.kept_only = 1; mc.merge_distance = 0; mc.when_full = LF_MAP_RING;
+    lf_map* map = NULL;
+    rc = lf_map_create(0, &mc, &map);
+    if (rc != LF_OK) { fprintf(stderr, "lf_map_create failed: %d (%s)\n", rc, lf_map_last_error(NULL)); return 2; }
+    int32_t* midx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(total > 0 ? total : 1));
+    float* mdist = (float*)malloc(sizeof(float) * (size_t)(total > 0 ? total : 1));
+    int map_size1 = 0, map_size2 = 0, matched0 = 0;
+    int64_t appended = 0, refreshed = 0;
+    rc = lf_map_step_host(map, &s, total, n, NULL, 0, midx, mdist);
+    if (rc != LF_OK) { fprintf(stderr, "lf_map_step_host failed: %d (%s)\n", rc, lf_map_last_error(map)); return 2; }
+    rc = lf_map_size(map, &map_size1, NULL, NULL, NULL);
+    if (rc != LF_OK) return 2;
+    rc = lf_map_step_host(map, &s, total, n, NULL, 1, midx, mdist);
+    if (rc != LF_OK) { fprintf(stderr, "lf_map_step_host (2) failed: %d (%s)\n", rc, lf_map_last_error(map)); return 2; }
+    rc = lf_map_size(map, &map_size2, NULL, &appended, &refreshed);
+    if (rc != LF_OK) return 2;
+    for (int i = 0; i < total; ++i) if (s.keep[i] && midx[i] >= 0 && mdist[i] == 0.f) ++matched0;
+    lf_map_destroy(map);
+
     /* SegmentList bodies line_sanity_node would publish */
     const size_t body_cap = 4 * (size_t)n + 73 * (size_t)total;
     uint8_t* body = (uint8_t*)malloc(body_cap ? body_cap : 1);
@@ -84,7 +107,9 @@ int main(int argc, char** argv)
     FILE* f = fopen(argv[4], "wb");
     if (!f) { perror(argv[4]); return 2; }
     int32_t head[4] = { total, rc_small, (int32_t)boff[n], LF_N_STAGES };
+    int32_t maphead[5] = { map_size1, map_size2, matched0, (int32_t)appended, (int32_t)refreshed };
     fwrite(head, sizeof(head), 1, f);
+    fwrite(maphead, sizeof(maphead), 1, f);
     fwrite(s.frame_offset, sizeof(int32_t), (size_t)n + 1, f);
     fwrite(s.lines, sizeof(float) * 4, (size_t)total, f);
     fwrite(s.ground, sizeof(double) * 4, (size_t)total, f);

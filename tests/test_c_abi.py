@@ -56,7 +56,8 @@ def test_c_client_matches_python_binding_and_oracle(tmp_path):
     raw = (tmp_path / "out.bin").read_bytes()
     total, rc_small, body_bytes, n_stages = struct.unpack_from("<4i", raw, 0)
     assert rc_small == -2 and n_stages == _lib.LF_N_STAGES          # LF_ERR_CAPACITY
-    pos = 16
+    map_size1, map_size2, matched0, appended, refreshed = struct.unpack_from("<5i", raw, 16)
+    pos = 36
 
     def take(dtype, count):
         nonlocal pos
@@ -84,5 +85,21 @@ def test_c_client_matches_python_binding_and_oracle(tmp_path):
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
     ref_body, ref_off = sm.serialize_segments(fe, seg, sm.FILTERED)
     assert np.array_equal(boff, ref_off) and np.array_equal(body, ref_body)
+    # the live map from plain C (lf_map_step_host): the same two steps through the oracle's statement of the contract
+    from oracle.oracle import OracleMap
+    om = OracleMap(capacity=4096, max_distance=128, policy="merge", kept_only=True, merge_distance=0)
+    om.step(code, seg.color, keep, ground, 0)
+    assert om.state()["size"] == map_size1
+    i2, d2 = om.step(code, seg.color, keep, ground, 1)
+    st = om.state()
+    assert (st["size"], st["total_appended"], st["total_refreshed"]) == (map_size2, appended, refreshed)
+    assert matched0 == int(((keep != 0) & (i2 >= 0) & (d2 == 0)).sum()) and matched0 >= int(keep.sum()) > 0
+    # and through the Python binding's host-array step
+    from lane_slam_amd import LineAssociator
+    la = LineAssociator(capacity=4096, max_distance=128, policy="merge", kept_only=True, merge_distance=0)
+    la.step(seg, step=0)
+    gi, gd = la.step(seg, step=1)
+    assert np.array_equal(gi, i2) and np.array_equal(gd, d2) and la.state()["size"] == map_size2
+    la.close()
     r0 = o.process_frame(frames[0])
     assert np.array_equal(lines[fo[0]:fo[1]], r0["lines"]) and np.array_equal(keep[fo[0]:fo[1]], r0["keep"])
