@@ -228,11 +228,13 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     const int lane = lane_id();
     int n = 1;
     reg_set(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
+    used_set(c, seed_e);
+#ifdef LF_HOST_SIM
     reg_angle = angle_of(c.deg[seed_e]);
     double s0, c0;
     dm::dsincos(reg_angle, s0, c0);
     float sumdx = (float)c0, sumdy = (float)s0;
-    used_set(c, seed_e);
+#endif
 #ifndef LF_HOST_SIM
     // Frontier points are taken in list order, 7 at a time: lane = 9*slot + neighbour, so
     // ascending lane order IS the reference's visiting order (point i, then its 3x3 window in
@@ -257,8 +259,26 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     {
         const int x = wx0 + k9, y = wy0 + slot;
         if (lane < 63 && x >= 0 && x < W && y >= 0 && y < H) w_e = find_e(c, x, y);
-        if (w_e >= 0) { w_deg = c.deg[w_e]; w_cs = c.cs[w_e]; w_sn = c.sn[w_e]; }
     }
+    // Two thirds of all seeds are ISOLATED: leftovers of earlier regions whose eight neighbours are all undefined or
+    // already used.  Their region is the seed alone whatever the angles are, and (for min_reg_size > 1) it is thrown
+    // away -- so it is recognised here from the row lists and the USED bits in LDS, before anything is fetched from
+    // the compact arrays and before the seed's sine / cosine are worked out.
+    if (c.min_reg_size > 1) {
+        const int ax = k9 - 4, ay = slot - 3;
+        const bool adj = lane < 63 && ax >= -1 && ax <= 1 && ay >= -1 && ay <= 1 && (ax != 0 || ay != 0);
+        if (__ballot(adj && w_e >= 0 && !used_get(c, w_e)) == 0ull) {
+            reg_size = 1;
+            reg_angle = NOTDEF_D;
+            LFG_CNT(c, 20, 1)
+            return;
+        }
+    }
+    reg_angle = angle_of(c.deg[seed_e]);
+    if (w_e >= 0) { w_deg = c.deg[w_e]; w_cs = c.cs[w_e]; w_sn = c.sn[w_e]; }
+    double s0, c0;
+    dm::dsincos(reg_angle, s0, c0);
+    float sumdx = (float)c0, sumdy = (float)s0;
     LFG_T1(c, 16)
     const float precf = (float)prec;
     const float EPSF = 0.0043633f;                        // 0.25 degree

@@ -24,7 +24,7 @@ print("wave totals (kcycles): slowest wave mean %.0f max %.0f | sum over waves m
 slow = tot_w.argmax(1)
 d = raw[np.arange(n * 3), slow][:, :27].astype(np.float64)          # the slowest wave of every problem
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
-         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc"] + ["-"] * 4 + ["total", "n_order", "n_comp"]
+         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc", "isolated_seeds"] + ["-"] * 3 + ["total", "n_order", "n_comp"]
 CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
 raw7 = raw[:, :, 7].sum(1)
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
