@@ -19,9 +19,13 @@
 // same three steps as LSD radix sorts with the items in HBM (five + three 4-bit passes; each lane owns a
 // contiguous run of items, per-lane bucket counters live in a [16][512] LDS matrix and one wave scans each
 // bucket row, so no atomics are needed).
+#include <cstdlib>
+#include <algorithm>
 #include "common.h"
 
 namespace lf {
+using std::max;
+using std::min;
 
 constexpr int OT = 512;          // threads
 constexpr int NB = 16;           // buckets per pass (4-bit digits; [16][512] u32 = 32 KB LDS)
@@ -326,7 +330,7 @@ constexpr int LT = 512;
 
 __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                   const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
-                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count)
+                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int comp_cap)
 {
     extern __shared__ uint32_t dyn_lds[];
     // 48 KB: three workgroups per CU, i.e. all 768 problems of a 256-frame batch are resident at once
@@ -387,11 +391,11 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     for (int e = t; e < n; e += LT)
         if (csize((uint32_t)e) >= minsz) {                       // only roots have a count
             const int k = atomicAdd(&n_roots, 1);
-            if (k < kCompCap) roots[k] = (uint16_t)e;
+            if (k < comp_cap) roots[k] = (uint16_t)e;
         }
     __syncthreads();
     const int C = n_roots;
-    if (C > kCompCap) {
+    if (C > comp_cap) {
         // more eligible components than the list holds (tiny min_reg_size): fall back to one component
         for (int e = t; e < n; e += LT) lab[e] = 0;
         if (t == 0) { list[0] = 0; comp_count[pc] = 1; }
@@ -419,7 +423,9 @@ void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const
             (void)hipGetLastError();
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count);
+    // LF_DIAG_COMP_CAP: a smaller component list, so that tests reach the "more components than the list holds" fallback
+    static const int comp_cap = getenv("LF_DIAG_COMP_CAP") ? max(1, min(kCompCap, atoi(getenv("LF_DIAG_COMP_CAP")))) : kCompCap;
+    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_cap);
 }
 
 // Debug only: dense angle / magnitude planes rebuilt from the compact arrays (NOTDEF / 0 elsewhere).

@@ -436,6 +436,51 @@ def test_lsd_on_clutter_matches_oracle(geo):
     fe.close()
 
 
+def test_lsd_on_many_components(tmp_path):
+    """k_lsd_label / k_lsd_grow corner cases on images made of many separate strokes (one connected component each,
+    some too small to hold a region): lines must come back in the sequential detector's order.  A second process
+    repeats it with the component list cut to 5 entries (LF_DIAG_COMP_CAP), which forces the "more eligible
+    components than the list holds" fallback -- the whole problem grown as one component."""
+    import os
+    import subprocess
+    import sys
+    from oracle.oracle import Oracle
+    cfg = default_config("fullres")
+    o = Oracle(cfg)
+    rng = np.random.default_rng(77)
+    imgs, refs = [], []
+    for t, (n_strokes, length) in enumerate([(90, 40), (160, 22), (60, 70)]):
+        img = np.zeros((320, 640), np.uint8)
+        for _ in range(n_strokes):
+            y, x = int(rng.integers(6, 314)), int(rng.integers(6, 634 - length))
+            slope = rng.uniform(-0.6, 0.6)
+            for k in range(length):
+                yy = int(round(y + slope * k))
+                if 0 <= yy < 320:
+                    img[yy, x + k] = 255
+        imgs.append(img)
+        refs.append(o.lsd(img, cap=8192))
+    assert sum(len(r) for r in refs) > 100
+    np.savez(tmp_path / "cases.npz", imgs=np.stack(imgs), **{"ref%d" % i: r for i, r in enumerate(refs)})
+    script = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from lane_slam_amd import FrontEnd, default_config\n"
+        "d = np.load(%r)\n"
+        "fe = FrontEnd(default_config('fullres'), max_frames=1, max_lines_per_color=8192)\n"
+        "for i, img in enumerate(d['imgs']):\n"
+        "    got = fe.lsd_binary(img)\n"
+        "    ref = d['ref%%d' %% i]\n"
+        "    assert got.shape == ref.shape and np.array_equal(got, ref), i\n"
+        "print('ok')\n" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "cases.npz")))
+    for cap in (None, "5"):
+        env = dict(os.environ)
+        if cap:
+            env["LF_DIAG_COMP_CAP"] = cap
+        p = subprocess.run([sys.executable, "-c", script], capture_output=True, env=env)
+        assert p.returncode == 0 and b"ok" in p.stdout, (cap, p.stderr.decode()[-800:])
+
+
 def test_lbd_gradient_planes(setup):
     """gray -> 5x5 fixed-point Gaussian -> Sobel (the LBD inputs) must be integer-exact everywhere.
     (This test caught hipcc's v_ashr_pk_u8_i32 fusion producing a wrong byte on gfx950.)"""
