@@ -184,6 +184,20 @@ LFG_DEV void used_set(const Ctx& c, int e) { if (e < c.used_lds) c.usedc[e >> 5]
 LFG_DEV void used_clr(const Ctx& c, int e) { if (e < c.used_lds) c.usedc[e >> 5] &= ~(1u << (e & 31)); else c.gused[e >> 5] &= ~(1u << (e & 31)); }
 #endif
 
+// sine and cosine of an angle through the deterministic routine, out of line for the same reason as nfa_eval below
+struct SinCos { double s, c; };
+#ifndef LF_HOST_SIM
+__device__ __noinline__
+#else
+static
+#endif
+SinCos sincos_eval(double x)
+{
+    SinCos r;
+    dm::dsincos(x, r.s, r.c);
+    return r;
+}
+
 LFG_DEV double angle_of(float deg) { return deg == NOTDEF_F ? NOTDEF_D : (double)deg * DEG2RAD; }
 
 LFG_DEV bool aligned_val(double a, double theta, double prec)
@@ -231,9 +245,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     used_set(c, seed_e);
 #ifdef LF_HOST_SIM
     reg_angle = angle_of(c.deg[seed_e]);
-    double s0, c0;
-    dm::dsincos(reg_angle, s0, c0);
-    float sumdx = (float)c0, sumdy = (float)s0;
+    const SinCos sc0 = sincos_eval(reg_angle);
+    float sumdx = (float)sc0.c, sumdy = (float)sc0.s;
 #endif
 #ifndef LF_HOST_SIM
     // Frontier points are taken in list order, 7 at a time: lane = 9*slot + neighbour, so
@@ -276,9 +289,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     }
     reg_angle = angle_of(c.deg[seed_e]);
     if (w_e >= 0) { w_deg = c.deg[w_e]; w_cs = c.cs[w_e]; w_sn = c.sn[w_e]; }
-    double s0, c0;
-    dm::dsincos(reg_angle, s0, c0);
-    float sumdx = (float)c0, sumdy = (float)s0;
+    const SinCos sc0 = sincos_eval(reg_angle);
+    float sumdx = (float)sc0.c, sumdy = (float)sc0.s;
     LFG_T1(c, 16)
     const float precf = (float)prec;
     const float EPSF = 0.0043633f;                        // 0.25 degree
@@ -490,9 +502,8 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
                                            : (double)dm::fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
     theta *= DEG2RAD;
     if (dabs(angle_diff_signed(theta, reg_angle)) > prec) theta += PI_;
-    double dsn, dcs;
-    dm::dsincos(theta, dsn, dcs);
-    const double dx = dcs, dy = dsn;
+    const SinCos sct = sincos_eval(theta);
+    const double dx = sct.c, dy = sct.s;
     // extents: max/min are order independent -> lane-parallel
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
     for (int i = lane; i < reg_size; i += LFG_NL) {
@@ -517,45 +528,37 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
 }
 
 // ------------------------------------------------------------------ refine
-LFG_DEV bool reduce_region_radius(const Ctx& c, int& reg_size, double reg_angle, double prec, double p, Rect& rec,
-                                  double density, double density_th)
+// OpenCV's refine() / reduce_region_radius() in pieces: detect() below drives them from ONE loop so that region_grow and
+// region2rect are instantiated once (they are the two largest inlined bodies; every copy is instruction-cache footprint).
+//
+// One radius-reduction step: shrink the radius by 0.75 and drop the region points beyond it (USED cleared).
+LFG_DEV void reduce_radius_step(const Ctx& c, int& reg_size, double xc, double yc, double& radSq)
 {
-    const uint32_t p0 = reg_get(c, 0);
-    const double xc = (double)(int)(p0 & 0xffffu), yc = (double)(int)(p0 >> 16);
-    const double radSq1 = dist_sq(xc, yc, rec.x1, rec.y1);
-    const double radSq2 = dist_sq(xc, yc, rec.x2, rec.y2);
-    double radSq = radSq1 > radSq2 ? radSq1 : radSq2;
-    while (density < density_th) {
-        radSq *= 0.75 * 0.75;
-        for (int i = 0; i < reg_size; ++i) {
-            const uint32_t pk = reg_get(c, i);
-            const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
-            if (dist_sq(xc, yc, (double)px, (double)py) > radSq) {
-                used_clr(c, find_e(c, px, py));
-                const uint32_t last = reg_get(c, reg_size - 1);
-                reg_set(c, i, last);
-                reg_set(c, reg_size - 1, pk);
-                mem_fence();
-                --reg_size;
-                --i;
-            }
+    radSq *= 0.75 * 0.75;
+    for (int i = 0; i < reg_size; ++i) {
+        const uint32_t pk = reg_get(c, i);
+        const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+        if (dist_sq(xc, yc, (double)px, (double)py) > radSq) {
+            used_clr(c, find_e(c, px, py));
+            const uint32_t last = reg_get(c, reg_size - 1);
+            reg_set(c, i, last);
+            reg_set(c, reg_size - 1, pk);
+            mem_fence();
+            --reg_size;
+            --i;
         }
-        if (reg_size < 2) return false;
-        region2rect(c, reg_size, reg_angle, prec, p, rec);
-        density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     }
-    return true;
 }
 
-LFG_DEV bool refine(const Ctx& c, int& reg_size, double reg_angle, double prec, double p, Rect& rec, double density_th)
+// First half of refine(): the region's points are released (USED cleared) and the tolerance tau for the second
+// growth is twice the standard deviation of the angles near the region's first point.
+LFG_DEV double refine_tau(const Ctx& c, int reg_size, const Rect& rec, int& x0, int& y0, int& e0)
 {
     const int lane = lane_id();
-    double density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-    if (density >= density_th) return true;
     const uint32_t p0 = reg_get(c, 0);
-    const int x0 = (int)(p0 & 0xffffu), y0 = (int)(p0 >> 16);
+    x0 = (int)(p0 & 0xffffu); y0 = (int)(p0 >> 16);
     const double xc = (double)x0, yc = (double)y0;
-    const int e0 = find_e(c, x0, y0);
+    e0 = find_e(c, x0, y0);
     const double ang_c = angle_of(c.deg[e0]);
     double sum = 0, s_sum = 0;
     int n = 0;
@@ -581,13 +584,7 @@ LFG_DEV bool refine(const Ctx& c, int& reg_size, double reg_angle, double prec, 
         }
     }
     const double mean_angle = sum / (double)n;
-    const double tau = 2.0 * dm::dsqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
-    region_grow(c, x0, y0, e0, reg_size, reg_angle, tau);
-    if (reg_size < 2) return false;
-    region2rect(c, reg_size, reg_angle, prec, p, rec);
-    density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-    if (density < density_th) return reduce_region_radius(c, reg_size, reg_angle, prec, p, rec, density, density_th);
-    return true;
+    return 2.0 * dm::dsqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
 }
 
 // ------------------------------------------------------------------ NFA
@@ -611,9 +608,16 @@ LFG_DEV double log_gamma_windschitl(double x)
 }
 LFG_DEV double log_gamma(double x) { return x > 15.0 ? log_gamma_windschitl(x) : log_gamma_lanczos(x); }
 
-LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
+// The NFA arithmetic (log-gamma, binomial tail: a few hundred f64 operations through the deterministic routines) is
+// reached from six places once everything is inlined; kept OUT of line it exists once, and the kernel's hot loops
+// stay inside the instruction cache (the kernel was 116 KB of code against a 64 KB cache shared by two CUs).
+#ifndef LF_HOST_SIM
+__device__ __noinline__
+#else
+static
+#endif
+double nfa_eval(int n, int k, double p, double LOG_NT)
 {
-    const double LOG_NT = c.log_nt;
     if (n == 0 || k == 0) return -LOG_NT;
     if (n == k) return -LOG_NT - (double)n * dm::dlog10(p);
     const double p_term = p / (1 - p);
@@ -627,7 +631,6 @@ LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
     double bin_tail = term;
     const double tolerance = 0.1;
     for (int i = k + 1; i <= n; ++i) {
-        LFG_CNT(c, 17, 1)
         const double bin_term = (double)(n - i + 1) / (double)i;
         const double mult_term = bin_term * p_term;
         term *= mult_term;
@@ -639,6 +642,7 @@ LFG_DEV double nfa(const Ctx& c, int n, int k, double p)
     }
     return -dm::dlog10(bin_tail) - LOG_NT;
 }
+LFG_DEV double nfa(const Ctx& c, int n, int k, double p) { return nfa_eval(n, k, p, c.log_nt); }
 
 // Row geometry of one rectangle: everything rect_nfa's scan-line walk needs, all integers.
 struct RowGeom { int min_x, flstep, slstep, frstep, srstep, ly, ry, y_start, y_end; };
@@ -999,25 +1003,49 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         const uint32_t sxy = c.gxy[se];
         const int tag = i;
 #endif
-        int reg_size;
-        double reg_angle;
-        region_grow(c, (int)(sxy & 0xffffu), (int)(sxy >> 16), se, reg_size, reg_angle, c.prec);
-        LFG_T1(c, 1)
-        LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size)
-        if (reg_size < c.min_reg_size) continue;
+        // region_grow -> region2rect -> [refine: second growth with tau -> region2rect] -> [radius reduction steps, each
+        // followed by region2rect], as one loop (see "refine" above).  phase 0: first growth, 1: grown again with tau,
+        // 2: reducing the radius.
+        int reg_size = 0;
+        double reg_angle = 0;
         Rect rec;
-        region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
-        LFG_T1(c, 2)
-        double log_nfa = -1;
-        if (c.refine > 0) {
-            bool ok_ = refine(c, reg_size, reg_angle, c.prec, c.p, rec, c.density_th);
-            LFG_T1(c, 3)
-            if (!ok_) continue;
-            if (c.refine >= 2) {
-                log_nfa = rect_improve(c, rec);
-                LFG_T1(c, 6)
-                if (log_nfa <= c.log_eps) continue;
+        int phase = 0, gx = (int)(sxy & 0xffffu), gy = (int)(sxy >> 16), ge = se;
+        double grow_prec = c.prec, radSq = 0, xc = 0, yc = 0;
+        bool rejected = false;
+        for (;;) {
+            if (phase < 2) {
+                region_grow(c, gx, gy, ge, reg_size, reg_angle, grow_prec);
+                if (phase == 0) { LFG_T1(c, 1) LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size) }
+                if (reg_size < (phase == 0 ? c.min_reg_size : 2)) { rejected = true; break; }
             }
+            region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
+            if (phase == 0) { LFG_T1(c, 2) }
+            if (c.refine <= 0) break;
+            const double density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+            if (density >= c.density_th) break;
+            if (phase == 0) {
+                grow_prec = refine_tau(c, reg_size, rec, gx, gy, ge);
+                phase = 1;
+                continue;
+            }
+            if (phase == 1) {
+                const uint32_t p0 = reg_get(c, 0);
+                xc = (double)(int)(p0 & 0xffffu); yc = (double)(int)(p0 >> 16);
+                const double radSq1 = dist_sq(xc, yc, rec.x1, rec.y1);
+                const double radSq2 = dist_sq(xc, yc, rec.x2, rec.y2);
+                radSq = radSq1 > radSq2 ? radSq1 : radSq2;
+                phase = 2;
+            }
+            reduce_radius_step(c, reg_size, xc, yc, radSq);
+            if (reg_size < 2) { rejected = true; break; }
+        }
+        LFG_T1(c, 3)
+        if (rejected) continue;
+        double log_nfa = -1;
+        if (c.refine >= 2) {
+            log_nfa = rect_improve(c, rec);
+            LFG_T1(c, 6)
+            if (log_nfa <= c.log_eps) continue;
         }
         rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
         if (c.scale != 1) {
