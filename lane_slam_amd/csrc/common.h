@@ -11,7 +11,8 @@ namespace lf {
 constexpr int kMaxKsize = 9;        // dilation structuring element
 constexpr int kMaxGaussTaps = 15;   // LSD Gaussian
 constexpr float kNotDef = -1024.0f; // LSD NOTDEF marker (angle plane, degrees)
-constexpr int kLabelItems = 8192;   // problems up to this many defined pixels are split into connected components
+constexpr int kLabelItems = 8192;   // problems up to this many defined pixels are split into connected components (LsdParams::label_items;
+                                    // 32768 for LSD images of more than 400 k pixels, i.e. 1080p frames)
 constexpr int kCompCap = 1024;      // component list entries per problem (more eligible components: one component)
 
 enum Stage {
@@ -48,6 +49,7 @@ struct LsdParams {
     double log_nt, log_eps, density_th, scale;
     int min_reg_size, n_bins, refine;
     int cap_lines;
+    int label_items;    // k_lsd_label's capacity: problems with more defined pixels are grown as one component
 };
 
 struct SegParams {

@@ -68,11 +68,11 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     c.sn = c_sn + (size_t)pc * Ps;
     c.usedc = usedc; c.gused = gu; c.used_lds = def_lds;
     // every wave has its own region list: reg_lds entries in LDS, the rest in its slice of the problem's scratch.
-    // Problems too large for k_lsd_label's LDS (> kLabelItems defined pixels) come as ONE component: wave 0 takes it
+    // Problems too large for k_lsd_label's LDS (> label_items defined pixels) come as ONE component: wave 0 takes it
     // with the whole scratch, the other waves have nothing to do.
-    const bool single = n_def > kLabelItems;
+    const bool single = n_def > p.label_items;
     c.lreg = lreg + wave * reg_lds; c.reg_lds = reg_lds;
-    c.greg = reg + (size_t)pc * reg_stride + (single ? (size_t)0 : (size_t)wave * kLabelItems);
+    c.greg = reg + (size_t)pc * reg_stride + (single ? (size_t)0 : (size_t)wave * p.label_items);
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
     c.min_reg_size = p.min_reg_size; c.refine = p.refine;
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
 size_t lsd_grow_reg_stride(const LsdParams& p)
 {
     // region scratch per problem: the whole scaled image for a single-component problem (one wave), or one
-    // slice per wave -- components come from k_lsd_label only for problems of <= 8192 defined pixels
+    // slice per wave -- components come from k_lsd_label only for problems of <= label_items defined pixels
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    const size_t need = (size_t)GROW_WAVES * kLabelItems;
+    const size_t need = (size_t)GROW_WAVES * p.label_items;
     return Ps > need ? Ps : need;
 }
 
@@ -140,6 +140,8 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.
+    // (An x-bucket table for the pixel searches -- 8 buckets per row, 9 KB -- was measured at +-0: the searches are
+    // ~6 % of the kernel and the table costs LDS residency.)
     const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4;
     // LFG_LDS_KB serves the 640x480 geometries (a few thousand defined pixels per problem).  Larger LSD images
     // (1080p: 1536x576) have proportionally more defined pixels and far fewer problems per batch, so latency

@@ -298,7 +298,7 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
 // of consecutive pixels are linked to their first entry up front, then each entry is united with its up-left / up /
 // up-right neighbours (found in the row lists).  The label of a
 // component is its first entry in raster order.
-//   c_label[e]      root of entry e                     (u16; problems of more than kLabelItems entries: all 0)
+//   c_label[e]      root of entry e                     (u16; problems of more than label_items entries: all 0)
 //   comp_list[k]    roots of the components with >= min_reg_size pixels, by size descending, root ascending
 //   comp_count      how many
 __device__ __forceinline__ uint32_t uf_find(volatile uint32_t* P, uint32_t x)
@@ -334,9 +334,10 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
 {
     extern __shared__ uint32_t dyn_lds[];
     // 48 KB: three workgroups per CU, i.e. all 768 problems of a 256-frame batch are resident at once
-    uint32_t* parent = dyn_lds;                               // [kLabelItems]
-    uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + kLabelItems);        // [kLabelItems], the union phase's x lists ...
-    uint32_t* csize2 = dyn_lds + kLabelItems;                 // ... then the component sizes, two u16 counters per word
+    const int LI = p.label_items;
+    uint32_t* parent = dyn_lds;                               // [label_items]
+    uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + LI);                 // [label_items], the union phase's x lists ...
+    uint32_t* csize2 = dyn_lds + LI;                          // ... then the component sizes, two u16 counters per word
     __shared__ uint16_t roots[kCompCap];
     __shared__ int n_roots;
     const int pc = blockIdx.x, t = threadIdx.x;
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     uint16_t* lab = c_label + o;
     uint16_t* list = comp_list + (size_t)pc * kCompCap;
     if (n == 0) { if (t == 0) comp_count[pc] = 0; return; }
-    if (n > kLabelItems) {
+    if (n > LI) {
         // too large for the LDS tables (1080p problems): one component = the whole problem, as before
         for (int e = t; e < n; e += LT) lab[e] = 0;
         if (t == 0) { list[0] = 0; comp_count[pc] = 1; }
@@ -416,12 +417,12 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
 void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
                       uint16_t* c_label, uint16_t* comp_list, int* comp_count, hipStream_t s)
 {
-    const size_t lds = (size_t)kLabelItems * (4 + 2);
-    static bool attr_set = false;
-    if (!attr_set) {
+    const size_t lds = (size_t)p.label_items * (4 + 2);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             (void)hipGetLastError();
-        attr_set = true;
+        attr_lds = lds;
     }
     // LF_DIAG_COMP_CAP: a smaller component list, so that tests reach the "more components than the list holds" fallback
     static const int comp_cap = getenv("LF_DIAG_COMP_CAP") ? max(1, min(kCompCap, atoi(getenv("LF_DIAG_COMP_CAP")))) : kCompCap;

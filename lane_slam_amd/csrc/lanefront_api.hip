@@ -268,6 +268,9 @@ static int build_params(lf_handle* h)
     L.min_reg_size = (int)(-L.log_nt / dm::dlog10(L.p));
     L.log_eps = c.lsd_log_eps; L.density_th = c.lsd_density_th;
     L.n_bins = c.lsd_n_bins; L.refine = c.lsd_refine; L.cap_lines = h->cap_lines;
+    // component labelling capacity: 8192 entries (48 KB of LDS, three problems per CU) for 640x480-class images,
+    // 24576 (144 KB, one problem per CU) for 1080p-class ones, whose problems hold 10-20 k defined pixels
+    L.label_items = h->Ps > 400000 ? 24576 : kLabelItems;
     // ---- segments
     SegParams& S = h->seg;
     memset(&S, 0, sizeof(S));
