@@ -150,6 +150,12 @@ size_t assoc_rows_padded_q(int nq);
 size_t assoc_rows_padded_m(int nm);
 void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
                        int8_t* cx, hipStream_t s);
+// Packed map operand layout (k_assoc.hip): blocked by the associator's 64-row LDS tile, [tile][16-byte chunk][row][16 B];
+// byte `byte` (0..255) of map row `row` lives at
+__host__ __device__ inline size_t assoc_map_offset(size_t row, int byte)
+{
+    return (row >> 6) * 16384 + (size_t)(byte >> 4) * 1024 + (row & 63) * 16 + (size_t)(byte & 15);
+}
 void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
                        const int* nm_dev, int gating, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,

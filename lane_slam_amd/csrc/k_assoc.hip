@@ -59,7 +59,8 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* _
         if (side == 0) { lo = (w0 * 0xC0u) ^ 0x20202020u; hi = (w1 * 0xC0u) ^ 0x20202020u; }
         else { lo = (w0 * 0xE0u) ^ 0x10101010u; hi = (w1 * 0xE0u) ^ 0x10101010u; }
     }
-    *reinterpret_cast<uint2*>(out + t * 8) = make_uint2(lo, hi);
+    // queries: row major [row][256]; map: blocked by LDS tile (common.h assoc_map_offset)
+    *reinterpret_cast<uint2*>(out + (side == 0 ? t * 8 : assoc_map_offset(row, (int)(t & 31) * 8))) = make_uint2(lo, hi);
     if ((t & 31) == 0) {
         uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if (live) {
@@ -94,7 +95,7 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
     // after an update still in flight) it is read here.  Rows in [size, bound) are all-zero operands and are dropped
     // below exactly like padding rows, so the result does not depend on how loose the bound was.
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
     const int r32 = lane & 31, half = lane >> 5;
     // QB row blocks of 32 queries per wave: every B fragment read from LDS feeds QB MFMAs
@@ -110,6 +111,10 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
     // value (the C operand of the first MFMA), a register set that is decremented once per block -- 16 vector adds
     // that issue beside the MFMAs instead of one more MFMA per accumulator (8 instead of 9 matrix steps per block).
     v16i negt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (!GATED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(negt[r]));      // a vector, not 16 copies of a scalar
+    }
     // Arg-max inside the matrix core (see the header): after the chain of 9 MFMAs the accumulator holds
     // key = 512 * dot - t - colour penalty, so the whole epilogue is ONE v_max per accumulator register: no zeroing
     // (the chain starts from the inline constant 0), no packing, no select.  dot and t are recovered from the key at
@@ -123,92 +128,124 @@ __device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const 
     const int m_end = min(nm_pad, m_begin + m_chunk);
     const int n_tiles = (m_end - m_begin) / AM;
     const unsigned tmask = half == 0 ? 0xffffu : 0u;          // the counter bytes live in k = 0, 1 (lanes 0..31)
-    // Map tiles go global -> LDS directly (global_load_lds, no staging registers: this kernel lives at the
-    // register cap), one tile ahead into the other buffer, so a tile's HBM/L2 latency hides behind the MFMAs of
-    // the tile before it; one barrier per tile.  An LDS-DMA instruction writes 64 lanes x 16 B contiguously, so
-    // the LDS image is linear (4 rows of 256 B per instruction) and the bank-conflict-free layout comes from
-    // swizzling the SOURCE: 16-byte chunk c of row r is stored at chunk position c ^ (r & 15).  The 32-byte
-    // ninth-step rows are read 16 B per lane, 64 lanes contiguous: linear as they are.
+    // Map tiles go global -> LDS directly (global_load_lds, no staging registers: this kernel lives at the register
+    // cap).  The packed map is stored BLOCKED by tile in memory -- [tile of 64 rows][16-byte chunk c][row][16 B],
+    // common.h assoc_map_offset -- so a tile is 16 KB of contiguous memory that goes to LDS as it is (an LDS-DMA
+    // instruction writes 64 lanes x 16 B contiguously), and the 32 lanes of a half wave read 512 contiguous bytes per
+    // fragment: no bank conflicts, no swizzle, one address register and immediate offsets on both sides.
+    const uint32_t lane16 = (uint32_t)lane * 16u;
     auto glds_tile = [&](int k, int buf) {
+        const int8_t* tbase = mx + (size_t)(m_begin + k * AM) * 256;          // uniform
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-            const int piece = pass * 4 + wave;                // 1 KB piece of the 16 KB tile
-            const int e = piece * 64 + lane, row = e >> 4, pos = e & 15;
-            const int8_t* src = mx + (size_t)(m_begin + k * AM + row) * 256 + 16 * (pos ^ (row & 15));
+            const int piece = pass * 4 + wave;                // 1 KB piece of the 16 KB tile = chunk `piece` of all 64 rows
+            const int8_t* src = tbase + piece * 1024 + lane16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(tile + buf * (AM * 256) + piece * 1024),
                                              16, 0, 0);
         }
         if (GATED && wave < 2) {
-            const int8_t* src = mcx + (size_t)(m_begin + k * AM) * 32 + (size_t)(wave * 64 + lane) * 16;
+            const int8_t* src = mcx + (size_t)(m_begin + k * AM) * 32 + wave * 1024 + lane16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(ctile + buf * (AM * 32) + wave * 1024),
                                              16, 0, 0);
         }
     };
-    // Three buffers, two tiles ahead: with every CU streaming the map through L2 at once a tile takes longer to land
-    // than the 36 MFMAs of one tile last, so the tile needed next was issued TWO tiles ago and the wait at the end of
-    // a tile leaves only the newest tile's pieces (4 per wave, 5 for waves 0 and 1) outstanding.
+    // Software pipeline over HALF tiles (32 map rows = one B fragment set of 8 x 16 B per lane):
+    //   step 2k    : read rows 32..63 of tile k into Bf[1]        | MFMAs on Bf[0] (rows 0..31 of tile k)
+    //                wait: tile k + 1 landed, own reads of tile k done; BARRIER  -> tile k's buffer is free
+    //                LDS-DMA of tile k + 3 into that buffer
+    //   step 2k+1  : read rows 0..31 of tile k + 1 into Bf[0]      | MFMAs on Bf[1]
+    // so a wave's LDS reads always run under its own MFMAs of the other half (the reads of all eight waves of a CU
+    // after a barrier take ~500 cycles of LDS bandwidth: in front of the MFMAs they were dead time), and a tile has two
+    // whole iterations to land.  Tile indices past the chunk are clamped (a redundant re-load of the last tile keeps
+    // the outstanding-load count uniform: 4 LDS-DMA instructions per tile and wave, 5 with the ninth-step rows).
+    const int last_tile = n_tiles - 1;
+    // ONE fragment set: fragment s of the next half is read into the registers of fragment s of the current half as soon
+    // as the MFMAs that consume it have issued, so it has 7/8 of a half step to arrive and the set costs 32 VGPRs, not 64.
+    v4i Bf[8], BX;
+    const int frag0 = half * 1024 + r32 * 16;                  // this lane inside chunk 2 s + half, row r32 (+ 32 cb)
+    auto read_frag = [&](const int8_t* buf, int cb, int s) {
+        Bf[s] = *reinterpret_cast<const v4i*>(buf + frag0 + s * 2048 + cb * 512);
+    };
+    auto read_x = [&](const int8_t* bufc, int cb) { BX = *reinterpret_cast<const v4i*>(bufc + (cb * 32 + r32) * 32 + 16 * half); };
+    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    // The arg-max of a half (one v_max per accumulator register) is folded in while the NEXT half's MFMAs run: two
+    // accumulator sets, so no MFMA result is waited for and a wave's stream is MFMA, MFMA, LDS read, a few vector ops, ...
+    // (the sched_group_barrier pattern) instead of a burst of 16 MFMAs followed by a burst of vector ops behind the
+    // last MFMA's latency.
+    v16i accs[2][QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accs[1][b][r] = (int)0x80000000;
+    // half step cb of a tile: MFMAs on the fragments in registers, which are refreshed from rows [32 ncb, 32 ncb + 32) of nbuf
+    auto half_step = [&](int cb, int tt, const int8_t* nbuf, const int8_t* nbufc, int ncb) {
+        if (GATED) {
+            const unsigned tbytes = ((unsigned)(-(tt >> 4)) & 0xffu) | (((unsigned)(-(tt & 15)) & 0xffu) << 8);
+            v4i bx = BX;
+            bx[0] |= (int)(tbytes & tmask);
+#pragma unroll
+            for (int b = 0; b < QB; ++b) accs[cb][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX[b], bx, zero, 0, 0, 0);
+            read_x(nbufc, ncb);
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+                accs[cb][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[s], (!GATED && s == 0) ? negt : accs[cb][b], 0, 0, 0);
+            read_frag(nbuf, ncb, s);
+        }
+        if (!GATED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negt[r] -= 1;
+        }
+        // the OTHER half's keys (previous step)
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                running[b][r] = max(running[b][r], accs[cb ^ 1][b][r]);
+                // keep this v_max in THIS half step: fused with the next half's into one v_max3 it would need both
+                // accumulator sets complete at once, which is exactly the wait this loop is built to avoid
+                asm("" : "+v"(running[b][r]));
+            }
+        // issue order
+#pragma unroll
+        for (int i = 0; i < 8 + (GATED ? 1 : 0); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 2 * QB, 0);
+        }
+    };
     if (n_tiles > 0) {
         glds_tile(0, 0);
-        if (n_tiles > 1) glds_tile(1, 1);
-        if (n_tiles > 1) { if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        glds_tile(min(1, last_tile), 1);
+        glds_tile(min(2, last_tile), 2);
+        if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int s = 0; s < 8; ++s) read_frag(tile, 0, s);
+        if (GATED) read_x(ctile, 0);
     }
-    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     int bcur = 0;
     for (int k = 0; k < n_tiles; ++k) {
         const int8_t* cur = tile + bcur * (AM * 256);
         const int8_t* curc = ctile + bcur * (AM * 32);
-        const int bnext2 = bcur == 0 ? 2 : bcur - 1;              // (bcur + 2) % 3: the buffer every wave left at the last barrier
-        if (k + 2 < n_tiles) glds_tile(k + 2, bnext2);
-        const int t = 2 * k;                                      // 32-column block counter
-        v4i Bf[2][8], BX[2];
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int row = cb * 32 + r32, c = 2 * s + half;
-                Bf[cb][s] = *reinterpret_cast<const v4i*>(cur + row * 256 + ((c ^ (row & 15)) << 4));
-            }
-            if (GATED) BX[cb] = *reinterpret_cast<const v4i*>(curc + (cb * 32 + r32) * 32 + 16 * half);
-        }
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            v16i acc[QB];
-            if (GATED) {
-                const int tt = t + cb;
-                const unsigned tbytes = ((unsigned)(-(tt >> 4)) & 0xffu) | (((unsigned)(-(tt & 15)) & 0xffu) << 8);
-                BX[cb][0] |= (int)(tbytes & tmask);
-#pragma unroll
-                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX[b], BX[cb], zero, 0, 0, 0);
-#pragma unroll
-                for (int s = 0; s < 8; ++s)
-#pragma unroll
-                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[cb][s], acc[b], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][0], Bf[cb][0], negt, 0, 0, 0);
-#pragma unroll
-                for (int s = 1; s < 8; ++s)
-#pragma unroll
-                    for (int b = 0; b < QB; ++b) acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[cb][s], acc[b], 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) negt[r] -= 1;
-            }
-#pragma unroll
-            for (int b = 0; b < QB; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) running[b][r] = max(running[b][r], acc[b][r]);
-        }
-        // the next tile has landed (this wave's pieces; the one after it may still be in flight) and every wave is done
-        // with the current one
-        if (k + 2 < n_tiles) { if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int bnext = bcur == 2 ? 0 : bcur + 1;
+        half_step(0, 2 * k, cur, curc, 1);
+        // tile k + 1 has landed (this wave's pieces; tile k + 2 may still be in flight), this wave holds the rest of tile k in registers
+        if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        bcur = bcur == 2 ? 0 : bcur + 1;
+        glds_tile(min(k + 3, last_tile), bcur);
+        half_step(1, 2 * k + 1, tile + bnext * (AM * 256), ctile + bnext * (AM * 32), 0);
+        bcur = bnext;
     }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) running[b][r] = max(running[b][r], accs[1][b][r]);
     // key -> (distance, column): 512 * dot = ceil(key / 512) * 512, t = 512 * dot - key; this lane's column inside
     // block t is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
     // column can only have displaced candidates with a negative dot, which are beyond 128 and never reported.  A

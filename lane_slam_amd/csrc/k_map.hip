@@ -195,7 +195,7 @@ __global__ void k_map_apply(MapDev m, const uint8_t* __restrict__ blocks, int n_
     m.code[(size_t)pos * 32 + b] = (uint8_t)byte;
     const uint32_t w0 = ((byte & 15u) * 0x00204081u) & 0x01010101u;
     const uint32_t w1 = ((byte >> 4) * 0x00204081u) & 0x01010101u;
-    *reinterpret_cast<uint2*>(m.mx + (size_t)pos * 256 + 8 * b) = make_uint2((w0 * 0xE0u) ^ 0x10101010u, (w1 * 0xE0u) ^ 0x10101010u);
+    *reinterpret_cast<uint2*>(m.mx + assoc_map_offset((size_t)pos, 8 * b)) = make_uint2((w0 * 0xE0u) ^ 0x10101010u, (w1 * 0xE0u) ^ 0x10101010u);
     if (b < 8) {
         // the ninth-step operand of a map row: bytes 0,1 zero (block counter, filled in by k_assoc), then -127 in the
         // ten bytes of each OTHER colour's group
