@@ -146,20 +146,22 @@ void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lin
                 const uint32_t* dxy, const float* gauss_g, const float* gauss_l,
                 float* desc, uint8_t* code, hipStream_t s);
 // ---- associator (k_assoc.hip): packed operands = [rows][256] int8 code bytes + [rows][32] int8 ninth-step operand
-size_t assoc_rows_padded_q(int nq);
 size_t assoc_rows_padded_m(int nm);
-void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
-                       int8_t* cx, hipStream_t s);
 // Packed map operand layout (k_assoc.hip): blocked by the associator's 64-row LDS tile, [tile][16-byte chunk][row][16 B];
 // byte `byte` (0..255) of map row `row` lives at
 __host__ __device__ inline size_t assoc_map_offset(size_t row, int byte)
 {
     return (row >> 6) * 16384 + (size_t)(byte >> 4) * 1024 + (row & 63) * 16 + (size_t)(byte & 15);
 }
-void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
-                       const int* nm_dev, int gating, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
-void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,
-                  unsigned int* best, int32_t* idx, float* dist, hipStream_t s);
+// per-caller scratch of the associator (k_assoc.hip): one key per query and map chunk + arrival counters; sized by
+// launch_assoc_core itself
+struct AssocScratch { unsigned int* part = nullptr; int* done = nullptr; size_t cap_part = 0, cap_blocks = 0; };
+void assoc_scratch_free(AssocScratch& w);
+void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int8_t* x, int8_t* cx, hipStream_t s);
+hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const int8_t* mcx, int nm,
+                             const int* nm_dev, int gating, int max_distance, AssocScratch& w, int32_t* idx, float* dist, hipStream_t s);
+hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
+                        float* dist, hipStream_t s);
 void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);
 // ---- live map (k_map.hip)
 struct MapDevice {

@@ -27,7 +27,9 @@
 //   Algorithmic ops: 2*N*M*256 int8.
 // k_assoc_float: 72-d float LBD, Euclidean, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 #include <cstdlib>
+#include <cstdio>
 #include "common.h"
+#include "k_assoc_loop.inc"
 
 namespace lf {
 
@@ -35,15 +37,21 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int AQ = 512;        // query rows are padded to this (both kernel shapes divide it)
+#ifdef LF_ASSOC_STAMPS
+__device__ unsigned long long g_assoc_stamps[8 * 8192];
+#define LF_STAMP(k) do { if (threadIdx.x == 0) { const unsigned w_ = blockIdx.y * gridDim.x + blockIdx.x; if (w_ < 8192) g_assoc_stamps[w_ * 8 + (k)] = (k) == 0 ? wall_clock64() : __builtin_readcyclecounter(); } } while (0)
+#else
+#define LF_STAMP(k) do { } while (0)
+#endif
+constexpr int AQW = 256;      // queries per workgroup (4 waves x 64)
 constexpr int AM = 64;         // map entries per LDS tile
 constexpr int kMaxBlocksPerChunk = 512;   // the in-accumulator block counter t has 9 bits
 
-// one thread per (row, code byte): 8 int8 = 2 dwords; thread 0 of a row also writes the row's ninth-step operand.
-// side 0: query (+-32, [16, 1] counter weights, +127 in the own colour's group when gating)
-// side 1: map   (+-16, zero counter bytes, -127 in the other colours' groups; colour >= 3 matches every colour)
-__global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ colors, int side, int gating,
-                             int n, int n_pad, int8_t* __restrict__ out, int8_t* __restrict__ outc)
+// Packs map rows for lf_associate's raw-map form (the live map keeps its rows packed: k_map.hip).  One thread per
+// (row, code byte): 8 int8 = 2 dwords; thread 0 of a row also writes the row's ninth-step operand (zero counter bytes,
+// -127 in the other colours' groups; colour >= 3 or no colours: matches every colour).
+__global__ void k_assoc_pack_map(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ colors, int n, int n_pad,
+                                 int8_t* __restrict__ out, int8_t* __restrict__ outc)
 {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t total = (size_t)n_pad * 32;
@@ -53,26 +61,20 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* _
     const bool live = row < (size_t)n;
     if (live) {
         uint32_t b = codes[t];
-        // nibble -> 4 bytes of 0/1, then 0 -> +mag, 1 -> -mag
+        // nibble -> 4 bytes of 0/1, then 0 -> +16, 1 -> -16
         uint32_t w0 = ((b & 15u) * 0x00204081u) & 0x01010101u;
         uint32_t w1 = ((b >> 4) * 0x00204081u) & 0x01010101u;
-        if (side == 0) { lo = (w0 * 0xC0u) ^ 0x20202020u; hi = (w1 * 0xC0u) ^ 0x20202020u; }
-        else { lo = (w0 * 0xE0u) ^ 0x10101010u; hi = (w1 * 0xE0u) ^ 0x10101010u; }
+        lo = (w0 * 0xE0u) ^ 0x10101010u; hi = (w1 * 0xE0u) ^ 0x10101010u;
     }
-    // queries: row major [row][256]; map: blocked by LDS tile (common.h assoc_map_offset)
-    *reinterpret_cast<uint2*>(out + (side == 0 ? t * 8 : assoc_map_offset(row, (int)(t & 31) * 8))) = make_uint2(lo, hi);
+    *reinterpret_cast<uint2*>(out + assoc_map_offset(row, (int)(t & 31) * 8)) = make_uint2(lo, hi);
     if ((t & 31) == 0) {
         uint32_t w[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if (live) {
             const int c = colors ? colors[row] : 255;
             uint8_t* wb = reinterpret_cast<uint8_t*>(w);
-            if (side == 0) {
-                wb[0] = 16; wb[1] = 1;
-                if (gating && c < 3) for (int k = 0; k < 10; ++k) wb[2 + 10 * c + k] = 127;
-            } else if (c < 3) {
+            if (c < 3)
                 for (int g = 0; g < 3; ++g)
                     if (g != c) for (int k = 0; k < 10; ++k) wb[2 + 10 * g + k] = (uint8_t)(-127);
-            }
         }
         uint4* o = reinterpret_cast<uint4*>(outc + row * 32);
         o[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -80,241 +82,198 @@ __global__ void k_assoc_pack(const uint8_t* __restrict__ codes, const uint8_t* _
     }
 }
 
-// QB = 32-query row blocks per wave.  Two shapes:
-//   QB = 2  256 queries per workgroup, 234 VGPRs, two workgroups per CU (small query counts: more workgroups)
-//   QB = 4  512 queries per workgroup, one wave per SIMD with the whole register file: every B fragment read from LDS
-//           feeds FOUR MFMAs (half the LDS reads and half the LDS-DMA traffic per MFMA, 72 MFMAs between barriers),
-//           and a wave never shares its matrix core with a wave of another workgroup whose barrier phase differs
-template <int QB, bool GATED>
-__device__ __forceinline__ void assoc_body(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+// four code bits -> four int8 query operand bytes: 0 -> +32, 1 -> -32
+__device__ __forceinline__ int q_expand(uint32_t nibble)
+{
+    return (int)((((nibble & 15u) * 0x00204081u) & 0x01010101u) * 0xC0u ^ 0x20202020u);
+}
+
+// One workgroup: 256 queries (4 waves x 2 x 32 rows) against one chunk of the map.
+//  * The query operands are expanded from the raw 32-byte codes straight into the A-fragment registers (no packed query
+//    array in memory, no pack kernel): lane (r32, half) of a wave holds, for row block b and step s, the 16 bits
+//    [32 s + 16 half, +16) of query q0 + 32 b + r32 as 16 int8.
+//  * The map chunk streams through three 16 KB LDS buffers; the tile loop is hand-scheduled assembly
+//    (k_assoc_loop.inc, generated by tools/gen_assoc_loop.py: register map, schedule, hazard notes there).  It leaves
+//    the running keys in LDS.
+//  * Keys are decoded and reduced to one word per query and chunk; the merge over the chunks is at the end of the body.
+template <bool GATED>
+__device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                            const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                            int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
-                                           unsigned int* __restrict__ best, int8_t* tile, int8_t* ctile)
+                                           int max_distance, unsigned int* __restrict__ part, int* __restrict__ done,
+                                           int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, int8_t* ctile, uint2* xtab)
 {
     // nm_bound sized the grid on the host; when the exact size is only known on the device (the live map's size
     // after an update still in flight) it is read here.  Rows in [size, bound) are all-zero operands and are dropped
     // below exactly like padding rows, so the result does not depend on how loose the bound was.
+    LF_STAMP(0); LF_STAMP(1);
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
+    const int q0 = blockIdx.x * AQW + wave * 64;
     const int r32 = lane & 31, half = lane >> 5;
-    // QB row blocks of 32 queries per wave: every B fragment read from LDS feeds QB MFMAs
-    v4i A[QB][8], AX[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            A[b][s] = *reinterpret_cast<const v4i*>(qx + (size_t)(q0 + 32 * b + r32) * 256 + 32 * s + 16 * half);
-        if (GATED) AX[b] = *reinterpret_cast<const v4i*>(qcx + (size_t)(q0 + 32 * b + r32) * 32 + 16 * half);
-    }
-    // Without colour gating the ninth MFMA step is not needed at all: the block counter enters as the chain's START
-    // value (the C operand of the first MFMA), a register set that is decremented once per block -- 16 vector adds
-    // that issue beside the MFMAs instead of one more MFMA per accumulator (8 instead of 9 matrix steps per block).
-    v16i negt = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (!GATED) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(negt[r]));      // a vector, not 16 copies of a scalar
-    }
-    // Arg-max inside the matrix core (see the header): after the chain of 9 MFMAs the accumulator holds
-    // key = 512 * dot - t - colour penalty, so the whole epilogue is ONE v_max per accumulator register: no zeroing
-    // (the chain starts from the inline constant 0), no packing, no select.  dot and t are recovered from the key at
-    // the very end.
-    int running[QB][16];
-#pragma unroll
-    for (int b = 0; b < QB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) running[b][r] = (int)0x80000000;
     const int m_begin = blockIdx.y * m_chunk;
     const int m_end = min(nm_pad, m_begin + m_chunk);
-    const int n_tiles = (m_end - m_begin) / AM;
-    const unsigned tmask = half == 0 ? 0xffffu : 0u;          // the counter bytes live in k = 0, 1 (lanes 0..31)
-    // Map tiles go global -> LDS directly (global_load_lds, no staging registers: this kernel lives at the register
-    // cap).  The packed map is stored BLOCKED by tile in memory -- [tile of 64 rows][16-byte chunk c][row][16 B],
-    // common.h assoc_map_offset -- so a tile is 16 KB of contiguous memory that goes to LDS as it is (an LDS-DMA
-    // instruction writes 64 lanes x 16 B contiguously), and the 32 lanes of a half wave read 512 contiguous bytes per
-    // fragment: no bank conflicts, no swizzle, one address register and immediate offsets on both sides.
-    const uint32_t lane16 = (uint32_t)lane * 16u;
-    auto glds_tile = [&](int k, int buf) {
-        const int8_t* tbase = mx + (size_t)(m_begin + k * AM) * 256;          // uniform
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {
-            const int piece = pass * 4 + wave;                // 1 KB piece of the 16 KB tile = chunk `piece` of all 64 rows
-            const int8_t* src = tbase + piece * 1024 + lane16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(tile + buf * (AM * 256) + piece * 1024),
-                                             16, 0, 0);
-        }
-        if (GATED && wave < 2) {
-            const int8_t* src = mcx + (size_t)(m_begin + k * AM) * 32 + wave * 1024 + lane16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ctile + buf * (AM * 32) + wave * 1024),
-                                             16, 0, 0);
-        }
-    };
-    // Software pipeline over HALF tiles (32 map rows = one B fragment set of 8 x 16 B per lane):
-    //   step 2k    : read rows 32..63 of tile k into Bf[1]        | MFMAs on Bf[0] (rows 0..31 of tile k)
-    //                wait: tile k + 1 landed, own reads of tile k done; BARRIER  -> tile k's buffer is free
-    //                LDS-DMA of tile k + 3 into that buffer
-    //   step 2k+1  : read rows 0..31 of tile k + 1 into Bf[0]      | MFMAs on Bf[1]
-    // so a wave's LDS reads always run under its own MFMAs of the other half (the reads of all eight waves of a CU
-    // after a barrier take ~500 cycles of LDS bandwidth: in front of the MFMAs they were dead time), and a tile has two
-    // whole iterations to land.  Tile indices past the chunk are clamped (a redundant re-load of the last tile keeps
-    // the outstanding-load count uniform: 4 LDS-DMA instructions per tile and wave, 5 with the ninth-step rows).
-    const int last_tile = n_tiles - 1;
-    // ONE fragment set: fragment s of the next half is read into the registers of fragment s of the current half as soon
-    // as the MFMAs that consume it have issued, so it has 7/8 of a half step to arrive and the set costs 32 VGPRs, not 64.
-    v4i Bf[8], BX;
-    const int frag0 = half * 1024 + r32 * 16;                  // this lane inside chunk 2 s + half, row r32 (+ 32 cb)
-    auto read_frag = [&](const int8_t* buf, int cb, int s) {
-        Bf[s] = *reinterpret_cast<const v4i*>(buf + frag0 + s * 2048 + cb * 512);
-    };
-    auto read_x = [&](const int8_t* bufc, int cb) { BX = *reinterpret_cast<const v4i*>(bufc + (cb * 32 + r32) * 32 + 16 * half); };
-    const v16i zero = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    // The arg-max of a half (one v_max per accumulator register) is folded in while the NEXT half's MFMAs run: two
-    // accumulator sets, so no MFMA result is waited for and a wave's stream is MFMA, MFMA, LDS read, a few vector ops, ...
-    // (the sched_group_barrier pattern) instead of a burst of 16 MFMAs followed by a burst of vector ops behind the
-    // last MFMA's latency.
-    v16i accs[2][QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) accs[1][b][r] = (int)0x80000000;
-    // half step cb of a tile: MFMAs on the fragments in registers, which are refreshed from rows [32 ncb, 32 ncb + 32) of nbuf
-    auto half_step = [&](int cb, int tt, const int8_t* nbuf, const int8_t* nbufc, int ncb) {
-        if (GATED) {
-            const unsigned tbytes = ((unsigned)(-(tt >> 4)) & 0xffu) | (((unsigned)(-(tt & 15)) & 0xffu) << 8);
-            v4i bx = BX;
-            bx[0] |= (int)(tbytes & tmask);
-#pragma unroll
-            for (int b = 0; b < QB; ++b) accs[cb][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(AX[b], bx, zero, 0, 0, 0);
-            read_x(nbufc, ncb);
-        }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-#pragma unroll
-            for (int b = 0; b < QB; ++b)
-                accs[cb][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[b][s], Bf[s], (!GATED && s == 0) ? negt : accs[cb][b], 0, 0, 0);
-            read_frag(nbuf, ncb, s);
-        }
-        if (!GATED) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) negt[r] -= 1;
-        }
-        // the OTHER half's keys (previous step)
-#pragma unroll
-        for (int b = 0; b < QB; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                running[b][r] = max(running[b][r], accs[cb ^ 1][b][r]);
-                // keep this v_max in THIS half step: fused with the next half's into one v_max3 it would need both
-                // accumulator sets complete at once, which is exactly the wait this loop is built to avoid
-                asm("" : "+v"(running[b][r]));
-            }
-        // issue order
-#pragma unroll
-        for (int i = 0; i < 8 + (GATED ? 1 : 0); ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, QB, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2 * QB, 0);
-        }
-    };
+    const int n_tiles = __builtin_amdgcn_readfirstlane((m_end - m_begin) / AM);
+    unsigned int mine = 0x7fffffffu;            // this thread's query of the block (mine_q) against this chunk
+    int mine_q = threadIdx.x;
     if (n_tiles > 0) {
-        glds_tile(0, 0);
-        glds_tile(min(1, last_tile), 1);
-        glds_tile(min(2, last_tile), 2);
-        if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // byte -> eight int8 operand bytes (bit j of the byte -> +32 / -32), one table for the workgroup: the expansion
+        // of the 2 x 8 fragments is then two 8-byte LDS reads each instead of ~20 vector instructions each (code size
+        // matters here: this straight-line code runs once, and every cold instruction line is a fetch stall)
+        if (threadIdx.x < 256) {
+            const uint32_t t = threadIdx.x;
+            xtab[t] = make_uint2((uint32_t)q_expand(t), (uint32_t)q_expand(t >> 4));
+        }
+        __syncthreads();
+        v4i A[2][8], AX[2];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) read_frag(tile, 0, s);
-        if (GATED) read_x(ctile, 0);
-    }
-    int bcur = 0;
-    for (int k = 0; k < n_tiles; ++k) {
-        const int8_t* cur = tile + bcur * (AM * 256);
-        const int8_t* curc = ctile + bcur * (AM * 32);
-        const int bnext = bcur == 2 ? 0 : bcur + 1;
-        half_step(0, 2 * k, cur, curc, 1);
-        // tile k + 1 has landed (this wave's pieces; tile k + 2 may still be in flight), this wave holds the rest of tile k in registers
-        if (GATED && wave < 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        glds_tile(min(k + 3, last_tile), bcur);
-        half_step(1, 2 * k + 1, tile + bnext * (AM * 256), ctile + bnext * (AM * 32), 0);
-        bcur = bnext;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        for (int b = 0; b < 2; ++b) {
+            const int qi = q0 + 32 * b + r32;
+            uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;        // padding rows: any operand will do, they are never reported
+            if (qi < nq) {
+                c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
+                c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
+            }
+            const uint32_t d[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
 #pragma unroll
-    for (int b = 0; b < QB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) running[b][r] = max(running[b][r], accs[1][b][r]);
-    // key -> (distance, column): 512 * dot = ceil(key / 512) * 512, t = 512 * dot - key; this lane's column inside
-    // block t is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
-    // column can only have displaced candidates with a negative dot, which are beyond 128 and never reported.  A
-    // candidate of another colour (gating) decodes to a distance beyond 128 and is dropped by k_assoc_finish.
-#pragma unroll
-    for (int b = 0; b < QB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = running[b][r];
+            for (int s = 0; s < 8; ++s) {
+                const uint32_t hw = d[s] >> (16 * half);               // code bytes 4 s + 2 half, + 1
+                const uint2 e0 = xtab[hw & 0xffu], e1 = xtab[(hw >> 8) & 0xffu];
+                A[b][s] = v4i{ (int)e0.x, (int)e0.y, (int)e1.x, (int)e1.y };
+            }
+            if (GATED) {
+                // ninth-step operand of a query: [16, 1] counter weights, then 127 in the ten bytes of ITS colour's group
+                const int c = qi < nq ? (int)qcolor[qi] : 255;
+                const int g0 = c == 0 ? 0x7f7f7f7f : 0, g1 = c == 1 ? 0x7f7f7f7f : 0, g2 = c == 2 ? 0x7f7f7f7f : 0;
+                if (half == 0) AX[b] = v4i{ (qi < nq ? 0x0110 : 0) | (g0 & (int)0x7f7f0000), g0, g0, g1 };
+                else AX[b] = v4i{ g1, (g1 & 0x00007f7f) | (g2 & (int)0x7f7f0000), g2, g2 };
+            }
+        }
+        const uint32_t lds_tile = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)tile;
+        const uint32_t vfrag = lds_tile + half * 1024 + r32 * 16;
+        const uint32_t voff = (uint32_t)lane * 16u;
+        const uint32_t vdump = lds_tile + wave * 8192 + lane * 16;
+        const uint64_t mbase = (uint64_t)(size_t)(mx + (size_t)m_begin * 256 + wave * 1024);
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mbase), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mbase >> 32));
+        const uint32_t m0base = __builtin_amdgcn_readfirstlane(lds_tile + wave * 1024);
+        LF_STAMP(2);
+#define LF_A_OPERANDS \
+        [a00] "{v[40:43]}"(A[0][0]), [a01] "{v[44:47]}"(A[0][1]), [a02] "{v[48:51]}"(A[0][2]), [a03] "{v[52:55]}"(A[0][3]), \
+        [a04] "{v[56:59]}"(A[0][4]), [a05] "{v[60:63]}"(A[0][5]), [a06] "{v[64:67]}"(A[0][6]), [a07] "{v[68:71]}"(A[0][7]), \
+        [a10] "{v[72:75]}"(A[1][0]), [a11] "{v[76:79]}"(A[1][1]), [a12] "{v[80:83]}"(A[1][2]), [a13] "{v[84:87]}"(A[1][3]), \
+        [a14] "{v[88:91]}"(A[1][4]), [a15] "{v[92:95]}"(A[1][5]), [a16] "{v[96:99]}"(A[1][6]), [a17] "{v[100:103]}"(A[1][7])
+        if (GATED) {
+            const uint32_t lds_ctile = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ctile;
+            const uint32_t vcfrag = lds_ctile + r32 * 32 + 16 * half;
+            const uint64_t cbase = (uint64_t)(size_t)(mcx + (size_t)m_begin * 32 + (wave & 1) * 1024);
+            const uint32_t clo = __builtin_amdgcn_readfirstlane((uint32_t)cbase), chi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
+            const uint32_t m0c = __builtin_amdgcn_readfirstlane(lds_ctile + (wave & 1) * 1024);
+            const uint32_t tmaskv = half == 0 ? 0xffffu : 0u;          // the counter bytes live in k = 0, 1 (lanes 0..31)
+            const uint64_t mpair = ((uint64_t)mhi << 32) | mlo, cpair = ((uint64_t)chi << 32) | clo;
+            asm volatile(LF_ASSOC_LOOP_GATED
+                         :
+                         : LF_A_OPERANDS, [ax0] "{v[232:235]}"(AX[0]), [ax1] "{v[236:239]}"(AX[1]), [vfrag] "v"(vfrag),
+                           [vcfrag] "v"(vcfrag), [voff] "v"(voff), [vdump] "v"(vdump), [tmaskv] "v"(tmaskv), [mbase] "s"(mpair),
+                           [cbase] "s"(cpair), [m0base] "s"(m0base), [m0c] "s"(m0c), [ntiles] "s"(n_tiles)
+                         : LF_ASSOC_LOOP_CLOBBERS_GATED);
+        } else {
+            const uint64_t mpair = ((uint64_t)mhi << 32) | mlo;
+            asm volatile(LF_ASSOC_LOOP_PLAIN
+                         :
+                         : LF_A_OPERANDS, [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair),
+                           [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
+                         : LF_ASSOC_LOOP_CLOBBERS_PLAIN);
+        }
+#undef LF_A_OPERANDS
+        LF_STAMP(3);
+        // key -> (distance, column): 512 * dot = ceil(key / 512) * 512, t = 512 * dot - key; this lane's column inside
+        // block t is r32.  Padding columns (>= nm; their rows are zero, i.e. "distance 128") are dropped here: a padding
+        // column can only have displaced candidates with a negative dot, which are beyond 128 and never reported.  A
+        // candidate of another colour (gating) decodes to a distance beyond 128 and is dropped below.  Running key
+        // i = 16 b + r of this lane sits in the wave's 8 KB of LDS.
+        // 1) every lane decodes its 32 keys in place (column = 32 t + this lane's r32)
+        int* dump = reinterpret_cast<int*>(tile) + wave * 2048;
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            int* slot = dump + (i >> 2) * 256 + lane * 4 + (i & 3);
+            const int key = *slot;
             int v = 0x7fffffff;
-            if (key != (int)0x80000000) {                             // this lane saw at least one column block
+            if (key != (int)0x80000000) {
                 const int dot512 = (key + 511) & ~511;
                 const int col = m_begin + 32 * (dot512 - key) + r32;
                 if (col < nm) v = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
             }
-#pragma unroll
-            for (int d = 16; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d));
-            if (r32 == 0) {
-                int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                int q = q0 + 32 * b + row;
-                if (q < nq) atomicMin(best + q, (unsigned int)v);
-            }
+            *slot = v;
         }
+        __syncthreads();
+        // 2) one lane per query: key i = 16 b + r of the 32 lanes (r32) of half h is query row (r & 3) + 8 (r >> 2) + 4 h
+        //    of block b; lane (i, h) takes the minimum over r32, reading in an order rotated by i >> 2 (bank spread)
+        {
+            const int i = lane & 31, h = lane >> 5;
+            const int* src = dump + (i >> 2) * 256 + h * 128 + (i & 3);
+            int v = 0x7fffffff;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) v = min(v, src[((k + (i >> 2)) & 31) * 4]);
+            const int b = i >> 4, r = i & 15;
+            mine = (unsigned int)v;
+            mine_q = wave * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+        }
+    }
+    LF_STAMP(4);
+    // The chunk's 256 keys go to this workgroup's row of part[] -- NOT atomicMin on a shared word per query: device-scope
+    // atomics are executed at the memory side, 131 072 of them (16 k queries x 8 chunks) are slow however short the
+    // chunks were.  The row is stored write-through (agent-scope relaxed atomic stores = sc1), drained, and then ONE
+    // atomic per workgroup counts the arrival: no release fence (an agent-scope __threadfence() writes the L2 back and was
+    // measured at 20-30 us per workgroup here).  The last workgroup of a query block to arrive reads the rows of all
+    // chunks with sc1 loads, writes idx / dist for its 256 queries and puts the counter back to zero, so an association is
+    // ONE kernel launch: no init pass, no finish pass.
+    __hip_atomic_store(part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AQW + mine_q, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+    __syncthreads();
+    LF_STAMP(5);
+    if (!s_last) return;
+    const int qq = blockIdx.x * AQW + threadIdx.x;
+    if (qq < nq) {
+        unsigned int v = 0x7fffffffu;
+        for (unsigned int c = 0; c < gridDim.y; ++c)
+            v = min(v, __hip_atomic_load(part + ((size_t)c * gridDim.x + blockIdx.x) * AQW + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int ham = (int)(v >> 22);
+        if (v == 0x7fffffffu || ham > max_distance) { idx[qq] = -1; dist[qq] = -1.f; }
+        else { idx[qq] = (int)(v & 0x1fffffu); dist[qq] = (float)ham; }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(done + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    LF_STAMP(6);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
-                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
-                                               unsigned int* __restrict__ best)
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
 {
-    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];     // triple buffered map tile, linear rows
+    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];     // triple buffered map tile
     __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];     // the tiles' ninth-step operands
-    assoc_body<2, true>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
+    __shared__ uint2 xtab[256];
+    assoc_body<true>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab);
 }
 
-// the same without colour gating: 8 MFMA steps per block, no ninth-step operands streamed
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_plain(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
+// the same without colour gating: 8 MFMA steps per block (the block counter is the chain's start value), no ninth-step
+// operands streamed
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_plain(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
-                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
-                                               unsigned int* __restrict__ best)
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];
-    assoc_body<2, false>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, nullptr);
+    __shared__ uint2 xtab[256];
+    assoc_body<false>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_assoc4(const int8_t* __restrict__ qx, const int8_t* __restrict__ qcx, int nq,
-                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
-                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
-                                               unsigned int* __restrict__ best)
+__global__ void k_fill_u32(unsigned int* p, size_t n, unsigned int v)
 {
-    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];
-    __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];
-    assoc_body<4, true>(qx, qcx, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, best, tile, ctile);
-}
-
-__global__ void k_assoc_finish(const unsigned int* __restrict__ best, int nq, int max_distance, int32_t* __restrict__ idx,
-                               float* __restrict__ dist)
-{
-    int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nq) return;
-    unsigned int v = best[q];
-    int ham = (int)(v >> 22);
-    if (v == 0x7fffffffu || ham > max_distance) { idx[q] = -1; dist[q] = -1.f; }
-    else { idx[q] = (int)(v & 0x1fffffu); dist[q] = (float)ham; }
-}
-
-__global__ void k_fill_u32(unsigned int* p, int n, unsigned int v)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
 
@@ -329,66 +288,87 @@ void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s)
     if (nq > 0) hipLaunchKernelGGL(k_fill_nomatch, dim3((nq + 255) / 256), dim3(256), 0, s, nq, idx, dist);
 }
 
-size_t assoc_rows_padded_q(int nq) { return ((size_t)nq + AQ - 1) / AQ * AQ; }
 size_t assoc_rows_padded_m(int nm) { return ((size_t)nm + AM - 1) / AM * AM; }
 
-void launch_assoc_pack(const uint8_t* codes, const uint8_t* colors, int side, int gating, int n, int n_pad, int8_t* x,
-                       int8_t* cx, hipStream_t s)
+// part[] (one word per query and map chunk, written before it is read by every launch) and done[] (one arrival counter
+// per 256-query block, idle 0: the kernel leaves it idle, so it is cleared only when it is (re)allocated)
+static hipError_t assoc_scratch_reserve(AssocScratch& w, size_t qblocks, size_t splits, hipStream_t s)
+{
+    hipError_t e;
+    if (qblocks * splits > w.cap_part) {
+        if (w.part) { if ((e = hipStreamSynchronize(s)) != hipSuccess) return e; (void)hipFree(w.part); w.part = nullptr; w.cap_part = 0; }
+        const size_t cap = qblocks * splits + qblocks * splits / 2;
+        if ((e = hipMalloc((void**)&w.part, cap * AQW * sizeof(unsigned int))) != hipSuccess) return e;
+        w.cap_part = cap;
+    }
+    if (qblocks > w.cap_blocks) {
+        if (w.done) { if ((e = hipStreamSynchronize(s)) != hipSuccess) return e; (void)hipFree(w.done); w.done = nullptr; w.cap_blocks = 0; }
+        const size_t cap = qblocks + qblocks / 2 + 8;
+        if ((e = hipMalloc((void**)&w.done, cap * sizeof(int))) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(w.done, 0, cap * sizeof(int), s)) != hipSuccess) return e;
+        w.cap_blocks = cap;
+    }
+    return hipSuccess;
+}
+
+void assoc_scratch_free(AssocScratch& w)
+{
+    if (w.part) (void)hipFree(w.part);
+    if (w.done) (void)hipFree(w.done);
+    w.part = nullptr; w.done = nullptr; w.cap_part = 0; w.cap_blocks = 0;
+}
+
+void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int8_t* x, int8_t* cx, hipStream_t s)
 {
     if (n_pad <= 0) return;
-    hipLaunchKernelGGL(k_assoc_pack, dim3(((size_t)n_pad * 32 + 255) / 256), dim3(256), 0, s, codes, colors, side, gating, n,
-                       n_pad, x, cx);
+    hipLaunchKernelGGL(k_assoc_pack_map, dim3(((size_t)n_pad * 32 + 255) / 256), dim3(256), 0, s, codes, colors, n, n_pad, x, cx);
 }
 
-// association of packed queries against a packed map (the live map keeps its side packed across calls;
-// lf_associate packs its caller's raw map first)
-void launch_assoc_core(const int8_t* qx, const int8_t* qcx, int nq, const int8_t* mx, const int8_t* mcx, int nm,
-                       const int* nm_dev, int gating, int max_distance, unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+// association of raw query codes against a packed map (the live map keeps its side packed across calls; lf_associate
+// packs its caller's raw map first).  ONE launch.
+hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const int8_t* mcx, int nm,
+                       const int* nm_dev, int gating, int max_distance, AssocScratch& w, int32_t* idx, float* dist, hipStream_t s)
 {
-    const int nq_pad = (int)assoc_rows_padded_q(nq), nm_pad = (int)assoc_rows_padded_m(nm);
-    hipLaunchKernelGGL(k_fill_u32, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, 0x7fffffffu);
+    const int nm_pad = (int)assoc_rows_padded_m(nm);
     const int tiles = nm_pad / AM;
     const int min_splits = (nm_pad + (kMaxBlocksPerChunk * 32) - 1) / (kMaxBlocksPerChunk * 32);
-    // Shape: 512-query workgroups (one per CU, QB = 4) once there are enough queries to give every CU a chunk of at
-    // least 16 tiles; below that the 256-query shape, two workgroups per CU.
-    const int qb4 = (nq_pad + 511) / 512;
-    int sp4 = 256 / qb4;
-    if (sp4 < 1) sp4 = 1;
-    // measured on MI355X: the 512-query shape is SLOWER (34 % vs 40 % of the int8 peak at 16 k x 50 k): with one wave per
-    // SIMD nothing covers a wave's LDS reads and barrier waits.  Kept for experiments (LF_ASSOC_QB4=1), not used.
-    static const bool allow_big = getenv("LF_ASSOC_QB4") != nullptr;
-    const bool big = allow_big && qb4 >= 4 && tiles / sp4 >= 16;
-    if (big) {
-        // one round of (at most) 256 workgroups; more query blocks than CUs: whole rounds
-        int splits = sp4;
-        if (splits < min_splits) splits = min_splits;
-        if (splits > tiles) splits = tiles;
-        const int m_chunk = (tiles + splits - 1) / splits * AM;
-        splits = (nm_pad + m_chunk - 1) / m_chunk;
-        hipLaunchKernelGGL(k_assoc4, dim3(qb4, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
-    } else {
-        const int qblocks = nq_pad / 256;
-        // 2 workgroups are resident per CU: split the map so that the grid is just under two full rounds of the 512
-        // slots -- long chunks amortise the A-fragment loads and the final cross-lane reduction
-        static const int slots = getenv("LF_ASSOC_SLOTS") ? atoi(getenv("LF_ASSOC_SLOTS")) : 512;   // one round of two workgroups per CU (measured best: 512 > 1024 > 768)
-        int splits = slots / qblocks;
-        if (splits < min_splits) splits = min_splits;
-        if (splits > tiles) splits = tiles;
-        if (splits < 1) splits = 1;
-        const int m_chunk = (tiles + splits - 1) / splits * AM;
-        splits = (nm_pad + m_chunk - 1) / m_chunk;
-        if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
-        else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, qx, qcx, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, best);
+    const int qblocks = (nq + AQW - 1) / AQW;
+    // 2 workgroups are resident per CU: split the map so that the grid is one round of the 512 slots -- long chunks
+    // amortise the query expansion and the final cross-lane reduction (measured: 512 > 1024 > 768 > 256)
+    static const int slots = getenv("LF_ASSOC_SLOTS") ? atoi(getenv("LF_ASSOC_SLOTS")) : 512;
+    int splits = slots / qblocks;
+    if (splits < min_splits) splits = min_splits;
+    if (splits > tiles) splits = tiles;
+    if (splits < 1) splits = 1;
+    const int m_chunk = (tiles + splits - 1) / splits * AM;
+    splits = (nm_pad + m_chunk - 1) / m_chunk;
+    hipError_t e = assoc_scratch_reserve(w, (size_t)qblocks, (size_t)splits, s);
+    if (e != hipSuccess) return e;
+    if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
+    else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
+#ifdef LF_ASSOC_STAMPS
+    {
+        static int calls = 0;
+        if (++calls == 12) {
+            (void)hipDeviceSynchronize();
+            static unsigned long long h[8 * 8192];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_assoc_stamps), sizeof(h));
+            const int n = qblocks * splits < 8192 ? qblocks * splits : 8192;
+            unsigned long long w0 = ~0ull, w1 = 0; double d[8] = { 0 };
+            for (int i = 0; i < n; ++i) { const unsigned long long* t = h + 8 * i; if (t[0] < w0) w0 = t[0]; if (t[0] > w1) w1 = t[0]; for (int k = 2; k <= 5; ++k) d[k] += (double)(t[k] - t[k - 1]); }
+            fprintf(stderr, "[assoc stamps] %d workgroups (%d x %d): start skew %.2f us | setup %.0f  loop %.0f  reduce %.0f  publish %.0f cycles (mean per workgroup)\n",
+                    n, qblocks, splits, (double)(w1 - w0) / 100.0, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
+        }
     }
-    hipLaunchKernelGGL(k_assoc_finish, dim3((nq + 255) / 256), dim3(256), 0, s, best, nq, max_distance, idx, dist);
+#endif
+    return hipGetLastError();
 }
 
-void launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* qx, int8_t* qcx, int8_t* mx, int8_t* mcx,
-                  unsigned int* best, int32_t* idx, float* dist, hipStream_t s)
+hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
+                        float* dist, hipStream_t s)
 {
-    launch_assoc_pack(m, nullptr, 1, 0, nm, (int)assoc_rows_padded_m(nm), mx, mcx, s);
-    launch_assoc_pack(q, nullptr, 0, 0, nq, (int)assoc_rows_padded_q(nq), qx, qcx, s);
-    launch_assoc_core(qx, qcx, nq, mx, mcx, nm, nullptr, 0, 128, best, idx, dist, s);
+    launch_assoc_pack_map(m, nullptr, nm, (int)assoc_rows_padded_m(nm), mx, mcx, s);
+    return launch_assoc_core(q, nullptr, nq, mx, mcx, nm, nullptr, 0, 128, w, idx, dist, s);
 }
 
 // ---------------------------------------------------------------- float LBD (72-d)

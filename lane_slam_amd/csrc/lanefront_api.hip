@@ -98,7 +98,8 @@ struct lf_handle {
     float* d_centers = nullptr;
     int out_capacity = 0;
     // associator scratch (grown on demand)
-    DevBuf a_q, a_m, a_qx, a_mx, a_qcx, a_mcx, a_best, a_idx, a_dist, a_qn, a_mn;
+    DevBuf a_q, a_m, a_mx, a_mcx, a_best, a_idx, a_dist, a_qn, a_mn;
+    AssocScratch a_ws;
     // pinned host scalars
     int* h_pinned = nullptr;     // [0] total segments, [1] overflow
     int last_frames = 0;
@@ -447,8 +448,9 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->a_q.p, h->a_m.p, h->a_qx.p, h->a_mx.p, h->a_qcx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
+                     h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    assoc_scratch_free(h->a_ws);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     for (DevBuf* b : { &h->m_fo, &h->m_color, &h->m_pn, &h->m_nm, &h->m_gr, &h->m_keep, &h->m_counts, &h->m_boff, &h->m_body, &h->m_bad })
         if (b->p) (void)hipFree(b->p);
@@ -741,10 +743,9 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
         } else { memcpy(idx, hi.data(), nq * sizeof(int32_t)); memcpy(dist, hd.data(), nq * sizeof(float)); }
         return LF_OK;
     }
-    const size_t nq_pad = assoc_rows_padded_q(nq), nm_pad = assoc_rows_padded_m(nm);
+    const size_t nm_pad = assoc_rows_padded_m(nm);
     int rc;
-    if ((rc = ensure(h, h->a_qx, nq_pad * 256)) || (rc = ensure(h, h->a_mx, nm_pad * 256)) || (rc = ensure(h, h->a_qcx, nq_pad * 32)) ||
-        (rc = ensure(h, h->a_mcx, nm_pad * 32)) || (rc = ensure(h, h->a_best, (size_t)nq * 8))) return rc;
+    if ((rc = ensure(h, h->a_mx, nm_pad * 256)) || (rc = ensure(h, h->a_mcx, nm_pad * 32))) return rc;
     const uint8_t *dq = query32, *dmp = map32;
     int32_t* didx = idx; float* ddist = dist;
     if (!on_device) {
@@ -756,8 +757,7 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
     }
     {
         StageTimer t(h, ST_ASSOC);
-        launch_assoc(dq, nq, dmp, nm, (int8_t*)h->a_qx.p, (int8_t*)h->a_qcx.p, (int8_t*)h->a_mx.p, (int8_t*)h->a_mcx.p,
-                     (unsigned int*)h->a_best.p, didx, ddist, s);
+        LF_HIP_CHECK(h, launch_assoc(dq, nq, dmp, nm, (int8_t*)h->a_mx.p, (int8_t*)h->a_mcx.p, h->a_ws, didx, ddist, s));
     }
     LF_HIP_CHECK(h, hipGetLastError());
     if (!on_device) {

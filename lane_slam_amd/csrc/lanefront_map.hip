@@ -25,7 +25,8 @@ struct lf_map {
     hipEvent_t ev_state = nullptr, ev_in = nullptr, ev_out = nullptr;
     bool state_pending = false;
     long long rows_in_flight = 0;            // rows handed to updates whose state copy has not been seen yet
-    Buf qx, qcx, best, act, own_block, pose, q_in, c_in, idx_out, dist_out, seed_code, seed_color, seed_ground;
+    AssocScratch ws;
+    Buf act, own_block, pose, q_in, c_in, idx_out, dist_out, seed_code, seed_color, seed_ground;
     Buf st_fo, st_code, st_color, st_keep, st_ground, st_idx, st_dist;     // staging of lf_map_step_host
     std::vector<double> h_pose;
     // per-stage timing with HIP events on the map's stream (resolved by lf_map_get_timing)
@@ -134,7 +135,7 @@ static int release_handle(lf_map* m, lf_handle* h)
     return LF_OK;
 }
 
-static const char* kMapStageNames[LF_MAP_N_STAGES] = { "assoc_pack_queries", "assoc_mfma", "map_pack_block", "map_update" };
+static const char* kMapStageNames[LF_MAP_N_STAGES] = { "assoc_pack_queries", "assoc_mfma", "map_pack_block", "map_update" };   // stage 0 is gone (queries are expanded inside the association kernel): always 0 calls
 
 extern "C" const char* lf_map_stage_name(int stage) { return (stage >= 0 && stage < LF_MAP_N_STAGES) ? kMapStageNames[stage] : "?"; }
 
@@ -173,7 +174,8 @@ extern "C" void lf_map_destroy(lf_map* m)
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     void* ptrs[] = { m->d.code, m->d.color, m->d.ground, m->d.hits, m->d.last_seen, m->d.winner, m->d.mx, m->d.mcx, m->d.state, m->d.totals };
     for (void* p : ptrs) if (p) (void)hipFree(p);
-    for (Buf* b : { &m->qx, &m->qcx, &m->best, &m->act, &m->own_block, &m->pose, &m->q_in, &m->c_in, &m->idx_out, &m->dist_out, &m->seed_code, &m->seed_color, &m->seed_ground,
+    assoc_scratch_free(m->ws);
+    for (Buf* b : { &m->act, &m->own_block, &m->pose, &m->q_in, &m->c_in, &m->idx_out, &m->dist_out, &m->seed_code, &m->seed_color, &m->seed_ground,
                      &m->st_fo, &m->st_code, &m->st_color, &m->st_keep, &m->st_ground, &m->st_idx, &m->st_dist })
         if (b->p) (void)hipFree(b->p);
     if (m->h_state) (void)hipHostFree(m->h_state);
@@ -370,17 +372,11 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
         // descriptor matrices cannot be void (binary_descriptor_matcher.cpp:201-205): report "no match"
         launch_assoc_nomatch(n, didx, ddist, s);
     } else {
-        const size_t nq_pad = assoc_rows_padded_q(n);
-        if ((rc = grow(m, m->qx, nq_pad * 256)) || (rc = grow(m, m->qcx, nq_pad * 32)) || (rc = grow(m, m->best, (size_t)n * 4))) return rc;
         {
-            MapTimer t(m, 0);
-            launch_assoc_pack(dq, m->cfg.color_gating ? dc : nullptr, 0, m->cfg.color_gating, n, (int)nq_pad, static_cast<int8_t*>(m->qx.p),
-                              static_cast<int8_t*>(m->qcx.p), s);
-        }
-        {
+            // one launch: query operands are expanded in registers, results are written by the last workgroup to arrive
             MapTimer t(m, 1);
-            launch_assoc_core(static_cast<const int8_t*>(m->qx.p), static_cast<const int8_t*>(m->qcx.p), n, m->d.mx, m->d.mcx, size,
-                              m->d.state, m->cfg.color_gating, m->cfg.max_distance, static_cast<unsigned int*>(m->best.p), didx, ddist, s);
+            MAP_HIP(m, launch_assoc_core(dq, m->cfg.color_gating ? dc : nullptr, n, m->d.mx, m->d.mcx, size, m->d.state, m->cfg.color_gating,
+                                         m->cfg.max_distance, m->ws, didx, ddist, s));
         }
     }
     MAP_HIP(m, hipGetLastError());

@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Generates lane_slam_amd/csrc/k_assoc_loop.inc: the associator's tile loop (k_assoc.hip) as gfx950 assembly.
+
+The loop is 32 v_mfma_i32_32x32x32_i8 per 64-row map tile and wave, and what decides its speed is the ORDER of the
+instructions around them: every B fragment must be on its way from LDS while the MFMAs of the previous one run, the
+arg-max of a half tile (one v_max per accumulator register) must issue under the MFMAs of the next half, the LDS-DMA
+pieces of the tile three ahead must be spread between them, and nothing may wait for an MFMA result.  hipcc's scheduler
+does not keep such an order (it fuses the two v_max into a v_max3 that needs both accumulator sets at once, copies the
+loop-carried set, and serialises the chains), so the loop is emitted here instruction by instruction with a fixed
+register map.  Run `python tools/gen_assoc_loop.py` after changing it; the .inc file is committed.
+
+Register map (VGPRs, clobbered by the asm statement; the compiler keeps v0..v39):
+  v[40:103]   A[b][s]     query fragments, b = 0,1 (32 queries each), s = 0..7 (32 bits of the code each); INPUTS of
+              the statement (bound to these registers by "{v[..]}" constraints), like AX below
+  v[104:135]  Bf[s]       map fragments of the current half tile; fragment s is refreshed in place right after its MFMAs
+  v[136:167]  accP[b]     accumulators of half 0 (map rows 0..31 of the tile)
+  v[168:199]  accQ[b]     accumulators of half 1
+  v[200:231]  running[b][r]  running arg-max keys
+  plain:  v[232:247] negt (the block counter, C operand of the first MFMA of a chain)
+  gated:  v[232:239] AX[b] (ninth-step query operands), v[240:243] BX (ninth-step map operand), v245 scratch
+  v248, v249  fragment read base in the LDS buffer of the current / next tile;  v250, v251 the same for the ninth-step rows
+SGPRs s40..s57 are scratch (s[50:51] / s[52:53]: base address of the map chunk / of its ninth-step rows; s54 / s55:
+byte offset of the current / next LDS buffer).
+Hazards (no hardware interlock): an MFMA result is read by a VALU op at least two MFMAs later; a VALU-written MFMA
+operand is followed by s_nop 1; M0 is followed by s_nop 0 before the LDS-DMA that uses it.
+"""
+import os
+
+A0, BF, ACCP, ACCQ, RUN, NEGT = 40, 104, 136, 168, 200, 232
+AX, BX, TMPV = 232, 240, 245
+VB_CUR, VB_NEXT, VC_CUR, VC_NEXT = 248, 249, 250, 251
+
+
+def rng(base, n):
+    return "v[%d:%d]" % (base, base + n - 1)
+
+
+def gen(gated):
+    L = []
+    e = L.append
+    n_piece = 5 if gated else 4
+    lgk_half0 = 8 if gated else 7
+
+    def dma_piece(buf, p):
+        # piece p of the tile whose address is in s[42:43] (ninth-step rows: s[48:49]) into LDS buffer `buf`
+        # (a number in the prologue; None inside the loop = the buffer of the current tile, byte offset in s54)
+        if p < 4:
+            if buf is None:
+                e("s_add_u32 s45, %[m0base], s54")
+                if p:
+                    e("s_add_u32 s45, s45, %d" % (p * 4096))
+            else:
+                e("s_add_u32 s45, %%[m0base], %d" % (buf * 16384 + p * 4096))
+            e("s_mov_b32 m0, s45")
+            e("s_nop 0")
+            e("global_load_lds_dwordx4 %[voff], s[42:43]")
+            e("s_add_u32 s42, s42, 4096")
+            e("s_addc_u32 s43, s43, 0")
+        else:
+            if buf is None:
+                e("s_lshr_b32 s45, s54, 3")
+                e("s_add_u32 s45, %[m0c], s45")
+            else:
+                e("s_add_u32 s45, %%[m0c], %d" % (buf * 2048))
+            e("s_mov_b32 m0, s45")
+            e("s_nop 0")
+            e("global_load_lds_dwordx4 %[voff], s[48:49]")
+
+    def tile_address(from_k_plus):
+        # s[42:43] (and s[48:49]) = address of tile min(k + from_k_plus, last)
+        e("s_add_i32 s44, s40, %d" % from_k_plus)
+        e("s_min_i32 s44, s44, s41")
+        e("s_lshl_b32 s42, s44, 14")
+        e("s_add_u32 s42, s50, s42")
+        e("s_addc_u32 s43, s51, 0")
+        if gated:
+            e("s_lshl_b32 s48, s44, 11")
+            e("s_add_u32 s48, s52, s48")
+            e("s_addc_u32 s49, s53, 0")
+
+    def tb(half):
+        # s46 = the two counter bytes of column block tt = 2 k + half: [-(tt >> 4), -(tt & 15)]
+        e("s_lshl_b32 s46, s40, 1")
+        if half:
+            e("s_or_b32 s46, s46, 1")
+        e("s_lshr_b32 s47, s46, 4")
+        e("s_sub_u32 s47, 0, s47")
+        e("s_and_b32 s47, s47, 0xff")
+        e("s_and_b32 s46, s46, 15")
+        e("s_sub_u32 s46, 0, s46")
+        e("s_and_b32 s46, s46, 0xff")
+        e("s_lshl_b32 s46, s46, 8")
+        e("s_or_b32 s46, s46, s47")
+
+    def half_step(half):
+        acc = ACCP if half == 0 else ACCQ
+        other = ACCQ if half == 0 else ACCP
+        vb = "v%d" % (VB_CUR if half == 0 else VB_NEXT)
+        vc = "v%d" % (VC_CUR if half == 0 else VC_NEXT)
+        roff = 512 if half == 0 else 0          # rows 32..63 of the current tile / rows 0..31 of the next
+        if gated:
+            tb(half)
+            if half == 0:
+                e("s_waitcnt lgkmcnt(%d)" % lgk_half0)
+            e("v_and_b32 v%d, s46, %%[tmaskv]" % TMPV)
+            e("v_or_b32 v%d, v%d, v%d" % (BX, BX, TMPV))
+            e("s_nop 1")
+            for b in range(2):
+                e("v_mfma_i32_32x32x32_i8 %s, %s, %s, 0" % (rng(acc + 16 * b, 16), rng(AX + 4 * b, 4), rng(BX, 4)))
+            e("ds_read_b128 %s, %s offset:%d" % (rng(BX, 4), vc, 1024 if half == 0 else 0))
+        for s in range(8):
+            if half == 0:
+                e("s_waitcnt lgkmcnt(%d)" % lgk_half0)
+            for b in range(2):
+                c = rng(NEGT, 16) if (s == 0 and not gated) else rng(acc + 16 * b, 16)
+                e("v_mfma_i32_32x32x32_i8 %s, %s, %s, %s" % (rng(acc + 16 * b, 16), rng(A0 + 32 * b + 4 * s, 4), rng(BF + 4 * s, 4), c))
+            e("ds_read_b128 %s, %s offset:%d" % (rng(BF + 4 * s, 4), vb, s * 2048 + roff))
+            for j in range(4):
+                i = 4 * s + j
+                e("v_max_i32 v%d, v%d, v%d" % (RUN + i, RUN + i, other + i))
+            if not gated and s >= 4:
+                for j in range(4):
+                    r = 4 * (s - 4) + j
+                    e("v_add_u32 v%d, -1, v%d" % (NEGT + r, NEGT + r))
+            if half == 0 and s == 1:
+                tile_address(3)
+            if half == 1 and s in (0, 2, 4, 6):
+                dma_piece(None, s // 2)
+            if half == 1 and gated and s == 7:
+                dma_piece(None, 4)
+
+    # ---------------- prologue
+    # (the query fragments A[b][s] -- and AX[b] -- arrive in their registers as operands of the statement)
+    e("s_mov_b64 s[50:51], %[mbase]")
+    if gated:
+        e("s_mov_b64 s[52:53], %[cbase]")
+    for i in range(32):
+        e("v_bfrev_b32 v%d, 1" % (RUN + i))
+        e("v_bfrev_b32 v%d, 1" % (ACCQ + i))
+    if not gated:
+        for r in range(16):
+            e("v_mov_b32 v%d, 0" % (NEGT + r))
+    e("v_mov_b32 v%d, %%[vfrag]" % VB_CUR)
+    e("v_add_u32 v%d, 16384, %%[vfrag]" % VB_NEXT)
+    if gated:
+        e("v_mov_b32 v%d, %%[vcfrag]" % VC_CUR)
+        e("v_add_u32 v%d, 2048, %%[vcfrag]" % VC_NEXT)
+    e("s_mov_b32 s40, 0")
+    e("s_add_i32 s41, %[ntiles], -1")
+    e("s_mov_b32 s54, 0")
+    e("s_mov_b32 s55, 16384")
+    for t in range(3):
+        tile_address(t)
+        for p in range(n_piece):
+            dma_piece(t, p)
+    e("s_waitcnt vmcnt(%d)" % (2 * n_piece))
+    e("s_barrier")
+    for s in range(8):
+        e("ds_read_b128 %s, %%[vfrag] offset:%d" % (rng(BF + 4 * s, 4), s * 2048))
+    if gated:
+        # issued AFTER the eight fragments here, BEFORE them in the loop: the first half 0 waits for everything
+        e("ds_read_b128 %s, %%[vcfrag]" % rng(BX, 4))
+        e("s_waitcnt lgkmcnt(0)")
+    # ---------------- the loop: ONE copy of the tile body (instruction fetch is not free: a cold 64-byte line costs
+    # hundreds of cycles and every wave of the chip runs this code at the same moment), the three LDS buffers rotate
+    # through s54 / s55 (byte offset of the current / next buffer) and the read bases derived from them
+    e("LT_%=:")
+    half_step(0)
+    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % n_piece)
+    e("s_barrier")
+    half_step(1)
+    e("v_mov_b32 v%d, v%d" % (VB_CUR, VB_NEXT))
+    e("s_mov_b32 s54, s55")
+    e("s_add_u32 s55, s55, 16384")
+    e("s_cmp_eq_u32 s55, 49152")
+    e("s_cselect_b32 s55, 0, s55")
+    e("v_add_u32 v%d, s55, %%[vfrag]" % VB_NEXT)
+    if gated:
+        e("v_mov_b32 v%d, v%d" % (VC_CUR, VC_NEXT))
+        e("s_lshr_b32 s56, s55, 3")
+        e("v_add_u32 v%d, s56, %%[vcfrag]" % VC_NEXT)
+    e("s_add_i32 s40, s40, 1")
+    e("s_cmp_lt_i32 s40, %[ntiles]")
+    e("s_cbranch_scc1 LT_%=")
+    # ---------------- epilogue: last half's keys, then the running keys go to LDS (the tile buffers are free)
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_nop 7")
+    e("s_nop 7")
+    for i in range(32):
+        e("v_max_i32 v%d, v%d, v%d" % (RUN + i, RUN + i, ACCQ + i))
+    e("s_barrier")
+    for i in range(8):
+        e("ds_write_b128 %%[vdump], %s offset:%d" % (rng(RUN + 4 * i, 4), i * 1024))
+    e("s_waitcnt lgkmcnt(0)")
+    return L
+
+
+def c_string(lines):
+    return "\n".join('    "%s\\n\\t"' % ln for ln in lines)
+
+
+def main():
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lane_slam_amd", "csrc", "k_assoc_loop.inc")
+    sclob = ", ".join('"s%d"' % i for i in range(40, 58)) + ', "memory", "scc"'
+    clob_plain = ", ".join('"v%d"' % i for i in range(104, 252)) + ", " + sclob
+    clob_gated = ", ".join('"v%d"' % i for i in list(range(104, 232)) + list(range(240, 252))) + ", " + sclob
+    with open(out, "w") as f:
+        f.write("// GENERATED by tools/gen_assoc_loop.py -- do not edit; see that file for the register map and the schedule.\n")
+        f.write("#define LF_ASSOC_LOOP_PLAIN \\\n" + c_string(gen(False)).replace("\n", " \\\n") + "\n\n")
+        f.write("#define LF_ASSOC_LOOP_GATED \\\n" + c_string(gen(True)).replace("\n", " \\\n") + "\n\n")
+        f.write("#define LF_ASSOC_LOOP_CLOBBERS_PLAIN " + clob_plain + "\n")
+        f.write("#define LF_ASSOC_LOOP_CLOBBERS_GATED " + clob_gated + "\n")
+    print("wrote", os.path.normpath(out), "plain", len(gen(False)), "gated", len(gen(True)), "instructions")
+
+
+if __name__ == "__main__":
+    main()
