@@ -25,47 +25,62 @@ constexpr int CT_W = 64, CT_H = 16;
 __global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint32_t* __restrict__ bgr,
                                                    uint32_t* __restrict__ strong, uint32_t* __restrict__ weak)
 {
-    __shared__ uint32_t px[(CT_H + 4) * (CT_W + 4)];
+    // the working image's pixels, unpacked ONCE when they are loaded: B | R << 16 (two 16-bit lanes for packed
+    // arithmetic) and G.  Every magnitude pixel reads its eight neighbours from both planes: no byte extraction in
+    // the 8-fold reused inner formula.
+    __shared__ uint32_t pbr[(CT_H + 4) * (CT_W + 4)];
+    __shared__ uint32_t pg[(CT_H + 4) * (CT_W + 4)];
     __shared__ int mag[(CT_H + 2) * (CT_W + 2)];
     __shared__ int gxy[(CT_H + 2) * (CT_W + 2)];
     int tbx, tby, f;
     lf_xcd_tile(tbx, tby, f);
     const int x0 = tbx * CT_W, y0 = tby * CT_H;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint32_t* img = bgr + (size_t)f * p.Hc * p.W;
     constexpr int PW = CT_W + 4, PH = CT_H + 4, MW = CT_W + 2, MH = CT_H + 2;
+    typedef short s2 __attribute__((ext_vector_type(2)));
 
+    const int tid = threadIdx.y * 64 + threadIdx.x;
     for (int idx = tid; idx < PW * PH; idx += 256) {
-        int ty = idx / PW, tx = idx - ty * PW;
-        int gx = min(max(x0 + tx - 2, 0), p.W - 1);
-        int gy = min(max(y0 + ty - 2, 0), p.Hc - 1);
-        px[idx] = img[(size_t)gy * p.W + gx];
+        const int ty = idx / PW, tx = idx - ty * PW;
+        const int gx = min(max(x0 + tx - 2, 0), p.W - 1);
+        const int gy = min(max(y0 + ty - 2, 0), p.Hc - 1);
+        const uint32_t a = img[(size_t)gy * p.W + gx];
+        pbr[idx] = a & 0x00ff00ffu;
+        pg[idx] = (a >> 8) & 0xffu;
     }
     __syncthreads();
-    for (int idx = tid; idx < MW * MH; idx += 256) {
-        int ty = idx / MW, tx = idx - ty * MW;
-        int gx = x0 + tx - 1, gy = y0 + ty - 1;
-        int best = 0, bx = 0, by = 0;
-        if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
-            best = -1;
-            const uint32_t* c = px + (ty + 1) * PW + (tx + 1);
-            uint32_t a00 = c[-PW - 1], a01 = c[-PW], a02 = c[-PW + 1];
-            uint32_t a10 = c[-1], a12 = c[1];
-            uint32_t a20 = c[PW - 1], a21 = c[PW], a22 = c[PW + 1];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                int sh = 8 * ch;
-                int v00 = (a00 >> sh) & 255, v01 = (a01 >> sh) & 255, v02 = (a02 >> sh) & 255;
-                int v10 = (a10 >> sh) & 255, v12 = (a12 >> sh) & 255;
-                int v20 = (a20 >> sh) & 255, v21 = (a21 >> sh) & 255, v22 = (a22 >> sh) & 255;
-                int dx = (v02 - v00) + 2 * (v12 - v10) + (v22 - v20);
-                int dy = (v20 - v00) + 2 * (v21 - v01) + (v22 - v02);
-                int m = abs(dx) + abs(dy);
-                if (m > best) { best = m; bx = dx; by = dy; }
+    {
+        for (int idx = tid; idx < MW * MH; idx += 256) {
+            const int ty = idx / MW, tx = idx - ty * MW;
+            const int gx = x0 + tx - 1, gy = y0 + ty - 1;
+            int best = 0, bx = 0, by = 0;
+            if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
+                const int o = (ty + 1) * PW + (tx + 1);
+                // B and R together, two signed 16-bit lanes (|dx|, |dy| <= 1020)
+                const uint32_t* c = pbr + o;
+                const s2 v00 = __builtin_bit_cast(s2, c[-PW - 1]), v01 = __builtin_bit_cast(s2, c[-PW]), v02 = __builtin_bit_cast(s2, c[-PW + 1]);
+                const s2 v10 = __builtin_bit_cast(s2, c[-1]), v12 = __builtin_bit_cast(s2, c[1]);
+                const s2 v20 = __builtin_bit_cast(s2, c[PW - 1]), v21 = __builtin_bit_cast(s2, c[PW]), v22 = __builtin_bit_cast(s2, c[PW + 1]);
+                const s2 two = { 2, 2 }, zero = { 0, 0 };
+                const s2 dx2 = (v02 - v00) + (v22 - v20) + two * (v12 - v10);
+                const s2 dy2 = (v20 - v00) + (v22 - v02) + two * (v21 - v01);
+                const s2 ax2 = __builtin_elementwise_max(dx2, zero - dx2), ay2 = __builtin_elementwise_max(dy2, zero - dy2);
+                const s2 m2 = ax2 + ay2;
+                // G in plain integers
+                const uint32_t* g = pg + o;
+                const int g00 = (int)g[-PW - 1], g01 = (int)g[-PW], g02 = (int)g[-PW + 1], g10 = (int)g[-1], g12 = (int)g[1];
+                const int g20 = (int)g[PW - 1], g21 = (int)g[PW], g22 = (int)g[PW + 1];
+                const int dxg = (g02 - g00) + 2 * (g12 - g10) + (g22 - g20);
+                const int dyg = (g20 - g00) + 2 * (g21 - g01) + (g22 - g02);
+                const int mg = abs(dxg) + abs(dyg);
+                // channel order B, G, R; the first of equal magnitudes wins
+                best = (int)m2.x; bx = (int)dx2.x; by = (int)dy2.x;
+                if (mg > best) { best = mg; bx = dxg; by = dyg; }
+                if ((int)m2.y > best) { best = (int)m2.y; bx = (int)dx2.y; by = (int)dy2.y; }
             }
+            mag[idx] = best;
+            gxy[idx] = (bx & 0xFFFF) | (by << 16);
         }
-        mag[idx] = best;
-        gxy[idx] = (bx & 0xFFFF) | (by << 16);
     }
     __syncthreads();
     const int TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5);
