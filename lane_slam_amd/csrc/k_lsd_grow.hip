@@ -5,12 +5,15 @@
 
 namespace lf {
 
-// Occupancy knobs.  The kernel is latency bound (one wave per problem, long dependent chains), so what
-// matters is how many problems -- and how many waves of the OTHER batches' streaming kernels -- fit on
-// a CU next to each other: 128 VGPRs (4 waves per SIMD; rect_improve regenerates its candidates instead
-// of keeping five rectangles live, so nothing hot spills) and 13 KB of LDS per problem (12 per CU).
+// Occupancy knobs.  The kernel is latency bound (one wave per component, long dependent chains) and the pipelined
+// rate follows the number of growing waves the chip can hold: capping the kernel at 12 waves per CU instead of 16 costs
+// 12 % of the frames/s, so the register budget is 96 VGPRs = FIVE waves per SIMD (20 per CU).  The compiler's natural
+// allocation is 128 (rect_improve already regenerates its candidates instead of keeping five rectangles live); at 96
+// about a hundred values are spilled around rect_improve and the seed loop, which costs 3 % of the kernel's solo time
+// and still nets +2.2 % frames/s with six batches in flight (80 VGPRs / six waves: no further gain).  13 KB of LDS per
+// problem (12 per CU) stays above the wave limit.
 #ifndef LFG_WAVES
-#define LFG_WAVES 4
+#define LFG_WAVES 5
 #endif
 #ifndef LFG_LDS_KB
 #define LFG_LDS_KB 13
