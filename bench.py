@@ -298,7 +298,7 @@ def main():
             "metric": "frames/sec (%dx%d) detect->descript->project->sanity->associate" % (in_cols, in_rows),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (i8 MFMA for association)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (FP4 e2m1 MFMA with exact f32 accumulation for association; i8 MFMA when colour gated)", "data": "synthetic",
             "config": {"workload": "%s%d-frame batch per GPU of %dx%d synthetic lane frames (%d distinct), %s geometry (working image %dx%d, "
                                    "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs the %d-entry live map + map update"
                                    % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",
@@ -545,10 +545,12 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
         stress.append({"N": nq, "M": 50000, "assoc_ms": round(ms_core, 4),
                        "Pop_per_s": round(ops / (ms_core * 1e-3) / 1e15, 3),
                        "frac_of_int8_mfma_peak": round(ops / (ms_core * 1e-3) / 1e15 / INT8_MFMA_PEAK_POPS, 3),
+                       "frac_of_fp4_mfma_peak": round(ops / (ms_core * 1e-3) / 1e15 / (2 * INT8_MFMA_PEAK_POPS), 3),
                        "matched_within_128": int((di >= 0).sum().item())})
     am.close()
     sec["assoc_stress_configs4"] = {"rows": stress, "peak_Pop_per_s": INT8_MFMA_PEAK_POPS,
-                                    "what": "lf_map_associate on a 50 000-code map kept packed on the device; ops = 2*N*M*256 (SURVEY 8d); "
+                                    "what": "lf_map_associate on a 50 000-code map kept packed on the device; ops = 2*N*M*256 (SURVEY 8d); the ungated map runs on the FP4 matrix "
+                                            "instruction (e2m1 +-1 operands, exact f32 accumulation), whose dense peak is 2 x the int8 peak: both fractions are given; "
                                             "assoc_ms = the whole association (ONE launch: query expansion, MFMA loop, merge, report), HIP events on the map's stream, 20 calls"}
     return sec
 

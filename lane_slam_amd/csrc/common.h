@@ -153,11 +153,25 @@ __host__ __device__ inline size_t assoc_map_offset(size_t row, int byte)
 {
     return (row >> 6) * 16384 + (size_t)(byte >> 4) * 1024 + (row & 63) * 16 + (size_t)(byte & 15);
 }
+// The ungated associator runs on the FP4 matrix instruction: one e2m1 nibble per code bit, 128 bytes per map row, blocked the
+// same way with 8 KB tiles: byte `byte` (0..127) of map row `row` lives at
+__host__ __device__ inline size_t assoc_map_offset_fp4(size_t row, int byte)
+{
+    return (row >> 6) * 8192 + (size_t)(byte >> 4) * 1024 + (row & 63) * 16 + (size_t)(byte & 15);
+}
+// eight code bits -> eight e2m1 nibbles: bit 0 -> +1.0 (0x2), bit 1 -> -1.0 (0xA); bit j in nibble j
+__host__ __device__ inline uint32_t assoc_fp4_expand(uint32_t byte)
+{
+    uint32_t t = (byte | (byte << 12)) & 0x000f000fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return (t << 3) | 0x22222222u;
+}
 // per-caller scratch of the associator (k_assoc.hip): one key per query and map chunk + arrival counters; sized by
 // launch_assoc_core itself
 struct AssocScratch { unsigned int* part = nullptr; int* done = nullptr; size_t cap_part = 0, cap_blocks = 0; };
 void assoc_scratch_free(AssocScratch& w);
-void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int8_t* x, int8_t* cx, hipStream_t s);
+void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int fp4, int8_t* x, int8_t* cx, hipStream_t s);
 hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const int8_t* mcx, int nm,
                              const int* nm_dev, int gating, int max_distance, AssocScratch& w, int32_t* idx, float* dist, hipStream_t s);
 hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
@@ -166,6 +180,7 @@ void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);
 // ---- live map (k_map.hip)
 struct MapDevice {
     int capacity, policy, kept_only, merge_distance, when_full;
+    int fp4;                       // packed operands are e2m1 nibbles (ungated maps) instead of int8 bytes + ninth-step rows
     uint8_t* code; uint8_t* color; double* ground; int* hits; int* last_seen; int* winner;
     int8_t* mx; int8_t* mcx;
     int* state;                    // [0] size [1] head [2] overflow [3] n_app [4] n_ref [5] old head [6] old size [7] step

@@ -50,7 +50,7 @@ constexpr int kMaxBlocksPerChunk = 512;   // the in-accumulator block counter t 
 // Packs map rows for lf_associate's raw-map form (the live map keeps its rows packed: k_map.hip).  One thread per
 // (row, code byte): 8 int8 = 2 dwords; thread 0 of a row also writes the row's ninth-step operand (zero counter bytes,
 // -127 in the other colours' groups; colour >= 3 or no colours: matches every colour).
-__global__ void k_assoc_pack_map(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ colors, int n, int n_pad,
+__global__ void k_assoc_pack_map(const uint8_t* __restrict__ codes, const uint8_t* __restrict__ colors, int n, int n_pad, int fp4,
                                  int8_t* __restrict__ out, int8_t* __restrict__ outc)
 {
     size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -65,6 +65,11 @@ __global__ void k_assoc_pack_map(const uint8_t* __restrict__ codes, const uint8_
         uint32_t w0 = ((b & 15u) * 0x00204081u) & 0x01010101u;
         uint32_t w1 = ((b >> 4) * 0x00204081u) & 0x01010101u;
         lo = (w0 * 0xE0u) ^ 0x10101010u; hi = (w1 * 0xE0u) ^ 0x10101010u;
+    }
+    if (fp4) {
+        // one e2m1 nibble per bit (padding rows: zeros = the value 0.0, "distance 128")
+        *reinterpret_cast<uint32_t*>(out + assoc_map_offset_fp4(row, (int)(t & 31) * 4)) = live ? assoc_fp4_expand(codes[t]) : 0u;
+        return;
     }
     *reinterpret_cast<uint2*>(out + assoc_map_offset(row, (int)(t & 31) * 8)) = make_uint2(lo, hi);
     if ((t & 31) == 0) {
@@ -86,6 +91,49 @@ __global__ void k_assoc_pack_map(const uint8_t* __restrict__ codes, const uint8_
 __device__ __forceinline__ int q_expand(uint32_t nibble)
 {
     return (int)((((nibble & 15u) * 0x00204081u) & 0x01010101u) * 0xC0u ^ 0x20202020u);
+}
+
+template <int QW>
+__device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int mine_q, int nq, int max_distance, unsigned int* __restrict__ part,
+                                                        int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    // The chunk's 256 keys go to this workgroup's row of part[] -- NOT atomicMin on a shared word per query: device-scope
+    // atomics are executed at the memory side, 131 072 of them (16 k queries x 8 chunks) are slow however short the
+    // chunks were.  The row is stored write-through (agent-scope relaxed atomic stores = sc1), drained, and then ONE
+    // atomic per workgroup counts the arrival: no release fence (an agent-scope __threadfence() writes the L2 back and was
+    // measured at 20-30 us per workgroup here).  The last workgroup of a query block to arrive reads the rows of all
+    // chunks with sc1 loads, writes idx / dist for its 256 queries and puts the counter back to zero, so an association is
+    // ONE kernel launch: no init pass, no finish pass.
+    __hip_atomic_store(part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AQW + mine_q, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+    __syncthreads();
+    LF_STAMP(5);
+    if (!s_last) return;
+    const int qq = blockIdx.x * AQW + threadIdx.x;
+    if (qq < nq) {
+        // eight rows in flight per thread: the merge is the serial tail of the launch (the last workgroup of the query block
+        // runs it alone), a dependent load per chunk would cost a memory round trip each
+        unsigned int v = 0x7fffffffu;
+        const unsigned int* col = part + (size_t)blockIdx.x * AQW + threadIdx.x;
+        const size_t stride = (size_t)gridDim.x * AQW;
+        const unsigned int nc = gridDim.y;
+        unsigned int c = 0;
+        for (; c + 8 <= nc; c += 8) {
+            unsigned int t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = __hip_atomic_load(col + (size_t)(c + k) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v = min(v, t[k]);
+        }
+        for (; c < nc; ++c) v = min(v, __hip_atomic_load(col + (size_t)c * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int ham = (int)(v >> 22);
+        if (v == 0x7fffffffu || ham > max_distance) { idx[qq] = -1; dist[qq] = -1.f; }
+        else { idx[qq] = (int)(v & 0x1fffffu); dist[qq] = (float)ham; }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(done + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One workgroup: 256 queries (4 waves x 2 x 32 rows) against one chunk of the map.
@@ -220,32 +268,106 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
         }
     }
     LF_STAMP(4);
-    // The chunk's 256 keys go to this workgroup's row of part[] -- NOT atomicMin on a shared word per query: device-scope
-    // atomics are executed at the memory side, 131 072 of them (16 k queries x 8 chunks) are slow however short the
-    // chunks were.  The row is stored write-through (agent-scope relaxed atomic stores = sc1), drained, and then ONE
-    // atomic per workgroup counts the arrival: no release fence (an agent-scope __threadfence() writes the L2 back and was
-    // measured at 20-30 us per workgroup here).  The last workgroup of a query block to arrive reads the rows of all
-    // chunks with sc1 loads, writes idx / dist for its 256 queries and puts the counter back to zero, so an association is
-    // ONE kernel launch: no init pass, no finish pass.
-    __hip_atomic_store(part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AQW + mine_q, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(done + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
-    __syncthreads();
-    LF_STAMP(5);
-    if (!s_last) return;
-    const int qq = blockIdx.x * AQW + threadIdx.x;
-    if (qq < nq) {
-        unsigned int v = 0x7fffffffu;
-        for (unsigned int c = 0; c < gridDim.y; ++c)
-            v = min(v, __hip_atomic_load(part + ((size_t)c * gridDim.x + blockIdx.x) * AQW + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        const int ham = (int)(v >> 22);
-        if (v == 0x7fffffffu || ham > max_distance) { idx[qq] = -1; dist[qq] = -1.f; }
-        else { idx[qq] = (int)(v & 0x1fffffu); dist[qq] = (float)ham; }
+    assoc_publish_and_merge<AQW>(mine, mine_q, nq, max_distance, part, done, idx, dist);
+}
+
+// The ungated kernel on the FP4 matrix instruction (k_assoc_loop.inc, LF_ASSOC_LOOP_FP4; gen_assoc_loop.py gen_fp4 has the
+// arithmetic): same work split and the same reduce / publish / merge tail as assoc_body; the map rows are e2m1 nibbles
+// (128 bytes per row, 8 KB tiles), the queries are expanded from the raw codes through a byte -> 8 nibbles table.
+__device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, int nq, const int8_t* __restrict__ mx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
+                                               int max_distance, unsigned int* __restrict__ part, int* __restrict__ done,
+                                               int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, uint32_t* xtab)
+{
+    LF_STAMP(0); LF_STAMP(1);
+    const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int QW = 256;
+    const int q0 = blockIdx.x * QW + wave * 64;
+    const int r32 = lane & 31, half = lane >> 5;
+    const int m_begin = blockIdx.y * m_chunk;
+    const int m_end = min(nm_pad, m_begin + m_chunk);
+    const int n_tiles = __builtin_amdgcn_readfirstlane((m_end - m_begin) / AM);
+    unsigned int mine = 0x7fffffffu;
+    int mine_q = threadIdx.x;
+    if (n_tiles > 0) {
+        xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
+        __syncthreads();
+        v4i A[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int qi = q0 + 32 * b + r32;
+            uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;        // padding rows: any operand will do, they are never reported
+            if (qi < nq) {
+                c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
+                c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
+            }
+            const uint32_t d[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                // step s, k-half `half`: bits [64 s + 32 half, +32) = code dword 2 s + half
+                const uint32_t w = half ? d[2 * s + 1] : d[2 * s];
+                A[b][s] = v4i{ (int)xtab[w & 0xffu], (int)xtab[(w >> 8) & 0xffu], (int)xtab[(w >> 16) & 0xffu], (int)xtab[w >> 24] };
+            }
+        }
+        // step five, query side: weights 4, 4, 0.5, 0.5 (block scale 2^4 -> 64, 64, 8, 8) in k-half 0; 1, 1 (scale 2^0) in k-half 1
+        const v4i AX = v4i{ half ? 0x22 : 0x1166, 0, 0, 0 };
+        const uint32_t scl5 = half ? 0x7f7f7f7fu : 0x83838383u;
+        const uint32_t mask0 = half ? 0u : 0xffffffffu, mask1 = ~mask0;
+        const uint32_t lds_tile = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)tile;
+        const uint32_t vfrag = lds_tile + half * 1024 + r32 * 16;
+        const uint32_t voff = (uint32_t)lane * 16u;
+        const uint32_t vdump = lds_tile + wave * 8192 + lane * 16;
+        const uint64_t mbase = (uint64_t)(size_t)(mx + (size_t)m_begin * 128 + wave * 1024);
+        const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mbase), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mbase >> 32));
+        const uint64_t mpair = ((uint64_t)mhi << 32) | mlo;
+        const uint32_t m0base = __builtin_amdgcn_readfirstlane(lds_tile + wave * 1024);
+        LF_STAMP(2);
+        asm volatile(LF_ASSOC_LOOP_FP4
+                     :
+                     : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [a10] "v"(A[1][0]), [a11] "v"(A[1][1]),
+                       [a12] "v"(A[1][2]), [a13] "v"(A[1][3]), [ax] "v"(AX), [scl5] "v"(scl5), [mask0] "v"(mask0), [mask1] "v"(mask1),
+                       [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair), [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
+                     : LF_ASSOC_LOOP_CLOBBERS_FP4);
+        LF_STAMP(3);
+        // keys are floats here: 512 * dot - t, exact integers
+        float* dump = reinterpret_cast<float*>(tile) + wave * 2048;
+#pragma unroll 4
+        for (int i = 0; i < 32; ++i) {
+            float* slot = dump + (i >> 2) * 256 + lane * 4 + (i & 3);
+            const float kf = *slot;
+            int v = 0x7fffffff;
+            if (kf > -1.0e30f) {
+                const int key = (int)kf;
+                const int dot512 = (key + 511) & ~511;
+                const int col = m_begin + 32 * (dot512 - key) + r32;
+                if (col < nm) v = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
+            }
+            *reinterpret_cast<int*>(slot) = v;
+        }
+        __syncthreads();
+        {
+            const int i = lane & 31, h = lane >> 5;
+            const int* src = reinterpret_cast<const int*>(dump) + (i >> 2) * 256 + h * 128 + (i & 3);
+            int v = 0x7fffffff;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) v = min(v, src[((k + (i >> 2)) & 31) * 4]);
+            const int b = i >> 4, r = i & 15;
+            mine = (unsigned int)v;
+            mine_q = wave * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+        }
     }
-    if (threadIdx.x == 0) __hip_atomic_store(done + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    LF_STAMP(6);
+    LF_STAMP(4);
+    assoc_publish_and_merge<QW>(mine, mine_q, nq, max_distance, part, done, idx, dist);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_fp4(const uint8_t* __restrict__ q, int nq, const int8_t* __restrict__ mx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[6 * AM * 128];     // six 8 KB tile buffers (gen_fp4 nbuf); the four key dumps reuse 32 KB of them
+    __shared__ uint32_t xtab[256];
+    assoc_body_fp4(q, nq, mx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, xtab);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
@@ -318,10 +440,10 @@ void assoc_scratch_free(AssocScratch& w)
     w.part = nullptr; w.done = nullptr; w.cap_part = 0; w.cap_blocks = 0;
 }
 
-void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int8_t* x, int8_t* cx, hipStream_t s)
+void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int fp4, int8_t* x, int8_t* cx, hipStream_t s)
 {
     if (n_pad <= 0) return;
-    hipLaunchKernelGGL(k_assoc_pack_map, dim3(((size_t)n_pad * 32 + 255) / 256), dim3(256), 0, s, codes, colors, n, n_pad, x, cx);
+    hipLaunchKernelGGL(k_assoc_pack_map, dim3(((size_t)n_pad * 32 + 255) / 256), dim3(256), 0, s, codes, colors, n, n_pad, fp4, x, cx);
 }
 
 // association of raw query codes against a packed map (the live map keeps its side packed across calls; lf_associate
@@ -344,7 +466,11 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     splits = (nm_pad + m_chunk - 1) / m_chunk;
     hipError_t e = assoc_scratch_reserve(w, (size_t)qblocks, (size_t)splits, s);
     if (e != hipSuccess) return e;
+    // ungated: the FP4 kernel (its map operands are e2m1 rows: MapDevice::fp4 / launch_assoc_pack_map(fp4 = 1));
+    // LF_ASSOC_INT8=1 keeps the int8 kernel for A/B runs -- the caller's operands must then be int8 rows
+    static const bool force_i8 = getenv("LF_ASSOC_INT8") != nullptr;
     if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
+    else if (!force_i8) hipLaunchKernelGGL(k_assoc_fp4, dim3(qblocks, splits), dim3(256), 0, s, q, nq, mx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
     else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
 #ifdef LF_ASSOC_STAMPS
     {
@@ -367,7 +493,8 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
 hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
                         float* dist, hipStream_t s)
 {
-    launch_assoc_pack_map(m, nullptr, nm, (int)assoc_rows_padded_m(nm), mx, mcx, s);
+    static const bool force_i8 = getenv("LF_ASSOC_INT8") != nullptr;
+    launch_assoc_pack_map(m, nullptr, nm, (int)assoc_rows_padded_m(nm), force_i8 ? 0 : 1, mx, mcx, s);
     return launch_assoc_core(q, nullptr, nq, mx, mcx, nm, nullptr, 0, 128, w, idx, dist, s);
 }
 

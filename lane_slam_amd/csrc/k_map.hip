@@ -33,7 +33,7 @@ constexpr int kRefFlag = 0x40000000;
 constexpr uint32_t kMagic = 0x4b42464cu;   // "LFBK"
 
 struct MapDev {
-    int capacity, policy, kept_only, merge_distance, when_full;
+    int capacity, policy, kept_only, merge_distance, when_full, fp4;
     uint8_t* code; uint8_t* color; double* ground; int* hits; int* last_seen; int* winner;
     int8_t* mx; int8_t* mcx;
     int* state;                    // [0] size [1] head [2] overflow [3] n_app [4] n_ref [5] old head [6] old size [7] step
@@ -195,8 +195,9 @@ __global__ void k_map_apply(MapDev m, const uint8_t* __restrict__ blocks, int n_
     m.code[(size_t)pos * 32 + b] = (uint8_t)byte;
     const uint32_t w0 = ((byte & 15u) * 0x00204081u) & 0x01010101u;
     const uint32_t w1 = ((byte >> 4) * 0x00204081u) & 0x01010101u;
-    *reinterpret_cast<uint2*>(m.mx + assoc_map_offset((size_t)pos, 8 * b)) = make_uint2((w0 * 0xE0u) ^ 0x10101010u, (w1 * 0xE0u) ^ 0x10101010u);
-    if (b < 8) {
+    if (m.fp4) *reinterpret_cast<uint32_t*>(m.mx + assoc_map_offset_fp4((size_t)pos, 4 * b)) = assoc_fp4_expand(byte);
+    else *reinterpret_cast<uint2*>(m.mx + assoc_map_offset((size_t)pos, 8 * b)) = make_uint2((w0 * 0xE0u) ^ 0x10101010u, (w1 * 0xE0u) ^ 0x10101010u);
+    if (b < 8 && !m.fp4) {
         // the ninth-step operand of a map row: bytes 0,1 zero (block counter, filled in by k_assoc), then -127 in the
         // ten bytes of each OTHER colour's group
         const int c = row[72];
@@ -270,7 +271,7 @@ void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks,
 {
     MapDev m;
     m.capacity = md.capacity; m.policy = md.policy; m.kept_only = md.kept_only; m.merge_distance = md.merge_distance;
-    m.when_full = md.when_full;
+    m.when_full = md.when_full; m.fp4 = md.fp4;
     m.code = md.code; m.color = md.color; m.ground = md.ground; m.hits = md.hits; m.last_seen = md.last_seen;
     m.winner = md.winner; m.mx = md.mx; m.mcx = md.mcx; m.state = md.state; m.totals = md.totals;
     hipLaunchKernelGGL(k_map_plan, dim3(1), dim3(1024), 0, s, m, blocks, n_blocks, block_rows, force_append, act);

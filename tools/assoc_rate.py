@@ -17,7 +17,8 @@ ap.add_argument("--gating", action="store_true", help="colour-gated association 
 ap.add_argument("--reps", type=int, default=20)
 args = ap.parse_args()
 torch.cuda.init()
-PEAK = 5.0e15
+PEAK = 5.0e15          # dense int8 MFMA peak (ops/s); the FP4 peak is twice that
+int8_forced = os.environ.get("LF_ASSOC_INT8") is not None
 for pair in args.pairs.split(","):
     n, m = (int(v) for v in pair.split("x"))
     am = LineAssociator(capacity=max(64, m), color_gating=args.gating, kept_only=False)
@@ -41,6 +42,10 @@ for pair in args.pairs.split(","):
     if t["assoc_pack_queries"][1] > 0:        # libraries before the single-launch associator packed the queries in a kernel of their own
         core += t["assoc_pack_queries"][0] / t["assoc_pack_queries"][1]
     ops = 2.0 * n * m * 256
-    print("N=%6d M=%7d%s: assoc %.4f ms (one launch: query expansion, MFMA, merge, report)  %.2f Pop/s  (%.1f %% of the dense int8 MFMA peak)"
-          % (n, m, " gated" if args.gating else "", core, ops / (core * 1e-3) / 1e15, 100 * ops / (core * 1e-3) / PEAK))
+    fp4 = not args.gating and not int8_forced          # ungated maps run on v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands
+    rate = ops / (core * 1e-3)
+    print("N=%6d M=%7d%s: assoc %.4f ms (one launch: query expansion, MFMA, merge, report)  %.2f Pop/s  %s"
+          % (n, m, " gated" if args.gating else "", core, rate / 1e15,
+             ("FP4 kernel: %.1f %% of the 10 Pop/s dense FP4 peak (= %.1f %% of the 5 Pop/s int8 peak the int8 kernel is priced against)" % (100 * rate / (2 * PEAK), 100 * rate / PEAK))
+             if fp4 else ("int8 kernel: %.1f %% of the 5 Pop/s dense int8 MFMA peak" % (100 * rate / PEAK))))
     am.close()

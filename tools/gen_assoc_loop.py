@@ -195,6 +195,156 @@ def gen(gated):
     return L
 
 
+def gen_fp4(nbuf=6):
+    """The ungated loop on the FP4 matrix instruction (gfx950 only): code bits as e2m1 +-1 nibbles, 64 bits per
+    v_mfma_scale_f32_32x32x64_f8f6f4 (same 32 cycles as the int8 32x32x32: twice the bits per cycle), the query side
+    scaled by 2^9 through the E8M0 block scale, f32 accumulation (exact: |512 dot| <= 2^17).  Four matrix steps per
+    32-column block instead of eight; the block counter enters through a FIFTH step computed once per half tile into a
+    register set of its own (nt) that is the C operand of both row blocks' chains -- on the vector side that leaves only the
+    32 v_max_f32 per half tile.  nt for half h + 1 is issued at the end of half h (two sets, no wait).
+    Step five: query-side weights 4, 4, 0.5, 0.5 (block scale 2^4: 64, 64, 8, 8) in the lanes of k-half 0 and 1, 1
+    (scale 2^0) in those of k-half 1; map side: the block number t = 64 a + 8 b + c as minus its octal digits, each digit
+    the sum of two e2m1 values (5 = 4 + 1, 7 = 4 + 3), written by the loop itself.
+    Registers: v[80:95] Bf[s] (4 fragments), v[96:127] accP, v[128:159] accQ, v[160:191] running, v[200:215] ntP,
+    v[216:231] ntQ, v[76:79] BX (v76 digits, v77..79 zero), v192 / v193 scale 2^9 / 2^0, v197 scratch, v198 / v199 read
+    bases; A[b][s], AX, the step-five scale and the two lane masks are operands.
+    `nbuf` 8 KB tile buffers: a half tile is only ~150 ns of matrix work per wave, so the tile nbuf - 1 ahead must be in
+    flight to cover a cold (MALL / HBM) fetch when few workgroups of an XCD share a chunk."""
+    L = []
+    e = L.append
+    BF, ACCP, ACCQ, RUN, NTP, NTQ, BXR, SCA, SCB, TMP, VBC, VBN = 80, 96, 128, 160, 200, 216, 76, 192, 193, 197, 198, 199
+    MF = "v_mfma_scale_f32_32x32x64_f8f6f4"
+    TAIL = "op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+
+    def dma_piece(buf, p):
+        if buf is None:
+            e("s_lshr_b32 s45, s54, 1")
+            e("s_add_u32 s45, %[m0base], s45")
+            if p:
+                e("s_add_u32 s45, s45, %d" % (p * 4096))
+        else:
+            e("s_add_u32 s45, %%[m0base], %d" % (buf * 8192 + p * 4096))
+        e("s_mov_b32 m0, s45")
+        e("s_nop 0")
+        e("global_load_lds_dwordx4 %[voff], s[42:43]")
+        e("s_add_u32 s42, s42, 4096")
+        e("s_addc_u32 s43, s43, 0")
+
+    def tile_address(from_k_plus):
+        e("s_add_i32 s44, s40, %d" % from_k_plus)
+        e("s_min_i32 s44, s44, s41")
+        e("s_lshl_b32 s42, s44, 13")
+        e("s_add_u32 s42, s50, s42")
+        e("s_addc_u32 s43, s51, 0")
+
+    def digits(tt_expr_lines):
+        # s46 = digit bytes of a | b << 8 (lanes of k-half 0), s47 = digit byte of c (k-half 1), tt in s44
+        for ln in tt_expr_lines:
+            e(ln)
+        e("s_lshr_b32 s46, s44, 6")
+        e("s_lshl_b32 s46, s46, 3")
+        e("s_lshr_b64 s[56:57], s[58:59], s46")
+        e("s_and_b32 s46, s56, 0xff")
+        e("s_bfe_u32 s47, s44, 0x30003")
+        e("s_lshl_b32 s47, s47, 3")
+        e("s_lshr_b64 s[56:57], s[58:59], s47")
+        e("s_and_b32 s47, s56, 0xff")
+        e("s_lshl_b32 s47, s47, 8")
+        e("s_or_b32 s46, s46, s47")
+        e("s_and_b32 s47, s44, 7")
+        e("s_lshl_b32 s47, s47, 3")
+        e("s_lshr_b64 s[56:57], s[58:59], s47")
+        e("s_and_b32 s47, s56, 0xff")
+        e("v_and_b32 v%d, s46, %%[mask0]" % TMP)
+        e("v_and_b32 v%d, s47, %%[mask1]" % BXR)
+        e("v_or_b32 v%d, v%d, v%d" % (BXR, BXR, TMP))
+
+    def nt_mfma(dst):
+        e("s_nop 1")
+        e("%s %s, %%[ax], %s, 0, %%[scl5], v%d %s" % (MF, rng(dst, 16), rng(BXR, 4), SCB, TAIL))
+
+    def half_step(half):
+        acc = ACCP if half == 0 else ACCQ
+        other = ACCQ if half == 0 else ACCP
+        nt = NTP if half == 0 else NTQ
+        nt_next = NTQ if half == 0 else NTP
+        vb = "v%d" % (VBC if half == 0 else VBN)
+        roff = 512 if half == 0 else 0
+        for s in range(4):
+            if half == 0:
+                e("s_waitcnt lgkmcnt(3)")
+            for b in range(2):
+                c = rng(nt, 16) if s == 0 else rng(acc + 16 * b, 16)
+                e("%s %s, %%[a%d%d], %s, %s, v%d, v%d %s" % (MF, rng(acc + 16 * b, 16), b, s, rng(BF + 4 * s, 4), c, SCA, SCB, TAIL))
+            e("ds_read_b128 %s, %s offset:%d" % (rng(BF + 4 * s, 4), vb, s * 2048 + roff))
+            for j in range(8):
+                i = 8 * s + j
+                e("v_max_f32 v%d, v%d, v%d" % (RUN + i, RUN + i, other + i))
+            if half == 0 and s == 1:
+                tile_address(nbuf)
+            if half == 1 and s in (0, 2):
+                dma_piece(None, s // 2)
+        # the block counter of the NEXT half step (tt + 1), into the other nt set
+        if half == 0:
+            digits(["s_lshl_b32 s44, s40, 1", "s_or_b32 s44, s44, 1"])
+        else:
+            digits(["s_lshl_b32 s44, s40, 1", "s_add_u32 s44, s44, 2"])
+        nt_mfma(nt_next)
+
+    # ---------------- prologue
+    e("s_mov_b64 s[50:51], %[mbase]")
+    e("s_mov_b32 s58, 0x0d0c0a00")          # digit -> two e2m1 nibbles (minus the digit): 0 1 2 3 | 4 5 6 7
+    e("s_mov_b32 s59, 0xde0fae0e")
+    for i in range(32):
+        e("v_mov_b32 v%d, 0xff800000" % (RUN + i))
+        e("v_mov_b32 v%d, 0xff800000" % (ACCQ + i))
+    for r in range(1, 4):
+        e("v_mov_b32 v%d, 0" % (BXR + r))
+    e("v_mov_b32 v%d, 0x88888888" % SCA)
+    e("v_mov_b32 v%d, 0x7f7f7f7f" % SCB)
+    e("v_mov_b32 v%d, %%[vfrag]" % VBC)
+    e("v_add_u32 v%d, 8192, %%[vfrag]" % VBN)
+    e("s_mov_b32 s40, 0")
+    e("s_add_i32 s41, %[ntiles], -1")
+    e("s_mov_b32 s54, 0")
+    e("s_mov_b32 s55, 16384")               # s54 / s55 count in the int8 loop's units (16 KB per buffer); halved where used
+    for t in range(nbuf):
+        tile_address(t)
+        for p in range(2):
+            dma_piece(t, p)
+    digits(["s_mov_b32 s44, 0"])
+    nt_mfma(NTP)
+    e("s_waitcnt vmcnt(%d)" % (2 * (nbuf - 1)))
+    e("s_barrier")
+    for s in range(4):
+        e("ds_read_b128 %s, %%[vfrag] offset:%d" % (rng(BF + 4 * s, 4), s * 2048))
+    e("LT_%=:")
+    half_step(0)
+    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * (nbuf - 2)))
+    e("s_barrier")
+    half_step(1)
+    e("v_mov_b32 v%d, v%d" % (VBC, VBN))
+    e("s_mov_b32 s54, s55")
+    e("s_add_u32 s55, s55, 16384")
+    e("s_cmp_eq_u32 s55, %d" % (nbuf * 16384))
+    e("s_cselect_b32 s55, 0, s55")
+    e("s_lshr_b32 s56, s55, 1")
+    e("v_add_u32 v%d, s56, %%[vfrag]" % VBN)
+    e("s_add_i32 s40, s40, 1")
+    e("s_cmp_lt_i32 s40, %[ntiles]")
+    e("s_cbranch_scc1 LT_%=")
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_nop 7")
+    e("s_nop 7")
+    for i in range(32):
+        e("v_max_f32 v%d, v%d, v%d" % (RUN + i, RUN + i, ACCQ + i))
+    e("s_barrier")
+    for i in range(8):
+        e("ds_write_b128 %%[vdump], %s offset:%d" % (rng(RUN + 4 * i, 4), i * 1024))
+    e("s_waitcnt lgkmcnt(0)")
+    return L
+
+
 def c_string(lines):
     return "\n".join('    "%s\\n\\t"' % ln for ln in lines)
 
@@ -208,6 +358,9 @@ def main():
         f.write("// GENERATED by tools/gen_assoc_loop.py -- do not edit; see that file for the register map and the schedule.\n")
         f.write("#define LF_ASSOC_LOOP_PLAIN \\\n" + c_string(gen(False)).replace("\n", " \\\n") + "\n\n")
         f.write("#define LF_ASSOC_LOOP_GATED \\\n" + c_string(gen(True)).replace("\n", " \\\n") + "\n\n")
+        f.write("#define LF_ASSOC_LOOP_FP4 \\\n" + c_string(gen_fp4()).replace("\n", " \\\n") + "\n\n")
+        clob_fp4 = ", ".join('"v%d"' % i for i in list(range(76, 200)) + list(range(200, 232))) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "memory", "scc"'
+        f.write("#define LF_ASSOC_LOOP_CLOBBERS_FP4 " + clob_fp4 + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_PLAIN " + clob_plain + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_GATED " + clob_gated + "\n")
     print("wrote", os.path.normpath(out), "plain", len(gen(False)), "gated", len(gen(True)), "instructions")
