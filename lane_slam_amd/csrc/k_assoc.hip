@@ -277,7 +277,7 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
 __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, int nq, const int8_t* __restrict__ mx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
                                                int max_distance, unsigned int* __restrict__ part, int* __restrict__ done,
-                                               int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, uint32_t* xtab)
+                                               int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, uint32_t* xtab, uint32_t* ttab)
 {
     LF_STAMP(0); LF_STAMP(1);
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
@@ -292,6 +292,14 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
     int mine_q = threadIdx.x;
     if (n_tiles > 0) {
         xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
+        // step five's map-side operand per block number t = 64 a + 8 b + c: minus the octal digits, each digit two e2m1 values
+        // (0 1 2 3 4 4+1 6 4+3); k-half 0 carries a (weights 64) and b (weights 8), k-half 1 carries c (weights 1)
+        for (int t = threadIdx.x; t < 512; t += 256) {
+            const unsigned long long dig = 0xde0fae0e0d0c0a00ull;
+            const uint32_t a = (uint32_t)(dig >> (8 * (t >> 6))) & 0xffu, b = (uint32_t)(dig >> (8 * ((t >> 3) & 7))) & 0xffu, c = (uint32_t)(dig >> (8 * (t & 7))) & 0xffu;
+            ttab[t] = a | (b << 8);
+            ttab[512 + t] = c;
+        }
         __syncthreads();
         v4i A[2][4];
 #pragma unroll
@@ -313,7 +321,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
         // step five, query side: weights 4, 4, 0.5, 0.5 (block scale 2^4 -> 64, 64, 8, 8) in k-half 0; 1, 1 (scale 2^0) in k-half 1
         const v4i AX = v4i{ half ? 0x22 : 0x1166, 0, 0, 0 };
         const uint32_t scl5 = half ? 0x7f7f7f7fu : 0x83838383u;
-        const uint32_t mask0 = half ? 0u : 0xffffffffu, mask1 = ~mask0;
+        const uint32_t vtab = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ttab + half * 2048;
         const uint32_t lds_tile = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)tile;
         const uint32_t vfrag = lds_tile + half * 1024 + r32 * 16;
         const uint32_t voff = (uint32_t)lane * 16u;
@@ -326,7 +334,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
         asm volatile(LF_ASSOC_LOOP_FP4
                      :
                      : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [a10] "v"(A[1][0]), [a11] "v"(A[1][1]),
-                       [a12] "v"(A[1][2]), [a13] "v"(A[1][3]), [ax] "v"(AX), [scl5] "v"(scl5), [mask0] "v"(mask0), [mask1] "v"(mask1),
+                       [a12] "v"(A[1][2]), [a13] "v"(A[1][3]), [ax] "v"(AX), [scl5] "v"(scl5), [vtab] "v"(vtab),
                        [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair), [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
                      : LF_ASSOC_LOOP_CLOBBERS_FP4);
         LF_STAMP(3);
@@ -367,7 +375,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[6 * AM * 128];     // six 8 KB tile buffers (gen_fp4 nbuf); the four key dumps reuse 32 KB of them
     __shared__ uint32_t xtab[256];
-    assoc_body_fp4(q, nq, mx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, xtab);
+    __shared__ uint32_t ttab[1024];
+    assoc_body_fp4(q, nq, mx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, xtab, ttab);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,

@@ -204,7 +204,8 @@ def gen_fp4(nbuf=6):
     32 v_max_f32 per half tile.  nt for half h + 1 is issued at the end of half h (two sets, no wait).
     Step five: query-side weights 4, 4, 0.5, 0.5 (block scale 2^4: 64, 64, 8, 8) in the lanes of k-half 0 and 1, 1
     (scale 2^0) in those of k-half 1; map side: the block number t = 64 a + 8 b + c as minus its octal digits, each digit
-    the sum of two e2m1 values (5 = 4 + 1, 7 = 4 + 3), written by the loop itself.
+    the sum of two e2m1 values (5 = 4 + 1, 7 = 4 + 3): one dword per lane and half step, read from a 4 KB table in LDS that
+    the C++ prologue fills (operand vtab = this lane's table base).
     Registers: v[80:95] Bf[s] (4 fragments), v[96:127] accP, v[128:159] accQ, v[160:191] running, v[200:215] ntP,
     v[216:231] ntQ, v[76:79] BX (v76 digits, v77..79 zero), v192 / v193 scale 2^9 / 2^0, v197 scratch, v198 / v199 read
     bases; A[b][s], AX, the step-five scale and the two lane masks are operands.
@@ -237,30 +238,16 @@ def gen_fp4(nbuf=6):
         e("s_add_u32 s42, s50, s42")
         e("s_addc_u32 s43, s51, 0")
 
-    def digits(tt_expr_lines):
-        # s46 = digit bytes of a | b << 8 (lanes of k-half 0), s47 = digit byte of c (k-half 1), tt in s44
-        for ln in tt_expr_lines:
+    def t_read(tt_lines):
+        # BX word of the half step whose block number the lines leave in s44: one dword per lane from the table the
+        # C++ prologue wrote to LDS ([k-half][512] words: minus the octal digits of t as e2m1 pairs, see the doc string)
+        for ln in tt_lines:
             e(ln)
-        e("s_lshr_b32 s46, s44, 6")
-        e("s_lshl_b32 s46, s46, 3")
-        e("s_lshr_b64 s[56:57], s[58:59], s46")
-        e("s_and_b32 s46, s56, 0xff")
-        e("s_bfe_u32 s47, s44, 0x30003")
-        e("s_lshl_b32 s47, s47, 3")
-        e("s_lshr_b64 s[56:57], s[58:59], s47")
-        e("s_and_b32 s47, s56, 0xff")
-        e("s_lshl_b32 s47, s47, 8")
-        e("s_or_b32 s46, s46, s47")
-        e("s_and_b32 s47, s44, 7")
-        e("s_lshl_b32 s47, s47, 3")
-        e("s_lshr_b64 s[56:57], s[58:59], s47")
-        e("s_and_b32 s47, s56, 0xff")
-        e("v_and_b32 v%d, s46, %%[mask0]" % TMP)
-        e("v_and_b32 v%d, s47, %%[mask1]" % BXR)
-        e("v_or_b32 v%d, v%d, v%d" % (BXR, BXR, TMP))
+        e("s_lshl_b32 s44, s44, 2")
+        e("v_add_u32 v%d, s44, %%[vtab]" % TMP)
+        e("ds_read_b32 v%d, v%d" % (BXR, TMP))
 
     def nt_mfma(dst):
-        e("s_nop 1")
         e("%s %s, %%[ax], %s, 0, %%[scl5], v%d %s" % (MF, rng(dst, 16), rng(BXR, 4), SCB, TAIL))
 
     def half_step(half):
@@ -270,9 +257,14 @@ def gen_fp4(nbuf=6):
         nt_next = NTQ if half == 0 else NTP
         vb = "v%d" % (VBC if half == 0 else VBN)
         roff = 512 if half == 0 else 0
+        # the NEXT half step's block number (tt + 1) is fetched first: it is the oldest LDS read at the end of the step
+        if half == 0:
+            t_read(["s_lshl_b32 s44, s40, 1", "s_or_b32 s44, s44, 1"])
+        else:
+            t_read(["s_lshl_b32 s44, s40, 1", "s_add_u32 s44, s44, 2"])
         for s in range(4):
             if half == 0:
-                e("s_waitcnt lgkmcnt(3)")
+                e("s_waitcnt lgkmcnt(4)")
             for b in range(2):
                 c = rng(nt, 16) if s == 0 else rng(acc + 16 * b, 16)
                 e("%s %s, %%[a%d%d], %s, %s, v%d, v%d %s" % (MF, rng(acc + 16 * b, 16), b, s, rng(BF + 4 * s, 4), c, SCA, SCB, TAIL))
@@ -284,17 +276,12 @@ def gen_fp4(nbuf=6):
                 tile_address(nbuf)
             if half == 1 and s in (0, 2):
                 dma_piece(None, s // 2)
-        # the block counter of the NEXT half step (tt + 1), into the other nt set
-        if half == 0:
-            digits(["s_lshl_b32 s44, s40, 1", "s_or_b32 s44, s44, 1"])
-        else:
-            digits(["s_lshl_b32 s44, s40, 1", "s_add_u32 s44, s44, 2"])
+        # the block counter of the NEXT half step, into the other nt set
+        e("s_waitcnt lgkmcnt(%d)" % (0 if half == 0 else 4))
         nt_mfma(nt_next)
 
     # ---------------- prologue
     e("s_mov_b64 s[50:51], %[mbase]")
-    e("s_mov_b32 s58, 0x0d0c0a00")          # digit -> two e2m1 nibbles (minus the digit): 0 1 2 3 | 4 5 6 7
-    e("s_mov_b32 s59, 0xde0fae0e")
     for i in range(32):
         e("v_mov_b32 v%d, 0xff800000" % (RUN + i))
         e("v_mov_b32 v%d, 0xff800000" % (ACCQ + i))
@@ -312,7 +299,8 @@ def gen_fp4(nbuf=6):
         tile_address(t)
         for p in range(2):
             dma_piece(t, p)
-    digits(["s_mov_b32 s44, 0"])
+    t_read(["s_mov_b32 s44, 0"])
+    e("s_waitcnt lgkmcnt(0)")
     nt_mfma(NTP)
     e("s_waitcnt vmcnt(%d)" % (2 * (nbuf - 1)))
     e("s_barrier")
@@ -320,7 +308,7 @@ def gen_fp4(nbuf=6):
         e("ds_read_b128 %s, %%[vfrag] offset:%d" % (rng(BF + 4 * s, 4), s * 2048))
     e("LT_%=:")
     half_step(0)
-    e("s_waitcnt vmcnt(%d) lgkmcnt(0)" % (2 * (nbuf - 2)))
+    e("s_waitcnt vmcnt(%d)" % (2 * (nbuf - 2)))
     e("s_barrier")
     half_step(1)
     e("v_mov_b32 v%d, v%d" % (VBC, VBN))
