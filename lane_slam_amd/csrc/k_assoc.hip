@@ -241,17 +241,22 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
         // i = 16 b + r of this lane sits in the wave's 8 KB of LDS.
         // 1) every lane decodes its 32 keys in place (column = 32 t + this lane's r32)
         int* dump = reinterpret_cast<int*>(tile) + wave * 2048;
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            int* slot = dump + (i >> 2) * 256 + lane * 4 + (i & 3);
-            const int key = *slot;
-            int v = 0x7fffffff;
-            if (key != (int)0x80000000) {
-                const int dot512 = (key + 511) & ~511;
-                const int col = m_begin + 32 * (dot512 - key) + r32;
-                if (col < nm) v = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
+#pragma unroll 2
+        for (int g = 0; g < 8; ++g) {                                  // four keys per 16-byte access: no bank conflicts
+            int4* slot = reinterpret_cast<int4*>(dump + g * 256 + lane * 4);
+            const int4 k4 = *slot;
+            const int key[4] = { k4.x, k4.y, k4.z, k4.w };
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = 0x7fffffff;
+                if (key[j] != (int)0x80000000) {
+                    const int dot512 = (key[j] + 511) & ~511;
+                    const int col = m_begin + 32 * (dot512 - key[j]) + r32;
+                    if (col < nm) v[j] = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
+                }
             }
-            *slot = v;
+            *slot = make_int4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
         // 2) one lane per query: key i = 16 b + r of the 32 lanes (r32) of half h is query row (r & 3) + 8 (r >> 2) + 4 h
@@ -301,6 +306,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
             ttab[512 + t] = c;
         }
         __syncthreads();
+        LF_STAMP(6);
         v4i A[2][4];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -310,14 +316,17 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
                 c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
                 c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
             }
-            const uint32_t d[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+            // step s, k-half `half`: bits [64 s + 32 half, +32) = code dword 2 s + half.  (Selects on registers, not an indexed
+            // array: the compiler turns `half ? d[2 s + 1] : d[2 s]` into d[2 s + half], keeps d[] in memory, promotes it to
+            // LDS and then needs the workgroup size from the dispatch packet -- a scalar load from host memory, 15 us.)
+            const uint32_t w4[4] = { half ? c0.y : c0.x, half ? c0.w : c0.z, half ? c1.y : c1.x, half ? c1.w : c1.z };
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                // step s, k-half `half`: bits [64 s + 32 half, +32) = code dword 2 s + half
-                const uint32_t w = half ? d[2 * s + 1] : d[2 * s];
+                const uint32_t w = w4[s];
                 A[b][s] = v4i{ (int)xtab[w & 0xffu], (int)xtab[(w >> 8) & 0xffu], (int)xtab[(w >> 16) & 0xffu], (int)xtab[w >> 24] };
             }
         }
+        LF_STAMP(7);
         // step five, query side: weights 4, 4, 0.5, 0.5 (block scale 2^4 -> 64, 64, 8, 8) in k-half 0; 1, 1 (scale 2^0) in k-half 1
         const v4i AX = v4i{ half ? 0x22 : 0x1166, 0, 0, 0 };
         const uint32_t scl5 = half ? 0x7f7f7f7fu : 0x83838383u;
@@ -340,18 +349,23 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
         LF_STAMP(3);
         // keys are floats here: 512 * dot - t, exact integers
         float* dump = reinterpret_cast<float*>(tile) + wave * 2048;
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-            float* slot = dump + (i >> 2) * 256 + lane * 4 + (i & 3);
-            const float kf = *slot;
-            int v = 0x7fffffff;
-            if (kf > -1.0e30f) {
-                const int key = (int)kf;
-                const int dot512 = (key + 511) & ~511;
-                const int col = m_begin + 32 * (dot512 - key) + r32;
-                if (col < nm) v = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
+#pragma unroll 2
+        for (int g = 0; g < 8; ++g) {                                  // four keys per 16-byte access: no bank conflicts
+            float4* slot = reinterpret_cast<float4*>(dump + g * 256 + lane * 4);
+            const float4 k4 = *slot;
+            const float kf[4] = { k4.x, k4.y, k4.z, k4.w };
+            int v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = 0x7fffffff;
+                if (kf[j] > -1.0e30f) {
+                    const int key = (int)kf[j];
+                    const int dot512 = (key + 511) & ~511;
+                    const int col = m_begin + 32 * (dot512 - key) + r32;
+                    if (col < nm) v[j] = (((256 << 9) - dot512) << 12) | col;      // hamming << 22 | col
+                }
             }
-            *reinterpret_cast<int*>(slot) = v;
+            *reinterpret_cast<int4*>(slot) = make_int4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
         {
@@ -490,7 +504,9 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
             (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_assoc_stamps), sizeof(h));
             const int n = qblocks * splits < 8192 ? qblocks * splits : 8192;
             unsigned long long w0 = ~0ull, w1 = 0; double d[8] = { 0 };
-            for (int i = 0; i < n; ++i) { const unsigned long long* t = h + 8 * i; if (t[0] < w0) w0 = t[0]; if (t[0] > w1) w1 = t[0]; for (int k = 2; k <= 5; ++k) d[k] += (double)(t[k] - t[k - 1]); }
+            double e6 = 0, e7 = 0;
+            for (int i = 0; i < n; ++i) { const unsigned long long* t = h + 8 * i; if (t[0] < w0) w0 = t[0]; if (t[0] > w1) w1 = t[0]; for (int k = 2; k <= 5; ++k) d[k] += (double)(t[k] - t[k - 1]); e6 += (double)(t[6] - t[1]); e7 += (double)(t[7] - t[1]); }
+            fprintf(stderr, "[assoc stamps] tables + barrier at +%.0f, fragments expanded at +%.0f cycles\n", e6 / n, e7 / n);
             fprintf(stderr, "[assoc stamps] %d workgroups (%d x %d): start skew %.2f us | setup %.0f  loop %.0f  reduce %.0f  publish %.0f cycles (mean per workgroup)\n",
                     n, qblocks, splits, (double)(w1 - w0) / 100.0, d[2] / n, d[3] / n, d[4] / n, d[5] / n);
         }
