@@ -8,6 +8,7 @@ per-call time of the association (HIP events on the map's stream) and 2*N*M*256 
 import argparse, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in device memory: ~2 us less per launch
 import torch
 from lane_slam_amd import LineAssociator, synth
 
