@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: per-phase cycle totals of k_lsd_grow.  Needs a library built with
+"""Diagnostic: per-phase cycle totals of k_lsd_grow.  usage: grow_stamps.py [frames] [geometry].  Needs a library built with
 `make -C lane_slam_amd/csrc EXTRA=-DLFG_STAMPS` (never the shipped build)."""
 import os, sys
 import numpy as np
@@ -8,7 +8,7 @@ from lane_slam_amd import FrontEnd, default_config, synth
 from lane_slam_amd import _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-cfg = default_config("fullres")
+cfg = default_config(sys.argv[2] if len(sys.argv) > 2 else "fullres")      # "parity": the 160x120 operating point of the reference
 fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=512)
 frames = synth.make_batch(n, 0)
 fe.process_batch(frames)
