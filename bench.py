@@ -77,7 +77,7 @@ def alloc_out(torch, dev, B, cap):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU per step (0: 256, or 128 for --geometry hd)")
     ap.add_argument("--geometry", default="fullres", choices=["fullres", "parity", "hd"],
