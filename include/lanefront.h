@@ -160,7 +160,8 @@ int lf_wait(lf_handle* h, int* n_segments);
  * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
  * each 256-bit query code in the map; idx = -1 and dist = -1 when the nearest
  * neighbour is farther than 128 bits (:721); ties -> lowest map index.
- * Computed as an int8 MFMA contraction.  on_device applies to all four arrays.
+ * Computed as an exact matrix-core contraction (FP4 e2m1 +-1 operands with f32 accumulation on gfx950; int8 when colour
+ * gated), one kernel launch per call.  on_device applies to all four arrays.
  */
 int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
                  int32_t* idx, float* dist, int on_device);
@@ -176,7 +177,7 @@ int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* 
  * to match -- and oracle/lf_oracle_map.c is its sequential statement.
  *
  * A map lives on one device: per entry the 32-byte code, colour, the two ground endpoints (x0 y0 x1 y1, map
- * frame, metres), hits, last_seen (step number), plus the int8 operands of the MFMA associator, which are
+ * frame, metres), hits, last_seen (step number), plus the matrix-core operands of the associator (e2m1 nibbles, or int8 bytes for a colour-gated map), which are
  * re-packed only for the rows an update touches.  All map work runs on the map's own HIP stream, in call order.
  *
  *   color_gating    0: a query may match any entry (a-10).  1: only entries of its own colour (Segment.color);
@@ -254,7 +255,8 @@ int lf_map_step_host(lf_map* m, const lf_segments* segs, int n, int n_frames, co
 int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,
                  int32_t* last_seen);
 
-/* per-stage timing with HIP events on the map's stream: 0 query packing, 1 association (MFMA), 2 block packing,
+/* per-stage timing with HIP events on the map's stream: 0 query packing (always 0 calls since the association became one
+ * launch that expands the queries itself), 1 association (MFMA), 2 block packing,
  * 3 map update.  lf_map_get_timing returns what accumulated since the previous call and resets it. */
 #define LF_MAP_N_STAGES 4
 int lf_map_set_profiling(lf_map* m, int enabled);
