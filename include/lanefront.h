@@ -169,6 +169,17 @@ int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* ma
 int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
                        int32_t* idx, float* dist, int on_device);
 
+/* Anti-instagram colour clustering (k-means part).  Replaces
+ *   anti_instagram/kmeans.py:22-47  runKMeans(cv_img, num_colors, init)
+ * = sklearn.cluster.KMeans(n_clusters, max_iter, init = <array>).fit_predict on B, G, R points + cluster_centers_, label
+ * counts, score.  bgr_points: [n][3] u8 -- the reference passes the pixels of the frame's last 100 rows (any order: the
+ * result does not depend on it except through which of several equally far samples re-seeds an empty cluster: the lowest
+ * index).  init_centers [k][3] f64, k <= 16; max_iter 25 and tol 1e-4 are the reference's (scikit-learn's default tol).
+ * centers_out [k][3] f64, counts_out [k], *inertia_out (score = -inertia), *n_iter_out.  Blocking.  LF_ERR_BAD_ARG when a
+ * cluster stays empty (fewer distinct samples than clusters). */
+int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int k, const double* init_centers, int max_iter,
+              double tol, double* centers_out, long long* counts_out, double* inertia_out, int* n_iter_out);
+
 /* ---- live map + associator (SURVEY a-11, 8f-3) ------------------------------------------------
  * What the package offers in place of the reference's line_associator node, which is an unfinished stub
  * (src/line_associator/src/line_associator_node.py:12-86), and of show_map's append-only segment store

@@ -19,7 +19,7 @@ LF_MSG_DETECTOR, LF_MSG_GROUND, LF_MSG_FILTERED = 0, 1, 2
 # every symbol include/lanefront.h declares
 EXPORTS = (
     "lf_abi_version", "lf_create", "lf_destroy", "lf_last_error", "lf_synchronize", "lf_get_stream",
-    "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float",
+    "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate", "lf_associate_float", "lf_kmeans",
     "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_probe", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing", "lf_reset_timing", "lf_stage_name",
     "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
@@ -77,6 +77,7 @@ def load():
     lib.lf_wait.restype = ci
     lib.lf_associate.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci]
     lib.lf_associate_float.argtypes = [vp, vp, ci, vp, ci, vp, vp, ci]
+    lib.lf_kmeans.argtypes = [vp, vp, ci, ci, ci, vp, ci, ctypes.c_double, vp, vp, vp, vp]
     lib.lf_jpeg_decode_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ci, ci, ci, vp, ci, ci,
                                          ctypes.POINTER(ci)]
     lib.lf_jpeg_decode_batch.restype = ci
@@ -130,7 +131,7 @@ def load():
               "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_fetch"):
         getattr(lib, f).restype = ci
     for f in ("lf_synchronize", "lf_set_image", "lf_detect_lines", "lf_process_batch", "lf_process_batch_async", "lf_wait", "lf_associate",
-              "lf_associate_float", "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
+              "lf_associate_float", "lf_kmeans", "lf_jpeg_decode_batch", "lf_jpeg_info", "lf_frames_buffer", "lf_serialize_segments", "lf_deserialize_segments",
     "lf_debug_fetch", "lf_debug_detmath", "lf_debug_lsd_binary", "lf_lsd_size", "lf_set_profiling", "lf_get_timing",
               "lf_reset_timing"):
         getattr(lib, f).restype = ci

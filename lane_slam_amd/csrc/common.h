@@ -177,6 +177,9 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
 hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
                         float* dist, hipStream_t s);
 void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);
+// ---- anti-instagram colour clustering (k_kmeans.hip)
+void launch_kmeans(const uint8_t* bgr, int n, int k, const double* init, int max_iter, double tol_rel, uint8_t* lab, double* out,
+                   long long* counts, int* status, hipStream_t s);
 // ---- live map (k_map.hip)
 struct MapDevice {
     int capacity, policy, kept_only, merge_distance, when_full;

@@ -99,6 +99,7 @@ struct lf_handle {
     int out_capacity = 0;
     // associator scratch (grown on demand)
     DevBuf a_q, a_m, a_mx, a_mcx, a_best, a_idx, a_dist, a_qn, a_mn;
+    DevBuf km_pts, km_lab, km_f64, km_cnt;
     AssocScratch a_ws;
     // pinned host scalars
     int* h_pinned = nullptr;     // [0] total segments, [1] overflow
@@ -448,7 +449,7 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
+                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     assoc_scratch_free(h->a_ws);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -803,6 +804,46 @@ extern "C" int lf_associate_float(lf_handle* h, const float* query72, int nq, co
 // of the pipeline (gradient -> order -> grow) with the colour mask forced to all ones.  Test and
 // diagnosis entry; lines are in working-image pixels before normal-based reordering, exactly what
 // cv2's detect() would return for this image under the oracle's restatement.
+// anti-instagram colour clustering (k_kmeans.hip): kmeans.py:22-47
+extern "C" int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int k, const double* init_centers, int max_iter,
+                         double tol, double* centers_out, long long* counts_out, double* inertia_out, int* n_iter_out)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!bgr_points || !init_centers || !centers_out || !counts_out || n < 1 || k < 1 || k > 16 || max_iter < 1) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_kmeans: null argument, n < 1, max_iter < 1 or k outside 1..16");
+        return LF_ERR_BAD_ARG;
+    }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    // f64 scratch: [0 .. 3k) init, [64 .. 64 + 3k] centres + inertia; counts: [k] + the status word behind them
+    if ((rc = ensure(h, h->km_lab, (size_t)n)) || (rc = ensure(h, h->km_f64, 128 * sizeof(double))) || (rc = ensure(h, h->km_cnt, 32 * sizeof(long long)))) return rc;
+    const uint8_t* dp = bgr_points;
+    if (!on_device) {
+        if ((rc = ensure(h, h->km_pts, (size_t)n * 3)) != LF_OK) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->km_pts.p, bgr_points, (size_t)n * 3, hipMemcpyHostToDevice, s));
+        dp = static_cast<const uint8_t*>(h->km_pts.p);
+    }
+    double* f64 = static_cast<double*>(h->km_f64.p);
+    long long* cnt = static_cast<long long*>(h->km_cnt.p);
+    int* status = reinterpret_cast<int*>(cnt + 16);
+    LF_HIP_CHECK(h, hipMemcpyAsync(f64, init_centers, (size_t)k * 3 * sizeof(double), hipMemcpyHostToDevice, s));
+    launch_kmeans(dp, n, k, f64, max_iter, tol, static_cast<uint8_t*>(h->km_lab.p), f64 + 64, cnt, status, s);
+    LF_HIP_CHECK(h, hipGetLastError());
+    double res[49];
+    long long hc[17];
+    LF_HIP_CHECK(h, hipMemcpyAsync(res, f64 + 64, (size_t)(3 * k + 1) * sizeof(double), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(hc, cnt, 17 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    const int iters = *reinterpret_cast<int*>(&hc[16]);
+    if (iters < 0) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_kmeans: a cluster stayed empty (fewer distinct samples than clusters)"); return LF_ERR_BAD_ARG; }
+    for (int j = 0; j < 3 * k; ++j) centers_out[j] = res[j];
+    for (int j = 0; j < k; ++j) counts_out[j] = hc[j];
+    if (inertia_out) *inertia_out = res[3 * k];
+    if (n_iter_out) *n_iter_out = iters;
+    return LF_OK;
+}
+
 extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;

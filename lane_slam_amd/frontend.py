@@ -199,6 +199,21 @@ class FrontEnd(object):
         self._check(self.lib.lf_associate_float(self.h, _ptr(q), q.shape[0], _ptr(m), m.shape[0], _ptr(idx), _ptr(dist), 0))
         return idx, dist
 
+    def kmeans(self, bgr_points, init_centers, max_iter=25, tol=1e-4):
+        """Lloyd's k-means from an explicit init on [N, 3] u8 B, G, R points (anti_instagram/kmeans.py:24-26, i.e.
+        sklearn.cluster.KMeans(n_clusters, max_iter=25, init=<array>)).  Returns (centers [k, 3] f64, counts [k] i64,
+        inertia, n_iter)."""
+        pts = np.ascontiguousarray(bgr_points, np.uint8).reshape(-1, 3)
+        init = np.ascontiguousarray(init_centers, np.float64).reshape(-1, 3)
+        k = init.shape[0]
+        centers = np.zeros((k, 3), np.float64)
+        counts = np.zeros(k, np.int64)
+        inertia = ctypes.c_double()
+        n_iter = ctypes.c_int()
+        self._check(self.lib.lf_kmeans(self.h, _ptr(pts), pts.shape[0], 0, k, _ptr(init), int(max_iter), float(tol), _ptr(centers),
+                                        _ptr(counts), ctypes.byref(inertia), ctypes.byref(n_iter)))
+        return centers, counts, inertia.value, n_iter.value
+
     # ------------------------------------------------------------------ host ingest (JPEG)
     def decode_jpeg_batch(self, streams, rows=None, cols=None, n_threads=0, device_ptr=None):
         """Decode a list of JPEG byte strings (what CompressedImage.data carries) into BGR frames --

@@ -165,4 +165,8 @@ int lfo_jpeg_coefficients(const uint8_t* data, size_t size, int16_t* qcoef, int 
 #ifdef __cplusplus
 }
 #endif
+/* anti-instagram colour clustering (kmeans.py:14-47 = scikit-learn's Lloyd iteration from a given init): lf_oracle_kmeans.c */
+int lfo_kmeans(const uint8_t* bgr, int n, int k, const double* init, int max_iter, double tol_rel, double* centers,
+               int64_t* counts, double* inertia);
+
 #endif

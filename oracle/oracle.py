@@ -430,3 +430,20 @@ class OracleMap(object):
         return {"code": arr("lfo_map_codes", ctypes.c_uint8, 32), "color": arr("lfo_map_colors", ctypes.c_uint8, 1),
                 "ground": arr("lfo_map_ground", ctypes.c_double, 4), "hits": arr("lfo_map_hits", ctypes.c_int32, 1),
                 "last_seen": arr("lfo_map_last_seen", ctypes.c_int32, 1)}
+
+
+def kmeans(bgr_points, init, max_iter=25, tol=1e-4):
+    """scikit-learn's Lloyd iteration from an explicit init, as kmeans.py:24-26 runs it.  bgr_points: [N, 3] u8.
+    Returns (centers [k, 3] f64, counts [k] i64, inertia, n_iter)."""
+    lib = ctypes.CDLL(build())
+    lib.lfo_kmeans.restype = ctypes.c_int
+    pts = np.ascontiguousarray(bgr_points, np.uint8).reshape(-1, 3)
+    init = np.ascontiguousarray(init, np.float64).reshape(-1, 3)
+    k = init.shape[0]
+    centers = np.zeros((k, 3), np.float64)
+    counts = np.zeros(k, np.int64)
+    inertia = ctypes.c_double()
+    it = lib.lfo_kmeans(_p(pts), pts.shape[0], k, _p(init), int(max_iter), ctypes.c_double(tol), _p(centers), _p(counts), ctypes.byref(inertia))
+    if it < 0:
+        raise ValueError("k-means: a cluster ran empty")
+    return centers, counts, inertia.value, it

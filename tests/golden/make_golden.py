@@ -21,6 +21,9 @@ What is imported from /root/reference (Python 3 can execute these files as they 
         GroundProjectionNode.lineseglist_cb: which fields travel on, in which order                 (a-7 glue)
   * src/duckietown_msgs/msg/{SegmentList,Segment,Vector2D}.msg
         parsed here to serialise the messages the two nodes built -> the ROS 1 wire bytes           (f-2)
+  * src/anti_instagram/include/anti_instagram/kmeans.py
+        runKMeans / getimgdatapts with the scikit-learn installed in this image (1.7.2: the reference does not pin
+        a version): cluster centres, label counts and score for the reference's two inits              (f-4, k-means part)
 The modules `rospy`, `cv2`, `*_msgs.msg` they import at file scope are absent from this
 image; they are replaced by empty name-only stubs (no arithmetic) so the import
 statements succeed.  Message classes are plain attribute holders with the constants of
@@ -451,6 +454,35 @@ def golden_node_pipeline():
     print("node_pipeline:", [int(cases["det_wire%d" % i].size) for i in range(len(geoms))], "wire bytes")
 
 
+def golden_kmeans():
+    """kmeans.py:22-47 on a few images: random pixels (exact distance ties in the first iteration, no convergence within
+    max_iter), synthetic lane frames (one of the init colours missing: empty-cluster relocation), a noisy lane frame."""
+    import contextlib, io, warnings
+    warnings.filterwarnings("ignore")
+    sys.path.insert(0, os.path.join(OUT, "..", ".."))
+    from lane_slam_amd import synth
+    km = load_file("ref_kmeans", os.path.join(REF, "anti_instagram/include/anti_instagram/kmeans.py"))
+    rng = np.random.default_rng(5)
+    imgs = {"random": np.random.default_rng(0).integers(0, 256, (120, 160, 3), dtype=np.uint8),
+            "lane_a": synth.make_frame(3)[::2, ::2], "lane_b": synth.make_frame(11)[::4, ::4], "lane_c": synth.make_frame(20)[::4, ::4],
+            "noisy": np.clip(synth.make_frame(5)[::2, ::2].astype(np.int32) + rng.integers(-40, 40, (240, 320, 3)), 0, 255).astype(np.uint8)}
+    out = {"inits3": np.asarray(km.CENTERS, np.float64), "inits4": np.asarray(km.CENTERS2, np.float64)}
+    for name, img in imgs.items():
+        out["img_" + name] = img
+        if name == "random":
+            out["pts_" + name] = np.ascontiguousarray(km.getimgdatapts(img[-100:, :, :]))   # the reference's own point order (column major)
+        for k, init in ((3, km.CENTERS), (4, km.CENTERS2)):
+            with contextlib.redirect_stdout(io.StringIO()):
+                centers, counts, score = km.runKMeans(img, k, init)
+            out["centers%d_%s" % (k, name)] = np.asarray(centers, np.float64)
+            out["counts%d_%s" % (k, name)] = np.array([int(counts[i]) for i in range(k)], np.int64)
+            out["score%d_%s" % (k, name)] = np.float64(score)
+    import sklearn
+    out["sklearn_version"] = np.array(sklearn.__version__)
+    np.savez_compressed(os.path.join(OUT, "kmeans.npz"), **out)
+    print("kmeans.npz:", len(imgs), "images x 2 inits, scikit-learn", sklearn.__version__)
+
+
 if __name__ == "__main__":
     install_stubs()
     golden_node_pipeline()
@@ -459,3 +491,5 @@ if __name__ == "__main__":
     golden_find_normal()
     golden_line_sanity()
     golden_scaleandshift()
+    install_stubs()
+    golden_kmeans()
