@@ -95,7 +95,7 @@ def main():
                     help="secondary measurements (stream replay, JPEG ingest, plugin latency, associator stress): auto = all at "
                          "N = 1 with the default geometry, none otherwise")
     ap.add_argument("--stream-frames", type=int, default=1024, help="frames of the configs[2] stream (replayed --stream-laps times)")
-    ap.add_argument("--stream-laps", type=int, default=4)
+    ap.add_argument("--stream-laps", type=int, default=12)
     args = ap.parse_args()
 
     import torch
@@ -413,38 +413,41 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
     frame_bytes = host[0].nbytes
     segs = [0]
 
-    def stream_pass(smap, lap):
+    def stream_pass(smap, lap0, n_laps):
+        """n_laps replays of the stream, back to back: the pipeline is filled once and drained once"""
         inflight = []
 
         def complete():
-            s0, k0 = inflight.pop(0)
+            s0, k0, lap = inflight.pop(0)
             n = fes[s0].wait()
             segs[0] += n
             t = np.arange(k0 * B, (k0 + 1) * B, dtype=np.float64) + lap * n_stream
             pose = np.column_stack([0.01 * t, 0.3 * np.sin(0.02 * t), 0.002 * t])
             smap.step_device(fes[s0], ptrs[s0], n, B, a_idx[s0].data_ptr(), a_dist[s0].data_ptr(), poses=pose, step=lap * 1000 + k0)
-        for k in range(n_stream // B):
-            slot = k % D
-            if len(inflight) == D:
-                complete()
-            fes[slot].submit_host(pinned.data_ptr() + k * B * frame_bytes, B, ptrs[slot], cap, describe=True)
-            inflight.append((slot, k))
+        j = 0
+        for lap in range(lap0, lap0 + n_laps):
+            for k in range(n_stream // B):
+                slot = j % D
+                j += 1
+                if len(inflight) == D:
+                    complete()
+                fes[slot].submit_host(pinned.data_ptr() + k * B * frame_bytes, B, ptrs[slot], cap, describe=True)
+                inflight.append((slot, k, lap))
         while inflight:
             complete()
 
     def new_map():
-        return LineAssociator(capacity=1 << 18, color_gating=False, max_distance=128, policy="append", kept_only=True,
+        return LineAssociator(capacity=1 << 19, color_gating=False, max_distance=128, policy="append", kept_only=True,
                               when_full="ring", device=device_id)
     smap = new_map()
-    stream_pass(smap, 0)                             # warm-up lap (allocations, first touch of the pinned pages)
+    stream_pass(smap, 0, 1)                          # warm-up lap (allocations, first touch of the pinned pages)
     smap.synchronize()
     torch.cuda.synchronize()
     smap.close()
     smap = new_map()
     segs[0] = 0
     t0 = time.perf_counter()
-    for lap in range(laps):
-        stream_pass(smap, lap)
+    stream_pass(smap, 0, laps)
     smap.synchronize()
     torch.cuda.synchronize()
     sdt = time.perf_counter() - t0
