@@ -573,6 +573,31 @@ def test_associate_large_map_and_many_ties():
 
 
 @pytest.mark.gpu
+def test_associate_odd_sizes_match_matcher_semantics():
+    """Query and map counts around every granule of the associator (32-row blocks, 64-row tiles, 256-query workgroups,
+    16 384-row chunks) and codes at distance 0 / 128 / 129 / 256: exact nearest neighbour, lowest index on ties, nothing
+    beyond 128 -- on the FP4 kernel (ungated, the default) through lf_associate."""
+    from oracle.oracle import Oracle
+    o = Oracle(default_config("parity"))
+    fe = FrontEnd(default_config("parity"))
+    rng = np.random.default_rng(77)
+    for nq, nm in ((1, 1), (31, 63), (255, 64), (256, 65), (257, 1000), (1000, 127), (300, 16385), (64, 40000), (513, 33000)):
+        m = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+        q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+        # some queries are copies of map rows with 0, 128, 129 or 256 bits flipped
+        for i in range(0, nq, 5):
+            src = m[rng.integers(0, nm)].copy()
+            nflip = (0, 128, 129, 256)[(i // 5) % 4]
+            bits = rng.permutation(256)[:nflip]
+            for b in bits:
+                src[b >> 3] ^= 1 << (b & 7)
+            q[i] = src
+        idx, dist = fe.associate(q, m)
+        oi, od = o.match(q, m)
+        assert np.array_equal(dist, od) and np.array_equal(idx, oi), (nq, nm)
+
+
+@pytest.mark.gpu
 def test_stream_handle_and_async_errors():
     fe = FrontEnd(default_config("parity"), max_frames=2, max_lines_per_color=64)
     assert fe.stream_ptr() != 0
