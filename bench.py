@@ -301,7 +301,7 @@ def main():
             "metric": "frames/sec (%dx%d) detect->descript->project->sanity->associate" % (in_cols, in_rows),
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (FP4 e2m1 MFMA with exact f32 accumulation for association; i8 MFMA when colour gated)", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (FP4 e2m1 MFMA with exact f32 accumulation for association)", "data": "synthetic",
             "config": {"workload": "%s%d-frame batch per GPU of %dx%d synthetic lane frames (%d distinct), %s geometry (working image %dx%d, "
                                    "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs the %d-entry live map + map update"
                                    % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",

@@ -160,8 +160,7 @@ int lf_wait(lf_handle* h, int* n_segments);
  * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
  * each 256-bit query code in the map; idx = -1 and dist = -1 when the nearest
  * neighbour is farther than 128 bits (:721); ties -> lowest map index.
- * Computed as an exact matrix-core contraction (FP4 e2m1 +-1 operands with f32 accumulation on gfx950; int8 when colour
- * gated), one kernel launch per call.  on_device applies to all four arrays.
+ * Computed as an exact matrix-core contraction (FP4 e2m1 +-1 operands with f32 accumulation on gfx950), one kernel launch per call.  on_device applies to all four arrays.
  */
 int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
                  int32_t* idx, float* dist, int on_device);
@@ -188,7 +187,7 @@ int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int
  * to match -- and oracle/lf_oracle_map.c is its sequential statement.
  *
  * A map lives on one device: per entry the 32-byte code, colour, the two ground endpoints (x0 y0 x1 y1, map
- * frame, metres), hits, last_seen (step number), plus the matrix-core operands of the associator (e2m1 nibbles, or int8 bytes for a colour-gated map), which are
+ * frame, metres), hits, last_seen (step number), plus the matrix-core operands of the associator (e2m1 nibbles and a colour row), which are
  * re-packed only for the rows an update touches.  All map work runs on the map's own HIP stream, in call order.
  *
  *   color_gating    0: a query may match any entry (a-10).  1: only entries of its own colour (Segment.color);

@@ -279,10 +279,13 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
 // The ungated kernel on the FP4 matrix instruction (k_assoc_loop.inc, LF_ASSOC_LOOP_FP4; gen_assoc_loop.py gen_fp4 has the
 // arithmetic): same work split and the same reduce / publish / merge tail as assoc_body; the map rows are e2m1 nibbles
 // (128 bytes per row, 8 KB tiles), the queries are expanded from the raw codes through a byte -> 8 nibbles table.
-__device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, int nq, const int8_t* __restrict__ mx,
+template <bool GATED>
+__device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
                                                int max_distance, unsigned int* __restrict__ part, int* __restrict__ done,
-                                               int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, uint32_t* xtab, uint32_t* ttab)
+                                               int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, int8_t* ctile,
+                                               uint32_t* xtab, uint32_t* ttab)
 {
     LF_STAMP(0); LF_STAMP(1);
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
@@ -307,7 +310,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
         }
         __syncthreads();
         LF_STAMP(6);
-        v4i A[2][4];
+        v4i A[2][4], AXC[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int qi = q0 + 32 * b + r32;
@@ -315,6 +318,11 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
             if (qi < nq) {
                 c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
                 c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
+            }
+            if (GATED) {
+                // colour step, query side: 6.0 (e2m1 0x7) in the nibble of the query's colour, k-half 0 only
+                const int c = qi < nq ? (int)qcolor[qi] : 255;
+                AXC[b] = v4i{ (half == 0 && c < 3) ? (0x7 << (4 * c)) : 0, 0, 0, 0 };
             }
             // step s, k-half `half`: bits [64 s + 32 half, +32) = code dword 2 s + half.  (Selects on registers, not an indexed
             // array: the compiler turns `half ? d[2 s + 1] : d[2 s]` into d[2 s + half], keeps d[] in memory, promotes it to
@@ -340,6 +348,21 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, in
         const uint64_t mpair = ((uint64_t)mhi << 32) | mlo;
         const uint32_t m0base = __builtin_amdgcn_readfirstlane(lds_tile + wave * 1024);
         LF_STAMP(2);
+        if (GATED) {
+            const uint32_t lds_ctile = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)ctile;
+            const uint32_t vcfrag = lds_ctile + r32 * 32 + 16 * half;
+            const uint64_t cbase = (uint64_t)(size_t)(mcx + (size_t)m_begin * 32 + (wave & 1) * 1024);
+            const uint32_t clo = __builtin_amdgcn_readfirstlane((uint32_t)cbase), chi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
+            const uint64_t cpair = ((uint64_t)chi << 32) | clo;
+            const uint32_t m0c = __builtin_amdgcn_readfirstlane(lds_ctile + (wave & 1) * 1024);
+            asm volatile(LF_ASSOC_LOOP_FP4_GATED
+                         :
+                         : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [a10] "v"(A[1][0]), [a11] "v"(A[1][1]),
+                           [a12] "v"(A[1][2]), [a13] "v"(A[1][3]), [ax] "v"(AX), [scl5] "v"(scl5), [vtab] "v"(vtab), [axc0] "v"(AXC[0]),
+                           [axc1] "v"(AXC[1]), [vcfrag] "v"(vcfrag), [cbase] "s"(cpair), [m0c] "s"(m0c),
+                           [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair), [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
+                         : LF_ASSOC_LOOP_CLOBBERS_FP4);
+        } else
         asm volatile(LF_ASSOC_LOOP_FP4
                      :
                      : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [a10] "v"(A[1][0]), [a11] "v"(A[1][1]),
@@ -390,7 +413,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(1024))) int8_t tile[6 * AM * 128];     // six 8 KB tile buffers (gen_fp4 nbuf); the four key dumps reuse 32 KB of them
     __shared__ uint32_t xtab[256];
     __shared__ uint32_t ttab[1024];
-    assoc_body_fp4(q, nq, mx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, xtab, ttab);
+    assoc_body_fp4<false>(q, nullptr, nq, mx, nullptr, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab, ttab);
+}
+
+// colour gated: one more matrix step per row block (gen_fp4 gated = True), the map's colour rows stream beside the tiles
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_fp4_gated(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[6 * AM * 128];
+    __shared__ __attribute__((aligned(1024))) int8_t ctile[6 * AM * 32];
+    __shared__ uint32_t xtab[256];
+    __shared__ uint32_t ttab[1024];
+    assoc_body_fp4<true>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab, ttab);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
@@ -492,7 +528,8 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     // ungated: the FP4 kernel (its map operands are e2m1 rows: MapDevice::fp4 / launch_assoc_pack_map(fp4 = 1));
     // LF_ASSOC_INT8=1 keeps the int8 kernel for A/B runs -- the caller's operands must then be int8 rows
     static const bool force_i8 = getenv("LF_ASSOC_INT8") != nullptr;
-    if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
+    if (gating && !force_i8) hipLaunchKernelGGL(k_assoc_fp4_gated, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
+    else if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
     else if (!force_i8) hipLaunchKernelGGL(k_assoc_fp4, dim3(qblocks, splits), dim3(256), 0, s, q, nq, mx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
     else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
 #ifdef LF_ASSOC_STAMPS

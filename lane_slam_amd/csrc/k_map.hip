@@ -197,6 +197,14 @@ __global__ void k_map_apply(MapDev m, const uint8_t* __restrict__ blocks, int n_
     const uint32_t w1 = ((byte >> 4) * 0x00204081u) & 0x01010101u;
     if (m.fp4) *reinterpret_cast<uint32_t*>(m.mx + assoc_map_offset_fp4((size_t)pos, 4 * b)) = assoc_fp4_expand(byte);
     else *reinterpret_cast<uint2*>(m.mx + assoc_map_offset((size_t)pos, 8 * b)) = make_uint2((w0 * 0xE0u) ^ 0x10101010u, (w1 * 0xE0u) ^ 0x10101010u);
+    if (b < 8 && m.fp4) {
+        // colour row of the FP4 gated kernel: -6.0 (e2m1 0xF) in the nibbles 0..2 of the OTHER colours, first dword; zeros after
+        const int c = row[72];
+        uint32_t w = 0;
+        if (b == 0 && c < 3)
+            for (int g = 0; g < 3; ++g) if (g != c) w |= 0xFu << (4 * g);
+        *reinterpret_cast<uint32_t*>(m.mcx + (size_t)pos * 32 + 4 * b) = w;
+    }
     if (b < 8 && !m.fp4) {
         // the ninth-step operand of a map row: bytes 0,1 zero (block counter, filled in by k_assoc), then -127 in the
         // ten bytes of each OTHER colour's group

@@ -246,7 +246,7 @@ extern "C" int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** o
 #undef CREATE_HIP
     m->d.capacity = cfg->capacity; m->d.policy = cfg->policy; m->d.kept_only = cfg->kept_only;
     m->d.merge_distance = cfg->merge_distance; m->d.when_full = cfg->when_full;
-    m->d.fp4 = (cfg->color_gating || getenv("LF_ASSOC_INT8")) ? 0 : 1;          // ungated maps keep e2m1 operands for the FP4 matrix instruction
+    m->d.fp4 = getenv("LF_ASSOC_INT8") ? 0 : 1;          // e2m1 operands for the FP4 matrix instruction (int8 rows only for A/B runs)
     *out = m;
     return LF_OK;
 }

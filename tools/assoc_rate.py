@@ -43,7 +43,7 @@ for pair in args.pairs.split(","):
     if t["assoc_pack_queries"][1] > 0:        # libraries before the single-launch associator packed the queries in a kernel of their own
         core += t["assoc_pack_queries"][0] / t["assoc_pack_queries"][1]
     ops = 2.0 * n * m * 256
-    fp4 = not args.gating and not int8_forced          # ungated maps run on v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands
+    fp4 = not int8_forced          # v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands (LF_ASSOC_INT8=1: the int8 kernels, for A/B)
     rate = ops / (core * 1e-3)
     print("N=%6d M=%7d%s: assoc %.4f ms (one launch: query expansion, MFMA, merge, report)  %.2f Pop/s  %s"
           % (n, m, " gated" if args.gating else "", core, rate / 1e15,

@@ -195,7 +195,7 @@ def gen(gated):
     return L
 
 
-def gen_fp4(nbuf=6):
+def gen_fp4(nbuf=6, gated=False):
     """The ungated loop on the FP4 matrix instruction (gfx950 only): code bits as e2m1 +-1 nibbles, 64 bits per
     v_mfma_scale_f32_32x32x64_f8f6f4 (same 32 cycles as the int8 32x32x32: twice the bits per cycle), the query side
     scaled by 2^9 through the E8M0 block scale, f32 accumulation (exact: |512 dot| <= 2^17).  Four matrix steps per
@@ -210,14 +210,31 @@ def gen_fp4(nbuf=6):
     v[216:231] ntQ, v[76:79] BX (v76 digits, v77..79 zero), v192 / v193 scale 2^9 / 2^0, v197 scratch, v198 / v199 read
     bases; A[b][s], AX, the step-five scale and the two lane masks are operands.
     `nbuf` 8 KB tile buffers: a half tile is only ~150 ns of matrix work per wave, so the tile nbuf - 1 ahead must be in
-    flight to cover a cold (MALL / HBM) fetch when few workgroups of an XCD share a chunk."""
+    flight to cover a cold (MALL / HBM) fetch when few workgroups of an XCD share a chunk.
+    gated: colour gating as one more matrix step per row block, first in the chain (C = nt): query side 6.0 in the nibble
+    of ITS colour (k-half 0, block scale 2^12), map side -6.0 in the nibbles of the OTHER colours (32-byte rows streamed
+    beside the tiles like the int8 kernel's ninth-step rows) -> -147 456 whenever the colours differ, below every key within
+    128 bits (>= -511).  v[232:235] BXC (refreshed in place like the fragments), v236 / v237 its read bases, v238 its scale."""
     L = []
     e = L.append
     BF, ACCP, ACCQ, RUN, NTP, NTQ, BXR, SCA, SCB, TMP, VBC, VBN = 80, 96, 128, 160, 200, 216, 76, 192, 193, 197, 198, 199
+    BXC, VCC, VCN, SCC = 232, 236, 237, 238
+    npw = 3 if gated else 2              # LDS-DMA pieces per tile and wave
+    lgk0 = 5 if gated else 4             # LDS reads in flight per half step, minus one
     MF = "v_mfma_scale_f32_32x32x64_f8f6f4"
     TAIL = "op_sel_hi:[0,0,0] cbsz:4 blgp:4"
 
     def dma_piece(buf, p):
+        if p == 2:                               # the tile's colour rows (gated): 2 KB, piece = wave & 1 (folded into the operands)
+            if buf is None:
+                e("s_lshr_b32 s45, s54, 3")
+                e("s_add_u32 s45, %[m0c], s45")
+            else:
+                e("s_add_u32 s45, %%[m0c], %d" % (buf * 2048))
+            e("s_mov_b32 m0, s45")
+            e("s_nop 0")
+            e("global_load_lds_dwordx4 %[voff], s[48:49]")
+            return
         if buf is None:
             e("s_lshr_b32 s45, s54, 1")
             e("s_add_u32 s45, %[m0base], s45")
@@ -237,6 +254,10 @@ def gen_fp4(nbuf=6):
         e("s_lshl_b32 s42, s44, 13")
         e("s_add_u32 s42, s50, s42")
         e("s_addc_u32 s43, s51, 0")
+        if gated:
+            e("s_lshl_b32 s48, s44, 11")
+            e("s_add_u32 s48, s52, s48")
+            e("s_addc_u32 s49, s53, 0")
 
     def t_read(tt_lines):
         # BX word of the half step whose block number the lines leave in s44: one dword per lane from the table the
@@ -262,11 +283,17 @@ def gen_fp4(nbuf=6):
             t_read(["s_lshl_b32 s44, s40, 1", "s_or_b32 s44, s44, 1"])
         else:
             t_read(["s_lshl_b32 s44, s40, 1", "s_add_u32 s44, s44, 2"])
+        if gated:
+            if half == 0:
+                e("s_waitcnt lgkmcnt(%d)" % lgk0)
+            for b in range(2):
+                e("%s %s, %%[axc%d], %s, %s, v%d, v%d %s" % (MF, rng(acc + 16 * b, 16), b, rng(BXC, 4), rng(nt, 16), SCC, SCB, TAIL))
+            e("ds_read_b128 %s, v%d offset:%d" % (rng(BXC, 4), VCC if half == 0 else VCN, 1024 if half == 0 else 0))
         for s in range(4):
             if half == 0:
-                e("s_waitcnt lgkmcnt(4)")
+                e("s_waitcnt lgkmcnt(%d)" % lgk0)
             for b in range(2):
-                c = rng(nt, 16) if s == 0 else rng(acc + 16 * b, 16)
+                c = rng(nt, 16) if (s == 0 and not gated) else rng(acc + 16 * b, 16)
                 e("%s %s, %%[a%d%d], %s, %s, v%d, v%d %s" % (MF, rng(acc + 16 * b, 16), b, s, rng(BF + 4 * s, 4), c, SCA, SCB, TAIL))
             e("ds_read_b128 %s, %s offset:%d" % (rng(BF + 4 * s, 4), vb, s * 2048 + roff))
             for j in range(8):
@@ -276,12 +303,19 @@ def gen_fp4(nbuf=6):
                 tile_address(nbuf)
             if half == 1 and s in (0, 2):
                 dma_piece(None, s // 2)
+            if half == 1 and gated and s == 3:
+                dma_piece(None, 2)
         # the block counter of the NEXT half step, into the other nt set
-        e("s_waitcnt lgkmcnt(%d)" % (0 if half == 0 else 4))
+        e("s_waitcnt lgkmcnt(%d)" % (0 if half == 0 else lgk0))
         nt_mfma(nt_next)
 
     # ---------------- prologue
     e("s_mov_b64 s[50:51], %[mbase]")
+    if gated:
+        e("s_mov_b64 s[52:53], %[cbase]")
+        e("v_mov_b32 v%d, 0x8b8b8b8b" % SCC)
+        e("v_mov_b32 v%d, %%[vcfrag]" % VCC)
+        e("v_add_u32 v%d, 2048, %%[vcfrag]" % VCN)
     for i in range(32):
         e("v_mov_b32 v%d, 0xff800000" % (RUN + i))
         e("v_mov_b32 v%d, 0xff800000" % (ACCQ + i))
@@ -297,18 +331,20 @@ def gen_fp4(nbuf=6):
     e("s_mov_b32 s55, 16384")               # s54 / s55 count in the int8 loop's units (16 KB per buffer); halved where used
     for t in range(nbuf):
         tile_address(t)
-        for p in range(2):
+        for p in range(npw):
             dma_piece(t, p)
     t_read(["s_mov_b32 s44, 0"])
     e("s_waitcnt lgkmcnt(0)")
     nt_mfma(NTP)
-    e("s_waitcnt vmcnt(%d)" % (2 * (nbuf - 1)))
+    e("s_waitcnt vmcnt(%d)" % (npw * (nbuf - 1)))
     e("s_barrier")
+    if gated:
+        e("ds_read_b128 %s, %%[vcfrag]" % rng(BXC, 4))
     for s in range(4):
         e("ds_read_b128 %s, %%[vfrag] offset:%d" % (rng(BF + 4 * s, 4), s * 2048))
     e("LT_%=:")
     half_step(0)
-    e("s_waitcnt vmcnt(%d)" % (2 * (nbuf - 2)))
+    e("s_waitcnt vmcnt(%d)" % (npw * (nbuf - 2)))
     e("s_barrier")
     half_step(1)
     e("v_mov_b32 v%d, v%d" % (VBC, VBN))
@@ -318,6 +354,10 @@ def gen_fp4(nbuf=6):
     e("s_cselect_b32 s55, 0, s55")
     e("s_lshr_b32 s56, s55, 1")
     e("v_add_u32 v%d, s56, %%[vfrag]" % VBN)
+    if gated:
+        e("v_mov_b32 v%d, v%d" % (VCC, VCN))
+        e("s_lshr_b32 s56, s55, 3")
+        e("v_add_u32 v%d, s56, %%[vcfrag]" % VCN)
     e("s_add_i32 s40, s40, 1")
     e("s_cmp_lt_i32 s40, %[ntiles]")
     e("s_cbranch_scc1 LT_%=")
@@ -347,7 +387,8 @@ def main():
         f.write("#define LF_ASSOC_LOOP_PLAIN \\\n" + c_string(gen(False)).replace("\n", " \\\n") + "\n\n")
         f.write("#define LF_ASSOC_LOOP_GATED \\\n" + c_string(gen(True)).replace("\n", " \\\n") + "\n\n")
         f.write("#define LF_ASSOC_LOOP_FP4 \\\n" + c_string(gen_fp4()).replace("\n", " \\\n") + "\n\n")
-        clob_fp4 = ", ".join('"v%d"' % i for i in list(range(76, 200)) + list(range(200, 232))) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "memory", "scc"'
+        f.write("#define LF_ASSOC_LOOP_FP4_GATED \\\n" + c_string(gen_fp4(gated=True)).replace("\n", " \\\n") + "\n\n")
+        clob_fp4 = ", ".join('"v%d"' % i for i in list(range(76, 200)) + list(range(200, 239))) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "memory", "scc"'
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_FP4 " + clob_fp4 + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_PLAIN " + clob_plain + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_GATED " + clob_gated + "\n")

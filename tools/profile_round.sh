@@ -7,6 +7,7 @@ python bench.py > $R/gpurun_out/$T/bench_n1.json 2> $R/gpurun_out/$T/bench_n1.er
 python tools/assoc_rate.py > $R/gpurun_out/$T/assoc_rate.txt 2>&1
 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
 LF_ASSOC_INT8=1 python tools/assoc_rate.py --pairs 16384x50000,65536x262144 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
+LF_ASSOC_INT8=1 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 B="--secondary none --cpu-frames -1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/d6 -- python3 $R/bench.py --steps 12 --warmup 4 $B > $R/gpurun_out/$T/bench_d6_rocprof.json 2>/dev/null
