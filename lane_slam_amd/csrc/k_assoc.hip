@@ -518,6 +518,7 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     // amortise the query expansion and the final cross-lane reduction (measured: 512 > 1024 > 768 > 256)
     static const int slots = getenv("LF_ASSOC_SLOTS") ? atoi(getenv("LF_ASSOC_SLOTS")) : 512;
     int splits = slots / qblocks;
+    if (splits > 128) splits = 128;            // one or two query blocks: more, shorter chunks only lengthen the merge (32 -> 19 us at 256 x 50 000)
     if (splits < min_splits) splits = min_splits;
     if (splits > tiles) splits = tiles;
     if (splits < 1) splits = 1;
