@@ -19,8 +19,8 @@ namespace lf {
 #define LFG_LDS_KB 13
 #endif
 #ifndef LFG_REG_LDS
-#define LFG_REG_LDS 512
-#endif
+#define LFG_REG_LDS 256        // region-list entries per wave kept in LDS (the rest of a long region goes to the wave's scratch slice):
+#endif                         // 256 instead of 512 = 3 KB less per problem, +1 % frames/s (other kernels' workgroups find LDS sooner)
 
 #ifndef LFG_GROW_WAVES
 #define LFG_GROW_WAVES 3
