@@ -5,27 +5,25 @@
 // Mihasher(256, 32), K = 1 (:635-753) and the popcount Hamming distance of
 // bitops_custom.hpp:83-96: the exact Hamming nearest neighbour; candidates farther than
 // D = 128 are never reported (:721).  The reference's multi-index hash is a CPU
-// pointer-chasing structure rebuilt on every call; on MI355X the N x M distance matrix is
-// one dense int8 contraction: query bits -> +-32, map bits -> +-16, so dot / 512 = 256 - 2*hamming,
-// exactly.
+// pointer-chasing structure rebuilt on every call; on MI355X the N x M distance matrix is one dense matrix-core
+// contraction of +-1 operands: dot = 256 - 2 * hamming, exactly.
 //
-// Packed operands (kept by the live map across calls, k_map.hip packs only the rows that change):
-//   qx / mx   [rows][256] int8   the code, one byte per bit
-//   qcx / mcx [rows][32]  int8   the operands of a NINTH MFMA step (K = 32) that folds two more terms into
-//                                the accumulator:
-//        k = 0, 1      query [16, 1]  x  map [-(t >> 4), -(t & 15)]  = -t, the number of the 32-column block inside
-//                      the workgroup's map chunk (written by the kernel, the bytes are zero in memory)
-//        k = 2 .. 31   three groups of ten, one per colour: query 127 in the group of ITS colour (only when colour
-//                      gating is on), map -127 in the groups of the OTHER colours -> -161 290 when the colours
-//                      differ, which is below every candidate within distance 128 (key >= -511)
-//   key = 512 * dot - t - penalty orders candidates by distance, then by column block, so the running arg-max is
-//   ONE v_max per accumulator register and colour gating (SURVEY a-11) costs nothing: it rides in the matrix core.
-// k_assoc      : 256 queries per workgroup (4 waves x 2 x 32 rows, A fragments resident in VGPRs; a B fragment
-//   read from LDS feeds two MFMAs), map streamed through LDS in 64-entry tiles by LDS-DMA (double buffered,
-//   source-swizzled: conflict-free ds_read_b128), v_mfma_i32_32x32x32_i8 over K = 256 + 32; ties resolve to the
-//   lowest map index.  Map chunks are spread over gridDim.y and merged with atomicMin on the packed word.
-//   Algorithmic ops: 2*N*M*256 int8.
-// k_assoc_float: 72-d float LBD, Euclidean, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
+// Kernels (one launch per association; DESIGN.md section 4 and 5 have the measurements):
+//   k_assoc_fp4 / k_assoc_fp4_gated   the product path: every code bit is an e2m1 nibble (+1.0 / -1.0), 64 bits per
+//       v_mfma_scale_f32_32x32x64_f8f6f4, query side scaled by 2^9 through the E8M0 block scale, exact f32 accumulation;
+//       the 32-column block number t enters through a fifth matrix step (weights 64, 8, 1 x minus the octal digits of
+//       t), colour gating through one more (-147 456 when the colours differ): key = 512 * dot - t - penalty orders
+//       candidates by distance, then by column block, so the running arg-max is ONE v_max_f32 per accumulator register.
+//       Map rows: 128 bytes, blocked by 64-row tile (assoc_map_offset_fp4); colour rows: 32 bytes per map row.
+//   k_assoc / k_assoc_plain           the int8 form (LF_ASSOC_INT8=1, kept for A/B runs): query bits +-32, map bits +-16,
+//       v_mfma_i32_32x32x32_i8, K = 256; the block number is the chain's start value (plain) or, with gating, part of
+//       a ninth step (K = 32: [16, 1] x [-(t >> 4), -(t & 15)], and 127 x -127 over ten bytes per colour group =
+//       -161 290 when the colours differ).  Map rows: 256 bytes blocked by tile (assoc_map_offset) + 32-byte ninth-step rows.
+//   All of them: 256 queries per workgroup (4 waves x 2 x 32 rows), query operands expanded from the raw 32-byte codes
+//   into registers, map chunk streamed by LDS-DMA through tile buffers, hand-scheduled tile loop (k_assoc_loop.inc,
+//   tools/gen_assoc_loop.py), per-chunk key rows written through and merged by the last workgroup to arrive; ties
+//   resolve to the lowest map index.  Algorithmic ops: 2*N*M*256.
+//   k_assoc_float: 72-d float LBD, Euclidean, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain).
 #include <cstdlib>
 #include <cstdio>
 #include "common.h"
