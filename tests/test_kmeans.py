@@ -71,6 +71,14 @@ def test_gpu_kmeans_is_bit_identical_to_oracle(golden, k):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2] and got[3] == want[3]
     with pytest.raises(Exception):
         fe.kmeans(np.zeros((2, 3), np.uint8), [[0, 0, 0], [1, 1, 1], [2, 2, 2]])
+    if k == 4:
+        # more clusters than the register-accumulation path holds (k > 4: one LDS atomic per sample), and the 16-cluster limit
+        rng = np.random.default_rng(12)
+        pts = rng.integers(0, 256, (30000, 3), dtype=np.uint8)
+        for kk in (6, 16):
+            init = rng.integers(0, 256, (kk, 3)).astype(np.float64)
+            want, got = O.kmeans(pts, init), fe.kmeans(pts, init)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2] and got[3] == want[3]
 
 
 @pytest.mark.gpu
