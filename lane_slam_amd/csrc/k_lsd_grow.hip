@@ -34,11 +34,11 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
                                                  const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
                                                  const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
                                                  int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
-                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds)
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, const int* __restrict__ perm)
 {
     extern __shared__ uint32_t lds[];
     __shared__ int next_comp, line_count, waves_done;
-    const int pc = blockIdx.x;
+    const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
@@ -139,7 +139,7 @@ size_t lsd_grow_reg_stride(const LsdParams& p)
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
-                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, hipStream_t s)
+                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm, hipStream_t s)
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.
@@ -163,7 +163,7 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
     const size_t lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
                        c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
-                       tmp_tags, lines, counts, reg_lds, def_lds);
+                       tmp_tags, lines, counts, reg_lds, def_lds, perm);
 }
 
 }  // namespace lf

@@ -330,7 +330,7 @@ constexpr int LT = 512;
 
 __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                   const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
-                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int comp_cap)
+                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int* __restrict__ comp_key, int comp_cap)
 {
     extern __shared__ uint32_t dyn_lds[];
     // 48 KB: three workgroups per CU, i.e. all 768 problems of a 256-frame batch are resident at once
@@ -345,11 +345,11 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     const int n = norder[pc];
     uint16_t* lab = c_label + o;
     uint16_t* list = comp_list + (size_t)pc * kCompCap;
-    if (n == 0) { if (t == 0) comp_count[pc] = 0; return; }
+    if (n == 0) { if (t == 0) { comp_count[pc] = 0; comp_key[pc] = 0; } return; }
     if (n > LI) {
         // too large for the LDS tables (1080p problems): one component = the whole problem, as before
         for (int e = t; e < n; e += LT) lab[e] = 0;
-        if (t == 0) { list[0] = 0; comp_count[pc] = 1; }
+        if (t == 0) { list[0] = 0; comp_count[pc] = 1; comp_key[pc] = n; }
         return;
     }
     const int* rs = row_start + (size_t)pc * (p.Hs + 1);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     if (C > comp_cap) {
         // more eligible components than the list holds (tiny min_reg_size): fall back to one component
         for (int e = t; e < n; e += LT) lab[e] = 0;
-        if (t == 0) { list[0] = 0; comp_count[pc] = 1; }
+        if (t == 0) { list[0] = 0; comp_count[pc] = 1; comp_key[pc] = n; }
         return;
     }
     for (int i = t; i < C; i += LT) {
@@ -410,12 +410,39 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
             rank += (sj > si || (sj == si && rj < ri)) ? 1 : 0;
         }
         list[rank] = (uint16_t)ri;
+        if (rank == 0) comp_key[pc] = (int)si;                   // launch-order key (k_lsd_rank): the largest component = the longest wave
     }
-    if (t == 0) comp_count[pc] = C;
+    if (t == 0) { comp_count[pc] = C; if (C == 0) comp_key[pc] = 0; }
+}
+
+// Launch order of k_lsd_grow's workgroups: problems with the largest connected component first (k_lsd_label's comp_key;
+// longest first: when the chip is
+// full of another batch's growing waves, the workgroups of this launch start as slots free up, and the long problems
+// should not be the last to start).  rank by counting: n_prob <= 768.
+__global__ __launch_bounds__(1024) void k_lsd_rank(int n_prob, const int* __restrict__ norder, int* __restrict__ perm)
+{
+    __shared__ int nd[1024];
+    for (int base = 0; base < n_prob; base += 1024) {       // (n_prob <= 1024 in every configuration; kept general)
+        const int i = base + threadIdx.x;
+        if (i < n_prob) nd[threadIdx.x] = norder[i];
+        __syncthreads();
+        if (i < n_prob && n_prob <= 1024) {
+            const int mine = nd[threadIdx.x];
+            int rank = 0;
+            for (int j = 0; j < n_prob; ++j) rank += (nd[j] > mine || (nd[j] == mine && j < i)) ? 1 : 0;
+            perm[rank] = i;
+        } else if (i < n_prob) perm[i] = i;
+        __syncthreads();
+    }
+}
+
+void launch_lsd_rank(int n_prob, const int* norder, int* perm, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lsd_rank, dim3(1), dim3(1024), 0, s, n_prob, norder, perm);
 }
 
 void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
-                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, hipStream_t s)
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, hipStream_t s)
 {
     const size_t lds = (size_t)p.label_items * (4 + 2);
     static size_t attr_lds = 0;
@@ -426,7 +453,7 @@ void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const
     }
     // LF_DIAG_COMP_CAP: a smaller component list, so that tests reach the "more components than the list holds" fallback
     static const int comp_cap = getenv("LF_DIAG_COMP_CAP") ? max(1, min(kCompCap, atoi(getenv("LF_DIAG_COMP_CAP")))) : kCompCap;
-    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_cap);
+    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap);
 }
 
 // Debug only: dense angle / magnitude planes rebuilt from the compact arrays (NOTDEF / 0 elsewhere).

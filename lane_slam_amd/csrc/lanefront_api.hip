@@ -84,6 +84,8 @@ struct lf_handle {
     float* d_slot_lines = nullptr;
     uint16_t *d_clabel = nullptr, *d_comp_list = nullptr;     // connected components of the LSD problems (k_lsd_label)
     int* d_comp_count = nullptr;
+    int* d_perm = nullptr;
+    int* d_comp_key = nullptr;
     float* d_tmp_lines = nullptr;                             // lines in completion order + their seed positions (k_lsd_grow)
     int* d_tmp_tags = nullptr;
     int* d_seg_frame = nullptr;
@@ -404,7 +406,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_tile_count, 1) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
         dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(h->lsd)) ||
-        dalloc(h, &h->d_clabel, nprob * Ps) || dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) ||
+        dalloc(h, &h->d_clabel, nprob * Ps) || dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) || dalloc(h, &h->d_perm, nprob) || dalloc(h, &h->d_comp_key, nprob) ||
         dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
@@ -446,7 +448,7 @@ extern "C" void lf_destroy(lf_handle* h)
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_gray, h->dbg_masks.p, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
                      h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
-                     h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
+                     h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
                      h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
@@ -546,7 +548,9 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s); }
     {
         StageTimer t(h, ST_LSD_ORDER);
-        launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, s);
+        launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
+        static const bool no_rank = getenv("LF_DIAG_NO_RANK") != nullptr;
+        if (!no_rank) launch_lsd_rank(n * 3, h->d_comp_key, h->d_perm, s);
     }
     static const char* diag_skip = getenv("LF_DIAG_SKIP");     // diagnostic only (what-if timing, results are wrong): "grow"
     if (diag_skip && strstr(diag_skip, "grow")) LF_HIP_CHECK(h, hipMemsetAsync(h->d_counts, 0, (size_t)n * 3 * sizeof(int), s));
@@ -554,7 +558,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         StageTimer t(h, ST_LSD_GROW);
         launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                        h->d_slot_lines, h->d_counts, s);
+                        h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
@@ -862,10 +866,10 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
                     h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
     launch_lsd_order(h->lsd, 1, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder,
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
-    launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, s);
+    launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                    h->d_slot_lines, h->d_counts, s);
+                    h->d_slot_lines, h->d_counts, nullptr, s);
     LF_HIP_CHECK(h, hipGetLastError());
     int n = 0;
     LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->d_counts, sizeof(int), hipMemcpyDeviceToHost, s));
