@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--cap", type=int, default=512, help="max lines per (frame, colour)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
-    ap.add_argument("--depth", type=int, default=0, help="independent batches in flight (handles/streams); 0: 6, or 3 for --geometry hd")
+    ap.add_argument("--depth", type=int, default=0, help="independent batches in flight (handles/streams); 0: 6")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     ap.add_argument("--secondary", default="auto", choices=["auto", "all", "none"],
@@ -131,7 +131,7 @@ def main():
 
     hd = args.geometry == "hd"
     B = args.batch or (128 if hd else 256)
-    D = args.depth if args.depth > 0 else (3 if hd else 6)
+    D = args.depth if args.depth > 0 else 6
     in_rows, in_cols = (1080, 1920) if hd else (480, 640)
     cfg = default_config("fullres", in_size=(in_rows, in_cols)) if hd else default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
