@@ -56,6 +56,9 @@ def load():
         raise RuntimeError(
             "lanefront: %s is missing. Build the HIP library first (python -c 'import __graft_entry__ as g; "
             "g.build()' or make -C lane_slam_amd/csrc). There is no CPU fallback." % SO_PATH)
+    # kernel arguments in device memory (about 2 us less per launch: INTEGRATION.md section 4); only a default, and only
+    # effective when the HIP runtime has not been initialised by someone else before
+    os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
     lib = ctypes.CDLL(SO_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     lib.lf_abi_version.restype = ci
