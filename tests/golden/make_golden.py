@@ -483,6 +483,23 @@ def golden_kmeans():
     print("kmeans.npz:", len(imgs), "images x 2 inits, scikit-learn", sklearn.__version__)
 
 
+def golden_real_frames():
+    """Three of the reference's real Duckiebot camera frames (src/anti_instagram/annotation-tool/images/*.jpg, data files
+    of the reference, not source) as decoded B, G, R pixel arrays: INPUT data for the GPU parity tests, so that the
+    front end is also compared with the oracle on camera images, not only on synthetic ones.  No expected outputs are
+    stored: the oracle computes them at test time."""
+    from PIL import Image
+    d = os.path.join(REF, "anti_instagram/annotation-tool/images")
+    names = sorted(os.listdir(d))
+    picks = [names[0], names[len(names) // 2], names[-1]]
+    out = {}
+    for k, n in enumerate(picks):
+        rgb = np.asarray(Image.open(os.path.join(d, n)).convert("RGB"))
+        out["frame%d" % k] = np.ascontiguousarray(rgb[:, :, ::-1])       # B, G, R like cv2.imdecode
+    np.savez_compressed(os.path.join(OUT, "real_frames.npz"), **out)
+    print("real_frames.npz:", picks, [v.shape for v in out.values()])
+
+
 if __name__ == "__main__":
     install_stubs()
     golden_node_pipeline()
@@ -493,3 +510,4 @@ if __name__ == "__main__":
     golden_scaleandshift()
     install_stubs()
     golden_kmeans()
+    golden_real_frames()

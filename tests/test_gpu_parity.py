@@ -4,6 +4,8 @@ descriptor floats are checked both bit-exact (same deterministic arithmetic) and
 north-star tolerance 1e-4."""
 import ctypes
 
+import os
+
 import numpy as np
 import pytest
 
@@ -570,6 +572,35 @@ def test_associate_large_map_and_many_ties():
     oi, od = o.match(q, m)
     assert np.array_equal(dist, od) and np.array_equal(idx, oi)
     assert (dist <= 2).all() and (np.diff(np.sort(idx)) >= 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo", ["fullres", "parity"])
+def test_real_camera_frames_match_oracle(geo, golden_dir):
+    """Three of the reference's own Duckiebot camera frames (night, day, ice rink lighting; decoded pixels in
+    tests/golden/real_frames.npz, generator make_golden.py: golden_real_frames): every output field of the front end
+    bit-identical to the oracle on camera images as well, and the anti-instagram clustering of their bottom strips."""
+    from oracle.oracle import Oracle, kmeans as oracle_kmeans
+    z = np.load(os.path.join(golden_dir, "real_frames.npz"))
+    frames = np.stack([z["frame%d" % k] for k in range(3)])
+    cfg = default_config(geo)
+    fe = FrontEnd(cfg, max_frames=3, max_lines_per_color=1024)
+    o = Oracle(cfg)
+    seg = fe.process_batch(frames, describe=True)
+    total = 0
+    for f in range(3):
+        r = o.process_frame(frames[f], cap=3 * 4096)
+        s = seg.frame(f)
+        assert s.n == r["n"], (f, s.n, r["n"])
+        total += s.n
+        for k in ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "code"):
+            assert np.array_equal(getattr(s, k), r[k]), (f, k)
+        assert np.array_equal(s.desc, r["desc"], equal_nan=True)
+        pts = np.ascontiguousarray(frames[f][-100:].reshape(-1, 3))
+        for init in ([[60, 60, 60], [50, 240, 240], [240, 240, 240]], [[60, 60, 60], [60, 60, 240], [50, 240, 240], [240, 240, 240]]):
+            got, want = fe.kmeans(pts, init), oracle_kmeans(pts, init)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and got[2] == want[2]
+    assert total > 30
 
 
 @pytest.mark.gpu
