@@ -22,6 +22,20 @@ namespace lf {
 #define LFG_REG_LDS 256        // region-list entries per wave kept in LDS (the rest of a long region goes to the wave's scratch slice):
 #endif                         // 256 instead of 512 = 3 KB less per problem, +1 % frames/s (other kernels' workgroups find LDS sooner)
 
+// Deferred evaluation (lsd_grow.h EvalQueue): the wave that runs out of components FIRST stays as the problem's helper for
+// as long as anyone grows (it polls the ring between s_sleeps, up to LFG_HELP_POLLS_FIRST empty polls in a row), the
+// other one leaves at once so that its wave slot goes to another problem.  Measured in the same call, configs[1]:
+// longest problem 7.96 -> 6.92 Mcycles, one batch alone 4.87 -> 4.33 ms, six batches in flight 127.5k -> 130.1k frames/s;
+// both helpers staying (polls 512 / 4096 for every wave) gives the same solo time but 127.5k / 128.5k pipelined.
+#ifndef LFG_EVAL_QUEUE
+#define LFG_EVAL_QUEUE 1
+#endif
+#ifndef LFG_HELP_POLLS_FIRST
+#define LFG_HELP_POLLS_FIRST 4096
+#endif
+#ifndef LFG_HELP_POLLS
+#define LFG_HELP_POLLS 0
+#endif
 #ifndef LFG_GROW_WAVES
 #define LFG_GROW_WAVES 3
 #endif
@@ -38,6 +52,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
 {
     extern __shared__ uint32_t lds[];
     __shared__ int next_comp, line_count, waves_done;
+    __shared__ grow::EvalQueue evalq;
     const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
@@ -55,15 +70,19 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     uint32_t* gu = gused + (size_t)pc * ((Ps + 31) / 32);
     if (n_def > def_lds)
         for (int i = tid; i < (n_def + 31) / 32; i += 64 * GROW_WAVES) gu[i] = 0u;
-    if (tid == 0) { next_comp = 0; line_count = 0; waves_done = 0; }
+    if (tid == 0) { next_comp = 0; line_count = 0; waves_done = 0; evalq.tail = 0; evalq.head = 0; evalq.growers = GROW_WAVES; }
+    if (tid < LFG_QN) evalq.seq[tid] = 0;
     __threadfence_block();
     __syncthreads();
     const int n_comp = comp_count[pc];
     const uint16_t* clist = comp_list + (size_t)pc * comp_cap;
     float* tl = tmp_lines + (size_t)pc * p.cap_lines * 4;
     int* tt = tmp_tags + (size_t)pc * p.cap_lines;
+    static_assert(LFG_QN <= 64, "ring slots are initialised by the first lanes");
+    const bool use_queue = LFG_EVAL_QUEUE != 0;
     grow::Ctx c;
     c.W = p.Ws; c.H = p.Hs;
+    c.q = use_queue ? &evalq : nullptr;
     c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
     c.deg = c_deg + (size_t)pc * Ps;
     c.mod = c_mod + (size_t)pc * Ps;
@@ -94,6 +113,32 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
         if (k >= n_comp) break;
         c.root = (int)clist[k];
         (void)grow::detect(c, order + (size_t)pc * Ps, n_def, tl, p.cap_lines);
+    }
+    // no more components for this wave: help with the deferred evaluations until every growing wave is done and the ring is
+    // empty -- or until there has been nothing to take for a while (an idle wave gives its slot back; whatever is pushed
+    // after that is taken by the waves that finish later, the last grower always drains the ring)
+    if (use_queue) {
+        int first = 0;
+        if (lane == 0) first = atomicSub(&evalq.growers, 1);
+        // the first wave to run out of components stays for as long as anyone grows; the others only briefly
+        const int polls = __builtin_amdgcn_readfirstlane(first) == GROW_WAVES ? LFG_HELP_POLLS_FIRST : LFG_HELP_POLLS;
+        int idle = 0;
+        for (;;) {
+            grow::Rect r;
+            int tag = 0;
+            if (grow::eval_pop(c, r, tag)) { (void)grow::evaluate_region(c, r, tag, tl, p.cap_lines, 0); idle = 0; continue; }
+            int g = 0;
+            if (lane == 0) g = __hip_atomic_load(&evalq.growers, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            g = __builtin_amdgcn_readfirstlane(g);
+            if (g == 0) {
+                int left = 0;
+                if (lane == 0) left = __hip_atomic_load(&evalq.tail, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - __hip_atomic_load(&evalq.head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (__builtin_amdgcn_readfirstlane(left) <= 0) break;
+                continue;
+            }
+            if (++idle > polls) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
     }
 #ifdef LFG_STAMPS
     if (lane == 0) {

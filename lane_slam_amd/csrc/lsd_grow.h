@@ -111,7 +111,27 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 
 // All per-pixel data live in COMPACT arrays indexed by e = raster rank among the problem's
 // defined pixels (written by k_lsd_order); the dense scaled-image planes are never touched here.
+// Deferred evaluation (GPU build).  Once a region has its final rectangle, what is left -- rect_improve's NFA search and
+// the emission of the line -- reads only the rectangle and the problem's immutable arrays and changes no USED bit, so it
+// does not have to happen before the next region is grown: the growing wave pushes (rectangle, seed tag) into a small
+// ring in LDS and goes on to the next seed; waves of the workgroup that have run out of components pop and evaluate.
+// Lines carry their seed's tag, so the order in which they are emitted does not matter (k_lsd_grow.hip restores it).
+// Nobody ever waits on the ring: a push that finds it full (or the slot not yet copied out) evaluates in place, a pop
+// that finds it empty returns; the only spin is a consumer waiting for the handful of stores of the producer whose
+// ticket it has claimed.
+#ifndef LFG_QN
+#define LFG_QN 16
+#endif
+struct EvalQueue {
+    int tail, head;            // tickets reserved by producers / claimed by consumers
+    int growers;               // waves of the workgroup that may still push
+    int seq[LFG_QN];           // 0: slot free; t + 1: the item of ticket t is complete
+    int tag[LFG_QN];
+    double rec[LFG_QN][12];
+};
+
 struct Ctx {
+    EvalQueue* q;             // LDS  deferred-evaluation ring of the workgroup, or nullptr (evaluate in place)
     int W, H;
     const int* rows;          // LDS  [H+1]  first entry of each row; rows[H] = number of defined pixels
     const uint16_t* lxs;      // LDS  x coordinate of entries e < def_lds (sorted inside a row)
@@ -964,6 +984,105 @@ LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 // ------------------------------------------------------------------ main loop (flsd)
 // order: sorted seed items ((1023-bin) << 20 | compact entry e); returns the number of lines this call found.
 // Lines go to slot atomicAdd(*c.line_count) while that is below cap, with their seed's position in `order` as tag.
+// rect_improve + emission of one finished region (in place, or by a helping wave from the ring)
+LFG_DEV bool evaluate_region(const Ctx& c, Rect& rec, int tag, float* lines, int cap, int n_lines)
+{
+    if (c.refine >= 2) {
+        const double log_nfa = rect_improve(c, rec);
+        if (log_nfa <= c.log_eps) return false;
+    }
+    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+    if (c.scale != 1) {
+        rec.x1 /= c.scale; rec.y1 /= c.scale; rec.x2 /= c.scale; rec.y2 /= c.scale;
+    }
+#ifndef LF_HOST_SIM
+    (void)n_lines;
+    if (lane_id() == 0) {
+        const int slot = atomicAdd(c.line_count, 1);          // any order: the tags restore the sequential one
+        if (slot < cap) {
+            lines[4 * slot + 0] = (float)rec.x1;
+            lines[4 * slot + 1] = (float)rec.y1;
+            lines[4 * slot + 2] = (float)rec.x2;
+            lines[4 * slot + 3] = (float)rec.y2;
+            c.tags[slot] = tag;
+        }
+    }
+#else
+    {
+        const int slot = c.line_count ? (*c.line_count)++ : n_lines;
+        if (slot < cap) {
+            lines[4 * slot + 0] = (float)rec.x1;
+            lines[4 * slot + 1] = (float)rec.y1;
+            lines[4 * slot + 2] = (float)rec.x2;
+            lines[4 * slot + 3] = (float)rec.y2;
+            if (c.tags) c.tags[slot] = tag;
+        }
+    }
+#endif
+    return true;
+}
+
+#ifndef LF_HOST_SIM
+LFG_DEV bool eval_push(const Ctx& c, const Rect& rec, int tag)
+{
+    EvalQueue* q = c.q;
+    int slot = -1;
+    if (lane_id() == 0) {
+        int t = __hip_atomic_load(&q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (;;) {
+            const int h = __hip_atomic_load(&q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (t - h >= LFG_QN) break;                                                                    // full
+            if (__hip_atomic_load(&q->seq[t % LFG_QN], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) break;   // still being copied out
+            const int old = atomicCAS(&q->tail, t, t + 1);
+            if (old == t) { slot = t; break; }
+            t = old;
+        }
+        if (slot >= 0) {
+            const int s = slot % LFG_QN;
+            double* d = q->rec[s];
+            d[0] = rec.x1; d[1] = rec.y1; d[2] = rec.x2; d[3] = rec.y2; d[4] = rec.width; d[5] = rec.x; d[6] = rec.y;
+            d[7] = rec.theta; d[8] = rec.dx; d[9] = rec.dy; d[10] = rec.prec; d[11] = rec.p;
+            q->tag[s] = tag;
+            __hip_atomic_store(&q->seq[s], slot + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(slot) >= 0;
+}
+
+LFG_DEV bool eval_pop(const Ctx& c, Rect& rec, int& tag)
+{
+    EvalQueue* q = c.q;
+    int t = -1;
+    if (lane_id() == 0) {
+        int h = __hip_atomic_load(&q->head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (;;) {
+            if (h >= __hip_atomic_load(&q->tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;   // empty
+            const int old = atomicCAS(&q->head, h, h + 1);
+            if (old == h) { t = h; break; }
+            h = old;
+        }
+        if (t >= 0) {
+            // the producer of ticket t reserved it before it wrote the item: a few stores away at most (bounded spin: a
+            // ring gone wrong must not hang the GPU; the parity tests would show the lost region)
+            int spins = 0;
+            while (__hip_atomic_load(&q->seq[t % LFG_QN], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t + 1 && ++spins < (1 << 20))
+                __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t < 0) return false;
+    const int s = t % LFG_QN;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const double* d = q->rec[s];
+    rec.x1 = d[0]; rec.y1 = d[1]; rec.x2 = d[2]; rec.y2 = d[3]; rec.width = d[4]; rec.x = d[5]; rec.y = d[6];
+    rec.theta = d[7]; rec.dx = d[8]; rec.dy = d[9]; rec.prec = d[10]; rec.p = d[11];
+    tag = q->tag[s];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane_id() == 0) __hip_atomic_store(&q->seq[s], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return true;
+}
+#endif
+
 LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* lines, int cap)
 {
     int n_lines = 0;
@@ -1041,39 +1160,10 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         }
         LFG_T1(c, 3)
         if (rejected) continue;
-        double log_nfa = -1;
-        if (c.refine >= 2) {
-            log_nfa = rect_improve(c, rec);
-            LFG_T1(c, 6)
-            if (log_nfa <= c.log_eps) continue;
-        }
-        rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-        if (c.scale != 1) {
-            rec.x1 /= c.scale; rec.y1 /= c.scale; rec.x2 /= c.scale; rec.y2 /= c.scale;
-        }
 #ifndef LF_HOST_SIM
-        if (lane_id() == 0) {
-            const int slot = atomicAdd(c.line_count, 1);          // any order: the tags restore the sequential one
-            if (slot < cap) {
-                lines[4 * slot + 0] = (float)rec.x1;
-                lines[4 * slot + 1] = (float)rec.y1;
-                lines[4 * slot + 2] = (float)rec.x2;
-                lines[4 * slot + 3] = (float)rec.y2;
-                c.tags[slot] = tag;
-            }
-        }
-#else
-        {
-            const int slot = c.line_count ? (*c.line_count)++ : n_lines;
-            if (slot < cap) {
-                lines[4 * slot + 0] = (float)rec.x1;
-                lines[4 * slot + 1] = (float)rec.y1;
-                lines[4 * slot + 2] = (float)rec.x2;
-                lines[4 * slot + 3] = (float)rec.y2;
-                if (c.tags) c.tags[slot] = tag;
-            }
-        }
+        if (c.q && c.refine >= 2 && eval_push(c, rec, tag)) continue;      // a helping wave takes it from here
 #endif
+        if (!evaluate_region(c, rec, tag, lines, cap, n_lines)) { LFG_T1(c, 6) continue; }
         ++n_lines;
         LFG_T1(c, 6)
       }

@@ -66,6 +66,7 @@ extern "C" int hs_lsd_detect_ex(const double* scaled, int H, int W, double rho, 
     std::vector<uint32_t> usedc((n_def + 63) / 32 + 1, 0u), gused((n_def + 63) / 32 + 1, 0u);
     std::vector<uint32_t> lreg(reg_lds > 0 ? reg_lds : 1), greg(Ps);
     grow::Ctx c;
+    c.q = nullptr;
     c.W = W; c.H = H;
     c.rows = rows.data(); c.lxs = xs.data(); c.gxy = gxy.data(); c.def_lds = reg_lds < n_def ? reg_lds : n_def;
     c.deg = deg.data(); c.mod = modc.data(); c.cs = csc.data(); c.sn = snc.data();

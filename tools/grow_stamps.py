@@ -22,6 +22,8 @@ tot_w = raw[:, :, 24].astype(np.float64)
 print("wave totals (kcycles): slowest wave mean %.0f max %.0f | sum over waves mean %.0f | components mean %.1f" % (
     tot_w.max(1).mean() / 1e3, tot_w.max() / 1e3, tot_w.sum(1).mean() / 1e3, raw[:, 0, 26].mean()))
 slow = tot_w.argmax(1)
+worst = np.argsort(tot_w.max(1))[-4:]
+print("waves of the four longest problems (kcycles):", [[int(v / 1e3) for v in tot_w[w]] for w in worst])
 d = raw[np.arange(n * 3), slow][:, :27].astype(np.float64)          # the slowest wave of every problem
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
          "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc", "isolated_seeds"] + ["-"] * 3 + ["total", "n_order", "n_comp"]
