@@ -6,9 +6,8 @@
 // wins ties), non-maximum suppression with the 15-bit TG22 sector test against a
 // zero-padded magnitude image, then 8-connected hysteresis.
 //
-// k_canny_nms: one 64x16 tile per workgroup; BGR tile (+2 halo) -> LDS, magnitude tile
-//   (+1 halo) -> LDS, NMS classification; each wave owns image rows so the 64-lane ballot
-//   IS the 64-pixel bit-plane word pair.  Output: `weak` (m > low and local max) and
+// k_canny_nms: one wave per 64-column x 62-row band, lane = column, rows streamed through registers (see the kernel);
+//   the 64-lane ballot of a row IS the 64-pixel bit-plane word pair.  Output: `weak` (m > low and local max) and
 //   `strong` (also m > high) bit planes, 1 bit per pixel -- 8x fewer bytes than u8 maps.
 //   Algorithmic bytes per pixel: 3 read (moved as one BGRX dword), 2/8 written.
 // k_hysteresis: one workgroup per frame, both bit planes resident in LDS (k_hysteresis_strips: strip by strip
@@ -20,112 +19,223 @@
 
 namespace lf {
 
-constexpr int CT_W = 64, CT_H = 16;
+// ---- k_canny_nms: one WAVE per 64-column x 62-row band, lane = column, rows stream through registers ----------
+// The kernel is bound by vector instructions, not by bytes (the tile version spent 159 lane-operations per pixel:
+// 16 LDS reads per magnitude, index arithmetic, two LDS round trips), so the layout is chosen for instruction count:
+//   * a lane owns one image column and walks down the rows; per row it loads its pixel and its two horizontal
+//     neighbours (three coalesced dword loads through the texture cache, columns clamped = BORDER_REPLICATE), and
+//     forms the row's horizontal difference and smoothing terms ONCE (Sobel is separable): B and R together in two
+//     16-bit lanes, G beside them;
+//   * a pixel's dx, dy combine the terms of three consecutive rows, which rotate through three register sets (the
+//     loop body is three steps, so nothing is ever copied); rows are fetched three steps ahead of their use;
+//   * per row the only unconditional work is the three magnitudes and their maximum; everything else -- which channel
+//     won, the sector test, the comparison with the neighbours -- runs only when some pixel of the 64 exceeds the low
+//     threshold, behind one wave-uniform branch;
+//   * horizontal neighbours of the magnitudes come from the adjacent lanes (DPP wave shifts); the two columns next to
+//     the strip (x0 - 1 and x0 + 64) are worked out once per band with lane = row (R + 2 = 64 rows) and enter the shifts
+//     as the value of the vacated lane;
+//   * the 64-lane ballot of a row IS the pair of bit-plane words, as before.
+#ifndef LF_CANNY_ROWS
+#define LF_CANNY_ROWS 62
+#endif
+constexpr int CB_R = LF_CANNY_ROWS;
+static_assert(CB_R + 2 <= 64, "the columns beside a strip are worked out with one lane per magnitude row");
 
-__global__ __launch_bounds__(256) void k_canny_nms(CannyParams p, const uint32_t* __restrict__ bgr,
-                                                   uint32_t* __restrict__ strong, uint32_t* __restrict__ weak)
+typedef short cn_s2 __attribute__((ext_vector_type(2)));
+
+struct CannyH {            // horizontal terms of one pixel row at this lane's column
+    cn_s2 d_br, s_br;      // right - left, left + 2 centre + right: (B, R)
+    int d_g, s_g;          // the same for G
+};
+struct CannyG {            // gradient of one pixel, all channels, and the channel magnitudes
+    cn_s2 dx_br, dy_br;
+    int dx_g, dy_g;
+    uint32_t m_br;         // |dx| + |dy|: B in the low half, R in the high half
+    int m_g;
+};
+
+__device__ __forceinline__ CannyH canny_hterms(uint32_t aL, uint32_t aM, uint32_t aR)
 {
-    // the working image's pixels, unpacked ONCE when they are loaded: B | R << 16 (two 16-bit lanes for packed
-    // arithmetic) and G.  Every magnitude pixel reads its eight neighbours from both planes: no byte extraction in
-    // the 8-fold reused inner formula.
-    __shared__ uint32_t pbr[(CT_H + 4) * (CT_W + 4)];
-    __shared__ uint32_t pg[(CT_H + 4) * (CT_W + 4)];
-    __shared__ int mag[(CT_H + 2) * (CT_W + 2)];
-    __shared__ int gxy[(CT_H + 2) * (CT_W + 2)];
-    int tbx, tby, f;
-    lf_xcd_tile(tbx, tby, f);
-    const int x0 = tbx * CT_W, y0 = tby * CT_H;
-    const uint32_t* img = bgr + (size_t)f * p.Hc * p.W;
-    constexpr int PW = CT_W + 4, PH = CT_H + 4, MW = CT_W + 2, MH = CT_H + 2;
-    typedef short s2 __attribute__((ext_vector_type(2)));
+    const cn_s2 two = { 2, 2 };
+    const cn_s2 l = __builtin_bit_cast(cn_s2, aL & 0x00ff00ffu), m = __builtin_bit_cast(cn_s2, aM & 0x00ff00ffu), r = __builtin_bit_cast(cn_s2, aR & 0x00ff00ffu);
+    const int lg = (int)((aL >> 8) & 0xffu), mg = (int)((aM >> 8) & 0xffu), rg = (int)((aR >> 8) & 0xffu);
+    CannyH h;
+    h.d_br = r - l;
+    h.s_br = l + two * m + r;
+    h.d_g = rg - lg;
+    h.s_g = lg + 2 * mg + rg;
+    return h;
+}
 
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    for (int idx = tid; idx < PW * PH; idx += 256) {
-        const int ty = idx / PW, tx = idx - ty * PW;
-        const int gx = min(max(x0 + tx - 2, 0), p.W - 1);
-        const int gy = min(max(y0 + ty - 2, 0), p.Hc - 1);
-        const uint32_t a = img[(size_t)gy * p.W + gx];
-        pbr[idx] = a & 0x00ff00ffu;
-        pg[idx] = (a >> 8) & 0xffu;
+// largest channel magnitude at (x, y), 0 outside the image (the zero-padded magnitude plane); plain integers, used
+// for the two columns beside a strip only
+__device__ __forceinline__ int canny_mag_at(const uint32_t* __restrict__ img, int W, int Hc, int x, int y)
+{
+    if (x < 0 || x >= W || y < 0 || y >= Hc) return 0;
+    const int xl = max(x - 1, 0), xr = min(x + 1, W - 1), yu = max(y - 1, 0), yd = min(y + 1, Hc - 1);
+    const uint32_t a00 = img[(size_t)yu * W + xl], a01 = img[(size_t)yu * W + x], a02 = img[(size_t)yu * W + xr];
+    const uint32_t a10 = img[(size_t)y * W + xl], a12 = img[(size_t)y * W + xr];
+    const uint32_t a20 = img[(size_t)yd * W + xl], a21 = img[(size_t)yd * W + x], a22 = img[(size_t)yd * W + xr];
+    int best = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int sh = 8 * ch;
+        const int v00 = (a00 >> sh) & 255, v01 = (a01 >> sh) & 255, v02 = (a02 >> sh) & 255, v10 = (a10 >> sh) & 255, v12 = (a12 >> sh) & 255;
+        const int v20 = (a20 >> sh) & 255, v21 = (a21 >> sh) & 255, v22 = (a22 >> sh) & 255;
+        const int dx = (v02 - v00) + 2 * (v12 - v10) + (v22 - v20);
+        const int dy = (v20 - v00) + 2 * (v21 - v01) + (v22 - v02);
+        best = max(best, abs(dx) + abs(dy));
     }
-    __syncthreads();
+    return best;
+}
+
+// lane i takes v of lane i - 1 (i + 1); the vacated lane 0 (63) takes `edge`
+__device__ __forceinline__ int canny_from_left(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int canny_from_right(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); }
+
+struct CannyBand {
+    const uint32_t* img;       // this frame's working image
+    uint32_t* weak;            // this frame's bit planes
+    uint32_t* strong;
+    int W, Hc, Ww, low, high;
+    int x0, y0, y_end;         // band: rows y0 .. y_end - 1
+    uint32_t xl, xm, xr;       // this lane's clamped columns, as byte offsets into a row
+    int lane;
+    bool in_image;             // this lane's column exists
+    bool st_ok;                // this lane stores a word of the bit planes (lanes 0, 1: the strip's first / second word)
+    uint32_t st_off;           // ... at this byte offset from the strip's first word
+    const int* halo;           // LDS, this wave's: [j] = magnitude at (x0 - 1, y0 - 1 + j), [64 + j] = at (x0 + 64, y0 - 1 + j)
+};
+
+__device__ __forceinline__ void canny_fetch(const CannyBand& c, int prow, uint32_t (&px)[3])
+{
+    const int yy = min(max(prow, 0), c.Hc - 1);
+    // scalar row base + 32-bit lane offset: no per-lane address arithmetic
+    const char* rp = reinterpret_cast<const char*>(c.img + (size_t)yy * c.W);
+    px[0] = *reinterpret_cast<const uint32_t*>(rp + c.xl); px[1] = *reinterpret_cast<const uint32_t*>(rp + c.xm); px[2] = *reinterpret_cast<const uint32_t*>(rp + c.xr);
+}
+
+// one row step.  Slots: (A, B, C) = the register sets of pixel rows (p - 2, p - 1, p); set C is overwritten here.
+template <int A, int B, int C>
+__device__ __forceinline__ void canny_step(const CannyBand& c, int t, uint32_t (&px)[3][3], CannyH (&H)[3], int (&M)[3], CannyG (&G)[3])
+{
+    const int p = c.y0 - 2 + t;
+    H[C] = canny_hterms(px[C][0], px[C][1], px[C][2]);
+    canny_fetch(c, p + 3, px[C]);                       // three rows ahead
+    if (t < 2) return;
+    // magnitudes of row y = p - 1
     {
-        for (int idx = tid; idx < MW * MH; idx += 256) {
-            const int ty = idx / MW, tx = idx - ty * MW;
-            const int gx = x0 + tx - 1, gy = y0 + ty - 1;
-            int best = 0, bx = 0, by = 0;
-            if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
-                const int o = (ty + 1) * PW + (tx + 1);
-                // B and R together, two signed 16-bit lanes (|dx|, |dy| <= 1020)
-                const uint32_t* c = pbr + o;
-                const s2 v00 = __builtin_bit_cast(s2, c[-PW - 1]), v01 = __builtin_bit_cast(s2, c[-PW]), v02 = __builtin_bit_cast(s2, c[-PW + 1]);
-                const s2 v10 = __builtin_bit_cast(s2, c[-1]), v12 = __builtin_bit_cast(s2, c[1]);
-                const s2 v20 = __builtin_bit_cast(s2, c[PW - 1]), v21 = __builtin_bit_cast(s2, c[PW]), v22 = __builtin_bit_cast(s2, c[PW + 1]);
-                const s2 two = { 2, 2 }, zero = { 0, 0 };
-                const s2 dx2 = (v02 - v00) + (v22 - v20) + two * (v12 - v10);
-                const s2 dy2 = (v20 - v00) + (v22 - v02) + two * (v21 - v01);
-                const s2 ax2 = __builtin_elementwise_max(dx2, zero - dx2), ay2 = __builtin_elementwise_max(dy2, zero - dy2);
-                const s2 m2 = ax2 + ay2;
-                // G in plain integers
-                const uint32_t* g = pg + o;
-                const int g00 = (int)g[-PW - 1], g01 = (int)g[-PW], g02 = (int)g[-PW + 1], g10 = (int)g[-1], g12 = (int)g[1];
-                const int g20 = (int)g[PW - 1], g21 = (int)g[PW], g22 = (int)g[PW + 1];
-                const int dxg = (g02 - g00) + 2 * (g12 - g10) + (g22 - g20);
-                const int dyg = (g20 - g00) + 2 * (g21 - g01) + (g22 - g02);
-                const int mg = abs(dxg) + abs(dyg);
-                // channel order B, G, R; the first of equal magnitudes wins
-                best = (int)m2.x; bx = (int)dx2.x; by = (int)dy2.x;
-                if (mg > best) { best = mg; bx = dxg; by = dyg; }
-                if ((int)m2.y > best) { best = (int)m2.y; bx = (int)dx2.y; by = (int)dy2.y; }
-            }
-            mag[idx] = best;
-            gxy[idx] = (bx & 0xFFFF) | (by << 16);
-        }
+        const int y = p - 1;
+        const cn_s2 two = { 2, 2 }, zero = { 0, 0 };
+        CannyG g;
+        g.dx_br = H[A].d_br + two * H[B].d_br + H[C].d_br;
+        g.dy_br = H[C].s_br - H[A].s_br;
+        g.dx_g = H[A].d_g + 2 * H[B].d_g + H[C].d_g;
+        g.dy_g = H[C].s_g - H[A].s_g;
+        const cn_s2 m_br = __builtin_elementwise_max(g.dx_br, zero - g.dx_br) + __builtin_elementwise_max(g.dy_br, zero - g.dy_br);
+        g.m_g = abs(g.dx_g) + abs(g.dy_g);
+        g.m_br = __builtin_bit_cast(uint32_t, m_br);
+        const int best = max(max((int)(g.m_br & 0xffffu), (int)(g.m_br >> 16)), g.m_g);
+        M[C] = (c.in_image && y >= 0 && y < c.Hc) ? best : 0;
+        G[C] = g;
     }
-    __syncthreads();
-    const int TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5);
-    for (int ry = threadIdx.y; ry < CT_H; ry += 4) {
-        const int gx = x0 + threadIdx.x, gy = y0 + ry;
-        bool keep = false, hi = false;
-        if (gx < p.W && gy < p.Hc) {
-            const int* pm = mag + (ry + 1) * MW + threadIdx.x + 1;
-            int m = pm[0];
-            if (m > p.low) {
-                int g = gxy[(ry + 1) * MW + threadIdx.x + 1];
-                int xs = (int)(short)(g & 0xFFFF), ys = g >> 16;
-                int ax = abs(xs);
-                int ay = abs(ys) << 15;
-                int tg22x = ax * TG22;
-                if (ay < tg22x) keep = (m > pm[-1] && m >= pm[1]);
-                else {
-                    int tg67x = tg22x + (ax << 16);
-                    if (ay > tg67x) keep = (m > pm[-MW] && m >= pm[MW]);
-                    else {
-                        int s = (xs ^ ys) < 0 ? -1 : 1;
-                        keep = (m > pm[-MW - s] && m > pm[MW + s]);
-                    }
-                }
-                hi = keep && m > p.high;
-            }
-        }
-        unsigned long long bw = __ballot(keep), bs = __ballot(hi);
-        if (gy < p.Hc) {
-            int word = (x0 >> 5) + (threadIdx.x >> 5);
-            if ((threadIdx.x & 31) == 0 && word < p.Ww) {
-                size_t o = ((size_t)f * p.Hc + gy) * p.Ww + word;
-                int sh = threadIdx.x & 32;
-                weak[o] = (uint32_t)(bw >> sh);
-                strong[o] = (uint32_t)(bs >> sh);
-            }
-        }
+    const int yn = p - 2;                               // magnitudes M[A] (yn - 1), M[B] (yn), M[C] (yn + 1)
+    if (yn < c.y0 || yn >= c.y_end) return;
+    const int m = M[B];
+    // lane decisions are kept as 64-bit lane masks: the sector logic is scalar bit arithmetic and the result IS the output
+    const unsigned long long over = __ballot(m > c.low);
+    unsigned long long keep = 0ull, hi = 0ull;
+    if (over != 0ull) {
+        // the magnitudes beside the strip: one LDS word per row and side, the same for every lane (it only lands in lane 0 / 63)
+        const int* hl = c.halo + (yn - c.y0 + 1);
+        const int up = M[A], dn = M[C];
+        const int mL = canny_from_left(m, hl[0]), mR = canny_from_right(m, hl[64]);
+        const int upL = canny_from_left(up, hl[-1]), upR = canny_from_right(up, hl[63]);
+        const int dnL = canny_from_left(dn, hl[1]), dnR = canny_from_right(dn, hl[65]);
+        // channel order B, G, R; the first of equal magnitudes wins
+        const CannyG g = G[B];
+        const int m_b = (int)(g.m_br & 0xffffu), m_r = (int)(g.m_br >> 16);
+        const bool take_g = g.m_g > m_b;
+        const bool take_r = m_r > max(m_b, g.m_g);
+        const int xs = take_r ? (int)g.dx_br.y : (take_g ? g.dx_g : (int)g.dx_br.x);
+        const int ys = take_r ? (int)g.dy_br.y : (take_g ? g.dy_g : (int)g.dy_br.x);
+        const int TG22 = (int)(0.4142135623730950488016887242097 * (1 << 15) + 0.5);
+        const int ax = abs(xs), ay = abs(ys) << 15;          // ax <= 1020: the 24-bit multiply is exact
+        int tg22x;
+        asm("v_mul_u32_u24 %0, %1, %2" : "=v"(tg22x) : "v"(ax), "v"(TG22));        // full rate; the compiler picks the quarter-rate 32-bit multiply
+        const int tg67x = tg22x + (ax << 16);
+        const bool neg = (xs ^ ys) < 0;                      // s = -1: (x + 1, y - 1) and (x - 1, y + 1)
+        const unsigned long long keep_h = __ballot(m > mL) & __ballot(m >= mR);
+        const unsigned long long keep_v = __ballot(m > up) & __ballot(m >= dn);
+        const unsigned long long keep_d = __ballot(m > (neg ? upR : upL)) & __ballot(m > (neg ? dnL : dnR));
+        const unsigned long long is_h = __ballot(ay < tg22x), is_v = __ballot(ay > tg67x) & ~is_h;
+        keep = over & ((is_h & keep_h) | (is_v & keep_v) | (~(is_h | is_v) & keep_d));
+        hi = keep & __ballot(m > c.high);
+    }
+    // lanes 0 and 1 store the row's two words of each plane (scalar row base + the lane's fixed offset)
+    if (c.st_ok) {
+        const size_t o = (size_t)yn * c.Ww + (c.x0 >> 5);
+        const bool second = c.lane != 0;
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c.weak + o) + c.st_off) = second ? (uint32_t)(keep >> 32) : (uint32_t)keep;
+        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c.strong + o) + c.st_off) = second ? (uint32_t)(hi >> 32) : (uint32_t)hi;
+    }
+}
+
+#ifndef LF_CANNY_WAVES
+#define LF_CANNY_WAVES 7
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LF_CANNY_WAVES, LF_CANNY_WAVES))) void k_canny_nms(CannyParams p, int n_units, int n_strips, int n_bands,
+                                                   const uint32_t* __restrict__ bgr, uint32_t* __restrict__ strong,
+                                                   uint32_t* __restrict__ weak)
+{
+    __shared__ int halo[4][128];
+    const int u = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: rows, bounds and row addresses stay in scalar registers
+    if (u >= n_units) return;                           // no barriers in this kernel: waves are independent
+    CannyBand c;
+    c.lane = (int)(threadIdx.x & 63u);
+    const int strip = u % n_strips, q = u / n_strips;
+    const int band = q % n_bands, f = q / n_bands;
+    c.W = p.W; c.Hc = p.Hc; c.Ww = p.Ww; c.low = p.low; c.high = p.high;
+    c.img = bgr + (size_t)f * p.Hc * p.W;
+    c.weak = weak + (size_t)f * p.Hc * p.Ww;
+    c.strong = strong + (size_t)f * p.Hc * p.Ww;
+    c.x0 = strip * 64; c.y0 = band * CB_R; c.y_end = min(c.y0 + CB_R, p.Hc);
+    const int x = c.x0 + c.lane;
+    c.in_image = x < p.W;
+    c.st_ok = c.lane < 2 && (c.x0 >> 5) + c.lane < p.Ww;
+    c.st_off = 4u * (uint32_t)c.lane;
+    const int xm = min(x, p.W - 1);
+    c.xm = 4u * (uint32_t)xm; c.xl = 4u * (uint32_t)max(xm - 1, 0); c.xr = 4u * (uint32_t)min(xm + 1, p.W - 1);
+    // the two columns beside the strip, lane = row (rows y0 - 1 .. y0 + 62)
+    {
+        int* hw = halo[threadIdx.x >> 6];
+        hw[c.lane] = c.x0 > 0 ? canny_mag_at(c.img, p.W, p.Hc, c.x0 - 1, c.y0 - 1 + c.lane) : 0;
+        hw[64 + c.lane] = c.x0 + 64 < p.W ? canny_mag_at(c.img, p.W, p.Hc, c.x0 + 64, c.y0 - 1 + c.lane) : 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        c.halo = hw;
+    }
+    uint32_t px[3][3];
+    CannyH H[3];
+    int M[3] = { 0, 0, 0 };
+    CannyG G[3];
+    canny_fetch(c, c.y0 - 2, px[0]);
+    canny_fetch(c, c.y0 - 1, px[1]);
+    canny_fetch(c, c.y0, px[2]);
+    const int steps = (c.y_end - c.y0) + 4;             // pixel rows y0 - 2 .. y_end + 1; output row yn is decided at step yn - y0 + 4
+    for (int t = 0; t < steps; t += 3) {
+        canny_step<1, 2, 0>(c, t, px, H, M, G);
+        canny_step<2, 0, 1>(c, t + 1, px, H, M, G);
+        canny_step<0, 1, 2>(c, t + 2, px, H, M, G);
     }
 }
 
 void launch_canny(const CannyParams& p, const uint32_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,
                   hipStream_t s)
 {
-    dim3 grid((p.W + CT_W - 1) / CT_W, (p.Hc + CT_H - 1) / CT_H, n_frames);
-    hipLaunchKernelGGL(k_canny_nms, grid, dim3(64, 4), 0, s, p, bgr, strong, weak);
+    const int n_strips = (p.W + 63) / 64, n_bands = (p.Hc + CB_R - 1) / CB_R;
+    const int n_units = n_strips * n_bands * n_frames;
+    hipLaunchKernelGGL(k_canny_nms, dim3((n_units + 3) / 4), dim3(256), 0, s, p, n_units, n_strips, n_bands, bgr, strong, weak);
 }
 
 // fill every run of ones in w that contains a one of s (s is a subset of w), upward direction
