@@ -54,14 +54,22 @@ struct CannyG {            // gradient of one pixel, all channels, and the chann
     int m_g;
 };
 
+// a + 2 b in both 16-bit lanes, one instruction (the compiler splits it into a shift and an add)
+__device__ __forceinline__ cn_s2 canny_a_plus_2b(cn_s2 a, cn_s2 b)
+{
+    cn_s2 d;
+    const uint32_t two = 0x00020002u;
+    asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(two), "v"(a));
+    return d;
+}
+
 __device__ __forceinline__ CannyH canny_hterms(uint32_t aL, uint32_t aM, uint32_t aR)
 {
-    const cn_s2 two = { 2, 2 };
     const cn_s2 l = __builtin_bit_cast(cn_s2, aL & 0x00ff00ffu), m = __builtin_bit_cast(cn_s2, aM & 0x00ff00ffu), r = __builtin_bit_cast(cn_s2, aR & 0x00ff00ffu);
     const int lg = (int)((aL >> 8) & 0xffu), mg = (int)((aM >> 8) & 0xffu), rg = (int)((aR >> 8) & 0xffu);
     CannyH h;
     h.d_br = r - l;
-    h.s_br = l + two * m + r;
+    h.s_br = canny_a_plus_2b(l, m) + r;
     h.d_g = rg - lg;
     h.s_g = lg + 2 * mg + rg;
     return h;
@@ -95,8 +103,8 @@ __device__ __forceinline__ int canny_from_right(int v, int edge) { return __buil
 
 struct CannyBand {
     const uint32_t* img;       // this frame's working image
-    uint32_t* weak;            // this frame's bit planes
-    uint32_t* strong;
+    __amdgpu_buffer_rsrc_t rsrc;   // ... as a raw buffer
+    __amdgpu_buffer_rsrc_t rs_weak, rs_strong;   // this frame's bit planes
     int W, Hc, Ww, low, high;
     int x0, y0, y_end;         // band: rows y0 .. y_end - 1
     uint32_t xl, xm, xr;       // this lane's clamped columns, as byte offsets into a row
@@ -110,9 +118,11 @@ struct CannyBand {
 __device__ __forceinline__ void canny_fetch(const CannyBand& c, int prow, uint32_t (&px)[3])
 {
     const int yy = min(max(prow, 0), c.Hc - 1);
-    // scalar row base + 32-bit lane offset: no per-lane address arithmetic
-    const char* rp = reinterpret_cast<const char*>(c.img + (size_t)yy * c.W);
-    px[0] = *reinterpret_cast<const uint32_t*>(rp + c.xl); px[1] = *reinterpret_cast<const uint32_t*>(rp + c.xm); px[2] = *reinterpret_cast<const uint32_t*>(rp + c.xr);
+    // buffer loads: scalar row offset + the lane's fixed byte offset, no per-lane address arithmetic
+    const int row = yy * c.W * 4;
+    px[0] = __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)c.xl, row, 0);
+    px[1] = __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)c.xm, row, 0);
+    px[2] = __builtin_amdgcn_raw_buffer_load_b32(c.rsrc, (int)c.xr, row, 0);
 }
 
 // one row step.  Slots: (A, B, C) = the register sets of pixel rows (p - 2, p - 1, p); set C is overwritten here.
@@ -126,9 +136,9 @@ __device__ __forceinline__ void canny_step(const CannyBand& c, int t, uint32_t (
     // magnitudes of row y = p - 1
     {
         const int y = p - 1;
-        const cn_s2 two = { 2, 2 }, zero = { 0, 0 };
+        const cn_s2 zero = { 0, 0 };
         CannyG g;
-        g.dx_br = H[A].d_br + two * H[B].d_br + H[C].d_br;
+        g.dx_br = canny_a_plus_2b(H[A].d_br, H[B].d_br) + H[C].d_br;
         g.dy_br = H[C].s_br - H[A].s_br;
         g.dx_g = H[A].d_g + 2 * H[B].d_g + H[C].d_g;
         g.dy_g = H[C].s_g - H[A].s_g;
@@ -172,12 +182,12 @@ __device__ __forceinline__ void canny_step(const CannyBand& c, int t, uint32_t (
         keep = over & ((is_h & keep_h) | (is_v & keep_v) | (~(is_h | is_v) & keep_d));
         hi = keep & __ballot(m > c.high);
     }
-    // lanes 0 and 1 store the row's two words of each plane (scalar row base + the lane's fixed offset)
+    // lanes 0 and 1 store the row's two words of each plane (buffer stores: scalar row offset + the lane's fixed offset)
     if (c.st_ok) {
-        const size_t o = (size_t)yn * c.Ww + (c.x0 >> 5);
+        const int o = (yn * c.Ww + (c.x0 >> 5)) * 4;
         const bool second = c.lane != 0;
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c.weak + o) + c.st_off) = second ? (uint32_t)(keep >> 32) : (uint32_t)keep;
-        *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c.strong + o) + c.st_off) = second ? (uint32_t)(hi >> 32) : (uint32_t)hi;
+        __builtin_amdgcn_raw_buffer_store_b32(second ? (uint32_t)(keep >> 32) : (uint32_t)keep, c.rs_weak, (int)c.st_off, o, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(second ? (uint32_t)(hi >> 32) : (uint32_t)hi, c.rs_strong, (int)c.st_off, o, 0);
     }
 }
 
@@ -197,8 +207,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LF_CANNY_WA
     const int band = q % n_bands, f = q / n_bands;
     c.W = p.W; c.Hc = p.Hc; c.Ww = p.Ww; c.low = p.low; c.high = p.high;
     c.img = bgr + (size_t)f * p.Hc * p.W;
-    c.weak = weak + (size_t)f * p.Hc * p.Ww;
-    c.strong = strong + (size_t)f * p.Hc * p.Ww;
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(c.img), 0, p.Hc * p.W * 4, 0x00020000);
+    c.rs_weak = __builtin_amdgcn_make_buffer_rsrc(weak + (size_t)f * p.Hc * p.Ww, 0, p.Hc * p.Ww * 4, 0x00020000);
+    c.rs_strong = __builtin_amdgcn_make_buffer_rsrc(strong + (size_t)f * p.Hc * p.Ww, 0, p.Hc * p.Ww * 4, 0x00020000);
     c.x0 = strip * 64; c.y0 = band * CB_R; c.y_end = min(c.y0 + CB_R, p.Hc);
     const int x = c.x0 + c.lane;
     c.in_image = x < p.W;
