@@ -61,9 +61,31 @@ __global__ void k_probe_write(uint32_t* __restrict__ dst, size_t n_words)
     }
 }
 
+// k_canny_nms's access shape: the buffer as 640 x 320 dword images; a wave walks a 64-column strip down 62 rows and reads,
+// per row, its column and both horizontal neighbours with three buffer loads (scalar row offset + fixed lane offset).
+// Every byte of the buffer is needed exactly once (the +-1 columns overlap between the three loads and between strips).
+__global__ __launch_bounds__(256) void k_probe_stencil(const uint32_t* __restrict__ src, int n_frames, uint32_t* __restrict__ sink)
+{
+    constexpr int W = 640, H = 320, R = 62, STRIPS = W / 64, BANDS = (H + R - 1) / R;
+    const int u = (int)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int f = u / (STRIPS * BANDS), uf = u - f * (STRIPS * BANDS);
+    if (f >= n_frames) return;
+    const int strip = uf % STRIPS, band = uf / STRIPS, lane = (int)(threadIdx.x & 63u);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(src + (size_t)f * W * H), 0, W * H * 4, 0x00020000);
+    const int x = strip * 64 + lane;
+    const int xm = 4 * x, xl = 4 * max(x - 1, 0), xr = 4 * min(x + 1, W - 1);
+    uint32_t acc = 0;
+    for (int y = band * R; y < min(band * R + R, H); ++y) {
+        const int row = y * W * 4;
+        acc ^= __builtin_amdgcn_raw_buffer_load_b32(rs, xl, row, 0) ^ __builtin_amdgcn_raw_buffer_load_b32(rs, xm, row, 0) ^
+               __builtin_amdgcn_raw_buffer_load_b32(rs, xr, row, 0);
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 }  // namespace lf
 
-// stream `bytes` of a scratch buffer `reps` times with the given access shape (width 4 / 8 / 12 / 16 bytes per lane;
+// stream `bytes` of a scratch buffer `reps` times with the given access shape (width 4 / 8 / 12 / 16 bytes per lane, 43 = k_canny_nms's stencil;
 // write != 0: stores, widths 4 and 16 only).  Diagnostic entry for tools/fetch_probe.py.
 extern "C" int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps)
 {
@@ -81,6 +103,9 @@ extern "C" int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, 
         if (write) {
             if (width == 4) hipLaunchKernelGGL(lf::k_probe_write<4>, grid, block, 0, 0, buf, nw);
             else hipLaunchKernelGGL(lf::k_probe_write<16>, grid, block, 0, 0, buf, nw);
+        } else if (width == 43) {                     // k_canny_nms's three-column stencil shape (whole 640 x 320 images only)
+            const int nf = (int)(bytes / (640 * 320 * 4));
+            hipLaunchKernelGGL(lf::k_probe_stencil, dim3((nf * 60 + 3) / 4), block, 0, 0, buf, nf, sink);
         } else if (width == 4) hipLaunchKernelGGL(lf::k_probe_read<4>, grid, block, 0, 0, buf, nw, sink);
         else if (width == 8) hipLaunchKernelGGL(lf::k_probe_read<8>, grid, block, 0, 0, buf, nw, sink);
         else if (width == 12) hipLaunchKernelGGL(lf::k_probe_read<12>, grid, block, 0, 0, buf, nw, sink);

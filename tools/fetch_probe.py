@@ -16,7 +16,7 @@ BYTES = 1 << 30
 if sys.argv[1] == "run":
     from lane_slam_amd import FrontEnd, default_config
     fe = FrontEnd(default_config("parity"))
-    for width, write in ((4, 0), (8, 0), (12, 0), (16, 0), (4, 1), (16, 1)):
+    for width, write in ((4, 0), (8, 0), (12, 0), (16, 0), (43, 0), (4, 1), (16, 1)):
         rc = fe.lib.lf_debug_probe(fe.h, width, write, BYTES, 3)
         assert rc == 0, rc
     fe.close()
@@ -26,9 +26,9 @@ else:
         with open(path) as f:
             for r in csv.DictReader(f):
                 m = re.search(r"k_probe_(read|write)<(\d+)>", r["Kernel_Name"])
-                if not m or r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
+                if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE") or not (m or "k_probe_stencil" in r["Kernel_Name"]):
                     continue
-                key = "%s_%sB_per_lane" % (m.group(1), m.group(2))
+                key = "%s_%sB_per_lane" % (m.group(1), m.group(2)) if m else "read_stencil3_buffer_loads(k_canny_nms)"
                 e = out["probes"].setdefault(key, {})
                 e.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for key, e in out["probes"].items():
