@@ -28,6 +28,11 @@ __device__ __forceinline__ int reflect101(int p, int n)
     return p;
 }
 
+// idx / n for idx < 4096, n < 128 without a division: (idx * (2^19 / n + 1)) >> 19 (checked exhaustively); the tile
+// phases below are flat loops over (row, column) pairs, so that all 256 lanes work whatever the tile's width is
+// (41 or 42 raw columns and 33 output columns left 36 - 48 % of the lanes of a 64-wide row loop idle)
+__device__ __forceinline__ int div_small(int idx, uint32_t magic) { return (int)(((uint32_t)idx * magic) >> 19); }
+
 // ---- pass 1: list the tiles whose raw footprint contains edge_color pixels ------------------
 // One workgroup per strip of 32 scaled rows: every edge-word AND mask-word under the strip's raw
 // footprint is tested once; non-zero words mark their word column in LDS; a tile is listed iff a
@@ -175,12 +180,14 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         __syncthreads();
         const int ox_n = min(GT, p.Ws - X0), oy_n = min(GT, p.Hs - Y0);
         // row filter (table lookup; general path for wide kernels or windows > 64 bits)
+        const bool small = rh * nsx < 4096 && nsx < 128;      // the magic division holds
+        const uint32_t m_nsx = (1u << 19) / (uint32_t)nsx + 1u, m_nox = (1u << 19) / (uint32_t)nox + 1u;
         if (use_table && rw <= 64) {
             const int msk = (1 << p.ntaps) - 1;
-            for (int ry = threadIdx.x >> 6; ry < rh; ry += 4) {
+            for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
+                const int ry = small ? div_small(idx, m_nsx) : idx / nsx, cx = idx - ry * nsx;
                 const unsigned long long rb = rowbits[ry];
-                for (int cx = threadIdx.x & 63; cx < nsx; cx += 64)
-                    F[ry * nsx + cx] = rb ? T[(int)(rb >> cx) & msk] : 0.0;
+                F[idx] = rb ? T[(int)(rb >> cx) & msk] : 0.0;
             }
         } else {
             for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
@@ -198,42 +205,36 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         }
         __syncthreads();
         // column filter
-        for (int by = threadIdx.x >> 6; by < nsy; by += 4) {
-            for (int cx = threadIdx.x & 63; cx < nsx; cx += 64) {
-                const double* S = F + (by + h) * nsx + cx;
-                // F holds sums of positive constants (or +0.0): an all-zero window gives exactly +0.0
-                unsigned long long nz = __double_as_longlong(S[0]);
-                for (int j = 1; j <= h; ++j) nz |= __double_as_longlong(S[j * nsx]) | __double_as_longlong(S[-j * nsx]);
-                double s = 0.0;
-                if (nz) {
-                    s = p.k[h] * S[0] + 0.0;
-                    for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
-                }
-                Bl[by * nsx + cx] = s;
+        for (int idx = threadIdx.x; idx < nsy * nsx; idx += 256) {
+            const double* S = F + idx + h * nsx;                  // (by + h, cx) of idx = by * nsx + cx
+            // F holds sums of positive constants (or +0.0): an all-zero window gives exactly +0.0
+            unsigned long long nz = __double_as_longlong(S[0]);
+            for (int j = 1; j <= h; ++j) nz |= __double_as_longlong(S[j * nsx]) | __double_as_longlong(S[-j * nsx]);
+            double s = 0.0;
+            if (nz) {
+                s = p.k[h] * S[0] + 0.0;
+                for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
             }
+            Bl[idx] = s;
         }
         __syncthreads();
         // horizontal resize
-        for (int by = threadIdx.x >> 6; by < nsy; by += 4) {
-            const int ox = threadIdx.x & 63;
-            if (ox < nox) {
-                const int dx = X0 + ox;
-                const int sx = t_xofs[ox];
-                const double* S = Bl + by * nsx;
-                double v;
-                if (dx < rt.xmax) v = S[sx] * (double)t_xa[2 * ox] + S[sx + 1] * (double)t_xa[2 * ox + 1];
-                else v = S[sx] * 1.0;
-                Hb[by * (GT + 1) + ox] = v;
-            }
+        for (int idx = threadIdx.x; idx < nsy * nox; idx += 256) {
+            const int by = small ? div_small(idx, m_nox) : idx / nox, ox = idx - by * nox;
+            const int dx = X0 + ox;
+            const int sx = t_xofs[ox];
+            const double* S = Bl + by * nsx;
+            double v;
+            if (dx < rt.xmax) v = S[sx] * (double)t_xa[2 * ox] + S[sx + 1] * (double)t_xa[2 * ox + 1];
+            else v = S[sx] * 1.0;
+            Hb[by * (GT + 1) + ox] = v;
         }
         __syncthreads();
         // vertical resize
-        for (int oy = threadIdx.x >> 6; oy < noy; oy += 4) {
-            const int ox = threadIdx.x & 63;
-            if (ox < nox) {
-                const int r0 = t_y0[oy], r1 = t_y1[oy];
-                Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)t_yb[2 * oy] + Hb[r1 * (GT + 1) + ox] * (double)t_yb[2 * oy + 1];
-            }
+        for (int idx = threadIdx.x; idx < noy * nox; idx += 256) {
+            const int oy = small ? div_small(idx, m_nox) : idx / nox, ox = idx - oy * nox;
+            const int r0 = t_y0[oy], r1 = t_y1[oy];
+            Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)t_yb[2 * oy] + Hb[r1 * (GT + 1) + ox] * (double)t_yb[2 * oy + 1];
         }
         __syncthreads();
         // gradient + level-line angle; defined pixels are queued for the trigonometry pass
