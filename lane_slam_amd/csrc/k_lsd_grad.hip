@@ -207,14 +207,10 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         // column filter
         for (int idx = threadIdx.x; idx < nsy * nsx; idx += 256) {
             const double* S = F + idx + h * nsx;                  // (by + h, cx) of idx = by * nsx + cx
-            // F holds sums of positive constants (or +0.0): an all-zero window gives exactly +0.0
-            unsigned long long nz = __double_as_longlong(S[0]);
-            for (int j = 1; j <= h; ++j) nz |= __double_as_longlong(S[j * nsx]) | __double_as_longlong(S[-j * nsx]);
-            double s = 0.0;
-            if (nz) {
-                s = p.k[h] * S[0] + 0.0;
-                for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
-            }
+            // F holds sums of positive constants or +0.0, so an all-zero window gives exactly +0.0 through the same
+            // arithmetic (testing the window for zero first cost twice the instructions of the seven multiply-adds)
+            double s = p.k[h] * S[0] + 0.0;
+            for (int j = 1; j <= h; ++j) s += p.k[h + j] * (S[j * nsx] + S[-j * nsx]);
             Bl[idx] = s;
         }
         __syncthreads();
