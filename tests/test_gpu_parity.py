@@ -349,6 +349,40 @@ def test_plugin_handles_changing_image_size():
         assert np.array_equal(d.lines, ol) and np.array_equal(d.normals, on)
 
 
+@pytest.mark.parametrize("img_size,top_cutoff", [((75, 96), 12), ((200, 224), 31), ((131, 32), 3)])
+def test_odd_working_geometries_match_oracle(img_size, top_cutoff):
+    """Working images whose sides are no multiple of the kernels' strip / band / tile sizes (k_canny_nms: 64-column
+    strips x 62-row bands, one wave each; k_pre 128x22, k_lbd_grad 64x64, k_lsd_grad 32x32 scaled tiles): a last band of
+    ONE row (63 = 62 + 1), half strips, an image narrower than one strip.  Edge planes, masks and the final segments
+    against the oracle, bit for bit."""
+    from oracle.oracle import Oracle
+    cfg = default_config("parity")
+    cfg["img_size"] = list(img_size)
+    cfg["top_cutoff"] = top_cutoff
+    n = 3
+    fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=2048)
+    o = Oracle(cfg)
+    assert (fe.rows, fe.cols) == (img_size[0] - top_cutoff, img_size[1])
+    frames = synth.make_batch(n, 40)
+    seg = fe.process_batch(frames)
+    edges = fe.fetch(_lib.LF_BUF_EDGES, n)
+    masks = fe.fetch(_lib.LF_BUF_MASKS, n)
+    dx = fe.fetch(_lib.LF_BUF_LBD_DX, n)
+    for f in range(n):
+        work = o.preprocess(frames[f])
+        assert np.array_equal(edges[f], o.canny(work)), "canny frame %d" % f
+        bw = o.color_masks(o.bgr2hsv(work))
+        for c in range(3):
+            assert np.array_equal(masks[f, c], o.dilate(bw[c])), (f, c)
+        r = o.process_frame(frames[f])
+        s_ = seg.frame(f)
+        assert s_.n == r["n"]
+        for k in ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "code"):
+            assert np.array_equal(getattr(s_, k), r[k]), (f, k)
+    assert edges.any() and dx.any()
+    fe.close()
+
+
 def test_set_image_on_an_upscaling_handle():
     """lf_set_image takes the WORKING image (img_size - top_cutoff rows); on a handle whose working image is larger
     than its input frames (img_size > in_size, nearest-neighbour upscaling) the staging buffer must still hold it
