@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
             uint32_t dxyv[LBD_STEPS];
 #pragma unroll
             for (int u = 0; u < LBD_STEPS; ++u) {
+                // (a branch-free form of the rounding -- integer +-1 corrections by compare -- measured 30 % slower here)
                 int tx = (int)dm::round_half_away_f(sCorX);
                 int xCor = tx < 0 ? 0 : (tx > imageWidth ? imageWidth : tx);
                 int ty = (int)dm::round_half_away_f(sCorY);
@@ -245,14 +246,21 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
         const int b = e >> 3, q = e & 7;
         const bool sq = q >= 4;
         const int src = q & 3;
+        // rows (b - 1) * 7 .. (b + 2) * 7 - 1 inside the support region, in order; row h0 + i always meets tap i of
+        // the 21-tap local Gaussian (bands b - 1, b, b + 1 use taps 0-6, 7-13, 14-20): uniform coefficients, no
+        // division, the row sums at fixed LDS offsets
+        const int h0 = (b - 1) * WBAND;
+        const float* rp = &rows[wave][0][src] + 4 * h0;
         float acc = 0;
-        for (int hID = max(0, (b - 1) * WBAND); hID < min(LSP_H, (b + 2) * WBAND); ++hID) {
-            const int rb = hID / WBAND;
-            const int tap = hID % WBAND + (rb == b ? WBAND : (rb == b + 1 ? 2 * WBAND : 0));
-            const float coef = gauss_l[tap];
-            const float v = rows[wave][hID][src];
-            if (!sq) acc += coef * v;
-            else acc += coef * coef * (v * v);
+#pragma unroll
+        for (int i = 0; i < 3 * WBAND; ++i) {
+            const int hID = h0 + i;
+            if (hID >= 0 && hID < LSP_H) {
+                const float coef = gauss_l[i];
+                const float v = rp[4 * i];
+                if (!sq) acc += coef * v;
+                else acc += coef * coef * (v * v);
+            }
         }
         D[e] = acc;     // temporarily: band sums laid out [b][q]
     }
