@@ -453,13 +453,16 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
     sdt = time.perf_counter() - t0
     st = smap.state()
     smap.close()
+    # lf_process_batch copies the source rows from top_cutoff down (no resize in these geometries: img_size == frame size)
+    copied_bytes = frame_bytes - int(cfg["top_cutoff"]) * host.shape[2] * 3 if list(cfg["img_size"]) == list(host.shape[1:3]) else frame_bytes
     sec["stream_configs2"] = {
         "value": round(laps * n_stream / sdt, 1), "unit": "frames/s",
         "what": "BASELINE configs[2]: %d-frame stream x %d laps, frames in pinned host memory, one async H2D copy per %d-frame batch "
-                "on its handle's stream (%d batches in flight), detect->describe->project->sanity->associate->map update, map "
-                "growing from empty by the kept segments (append, per-frame poses)" % (n_stream, laps, B, D),
+                "on its handle's stream (%d batches in flight; only the source rows the working image reads are copied: rows "
+                ">= top_cutoff, %d of %d bytes per frame), detect->describe->project->sanity->associate->map update, map "
+                "growing from empty by the kept segments (append, per-frame poses)" % (n_stream, laps, B, D, copied_bytes, frame_bytes),
         "frames": laps * n_stream, "distinct_frames_per_lap": n_stream, "seconds": round(sdt, 4),
-        "h2d_GBps": round(laps * n_stream * frame_bytes / sdt / 1e9, 2), "segments": segs[0], "map_final": st}
+        "h2d_GBps": round(laps * n_stream * copied_bytes / sdt / 1e9, 2), "segments": segs[0], "map_final": st}
 
     # ---- JPEG ingest (8f-1): CompressedImage streams -> host Huffman decode -> GPU IDCT/colour -> the same path
     try:

@@ -603,7 +603,16 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
     const size_t frame_bytes = (size_t)h->cfg.in_rows * h->cfg.in_cols * 3;
     const uint8_t* d_in = frames;
     if (!frames_on_device) {
-        LF_HIP_CHECK(h, hipMemcpyAsync(h->d_frames, frames, frame_bytes * n_frames, hipMemcpyHostToDevice, s));
+        // Only the source rows k_pre reads cross the bus: the working image starts at row top_cutoff of the (resized)
+        // frame, so the rows above its first source row are never touched (a third of a 640x480 frame with the
+        // full-resolution geometry: the host-fed rate is PCIe bound).  One strided copy, the device layout stays
+        // whole frames.
+        int r0 = h->cfg.top_cutoff;
+        if (h->pre.resize) r0 = dm::ifloor(h->cfg.top_cutoff * h->pre.ify) - 1;      // first row of the nearest-neighbour map, one row of slack
+        r0 = r0 < 0 ? 0 : (r0 > h->cfg.in_rows - 1 ? h->cfg.in_rows - 1 : r0);
+        const size_t skip = (size_t)r0 * h->cfg.in_cols * 3;
+        LF_HIP_CHECK(h, hipMemcpy2DAsync(h->d_frames + skip, frame_bytes, frames + skip, frame_bytes, frame_bytes - skip, (size_t)n_frames,
+                                         hipMemcpyHostToDevice, s));
         d_in = h->d_frames;
     }
     h->plugin_ready = false;
