@@ -141,6 +141,9 @@ int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, fl
  *   (binary_descriptor_custom.cpp:524-687) on the detected segments.
  * frames_on_device / out_on_device: 0 = host pointers, 1 = device pointers
  * (all arrays of `out` alike).  n_segments receives the total (host int).
+ * Host frames are copied to the device one batch per call, and only the source
+ * rows the working image reads (the rows from top_cutoff down; the crop of
+ * line_detector_node.py:169 happens before anything else looks at a pixel).
  * With device outputs the call is asynchronous except for the final count
  * read-back; with host outputs it returns when the data is in place.
  */
