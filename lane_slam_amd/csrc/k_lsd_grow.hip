@@ -22,24 +22,25 @@ namespace lf {
 #define LFG_REG_LDS 256        // region-list entries per wave kept in LDS (the rest of a long region goes to the wave's scratch slice):
 #endif                         // 256 instead of 512 = 3 KB less per problem, +1 % frames/s (other kernels' workgroups find LDS sooner)
 
-// Deferred evaluation (lsd_grow.h EvalQueue): the wave that runs out of components FIRST stays as the problem's helper for
-// as long as anyone grows (it polls the ring between s_sleeps, up to LFG_HELP_POLLS_FIRST empty polls in a row), the
-// other one leaves at once so that its wave slot goes to another problem.  Measured in the same call, configs[1]:
-// longest problem 7.96 -> 6.92 Mcycles, one batch alone 4.87 -> 4.33 ms, six batches in flight 127.5k -> 130.1k frames/s;
-// both helpers staying (polls 512 / 4096 for every wave) gives the same solo time but 127.5k / 128.5k pipelined.
+// Deferred evaluation (lsd_grow.h EvalQueue): FOUR waves per problem, three grow components and the last one only
+// evaluates the finished regions the growers push into the ring (it stays for as long as anyone grows, polling between
+// s_sleeps; a grower that has finished drains what is there and leaves, its wave slot goes to another problem).  With a
+// wave that is always there to evaluate, rect_improve is instantiated ONCE, in the helper loop below: a grower never
+// evaluates in place (it waits the few cycles a full ring would take to move), and the kernel is 44 KB of code instead
+// of the 71 KB it was with a second inlined copy in detect() -- the instruction cache is 64 KB for two CUs.
+// Measured in the same call, configs[1], against "first idle wave of three helps, in-place evaluation when the ring is
+// full" (r02_l .. r02_o): kernel alone 2.95 -> 2.82 ms, six batches in flight 139.3k -> 141.4k frames/s.  Two growers
+// + helper: 3.39 ms, 131.4k (problems with three or more components lose a grower).  r02_l's history: ring + first
+// idle wave of three vs. no ring: longest problem 7.96 -> 6.92 Mcycles, 127.5k -> 130.1k frames/s.
 #ifndef LFG_EVAL_QUEUE
 #define LFG_EVAL_QUEUE 1
 #endif
-#ifndef LFG_HELP_POLLS_FIRST
-#define LFG_HELP_POLLS_FIRST 4096
-#endif
-#ifndef LFG_HELP_POLLS
-#define LFG_HELP_POLLS 0
-#endif
 #ifndef LFG_GROW_WAVES
-#define LFG_GROW_WAVES 3
+#define LFG_GROW_WAVES 4
 #endif
-constexpr int GROW_WAVES = LFG_GROW_WAVES;   // waves per problem: components of the defined-pixel graph are handed out among them
+static_assert(LFG_GROW_WAVES >= 2 || !LFG_EVAL_QUEUE, "with the evaluation ring the last wave of a workgroup never grows");
+constexpr int GROW_WAVES = LFG_GROW_WAVES;   // waves per problem: components of the defined-pixel graph are handed out among the growing ones
+constexpr int GROW_LISTS = LFG_EVAL_QUEUE ? GROW_WAVES - 1 : GROW_WAVES;    // region lists (LDS + scratch slice): one per GROWING wave
 
 __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     int* rows = reinterpret_cast<int*>(lds);
     uint32_t* usedc = lds + ((p.Hs + 2) & ~1);
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
-    uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_WAVES * reg_lds);
+    uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_LISTS * reg_lds);
     const int n_def = norder[pc];
     const uint32_t* gxy = c_xy + (size_t)pc * Ps;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
@@ -93,8 +94,8 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     // Problems too large for k_lsd_label's LDS (> label_items defined pixels) come as ONE component: wave 0 takes it
     // with the whole scratch, the other waves have nothing to do.
     const bool single = n_def > p.label_items;
-    c.lreg = lreg + wave * reg_lds; c.reg_lds = reg_lds;
-    c.greg = reg + (size_t)pc * reg_stride + (single ? (size_t)0 : (size_t)wave * p.label_items);
+    c.lreg = lreg + (wave < GROW_LISTS ? wave : 0) * reg_lds; c.reg_lds = reg_lds;      // the evaluating wave never grows: no list of its own
+    c.greg = reg + (size_t)pc * reg_stride + (single || wave >= GROW_LISTS ? (size_t)0 : (size_t)wave * p.label_items);
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
     c.min_reg_size = p.min_reg_size; c.refine = p.refine;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     // components largest first (k_lsd_label sorted them), next one to whichever wave is free
     for (;;) {
         if (single && wave != 0) break;
+        if (use_queue && wave == GROW_WAVES - 1) break;       // the workgroup's last wave only evaluates (see detect())
         int k = 0;
         if (lane == 0) k = atomicAdd(&next_comp, 1);
         k = __builtin_amdgcn_readfirstlane(k);
@@ -118,15 +120,13 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     // empty -- or until there has been nothing to take for a while (an idle wave gives its slot back; whatever is pushed
     // after that is taken by the waves that finish later, the last grower always drains the ring)
     if (use_queue) {
-        int first = 0;
-        if (lane == 0) first = atomicSub(&evalq.growers, 1);
-        // the first wave to run out of components stays for as long as anyone grows; the others only briefly
-        const int polls = __builtin_amdgcn_readfirstlane(first) == GROW_WAVES ? LFG_HELP_POLLS_FIRST : LFG_HELP_POLLS;
-        int idle = 0;
+        if (lane == 0) atomicSub(&evalq.growers, 1);
+        // the last wave stays for as long as anyone grows; a wave that has finished its components only drains what is there
+        const bool stay = wave == GROW_WAVES - 1;
         for (;;) {
             grow::Rect r;
             int tag = 0;
-            if (grow::eval_pop(c, r, tag)) { (void)grow::evaluate_region(c, r, tag, tl, p.cap_lines, 0); idle = 0; continue; }
+            if (grow::eval_pop(c, r, tag)) { (void)grow::evaluate_region<true>(c, r, tag, tl, p.cap_lines, 0); continue; }
             int g = 0;
             if (lane == 0) g = __hip_atomic_load(&evalq.growers, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
             g = __builtin_amdgcn_readfirstlane(g);
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
                 if (__builtin_amdgcn_readfirstlane(left) <= 0) break;
                 continue;
             }
-            if (++idle > polls) break;
+            if (!stay) break;
             __builtin_amdgcn_s_sleep(64);
         }
     }
@@ -177,7 +177,7 @@ size_t lsd_grow_reg_stride(const LsdParams& p)
     // region scratch per problem: the whole scaled image for a single-component problem (one wave), or one
     // slice per wave -- components come from k_lsd_label only for problems of <= label_items defined pixels
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    const size_t need = (size_t)GROW_WAVES * p.label_items;
+    const size_t need = (size_t)GROW_LISTS * p.label_items;
     return Ps > need ? Ps : need;
 }
 
@@ -195,7 +195,7 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
     // (1080p: 1536x576) have proportionally more defined pixels and far fewer problems per batch, so latency
     // matters more than residency: grow the slice with the image (~3 % of the pixels defined), up to 64 KB.
     int reg_lds = LFG_REG_LDS;
-    const size_t regs = (size_t)GROW_WAVES * reg_lds * 4;
+    const size_t regs = (size_t)GROW_LISTS * reg_lds * 4;
     size_t budget = LFG_LDS_KB * 1024 + regs - (size_t)reg_lds * 4;
     {
         const size_t want = fixed + regs + 8 + (size_t)((double)Ps * 0.03 * 17.0 / 8.0);

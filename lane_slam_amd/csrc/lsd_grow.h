@@ -122,6 +122,9 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 #ifndef LFG_QN
 #define LFG_QN 16
 #endif
+#ifndef LFG_EVAL_QUEUE
+#define LFG_EVAL_QUEUE 1
+#endif
 struct EvalQueue {
     int tail, head;            // tickets reserved by producers / claimed by consumers
     int growers;               // waves of the workgroup that may still push
@@ -985,9 +988,11 @@ LFG_DEV double rect_improve(const Ctx& c, Rect& rec)
 // order: sorted seed items ((1023-bin) << 20 | compact entry e); returns the number of lines this call found.
 // Lines go to slot atomicAdd(*c.line_count) while that is below cap, with their seed's position in `order` as tag.
 // rect_improve + emission of one finished region (in place, or by a helping wave from the ring)
+// IMPROVE = false: the caller knows that refine < 2 (no rect_improve: nothing but the emission is instantiated)
+template <bool IMPROVE>
 LFG_DEV bool evaluate_region(const Ctx& c, Rect& rec, int tag, float* lines, int cap, int n_lines)
 {
-    if (c.refine >= 2) {
+    if (IMPROVE && c.refine >= 2) {
         const double log_nfa = rect_improve(c, rec);
         if (log_nfa <= c.log_eps) return false;
     }
@@ -1160,10 +1165,19 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         }
         LFG_T1(c, 3)
         if (rejected) continue;
-#ifndef LF_HOST_SIM
-        if (c.q && c.refine >= 2 && eval_push(c, rec, tag)) continue;      // a helping wave takes it from here
+#if !defined(LF_HOST_SIM) && LFG_EVAL_QUEUE
+        // rect_improve lives in ONE place, the helper loop of k_lsd_grow.hip (a second inlined copy here made the kernel
+        // 71 KB of code against a 64 KB instruction cache): regions that need it always go through the ring.  The
+        // workgroup's last wave never grows, so a full ring (sixteen regions waiting: the helper would have to fall
+        // 16 x 60 k cycles behind) only ever means a short wait.
+        if (c.refine >= 2) {
+            while (!eval_push(c, rec, tag)) __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        if (!evaluate_region<false>(c, rec, tag, lines, cap, n_lines)) { LFG_T1(c, 6) continue; }
+#else
+        if (!evaluate_region<true>(c, rec, tag, lines, cap, n_lines)) { LFG_T1(c, 6) continue; }
 #endif
-        if (!evaluate_region(c, rec, tag, lines, cap, n_lines)) { LFG_T1(c, 6) continue; }
         ++n_lines;
         LFG_T1(c, 6)
       }

@@ -15,8 +15,8 @@ fe.process_batch(frames)
 seg = fe.process_batch(frames)
 scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
 Ps = scr.shape[2]
-# GROW_WAVES (3) waves per problem, 32 u64 each, in the last 64 * GROW_WAVES words of the problem's region scratch
-GW = 3
+# GROW_WAVES (4: three growing + the evaluating one) waves per problem, 32 u64 each, in the last 64 * GROW_WAVES words of the problem's region scratch
+GW = 4
 raw = scr[:, :, Ps - 64 * GW:].copy().view(np.uint64).reshape(n * 3, GW, 32)
 tot_w = raw[:, :, 24].astype(np.float64)
 print("wave totals (kcycles): slowest wave mean %.0f max %.0f | sum over waves mean %.0f | components mean %.1f" % (
