@@ -6,14 +6,14 @@
 namespace lf {
 
 // Occupancy knobs.  The kernel is latency bound (one wave per component, long dependent chains) and the pipelined
-// rate follows the number of growing waves the chip can hold: capping the kernel at 12 waves per CU instead of 16 costs
-// 12 % of the frames/s, so the register budget is 96 VGPRs = FIVE waves per SIMD (20 per CU).  The compiler's natural
-// allocation is 128 (rect_improve already regenerates its candidates instead of keeping five rectangles live); at 96
-// about a hundred values are spilled around rect_improve and the seed loop, which costs 3 % of the kernel's solo time
-// and still nets +2.2 % frames/s with six batches in flight (80 VGPRs / six waves: no further gain).  13 KB of LDS per
-// problem (12 per CU) stays above the wave limit.
+// rate follows the number of growing waves the chip can hold.  With rect_improve in the evaluating wave's loop only
+// (below) the growing code needs far fewer registers than it did: at 96 VGPRs (five waves per SIMD) 19 values spill,
+// at 80 (SIX waves per SIMD = six four-wave problems per CU) a few more, and the pipelined bench gains 2.3 %
+// (same-call A/B: 141.8 k -> 145.0 k frames/s; kernel alone 2.84 -> 2.89 ms; 72 / 64 VGPRs: 146 k / 145 k on a box where
+// 80 gave 146.6 k).  History: 128 natural -> 96 at three waves per problem was +2.2 %; capping the kernel at 12 waves per
+// CU instead of 16 cost 12 %.  13 KB of LDS per problem stays above the wave limit.
 #ifndef LFG_WAVES
-#define LFG_WAVES 5
+#define LFG_WAVES 6
 #endif
 #ifndef LFG_LDS_KB
 #define LFG_LDS_KB 13
