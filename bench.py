@@ -454,7 +454,8 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
     st = smap.state()
     smap.close()
     # lf_process_batch copies the source rows from top_cutoff down (no resize in these geometries: img_size == frame size)
-    copied_bytes = frame_bytes - int(cfg["top_cutoff"]) * host.shape[2] * 3 if list(cfg["img_size"]) == list(host.shape[1:3]) else frame_bytes
+    scfg = fes[0].cfg
+    copied_bytes = frame_bytes - int(scfg["top_cutoff"]) * host.shape[2] * 3 if list(scfg["img_size"]) == list(host.shape[1:3]) else frame_bytes
     sec["stream_configs2"] = {
         "value": round(laps * n_stream / sdt, 1), "unit": "frames/s",
         "what": "BASELINE configs[2]: %d-frame stream x %d laps, frames in pinned host memory, one async H2D copy per %d-frame batch "
