@@ -336,7 +336,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         LFG_CNT(c, 15, __ballot(inb && !inwin) != 0ull)
         if (!inwin) {
             e = inb ? find_e(c, xx, yy) : -1;
-            if (e >= 0 && !used_get(c, e)) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }
+            if (e >= 0) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
         }
         bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
         const double a = (double)dg * DEG2RAD;
@@ -1103,9 +1103,9 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         bool sv = base + lane_id() < n_order;
         const uint32_t seed_items = sv ? order[base + lane_id()] : 0u;
         const int my_e = (int)(seed_items & 0xfffffu);
+        const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;               // beside the label, not behind it: one round trip per chunk less
         if (sv && c.label) sv = (int)c.label[my_e] == c.root;          // seeds of other components are not ours
         if (__ballot(sv) == 0ull) continue;
-        const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;
         LFG_T1(c, 8)
         unsigned long long pending = ~0ull;
       for (;;) {
