@@ -8,7 +8,7 @@
 // Layout: each workgroup owns a 128x30 tile of the working image (32 rows with the 3x3 halo).  Phase 1 converts the
 // tile plus its dilation halo to packed (b,g,r,maskbits) words in LDS (HSV is computed
 // once per pixel, never written to HBM).  Phase 2: each lane owns 4 adjacent pixels,
-// ORs the structuring element over the LDS mask bits and writes 16 B of corrected BGRX (one dword
+// ORs the structuring element over the LDS mask bits and writes 16 B of corrected BGRX (byte 3 is not cleared; one dword
 // per pixel, so the Canny stencil loads whole pixels), 4 B of gray (BGR2GRAY, 1 byte per pixel: what the LBD
 // gradient stage reads) and the three dilated colour masks as BIT PLANES, 1 bit per pixel (8 lanes OR their
 // nibbles into one word): the LSD stage ANDs them with the edge bit plane, _findNormal tests single bits, and the
@@ -26,12 +26,15 @@ constexpr int TW = 128, TH = LF_PRE_TILE_H, PRE_THREADS = 256;   // (TH + 2) row
 
 struct PixOut { uint32_t packed; };
 
-__device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const PreParams& p, const int* sdiv, const int* hdiv,
+// p24: B | G << 8 | R << 16 as it sits in the frame (anything above bit 23 is ignored)
+__device__ __forceinline__ uint32_t convert_pixel(uint32_t p24, const PreParams& p, const int* sdiv, const int* hdiv,
                                                   const uint8_t* boxes)
 {
     // scaleandshift2 (float32) + convertScaleAbs, then OpenCV RGB2HSV_b (hsv_shift 12, hue range 180) + 4 inRange boxes
-    int c[3] = {b0, g0, r0};
-    if (!p.identity_ai) {                      // scale 1, shift 0 leaves every u8 value unchanged: skip
+    uint32_t pk = p24 & 0xFFFFFFu;
+    int b = (int)(p24 & 255u), g = (int)((p24 >> 8) & 255u), r = (int)((p24 >> 16) & 255u);
+    if (!p.identity_ai) {                      // scale 1, shift 0 leaves every u8 value unchanged: the packed pixel is the output
+        int c[3] = { b, g, r };
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float v = (float)c[ch] * p.ai_scale[ch];
@@ -40,14 +43,15 @@ __device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const 
             int iv = (int)__builtin_rintf(a);  // v_rndne_f32: round half to even, as cvRound
             c[ch] = min(max(iv, 0), 255);
         }
+        b = c[0]; g = c[1]; r = c[2];
+        pk = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
     }
-    const int b = c[0], g = c[1], r = c[2];
     int v = max(b, max(g, r)), vmin = min(b, min(g, r));
     // Every inRange box needs its V interval first: a pixel whose V (= max channel) lies in none of them is in no mask
     // whatever its hue and saturation are, and those are the expensive part (two table divisions).  On road images most
     // pixels are dark asphalt, so whole waves leave here.
     const int in_v = boxes[512 + v];
-    if (in_v == 0) return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+    if (in_v == 0) return pk;
     int diff = v - vmin;
     int vr = v == r ? -1 : 0;
     int vg = v == g ? -1 : 0;
@@ -59,7 +63,7 @@ __device__ __forceinline__ uint32_t convert_pixel(int b0, int g0, int r0, const 
     // inRange against the 4 HSV boxes: per-channel acceptance masks (bit k = box k) from LDS tables
     const int in4 = boxes[h] & boxes[256 + s] & in_v;
     const int bits = (in4 & 3) | (((in4 >> 2) | (in4 >> 3)) & 1) << 2;       // white, yellow, red = red1 | red2
-    return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16) | ((uint32_t)bits << 24);
+    return pk | ((uint32_t)bits << 24);
 }
 
 __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t* __restrict__ frames,
@@ -98,10 +102,10 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
             if (gx < p.W && gy >= 0 && gy < p.Hc) {
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3);
                 const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
-                o[0] = convert_pixel(d0 & 255, (d0 >> 8) & 255, (d0 >> 16) & 255, p, sdiv, hdiv, boxes);
-                o[1] = convert_pixel(d0 >> 24, d1 & 255, (d1 >> 8) & 255, p, sdiv, hdiv, boxes);
-                o[2] = convert_pixel((d1 >> 16) & 255, d1 >> 24, d2 & 255, p, sdiv, hdiv, boxes);
-                o[3] = convert_pixel((d2 >> 8) & 255, (d2 >> 16) & 255, d2 >> 24, p, sdiv, hdiv, boxes);
+                o[0] = convert_pixel(d0, p, sdiv, hdiv, boxes);
+                o[1] = convert_pixel((d0 >> 24) | (d1 << 8), p, sdiv, hdiv, boxes);
+                o[2] = convert_pixel((d1 >> 16) | (d2 << 16), p, sdiv, hdiv, boxes);
+                o[3] = convert_pixel(d2 >> 8, p, sdiv, hdiv, boxes);
             }
             *reinterpret_cast<uint4*>(tile + ty * tw + XO + 4 * cg) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
             uint32_t packed = 0;
             if (gx >= 0 && gx < p.W && gy >= 0 && gy < p.Hc) {
                 const uint8_t* q = src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3;
-                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv, boxes);
+                packed = convert_pixel((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16), p, sdiv, hdiv, boxes);
             }
             tile[ty * tw + tx] = packed;
         }
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                     sx = min(dm::ifloor(gx * p.ifx), p.in_cols - 1);
                 }
                 const uint8_t* q = src + ((size_t)sy * p.in_cols + sx) * 3;
-                packed = convert_pixel(q[0], q[1], q[2], p, sdiv, hdiv, boxes);
+                packed = convert_pixel((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16), p, sdiv, hdiv, boxes);
             }
             tile[ty * tw + tx] = packed;
         }
@@ -162,20 +166,22 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
                 cross[2] = c4.z | c4.y | c4.w | up.z | dn.z;
                 cross[3] = c4.w | c4.z | rgt | up.w | dn.w;
             }
+            if (p.ksize != 3) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t bits = cross[k] >> 24;
-                if (p.ksize != 3) {
-                    bits = 0;
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t bits = 0;
                     for (int i = 0; i < p.ksize; ++i)
                         for (int j = p.j1[i]; j < p.j2[i]; ++j)
                             bits |= tile[(ly + i) * tw + XO - r + lx + k + j] >> 24;
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    nib[c] |= ((bits >> c) & 1u) << k;
+                    cross[k] = bits << 24;
                 }
             }
+            // the four pixels' mask bytes in one word, then one dot product per colour gathers bit c of every byte into a
+            // nibble: sum_k ((byte_k >> c) & 1) << k
+            const uint32_t t4 = __builtin_amdgcn_perm(cross[1], cross[0], 0x0c0c0703u) | __builtin_amdgcn_perm(cross[3], cross[2], 0x07030c0cu);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                nib[c] = __builtin_amdgcn_udot4(t4 & (0x01010101u << c), 0x08040201u, 0u, false) >> c;
         }
         // bit-plane copy of the dilated masks (1 bit / pixel): 8 lanes x 4 pixels = one 32-pixel word
 #pragma unroll
@@ -196,14 +202,17 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
         // corrected working image as BGRX dwords: one 16-byte store for the lane's 4 pixels
         const size_t pix = (size_t)gy * p.W + gx;
         *reinterpret_cast<uint4*>(bgrx_out + (size_t)f * P + pix) =
-            make_uint4(px[0] & 0xFFFFFFu, px[1] & 0xFFFFFFu, px[2] & 0xFFFFFFu, px[3] & 0xFFFFFFu);
+            make_uint4(px[0], px[1], px[2], px[3]);      // byte 3 still holds the pixel's own mask bits: no reader looks at it
         // BGR2GRAY (fixed point, as cvtColor) of the same four pixels: the 1 byte/pixel plane the LBD gradient stage
         // reads instead of the 4 byte/pixel working image (binary_descriptor_custom.cpp:350-398 works on gray)
+        // (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14 with the coefficients split into bytes: two 4 x u8 dot products
+        // per pixel (byte 3 meets a zero coefficient); the result is <= 255
         uint32_t gq = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t q = px[k];
-            gq |= ((((q & 255u) * 1868u + ((q >> 8) & 255u) * 9617u + ((q >> 16) & 255u) * 4899u + (1u << 13)) >> 14) & 255u) << (8 * k);
+            const uint32_t lo = __builtin_amdgcn_udot4(px[k], 0x0023914Cu, 1u << 13, false);
+            const uint32_t hi = __builtin_amdgcn_udot4(px[k], 0x00132507u, 0u, false);
+            gq |= (((hi << 8) + lo) >> 14) << (8 * k);
         }
         *reinterpret_cast<uint32_t*>(gray_out + (size_t)f * P + pix) = gq;
     }
