@@ -55,9 +55,11 @@ __device__ __forceinline__ uint32_t convert_pixel(uint32_t p24, const PreParams&
     int diff = v - vmin;
     int vr = v == r ? -1 : 0;
     int vg = v == g ? -1 : 0;
-    int s = (diff * sdiv[v] + (1 << 11)) >> 12;
+    // 24-bit multiplies (full rate; the compiler's 32 x 32 -> 64 multiply-add is a quarter of that): diff <= 255, sdiv <= 255 << 12,
+    // |h| <= 1530, hdiv <= 180 << 12 / 6 -- both products are exact in 32 bits
+    int s = (__mul24(diff, sdiv[v]) + (1 << 11)) >> 12;
     int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-    h = (h * hdiv[diff] + (1 << 11)) >> 12;
+    h = (__mul24(h, hdiv[diff]) + (1 << 11)) >> 12;
     h += h < 0 ? 180 : 0;
     h = min(max(h, 0), 255);
     // inRange against the 4 HSV boxes: per-channel acceptance masks (bit k = box k) from LDS tables
@@ -100,7 +102,9 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
             const int gx = x0 + 4 * cg, gy = y0 + ty - r;
             uint32_t o[4] = {0, 0, 0, 0};
             if (gx < p.W && gy >= 0 && gy < p.Hc) {
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(src + ((size_t)(gy + p.top_cutoff) * p.in_cols + gx) * 3);
+                // byte offset inside the frame in 32 bits (24-bit multiply: rows and columns are far below 2^24)
+                const uint32_t off = (__umul24((uint32_t)(gy + p.top_cutoff), (uint32_t)p.in_cols) + (uint32_t)gx) * 3u;
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(src + off);
                 const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
                 o[0] = convert_pixel(d0, p, sdiv, hdiv, boxes);
                 o[1] = convert_pixel((d0 >> 24) | (d1 << 8), p, sdiv, hdiv, boxes);
