@@ -82,6 +82,26 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
     const int th = TH + 2 * r;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, f = blockIdx.z;
     const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
+    // The frame pixels do not depend on the tables below: in the common geometry (no resize) every lane's three-dword
+    // groups are requested first, so their trip to HBM runs under the table setup and the barrier.
+    const bool fast = !p.resize && (p.in_cols & 3) == 0 && (p.W & 3) == 0;
+    constexpr int MAXG = ((TH + 2 * (kMaxKsize / 2)) * (TW / 4) + PRE_THREADS - 1) / PRE_THREADS;
+    uint32_t D[MAXG][3];
+    if (fast) {
+#pragma unroll
+        for (int it = 0; it < MAXG; ++it) {
+            const int g = (int)threadIdx.x + it * PRE_THREADS;
+            const int ty = g / (TW / 4), cg = g - ty * (TW / 4);
+            const int gx = x0 + 4 * cg, gy = y0 + ty - r;
+            D[it][0] = D[it][1] = D[it][2] = 0u;
+            if (g < th * (TW / 4) && gx < p.W && gy >= 0 && gy < p.Hc) {
+                // byte offset inside the frame in 32 bits (24-bit multiply: rows and columns are far below 2^24)
+                const uint32_t off = (__umul24((uint32_t)(gy + p.top_cutoff), (uint32_t)p.in_cols) + (uint32_t)gx) * 3u;
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(src + off);
+                D[it][0] = q[0]; D[it][1] = q[1]; D[it][2] = q[2];
+            }
+        }
+    }
     sdiv[threadIdx.x] = sdiv_g[threadIdx.x];
     hdiv[threadIdx.x] = hdiv_g[threadIdx.x];
 #pragma unroll
@@ -93,19 +113,17 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
     }
     __syncthreads();
 
-    const bool fast = !p.resize && (p.in_cols & 3) == 0 && (p.W & 3) == 0;
     if (fast) {
         // interior columns: one lane = 4 pixels = 3 aligned dwords of the source row
-        const int groups = th * (TW / 4);
-        for (int g = threadIdx.x; g < groups; g += PRE_THREADS) {
+#pragma unroll
+        for (int it = 0; it < MAXG; ++it) {
+            const int g = (int)threadIdx.x + it * PRE_THREADS;
+            if (g >= th * (TW / 4)) break;
             const int ty = g / (TW / 4), cg = g - ty * (TW / 4);
             const int gx = x0 + 4 * cg, gy = y0 + ty - r;
             uint32_t o[4] = {0, 0, 0, 0};
             if (gx < p.W && gy >= 0 && gy < p.Hc) {
-                // byte offset inside the frame in 32 bits (24-bit multiply: rows and columns are far below 2^24)
-                const uint32_t off = (__umul24((uint32_t)(gy + p.top_cutoff), (uint32_t)p.in_cols) + (uint32_t)gx) * 3u;
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(src + off);
-                const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+                const uint32_t d0 = D[it][0], d1 = D[it][1], d2 = D[it][2];
                 o[0] = convert_pixel(d0, p, sdiv, hdiv, boxes);
                 o[1] = convert_pixel((d0 >> 24) | (d1 << 8), p, sdiv, hdiv, boxes);
                 o[2] = convert_pixel((d1 >> 16) | (d2 << 16), p, sdiv, hdiv, boxes);
