@@ -205,10 +205,15 @@ int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int
  *                   segments of one update hit the same entry the last in SegmentList order wins); the others
  *                   are appended.
  *   when_full       LF_MAP_RING: appends wrap around and overwrite the oldest entries.
- *                   LF_MAP_FULL_ERROR: what does not fit is dropped and the next call that synchronises with
- *                   the map returns LF_ERR_CAPACITY.
+ *                   LF_MAP_FULL_ERROR: what does not fit is dropped and the failure is reported as below.
+ * Failing updates (map full under LF_MAP_FULL_ERROR; a block with a bad header; a block carrying the overflow
+ * marker) are detected on the device, so they are reported LATER and exactly ONCE: the first of lf_map_size,
+ * lf_map_associate, lf_map_step, lf_map_step_host that sees the flag returns the error (LF_ERR_CAPACITY /
+ * LF_ERR_BAD_ARG) WITHOUT doing its own work -- call it again.  Nothing is sticky: a full map can still be queried
+ * and, under MERGE, refreshed.
  * One update consumes BLOCKS: [1 + rows][LF_BLOCK_ROW_BYTES] bytes each, row 0 = header
- * {u32 magic "LFBK", u32 count, i32 step, u32 n_frames}, then per segment, SegmentList order:
+ * {u32 magic "LFBK", u32 count, i32 step, u32 n_frames, u32 overflow (0, or the segment count that did not fit:
+ * count is 0 then), zeros}, then per segment, SegmentList order:
  *   0..31 code | 32..63 f64 x0 y0 x1 y1 in the MAP frame | 64 i32 idx | 68 f32 dist | 72 colour | 73 keep | 0-pad
  * (idx / dist = the segment's association result against the map as it stood BEFORE this update).  A block is
  * what ranks exchange with ONE all-gather per step; blocks are applied in the order given, so
@@ -242,7 +247,8 @@ int lf_map_get_stream(lf_map* m, void** hip_stream);
 int lf_map_synchronize(lf_map* m);
 /* append n entries as they are (color NULL: 255 = matches every colour; ground NULL: zeros); hits 1, last_seen -1 */
 int lf_map_seed(lf_map* m, const uint8_t* code32, const uint8_t* color, const double* ground4, int n, int on_device);
-/* entries in use, ring head, lifetime counters; waits for the map's stream; LF_ERR_CAPACITY if an update overflowed */
+/* entries in use, ring head, lifetime counters; waits for the map's stream; reports a failing update (once, the
+ * outputs are still filled in) */
 int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_t* total_refreshed);
 /* Nearest map entry of n queries (a-10 semantics + the map's gating / max_distance).  color may be NULL when
  * gating is off.  h: the handle whose stream produced the query arrays (the map's stream waits for it, and the
@@ -251,11 +257,14 @@ int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_
 int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, const uint8_t* color, int n,
                      int32_t* idx, float* dist, int on_device);
 /* Device arrays of `segs` (frame_offset, code, color, keep, ground; capacity ignored) + idx / dist -> one block in
- * device memory (block_rows >= n + 1 rows, else LF_ERR_CAPACITY -- never truncated).  frame_pose: host
- * [n_frames][3] = x, y, theta per frame, or NULL. */
+ * device memory.  block_rows < n + 1: LF_ERR_CAPACITY -- never truncated: the block is then ONLY a header with the
+ * overflow marker, which a rank of a multi-GPU step still all-gathers so that every replica skips that step's update
+ * together (lf_map_update) and reports LF_ERR_CAPACITY instead of waiting for a collective that never comes.
+ * frame_pose: host [n_frames][3] = x, y, theta per frame, or NULL. */
 int lf_map_pack_block(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const int32_t* idx,
                       const float* dist, const double* frame_pose, int step, uint8_t* block, int block_rows);
-/* apply n_blocks consecutive blocks of block_rows rows each (device memory), in order */
+/* apply n_blocks consecutive blocks of block_rows rows each (device memory), in order.  If any of them has a bad
+ * header or the overflow marker, NONE is applied (reported as described above). */
 int lf_map_update(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows);
 /* single-GPU convenience: lf_map_associate + lf_map_pack_block + lf_map_update; idx / dist device arrays [n] */
 int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const double* frame_pose,

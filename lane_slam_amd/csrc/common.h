@@ -187,13 +187,15 @@ struct MapDevice {
     int fp4;                       // packed operands are e2m1 nibbles (ungated maps) instead of int8 bytes + ninth-step rows
     uint8_t* code; uint8_t* color; double* ground; int* hits; int* last_seen; int* winner;
     int8_t* mx; int8_t* mcx;
-    int* state;                    // [0] size [1] head [2] overflow [3] n_app [4] n_ref [5] old head [6] old size [7] step
+    int* state;                    // 16 ints: [0] size [1] head [2] flags of the latest failing update [3] n_app [4] n_ref [5] old head
+                                   // [6] old size [7] step [8] failing updates so far [9], [10] accumulators (k_map.hip)
     unsigned long long* totals;    // [0] appended [1] refreshed
 };
 void launch_fill_i32(int* p, size_t n, int v, hipStream_t s);
 void launch_map_pack_block(int n, int n_frames, const int* frame_offset, const uint8_t* code, const uint8_t* color,
                            const uint8_t* keep, const double* ground, const int32_t* idx, const float* dist,
                            const double* pose4, int step, uint8_t* block, hipStream_t s);
+void launch_map_overflow_block(int n, int n_frames, int step, uint8_t* block, hipStream_t s);
 void launch_map_seed_block(int n, const uint8_t* code, const uint8_t* color, const double* ground, uint8_t* block, hipStream_t s);
 void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks, int block_rows, int force_append, int* act,
                        hipStream_t s);

@@ -36,7 +36,9 @@ struct MapDev {
     int capacity, policy, kept_only, merge_distance, when_full, fp4;
     uint8_t* code; uint8_t* color; double* ground; int* hits; int* last_seen; int* winner;
     int8_t* mx; int8_t* mcx;
-    int* state;                    // [0] size [1] head [2] overflow [3] n_app [4] n_ref [5] old head [6] old size [7] step
+    int* state;                    // [0] size [1] head [2] flags of the latest failing update (1 full, 2 bad header, 4 a peer's block
+                                   // overflowed) [3] n_app [4] n_ref [5] old head [6] old size [7] step [8] failing updates so far
+                                   // [9], [10] accumulators of the update in flight (refreshes, flags)
     unsigned long long* totals;    // [0] appended [1] refreshed
 };
 
@@ -82,89 +84,135 @@ __global__ void k_map_pack_block(int n, int n_frames, const int* __restrict__ fr
     row[74] = row[75] = row[76] = row[77] = row[78] = row[79] = 0;
 }
 
-// one workgroup of 1024: classify every row, rank the appends, elect the refresh winners, advance the state
-__global__ __launch_bounds__(1024) void k_map_plan(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int block_rows,
-                                                   int force_append, int* __restrict__ act)
+// ---- update, step 1 of 3: classification.  1024 rows per workgroup, any number of workgroups (an 8-rank step is
+// 8 x 16 Ki rows): every row becomes "refresh entry t", "append, rank r among this workgroup's appends" or nothing;
+// refresh winners are elected (atomicMax) and hits counted here, the appends of each workgroup are counted for the
+// scan in k_map_plan.  A block with a bad header, or one that carries the OVERFLOW marker (its rank had more
+// segments than a block holds and sent only the header, lf_map_pack_block), makes EVERY workgroup skip the whole
+// update: all replicas see the same blocks, so all of them skip the same step.
+__global__ __launch_bounds__(1024) void k_map_classify(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int block_rows,
+                                                       int force_append, int* __restrict__ act, int* __restrict__ wg_count)
 {
     __shared__ int wave_count[16];
-    __shared__ int base_sh, nref_sh, bad_sh;
+    __shared__ int bad_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = block_rows - 1;
     const int total = n_blocks * G;
-    const int size0 = m.state[0], head0 = m.state[1];
-    if (tid == 0) { base_sh = 0; nref_sh = 0; bad_sh = 0; }
+    const int size0 = m.state[0];
+    if (tid == 0) bad_sh = 0;
     __syncthreads();
-    for (int start = 0; start < total; start += 1024) {
-        const int s = start + tid;
-        bool is_app = false, is_ref = false;
-        int target = -1;
-        if (s < total) {
-            const int blk = s / G, r = s - blk * G;
-            const uint8_t* bb = blocks + (size_t)blk * block_rows * kRow;
-            const uint32_t* hd = reinterpret_cast<const uint32_t*>(bb);
-            const int count = hd[0] == kMagic ? (int)hd[1] : -1;
-            if (count < 0 || count > G) { if (r == 0) atomicOr(&bad_sh, 1); }
-            else if (r < count) {
-                const uint8_t* row = bb + (size_t)(1 + r) * kRow;
-                const int idx = *reinterpret_cast<const int32_t*>(row + 64);
-                const float dist = *reinterpret_cast<const float*>(row + 68);
-                const bool eligible = !m.kept_only || row[73] != 0 || force_append;
-                is_ref = eligible && !force_append && m.policy == LF_MAP_MERGE && idx >= 0 && idx < size0 && dist >= 0.f &&
-                         dist <= (float)m.merge_distance;
-                is_app = eligible && !is_ref;
-                target = idx;
-            }
+    for (int b = tid; b < n_blocks; b += 1024) {
+        const uint32_t* hd = reinterpret_cast<const uint32_t*>(blocks + (size_t)b * block_rows * kRow);
+        int f = 0;
+        if (hd[0] != kMagic || hd[1] > (uint32_t)G) f |= 2;
+        else if (hd[4] != 0u) f |= 4;
+        if (f) atomicOr(&bad_sh, f);
+    }
+    __syncthreads();
+    const int bad = bad_sh;
+    const int s = blockIdx.x * 1024 + tid;
+    bool is_app = false, is_ref = false;
+    int target = -1;
+    if (!bad && s < total) {
+        const int blk = s / G, r = s - blk * G;
+        const uint8_t* bb = blocks + (size_t)blk * block_rows * kRow;
+        const int count = (int)reinterpret_cast<const uint32_t*>(bb)[1];
+        if (r < count) {
+            const uint8_t* row = bb + (size_t)(1 + r) * kRow;
+            const int idx = *reinterpret_cast<const int32_t*>(row + 64);
+            const float dist = *reinterpret_cast<const float*>(row + 68);
+            const bool eligible = !m.kept_only || row[73] != 0 || force_append;
+            is_ref = eligible && !force_append && m.policy == LF_MAP_MERGE && idx >= 0 && idx < size0 && dist >= 0.f &&
+                     dist <= (float)m.merge_distance;
+            is_app = eligible && !is_ref;
+            target = idx;
         }
-        const unsigned long long bal = __ballot(is_app);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_count[wave] = __popcll(bal);
+    }
+    const unsigned long long bal = __ballot(is_app);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_count[wave] = __popcll(bal);
+    const unsigned long long rbal = __ballot(is_ref);
+    __syncthreads();
+    int off = 0, all = 0;
+    for (int w = 0; w < 16; ++w) { const int c = wave_count[w]; if (w < wave) off += c; all += c; }
+    if (s < total) act[s] = is_ref ? (target | kRefFlag) : (is_app ? off + before : -1);
+    if (is_ref) {
+        atomicMax(&m.winner[target], s);
+        atomicAdd(&m.hits[target], 1);
+    }
+    if (lane == 0 && rbal) atomicAdd(&m.state[9], __popcll(rbal));
+    if (tid == 0) {
+        wg_count[blockIdx.x] = all;
+        if (blockIdx.x == 0 && bad) m.state[10] = bad;
+    }
+}
+
+// ---- step 2 of 3: one workgroup scans the workgroups' append counts (wg_count -> exclusive bases, in place) and
+// advances the map's state
+__global__ __launch_bounds__(1024) void k_map_plan(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int n_wg,
+                                                   int* __restrict__ wg_count)
+{
+    __shared__ int wave_sum[16];
+    __shared__ int carry_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_sh = 0;
+    __syncthreads();
+    for (int start = 0; start < n_wg; start += 1024) {
+        const int i = start + tid;
+        const int v = i < n_wg ? wg_count[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) wave_sum[wave] = incl;
         __syncthreads();
-        int off = base_sh;
-        for (int w = 0; w < wave; ++w) off += wave_count[w];
-        if (s < total) act[s] = is_ref ? (target | kRefFlag) : (is_app ? off + before : -1);
-        if (is_ref) {
-            atomicMax(&m.winner[target], s);
-            atomicAdd(&m.hits[target], 1);
-            atomicAdd(&nref_sh, 1);
-        }
+        int off = carry_sh;
+        for (int w = 0; w < wave; ++w) off += wave_sum[w];
+        if (i < n_wg) wg_count[i] = off + incl - v;
         __syncthreads();
-        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_count[w]; base_sh += t; }
+        if (tid == 1023) carry_sh = off + incl;
         __syncthreads();
     }
     if (tid == 0) {
         // every block of one update carries the same step number; block 0's is taken
         const uint32_t* hd = reinterpret_cast<const uint32_t*>(blocks);
         const int step = n_blocks > 0 ? (int)hd[2] : 0;
-        const int n_app = base_sh;
-        int new_size, new_head, overflow = m.state[2] | (bad_sh ? 2 : 0);
+        const int size0 = m.state[0], head0 = m.state[1];
+        const int n_app = carry_sh, n_ref = m.state[9];
+        int new_size, new_head, flags = m.state[10];
         if (m.when_full == LF_MAP_RING) {
             const long long sz = (long long)size0 + n_app;
             new_size = sz > m.capacity ? m.capacity : (int)sz;
             new_head = (int)(((long long)head0 + n_app) % m.capacity);
         } else {
             const int fit = n_app < m.capacity - size0 ? n_app : m.capacity - size0;
-            if (fit < n_app) overflow |= 1;
+            if (fit < n_app) flags |= 1;
             new_size = size0 + fit;
             new_head = new_size % m.capacity;
         }
-        m.state[3] = n_app; m.state[4] = nref_sh; m.state[5] = head0; m.state[6] = size0; m.state[7] = step;
-        m.state[0] = new_size; m.state[1] = new_head; m.state[2] = overflow;
+        m.state[3] = n_app; m.state[4] = n_ref; m.state[5] = head0; m.state[6] = size0; m.state[7] = step;
+        m.state[0] = new_size; m.state[1] = new_head;
+        // error events: the flags of the latest failing update + a running count the host compares with what it has
+        // already reported (nothing is sticky: the map stays usable)
+        if (flags) { m.state[2] = flags; m.state[8] += 1; }
+        m.state[9] = 0; m.state[10] = 0;
         m.totals[0] += (unsigned long long)n_app;
-        m.totals[1] += (unsigned long long)nref_sh;
+        m.totals[1] += (unsigned long long)n_ref;
     }
 }
 
 // 32 threads per row (one per code byte): write the entry, its packed operands and, from thread 0, the rest
+// ---- step 3 of 3
 __global__ void k_map_apply(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int block_rows,
-                            const int* __restrict__ act)
+                            const int* __restrict__ act, const int* __restrict__ wg_base)
 {
     const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const int G = block_rows - 1;
     const size_t total = (size_t)n_blocks * G;
     const int s = (int)(t >> 5), b = (int)(t & 31);
     if ((size_t)s >= total) return;
-    const int a = act[s];
+    int a = act[s];
     if (a == -1) return;
+    if (!(a & kRefFlag)) a += wg_base[s >> 10];
     const int n_app = m.state[3], head0 = m.state[5], size0 = m.state[6], step = m.state[7];
     const int cap = m.capacity;
     int pos;
@@ -268,6 +316,18 @@ void launch_map_pack_block(int n, int n_frames, const int* frame_offset, const u
                        keep, ground, idx, dist, pose4, step, block);
 }
 
+__global__ void k_map_overflow_block(int n, int n_frames, int step, uint8_t* __restrict__ block)
+{
+    uint32_t* hd = reinterpret_cast<uint32_t*>(block);
+    const int k = threadIdx.x;
+    if (k < kRow / 4) hd[k] = k == 0 ? kMagic : k == 2 ? (uint32_t)step : k == 3 ? (uint32_t)n_frames : k == 4 ? (uint32_t)n : 0u;
+}
+
+void launch_map_overflow_block(int n, int n_frames, int step, uint8_t* block, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_map_overflow_block, dim3(1), dim3(64), 0, s, n, n_frames, step, block);
+}
+
 void launch_map_seed_block(int n, const uint8_t* code, const uint8_t* color, const double* ground, uint8_t* block, hipStream_t s)
 {
     const int threads = n > 0 ? n : 1;
@@ -282,10 +342,16 @@ void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks,
     m.when_full = md.when_full; m.fp4 = md.fp4;
     m.code = md.code; m.color = md.color; m.ground = md.ground; m.hits = md.hits; m.last_seen = md.last_seen;
     m.winner = md.winner; m.mx = md.mx; m.mcx = md.mcx; m.state = md.state; m.totals = md.totals;
-    hipLaunchKernelGGL(k_map_plan, dim3(1), dim3(1024), 0, s, m, blocks, n_blocks, block_rows, force_append, act);
-    const size_t threads = (size_t)n_blocks * (block_rows - 1) * 32;
+    // act: [rows] actions, then [n_wg] append counts / bases of the classification workgroups
+    const size_t rows = (size_t)n_blocks * (block_rows - 1);
+    const int n_wg = (int)((rows + 1023) / 1024);
+    int* wg_count = act + rows;
+    if (n_wg)
+        hipLaunchKernelGGL(k_map_classify, dim3(n_wg), dim3(1024), 0, s, m, blocks, n_blocks, block_rows, force_append, act, wg_count);
+    hipLaunchKernelGGL(k_map_plan, dim3(1), dim3(1024), 0, s, m, blocks, n_blocks, n_wg, wg_count);
+    const size_t threads = rows * 32;
     if (threads)
-        hipLaunchKernelGGL(k_map_apply, dim3((threads + 255) / 256), dim3(256), 0, s, m, blocks, n_blocks, block_rows, act);
+        hipLaunchKernelGGL(k_map_apply, dim3((threads + 255) / 256), dim3(256), 0, s, m, blocks, n_blocks, block_rows, act, wg_count);
 }
 
 }  // namespace lf

@@ -21,7 +21,8 @@ struct lf_map {
     MapDevice d;
     size_t cap_pad = 0;
     // host mirror of the device state, refreshed behind every update
-    int* h_state = nullptr;                  // pinned: [0..7] state, then 2 x u64 totals at +8 ints
+    int* h_state = nullptr;                  // pinned: [0..15] state, then 2 x u64 totals at +16 ints
+    int errors_reported = 0;                 // failing updates (state[8]) the host has already returned an error for
     hipEvent_t ev_state = nullptr, ev_in = nullptr, ev_out = nullptr;
     bool state_pending = false;
     long long rows_in_flight = 0;            // rows handed to updates whose state copy has not been seen yet
@@ -99,15 +100,22 @@ static int refresh_state(lf_map* m, bool block = true)
         m->state_pending = false;
         m->rows_in_flight = 0;
     }
-    if (m->h_state[2] & 2) { map_error(m, "lf_map_update was given a block with a bad header (magic / count)"); return LF_ERR_BAD_ARG; }
-    if (m->h_state[2] & 1) { map_error(m, "the map is full (capacity %d, LF_MAP_FULL_ERROR): segments were dropped", m->cfg.capacity); return LF_ERR_CAPACITY; }
+    // a failing update is reported ONCE, by the first call that sees it; the map stays usable (nothing is sticky)
+    if (m->h_state[8] != m->errors_reported) {
+        const int n_new = m->h_state[8] - m->errors_reported, flags = m->h_state[2];
+        m->errors_reported = m->h_state[8];
+        if (flags & 2) { map_error(m, "lf_map_update was given a block with a bad header (magic / count): that update was not applied (%d failing update(s) since the last report)", n_new); return LF_ERR_BAD_ARG; }
+        if (flags & 4) { map_error(m, "a rank's segments did not fit its block (overflow marker in a gathered header): that step's update was applied on no replica (%d failing update(s) since the last report)", n_new); return LF_ERR_CAPACITY; }
+        map_error(m, "the map is full (capacity %d, LF_MAP_FULL_ERROR): segments were dropped (%d failing update(s) since the last report)", m->cfg.capacity, n_new);
+        return LF_ERR_CAPACITY;
+    }
     return LF_OK;
 }
 
 static int queue_state_copy(lf_map* m)
 {
-    MAP_HIP(m, hipMemcpyAsync(m->h_state, m->d.state, 8 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
-    MAP_HIP(m, hipMemcpyAsync(m->h_state + 8, m->d.totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
+    MAP_HIP(m, hipMemcpyAsync(m->h_state, m->d.state, 16 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
+    MAP_HIP(m, hipMemcpyAsync(m->h_state + 16, m->d.totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, m->stream));
     MAP_HIP(m, hipEventRecord(m->ev_state, m->stream));
     m->state_pending = true;
     return LF_OK;
@@ -226,10 +234,10 @@ extern "C" int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** o
     CREATE_HIP(hipMalloc((void**)&m->d.winner, cap * sizeof(int)));
     CREATE_HIP(hipMalloc((void**)&m->d.mx, m->cap_pad * 256));
     CREATE_HIP(hipMalloc((void**)&m->d.mcx, m->cap_pad * 32));
-    CREATE_HIP(hipMalloc((void**)&m->d.state, 8 * sizeof(int)));
+    CREATE_HIP(hipMalloc((void**)&m->d.state, 16 * sizeof(int)));
     CREATE_HIP(hipMalloc((void**)&m->d.totals, 2 * sizeof(unsigned long long)));
-    CREATE_HIP(hipHostMalloc((void**)&m->h_state, 16 * sizeof(int)));
-    memset(m->h_state, 0, 16 * sizeof(int));
+    CREATE_HIP(hipHostMalloc((void**)&m->h_state, 24 * sizeof(int)));
+    memset(m->h_state, 0, 24 * sizeof(int));
     // rows beyond the map's size must read as "all zero" operands (distance 128): zero everything once
     CREATE_HIP(hipMemsetAsync(m->d.mx, 0, m->cap_pad * 256, m->stream));
     CREATE_HIP(hipMemsetAsync(m->d.mcx, 0, m->cap_pad * 32, m->stream));
@@ -238,7 +246,7 @@ extern "C" int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** o
     CREATE_HIP(hipMemsetAsync(m->d.ground, 0, cap * 4 * sizeof(double), m->stream));
     CREATE_HIP(hipMemsetAsync(m->d.hits, 0, cap * sizeof(int), m->stream));
     CREATE_HIP(hipMemsetAsync(m->d.last_seen, 0, cap * sizeof(int), m->stream));
-    CREATE_HIP(hipMemsetAsync(m->d.state, 0, 8 * sizeof(int), m->stream));
+    CREATE_HIP(hipMemsetAsync(m->d.state, 0, 16 * sizeof(int), m->stream));
     CREATE_HIP(hipMemsetAsync(m->d.totals, 0, 2 * sizeof(unsigned long long), m->stream));
     launch_fill_i32(m->d.winner, cap, -1, m->stream);
     CREATE_HIP(hipGetLastError());
@@ -273,7 +281,7 @@ static int update_blocks(lf_map* m, const uint8_t* blocks, int n_blocks, int blo
     int rc;
     const size_t rows = (size_t)n_blocks * (size_t)(block_rows - 1);
     if (rows >= (1u << 30)) { map_error(m, "lf_map_update: too many rows"); return LF_ERR_CAPACITY; }
-    if ((rc = grow(m, m->act, (rows + 1) * sizeof(int))) != LF_OK) return rc;
+    if ((rc = grow(m, m->act, (rows + rows / 1024 + 2) * sizeof(int))) != LF_OK) return rc;      // actions + per-workgroup append counts
     {
         MapTimer t(m, 3);
         launch_map_update(m->d, blocks, n_blocks, block_rows, force_append, static_cast<int*>(m->act.p), m->stream);
@@ -331,7 +339,7 @@ extern "C" int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appen
     const int rc = refresh_state(m);
     if (size) *size = m->h_state[0];
     if (head) *head = m->h_state[1];
-    const unsigned long long* t = reinterpret_cast<const unsigned long long*>(m->h_state + 8);
+    const unsigned long long* t = reinterpret_cast<const unsigned long long*>(m->h_state + 16);
     if (total_appended) *total_appended = (int64_t)t[0];
     if (total_refreshed) *total_refreshed = (int64_t)t[1];
     return rc;
@@ -398,12 +406,18 @@ extern "C" int lf_map_pack_block(lf_map* m, lf_handle* h, const lf_segments* seg
         map_error(m, "lf_map_pack_block: bad argument (segs->code is required; frame_pose needs segs->frame_offset and n_frames >= 1)");
         return LF_ERR_BAD_ARG;
     }
-    if (n + 1 > block_rows) {
-        map_error(m, "lf_map_pack_block: %d segments do not fit a block of %d rows (header + %d); nothing was written", n, block_rows, block_rows - 1);
-        return LF_ERR_CAPACITY;
-    }
+    if (block_rows < 1) { map_error(m, "lf_map_pack_block: block_rows < 1"); return LF_ERR_BAD_ARG; }
     MAP_HIP(m, hipSetDevice(m->device));
     int rc;
+    if (n + 1 > block_rows) {
+        // never truncated: the block becomes a header with count 0 and the OVERFLOW marker (word 4 = n).  A rank of a
+        // multi-GPU step still takes part in the all-gather with it, and lf_map_update skips, on every replica alike, an
+        // update that contains such a block -- so the failure is collective instead of a hang.
+        launch_map_overflow_block(n, n_frames, step, block, m->stream);
+        MAP_HIP(m, hipGetLastError());
+        map_error(m, "lf_map_pack_block: %d segments do not fit a block of %d rows (header + %d); only a header with the overflow marker was written", n, block_rows, block_rows - 1);
+        return LF_ERR_CAPACITY;
+    }
     if ((rc = after_handle(m, h)) != LF_OK) return rc;
     const double* dpose = nullptr;
     if (frame_pose) {

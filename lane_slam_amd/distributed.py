@@ -23,8 +23,9 @@ BLOCK_MAGIC = 0x4B42464C          # "LFBK"
 ROW_DTYPE = np.dtype({"names": ["code", "ground", "idx", "dist", "color", "keep", "pad"],
                       "formats": [("u1", 32), ("<f8", 4), "<i4", "<f4", "u1", "u1", ("u1", 6)],
                       "offsets": [0, 32, 64, 68, 72, 73, 74], "itemsize": BLOCK_ROW_BYTES})
-HEADER_DTYPE = np.dtype({"names": ["magic", "count", "step", "n_frames"], "formats": ["<u4", "<u4", "<i4", "<u4"],
-                         "offsets": [0, 4, 8, 12], "itemsize": BLOCK_ROW_BYTES})
+HEADER_DTYPE = np.dtype({"names": ["magic", "count", "step", "n_frames", "overflow"], "formats": ["<u4", "<u4", "<i4", "<u4", "<u4"],
+                         "offsets": [0, 4, 8, 12, 16], "itemsize": BLOCK_ROW_BYTES})
+LF_ERR_CAPACITY = -2
 
 
 def block_header(block_bytes):
@@ -45,7 +46,10 @@ class ShardedAssociator(object):
     """One rank's replica of the live map plus the per-step exchange.
 
     amap            LineAssociator (or an object with its device interface)
-    block_segments  capacity of one rank's block; a step with more segments raises (never truncates)
+    block_segments  capacity of one rank's block; a step with more segments raises (never truncates) -- on EVERY rank:
+                    the overflowing rank still takes part in the all-gather with a header-only block that carries the
+                    overflow marker, every replica skips that step's update, the overflowing rank raises at once and
+                    the others at their next call that synchronises with the map (lanefront.h, "failing updates")
     device          torch device of the segment arrays and blocks
     backend         "nccl" (= RCCL over xGMI, device buffers), "gloo" (CPU tensors; with a CUDA device the blocks are
                     staged through the host -- dry runs only)
@@ -77,9 +81,16 @@ class ShardedAssociator(object):
         ptrs = {k: out[k].data_ptr() for k in ("frame_offset", "code", "color", "keep", "ground")}
         if n > 0:
             m.associate_device(fe, ptrs["code"], ptrs["color"], n, idx.data_ptr(), dist_out.data_ptr())
-        # raises LanefrontError(LF_ERR_CAPACITY) when n does not fit the block: fail loudly, never truncate
-        m.pack_block_device(fe, ptrs, n, n_frames, idx.data_ptr(), dist_out.data_ptr(), poses, step, self.block.data_ptr(),
-                            self.rows)
+        # LF_ERR_CAPACITY when n does not fit the block: fail loudly, never truncate -- but only AFTER the collective,
+        # which the other ranks have entered or will enter (the block is then a header with the overflow marker)
+        overflow = None
+        try:
+            m.pack_block_device(fe, ptrs, n, n_frames, idx.data_ptr(), dist_out.data_ptr(), poses, step, self.block.data_ptr(),
+                                self.rows)
+        except Exception as e:
+            if getattr(e, "code", None) != LF_ERR_CAPACITY or not self.collective:
+                raise
+            overflow = e
         if self.collective:
             if self.cuda:
                 torch.cuda.current_stream(self.device).wait_stream(self.ext)      # the block is complete
@@ -92,4 +103,8 @@ class ShardedAssociator(object):
                 dist.all_gather_into_tensor(self.gathered, self.block)             # the step's ONE collective
             if self.cuda:
                 self.ext.wait_stream(torch.cuda.current_stream(self.device))
-        m.update_device(self.gathered.data_ptr(), self.world if self.collective else 1, self.rows)
+        try:
+            m.update_device(self.gathered.data_ptr(), self.world if self.collective else 1, self.rows)
+        finally:
+            if overflow is not None:
+                raise overflow

@@ -8,6 +8,7 @@ import ctypes
 import numpy as np
 
 from lane_slam_amd.distributed import BLOCK_MAGIC, BLOCK_ROW_BYTES, HEADER_DTYPE, ROW_DTYPE
+from lane_slam_amd.frontend import LanefrontError
 from oracle.oracle import OracleMap
 
 
@@ -34,11 +35,14 @@ class HostMap(object):
         _view(dist_ptr, np.float32, n)[:] = dist
 
     def pack_block_device(self, fe, ptrs, n, n_frames, idx_ptr, dist_ptr, poses, step, block_ptr, block_rows):
-        if n + 1 > block_rows:
-            raise RuntimeError("lanefront error -2: %d segments do not fit a block of %d rows" % (n, block_rows))
         blk = _view(block_ptr, np.uint8, block_rows * BLOCK_ROW_BYTES)
         hdr = np.zeros(1, HEADER_DTYPE)
         hdr["magic"], hdr["count"], hdr["step"], hdr["n_frames"] = BLOCK_MAGIC, n, step, n_frames
+        if n + 1 > block_rows:
+            # as lf_map_pack_block: a header with the overflow marker, then LF_ERR_CAPACITY
+            hdr["count"], hdr["overflow"] = 0, n
+            blk[:BLOCK_ROW_BYTES] = np.frombuffer(hdr.tobytes(), np.uint8)
+            raise LanefrontError(-2, "%d segments do not fit a block of %d rows" % (n, block_rows))
         blk[:BLOCK_ROW_BYTES] = np.frombuffer(hdr.tobytes(), np.uint8)
         rows = np.zeros(n, ROW_DTYPE)
         rows["code"] = _view(ptrs["code"], np.uint8, n * 32).reshape(n, 32)
@@ -56,8 +60,13 @@ class HostMap(object):
     def update_device(self, blocks_ptr, n_blocks, block_rows):
         raw = _view(blocks_ptr, np.uint8, n_blocks * block_rows * BLOCK_ROW_BYTES).reshape(n_blocks, block_rows * BLOCK_ROW_BYTES)
         parts, step = [], 0
+        hdrs = [np.frombuffer(raw[b, :BLOCK_ROW_BYTES].tobytes(), HEADER_DTYPE)[0] for b in range(n_blocks)]
+        if any(int(h["overflow"]) for h in hdrs):
+            # as lf_map_update: nothing is applied on any replica; the device map reports it at its next synchronising
+            # call, this stand-in at once
+            raise LanefrontError(-2, "a rank's segments did not fit its block: the step was applied on no replica")
         for b in range(n_blocks):
-            hdr = np.frombuffer(raw[b, :BLOCK_ROW_BYTES].tobytes(), HEADER_DTYPE)[0]
+            hdr = hdrs[b]
             assert int(hdr["magic"]) == BLOCK_MAGIC
             if b == 0:
                 step = int(hdr["step"])

@@ -115,6 +115,75 @@ def test_two_rank_replicas_equal_the_one_rank_map():
             assert np.array_equal(res1[step][1][sl], res[r][1][step][1])      # dist
 
 
+def _big_chunk(step, rank, n):
+    rng = np.random.default_rng(77 * step + rank)
+    return {"frame_offset": np.array([0, n // 2, n], np.int32), "code": rng.integers(0, 256, (n, 32), dtype=np.uint8),
+            "color": rng.integers(0, 3, n).astype(np.uint8), "keep": np.ones(n, np.uint8), "ground": rng.normal(size=(n, 4)),
+            "poses": rng.normal(size=(2, 3)), "n": n}
+
+
+def _overflow_worker(rank, world, port, q):
+    """Step 1: rank 1 alone has more segments than a block holds.  Both ranks must come out of the step with an
+    error (no rank left waiting in the all-gather), hold unchanged and identical replicas, and go on."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from host_map import HostMap
+    from lane_slam_amd.distributed import ShardedAssociator
+    from lane_slam_amd.frontend import LanefrontError
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sh = ShardedAssociator(HostMap(**MAP_KW), block_segments=32, device="cpu", backend="gloo")
+    raised, sizes = [], []
+    for step in range(4):
+        c = _big_chunk(step, rank, 40) if (step == 1 and rank == 1) else _chunk(step, rank)
+        out = {k: torch.from_numpy(c[k]) for k in ("frame_offset", "code", "color", "keep", "ground")}
+        idx = torch.zeros(max(c["n"], 1), dtype=torch.int32)
+        dd = torch.zeros(max(c["n"], 1), dtype=torch.float32)
+        try:
+            sh.step(None, out, c["n"], 2, idx, dd, poses=c["poses"], step=step)
+        except LanefrontError as e:
+            raised.append((step, e.code))
+        sizes.append(sh.map.o.state()["total_appended"])
+    q.put((rank, raised, sizes, sh.map.o.fetch(), sh.map.o.state()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_overflowing_fails_the_step_on_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overflow_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])        # a hang would time out here
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert res[r][1] == [(1, -2)], res[r][1]                   # LF_ERR_CAPACITY at step 1, on both ranks, nowhere else
+        assert res[r][2][1] == res[r][2][0] and res[r][2][2] > res[r][2][1]          # step 1 applied nothing; step 2 went on
+    for k in ("code", "color", "ground", "hits", "last_seen"):
+        assert np.array_equal(res[0][3][k], res[1][3][k]), k
+    assert res[0][4] == res[1][4]
+    # = the one-rank map over steps 0, 2, 3
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from host_map import HostMap
+    from lane_slam_amd.distributed import ShardedAssociator
+    one = ShardedAssociator(HostMap(**MAP_KW), block_segments=64, device="cpu", backend="gloo")
+    for step in (0, 2, 3):
+        c = _merge_chunks(step, world)
+        out = {k: torch.from_numpy(c[k]) for k in ("frame_offset", "code", "color", "keep", "ground")}
+        one.step(None, out, c["n"], 4, torch.zeros(max(c["n"], 1), dtype=torch.int32), torch.zeros(max(c["n"], 1), dtype=torch.float32),
+                 poses=c["poses"], step=step)
+    assert one.map.o.state() == res[0][4]
+    f1 = one.map.o.fetch()
+    for k in ("code", "color", "ground", "hits", "last_seen"):
+        assert np.array_equal(f1[k], res[0][3][k]), k
+
+
 def test_block_overflow_is_an_error_not_a_truncation():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from host_map import HostMap
