@@ -178,7 +178,7 @@ int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* 
  * result does not depend on it except through which of several equally far samples re-seeds an empty cluster: the lowest
  * index).  init_centers [k][3] f64, k <= 16; max_iter 25 and tol 1e-4 are the reference's (scikit-learn's default tol).
  * centers_out [k][3] f64, counts_out [k], *inertia_out (score = -inertia), *n_iter_out.  Blocking.  LF_ERR_BAD_ARG when a
- * cluster stays empty (fewer distinct samples than clusters). */
+ * cluster stays empty (fewer distinct samples than clusters); LF_ERR_UNSUPPORTED for n > 2^24 points. */
 int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int k, const double* init_centers, int max_iter,
               double tol, double* centers_out, long long* counts_out, double* inertia_out, int* n_iter_out);
 

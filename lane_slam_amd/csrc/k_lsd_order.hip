@@ -274,12 +274,10 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
                       int* row_start, hipStream_t s)
 {
     const size_t lds = ((size_t)2 * LDS_ITEMS + 2 * (size_t)(p.Hs + 2) + 2 * (OT / 64) * 32) * sizeof(uint32_t);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {   // more than 64 KB of dynamic LDS needs the opt-in (a refusal is not fatal here: the launch says so)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_order), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            (void)hipGetLastError();
-        attr_lds = lds;
-    }
+    // more than 64 KB of dynamic LDS needs the opt-in; the attribute is PER DEVICE, so it is set before every such launch
+    // (a refusal surfaces through hipGetLastError() in the caller's LF_HIP_CHECK after the launch)
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_order), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lsd_order, dim3(n_frames * 3), dim3(OT), lds, s, p, r_addr, r_deg, r_mod, r_cs, r_sn, n_rec, maxgrad,
                        sort_a, sort_b, order_a, order_b, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start);
 }
@@ -445,12 +443,8 @@ void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const
                       uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, hipStream_t s)
 {
     const size_t lds = (size_t)p.label_items * (4 + 2);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            (void)hipGetLastError();
-        attr_lds = lds;
-    }
+    if (lds > 48 * 1024)      // per device: set before every launch that needs it (see launch_lsd_order)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // LF_DIAG_COMP_CAP: a smaller component list, so that tests reach the "more components than the list holds" fallback
     static const int comp_cap = getenv("LF_DIAG_COMP_CAP") ? max(1, min(kCompCap, atoi(getenv("LF_DIAG_COMP_CAP")))) : kCompCap;
     hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap);

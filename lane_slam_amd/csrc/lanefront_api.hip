@@ -826,6 +826,10 @@ extern "C" int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_
         lf_set_error(h, LF_ERR_BAD_ARG, "lf_kmeans: null argument, n < 1, max_iter < 1 or k outside 1..16");
         return LF_ERR_BAD_ARG;
     }
+    if (n > (1 << 24)) {      // k_kmeans' per-wave 32-bit colour sums (64 lanes x n / 1024 points x 255) stay exact up to here
+        lf_set_error(h, LF_ERR_UNSUPPORTED, "lf_kmeans: more than 2^24 points (%d) are not supported", n);
+        return LF_ERR_UNSUPPORTED;
+    }
     LF_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     int rc;

@@ -379,7 +379,7 @@ def c_string(lines):
 
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "lane_slam_amd", "csrc", "k_assoc_loop.inc")
-    sclob = ", ".join('"s%d"' % i for i in range(40, 58)) + ', "memory", "scc"'
+    sclob = ", ".join('"s%d"' % i for i in range(40, 58)) + ', "m0", "memory", "scc"'
     clob_plain = ", ".join('"v%d"' % i for i in range(104, 252)) + ", " + sclob
     clob_gated = ", ".join('"v%d"' % i for i in list(range(104, 232)) + list(range(240, 252))) + ", " + sclob
     with open(out, "w") as f:
@@ -388,7 +388,7 @@ def main():
         f.write("#define LF_ASSOC_LOOP_GATED \\\n" + c_string(gen(True)).replace("\n", " \\\n") + "\n\n")
         f.write("#define LF_ASSOC_LOOP_FP4 \\\n" + c_string(gen_fp4()).replace("\n", " \\\n") + "\n\n")
         f.write("#define LF_ASSOC_LOOP_FP4_GATED \\\n" + c_string(gen_fp4(gated=True)).replace("\n", " \\\n") + "\n\n")
-        clob_fp4 = ", ".join('"v%d"' % i for i in list(range(76, 200)) + list(range(200, 239))) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "memory", "scc"'
+        clob_fp4 = ", ".join('"v%d"' % i for i in list(range(76, 200)) + list(range(200, 239))) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "m0", "memory", "scc"'
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_FP4 " + clob_fp4 + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_PLAIN " + clob_plain + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_GATED " + clob_gated + "\n")
