@@ -28,6 +28,9 @@
 #include <cstdio>
 #include "common.h"
 #include "k_assoc_loop.inc"
+// The tile loops set m0 before every global_load_lds and say so in their clobber lists, so that the compiler's
+// merging of its own m0 set-ups never reaches across an asm statement; clang notes that m0 is a reserved register.
+#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace lf {
 
