@@ -114,6 +114,59 @@ void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
 /* float-descriptor L2 NN (72-d) */
 void lfo_match_float(const float* q72, int nq, const float* t72, int nt, int32_t* idx, float* dist);
 
+/* ---- EDLines + multi-octave KeyLines / LBD (lf_oracle_edlines.c) ---- */
+typedef struct lfo_edlines_params {      /* EDLineDetector::EDLineDetector(), binary_descriptor_custom.cpp:1374-1385 */
+    int32_t ksize; float sigma;          /* unused by the detector itself (the caller blurs), kept for the record */
+    int32_t gradient_threshold, anchor_threshold, scan_intervals, min_line_len;
+    double line_fit_err_threshold;
+} lfo_edlines_params;
+void lfo_edlines_params_default(lfo_edlines_params* p);
+void lfo_gaussian_taps_q8(int ksize, double sigma, int32_t* taps);
+void lfo_gaussian_blur_u8(const uint8_t* src, int rows, int cols, int ksize, double sigma, uint8_t* dst);
+void lfo_resize_size(int rows, int cols, double inv_scale, int* drows, int* dcols);
+void lfo_resize_linear_u8(const uint8_t* src, int rows, int cols, double inv_scale, uint8_t* dst);
+void lfo_pyrdown_u8(const uint8_t* src, int rows, int cols, uint8_t* dst);
+void lfo_ed_gradient(const uint8_t* img, int rows, int cols, int gradient_threshold, int16_t* dx, int16_t* dy, int16_t* g,
+                     int16_t* gwo, uint8_t* dir);
+int lfo_ed_anchors(const int16_t* g, const uint8_t* dir, int rows, int cols, int anchor_threshold, int scan, uint32_t* ax,
+                   uint32_t* ay, int cap);
+int lfo_ed_link(const int16_t* g, const uint8_t* dir, int rows, int cols, const uint32_t* ax, const uint32_t* ay, int n_anchors,
+                int min_line_len, uint32_t* xcors, uint32_t* ycors, uint32_t* sid, uint8_t* edge_out);
+double lfo_ed_nfa(int n, int k, double p, double logNT);
+int lfo_ed_lines(const int16_t* pdx, const int16_t* pdy, const uint8_t* dir, int rows, int cols, const uint32_t* xcors,
+                 const uint32_t* ycors, const uint32_t* sid, int n_edges, int min_line_len, double fit_err_threshold,
+                 uint32_t* lx, uint32_t* ly, uint32_t* lsid, double* equations3, float* endpoints4, float* direction, int cap_lines);
+void lfo_ed_salience(const int16_t* gwo, int cols, const uint32_t* lx, const uint32_t* ly, const uint32_t* lsid, int n_lines,
+                     float* salience);
+/* one octave, all stages kept: which = 0 dx 1 dy 2 g 3 gwo (s16) | 4 dir 5 edge (u8) | 6 ax 7 ay 8 xcors 9 ycors 10 sid
+ * 11 lx 12 ly 13 lsid (u32) | 14 equations (f64 x3) | 15 endpoints (f32 x4) 16 direction 17 salience (f32) */
+typedef struct lfo_edlines lfo_edlines;
+lfo_edlines* lfo_edlines_run(const lfo_edlines_params* p, const uint8_t* blurred, int rows, int cols);
+void lfo_edlines_free(lfo_edlines* e);
+int lfo_edlines_counts(const lfo_edlines* e, int* n_anchors, int* n_edges, int* n_edge_pixels, int* n_lines, int* n_line_pixels);
+const void* lfo_edlines_array(const lfo_edlines* e, int which);
+/* KeyLines of BinaryDescriptor::detect + their descriptors (operator(), :263-301), one row per KeyLine */
+typedef struct lfo_keylines_out {
+    float* start_end;      /* startPointX, startPointY, endPointX, endPointY (original image scale) */
+    float* in_octave;      /* sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY */
+    float* angle;          /* KeyLine::angle = the line's direction, dark side on the left */
+    int32_t* num_pixels;
+    float* line_length;
+    int32_t* octave;
+    int32_t* class_id;
+    float* response;       /* may be NULL, like the next four */
+    float* size;
+    float* pt;             /* 2 per line */
+    float* salience;       /* OctaveSingleLine::salience (not part of KeyLine) */
+    float* desc;           /* 72 per line */
+    uint8_t* code;         /* 32 per line */
+    int32_t octave_rows[8], octave_cols[8], octave_lines[8];
+} lfo_keylines_out;
+int lfo_octave_keylines(const lfo_edlines_params* p, const uint8_t* gray, int rows, int cols, int n_octaves, int ksize, int cap,
+                        lfo_keylines_out* out);
+int lfo_describe_keylines(const uint8_t* gray, int rows, int cols, const float* in_octave4, const float* angle,
+                          const int32_t* num_pixels, const int32_t* octave, int n, float* desc72, uint8_t* code32);
+
 /* ---- live map + associator (lf_oracle_map.c): the build's own contract, see that file's header ---- */
 #define LFO_MAP_APPEND 0
 #define LFO_MAP_MERGE 1

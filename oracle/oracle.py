@@ -447,3 +447,145 @@ def kmeans(bgr_points, init, max_iter=25, tol=1e-4):
     if it < 0:
         raise ValueError("k-means: a cluster ran empty")
     return centers, counts, inertia.value, it
+
+
+# ---------------------------------------------------------------- EDLines + multi-octave KeyLines (lf_oracle_edlines.c)
+class LfoEdlinesParams(ctypes.Structure):
+    _fields_ = [("ksize", ctypes.c_int32), ("sigma", ctypes.c_float), ("gradient_threshold", ctypes.c_int32),
+                ("anchor_threshold", ctypes.c_int32), ("scan_intervals", ctypes.c_int32), ("min_line_len", ctypes.c_int32),
+                ("line_fit_err_threshold", ctypes.c_double)]
+
+
+class _KeylinesOut(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_void_p) for k in ("start_end", "in_octave", "angle", "num_pixels", "line_length", "octave",
+                                               "class_id", "response", "size", "pt", "salience", "desc", "code")] + \
+               [("octave_rows", ctypes.c_int32 * 8), ("octave_cols", ctypes.c_int32 * 8), ("octave_lines", ctypes.c_int32 * 8)]
+
+
+def _edlib():
+    lib = ctypes.CDLL(build())
+    lib.lfo_edlines_run.restype = ctypes.c_void_p
+    lib.lfo_edlines_array.restype = ctypes.c_void_p
+    lib.lfo_ed_nfa.restype = ctypes.c_double
+    return lib
+
+
+def edlines_params(**kw):
+    """EDLineDetector's defaults (binary_descriptor_custom.cpp:1374-1385), optionally overridden."""
+    p = LfoEdlinesParams()
+    _edlib().lfo_edlines_params_default(ctypes.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def gaussian_taps_q8(ksize, sigma):
+    taps = np.zeros(ksize, np.int32)
+    _edlib().lfo_gaussian_taps_q8(int(ksize), ctypes.c_double(sigma), _p(taps))
+    return taps
+
+
+def gaussian_blur_u8(img, ksize, sigma):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty_like(img)
+    _edlib().lfo_gaussian_blur_u8(_p(img), img.shape[0], img.shape[1], int(ksize), ctypes.c_double(sigma), _p(out))
+    return out
+
+
+def resize_linear_u8(img, inv_scale):
+    img = np.ascontiguousarray(img, np.uint8)
+    lib = _edlib()
+    r, c = ctypes.c_int(), ctypes.c_int()
+    lib.lfo_resize_size(img.shape[0], img.shape[1], ctypes.c_double(inv_scale), ctypes.byref(r), ctypes.byref(c))
+    out = np.empty((r.value, c.value), np.uint8)
+    lib.lfo_resize_linear_u8(_p(img), img.shape[0], img.shape[1], ctypes.c_double(inv_scale), _p(out))
+    return out
+
+
+def pyrdown_u8(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    out = np.empty((img.shape[0] // 2, img.shape[1] // 2), np.uint8)
+    _edlib().lfo_pyrdown_u8(_p(img), img.shape[0], img.shape[1], _p(out))
+    return out
+
+
+def ed_nfa(n, k, p, log_nt):
+    return _edlib().lfo_ed_nfa(int(n), int(k), ctypes.c_double(p), ctypes.c_double(log_nt))
+
+
+_ED_ARRAYS = [("dx", np.int16), ("dy", np.int16), ("g", np.int16), ("gwo", np.int16), ("dir", np.uint8), ("edge", np.uint8),
+              ("ax", np.uint32), ("ay", np.uint32), ("xcors", np.uint32), ("ycors", np.uint32), ("sid", np.uint32),
+              ("lx", np.uint32), ("ly", np.uint32), ("lsid", np.uint32), ("equations", np.float64), ("endpoints", np.float32),
+              ("direction", np.float32), ("salience", np.float32)]
+
+
+def edlines(blurred, params=None):
+    """EDLineDetector::EDline on an already blurred u8 image, every stage kept.  None when the detector gives up."""
+    lib = _edlib()
+    img = np.ascontiguousarray(blurred, np.uint8)
+    rows, cols = img.shape
+    params = params or edlines_params()
+    e = lib.lfo_edlines_run(ctypes.byref(params), _p(img), rows, cols)
+    if not e:
+        return None
+    e = ctypes.c_void_p(e)
+    cnt = [ctypes.c_int() for _ in range(5)]
+    lib.lfo_edlines_counts(e, *[ctypes.byref(c) for c in cnt])
+    n_anchors, n_edges, n_edge_px, n_lines, n_line_px = (c.value for c in cnt)
+    sizes = {"dx": rows * cols, "dy": rows * cols, "g": rows * cols, "gwo": rows * cols, "dir": rows * cols, "edge": rows * cols,
+             "ax": n_anchors, "ay": n_anchors, "xcors": n_edge_px, "ycors": n_edge_px, "sid": n_edges + 1, "lx": n_line_px,
+             "ly": n_line_px, "lsid": n_lines + 1, "equations": 3 * n_lines, "endpoints": 4 * n_lines, "direction": n_lines,
+             "salience": n_lines}
+    out = {"n_anchors": n_anchors, "n_edges": n_edges, "n_lines": n_lines}
+    for which, (name, dt) in enumerate(_ED_ARRAYS):
+        n = sizes[name]
+        ptr = lib.lfo_edlines_array(e, which)
+        a = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(dt))), shape=(max(n, 1),))[:n].copy()
+        out[name] = a
+    for k in ("dx", "dy", "g", "gwo", "dir", "edge"):
+        out[k] = out[k].reshape(rows, cols)
+    out["equations"] = out["equations"].reshape(-1, 3)
+    out["endpoints"] = out["endpoints"].reshape(-1, 4)
+    lib.lfo_edlines_free(e)
+    return out
+
+
+def octave_keylines(gray, n_octaves=1, params=None, ksize=5, cap=20000):
+    """BinaryDescriptor::operator() (detect with EDLines over n_octaves + LBD on the detector's gradients): dict of
+    per-KeyLine arrays in detectImpl's order, plus 'octave_size' [(rows, cols)] and 'octave_lines'."""
+    lib = _edlib()
+    lib.lfo_octave_keylines.restype = ctypes.c_int
+    gray = np.ascontiguousarray(gray, np.uint8)
+    params = params or edlines_params()
+    shapes = {"start_end": (np.float32, 4), "in_octave": (np.float32, 4), "angle": (np.float32, 1), "num_pixels": (np.int32, 1),
+              "line_length": (np.float32, 1), "octave": (np.int32, 1), "class_id": (np.int32, 1), "response": (np.float32, 1),
+              "size": (np.float32, 1), "pt": (np.float32, 2), "salience": (np.float32, 1), "desc": (np.float32, 72), "code": (np.uint8, 32)}
+    arrs = {k: np.zeros((cap, c) if c > 1 else cap, dt) for k, (dt, c) in shapes.items()}
+    o = _KeylinesOut()
+    for k, a in arrs.items():
+        setattr(o, k, a.ctypes.data)
+    n = lib.lfo_octave_keylines(ctypes.byref(params), _p(gray), gray.shape[0], gray.shape[1], int(n_octaves), int(ksize), int(cap), ctypes.byref(o))
+    if n < 0:
+        return None
+    out = {k: a[:n].copy() for k, a in arrs.items()}
+    out["n"] = n
+    out["octave_size"] = [(o.octave_rows[i], o.octave_cols[i]) for i in range(n_octaves)]
+    out["octave_lines"] = [o.octave_lines[i] for i in range(n_octaves)]
+    return out
+
+
+def describe_keylines(gray, in_octave, angle, num_pixels, octave):
+    """BinaryDescriptor::compute on given KeyLines (pyramid of computeGaussianPyramid): (desc [n, 72], code [n, 32])."""
+    lib = _edlib()
+    lib.lfo_describe_keylines.restype = ctypes.c_int
+    gray = np.ascontiguousarray(gray, np.uint8)
+    io = np.ascontiguousarray(in_octave, np.float32).reshape(-1, 4)
+    n = io.shape[0]
+    ang = np.ascontiguousarray(angle, np.float32)
+    npx = np.ascontiguousarray(num_pixels, np.int32)
+    octv = np.ascontiguousarray(octave, np.int32)
+    desc, code = np.zeros((n, 72), np.float32), np.zeros((n, 32), np.uint8)
+    rc = lib.lfo_describe_keylines(_p(gray), gray.shape[0], gray.shape[1], _p(io), _p(ang), _p(npx), _p(octv), n, _p(desc), _p(code))
+    if rc < 0:
+        raise ValueError("describe_keylines: octave out of range")
+    return desc, code
