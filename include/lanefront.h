@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 3   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages; 3: live map (lf_map_*) */
+#define LF_ABI_VERSION 4   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages; 3: live map (lf_map_*); 4: EDLines / KeyLines, block overflow marker */
 
 typedef enum lf_status {
     LF_OK = 0,
@@ -284,6 +284,73 @@ int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, d
 int lf_map_set_profiling(lf_map* m, int enabled);
 int lf_map_get_timing(lf_map* m, double* ms_per_stage, int32_t* launches_per_stage, int n);
 const char* lf_map_stage_name(int stage);
+
+/* ---- EDLines detector + multi-octave KeyLines / LBD --------------------------------
+ * The reference's second detector: BinaryDescriptor::operator() with useProvidedKeyLines = false
+ * (src/line_descriptor/src/binary_descriptor_custom.cpp:263-301) = detectImpl (:455-513: OctaveKeyLines :689-1024,
+ * one EDLineDetector per octave :1442-2751) followed by computeImpl on the DETECTOR's own gradient images
+ * (:1079-1090).  Per octave: GaussianBlur(ksize 5, sigma 1, 1, sqrt 2, 2, ...), EDLines (Sobel, thresholded gradient,
+ * anchors, smart routing, least-squares line fitting, NFA validation), resize by 1 / sqrt 2; the octaves' lines that
+ * belong together share a class_id; KeyLines come ordered by class_id, then octave.  Parity: held bit for bit to
+ * oracle/lf_oracle_edlines.c, which restates the in-tree C++ -- unpinned against a real build of it (needs OpenCV).
+ *
+ * lf_edlines_params   EDLineDetector::EDLineDetector() defaults (:1374-1385): gradient_threshold 80, anchor_threshold 8,
+ *                     scan_intervals 2, min_line_len 15 (<= 64), line_fit_err_threshold 1.6; ksize 5 (only 5 is built)
+ * lf_keylines         struct of arrays, caller allocated for `capacity` lines, NULL arrays are skipped; field meaning =
+ *                     KeyLine (include/line_descriptor/descriptor_custom.hpp:105-144): start_end = startPointX/Y,
+ *                     endPointX/Y (original image scale), in_octave = s/ePointInOctaveX/Y, angle = direction of the line
+ *                     (dark side on its left), num_pixels, line_length, octave, class_id, response, size, pt (2 per
+ *                     line), salience (OctaveSingleLine::salience, not a KeyLine field), desc (72 f32) / code (32 B)
+ * input_kind          0: raw camera frames [n][in_rows][in_cols][3] BGR -- the gray image is BGR2GRAY of the handle's
+ *                     working image (resize / crop / colour correction as in lf_process_batch); 1: gray working
+ *                     images [n][img_rows - top_cutoff][img_cols] u8 as they are
+ * frame_status        optional host [n_frames]: 0 ok; 1..4: the detector gave up on an octave of that frame (anchor /
+ *                     edge arrays full, :1533-1537, :2185-2196; more than 5 lines per edge or than the handle holds;
+ *                     more than 4096 lines in the frame) -- such a frame has no KeyLines, as in the reference, where
+ *                     detectImpl ignores OctaveKeyLines' return value (:465-468)
+ * Synchronous.  LF_ERR_CAPACITY when the KeyLines do not fit out->capacity. */
+#define LF_MAX_OCTAVES 5
+typedef struct lf_edlines_params {
+    int32_t gradient_threshold, anchor_threshold, scan_intervals, min_line_len;
+    double line_fit_err_threshold;
+    int32_t ksize;
+} lf_edlines_params;
+typedef struct lf_keylines {
+    int32_t capacity;
+    int32_t* frame_offset;      /* n_frames + 1 */
+    float* start_end;
+    float* in_octave;
+    float* angle;
+    int32_t* num_pixels;
+    float* line_length;
+    int32_t* octave;
+    int32_t* class_id;
+    float* response;
+    float* size;
+    float* pt;
+    float* salience;
+    float* desc;
+    uint8_t* code;
+} lf_keylines;
+void lf_edlines_default_params(lf_edlines_params* p);
+int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+                      const lf_edlines_params* params_or_null, lf_keylines* out, int out_on_device, int describe,
+                      int* n_keylines, int32_t* frame_status_or_null);
+/* BinaryDescriptor::compute on GIVEN KeyLines (:524-687, useDetectionData = false): gradients from
+ * computeGaussianPyramid (:350-371: GaussianBlur 5x5 sigma 1, then pyrDown by 2 per octave) + Sobel (:374-398).
+ * gray: [n_frames][rows][cols] u8 working images; per line: its frame, in_octave endpoints (4), angle, num_pixels,
+ * octave (< LF_MAX_OCTAVES).  desc [n][72] / code [n][32], either may be NULL.  All arrays host (on_device = 0) or
+ * device.  The multi-octave LSD KeyLines of LSDDetector_custom.cpp:130-215 (scale 2) are what lives on this pyramid. */
+int lf_describe_keylines(lf_handle* h, const uint8_t* gray, int n_frames, const int32_t* line_frame, const float* in_octave4,
+                         const float* angle, const int32_t* num_pixels, const int32_t* octave, int n, float* desc72,
+                         uint8_t* code32, int on_device);
+/* intermediate results of the last lf_keylines_batch for tests (synchronises): `what` = 0 blurred octave image (u8)
+ * 1 dx | dy << 16 (u32) 2 thresholded gradient / 4 | direction << 15 (u16) 3 anchors (u32 x | y << 16, [frames][cap])
+ * 4 edge chains (u32, [frames][2 cap]) 5 chain starts (u32, [frames][max_edges + 2]) 6 counts (i32 [frames][4]: anchors,
+ * edges, lines, status) 7 line endpoints (f32 x4, [frames][max_lines]) 8 lineEquation[2] (f64) 9 direction (f32)
+ * 10 pixels per line (i32) 11 salience (f32) 12 the octave's input image (u8); dims: octave rows, cols, cap, max_edges,
+ * max_lines */
+int lf_keylines_debug_fetch(lf_handle* h, int octave, int what, void* dst, size_t bytes, int32_t* dims5_or_null);
 
 /* ---- host ingest: replaces duckietown_utils.jpg.image_cv_from_jpg ---------------
  * = cv2.imdecode(np.fromstring(data, np.uint8), cv2.IMREAD_COLOR)

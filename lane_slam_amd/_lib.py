@@ -25,7 +25,9 @@ EXPORTS = (
     "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
     "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_step_host", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
+    "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch",
 )
+LF_MAX_OCTAVES = 5
 
 
 class LfSegments(ctypes.Structure):
@@ -36,6 +38,22 @@ class LfSegments(ctypes.Structure):
         ("pixels_normalized", ctypes.c_void_p), ("ground", ctypes.c_void_p), ("keep", ctypes.c_void_p),
         ("desc", ctypes.c_void_p), ("code", ctypes.c_void_p),
     ]
+
+
+class LfEdlinesParams(ctypes.Structure):
+    """ctypes mirror of `lf_edlines_params` (include/lanefront.h)."""
+    _fields_ = [("gradient_threshold", ctypes.c_int32), ("anchor_threshold", ctypes.c_int32), ("scan_intervals", ctypes.c_int32),
+                ("min_line_len", ctypes.c_int32), ("line_fit_err_threshold", ctypes.c_double), ("ksize", ctypes.c_int32)]
+
+
+KEYLINE_FIELDS = (("start_end", "f4", 4), ("in_octave", "f4", 4), ("angle", "f4", 1), ("num_pixels", "i4", 1), ("line_length", "f4", 1),
+                  ("octave", "i4", 1), ("class_id", "i4", 1), ("response", "f4", 1), ("size", "f4", 1), ("pt", "f4", 2), ("salience", "f4", 1),
+                  ("desc", "f4", 72), ("code", "u1", 32))
+
+
+class LfKeylines(ctypes.Structure):
+    """ctypes mirror of `lf_keylines` (include/lanefront.h)."""
+    _fields_ = [("capacity", ctypes.c_int32), ("frame_offset", ctypes.c_void_p)] + [(k, ctypes.c_void_p) for k, _, _ in KEYLINE_FIELDS]
 
 
 class LfMapConfig(ctypes.Structure):
@@ -130,6 +148,15 @@ def load():
     lib.lf_map_get_timing.restype = ci
     lib.lf_map_stage_name.argtypes = [ci]
     lib.lf_map_stage_name.restype = ctypes.c_char_p
+    lib.lf_edlines_default_params.argtypes = [ctypes.POINTER(LfEdlinesParams)]
+    lib.lf_edlines_default_params.restype = None
+    lib.lf_keylines_batch.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfEdlinesParams), ctypes.POINTER(LfKeylines), ci, ci,
+                                      ctypes.POINTER(ci), vp]
+    lib.lf_keylines_batch.restype = ci
+    lib.lf_describe_keylines.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, ci]
+    lib.lf_describe_keylines.restype = ci
+    lib.lf_keylines_debug_fetch.argtypes = [vp, ci, ci, vp, ctypes.c_size_t, vp]
+    lib.lf_keylines_debug_fetch.restype = ci
     for f in ("lf_map_create", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size", "lf_map_associate",
               "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_fetch"):
         getattr(lib, f).restype = ci

@@ -1,0 +1,831 @@
+// EDLines detector + multi-octave KeyLines: the reference's BinaryDescriptor::detect path,
+//   /root/reference/src/line_descriptor/src/binary_descriptor_custom.cpp
+//     :689-1024  OctaveKeyLines (Gaussian blur per octave, EDLines, resize by 1/sqrt 2, grouping of the octaves' lines)
+//     :1442-2240 EdgeDrawing    :2242-2482 EDline    :2484-2643 LeastSquaresLineFit_    :2645-2726 LineValidation_
+//     :455-513   detectImpl (KeyLine fields and order)
+// re-designed for the MI355X; oracle/lf_oracle_edlines.c is the sequential statement these kernels are held to, bit
+// for bit (tests/test_gpu_edlines.py).
+//
+//   k_ed_grad     streaming, one 64x16 tile per workgroup: 5x5 fixed-point Gaussian (taps from the host) -> blurred u8
+//                 plane (the next octave is resized from it), Sobel 3x3 -> dx | dy << 16 per pixel (the plane k_lbd
+//                 gathers from: the descriptor of a detected line uses the DETECTOR's gradients, :1079-1090), and the
+//                 thresholded gradient / 4 (round half to even) with the pixel's direction in bit 15 (u16 plane).
+//                 HBM bound: reads P, writes P + 4P + 2P.
+//   k_ed_resize   cv::resize INTER_LINEAR by 1/sqrt 2 on u8 (11-bit fixed-point weights), one thread per pixel.
+//   k_ed_detect   one workgroup per (frame, octave).  Anchors: every wave tests candidates row-major (coalesced) into a
+//                 bit plane in LDS indexed COLUMN-major -- the order the reference scans them in, which decides which
+//                 anchor draws which edge -- then a ballot / prefix pass lists them.  Smart routing is sequential by
+//                 definition (a walk stops at pixels earlier walks marked): ONE wave walks, edge marks are a bit plane
+//                 in LDS (global memory for octave images beyond the LDS budget), the chain is assembled in place
+//                 (first part reversed by all 64 lanes, second part written behind it as it is walked).  Line fitting
+//                 then runs on the same wave, chain by chain: the 64 lanes take the pixels of a run at once (distance
+//                 tests by ballot and bit tricks, exact integer sums for the normal equations, ordered f64 sums where
+//                 the reference's order matters), one lane-uniform evaluation of the NFA.
+//   k_kl_assemble one workgroup per frame: groups the octaves' lines (each line of octave o against all lines of the
+//                 octaves below, lanes = lines), orders KeyLines by (class, octave) and fills the output rows.
+#include "common.h"
+#include "k_edlines_types.h"
+
+namespace lf {
+
+constexpr int ET_W = 64, ET_H = 16;                 // k_ed_grad tile
+constexpr int kHorizontal = 0x8000;                 // bit 15 of the g plane: |dx| < |dy|
+
+__device__ __forceinline__ int ed_reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; }
+    return p;
+}
+
+__device__ __forceinline__ int ed_div4_half_even(int v)
+{
+    const int q = v >> 2, r = v & 3;
+    return r < 2 ? q : (r == 3 ? q + 1 : q + (q & 1));
+}
+
+// src u8 [B][H][W] -> blur u8, dxy u32, g u16.  taps: 5 ints (sum ~ 256).
+__global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __restrict__ src, int t0, int t1, int t2, int t3, int t4,
+                                                 int grad_threshold, uint8_t* __restrict__ blur, uint32_t* __restrict__ dxy,
+                                                 uint16_t* __restrict__ g)
+{
+    // rows ty-3 .. ty+ET_H+2, cols tx-3 .. tx+ET_W+2 of the source (in-image part), then the row filter, then the blurred
+    // tile with a 1-pixel ring (in-image part; the Sobel reflects INTO it: BORDER_REFLECT_101 of the blurred image)
+    __shared__ uint8_t s_src[ET_H + 6][ET_W + 8];
+    __shared__ int s_row[ET_H + 6][ET_W + 2];
+    __shared__ uint8_t s_blur[ET_H + 2][ET_W + 4];
+    const int tx = blockIdx.x * ET_W, ty = blockIdx.y * ET_H;
+    const size_t fo = (size_t)blockIdx.z * H * W;
+    const uint8_t* S = src + fo;
+    const int tid = threadIdx.x;
+    const int k[5] = { t0, t1, t2, t3, t4 };
+    // source region: LDS (r, c) <-> image (ty - 3 + r, tx - 3 + c); out-of-image entries are never read (all readers
+    // reflect first)
+    for (int i = tid; i < (ET_H + 6) * (ET_W + 6); i += 256) {
+        const int r = i / (ET_W + 6), c = i - r * (ET_W + 6);
+        const int y = ty - 3 + r, x = tx - 3 + c;
+        s_src[r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? S[(size_t)y * W + x] : (uint8_t)0;
+    }
+    __syncthreads();
+    // row filter at (y, x), x in tx-1 .. tx+ET_W, y in ty-3 .. ty+ET_H+2 (in-image positions only)
+    for (int i = tid; i < (ET_H + 6) * (ET_W + 2); i += 256) {
+        const int r = i / (ET_W + 2), c = i - r * (ET_W + 2);
+        const int y = ty - 3 + r, x = tx - 1 + c;
+        int s = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+#pragma unroll
+            for (int j = -2; j <= 2; ++j) {
+                const int xx = ed_reflect101(x + j, W);
+                s += k[j + 2] * (int)s_src[r][xx - (tx - 3)];
+            }
+        }
+        s_row[r][c] = s;
+    }
+    __syncthreads();
+    // column filter -> blurred value at (y, x), y in ty-1 .. ty+ET_H, x in tx-1 .. tx+ET_W
+    for (int i = tid; i < (ET_H + 2) * (ET_W + 2); i += 256) {
+        const int r = i / (ET_W + 2), c = i - r * (ET_W + 2);
+        const int y = ty - 1 + r, x = tx - 1 + c;
+        int v = 0;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            int s = 0;
+#pragma unroll
+            for (int j = -2; j <= 2; ++j) {
+                const int yy = ed_reflect101(y + j, H);
+                s += k[j + 2] * s_row[yy - (ty - 3)][c];
+            }
+            v = (s + (1 << 15)) >> 16;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+        }
+        s_blur[r][c] = (uint8_t)v;
+    }
+    __syncthreads();
+    for (int i = tid; i < ET_H * ET_W; i += 256) {
+        const int r = i / ET_W, c = i - r * ET_W;
+        const int y = ty + r, x = tx + c;
+        if (y >= H || x >= W) continue;
+        // neighbours of the blurred image with BORDER_REFLECT_101
+        const int ym = ed_reflect101(y - 1, H) - (ty - 1), y0 = r + 1, yp = ed_reflect101(y + 1, H) - (ty - 1);
+        const int xm = ed_reflect101(x - 1, W) - (tx - 1), x0 = c + 1, xp = ed_reflect101(x + 1, W) - (tx - 1);
+#define B_(yy, xx) ((int)s_blur[yy][xx])
+        const int vx = (B_(ym, xp) - B_(ym, xm)) + 2 * (B_(y0, xp) - B_(y0, xm)) + (B_(yp, xp) - B_(yp, xm));
+        const int vy = (B_(yp, xm) - B_(ym, xm)) + 2 * (B_(yp, x0) - B_(ym, x0)) + (B_(yp, xp) - B_(ym, xp));
+        const size_t o = fo + (size_t)y * W + x;
+        blur[o] = (uint8_t)B_(y0, x0);
+#undef B_
+        dxy[o] = ((uint32_t)vx & 0xffffu) | ((uint32_t)vy << 16);
+        const int ax = vx < 0 ? -vx : vx, ay = vy < 0 ? -vy : vy;
+        const int sum = ax + ay;
+        const int gv = ed_div4_half_even(sum > grad_threshold + 1 ? sum : 0);
+        g[o] = (uint16_t)(gv | (ax < ay ? kHorizontal : 0));
+    }
+}
+
+void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* taps5, int grad_threshold, uint8_t* blur,
+                    uint32_t* dxy, uint16_t* g, hipStream_t s)
+{
+    dim3 grid((W + ET_W - 1) / ET_W, (H + ET_H - 1) / ET_H, n_frames);
+    hipLaunchKernelGGL(k_ed_grad, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold,
+                       blur, dxy, g);
+}
+
+// cv::resize(src, dst, Size(), inv, inv), INTER_LINEAR, u8: 11-bit coefficients from float weights
+__global__ void k_ed_resize(int H, int W, int DH, int DW, double scale, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= DW) return;
+    const uint8_t* S = src + (size_t)blockIdx.z * H * W;
+    float fx = (float)(((double)dx + 0.5) * scale - 0.5);
+    int sx = dm::ifloor((double)fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0.f; sx = 0; }
+    if (sx >= W - 1) { fx = 0.f; sx = W - 1; }
+    const int a0 = dm::round_half_even((double)((1.f - fx) * 2048.f)), a1 = dm::round_half_even((double)(fx * 2048.f));
+    float fy = (float)(((double)dy + 0.5) * scale - 0.5);
+    const int sy = dm::ifloor((double)fy);
+    fy -= (float)sy;
+    const int b0 = dm::round_half_even((double)((1.f - fy) * 2048.f)), b1 = dm::round_half_even((double)(fy * 2048.f));
+    int y0 = sy, y1 = sy + 1;
+    y0 = y0 >= 0 ? (y0 < H ? y0 : H - 1) : 0;
+    y1 = y1 >= 0 ? (y1 < H ? y1 : H - 1) : 0;
+    const int sx1 = sx + 1 < W ? sx + 1 : sx;
+    const int S0 = (int)S[(size_t)y0 * W + sx] * a0 + (int)S[(size_t)y0 * W + sx1] * a1;
+    const int S1 = (int)S[(size_t)y1 * W + sx] * a0 + (int)S[(size_t)y1 * W + sx1] * a1;
+    int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dst[((size_t)blockIdx.z * DH + dy) * DW + dx] = (uint8_t)v;
+}
+
+void launch_ed_resize(int H, int W, int DH, int DW, double scale, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    dim3 grid((DW + 255) / 256, DH, n_frames);
+    hipLaunchKernelGGL(k_ed_resize, grid, dim3(256), 0, s, H, W, DH, DW, scale, src, dst);
+}
+
+// cv::pyrDown u8 -> (H/2, W/2): [1 4 6 4 1]^2, (sum + 128) >> 8, BORDER_REFLECT_101 (compute-only pyramid, :350-371)
+__global__ void k_pyrdown(int H, int W, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+{
+    const int DW = W / 2, DH = H / 2;
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= DW) return;
+    const uint8_t* S = src + (size_t)blockIdx.z * H * W;
+    const int k[5] = { 1, 4, 6, 4, 1 };
+    int s = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+        const uint8_t* row = S + (size_t)ed_reflect101(2 * dy + j, H) * W;
+        int r = 0;
+#pragma unroll
+        for (int i = -2; i <= 2; ++i) r += k[i + 2] * (int)row[ed_reflect101(2 * dx + i, W)];
+        s += k[j + 2] * r;
+    }
+    dst[((size_t)blockIdx.z * DH + dy) * DW + dx] = (uint8_t)((s + 128) >> 8);
+}
+
+void launch_pyrdown(int H, int W, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    dim3 grid((W / 2 + 255) / 256, H / 2, n_frames);
+    if (W / 2 > 0 && H / 2 > 0) hipLaunchKernelGGL(k_pyrdown, grid, dim3(256), 0, s, H, W, src, dst);
+}
+
+// ------------------------------------------------------------------------------------------------ k_ed_detect
+enum { UpDir = 1, RightDir = 2, DownDir = 3, LeftDir = 4 };
+
+struct EdWalk {
+    const uint16_t* g; uint32_t* marks;
+    int W, H;
+    unsigned lastX, lastY;
+};
+
+__device__ __forceinline__ bool ed_marked(const uint32_t* m, int i) { return (m[i >> 5] >> (i & 31)) & 1u; }
+
+// one walk of the smart routing (:1577-1720 and its three copies), executed uniformly by the wave; pixels go to out[]
+// from *off on (packed x | y << 16).  Returns false when the part array would overflow.
+__device__ bool ed_walk(EdWalk& c, unsigned x, unsigned y, int lastDirection, uint32_t* __restrict__ out, unsigned base, unsigned& off,
+                        unsigned cap)
+{
+    const int W = c.W, H = c.H;
+    const uint16_t* pg = c.g;
+    int i = (int)(y * W + x);
+    uint32_t gv = pg[i];
+    while ((gv & 0x7fffu) > 0 && !ed_marked(c.marks, i)) {
+        c.marks[i >> 5] |= 1u << (i & 31);
+        if (off >= cap) return false;
+        out[base + off] = x | (y << 16);
+        ++off;
+        int should = 0, go = 0;
+        if (gv & kHorizontal) {
+            if (lastDirection == UpDir || lastDirection == DownDir) should = x > c.lastX ? RightDir : LeftDir;
+            c.lastX = x; c.lastY = y;
+            if (lastDirection == RightDir || should == RightDir) go = RightDir;
+            else if (lastDirection == LeftDir || should == LeftDir) go = LeftDir;
+        } else {
+            if (lastDirection == RightDir || lastDirection == LeftDir) should = y > c.lastY ? DownDir : UpDir;
+            c.lastX = x; c.lastY = y;
+            if (lastDirection == DownDir || should == DownDir) go = DownDir;
+            else if (lastDirection == UpDir || should == UpDir) go = UpDir;
+        }
+        // the three pixels ahead: i1 / i3 diagonal, i2 straight; gradient values compared as (unsigned char) (:1607-1609)
+        int i1, i2, i3;
+        if (go == RightDir) {
+            if (x == (unsigned)W - 1 || y == 0 || y == (unsigned)H - 1) break;
+            i1 = i - W + 1; i2 = i + 1; i3 = i + W + 1;
+        } else if (go == LeftDir) {
+            if (x == 0 || y == 0 || y == (unsigned)H - 1) break;
+            i1 = i - W - 1; i2 = i - 1; i3 = i + W - 1;
+        } else if (go == DownDir) {
+            if (x == 0 || x == (unsigned)W - 1 || y == (unsigned)H - 1) break;
+            i1 = i + W + 1; i2 = i + W; i3 = i + W - 1;
+        } else if (go == UpDir) {
+            if (x == 0 || x == (unsigned)W - 1 || y == 0) break;
+            i1 = i - W + 1; i2 = i - W; i3 = i - W - 1;
+        } else break;                                  // (cannot happen: one of the four always applies)
+        const uint32_t v1 = pg[i1], v2 = pg[i2], v3 = pg[i3];
+        const unsigned g1 = v1 & 0xffu, g2 = v2 & 0xffu, g3 = v3 & 0xffu;
+        if (g1 >= g2 && g1 >= g3) { i = i1; gv = v1; }
+        else if (g3 >= g2 && g3 >= g1) { i = i3; gv = v3; }
+        else { i = i2; gv = v2; }
+        y = (unsigned)i / (unsigned)W;
+        x = (unsigned)i - y * (unsigned)W;
+        lastDirection = go;
+    }
+    return true;
+}
+
+// ---- NFA (descriptor_custom.hpp:630-813), lane-uniform
+__device__ __noinline__ double ed_log_gamma(double x)
+{
+    if (x > 15.0)
+        return 0.918938533204673 + (x - 0.5) * dm::dlog(x) - x + 0.5 * x * dm::dlog(x * dm::dsinh_small(1 / x) + 1 / (810.0 * dm::dpow(x, 6.0)));
+    const double q[7] = { 75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511 };
+    double a = (x + 0.5) * dm::dlog(x + 5.5) - (x + 5.5);
+    double b = 0.0;
+    for (int n = 0; n < 7; n++) {
+        a -= dm::dlog(x + (double)n);
+        b += q[n] * dm::dpow(x, (double)n);
+    }
+    return a + dm::dlog(b);
+}
+
+__device__ __forceinline__ bool ed_double_equal(double a, double b)
+{
+    if (a == b) return true;
+    const double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b);
+    double abs_max = aa > bb ? aa : bb;
+    if (abs_max < 2.2250738585072014e-308) abs_max = 2.2250738585072014e-308;
+    return (abs_diff / abs_max) <= (100.0 * 2.2204460492503131e-16);
+}
+
+__device__ __noinline__ double ed_nfa(int n, int k, double p, double logNT)
+{
+    const double tolerance = 0.1;
+    if (n == 0 || k == 0) return -logNT;
+    if (n == k) return -logNT - (double)n * dm::dlog10(p);
+    const double p_term = p / (1.0 - p);
+    const double log1term = ed_log_gamma((double)n + 1.0) - ed_log_gamma((double)k + 1.0) - ed_log_gamma((double)(n - k) + 1.0)
+                          + (double)k * dm::dlog(p) + (double)(n - k) * dm::dlog(1.0 - p);
+    double term = dm::dexp(log1term);
+    if (ed_double_equal(term, 0.0)) {
+        if ((double)k > (double)n * p) return -log1term / 2.30258509299404568402 - logNT;
+        return -logNT;
+    }
+    double bin_tail = term;
+    for (int i = k + 1; i <= n; i++) {
+        const double bin_term = (double)(n - i + 1) / (double)i;
+        const double mult_term = bin_term * p_term;
+        term *= mult_term;
+        bin_tail += term;
+        if (bin_term < 1.0) {
+            const double err = term * ((1.0 - dm::dpow(mult_term, (double)(n - i + 1))) / (1.0 - mult_term) - 1.0);
+            if (err < tolerance * fabs(-dm::dlog10(bin_tail) - logNT) * bin_tail) break;
+        }
+    }
+    return -dm::dlog10(bin_tail) - logNT;
+}
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+struct EdFit { float ATA[4], ATV[2]; };
+
+// [sum a^2, sum a; sum a, n], [sum a b, sum b] over chain[s, s + n): exact integer sums, rounded once to float
+__device__ __forceinline__ void ed_sums(const uint32_t* __restrict__ chain, unsigned s, int n, bool horizontal, int lane, float* m4, float* v2)
+{
+    long long saa = 0, sa = 0, sab = 0, sb = 0;
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t p = chain[s + i];
+        const long long X = p & 0xffffu, Y = p >> 16;
+        const long long A = horizontal ? X : Y, B = horizontal ? Y : X;
+        saa += A * A; sa += A; sab += A * B; sb += B;
+    }
+    saa = wave_sum_ll(saa); sa = wave_sum_ll(sa); sab = wave_sum_ll(sab); sb = wave_sum_ll(sb);
+    m4[0] = (float)saa; m4[1] = (float)sa; m4[2] = (float)sa; m4[3] = (float)n;
+    v2[0] = (float)sab; v2[1] = (float)sb;
+}
+
+__device__ __forceinline__ void ed_solve(const EdFit& f, double& e0, double& e1)
+{
+    const float* A = f.ATA;
+    const double coef = 1.0 / ((double)A[0] * (double)A[3] - (double)A[1] * (double)A[2]);
+    e0 = coef * ((double)A[3] * (double)f.ATV[0] - (double)A[1] * (double)f.ATV[1]);
+    e1 = coef * ((double)A[0] * (double)f.ATV[1] - (double)A[2] * (double)f.ATV[0]);
+}
+
+__global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, int n_octaves)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ int s_wave_count[4];
+    __shared__ int s_base;
+    const int oc = blockIdx.y, f = blockIdx.x;
+    const EdOct& o = all.o[oc];
+    const int W = o.W, H = o.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t P = (size_t)W * H;
+    const uint16_t* g = o.g + (size_t)f * P;
+    const int scan = fp.scan;
+    const int nW = W > 2 ? (W - 2 + scan - 1) / scan : 0, nH = H > 2 ? (H - 2 + scan - 1) / scan : 0;
+    const int n_cand = nW * nH, n_cwords = (n_cand + 31) / 32;
+    const int n_mwords = (int)((P + 31) / 32);
+    uint32_t* flags = lds;                                   // candidate bits, column-major
+    uint32_t* marks = o.marks_in_lds ? lds + n_cwords : o.gmarks + (size_t)f * n_mwords;
+    int* cnt = o.counts + 4 * (size_t)f;
+    for (int i = tid; i < n_cwords; i += 256) flags[i] = 0u;
+    for (int i = tid; i < n_mwords; i += 256) marks[i] = 0u;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    // ---- anchors (:1504-1532): tested row-major, recorded column-major
+    for (int i = tid; i < n_cand; i += 256) {
+        const int ch = i / nW, cw = i - ch * nW;
+        const int w = 1 + scan * cw, h = 1 + scan * ch;
+        const int idx = h * W + w;
+        const uint32_t v = g[idx];
+        const int gv = (int)(v & 0x7fffu);
+        bool ok;
+        if (v & kHorizontal) ok = gv >= (int)(g[idx - W] & 0x7fffu) + fp.anchor_threshold && gv >= (int)(g[idx + W] & 0x7fffu) + fp.anchor_threshold;
+        else ok = gv >= (int)(g[idx - 1] & 0x7fffu) + fp.anchor_threshold && gv >= (int)(g[idx + 1] & 0x7fffu) + fp.anchor_threshold;
+        if (ok) { const int b = cw * nH + ch; atomicOr(&flags[b >> 5], 1u << (b & 31)); }
+    }
+    __syncthreads();
+    uint32_t* anchors = o.anchors + (size_t)f * o.cap;
+    for (int start = 0; start < n_cwords; start += 256) {
+        const int wi = start + tid;
+        const uint32_t word = wi < n_cwords ? flags[wi] : 0u;
+        const int c = __popc(word);
+        int incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (lane == 63) s_wave_count[wave] = incl;
+        __syncthreads();
+        int off = s_base;
+        for (int w2 = 0; w2 < wave; ++w2) off += s_wave_count[w2];
+        off += incl - c;
+        uint32_t bits = word;
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            const int bi = wi * 32 + b;
+            const int cw = bi / nH, ch = bi - cw * nH;
+            if (off < o.cap) anchors[off] = (uint32_t)(1 + scan * cw) | ((uint32_t)(1 + scan * ch) << 16);
+            ++off;
+        }
+        __syncthreads();
+        if (tid == 255) s_base = off;
+        __syncthreads();
+    }
+    const int n_anchors = s_base;
+    if (wave != 0) return;
+    // ================= one wave from here on =================
+    if (n_anchors > o.cap) {                                  // the reference returns -1 ("anchor size is larger than its maximal size")
+        if (lane == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = 1; }
+        return;
+    }
+    uint32_t* part = o.part + (size_t)f * o.cap;
+    uint32_t* chain = o.chain + (size_t)f * 2 * o.cap;
+    uint32_t* sid = o.sid + (size_t)f * (o.max_edges + 2);
+    EdWalk wk; wk.g = g; wk.marks = marks; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0;
+    const unsigned cap = (unsigned)o.cap;
+    unsigned offF = 0, offS = 0, ps = 0, cpos = 0;            // kept first / second part pixels, edges, chain pixels
+    bool fail = false;
+    for (int a = 0; a < n_anchors; ++a) {
+        const uint32_t an = anchors[a];
+        const unsigned x = an & 0xffffu, y = an >> 16;
+        const int i = (int)(y * W + x);
+        if (ed_marked(marks, i)) continue;
+        if (ps > (unsigned)o.max_edges) { fail = true; break; }
+        const bool horizontal = (g[i] & kHorizontal) != 0;
+        unsigned nF = offF;
+        if (!ed_walk(wk, x, y, horizontal ? RightDir : DownDir, part, 0u - offF, nF, cap)) { fail = true; break; }
+        const unsigned lenF = nF - offF;
+        marks[i >> 5] &= ~(1u << (i & 31));                    // the anchor starts the second part as well
+        // second part straight into the chain, behind the (still to be reversed) first part: entry t of the second
+        // part lands at cpos + lenF + t - 1, i.e. its entry 0 (the anchor again) on top of the first part's last slot,
+        // which the reversal below overwrites with the anchor anyway
+        unsigned nS = offS;
+        if (!ed_walk(wk, x, y, horizontal ? LeftDir : UpDir, chain, cpos + lenF - 1u - offS, nS, cap)) { fail = true; break; }
+        const unsigned lenS = nS - offS;
+        if ((int)(lenF + lenS) < fp.min_line_len + 1) continue;               // short chain: dropped, its marks stay
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (unsigned t = lane; t < lenF; t += 64) chain[cpos + t] = part[lenF - 1 - t];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        sid[ps] = cpos;
+        cpos += lenF + lenS - 1;
+        offF = nF; offS = nS;
+        ++ps;
+    }
+    if (!fail && ps > (unsigned)o.max_edges) fail = true;
+    if (fail) {
+        if (lane == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = 2; }
+        return;
+    }
+    sid[ps] = cpos;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- EDline (:2242-2482): chain by chain on this wave
+    const uint32_t* dxy = o.dxy + (size_t)f * P;
+    const int n_edges = (int)ps;
+    const int minLen = fp.min_line_len;
+    const double thr = fp.fit_err;
+    const double logNT = 2.0 * (dm::dlog10((double)(unsigned)W) + dm::dlog10((double)(unsigned)H));
+    const unsigned limit = min(5u * (unsigned)n_edges, (unsigned)o.max_lines);
+    float* l_ep = o.l_ep + (size_t)f * o.max_lines * 4;
+    double* l_c = o.l_c + (size_t)f * o.max_lines;
+    float* l_dir = o.l_dir + (size_t)f * o.max_lines;
+    int* l_npx = o.l_npx + (size_t)f * o.max_lines;
+    float* l_sal = o.l_sal + (size_t)f * o.max_lines;
+    unsigned numOfLines = 0;
+    EdFit fit;
+    for (int k = 0; k < 4; ++k) fit.ATA[k] = 0.f;
+    fit.ATV[0] = fit.ATV[1] = 0.f;
+    double lineFitErr = 0, e0 = 0, e1 = 0;
+    int status = 0;
+    for (int edgeID = 0; edgeID < n_edges && status == 0; ++edgeID) {
+        unsigned S = sid[edgeID];
+        const unsigned E = sid[edgeID + 1];
+        while (E > S + (unsigned)minLen) {
+            // an initial segment of minLen pixels that fits
+            while (E > S + (unsigned)minLen) {
+                const uint32_t p0 = chain[S];
+                const bool hz = (g[(p0 >> 16) * W + (p0 & 0xffffu)] & kHorizontal) != 0;
+                ed_sums(chain, S, minLen, hz, lane, fit.ATA, fit.ATV);
+                ed_solve(fit, e0, e1);
+                // ordered sum of the squared residuals (:2519-2525)
+                double c2 = 0;
+                if (lane < minLen) {
+                    const uint32_t p = chain[S + lane];
+                    const double X = (double)(p & 0xffffu), Y = (double)(p >> 16);
+                    const double c = hz ? (Y - X * e0 - e1) : (X - Y * e0 - e1);
+                    c2 = c * c;
+                }
+                double err = 0;
+                for (int i = 0; i < minLen; ++i) err += __shfl(c2, i);
+                lineFitErr = dm::dsqrt(err);
+                if (lineFitErr <= thr) break;
+                S += 2;
+            }
+            if (lineFitErr > thr) break;
+            if (numOfLines >= limit) { status = 3; break; }
+            const unsigned lstart = S;
+            const uint32_t pl = chain[S];
+            const bool horizontal = (g[(pl >> 16) * W + (pl & 0xffffu)] & kHorizontal) != 0;
+            double coef1 = 0;
+            bool bExtended = true, bFirstTry = true;
+            int numOfOutlier, tryTimes = 0;
+            unsigned newS = 0;
+            while (bExtended) {
+                tryTimes++;
+                if (bFirstTry) { bFirstTry = false; S += (unsigned)minLen; }
+                else {
+                    float m[4], v[2];
+                    ed_sums(chain, newS, (int)(S - newS), horizontal, lane, m, v);
+                    for (int k = 0; k < 4; ++k) fit.ATA[k] = fit.ATA[k] + m[k];
+                    for (int k = 0; k < 2; ++k) fit.ATV[k] = fit.ATV[k] + v[k];
+                    ed_solve(fit, e0, e1);
+                }
+                coef1 = horizontal ? 1 / dm::dsqrt(e0 * e0 + 1) : 1 / dm::dsqrt(1 + e0 * e0);
+                numOfOutlier = 0;
+                newS = S;
+                // extend while fewer than four consecutive pixels are farther than the threshold: 64 pixels per step
+                while (E > S) {
+                    const unsigned rem = E - S;
+                    const int nv = rem < 64u ? (int)rem : 64;
+                    bool outl = false;
+                    if (lane < nv) {
+                        const uint32_t p = chain[S + lane];
+                        const double X = (double)(p & 0xffffu), Y = (double)(p >> 16);
+                        const double dis = horizontal ? fabs(e0 * X - Y + e1) * coef1 : fabs(X - e0 * Y - e1) * coef1;
+                        outl = dis > thr;
+                    }
+                    const unsigned long long O = __ballot(outl);
+                    int stop = -1;
+                    const int lead = O == ~0ull ? 64 : __ffsll((long long)~O) - 1;      // outliers at the start of the chunk
+                    if (numOfOutlier > 0 && numOfOutlier + lead >= 4) stop = 3 - numOfOutlier;
+                    else {
+                        const unsigned long long Q = O & (O >> 1) & (O >> 2) & (O >> 3);
+                        if (Q) stop = __ffsll((long long)Q) - 1 + 3;
+                    }
+                    if (stop >= 0) { S += (unsigned)stop + 1u; numOfOutlier = 4; break; }
+                    // the run of outliers the chunk ends with carries into the next
+                    const unsigned long long valid = nv == 64 ? ~0ull : ((1ull << nv) - 1ull);
+                    if ((O & valid) == valid) numOfOutlier += nv;
+                    else {
+                        const unsigned long long inv = ~O & valid;              // highest non-outlier position
+                        numOfOutlier = nv - 1 - (63 - __clzll((long long)inv));
+                    }
+                    S += (unsigned)nv;
+                }
+                S -= (unsigned)numOfOutlier;
+                if (!(S > newS && tryTimes < 6)) bExtended = false;
+            }
+            double q0, q1, q2;
+            if (horizontal) { q0 = e0 * coef1; q1 = -1 * coef1; q2 = e1 * coef1; }
+            else { q0 = 1 * coef1; q1 = -e0 * coef1; q2 = -e1 * coef1; }
+            // ---- LineValidation_ (:2645-2726)
+            const int n = (int)(S - lstart);
+            int mgx = 0, mgy = 0;
+            for (int i = lane; i < n; i += 64) {
+                const uint32_t p = chain[lstart + i];
+                const uint32_t d = dxy[(p >> 16) * W + (p & 0xffffu)];
+                mgx += (int)(int16_t)(d & 0xffffu);
+                mgy += (int)d >> 16;
+            }
+            mgx = wave_sum_i(mgx); mgy = wave_sum_i(mgy);
+            const double adx = fabs(q1), ady = fabs(q0);
+            float direction = 0.f;
+            bool ok = !(mgx == 0 && mgy == 0);
+            if (ok) {
+                if (mgx > 0 && mgy >= 0) direction = (float)dm::datan2(-ady, adx);
+                if (mgx <= 0 && mgy > 0) direction = (float)dm::datan2(ady, adx);
+                if (mgx < 0 && mgy <= 0) direction = (float)dm::datan2(ady, -adx);
+                if (mgx >= 0 && mgy < 0) direction = (float)dm::datan2(-ady, -adx);
+                const double PI = 3.14159265358979323846;
+                if (fabs((double)direction) < 0.15 || PI - fabs((double)direction) < 0.15)
+                    if (fabs(q2) < 10 || fabs((double)(unsigned)H - fabs(q2)) < 10) ok = false;
+                if (ok && fabs(fabs((double)direction) - PI * 0.5) < 0.15)
+                    if (fabs(q2) < 10 || fabs((double)(unsigned)W - fabs(q2)) < 10) ok = false;
+                if (ok) {
+                    int kk = 0;
+                    for (int i = lane; i < n; i += 64) {
+                        const uint32_t p = chain[lstart + i];
+                        const uint32_t d = dxy[(p >> 16) * W + (p & 0xffffu)];
+                        const double pd = dm::datan2(-(double)(int)(int16_t)(d & 0xffffu), (double)((int)d >> 16));
+                        const double dis = fabs((double)direction - pd);
+                        if (fabs(2 * PI - dis) < 0.392699 || dis < 0.392699) kk++;
+                    }
+                    kk = wave_sum_i(kk);
+                    ok = ed_nfa(n, kk, 0.125, logNT) > 0;
+                }
+            }
+            if (ok) {
+                const double a1 = q1 * q1, a2 = q0 * q0, a3 = q0 * q1, a4 = q2 * q0, a5 = q2 * q1;
+                const uint32_t pa = chain[lstart], pb = chain[S - 1];
+                // salience (:2728-2751): the CV_16S plane sumDxDy / 4 read through an unsigned char pointer with a PIXEL
+                // index -- byte (i & 1) of element i >> 1
+                int sal = 0;
+                for (int i = lane; i < n; i += 64) {
+                    const uint32_t p = chain[lstart + i];
+                    const unsigned bi = (p >> 16) * (unsigned)W + (p & 0xffffu);
+                    const uint32_t d = dxy[bi >> 1];
+                    const int vx = (int)(int16_t)(d & 0xffffu), vy = (int)d >> 16;
+                    const int gwo = ed_div4_half_even((vx < 0 ? -vx : vx) + (vy < 0 ? -vy : vy));
+                    sal += (bi & 1u) ? ((gwo >> 8) & 0xff) : (gwo & 0xff);
+                }
+                sal = wave_sum_i(sal);
+                if (lane == 0) {
+                    const unsigned Px = pa & 0xffffu, Py = pa >> 16, Qx = pb & 0xffffu, Qy = pb >> 16;
+                    float* ep = l_ep + 4 * (size_t)numOfLines;
+                    ep[0] = (float)(a1 * Px - a3 * Py - a4);
+                    ep[1] = (float)(a2 * Py - a3 * Px - a5);
+                    ep[2] = (float)(a1 * Qx - a3 * Qy - a4);
+                    ep[3] = (float)(a2 * Qy - a3 * Qx - a5);
+                    l_c[numOfLines] = q2;
+                    l_dir[numOfLines] = direction;
+                    l_npx[numOfLines] = n;
+                    l_sal[numOfLines] = (float)sal;
+                }
+                numOfLines++;
+            }
+        }
+    }
+    if (lane == 0) {
+        cnt[0] = n_anchors;
+        cnt[1] = status ? -1 : n_edges;
+        cnt[2] = status ? 0 : (int)numOfLines;
+        cnt[3] = status;
+    }
+}
+
+size_t ed_detect_lds_bytes(int W, int H, int scan, bool* marks_in_lds)
+{
+    const int nW = W > 2 ? (W - 2 + scan - 1) / scan : 0, nH = H > 2 ? (H - 2 + scan - 1) / scan : 0;
+    const size_t cw = ((size_t)nW * nH + 31) / 32, mw = ((size_t)W * H + 31) / 32;
+    const bool fits = (cw + mw) * 4 <= 150 * 1024;
+    if (marks_in_lds) *marks_in_lds = fits;
+    return (fits ? cw + mw : cw) * 4;
+}
+
+int launch_ed_detect(const EdAll& all, const EdFitParams& fp, int n_octaves, int n_frames, size_t lds_bytes, hipStream_t s)
+{
+    if (lds_bytes > 48 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ed_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_ed_detect, dim3(n_frames, n_octaves), dim3(256), lds_bytes, s, all, fp, n_octaves);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ k_kl_assemble
+// OctaveKeyLines' second half (:726-1022) + detectImpl (:478-509).  One workgroup per frame; lines of all octaves
+// indexed 0 .. n-1 in octave order (= octaveLines).  LDS: per line octave / id-in-octave / class / length.
+constexpr int kKlMaxLines = 4096;           // lines of one frame over all octaves that the grouping can hold in LDS
+
+__global__ __launch_bounds__(256) void k_kl_count(EdAll all, int n_octaves, int n_frames, int* __restrict__ frame_count, int* __restrict__ status)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    int total = 0, st = 0;
+    for (int oc = 0; oc < n_octaves; ++oc) {
+        const int* c = all.o[oc].counts + 4 * (size_t)f;
+        if (c[1] < 0) st = c[3] ? c[3] : 2;
+        total += c[2];
+    }
+    if (total > kKlMaxLines) st = 4;
+    frame_count[f] = st ? 0 : total;          // a failing detector yields no KeyLines for its frame (:465-468, return value ignored)
+    status[f] = st;
+}
+
+__global__ __launch_bounds__(256) void k_kl_assemble(EdAll all, int n_octaves, const int* __restrict__ frame_offset, int capacity, KlOut out)
+{
+    __shared__ float s_len[kKlMaxLines];
+    __shared__ uint16_t s_oct[kKlMaxLines], s_lid[kKlMaxLines], s_cls[kKlMaxLines];
+    __shared__ int s_ostart[LF_MAX_OCTAVES + 1];
+    __shared__ int s_wave[4], s_next_class;
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = frame_offset[f], n = frame_offset[f + 1] - base;
+    if (n <= 0 || base + n > capacity) return;
+    if (tid == 0) {
+        int acc = 0;
+        for (int oc = 0; oc < n_octaves; ++oc) { s_ostart[oc] = acc; acc += all.o[oc].counts[4 * (size_t)f + 2]; }
+        s_ostart[n_octaves] = acc;
+        s_next_class = 0;
+    }
+    __syncthreads();
+    float scale[LF_MAX_OCTAVES];
+    scale[0] = 1.f;
+    {
+        const double factor = dm::dsqrt(2.0);
+        for (int oc = 1; oc < LF_MAX_OCTAVES; ++oc) scale[oc] = (float)(factor * scale[oc - 1]);
+    }
+    const double twoPI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
+    for (int oc = 0; oc < n_octaves; ++oc) {
+        const EdOct& o = all.o[oc];
+        const int o0 = s_ostart[oc], on = s_ostart[oc + 1] - o0;
+        const float* ep_o = o.l_ep + (size_t)f * o.max_lines * 4;
+        const double* c_o = o.l_c + (size_t)f * o.max_lines;
+        const float* dir_o = o.l_dir + (size_t)f * o.max_lines;
+        const int cls0 = s_next_class;
+        __syncthreads();
+        for (int start = 0; start < on; start += 256) {
+            const int l = start + tid;
+            bool fresh = false;
+            int cls = 0;
+            float length = 0.f;
+            if (l < on) {
+                const float* ep = ep_o + 4 * (size_t)l;
+                float dx = (float)fabs((double)(ep[0] - ep[2])), dy = (float)fabs((double)(ep[1] - ep[3]));
+                if (oc == 0) {
+                    length = dm::fsqrt(dx * dx + dy * dy);
+                    fresh = true;
+                } else {
+                    const float rho1 = (float)(scale[oc] * fabs(c_o[l]));
+                    const float tempValue = (float)(rho1 * 0.0152);
+                    float diffNearThreshold = (tempValue > 6) ? tempValue : 6;
+                    diffNearThreshold = (diffNearThreshold < 12) ? diffNearThreshold : 12;
+                    length = scale[oc] * dm::fsqrt(dx * dx + dy * dy);
+                    float minEndPointDis = 12;
+                    int closeLineID = 0;
+                    const float lp0 = scale[oc] * ep[0], lp1 = scale[oc] * ep[1], lp2 = scale[oc] * ep[2], lp3 = scale[oc] * ep[3];
+                    for (int nx = 0; nx < o0; ++nx) {
+                        const int oid = s_oct[nx], lid = s_lid[nx];
+                        const EdOct& q = all.o[oid];
+                        const float direction = (float)fabs((double)(dir_o[l] - q.l_dir[(size_t)f * q.max_lines + lid]));
+                        if (direction > 0.1745 && (twoPI - direction > 0.1745)) continue;
+                        const float rho2 = (float)(scale[oid] * fabs(q.l_c[(size_t)f * q.max_lines + lid]));
+                        const float diffNear = (float)fabs((double)(rho1 - rho2));
+                        if (diffNear > diffNearThreshold) continue;
+                        const float* np_ = q.l_ep + ((size_t)f * q.max_lines + lid) * 4;
+                        const float np0 = scale[oid] * np_[0], np1 = scale[oid] * np_[1], np2 = scale[oid] * np_[2], np3 = scale[oid] * np_[3];
+                        float endPointDis, minLocalDis, maxLocalDis;
+                        dx = lp0 - np0; dy = lp1 - np1;
+                        endPointDis = dm::fsqrt(dx * dx + dy * dy);
+                        minLocalDis = endPointDis; maxLocalDis = endPointDis;
+                        dx = lp2 - np2; dy = lp3 - np3;
+                        endPointDis = dm::fsqrt(dx * dx + dy * dy);
+                        minLocalDis = (endPointDis < minLocalDis) ? endPointDis : minLocalDis;
+                        maxLocalDis = (endPointDis > maxLocalDis) ? endPointDis : maxLocalDis;
+                        dx = lp0 - np2; dy = lp1 - np3;
+                        endPointDis = dm::fsqrt(dx * dx + dy * dy);
+                        minLocalDis = (endPointDis < minLocalDis) ? endPointDis : minLocalDis;
+                        maxLocalDis = (endPointDis > maxLocalDis) ? endPointDis : maxLocalDis;
+                        dx = lp2 - np0; dy = lp3 - np1;
+                        endPointDis = dm::fsqrt(dx * dx + dy * dy);
+                        minLocalDis = (endPointDis < minLocalDis) ? endPointDis : minLocalDis;
+                        maxLocalDis = (endPointDis > maxLocalDis) ? endPointDis : maxLocalDis;
+                        if (((double)maxLocalDis < 0.8 * (double)(length + s_len[nx])) && (minLocalDis < minEndPointDis)) {
+                            minEndPointDis = minLocalDis;
+                            closeLineID = nx;
+                        }
+                    }
+                    if (minEndPointDis < 12) cls = s_cls[closeLineID];
+                    else fresh = true;
+                }
+            }
+            // new class ids in line order: exclusive count of the fresh lines before this one
+            const unsigned long long bal = __ballot(fresh);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_wave[wave] = __popcll(bal);
+            __syncthreads();
+            int off = s_next_class;
+            for (int w2 = 0; w2 < wave; ++w2) off += s_wave[w2];
+            if (l < on) {
+                if (fresh) cls = off + before;
+                s_oct[o0 + l] = (uint16_t)oc; s_lid[o0 + l] = (uint16_t)l; s_cls[o0 + l] = (uint16_t)cls; s_len[o0 + l] = length;
+            }
+            __syncthreads();
+            if (tid == 0) s_next_class += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+            __syncthreads();
+        }
+        (void)cls0;
+    }
+    __syncthreads();
+    // detectImpl's order: class id, then octaveLines order inside a class
+    for (int i = tid; i < n; i += 256) {
+        const int ci = s_cls[i];
+        int pos = 0;
+        for (int j = 0; j < n; ++j) { const int cj = s_cls[j]; pos += (cj < ci) || (cj == ci && j < i); }
+        const int oid = s_oct[i], lid = s_lid[i];
+        const EdOct& q = all.o[oid];
+        const size_t li = (size_t)f * q.max_lines + lid;
+        const float direction = q.l_dir[li];
+        const float* ep = q.l_ep + 4 * li;
+        const float s1 = ep[0], s2 = ep[1], e1 = ep[2], e2 = ep[3];
+        const float dx = e1 - s1, dy = e2 - s2;
+        bool shouldChange = false;
+        if (direction >= -0.75 * PI && direction < -0.25 * PI) { if (dy > 0) shouldChange = true; }
+        if (direction >= -0.25 * PI && direction < 0.25 * PI) { if (dx < 0) shouldChange = true; }
+        if (direction >= 0.25 * PI && direction < 0.75 * PI) { if (dy < 0) shouldChange = true; }
+        if ((direction >= 0.75 * PI && direction < PI) || (direction >= -PI && direction < -0.75 * PI)) { if (dx > 0) shouldChange = true; }
+        const float t = scale[oid];
+        const size_t k = (size_t)base + pos;
+        float io[4], st[4];
+        if (shouldChange) { io[0] = e1; io[1] = e2; io[2] = s1; io[3] = s2; }
+        else { io[0] = s1; io[1] = s2; io[2] = e1; io[3] = e2; }
+        for (int c = 0; c < 4; ++c) st[c] = t * io[c];
+        for (int c = 0; c < 4; ++c) { if (out.in_octave) out.in_octave[4 * k + c] = io[c]; if (out.start_end) out.start_end[4 * k + c] = st[c]; }
+        if (out.angle) out.angle[k] = direction;
+        if (out.num_pixels) out.num_pixels[k] = q.l_npx[li];
+        if (out.line_length) out.line_length[k] = s_len[i];
+        if (out.octave) out.octave[k] = oid;
+        if (out.class_id) out.class_id[k] = ci;
+        if (out.salience) out.salience[k] = q.l_sal[li];
+        if (out.size) out.size[k] = (st[2] - st[0]) * (st[3] - st[1]);
+        if (out.response) out.response[k] = s_len[i] / (float)(q.W > q.H ? q.W : q.H);
+        if (out.pt) { out.pt[2 * k] = (st[2] + st[0]) / 2; out.pt[2 * k + 1] = (st[3] + st[1]) / 2; }
+        if (out.frame) out.frame[k] = f;
+    }
+}
+
+void launch_kl_count(const EdAll& all, int n_octaves, int n_frames, int* frame_count, int* status, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kl_count, dim3((n_frames + 255) / 256), dim3(256), 0, s, all, n_octaves, n_frames, frame_count, status);
+}
+
+void launch_kl_assemble(const EdAll& all, int n_octaves, int n_frames, const int* frame_offset, int capacity, const KlOut& out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kl_assemble, dim3(n_frames), dim3(256), 0, s, all, n_octaves, frame_offset, capacity, out);
+}
+
+// exclusive scan of the per-frame counts -> frame_offset [n_frames + 1]; total and overflow flag into pinned[0..1]
+__global__ void k_kl_offsets(int n_frames, const int* __restrict__ frame_count, int capacity, int* __restrict__ frame_offset, int* __restrict__ totals)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int acc = 0;
+    for (int f = 0; f < n_frames; ++f) { frame_offset[f] = acc; acc += frame_count[f]; }
+    frame_offset[n_frames] = acc;
+    totals[0] = acc;
+    totals[1] = acc > capacity ? 1 : 0;
+}
+
+void launch_kl_offsets(int n_frames, const int* frame_count, int capacity, int* frame_offset, int* totals, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kl_offsets, dim3(1), dim3(64), 0, s, n_frames, frame_count, capacity, frame_offset, totals);
+}
+
+}  // namespace lf

@@ -159,11 +159,18 @@ __constant__ int c_comb[32][2] = {
 constexpr int NBANDS = 9, WBAND = 7, LSP_H = 63;
 constexpr int LBD_STEPS = 8;      // support-region columns fetched per round trip
 
-__global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restrict__ n_seg_ptr,
+// KL = false: segments of the LSD front end (KeyLine fields worked out here, LSDDetector_custom.cpp:73-102,169-197, one
+// octave).  KL = true: KeyLines of the EDLines / multi-octave path (k_edlines.hip, lf_describe_keylines): endpoints in the
+// octave image, direction and numOfPixels are given, and every line names its octave's gradient plane (computeLBD,
+// binary_descriptor_custom.cpp:1070-1100: edLineVec_[octave]->dxImg_ or dxImg_vector[octave]).
+template <bool KL>
+__global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restrict__ n_seg_ptr,
                                              const float* __restrict__ lines, const int* __restrict__ seg_frame,
                                              const uint32_t* __restrict__ dxyi,
                                              const float* __restrict__ gauss_g /*63*/, const float* __restrict__ gauss_l /*21*/,
-                                             float* __restrict__ desc, uint8_t* __restrict__ code)
+                                             float* __restrict__ desc, uint8_t* __restrict__ code,
+                                             LbdPlanes planes, const float* __restrict__ kl_angle, const int* __restrict__ kl_npx,
+                                             const int* __restrict__ kl_octave)
 {
     __shared__ float rows[4][LSP_H][4];      // per wave: row sums pgdL, ngdL, pgdO, ngdO (already * coefG)
     __shared__ float dsc[4][72];
@@ -174,9 +181,20 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int f = seg_frame[seg];
-    const uint32_t* pdxy = dxyi + (size_t)f * Hc * W;
-    // KeyLine fields (LSDDetector_custom.cpp:73-102,169-197), octave 0
+    int Hc = Hc_, W = W_;
+    const uint32_t* pdxy;
     float e0 = lines[4 * (size_t)seg], e1 = lines[4 * (size_t)seg + 1], e2 = lines[4 * (size_t)seg + 2], e3 = lines[4 * (size_t)seg + 3];
+    int lengthOfLSP;
+    float direction;
+    if (KL) {
+        const int oc = kl_octave[seg];
+        Hc = planes.H[oc]; W = planes.W[oc];
+        pdxy = planes.base[oc] + (size_t)f * Hc * W;
+        lengthOfLSP = (int)(short)kl_npx[seg];                  // `short lengthOfLSP` (:1106)
+        direction = kl_angle[seg];
+    } else {
+    pdxy = dxyi + (size_t)f * Hc * W;
+    // KeyLine fields (LSDDetector_custom.cpp:73-102,169-197), octave 0
     if (e0 < 0) e0 = 0;
     if (e0 >= W) e0 = (float)W - 1.0f;
     if (e2 < 0) e2 = 0;
@@ -187,9 +205,10 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc, int W, const int* __restric
     if (e3 >= Hc) e3 = (float)Hc - 1.0f;
     const int ix0 = dm::round_half_even((double)e0), iy0 = dm::round_half_even((double)e1);
     const int ix1 = dm::round_half_even((double)e2), iy1 = dm::round_half_even((double)e3);
-    const int lengthOfLSP = max(abs(ix1 - ix0), abs(iy1 - iy0)) + 1;
+    lengthOfLSP = max(abs(ix1 - ix0), abs(iy1 - iy0)) + 1;
     const float ddy = e3 - e1, ddx = e2 - e0;
-    const float direction = (float)dm::datan2((double)ddy, (double)ddx);
+    direction = (float)dm::datan2((double)ddy, (double)ddx);
+    }
     const int halfWidth = (lengthOfLSP - 1) / 2;
     const int halfHeight = (LSP_H - 1) / 2;
     const int imageWidth = W - 1, imageHeight = Hc - 1;
@@ -332,8 +351,21 @@ void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lin
     if (n_seg_cap <= 0) return;
     int blocks = (n_seg_cap + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_lbd, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
-                       gauss_g, gauss_l, desc, code);
+    LbdPlanes none;
+    for (int i = 0; i < LF_MAX_OCTAVES; ++i) { none.base[i] = nullptr; none.W[i] = 0; none.H[i] = 0; }
+    hipLaunchKernelGGL(k_lbd<false>, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
+                       gauss_g, gauss_l, desc, code, none, nullptr, nullptr, nullptr);
+}
+
+void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
+                         const int* octave, const int* frame, const float* gauss_g, const float* gauss_l, float* desc, uint8_t* code,
+                         hipStream_t s)
+{
+    if (n_cap <= 0) return;
+    int blocks = (n_cap + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_lbd<true>, dim3(blocks), dim3(256), 0, s, 0, 0, n_lines, in_octave4, frame, nullptr, gauss_g, gauss_l, desc, code,
+                       planes, angle, npx, octave);
 }
 
 // Debug only: the two s16 planes tests compare with the oracle's Sobel output.

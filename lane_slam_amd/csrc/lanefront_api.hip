@@ -111,6 +111,7 @@ struct lf_handle {
     int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
     JpegState* jpeg = nullptr;
+    struct KlState* kl = nullptr;       // EDLines / KeyLines state (lanefront_keylines.inc), allocated on first use
     DevBuf m_fo, m_color, m_pn, m_nm, m_gr, m_keep, m_counts, m_boff, m_body, m_bad;   // SegmentList glue scratch
     // profiling
     bool profiling = false;
@@ -440,6 +441,9 @@ extern "C" const char* lf_last_error(const lf_handle* h) { return h ? h->err : g
 
 extern "C" const char* lf_stage_name(int stage) { return (stage >= 0 && stage < LF_N_STAGES) ? kStageNames[stage] : "?"; }
 
+struct KlState;
+static void kl_free(KlState* k);
+
 extern "C" void lf_destroy(lf_handle* h)
 {
     if (!h) return;
@@ -464,6 +468,7 @@ extern "C" void lf_destroy(lf_handle* h)
         if (j->staged) (void)hipEventDestroy(j->staged);
         delete j;
     }
+    kl_free(h->kl);
     timing_resolve(h);
     for (EvPair& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1273,3 +1278,5 @@ extern "C" int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int 
     }
     return LF_OK;
 }
+
+#include "lanefront_keylines.inc"

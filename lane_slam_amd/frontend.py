@@ -214,6 +214,81 @@ class FrontEnd(object):
                                         _ptr(counts), ctypes.byref(inertia), ctypes.byref(n_iter)))
         return centers, counts, inertia.value, n_iter.value
 
+    # ------------------------------------------------------------------ EDLines / multi-octave KeyLines
+    def edlines_params(self, **kw):
+        """EDLineDetector's defaults (ref: binary_descriptor_custom.cpp:1374-1385), optionally overridden."""
+        p = _lib.LfEdlinesParams()
+        self.lib.lf_edlines_default_params(ctypes.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    def keylines_batch(self, images, n_octaves=1, describe=True, params=None, gray=False, capacity=None):
+        """BinaryDescriptor::operator() with drawn KeyLines (ref: binary_descriptor_custom.cpp:263-301): EDLines over
+        n_octaves octaves + LBD on the detector's gradients.  images: raw camera frames (n, in_rows, in_cols, 3) BGR, or
+        with gray=True working-size gray images (n, rows, cols) u8.  Returns a dict of per-KeyLine numpy arrays (KeyLine
+        fields, include/lanefront.h) + 'n', 'frame_offset' and 'frame_status'."""
+        images = np.ascontiguousarray(images, np.uint8)
+        want = (self.rows, self.cols) if gray else (self.in_rows, self.in_cols, 3)
+        if images.ndim == len(want):
+            images = images[None]
+        if images.shape[1:] != want:
+            raise ValueError("images must be (n,%s), got %r" % (",".join(map(str, want)), images.shape))
+        n = images.shape[0]
+        cap = int(capacity) if capacity else n * 2048
+        out = {"frame_offset": np.zeros(n + 1, np.int32)}
+        s = _lib.LfKeylines()
+        s.capacity = cap
+        s.frame_offset = out["frame_offset"].ctypes.data
+        for k, dt, c in _lib.KEYLINE_FIELDS:
+            if k in ("desc", "code") and not describe:
+                continue
+            out[k] = np.zeros((cap, c) if c > 1 else cap, np.dtype(dt))
+            setattr(s, k, out[k].ctypes.data)
+        total = ctypes.c_int()
+        status = np.zeros(n, np.int32)
+        self._check(self.lib.lf_keylines_batch(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves),
+                                               ctypes.byref(params) if params is not None else None, ctypes.byref(s), 0,
+                                               int(bool(describe)), ctypes.byref(total), _ptr(status)))
+        t = total.value
+        for k, _, _ in _lib.KEYLINE_FIELDS:
+            if k in out:
+                out[k] = out[k][:t]
+        out["n"] = t
+        out["frame_status"] = status
+        return out
+
+    def describe_keylines(self, gray, line_frame, in_octave, angle, num_pixels, octave):
+        """BinaryDescriptor::compute on GIVEN KeyLines (ref: binary_descriptor_custom.cpp:524-687; pyramid of
+        computeGaussianPyramid :350-371).  gray: (n_frames, rows, cols) u8.  Returns (desc [n, 72], code [n, 32])."""
+        gray = np.ascontiguousarray(gray, np.uint8)
+        if gray.ndim == 2:
+            gray = gray[None]
+        if gray.shape[1:] != (self.rows, self.cols):
+            raise ValueError("gray must be (n,%d,%d)" % (self.rows, self.cols))
+        fr = np.ascontiguousarray(line_frame, np.int32)
+        io = np.ascontiguousarray(in_octave, np.float32).reshape(-1, 4)
+        ang = np.ascontiguousarray(angle, np.float32)
+        npx = np.ascontiguousarray(num_pixels, np.int32)
+        octv = np.ascontiguousarray(octave, np.int32)
+        n = io.shape[0]
+        desc, code = np.zeros((n, 72), np.float32), np.zeros((n, 32), np.uint8)
+        self._check(self.lib.lf_describe_keylines(self.h, _ptr(gray), gray.shape[0], _ptr(fr), _ptr(io), _ptr(ang), _ptr(npx), _ptr(octv), n,
+                                                  _ptr(desc), _ptr(code), 0))
+        return desc, code
+
+    def keylines_fetch(self, octave, what, n_frames):
+        """Intermediate buffer `what` (include/lanefront.h, lf_keylines_debug_fetch) of the last keylines_batch."""
+        dims = np.zeros(5, np.int32)
+        self._check(self.lib.lf_keylines_debug_fetch(self.h, int(octave), int(what), None, 0, _ptr(dims)))
+        H, W, cap, max_edges, max_lines = (int(v) for v in dims)
+        shape, dt = {0: ((H, W), np.uint8), 1: ((H, W), np.uint32), 2: ((H, W), np.uint16), 3: ((cap,), np.uint32), 4: ((2 * cap,), np.uint32),
+                     5: ((max_edges + 2,), np.uint32), 6: ((4,), np.int32), 7: ((max_lines, 4), np.float32), 8: ((max_lines,), np.float64),
+                     9: ((max_lines,), np.float32), 10: ((max_lines,), np.int32), 11: ((max_lines,), np.float32), 12: ((H, W), np.uint8)}[what]
+        a = np.empty((n_frames,) + shape, dt)
+        self._check(self.lib.lf_keylines_debug_fetch(self.h, int(octave), int(what), _ptr(a), a.nbytes, None))
+        return a
+
     # ------------------------------------------------------------------ host ingest (JPEG)
     def decode_jpeg_batch(self, streams, rows=None, cols=None, n_threads=0, device_ptr=None):
         """Decode a list of JPEG byte strings (what CompressedImage.data carries) into BGR frames --

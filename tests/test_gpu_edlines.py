@@ -1,0 +1,169 @@
+"""GPU parity tests of the EDLines detector + multi-octave KeyLines / LBD (k_edlines.hip, lf_keylines_batch,
+lf_describe_keylines) against the oracle's restatement of binary_descriptor_custom.cpp:263-301,
+689-1024, 1374-2751 (oracle/lf_oracle_edlines.c): every stage bit for bit -- blurred octave images, gradient planes,
+anchors in scan order, edge chains, fitted lines, KeyLine fields and order, descriptors."""
+import os
+
+import numpy as np
+import pytest
+
+from lane_slam_amd import FrontEnd, LanefrontError, default_config, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+INV = float(np.float64(np.float32(1.0)) / np.sqrt(2.0))
+
+
+def _gray_frames(cfg, frames):
+    o = O.Oracle(cfg)
+    return np.stack([o.bgr2gray(o.preprocess(f)) for f in frames])
+
+
+def _octave_images(gray, n_octaves):
+    """(input, blurred) image of every octave as OctaveKeyLines builds them (:697-728)."""
+    out, img, pre, cur = [], gray, np.float32(0), np.float32(1)
+    for _ in range(n_octaves):
+        sigma = float(np.sqrt(np.float32(cur - pre), dtype=np.float32))
+        blur = O.gaussian_blur_u8(img, 5, sigma)
+        out.append((img, blur))
+        img = O.resize_linear_u8(blur, INV)
+        pre, cur = cur, np.float32(cur * 2)
+    return out
+
+
+def _check_stages(fe, gray, n_octaves, params=None):
+    """Intermediate buffers of the last keylines_batch against the oracle's, frame by frame and octave by octave."""
+    B = gray.shape[0]
+    op = O.edlines_params(**({} if params is None else {k: getattr(params, k) for k in ("gradient_threshold", "anchor_threshold", "scan_intervals", "min_line_len", "line_fit_err_threshold")}))
+    for oc in range(n_octaves):
+        bufs = {w: fe.keylines_fetch(oc, w, B) for w in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)}
+        src = fe.keylines_fetch(oc, 12, B) if oc else None
+        for f in range(B):
+            img, blur = _octave_images(gray[f], oc + 1)[oc]
+            if oc:
+                assert np.array_equal(src[f], img), (f, oc, "resized octave image")
+            assert np.array_equal(bufs[0][f], blur), (f, oc, "blur")
+            e = O.edlines(blur, op)
+            cnt = bufs[6][f]
+            if e is None:
+                assert cnt[1] == -1
+                continue
+            dxy = bufs[1][f]
+            assert np.array_equal((dxy & 0xffff).astype(np.uint16).view(np.int16), e["dx"]) and np.array_equal((dxy >> 16).astype(np.uint16).view(np.int16), e["dy"])
+            assert np.array_equal(bufs[2][f], (e["g"].astype(np.uint16) | np.where(e["dir"] == 255, 0x8000, 0).astype(np.uint16)))
+            assert cnt[0] == e["n_anchors"] and np.array_equal(bufs[3][f][:cnt[0]], e["ax"] | (e["ay"] << 16)), (f, oc, "anchors")
+            assert cnt[1] == e["n_edges"] and np.array_equal(bufs[5][f][:cnt[1] + 1], e["sid"]), (f, oc, "chains")
+            npx = int(e["sid"][-1])
+            assert np.array_equal(bufs[4][f][:npx], e["xcors"] | (e["ycors"] << 16)), (f, oc, "chain pixels")
+            n = e["n_lines"]
+            assert cnt[2] == n and cnt[3] == 0, (f, oc, cnt, n)
+            assert np.array_equal(bufs[7][f][:n], e["endpoints"]) and np.array_equal(bufs[8][f][:n], e["equations"][:, 2])
+            assert np.array_equal(bufs[9][f][:n], e["direction"]) and np.array_equal(bufs[10][f][:n], np.diff(e["lsid"]).astype(np.int32))
+            assert np.array_equal(bufs[11][f][:n], e["salience"])
+
+
+def _check_keylines(k, gray, n_octaves, params=None, describe=True):
+    op = None if params is None else O.edlines_params(**{f: getattr(params, f) for f in ("gradient_threshold", "anchor_threshold", "scan_intervals", "min_line_len", "line_fit_err_threshold")})
+    total = 0
+    for f in range(gray.shape[0]):
+        r = O.octave_keylines(gray[f], n_octaves, op)
+        a, b = int(k["frame_offset"][f]), int(k["frame_offset"][f + 1])
+        if r is None:
+            assert b == a and k["frame_status"][f] != 0
+            continue
+        assert b - a == r["n"] and k["frame_status"][f] == 0, (f, b - a, r["n"])
+        for name in ("start_end", "in_octave", "angle", "num_pixels", "line_length", "octave", "class_id", "response", "size", "pt", "salience"):
+            assert np.array_equal(k[name][a:b], r[name]), (f, name)
+        if describe:
+            assert np.array_equal(k["code"][a:b], r["code"]), f
+            assert np.array_equal(k["desc"][a:b], r["desc"]) and np.abs(k["desc"][a:b] - r["desc"]).max(initial=0) <= 1e-4     # north_star: 1e-4 fp32
+        total += r["n"]
+    assert k["n"] == total
+    return total
+
+
+@pytest.mark.parametrize("geometry,n_octaves", [("fullres", 3), ("parity", 2), ("fullres", 1), ("fullres", 5)])
+def test_keylines_on_lane_frames_match_oracle(geometry, n_octaves):
+    cfg = default_config(geometry)
+    B = 6 if n_octaves < 5 else 3
+    frames = synth.make_batch(B, seed0=900 + n_octaves)
+    gray = _gray_frames(cfg, frames)
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=256)
+    k = fe.keylines_batch(frames, n_octaves=n_octaves)
+    _check_stages(fe, gray, n_octaves)
+    n = _check_keylines(k, gray, n_octaves)
+    assert n > B * (2 if geometry == "parity" else 8)
+    # the gray-image entry point gives the same
+    k2 = fe.keylines_batch(gray, n_octaves=n_octaves, gray=True)
+    for name in ("frame_offset", "in_octave", "class_id", "code", "desc"):
+        assert np.array_equal(k[name], k2[name]), name
+    fe.close()
+
+
+def test_keylines_on_clutter_shapes_and_real_frames(golden_dir):
+    cfg = default_config("fullres")
+    rows, cols = cfg["img_size"][0] - cfg["top_cutoff"], cfg["img_size"][1]
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    imgs = []
+    imgs.append(((rng.random((rows, cols)) < 0.5) * 220).astype(np.uint8))                               # salt and pepper: thousands of anchors
+    imgs.append(np.clip(128 + 90 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + rng.normal(0, 6, (rows, cols)), 0, 255).astype(np.uint8))   # curved edges
+    sq = np.full((rows, cols), 40, np.uint8)
+    for i in range(12):                                                                                   # nested / overlapping rectangles
+        x0, y0 = int(rng.integers(5, cols - 120)), int(rng.integers(5, rows - 90))
+        sq[y0:y0 + int(rng.integers(20, 80)), x0:x0 + int(rng.integers(30, 110))] = int(rng.integers(60, 250))
+    imgs.append(sq)
+    imgs.append(np.full((rows, cols), 99, np.uint8))                                                      # nothing at all
+    imgs.append((np.hypot(xx - 300, yy - 150) < 100).astype(np.uint8) * 180 + 30)                         # a disc: chains that turn
+    real = np.load(os.path.join(golden_dir, "real_frames.npz"))
+    o = O.Oracle(cfg)
+    for name in real.files:
+        if real[name].ndim == 3:
+            imgs.append(o.bgr2gray(o.preprocess(real[name])))
+    gray = np.stack(imgs)
+    B = gray.shape[0]
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=256)
+    k = fe.keylines_batch(gray, n_octaves=3, gray=True, capacity=B * 6000)
+    _check_stages(fe, gray, 3)
+    n = _check_keylines(k, gray, 3)
+    assert n > 200 and k["frame_offset"][4] == k["frame_offset"][3]
+    # other detector parameters
+    p = fe.edlines_params(gradient_threshold=25, anchor_threshold=4, scan_intervals=1, min_line_len=10, line_fit_err_threshold=1.4)
+    k = fe.keylines_batch(gray[1:4], n_octaves=2, gray=True, params=p, capacity=30000)
+    _check_stages(fe, gray[1:4], 2, p)
+    _check_keylines(k, gray[1:4], 2, p)
+    with pytest.raises(LanefrontError):
+        fe.keylines_batch(gray, n_octaves=3, gray=True, capacity=5)                                       # too small an output: an error, no truncation
+    with pytest.raises(LanefrontError):
+        fe.keylines_batch(gray, n_octaves=6, gray=True)
+    fe.close()
+
+
+def test_describe_given_keylines_on_the_pyrdown_pyramid():
+    """BinaryDescriptor::compute with KeyLines that live on computeGaussianPyramid's levels (scale 2 per octave, what
+    LSDDetector_custom.cpp:130-215 produces): descriptors from blur(sigma 1) -> pyrDown -> Sobel per level."""
+    cfg = default_config("fullres")
+    B = 4
+    frames = synth.make_batch(B, seed0=77)
+    gray = _gray_frames(cfg, frames)
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=256)
+    k = fe.keylines_batch(gray, n_octaves=1, gray=True)
+    fo = k["frame_offset"]
+    frame = np.repeat(np.arange(B, dtype=np.int32), np.diff(fo))
+    io, ang, npx, octv, fr = [], [], [], [], []
+    for lvl in range(4):
+        io.append(k["in_octave"] / (1 << lvl)); ang.append(k["angle"]); npx.append(np.maximum(k["num_pixels"] >> lvl, 1))
+        octv.append(np.full(k["n"], lvl, np.int32)); fr.append(frame)
+    io, ang, npx, octv, fr = (np.concatenate(v) for v in (io, ang, npx, octv, fr))
+    perm = np.random.default_rng(1).permutation(io.shape[0])                                             # any order
+    io, ang, npx, octv, fr = io[perm], ang[perm], npx[perm], octv[perm], fr[perm]
+    desc, code = fe.describe_keylines(gray, fr, io, ang, npx, octv)
+    for f in range(B):
+        m = fr == f
+        wd, wc = O.describe_keylines(gray[f], io[m], ang[m], npx[m], octv[m])
+        assert np.array_equal(code[m], wc) and np.array_equal(desc[m], wd)
+    # level 0 of this pyramid is the detector's first octave (blur sigma 1, Sobel): the same descriptors
+    d0, c0 = fe.describe_keylines(gray, frame, k["in_octave"], k["angle"], k["num_pixels"], np.zeros(k["n"], np.int32))
+    assert np.array_equal(d0, k["desc"]) and np.array_equal(c0, k["code"])
+    fe.close()
