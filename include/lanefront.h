@@ -336,6 +336,16 @@ void lf_edlines_default_params(lf_edlines_params* p);
 int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                       const lf_edlines_params* params_or_null, lf_keylines* out, int out_on_device, int describe,
                       int* n_keylines, int32_t* frame_status_or_null);
+/* Plugin path with the EDLines detector: lf_set_image_edlines, then lf_detect_lines exactly as after lf_set_image.
+ * The reference has ONE LineDetectorInterface implementation working on colour masks (LineDetectorLSD,
+ * line_detector_lsd.py:11-142); this is the package's second (SURVEY 8f-4 "alternative detector plugin") and its
+ * contract is the package's own: EDLines (one octave; KeyLine endpoints sPointInOctave -> ePointInOctave) runs on
+ * BGR2GRAY of the working image, a line belongs to colour c when the dilated colour mask `bw` of that colour
+ * (line_detector_lsd.py:38-58) is set under the truncated, clamped centre of the line; normals, centres and the
+ * endpoint ordering come from the same code as for LSD lines (_findNormal / _correctPixelOrdering, :74-125).
+ * LF_ERR_CAPACITY when the detector gives up on the image (the reference prints "Line Detection not finished"). */
+int lf_set_image_edlines(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes,
+                         const lf_edlines_params* params_or_null);
 /* BinaryDescriptor::compute on GIVEN KeyLines (:524-687, useDetectionData = false): gradients from
  * computeGaussianPyramid (:350-371: GaussianBlur 5x5 sigma 1, then pyrDown by 2 per octave) + Sobel (:374-398).
  * gray: [n_frames][rows][cols] u8 working images; per line: its frame, in_octave endpoints (4), angle, num_pixels,

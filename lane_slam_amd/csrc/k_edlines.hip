@@ -802,6 +802,55 @@ __global__ __launch_bounds__(256) void k_kl_assemble(EdAll all, int n_octaves, c
     }
 }
 
+// plugin path: the octave-0 lines of frame 0 -> the per-colour slot lists the segment stage reads (lanefront_keylines.inc,
+// lf_set_image_edlines).  One wave; lines keep their order inside a colour.
+__global__ __launch_bounds__(64) void k_ed_slots(EdAll all, const uint32_t* __restrict__ maskbits, int Ww, int cap_lines,
+                                                float* __restrict__ slot_lines, int* __restrict__ counts)
+{
+    const EdOct& o = all.o[0];
+    const int lane = threadIdx.x;
+    const int n = o.counts[1] < 0 ? 0 : o.counts[2];
+    const double PI = 3.14159265358979323846;
+    int cnt[3] = { 0, 0, 0 };
+    for (int start = 0; start < n; start += 64) {
+        const int l = start + lane;
+        float io[4] = { 0, 0, 0, 0 };
+        int member = 0;
+        if (l < n) {
+            const float direction = o.l_dir[l];
+            const float* ep = o.l_ep + 4 * (size_t)l;
+            const float s1 = ep[0], s2 = ep[1], e1 = ep[2], e2 = ep[3];
+            const float dx = e1 - s1, dy = e2 - s2;
+            bool shouldChange = false;                                   // OctaveKeyLines :966-997
+            if (direction >= -0.75 * PI && direction < -0.25 * PI) { if (dy > 0) shouldChange = true; }
+            if (direction >= -0.25 * PI && direction < 0.25 * PI) { if (dx < 0) shouldChange = true; }
+            if (direction >= 0.25 * PI && direction < 0.75 * PI) { if (dy < 0) shouldChange = true; }
+            if ((direction >= 0.75 * PI && direction < PI) || (direction >= -PI && direction < -0.75 * PI)) { if (dx > 0) shouldChange = true; }
+            if (shouldChange) { io[0] = e1; io[1] = e2; io[2] = s1; io[3] = s2; }
+            else { io[0] = s1; io[1] = s2; io[2] = e1; io[3] = e2; }
+            const float cx = (io[0] + io[2]) / 2, cy = (io[1] + io[3]) / 2;
+            int ix = (int)cx, iy = (int)cy;
+            ix = ix < 0 ? 0 : (ix > o.W - 1 ? o.W - 1 : ix);
+            iy = iy < 0 ? 0 : (iy > o.H - 1 ? o.H - 1 : iy);
+            for (int c = 0; c < 3; ++c)
+                if ((maskbits[((size_t)c * o.H + iy) * Ww + (ix >> 5)] >> (ix & 31)) & 1u) member |= 1 << c;
+        }
+        for (int c = 0; c < 3; ++c) {
+            const unsigned long long bal = __ballot((member >> c) & 1);
+            const int pos = cnt[c] + __popcll(bal & ((1ull << lane) - 1ull));
+            if (((member >> c) & 1) && pos < cap_lines)
+                for (int q = 0; q < 4; ++q) slot_lines[((size_t)c * cap_lines + pos) * 4 + q] = io[q];
+            cnt[c] += __popcll(bal);
+        }
+    }
+    if (lane < 3) counts[lane] = cnt[lane];         // more than cap_lines: the segment stage reports the overflow
+}
+
+void launch_ed_slots(const EdAll& all, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_ed_slots, dim3(1), dim3(64), 0, s, all, maskbits, Ww, cap_lines, slot_lines, counts);
+}
+
 void launch_kl_count(const EdAll& all, int n_octaves, int n_frames, int* frame_count, int* status, hipStream_t s)
 {
     hipLaunchKernelGGL(k_kl_count, dim3((n_frames + 255) / 256), dim3(256), 0, s, all, n_octaves, n_frames, frame_count, status);

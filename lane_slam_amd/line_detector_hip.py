@@ -107,3 +107,35 @@ class LineDetectorHIP(LineDetectorInterface):
 
     def getImage(self):
         return self.bgr
+
+
+class LineDetectorEDLines(LineDetectorHIP):
+    """The same plugin interface over the EDLines detector of the reference's line_descriptor library
+    (ref: src/line_descriptor/src/binary_descriptor_custom.cpp:1374-2751, BinaryDescriptor::detect) instead of OpenCV's
+    LSD -- SURVEY 8f-4's "alternative detector plugin".  Same constructor contract and the same 13 configuration keys
+    as LineDetectorLSD (the HSV boxes and dilation_kernel_size decide the colour of a line; canny_thresholds is
+    accepted and unused: EDLines works on the gray image, not on Canny edges).  Contract (this package's own, stated in
+    include/lanefront.h at lf_set_image_edlines): a detected line belongs to every colour whose dilated mask covers its
+    centre; normals, centres and endpoint ordering as in LineDetectorLSD._findNormal / _correctPixelOrdering.
+
+        detector:
+          - lane_slam_amd.LineDetectorEDLines
+          - configuration: { ...same 13 keys... }
+
+    Optional keyword `edlines`: dict overriding EDLineDetector's defaults (gradient_threshold 80, anchor_threshold 8,
+    scan_intervals 2, min_line_len 15, line_fit_err_threshold 1.6)."""
+
+    def __init__(self, configuration, device=0, max_lines_per_color=2048, edlines=None):
+        LineDetectorHIP.__init__(self, configuration, device=device, max_lines_per_color=max_lines_per_color)
+        self._edlines = dict(edlines or {})
+
+    def setImage(self, bgr):
+        bgr = np.asarray(bgr)
+        if bgr.ndim != 3 or bgr.shape[2] != 3 or bgr.dtype != np.uint8:
+            raise ValueError("setImage expects a uint8 HxWx3 BGR image")
+        self.bgr = np.copy(bgr)
+        fe = self._frontend(bgr.shape[0], bgr.shape[1])
+        img = np.ascontiguousarray(self.bgr)
+        p = fe.edlines_params(**self._edlines)
+        fe._check(fe.lib.lf_set_image_edlines(fe.h, img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1], img.strides[0],
+                                              ctypes.byref(p)))

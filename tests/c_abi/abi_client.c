@@ -104,6 +104,20 @@ int main(int argc, char** argv)
     int t2 = 0;
     const int rc_small = total > 1 ? lf_process_batch(h, frames, n, 0, &tiny, 0, 0, &t2) : LF_ERR_CAPACITY;
 
+    /* the second detector from plain C: EDLines over two octaves + descriptors (lf_keylines_batch) */
+    const int kcap = 2048 * n;
+    lf_keylines kl;
+    memset(&kl, 0, sizeof(kl));
+    kl.capacity = kcap;
+    kl.frame_offset = (int32_t*)calloc((size_t)n + 1, sizeof(int32_t));
+    kl.in_octave = (float*)malloc(sizeof(float) * 4 * (size_t)kcap);
+    kl.octave = (int32_t*)malloc(sizeof(int32_t) * (size_t)kcap);
+    kl.class_id = (int32_t*)malloc(sizeof(int32_t) * (size_t)kcap);
+    kl.code = (uint8_t*)malloc(32 * (size_t)kcap);
+    int n_kl = 0;
+    rc = lf_keylines_batch(h, frames, n, 0, 0, 2, NULL, &kl, 0, 1, &n_kl, NULL);
+    if (rc != LF_OK) die("lf_keylines_batch", h, rc);
+
     FILE* f = fopen(argv[4], "wb");
     if (!f) { perror(argv[4]); return 2; }
     int32_t head[4] = { total, rc_small, (int32_t)boff[n], LF_N_STAGES };
@@ -119,6 +133,13 @@ int main(int argc, char** argv)
     fwrite(dist, sizeof(float), (size_t)total, f);
     fwrite(boff, sizeof(int64_t), (size_t)n + 1, f);
     fwrite(body, 1, (size_t)boff[n], f);
+    int32_t klhead[1] = { n_kl };
+    fwrite(klhead, sizeof(klhead), 1, f);
+    fwrite(kl.frame_offset, sizeof(int32_t), (size_t)n + 1, f);
+    fwrite(kl.in_octave, sizeof(float) * 4, (size_t)n_kl, f);
+    fwrite(kl.octave, sizeof(int32_t), (size_t)n_kl, f);
+    fwrite(kl.class_id, sizeof(int32_t), (size_t)n_kl, f);
+    fwrite(kl.code, 32, (size_t)n_kl, f);
     fclose(f);
     lf_destroy(h);
     printf("abi_client: %d frames, %d segments, %lld body bytes\n", n, total, (long long)boff[n]);

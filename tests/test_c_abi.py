@@ -74,6 +74,12 @@ def test_c_client_matches_python_binding_and_oracle(tmp_path):
     dist = take(np.float32, total)
     boff = take(np.int64, n + 1)
     body = take(np.uint8, body_bytes)
+    n_kl = int(take(np.int32, 1)[0])
+    kfo = take(np.int32, n + 1)
+    kio = take(np.float32, n_kl * 4).reshape(-1, 4)
+    koct = take(np.int32, n_kl)
+    kcls = take(np.int32, n_kl)
+    kcode = take(np.uint8, n_kl * 32).reshape(-1, 32)
     assert pos == len(raw) and total > 20
     fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=512)
     seg = fe.process_batch(frames)
@@ -101,5 +107,13 @@ def test_c_client_matches_python_binding_and_oracle(tmp_path):
     gi, gd = la.step(seg, step=1)
     assert np.array_equal(gi, i2) and np.array_equal(gd, d2) and la.state()["size"] == map_size2
     la.close()
+    # the EDLines / KeyLines call from plain C against the oracle
+    from oracle import oracle as O
+    assert n_kl > 0 and kfo[-1] == n_kl
+    for f in range(n):
+        r = O.octave_keylines(o.bgr2gray(o.preprocess(frames[f])), 2)
+        a, b = int(kfo[f]), int(kfo[f + 1])
+        assert b - a == r["n"] and np.array_equal(kio[a:b], r["in_octave"]) and np.array_equal(koct[a:b], r["octave"])
+        assert np.array_equal(kcls[a:b], r["class_id"]) and np.array_equal(kcode[a:b], r["code"])
     r0 = o.process_frame(frames[0])
     assert np.array_equal(lines[fo[0]:fo[1]], r0["lines"]) and np.array_equal(keep[fo[0]:fo[1]], r0["keep"])
