@@ -45,6 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 INT8_MFMA_PEAK_POPS = 5.0     # dense int8 MFMA, MI355X_MICROARCH.md (2x the ~2.5 PF bf16 rate)
+FP4_MFMA_PEAK_POPS = 10.0     # dense FP4 (f8f6f4 with e2m1 operands), MI355X_MICROARCH.md: 2x the int8 / fp8 rate
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 MAP_ROLL = 16384               # live map = --map seeded codes + this many more entries, kept full (ring)
 
@@ -58,6 +59,16 @@ def stage_bytes(P):
         "canny_nms": 3 * P + P,                                              # K_canny_grad: read 3P, write P
         "lbd_gray_blur_sobel": P + 4 * P,                                    # K_sobel_lbd: read P (gray), write 4P
     }
+
+
+def source_digest(*rel):
+    """sha256 (16 hex digits) of library sources: ties a PMC traffic file to the kernel it was measured on"""
+    import hashlib
+    h = hashlib.sha256()
+    for r in rel:
+        with open(os.path.join(ROOT, r), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def alloc_out(torch, dev, B, cap):
@@ -146,7 +157,12 @@ def main():
     host = synth.make_batch(uniq, seed0=10000 * rank, rows=in_rows, cols=in_cols, threads=host_threads)
     reps = (B + uniq - 1) // uniq
     host = np.ascontiguousarray(np.tile(host, (reps, 1, 1, 1))[:B])
-    frames = torch.from_numpy(host).to(dev)
+    # one device-resident input batch PER HANDLE (D distinct buffers, the frames of batch k shifted sideways by 9 k pixels):
+    # consecutive steps read different memory, so no step finds its input in the 256 MiB Infinity Cache because the
+    # previous one left it there (one shared 236 MB tensor could not rule that out)
+    frames0 = torch.from_numpy(host).to(dev)
+    frames_d = [frames0] + [torch.roll(frames0, 9 * k, dims=2).contiguous() for k in range(1, D)]
+    frames = frames0
 
     cap = B * 3 * args.cap
     outs = [alloc_out(torch, dev, B, cap) for _ in range(D)]
@@ -193,7 +209,7 @@ def main():
             slot = k % D
             if len(inflight) == D:
                 finish(inflight.pop(0))
-            fes[slot].submit_device(frames.data_ptr(), B, ptrs[slot], cap, describe=True)
+            fes[slot].submit_device(frames_d[slot].data_ptr(), B, ptrs[slot], cap, describe=True)
             inflight.append(slot)
         while inflight:
             finish(inflight.pop(0))
@@ -243,7 +259,7 @@ def main():
         f.reset_timing()
     fes[0].set_profiling(True)
     for _ in range(solo_steps):
-        fes[0].submit_device(frames.data_ptr(), B, ptrs[0], cap, describe=True)
+        fes[0].submit_device(frames_d[0].data_ptr(), B, ptrs[0], cap, describe=True)
         finish(0)
         amap.synchronize()
     sync_all()
@@ -268,32 +284,40 @@ def main():
                 e["GBps"] = round(sb[name] * B / (avg * 1e-3) / 1e9, 1)
                 e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
             if name == "assoc_mfma" and avg > 0 and seg_total[0] > 0:
-                # 2 * N * M * 256 int8 ops per call against the dense int8 MFMA peak (the kernel, its
-                # best-slot fill and the final decode; the map's operands stay packed across calls)
+                # 2 * N * M * 256 ops per call (one launch: query expansion, matrix loop, merge, report; the
+                # map's operands stay packed across calls), priced against the dense peak OF THE INSTRUCTION IT RUNS ON
                 ops = 2.0 * seg_total[0] * M * 256
+                fp4 = os.environ.get("LF_ASSOC_INT8") is None
+                peak = FP4_MFMA_PEAK_POPS if fp4 else INT8_MFMA_PEAK_POPS
                 e["algorithmic_ops"] = ops
                 e["Pop_per_s"] = round(ops / (avg * 1e-3) / 1e15, 3)
-                e["mfma_peak_Pop_per_s"] = INT8_MFMA_PEAK_POPS
-                e["frac_of_mfma_peak"] = round(ops / (avg * 1e-3) / 1e15 / INT8_MFMA_PEAK_POPS, 3)
+                e["instruction"] = "v_mfma_scale_f32_32x32x64_f8f6f4 (e2m1 operands)" if fp4 else "v_mfma_i32_32x32x32_i8"
+                e["mfma_peak_Pop_per_s"] = peak
+                e["frac_of_mfma_peak"] = round(ops / (avg * 1e-3) / 1e15 / peak, 3)
             kernels.append(e)
         streaming = [k for k in kernels if "GBps" in k]
         # dominant streaming kernel = the one that has to move the most bytes
         dom = max(streaming, key=lambda k: k["algorithmic_bytes"]) if streaming else None
         roofline = None
         if dom:
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+            # PMC traffic is measured offline (separate rocprofv3 --pmc passes, tools/profile_round.sh) and is only quoted
+            # while the kernel it was measured on is the kernel that runs: the file records the digest of its source
+            traffic, traffic_note = None, None
+            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj["workload"] == {"batch": B, "geometry": args.geometry}:
-                    traffic = tj["traffic_bytes_per_launch"].get(dom["stage"])
+                    if tj.get("source_digest", {}).get("k_pre") == source_digest("lane_slam_amd/csrc/k_pre.hip"):
+                        traffic = tj["traffic_bytes_per_launch"].get(dom["stage"])
+                    else:
+                        traffic_note = "profiles/r03_traffic.json was measured on another k_pre.hip: not quoted"
             roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
                         "measured": "HIP events on the launch stream, %d single-batch steps run right after the "
                                     "timed region (per-kernel times inside the overlapped region are in "
                                     "kernels_timed_region)" % solo_steps,
-                        "traffic_source": "profiles/r02_traffic.json (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes)" if traffic else None,
+                        "traffic_source": "profiles/r03_traffic.json (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes)" if traffic else traffic_note,
                         "note": "dominant STREAMING kernel (most algorithmic bytes, SURVEY 8d).  The longest kernel by time, lsd_grow "
                                 "(sequential-semantics LSD region growing), is latency / issue bound and "
                                 "has no bandwidth or MFMA roofline (SURVEY 8d: report time); its time is in `kernels`"}
@@ -303,9 +327,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/f64 (FP4 e2m1 MFMA with exact f32 accumulation for association)", "data": "synthetic",
             "config": {"workload": "%s%d-frame batch per GPU of %dx%d synthetic lane frames (%d distinct), %s geometry (working image %dx%d, "
-                                   "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs the %d-entry live map + map update"
+                                   "LSD image %dx%d), LSD+LBD+project+sanity, Hamming association vs the %d-entry live map + map update; %d distinct device-resident input batches in rotation"
                                    % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",
-                                      B, in_cols, in_rows, uniq, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M),
+                                      B, in_cols, in_rows, uniq, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M, D),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0], "live_map": map_state,
                        "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, one all-gather of segment blocks per step, replicated map" % world},
@@ -464,6 +488,89 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
                 "growing from empty by the kept segments (append, per-frame poses)" % (n_stream, laps, B, D, copied_bytes, frame_bytes),
         "frames": laps * n_stream, "distinct_frames_per_lap": n_stream, "seconds": round(sdt, 4),
         "h2d_GBps": round(laps * n_stream * copied_bytes / sdt / 1e9, 2), "segments": segs[0], "map_final": st}
+
+    # ---- other content: the rate of region growing depends on what is in the frames.  (a) the three real Duckiebot
+    # camera frames committed as test inputs (tests/golden/real_frames.npz), tiled to a batch, each copy shifted sideways;
+    # (b) the synthetic frames with clutter (speckle + 40 random strokes in lane colours per frame: many short regions)
+    def content_rate(batch_host, label):
+        d = torch.from_numpy(np.ascontiguousarray(batch_host)).to(dev)
+        torch.cuda.synchronize()
+
+        def go(nb):
+            inflight, segsum = [], 0
+            for k in range(nb):
+                slot = k % D
+                if len(inflight) == D:
+                    segsum += fes[inflight.pop(0)].wait()
+                fes[slot].submit_device(d.data_ptr(), B, ptrs[slot], cap, describe=True)
+                inflight.append(slot)
+            while inflight:
+                segsum += fes[inflight.pop(0)].wait()
+            return segsum
+        go(D)
+        torch.cuda.synchronize()
+        nb = 4 * D
+        t0 = time.perf_counter()
+        n_seg = go(nb)
+        torch.cuda.synchronize()
+        cdt = time.perf_counter() - t0
+        return {"value": round(nb * B / cdt, 1), "unit": "frames/s", "segments_per_frame": round(n_seg / (nb * B), 1),
+                "what": "%s; detect->describe->project->sanity (no association), %d batches of %d frames, %d in flight" % (label, nb, B, D)}
+    try:
+        real = np.load(os.path.join(ROOT, "tests", "golden", "real_frames.npz"))
+        rf = [real[k] for k in real.files if real[k].ndim == 3 and real[k].shape == host.shape[1:]]
+        if rf:
+            tiled = np.stack([np.roll(rf[i % len(rf)], 7 * (i // len(rf)), axis=1) for i in range(B)])
+            sec["real_frames"] = content_rate(tiled, "%d real Duckiebot camera frames (the reference's anti_instagram annotation images) tiled to %d, each copy shifted by 7 px" % (len(rf), B))
+    except Exception as e:
+        sec["real_frames"] = {"error": repr(e)}
+    try:
+        rng_c = np.random.default_rng(4321)
+        cl = host.copy()
+        for f_ in range(cl.shape[0]):
+            img = cl[f_]
+            r0 = img.shape[0] // 3
+            for _ in range(40):
+                y, x = rng_c.integers(r0 + 10, img.shape[0] - 10), rng_c.integers(10, img.shape[1] - 10)
+                dy, dx = rng_c.integers(-12, 13), rng_c.integers(-40, 41)
+                col = ((235, 235, 235), (40, 220, 235), (40, 40, 220))[rng_c.integers(0, 3)]
+                t_ = np.linspace(0, 1, 80)
+                yy = np.clip((y + t_ * dy + rng_c.normal(0, 0.7, 80)).astype(int), r0, img.shape[0] - 1)
+                xx = np.clip((x + t_ * dx + rng_c.normal(0, 0.7, 80)).astype(int), 0, img.shape[1] - 1)
+                img[yy, xx] = col
+            img[rng_c.random(img.shape[:2]) < 0.004] = (235, 235, 235)
+        sec["clutter_frames"] = content_rate(cl, "the step's synthetic frames + speckle and 40 random strokes in lane colours each (tools/soak_parity.py's clutter)")
+    except Exception as e:
+        sec["clutter_frames"] = {"error": repr(e)}
+
+    # ---- the second detector: EDLines over 3 octaves + LBD on the detector's gradients, same frames
+    try:
+        import ctypes as ct
+        from lane_slam_amd import _lib as L
+        kcap = B * 512
+        kout = {k: torch.zeros((kcap, c) if c > 1 else kcap, dtype={"f4": torch.float32, "i4": torch.int32, "u1": torch.uint8}[dt], device=dev)
+                for k, dt, c in L.KEYLINE_FIELDS}
+        kfo = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        ks = L.LfKeylines()
+        ks.capacity = kcap
+        ks.frame_offset = kfo.data_ptr()
+        for k, _, _ in L.KEYLINE_FIELDS:
+            setattr(ks, k, kout[k].data_ptr())
+        d = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+        ktot = ct.c_int()
+
+        def kl():
+            fes[0]._check(fes[0].lib.lf_keylines_batch(fes[0].h, ct.c_void_p(d.data_ptr()), B, 0, 1, 3, None, ct.byref(ks), 1, 1, ct.byref(ktot), None))
+        kl(); kl()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            kl()
+        kdt = (time.perf_counter() - t0) / 5
+        sec["edlines_keylines"] = {"value": round(B / kdt, 1), "unit": "frames/s", "ms_per_batch": round(kdt * 1e3, 3), "keylines_per_frame": round(ktot.value / B, 1),
+                                   "what": "lf_keylines_batch: EDLines over 3 octaves + multi-octave LBD (BinaryDescriptor::operator()), %d frames resident, ONE batch in "
+                                           "flight (synchronous call)" % B}
+    except Exception as e:
+        sec["edlines_keylines"] = {"error": repr(e)}
 
     # ---- JPEG ingest (8f-1): CompressedImage streams -> host Huffman decode -> GPU IDCT/colour -> the same path
     try:

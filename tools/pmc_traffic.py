@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """Derive per-launch HBM traffic from two rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE; separate runs).
 
-usage: tools/pmc_traffic.py <pmc_write.csv> <pmc_fetch.csv> <tag> > profiles/r02_traffic.json
+usage: tools/pmc_traffic.py <pmc_write.csv> <pmc_fetch.csv> <tag> > profiles/r03_traffic.json
 
 Counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (the counter
 reports half the bytes of wide coalesced reads).  Output keys: kernel short names plus the stage
 aliases bench.py looks up for `roofline.traffic`."""
-import csv, json, re, sys
+import csv, hashlib, json, os, re, sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def digest(rel):
+    with open(os.path.join(ROOT, rel), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 def per_kernel(path, counter):
     tot, cnt = defaultdict(float), defaultdict(int)
@@ -32,6 +39,8 @@ for a, k in alias.items():
     if k in tr:
         tr[a] = tr[k]
 json.dump({"workload": {"batch": 256, "geometry": "fullres"},
+           # bench.py quotes roofline.traffic only while the dominant kernel's source is the one measured here
+           "source_digest": {"k_pre": digest("lane_slam_amd/csrc/k_pre.hip")},
            "source": "rocprofv3 --pmc WRITE_SIZE / --pmc FETCH_SIZE in separate passes of `bench.py --steps 2 --warmup 1 "
                      "--cpu-frames -1 --depth 1` (profiles/%s_pmc_*.csv); counters are in KB; FETCH_SIZE doubled per "
                      "MI355X_MICROARCH.md (gfx950 reports half the bytes of coalesced reads; the factor was calibrated on this "
