@@ -84,6 +84,8 @@ void lfo_lsd_scaled_image(const lfo_config* c, const uint8_t* img, int rows, int
    (pixel addresses, descending bin then raster); returns list length */
 int lfo_lsd_ll_angle(const lfo_config* c, const double* scaled, int srows, int scols,
                      double* angles, double* modgrad, int32_t* order);
+/* seed order inside a gradient bin: 0 raster (default), 1 libstdc++ std::sort as the later OpenCV 3.x (lf_oracle_sort.cpp) */
+void lfo_lsd_set_seed_order(int mode);
 /* full detector: lines (x1,y1,x2,y2) float32, returns count (<= cap); extra = width,prec,nfa per line or NULL */
 int lfo_lsd_detect(const lfo_config* c, const uint8_t* img, int rows, int cols,
                    float* lines4, double* extra3, int cap);
@@ -111,6 +113,8 @@ void lfo_lbd(const int16_t* dx, const int16_t* dy, int rows, int cols,
 /* a-10: exact Hamming NN, distance > 128 => idx -1, dist -1; ties -> lowest train index */
 void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
                int32_t* idx, float* dist);
+/* the same with the reference's tie rule (first discovered by Mihasher::query) and the number of equally near codes */
+void lfo_match_mih(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int32_t* idx, float* dist, int32_t* n_ties);
 /* float-descriptor L2 NN (72-d) */
 void lfo_match_float(const float* q72, int nq, const float* t72, int nt, int32_t* idx, float* dist);
 

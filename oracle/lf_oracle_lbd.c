@@ -232,6 +232,85 @@ void lfo_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,
     }
 }
 
+/* The same nearest neighbour with the REFERENCE's tie rule, for quantifying the documented deviation (lowest index
+ * here and on the GPU).  Mihasher::query (binary_descriptor_matcher.cpp:635-753) with B = 256, m = 32 (8-bit
+ * substrings, all of them: mplus = 32), D = 128, d = 4, K = 1 visits, for radius s = 0, 1, ... and substring k = 0..31, the
+ * buckets H[k][chunk_k(query) ^ bitstr] over all bitstr of weight s in the order its combination loop (:681-741)
+ * produces them; a bucket lists its codes in insertion = train index order (BucketGroup::insert appends at the end of
+ * the bucket's range, :927-947; populate inserts i = 0 .. N-1, :806-819).  The first time an index shows up its full
+ * distance is computed and the FIRST index seen per distance is kept (:716-722); after finishing (s, k) the search
+ * stops as soon as a code at distance exactly s * 32 + k has been seen (:744-746) -- by then every code within that
+ * distance has, so the answer is the exact nearest neighbour, and among equally near ones the one whose earliest
+ * discovery (s, k, position of bitstr in the enumeration, train index) comes first. */
+static int mih_rank[5][256];
+static int mih_rank_ready = 0;
+
+static void mih_build_ranks(void)
+{
+    for (int s = 0; s <= 4; ++s) {
+        int power[8], order = 0;
+        const int curb = 8;
+        unsigned long long bitstr = 0;
+        for (int i = 0; i < s; i++) power[i] = i;
+        power[s] = curb + 1;
+        int bit = s - 1;
+        for (;;) {
+            if (bit != -1) {
+                bitstr ^= (power[bit] == bit) ? (1ull << power[bit]) : (3ull << (power[bit] - 1));
+                power[bit]++;
+                bit--;
+            } else {
+                mih_rank[s][bitstr & 255] = order++;
+                while (++bit < s && power[bit] == power[bit + 1] - 1) {
+                    bitstr ^= 1ull << (power[bit] - 1);
+                    power[bit] = bit;
+                }
+                if (bit == s) break;
+            }
+        }
+    }
+    mih_rank_ready = 1;
+}
+
+void lfo_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist, int32_t* n_ties)
+{
+    if (!mih_rank_ready) mih_build_ranks();
+    int* dd = (int*)malloc((size_t)(nt > 0 ? nt : 1) * sizeof(int));
+    for (int i = 0; i < nq; ++i) {
+        const uint8_t* a = q + (size_t)32 * i;
+        int best = 1 << 30;
+        for (int j = 0; j < nt; ++j) {
+            const uint8_t* b = t + (size_t)32 * j;
+            int d = 0;
+            for (int k = 0; k < 32; ++k) d += __builtin_popcount((unsigned)(a[k] ^ b[k]));
+            dd[j] = d;
+            if (d < best) best = d;
+        }
+        int ties = 0, bi = -1;
+        long long bkey = 0;
+        if (nt > 0 && best <= 128) {
+            for (int j = 0; j < nt; ++j) {
+                if (dd[j] != best) continue;
+                ties++;
+                const uint8_t* b = t + (size_t)32 * j;
+                long long key = -1;
+                for (int k = 0; k < 32; ++k) {          /* substring k = byte k (split(), bitops_custom.hpp:99-124, b = 8) */
+                    const int x = a[k] ^ b[k], h = __builtin_popcount((unsigned)x);
+                    if (h > 4) continue;                /* never looked up in table k: radius d = 4 */
+                    const long long kk = (((long long)h * 32 + k) * 256 + mih_rank[h][x]);
+                    if (key < 0 || kk < key) key = kk;
+                }
+                /* key >= 0 always: a code within 128 bits has a substring within 4 */
+                if (bi < 0 || key < bkey) { bi = j; bkey = key; }        /* equal keys: same bucket, lower train index first */
+            }
+        }
+        if (bi >= 0) { idx[i] = bi; dist[i] = (float)best; }
+        else { idx[i] = -1; dist[i] = -1.f; }
+        if (n_ties) n_ties[i] = ties;
+    }
+    free(dd);
+}
+
 /* float LBD nearest neighbour (Euclidean); double accumulation, float result */
 void lfo_match_float(const float* q, int nq, const float* t, int nt, int32_t* idx, float* dist)
 {

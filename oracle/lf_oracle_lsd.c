@@ -151,6 +151,13 @@ void lfo_lsd_scaled_image(const lfo_config* c, const uint8_t* img, int rows, int
     free(rowf); free(blur); free(xofs); free(xa); free(hbuf);
 }
 
+/* seed order inside a gradient bin: 0 = raster (OpenCV 3.0's per-bin lists; the default here and on the GPU),
+ * 1 = what std::sort(ordered_points, compare_norm) of the later 3.x leaves (lf_oracle_sort.cpp): a switch for
+ * counting how much that lead matters, never the product's behaviour */
+static int g_seed_order = 0;
+void lfo_lsd_set_seed_order(int mode) { g_seed_order = mode; }
+void lfo_std_sort_seed_order(const int32_t* bin_of_pixel, int H, int W, int32_t* order);
+
 int lfo_lsd_ll_angle(const lfo_config* c, const double* scaled, int H, int W,
                      double* angles, double* modgrad, int32_t* order)
 {
@@ -192,6 +199,14 @@ int lfo_lsd_ll_angle(const lfo_config* c, const double* scaled, int H, int W,
             order[start[i]++] = y * W + x;
         }
     free(count); free(start);
+    if (g_seed_order == 1) {
+        int32_t* bins = (int32_t*)malloc(sizeof(int32_t) * (size_t)(H - 1) * (W - 1));
+        size_t k = 0;
+        for (int y = 0; y < H - 1; ++y)
+            for (int x = 0; x < W - 1; ++x) bins[k++] = (int)(modgrad[(size_t)y * W + x] * bin_coef);
+        lfo_std_sort_seed_order(bins, H, W, order);
+        free(bins);
+    }
     return acc;
 }
 

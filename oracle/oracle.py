@@ -17,7 +17,7 @@ _SO = os.path.join(_HERE, "_build", "liblforacle.so")
 
 def build(force=False):
     """Compile the oracle with gcc (idempotent)."""
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h", ".cpp"))]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -255,6 +255,21 @@ class Oracle(object):
         dist = np.empty(q.shape[0], np.float32)
         self.lib.lfo_match(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist))
         return idx, dist
+
+    def match_mih(self, q, t):
+        """Nearest neighbour with the reference's tie rule (first discovered by Mihasher::query,
+        binary_descriptor_matcher.cpp:635-753): (idx, dist, number of equally near train codes)."""
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
+        idx = np.empty(q.shape[0], np.int32)
+        dist = np.empty(q.shape[0], np.float32)
+        ties = np.empty(q.shape[0], np.int32)
+        self.lib.lfo_match_mih(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist), _p(ties))
+        return idx, dist, ties
+
+    def set_lsd_seed_order(self, mode):
+        """0: raster inside a gradient bin (default); 1: libstdc++ std::sort order (the later OpenCV 3.x)."""
+        self.lib.lfo_lsd_set_seed_order(int(mode))
 
     def match_float(self, q, t):
         q = np.ascontiguousarray(q, dtype=np.float32).reshape(-1, 72)
