@@ -294,6 +294,17 @@ def main():
                 e["instruction"] = "v_mfma_scale_f32_32x32x64_f8f6f4 (e2m1 operands)" if fp4 else "v_mfma_i32_32x32x32_i8"
                 e["mfma_peak_Pop_per_s"] = peak
                 e["frac_of_mfma_peak"] = round(ops / (avg * 1e-3) / 1e15 / peak, 3)
+            if name == "lsd_grow":
+                # latency / issue bound: no bandwidth or matrix roofline.  What bounds it, as counters: wave-slot
+                # occupancy, vector issue utilisation and where its wave-cycles go (rocprofv3 SQ passes measured offline by
+                # tools/profile_round.sh; quoted only while the kernel source is the one they were measured on)
+                gpath = os.path.join(ROOT, "profiles", "r03_grow_counters.json")
+                if os.path.exists(gpath):
+                    gj = json.load(open(gpath))
+                    if gj.get("source_digest") == source_digest("lane_slam_amd/csrc/lsd_grow.h", "lane_slam_amd/csrc/k_lsd_grow.hip"):
+                        e["counters"] = {k_: v for k_, v in gj.items() if k_ in ("one_batch_in_flight", "six_batches_in_flight", "source")}
+                    else:
+                        e["counters"] = "profiles/r03_grow_counters.json was measured on another lsd_grow.h / k_lsd_grow.hip: not quoted"
             kernels.append(e)
         streaming = [k for k in kernels if "GBps" in k]
         # dominant streaming kernel = the one that has to move the most bytes

@@ -171,6 +171,20 @@ int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* ma
 int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
                        int32_t* idx, float* dist, int on_device);
 
+/* The list forms of the matcher (SURVEY a-10): BinaryDescriptorMatcher::knnMatch (binary_descriptor_matcher.cpp:258-335)
+ * and radiusMatch (:428-504) = Mihasher with K = k / K = N: the nearest map codes within D = 128 bits, nearest first.
+ * Among equally near codes: index order (the reference: its hash tables' discovery order; same deviation as lf_associate).
+ * lf_knn_match    idx / dist [nq][k], k <= 16; slots beyond the matches within 128 bits: idx -1, dist -1 (the reference
+ *                 leaves them unset)
+ * lf_radius_match all map codes within min(max_distance, 128) bits per query as a CSR list: offsets [nq + 1], idx / dist
+ *                 [cap] (distance ascending, then index); *total = number of matches; LF_ERR_CAPACITY when total > cap
+ *                 (offsets and *total are complete then: size the arrays and call again)
+ * Exact XOR / popcount, one lane per query (k_knn.hip); on_device applies to every array. */
+int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, int k, int32_t* idx, float* dist,
+                 int on_device);
+int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, float max_distance,
+                    int32_t* offsets, int32_t* idx, float* dist, int cap, int* total, int on_device);
+
 /* Anti-instagram colour clustering (k-means part).  Replaces
  *   anti_instagram/kmeans.py:22-47  runKMeans(cv_img, num_colors, init)
  * = sklearn.cluster.KMeans(n_clusters, max_iter, init = <array>).fit_predict on B, G, R points + cluster_centers_, label

@@ -204,6 +204,10 @@ void launch_map_overflow_block(int n, int n_frames, int step, uint8_t* block, hi
 void launch_map_seed_block(int n, const uint8_t* code, const uint8_t* color, const double* ground, uint8_t* block, hipStream_t s);
 void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks, int block_rows, int force_append, int* act,
                        hipStream_t s);
+// knnMatch / radiusMatch forms (k_knn.hip)
+void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int32_t* idx, float* dist, hipStream_t s);
+void launch_radius(const uint8_t* q, int nq, const uint8_t* m, int nm, int max_distance, int32_t* hist, int32_t* count, int32_t* offsets,
+                   int* total, int cap, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc_float(const float* q, int nq, const float* m, int nm, float* qn, float* mn,
                         unsigned long long* best, int32_t* idx, float* dist, hipStream_t s);
 // ---- JPEG ingest (k_jpeg.hip)

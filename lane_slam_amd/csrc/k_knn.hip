@@ -1,0 +1,181 @@
+// knnMatch / radiusMatch forms of the associator (SURVEY a-10):
+//   BinaryDescriptorMatcher::knnMatch     /root/reference/src/line_descriptor/src/binary_descriptor_matcher.cpp:258-335
+//   BinaryDescriptorMatcher::radiusMatch  :428-504
+// Both run Mihasher(256, 32) with K = k / K = N (:756-819, 635-753): the K nearest train codes within D = 128 bits,
+// nearest first; radiusMatch then keeps those within maxDistance.  Among equally near codes the reference lists them in
+// its hash tables' discovery order; here (as for lf_associate, include/lanefront.h a-10) in index order.
+//
+// These are the secondary forms of the matcher -- the 1-NN association of the hot path runs on the matrix cores
+// (k_assoc.hip); a list of neighbours per query has no arg-max epilogue to ride on, so this is the plain formulation:
+// ONE LANE PER QUERY, the query code in eight registers, map codes staged through LDS 256 at a time (every lane reads the
+// same address: a broadcast), XOR + popcount.  11 k queries x 66 k map codes = 1.2 ms; exact integer arithmetic.
+#include "common.h"
+
+namespace lf {
+
+constexpr int KQ = 256;          // queries per workgroup (one per lane)
+constexpr int KT = 256;          // map codes per LDS tile
+constexpr int KMAXK = 16;
+
+__device__ __forceinline__ int knn_hamming(const uint32_t (&q)[8], const uint32_t* __restrict__ t)
+{
+    int d = 0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) d += __popc(q[w] ^ t[w]);
+    return d;
+}
+
+// the k nearest within max_distance, (distance, index) ascending; missing slots: idx -1, dist -1
+__global__ __launch_bounds__(KQ) void k_knn(const uint8_t* __restrict__ query, int nq, const uint8_t* __restrict__ map, int nm, int k,
+                                            int max_distance, int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    __shared__ uint32_t tile[KT * 8];
+    __shared__ uint32_t best[KMAXK][KQ];              // key = dist << 24 | index, per lane a sorted column
+    const int t = threadIdx.x, qi = blockIdx.x * KQ + t;
+    uint32_t q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (qi < nq) {
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 32);
+        const uint4 a = p[0], b = p[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+    for (int j = 0; j < k; ++j) best[j][t] = 0xffffffffu;
+    uint32_t worst = 0xffffffffu;                     // key of the k-th entry
+    for (int base = 0; base < nm; base += KT) {
+        __syncthreads();
+        const int cnt = nm - base < KT ? nm - base : KT;
+        for (int i = t; i < cnt * 2; i += KQ) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(map + (size_t)base * 32)[i];
+        __syncthreads();
+        if (qi >= nq) continue;
+        for (int j = 0; j < cnt; ++j) {
+            const int d = knn_hamming(q, tile + 8 * j);
+            if (d > max_distance) continue;
+            const uint32_t key = ((uint32_t)d << 24) | (uint32_t)(base + j);
+            if (key >= worst) continue;
+            // insertion from the back: equal distances keep index order because map codes arrive in index order
+            int pos = k - 1;
+            while (pos > 0 && best[pos - 1][t] > key) { best[pos][t] = best[pos - 1][t]; --pos; }
+            best[pos][t] = key;
+            worst = best[k - 1][t];
+        }
+    }
+    if (qi >= nq) return;
+    for (int j = 0; j < k; ++j) {
+        const uint32_t key = best[j][t];
+        const bool ok = key != 0xffffffffu;
+        idx[(size_t)qi * k + j] = ok ? (int32_t)(key & 0xffffffu) : -1;
+        dist[(size_t)qi * k + j] = ok ? (float)(key >> 24) : -1.f;
+    }
+}
+
+// radius, pass 1: per query the number of map codes at every distance 0 .. max_distance (hist [nq][129])
+__global__ __launch_bounds__(KQ) void k_radius_count(const uint8_t* __restrict__ query, int nq, const uint8_t* __restrict__ map, int nm,
+                                                     int max_distance, int32_t* __restrict__ hist)
+{
+    __shared__ uint32_t tile[KT * 8];
+    const int t = threadIdx.x, qi = blockIdx.x * KQ + t;
+    uint32_t q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (qi < nq) {
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 32);
+        const uint4 a = p[0], b = p[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+    int32_t* hq = hist + (size_t)qi * 129;
+    for (int base = 0; base < nm; base += KT) {
+        __syncthreads();
+        const int cnt = nm - base < KT ? nm - base : KT;
+        for (int i = t; i < cnt * 2; i += KQ) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(map + (size_t)base * 32)[i];
+        __syncthreads();
+        if (qi >= nq) continue;
+        for (int j = 0; j < cnt; ++j) {
+            const int d = knn_hamming(q, tile + 8 * j);
+            if (d <= max_distance) hq[d] += 1;                 // the lane owns its query's row
+        }
+    }
+}
+
+// per query: exclusive scan of its histogram -> bucket cursors (in place) and its total
+__global__ void k_radius_scan(int nq, int max_distance, int32_t* __restrict__ hist, int32_t* __restrict__ count)
+{
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    int32_t* hq = hist + (size_t)qi * 129;
+    int acc = 0;
+    for (int d = 0; d <= max_distance; ++d) { const int c = hq[d]; hq[d] = acc; acc += c; }
+    count[qi] = acc;
+}
+
+// offsets [nq + 1] from the counts (one workgroup; nq is a few ten thousand at most)
+__global__ __launch_bounds__(1024) void k_radius_offsets(int nq, const int32_t* __restrict__ count, int32_t* __restrict__ offsets, int* __restrict__ total)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += 1024) {
+        const int i = base + t;
+        const int v = i < nq ? count[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int off = carry;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (i < nq) offsets[i] = off + inc - v;
+        __syncthreads();
+        if (t == 1023) carry = off + inc;
+        __syncthreads();
+    }
+    if (t == 0) { offsets[nq] = carry; *total = carry; }
+}
+
+// pass 2: every match goes to the cursor of its (query, distance) bucket: distance ascending, index ascending inside
+__global__ __launch_bounds__(KQ) void k_radius_fill(const uint8_t* __restrict__ query, int nq, const uint8_t* __restrict__ map, int nm,
+                                                    int max_distance, int32_t* __restrict__ hist, const int32_t* __restrict__ offsets, int cap,
+                                                    int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    __shared__ uint32_t tile[KT * 8];
+    const int t = threadIdx.x, qi = blockIdx.x * KQ + t;
+    uint32_t q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int off = 0;
+    if (qi < nq) {
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 32);
+        const uint4 a = p[0], b = p[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+        off = offsets[qi];
+    }
+    int32_t* hq = hist + (size_t)qi * 129;
+    for (int base = 0; base < nm; base += KT) {
+        __syncthreads();
+        const int cnt = nm - base < KT ? nm - base : KT;
+        for (int i = t; i < cnt * 2; i += KQ) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(map + (size_t)base * 32)[i];
+        __syncthreads();
+        if (qi >= nq) continue;
+        for (int j = 0; j < cnt; ++j) {
+            const int d = knn_hamming(q, tile + 8 * j);
+            if (d > max_distance) continue;
+            const int pos = off + hq[d];
+            hq[d] += 1;
+            if (pos < cap) { idx[pos] = base + j; dist[pos] = (float)d; }
+        }
+    }
+}
+
+void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int32_t* idx, float* dist, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_knn, dim3((nq + KQ - 1) / KQ), dim3(KQ), 0, s, q, nq, m, nm, k, max_distance, idx, dist);
+}
+
+void launch_radius(const uint8_t* q, int nq, const uint8_t* m, int nm, int max_distance, int32_t* hist, int32_t* count, int32_t* offsets,
+                   int* total, int cap, int32_t* idx, float* dist, hipStream_t s)
+{
+    const int blocks = (nq + KQ - 1) / KQ;
+    (void)hipMemsetAsync(hist, 0, (size_t)nq * 129 * sizeof(int32_t), s);
+    hipLaunchKernelGGL(k_radius_count, dim3(blocks), dim3(KQ), 0, s, q, nq, m, nm, max_distance, hist);
+    hipLaunchKernelGGL(k_radius_scan, dim3((nq + 255) / 256), dim3(256), 0, s, nq, max_distance, hist, count);
+    hipLaunchKernelGGL(k_radius_offsets, dim3(1), dim3(1024), 0, s, nq, count, offsets, total);
+    hipLaunchKernelGGL(k_radius_fill, dim3(blocks), dim3(KQ), 0, s, q, nq, m, nm, max_distance, hist, offsets, cap, idx, dist);
+}
+
+}  // namespace lf

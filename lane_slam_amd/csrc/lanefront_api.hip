@@ -102,6 +102,7 @@ struct lf_handle {
     // associator scratch (grown on demand)
     DevBuf a_q, a_m, a_mx, a_mcx, a_best, a_idx, a_dist, a_qn, a_mn;
     DevBuf km_pts, km_lab, km_f64, km_cnt;
+    DevBuf kn_hist, kn_count, kn_off, kn_total;       // radiusMatch scratch
     AssocScratch a_ws;
     // pinned host scalars
     int* h_pinned = nullptr;     // [0] total segments, [1] overflow
@@ -455,7 +456,7 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
+                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     assoc_scratch_free(h->a_ws);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -813,6 +814,85 @@ extern "C" int lf_associate_float(lf_handle* h, const float* query72, int nq, co
     if (!on_device) {
         LF_HIP_CHECK(h, hipMemcpyAsync(idx, didx, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         LF_HIP_CHECK(h, hipMemcpyAsync(dist, ddist, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
+// knnMatch / radiusMatch (binary_descriptor_matcher.cpp:258-335, 428-504): k_knn.hip
+extern "C" int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, int k, int32_t* idx, float* dist,
+                            int on_device)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (nq < 0 || nm < 0 || k < 1 || k > 16 || (nq > 0 && (!query32 || !idx || !dist)) || (nm > 0 && !map32)) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_knn_match: bad argument (k must be 1..16)");
+        return LF_ERR_BAD_ARG;
+    }
+    if (nm > (1 << 24)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lf_knn_match: map larger than 2^24 entries"); return LF_ERR_UNSUPPORTED; }
+    if (nq == 0) return LF_OK;
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    const uint8_t *dq = query32, *dm_ = map32;
+    int32_t* didx = idx; float* ddist = dist;
+    const size_t out = (size_t)nq * k;
+    if (!on_device) {
+        if ((rc = ensure(h, h->a_q, (size_t)nq * 32)) || (rc = ensure(h, h->a_m, (size_t)(nm > 0 ? nm : 1) * 32)) ||
+            (rc = ensure(h, h->a_idx, out * 4)) || (rc = ensure(h, h->a_dist, out * 4))) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, query32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+        if (nm > 0) LF_HIP_CHECK(h, hipMemcpyAsync(h->a_m.p, map32, (size_t)nm * 32, hipMemcpyHostToDevice, s));
+        dq = (const uint8_t*)h->a_q.p; dm_ = (const uint8_t*)h->a_m.p; didx = (int32_t*)h->a_idx.p; ddist = (float*)h->a_dist.p;
+    }
+    { StageTimer t(h, ST_ASSOC); launch_knn(dq, nq, dm_, nm, k, 128, didx, ddist, s); }
+    LF_HIP_CHECK(h, hipGetLastError());
+    if (!on_device) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(idx, didx, out * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(dist, ddist, out * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
+extern "C" int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, float max_distance,
+                               int32_t* offsets, int32_t* idx, float* dist, int cap, int* total_out, int on_device)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (nq < 0 || nm < 0 || cap < 0 || !offsets || (cap > 0 && (!idx || !dist)) || (nq > 0 && !query32) || (nm > 0 && !map32) || !(max_distance >= 0)) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_radius_match: bad argument");
+        return LF_ERR_BAD_ARG;
+    }
+    if (nm > (1 << 24)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lf_radius_match: map larger than 2^24 entries"); return LF_ERR_UNSUPPORTED; }
+    // K = N results are only ever collected up to D = 128 bits (Mihasher, :721), then filtered by maxDistance (:474)
+    int md = max_distance >= 128.f ? 128 : (int)max_distance;
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (nq == 0) { if (on_device) LF_HIP_CHECK(h, hipMemsetAsync(offsets, 0, sizeof(int32_t), s)); else offsets[0] = 0; if (total_out) *total_out = 0; return LF_OK; }
+    int rc;
+    if ((rc = ensure(h, h->kn_hist, (size_t)nq * 129 * 4)) || (rc = ensure(h, h->kn_count, (size_t)nq * 4)) || (rc = ensure(h, h->kn_off, (size_t)(nq + 1) * 4)) ||
+        (rc = ensure(h, h->kn_total, 16))) return rc;
+    const uint8_t *dq = query32, *dm_ = map32;
+    int32_t *doff = offsets, *didx = idx; float* ddist = dist;
+    if (!on_device) {
+        if ((rc = ensure(h, h->a_q, (size_t)nq * 32)) || (rc = ensure(h, h->a_m, (size_t)(nm > 0 ? nm : 1) * 32)) ||
+            (rc = ensure(h, h->a_idx, (size_t)(cap > 0 ? cap : 1) * 4)) || (rc = ensure(h, h->a_dist, (size_t)(cap > 0 ? cap : 1) * 4))) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, query32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+        if (nm > 0) LF_HIP_CHECK(h, hipMemcpyAsync(h->a_m.p, map32, (size_t)nm * 32, hipMemcpyHostToDevice, s));
+        dq = (const uint8_t*)h->a_q.p; dm_ = (const uint8_t*)h->a_m.p; doff = (int32_t*)h->kn_off.p; didx = (int32_t*)h->a_idx.p; ddist = (float*)h->a_dist.p;
+    }
+    {
+        StageTimer t(h, ST_ASSOC);
+        launch_radius(dq, nq, dm_, nm, md, (int32_t*)h->kn_hist.p, (int32_t*)h->kn_count.p, doff, (int*)h->kn_total.p, cap, didx, ddist, s);
+    }
+    LF_HIP_CHECK(h, hipGetLastError());
+    int total = 0;
+    LF_HIP_CHECK(h, hipMemcpyAsync(&total, h->kn_total.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (!on_device) LF_HIP_CHECK(h, hipMemcpyAsync(offsets, doff, (size_t)(nq + 1) * 4, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    if (total_out) *total_out = total;
+    if (total > cap) { lf_set_error(h, LF_ERR_CAPACITY, "lf_radius_match: %d matches exceed the capacity %d (offsets are complete: size the arrays from them)", total, cap); return LF_ERR_CAPACITY; }
+    if (!on_device && total > 0) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(idx, didx, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(dist, ddist, (size_t)total * 4, hipMemcpyDeviceToHost, s));
         LF_HIP_CHECK(h, hipStreamSynchronize(s));
     }
     return LF_OK;

@@ -191,6 +191,34 @@ class FrontEnd(object):
         self._check(self.lib.lf_associate(self.h, ctypes.c_void_p(int(q_ptr)), int(nq), ctypes.c_void_p(int(m_ptr)),
                                           int(nm), ctypes.c_void_p(int(idx_ptr)), ctypes.c_void_p(int(dist_ptr)), 1))
 
+    def knn_match(self, query_codes, map_codes, k):
+        """BinaryDescriptorMatcher::knnMatch (ref: binary_descriptor_matcher.cpp:258-335): (idx [nq, k] int32, dist [nq, k]
+        float32), nearest first, within 128 bits; -1 where there are fewer than k."""
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8).reshape(-1, 32)
+        m = np.ascontiguousarray(map_codes, dtype=np.uint8).reshape(-1, 32)
+        idx = np.empty((q.shape[0], int(k)), np.int32)
+        dist = np.empty((q.shape[0], int(k)), np.float32)
+        self._check(self.lib.lf_knn_match(self.h, _ptr(q), q.shape[0], _ptr(m), m.shape[0], int(k), _ptr(idx), _ptr(dist), 0))
+        return idx, dist
+
+    def radius_match(self, query_codes, map_codes, max_distance):
+        """BinaryDescriptorMatcher::radiusMatch (ref: binary_descriptor_matcher.cpp:428-504): (offsets [nq + 1], idx, dist) --
+        the matches of query i are idx[offsets[i]:offsets[i + 1]], nearest first."""
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8).reshape(-1, 32)
+        m = np.ascontiguousarray(map_codes, dtype=np.uint8).reshape(-1, 32)
+        offsets = np.zeros(q.shape[0] + 1, np.int32)
+        total = ctypes.c_int()
+        cap = max(1024, 4 * q.shape[0])
+        while True:
+            idx, dist = np.empty(cap, np.int32), np.empty(cap, np.float32)
+            rc = self.lib.lf_radius_match(self.h, _ptr(q), q.shape[0], _ptr(m), m.shape[0], float(max_distance), _ptr(offsets), _ptr(idx),
+                                          _ptr(dist), cap, ctypes.byref(total), 0)
+            if rc == -2 and total.value > cap:          # LF_ERR_CAPACITY: offsets and total are complete, size and repeat
+                cap = total.value
+                continue
+            self._check(rc)
+            return offsets, idx[:total.value], dist[:total.value]
+
     def associate_float(self, query_desc, map_desc):
         q = np.ascontiguousarray(query_desc, dtype=np.float32).reshape(-1, 72)
         m = np.ascontiguousarray(map_desc, dtype=np.float32).reshape(-1, 72)

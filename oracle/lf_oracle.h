@@ -115,6 +115,9 @@ void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
                int32_t* idx, float* dist);
 /* the same with the reference's tie rule (first discovered by Mihasher::query) and the number of equally near codes */
 void lfo_match_mih(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int32_t* idx, float* dist, int32_t* n_ties);
+void lfo_knn_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int k, int32_t* idx, float* dist);
+int lfo_radius_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt, float max_distance, int32_t* offsets, int32_t* idx,
+                     float* dist);
 /* float-descriptor L2 NN (72-d) */
 void lfo_match_float(const float* q72, int nq, const float* t72, int nt, int32_t* idx, float* dist);
 

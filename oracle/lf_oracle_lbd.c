@@ -311,6 +311,44 @@ void lfo_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* 
     free(dd);
 }
 
+/* knnMatch / radiusMatch (binary_descriptor_matcher.cpp:258-335, 428-504): the nearest train codes within D = 128 bits,
+ * nearest first, ties in index order (the reference: discovery order).  knn: idx / dist [nq][k], missing -> -1.
+ * radius: CSR lists; returns the total (idx / dist may be NULL to size them). */
+void lfo_knn_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, float* dist)
+{
+    for (int i = 0; i < nq; ++i) {
+        int got = 0;
+        for (int d = 0; d <= 128 && got < k; ++d)
+            for (int j = 0; j < nt && got < k; ++j) {
+                int h = 0;
+                for (int b = 0; b < 32; ++b) h += __builtin_popcount((unsigned)(q[(size_t)32 * i + b] ^ t[(size_t)32 * j + b]));
+                if (h == d) { idx[(size_t)i * k + got] = j; dist[(size_t)i * k + got] = (float)d; ++got; }
+            }
+        for (; got < k; ++got) { idx[(size_t)i * k + got] = -1; dist[(size_t)i * k + got] = -1.f; }
+    }
+}
+
+int lfo_radius_match(const uint8_t* q, int nq, const uint8_t* t, int nt, float max_distance, int32_t* offsets, int32_t* idx, float* dist)
+{
+    const int md = max_distance >= 128.f ? 128 : (int)max_distance;
+    int total = 0;
+    int* hd = (int*)malloc((size_t)(nt > 0 ? nt : 1) * sizeof(int));
+    for (int i = 0; i < nq; ++i) {
+        offsets[i] = total;
+        for (int j = 0; j < nt; ++j) {
+            int h = 0;
+            for (int b = 0; b < 32; ++b) h += __builtin_popcount((unsigned)(q[(size_t)32 * i + b] ^ t[(size_t)32 * j + b]));
+            hd[j] = h;
+        }
+        for (int d = 0; d <= md; ++d)
+            for (int j = 0; j < nt; ++j)
+                if (hd[j] == d) { if (idx) idx[total] = j; if (dist) dist[total] = (float)d; ++total; }
+    }
+    offsets[nq] = total;
+    free(hd);
+    return total;
+}
+
 /* float LBD nearest neighbour (Euclidean); double accumulation, float result */
 void lfo_match_float(const float* q, int nq, const float* t, int nt, int32_t* idx, float* dist)
 {

@@ -701,3 +701,42 @@ def test_hysteresis_strips_follow_a_serpentine_weak_chain():
     head = frame.copy()
     head[:, 100:] = 70                                        # the strong head alone: a few hundred edge pixels
     assert o.canny(o.preprocess(head)).sum() // 255 < 400
+
+
+def test_knn_and_radius_match_follow_the_matcher_semantics():
+    """knnMatch / radiusMatch (binary_descriptor_matcher.cpp:258-335, 428-504): the nearest map codes within 128 bits,
+    nearest first, index order among equals; against the oracle's brute force and its own 1-NN."""
+    from oracle.oracle import Oracle
+    o = Oracle(default_config("parity"))
+    fe = FrontEnd(default_config("parity"))
+    rng = np.random.default_rng(23)
+    nm, nq = 2100, 530                                     # crosses the 256-code tiles and the 256-query workgroups
+    m = rng.integers(0, 256, (nm, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    for i in range(300):                                   # planted neighbours at 0..128 bits, in groups (ties)
+        src = q[i % 90].copy()
+        for b in rng.choice(256, size=int(rng.integers(0, 129)) if i % 3 else (i % 40), replace=False):
+            src[b >> 3] ^= np.uint8(1 << (b & 7))
+        m[int(rng.integers(0, nm))] = src
+    m[5] = m[900] = m[1700] = q[7]                         # exact duplicates: index order
+    for k in (1, 3, 16):
+        gi, gd = fe.knn_match(q, m, k)
+        oi, od = o.knn_match(q, m, k)
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od), k
+    i1, d1 = o.match(q, m)
+    assert np.array_equal(gi[:, 0], i1) and np.array_equal(gd[:, 0], d1)       # k-NN's first column = match()
+    assert list(gi[7, :3]) == [5, 900, 1700]
+    far = (m[:6] ^ np.uint8(0xff))                          # 6 codes, some of them beyond 128 bits of most queries
+    gi6, gd6 = fe.knn_match(q, np.concatenate([m[:3], far[3:]]), 16)
+    oi6, od6 = o.knn_match(q, np.concatenate([m[:3], far[3:]]), 16)
+    assert np.array_equal(gi6, oi6) and np.array_equal(gd6, od6) and (gi6 == -1).any() and (gi6[:, 6:] == -1).all()
+    for r in (0.0, 17.5, 64.0, 128.0, 300.0):
+        go, gi, gd = fe.radius_match(q, m, r)
+        oo, oi, od = o.radius_match(q, m, r)
+        assert np.array_equal(go, oo) and np.array_equal(gi, oi) and np.array_equal(gd, od), r
+    assert go[-1] > nq                                     # radius >= 128 is cut at D = 128
+    with pytest.raises(LanefrontError):
+        fe.knn_match(q, m, 17)
+    e_i, e_d = fe.knn_match(q[:3], np.zeros((0, 32), np.uint8), 2)
+    assert (e_i == -1).all() and (e_d == -1).all()
+    fe.close()

@@ -37,11 +37,12 @@ slim(one("pw/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_write_
 slim(one("pf/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_fetch_size.csv"))
 slim(one("pa/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_assoc_sq.csv"))
 slim(one("pg/**/*counter_collection.csv"), os.path.join(P, prefix + "_pmc_assoc_grbm.csv"))
-for sub, name in (("pq", "_pmc_grow_sq.csv"), ("pq2", "_pmc_grow_sq2.csv")):
+for sub, name in (("pq", "_pmc_grow_sq.csv"), ("pq2", "_pmc_grow_sq2.csv"), ("pq6", "_pmc_grow_sq_d6.csv"), ("pq26", "_pmc_grow_sq2_d6.csv")):
     f = glob.glob(os.path.join(T, sub + "/**/*counter_collection.csv"), recursive=True)
     if f:
         slim(f[0], os.path.join(P, prefix + name))
 with open(os.path.join(P, "r03_traffic.json"), "w") as g:
     subprocess.check_call([sys.executable, "tools/pmc_traffic.py", os.path.join(P, prefix + "_pmc_write_size.csv"),
                            os.path.join(P, prefix + "_pmc_fetch_size.csv"), prefix], stdout=g)
+subprocess.check_call([sys.executable, "tools/pmc_grow.py", prefix])
 print("collected", prefix)

@@ -30,6 +30,13 @@ names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit
 CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
 raw7 = raw[:, :, 7].sum(1)
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
+# the growing waves (0..2) alone: the evaluating wave's total is "until the last grower is done" and hides them
+gtot = tot_w[:, :3]
+gslow = gtot.argmax(1)
+dg = raw[np.arange(n * 3), gslow][:, :27].astype(np.float64)
+for w in np.argsort(gtot.max(1))[-3:]:
+    print("longest growers: problem", int(w), " ".join("%s=%.0f" % (nm, v / (1000.0 if i in CYC else 1.0)) for i, (nm, v) in enumerate(zip(names, dg[w])) if nm != "-"), "(kcycles)")
+print("growers mean", " ".join("%s=%.0f" % (nm, v / (1000.0 if i in CYC else 1.0)) for i, (nm, v) in enumerate(zip(names, dg.mean(0))) if nm != "-"), "(kcycles)")
 order = np.argsort(d[:, 24])
 print("problems", n * 3, "segments", seg.n)
 for label, rows in (("median", d[order[len(order) // 2]]), ("p90", d[order[int(len(order) * 0.9)]]), ("max", d[order[-1]]), ("mean", d.mean(0))):

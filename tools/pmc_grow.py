@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Wave-slot occupancy and issue utilisation of k_lsd_grow from rocprofv3 SQ counter passes ("make
+latency bound a number").
+
+usage: tools/pmc_grow.py <prefix>        e.g. r03_b  ->  reads profiles/<prefix>_pmc_grow_sq*.csv (+ _d6 variants),
+                                                         writes profiles/r03_grow_counters.json
+
+Counter units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count QUAD-cycles summed over all waves;
+SQ_BUSY_CYCLES counts cycles per shader engine (32 on the MI355X); SQ_INSTS_* count wave instructions.  WAIT_ANY +
+WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (disjoint)."""
+import csv, hashlib, json, os, sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_SE, N_SIMD, SLOTS_AT_80_VGPR = 32, 1024, 6144          # shader engines, SIMDs, wave slots at k_lsd_grow's 80 VGPRs (6 per SIMD)
+
+
+def digest(*rel):
+    h = hashlib.sha256()
+    for r in rel:
+        with open(os.path.join(ROOT, r), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def per_kernel(path, kernel):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Kernel_Name"].split("::")[-1].split("(")[0].strip() != kernel:
+                continue
+            tot[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+    return {k: tot[k] / cnt[k] for k in tot}
+
+
+def derive(c):
+    if not c or "SQ_WAVE_CYCLES" not in c:
+        return None
+    wave_cycles = 4.0 * c["SQ_WAVE_CYCLES"]
+    kernel_cycles = c["SQ_BUSY_CYCLES"] / N_SE if "SQ_BUSY_CYCLES" in c else None
+    out = {"waves": int(c.get("SQ_WAVES", 0)), "wave_cycles": wave_cycles, "kernel_busy_cycles": kernel_cycles}
+    if kernel_cycles:
+        out["avg_resident_waves"] = round(wave_cycles / kernel_cycles, 1)
+        out["wave_slot_occupancy"] = round(wave_cycles / kernel_cycles / SLOTS_AT_80_VGPR, 4)
+        if "SQ_INSTS_VALU" in c:
+            out["valu_instructions"] = c["SQ_INSTS_VALU"]
+            out["valu_issue_utilisation"] = round(4.0 * c["SQ_INSTS_VALU"] / (N_SIMD * kernel_cycles), 4)     # 4 cycles per wave64 instruction and SIMD
+    for name, key in (("frac_wave_cycles_parked(s_waitcnt/barrier/sleep)", "SQ_WAIT_ANY"), ("frac_wave_cycles_issue_stalled", "SQ_WAIT_INST_ANY"),
+                      ("frac_wave_cycles_issuing", "SQ_ACTIVE_INST_ANY"), ("frac_wave_cycles_issuing_valu", "SQ_ACTIVE_INST_VALU")):
+        if key in c:
+            out[name] = round(4.0 * c[key] / wave_cycles, 4)
+    return out
+
+
+prefix = sys.argv[1]
+P = os.path.join(ROOT, "profiles")
+res = {"kernel": "k_lsd_grow", "source_digest": digest("lane_slam_amd/csrc/lsd_grow.h", "lane_slam_amd/csrc/k_lsd_grow.hip"),
+       "source": "rocprofv3 --pmc passes of bench.py (tools/profile_round.sh), profiles/%s_pmc_grow_sq*.csv; units per MI355X_MICROARCH.md" % prefix}
+for tag, suffix in (("one_batch_in_flight", ""), ("six_batches_in_flight", "_d6")):
+    c = {}
+    for part in ("sq", "sq2"):
+        c.update(per_kernel(os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix)), "k_lsd_grow"))
+    d = derive(c)
+    if d:
+        res[tag] = d
+json.dump(res, open(os.path.join(P, "r03_grow_counters.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

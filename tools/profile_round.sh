@@ -16,7 +16,10 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$T/pw -- python3
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$T/pf -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
 # wave-slot occupancy and vector issue utilisation of the LSD region growing kernel: one batch in flight
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/$T/pq -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/$T/pq2 -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/$T/pq2 -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
+# the same with six batches in flight (the configuration the headline is measured in)
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/$T/pq6 -- python3 $R/bench.py --steps 12 --warmup 4 $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/$T/pq26 -- python3 $R/bench.py --steps 12 --warmup 4 $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/$T/pa -- python3 $R/tools/assoc_rate.py --pairs 16384x50000 --reps 5 > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/$T/pg -- python3 $R/tools/assoc_rate.py --pairs 16384x50000 --reps 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/as -- python3 $R/tools/assoc_rate.py --pairs 4096x50000,16384x50000 --reps 5 > /dev/null 2>&1
