@@ -399,6 +399,14 @@ int lf_keylines_debug_fetch(lf_handle* h, int octave, int what, void* dst, size_
 int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
                          int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
                          int* frame_status);
+/* The same with the ENTROPY DECODER ON THE DEVICE as well (k_jhuff.hip): the host only parses the headers; unstuffing,
+ * Huffman decoding (self-synchronising subsequences, one thread per 128 bytes), DC prediction and everything after it run on
+ * the handle's stream.  Same streams accepted, same output bits, same per-frame status as lf_jpeg_decode_batch.  n_threads:
+ * host threads for header parsing and for copying the entropy-coded bytes into pinned memory (<= 0: up to 16).  The call
+ * returns when the batch is decoded (the per-frame status comes from the device). */
+int lf_jpeg_decode_batch_gpu(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
+                             int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
+                             int* frame_status);
 /* size and layout of one stream without decoding it (hmax x vmax = luma sampling factors) */
 int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax);
 /* the handle's own device staging buffer for input frames ([max_frames][in_rows][in_cols][3] u8): decode

@@ -25,7 +25,7 @@ EXPORTS = (
     "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
     "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_step_host", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
-    "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match",
+    "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu",
 )
 LF_MAX_OCTAVES = 5
 
@@ -102,6 +102,8 @@ def load():
     lib.lf_jpeg_decode_batch.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ci, ci, ci, vp, ci, ci,
                                          ctypes.POINTER(ci)]
     lib.lf_jpeg_decode_batch.restype = ci
+    lib.lf_jpeg_decode_batch_gpu.argtypes = lib.lf_jpeg_decode_batch.argtypes
+    lib.lf_jpeg_decode_batch_gpu.restype = ci
     lib.lf_jpeg_info.argtypes = [vp, ctypes.c_size_t] + [ctypes.POINTER(ci)] * 5
     lib.lf_jpeg_info.restype = ci
     lib.lf_frames_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]

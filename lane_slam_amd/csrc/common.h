@@ -217,6 +217,13 @@ void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const j
                         const uint32_t* entries, const uint32_t* block_end, uint8_t* planes, uint8_t* frames,
                         hipStream_t s);
 
+void launch_jpeg_color(const JpegGeom& g, int n_frames, const void* hdrs, size_t hdr_stride, const uint8_t* planes, uint8_t* frames, hipStream_t s);
+// entropy decoding on the device (k_jhuff.hip)
+namespace jpeg { struct DevFrame; }
+void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, jpeg::DevFrame* frames, const uint8_t* bytes, uint8_t* clean,
+                      uint32_t* seg_begin, void* info, uint32_t* sub, int16_t* coef, int* status, uint8_t* planes, hipStream_t s);
+size_t jh_info_bytes();
+
 // ---- SegmentList wire bodies (k_msgs.hip)
 void launch_msg_layout(int n_frames, int stage, const int* frame_offset, const uint8_t* keep, int* counts,
                        long long* byte_offset, hipStream_t s);

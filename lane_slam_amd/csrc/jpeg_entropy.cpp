@@ -398,6 +398,59 @@ static int decode_coefficients_impl(const uint8_t* data, size_t size, FrameCoefs
     return LF_OK;
 }
 
+int prepare_device_frame(const uint8_t* data, size_t size, int expect_rows, int expect_cols, DevFrame& out, size_t* scan_begin)
+{
+    out.hdr.valid = 0;
+    out.hdr.nblocks = 0;
+    out.scan_off = out.scan_len = 0;
+    if (scan_begin) *scan_begin = 0;
+    Stream j;
+    int rc = parse_headers(data, size, j);
+    if (rc != LF_OK) return rc;
+    if (expect_rows > 0 && expect_cols > 0 && (j.rows != expect_rows || j.cols != expect_cols)) return LF_ERR_BAD_ARG;
+    FrameHeader& h = out.hdr;
+    h.ncomp = j.ncomp;
+    h.hmax = j.hmax;
+    h.vmax = j.vmax;
+    h.mcux = (j.cols + 8 * j.hmax - 1) / (8 * j.hmax);
+    h.mcuy = (j.rows + 8 * j.vmax - 1) / (8 * j.vmax);
+    h.is_rgb = j.is_rgb ? 1 : 0;
+    const int luma_blocks = j.ncomp == 1 ? 1 : j.hmax * j.vmax;
+    const int bpm = j.ncomp == 1 ? 1 : luma_blocks + 2;
+    const long nblocks = (long)h.mcux * h.mcuy * bpm;
+    if (nblocks > (1L << 24)) return LF_ERR_UNSUPPORTED;
+    const size_t scan_len = (size_t)(j.end - j.scan);
+    if ((size_t)nblocks > 4 * scan_len + 64) return LF_ERR_DECODE;          // same bound as the host decoder: too short for its size
+    if (scan_len >= (1u << 28)) return LF_ERR_UNSUPPORTED;
+    h.nblocks = (int32_t)nblocks;
+    h.entry_base = h.block_base = 0;
+    for (int c = 0; c < 3; ++c)
+        std::memcpy(h.qt[c], j.qt[j.comp[c < j.ncomp ? c : 0].tq], sizeof(h.qt[c]));
+    out.restart = j.restart;
+    out.n_mcu = h.mcux * h.mcuy;
+    out.bpm = bpm;
+    out.luma = luma_blocks;
+    for (int c = 0; c < 3; ++c) {
+        const Component& cp = j.comp[c < j.ncomp ? c : 0];
+        out.tab_dc[c] = cp.td;
+        out.tab_ac[c] = 4 + cp.ta;
+    }
+    for (int t = 0; t < 8; ++t) {
+        const HuffTable& src = t < 4 ? j.dc[t] : j.ac[t - 4];
+        HuffDev& d = out.tabs[t];
+        d.present = src.present ? 1 : 0;
+        if (!src.present) { std::memset(&d, 0, sizeof(d)); continue; }
+        std::memcpy(d.fast, src.fast, sizeof(d.fast));
+        std::memcpy(d.maxcode, src.maxcode, sizeof(d.maxcode));
+        std::memcpy(d.delta, src.delta, sizeof(d.delta));
+        std::memcpy(d.vals, src.vals, sizeof(d.vals));
+    }
+    out.scan_len = (uint32_t)scan_len;
+    if (scan_begin) *scan_begin = (size_t)(j.scan - data);
+    h.valid = 1;
+    return LF_OK;
+}
+
 int decode_coefficients(const uint8_t* data, size_t size, FrameCoefs& out, int expect_rows, int expect_cols)
 {
     // never let an exception cross into a worker thread or the C ABI

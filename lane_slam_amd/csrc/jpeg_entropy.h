@@ -42,6 +42,34 @@ struct FrameCoefs {
     std::vector<uint32_t> block_end;    // entries of blocks 0..b, per block (hdr.nblocks valid)
 };
 
+// ---- entropy decoding ON THE DEVICE (k_jhuff.hip): the host only parses the headers.
+// One canonical Huffman table as both decoders use it: 9-bit lookahead ((length << 8) | symbol, 0 = longer code), then
+// maxcode / delta per length (T.81 Annex C / F.2.2.3).
+struct HuffDev {
+    uint16_t fast[512];
+    int32_t maxcode[18];
+    int32_t delta[17];
+    int32_t present;
+    uint8_t vals[256];
+};
+// Per frame, copied to the device as is.
+struct DevFrame {
+    FrameHeader hdr;            // valid = 1 when the headers parsed; the device clears it when the entropy data is corrupt
+    uint32_t scan_off;          // entropy-coded data of this frame in the batch's byte buffer (raw: stuffed, with markers)
+    uint32_t scan_len;          // bytes from the end of the SOS header to the end of the stream
+    int32_t restart;            // MCUs per restart interval, 0 = none
+    int32_t n_mcu, bpm, luma;   // MCUs in the scan, blocks per MCU, luma blocks per MCU
+    int32_t tab_dc[3], tab_ac[3];   // per component: its DC table (0..3) and AC table (4..7) in tabs[]
+    uint32_t coef_base;         // first block of this frame in the batch's dense coefficient array
+    uint32_t clean_off;         // this frame's region of the unstuffed byte buffer / of the per-subsequence arrays
+    uint32_t sub_off, seg_off;
+    int32_t max_sub, max_seg;   // capacity of those regions
+    HuffDev tabs[8];
+};
+// Headers only: fills out (tables, geometry, where the scan starts); lf_status.  scan_begin = offset of the entropy data
+// in `data`.
+int prepare_device_frame(const uint8_t* data, size_t size, int expect_rows, int expect_cols, DevFrame& out, size_t* scan_begin);
+
 // rows / cols / components / sampling of a stream; lf_status.
 int peek(const uint8_t* data, size_t size, int* rows, int* cols, int* ncomp, int* hmax, int* vmax);
 

@@ -1,0 +1,506 @@
+// JPEG entropy decoding ON THE DEVICE: the Huffman-coded scan of every frame of a batch is
+// decoded by the GPU, the host only parses the headers (jpeg_entropy.cpp: prepare_device_frame).  Replaces the decode
+// half of duckietown_utils.jpg.image_cv_from_jpg = cv2.imdecode (ref: src/duckietown/include/duckietown_utils/jpg.py:21-31,
+// called per frame from src/line_detector/src/line_detector_node.py:153-158), i.e. libjpeg-turbo's baseline decoder
+// (ITU-T T.81 F.2.2); same results, bit for bit, as the host decoder and oracle/lf_oracle_jpeg.c.
+//
+// A Huffman stream has no random access: where a code starts is only known once everything before it is decoded.  But
+// it SELF-SYNCHRONISES: a decoder started at a wrong position falls into step with the true sequence of codes after a
+// few symbols.  So the scan is cut into subsequences of 128 bytes, one thread each:
+//   k_jh_unstuff   per frame: removes the stuffed zeros (FF 00 -> FF) and the restart markers, notes where every restart
+//                  interval begins (an interval starts byte aligned, at an MCU boundary, with a known decoder state) and
+//                  where the scan ends -- three passes over ~50 KB, prefix counts by ballot / LDS
+//   k_jh_decode    per frame, 256 threads.  Pass 0: every thread decodes its subsequence from an ASSUMED state (first
+//                  bit, start of an MCU) and records the state in which it crosses into the next subsequence.  Passes
+//                  1, 2, ...: a thread whose predecessor handed over a different state than the one it started from decodes
+//                  again from that state; when nothing changes any more every subsequence has its true entry state
+//                  (subsequence 0 of an interval is exact from the start, so after pass p the first p + 1 are: at most as
+//                  many passes as subsequences, two or three in practice).  Then the blocks completed per subsequence are
+//                  prefix-summed and a last decode writes the quantised coefficients (int16, natural order, dense 64 per
+//                  block; DC still as differences) and performs the checks of a sequential decoder: invalid code, run past
+//                  63, DC size > 11, reading beyond the interval, a restart interval of the wrong length.
+//   k_jh_dc        DC prediction: running sum per component over the blocks of a restart interval
+//   k_jpeg_idct_dense  dequantisation + the 13-bit integer inverse DCT of k_jpeg.hip on the dense blocks
+// Chroma upsampling and colour conversion are k_jpeg.hip's k_jpeg_color, unchanged.
+#include "common.h"
+#include "jpeg_entropy.h"
+
+namespace lf {
+
+constexpr int JH_T = 256;
+constexpr int JH_SB = 128;         // clean bytes per subsequence
+
+struct JhInfo { int clean_len, n_seg, n_sub, err; };
+
+__constant__ uint8_t c_zigzag[64] = {
+    0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+    35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+
+// ---------------------------------------------------------------------------------------------- k_jh_unstuff
+// classification of raw byte i: 0 dropped (stuffed zero / marker byte), 1 kept, 2 first byte of an RSTn marker, 3 terminal
+__device__ __forceinline__ int jh_classify(const uint8_t* raw, uint32_t i, uint32_t L, int restart)
+{
+    const uint32_t cur = raw[i];
+    if (cur == 0xFFu) {
+        const uint32_t nxt = i + 1 < L ? raw[i + 1] : 0xD9u;
+        if (nxt == 0u) return 1;
+        if (restart && nxt >= 0xD0u && nxt <= 0xD7u) return 2;
+        return 3;
+    }
+    if (i > 0 && raw[i - 1] == 0xFFu && (cur == 0u || (restart && cur >= 0xD0u && cur <= 0xD7u))) return 0;
+    return 1;
+}
+
+__global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ bytes,
+                                                     uint8_t* __restrict__ clean, uint32_t* __restrict__ seg_begin, JhInfo* __restrict__ info)
+{
+    __shared__ uint32_t s_term;
+    __shared__ int s_wk[4], s_wm[4], s_ck, s_cm, s_err;
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const jpeg::DevFrame& F = frames[f];
+    JhInfo* I = info + f;
+    if (!F.hdr.valid) { if (t == 0) { I->clean_len = 0; I->n_seg = 0; I->n_sub = 0; I->err = 0; } return; }
+    const uint8_t* raw = bytes + F.scan_off;
+    const uint32_t L = F.scan_len;
+    uint8_t* out = clean + F.clean_off;
+    uint32_t* sb = seg_begin + F.seg_off;
+    if (t == 0) { s_term = L; s_ck = 0; s_cm = 0; s_err = 0; }
+    __syncthreads();
+    // the scan ends at the first marker that is not a restart marker (EOI, normally)
+    uint32_t term = L;
+    for (uint32_t i = t; i < L; i += JH_T)
+        if (raw[i] == 0xFFu && jh_classify(raw, i, L, F.restart) == 3) { term = i; break; }
+    atomicMin(&s_term, term);
+    __syncthreads();
+    const uint32_t T = s_term;
+    const int expected_seg = F.restart > 0 ? (F.n_mcu + F.restart - 1) / F.restart : 1;
+    // chunks of 128 raw bytes per thread, rounds of 256 chunks: kept bytes and restart markers before every chunk
+    for (uint32_t base = 0; base < T; base += (uint32_t)JH_T * 128u) {
+        const uint32_t c0 = base + (uint32_t)t * 128u;
+        const uint32_t c1 = c0 + 128u < T ? c0 + 128u : T;
+        int kept = 0, marks = 0;
+        for (uint32_t i = c0; i < c1; ++i) { const int cl = jh_classify(raw, i, L, F.restart); kept += cl == 1; marks += cl == 2; }
+        int ik = kept, im = marks;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ik, d), b = __shfl_up(im, d); if (lane >= d) { ik += a; im += b; } }
+        if (lane == 63) { s_wk[wave] = ik; s_wm[wave] = im; }
+        __syncthreads();
+        int pos = s_ck, ord = s_cm;
+        for (int w = 0; w < wave; ++w) { pos += s_wk[w]; ord += s_wm[w]; }
+        pos += ik - kept; ord += im - marks;
+        for (uint32_t i = c0; i < c1; ++i) {
+            const int cl = jh_classify(raw, i, L, F.restart);
+            if (cl == 1) out[pos++] = raw[i];
+            else if (cl == 2) {
+                // RSTm: m counts modulo 8 (T.81 E.1.4); the next interval starts at the next clean byte
+                if ((int)raw[i + 1] != 0xD0 + (ord & 7)) atomicOr(&s_err, 1);
+                if (ord + 1 < F.max_seg) sb[ord + 1] = (uint32_t)pos;
+                ++ord;
+            }
+        }
+        __syncthreads();
+        if (t == JH_T - 1) { s_ck = pos; s_cm = ord; }
+        __syncthreads();
+    }
+    const int clean_len = s_ck, found = s_cm + 1;
+    for (int i = t; i < 32; i += JH_T) out[clean_len + i] = 0;          // the bit reader may look (never consume) past the end
+    if (t == 0) {
+        int err = s_err;
+        int n_seg = found;
+        if (found < expected_seg) err |= 1;                               // a restart marker is missing
+        if (n_seg > expected_seg) n_seg = expected_seg;                   // whatever follows the last MCU is ignored, as a sequential decoder does
+        if (n_seg > F.max_seg - 1) { n_seg = F.max_seg - 1; err |= 1; }
+        sb[0] = 0u;
+        // the interval after the last one used starts where the data of interest ends
+        if (n_seg == found) sb[n_seg] = (uint32_t)clean_len;
+        I->clean_len = clean_len; I->n_seg = n_seg; I->n_sub = 0; I->err = err;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_jh_decode
+struct JhTabs { jpeg::HuffDev t[8]; };
+
+__device__ __forceinline__ uint32_t jh_peek32(const uint8_t* clean, uint32_t bit)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, clean + (bit >> 3), 8);
+    v = __builtin_bswap64(v);
+    return (uint32_t)((v << (bit & 7u)) >> 32);
+}
+
+// one Huffman code from the top of w: returns length (0: no code of up to 16 bits matches) and the symbol
+__device__ __forceinline__ int jh_code(const jpeg::HuffDev& h, uint32_t w, int& sym)
+{
+    const uint32_t e = h.fast[w >> 23];
+    if (e) { sym = (int)(e & 255u); return (int)(e >> 8); }
+    const int code16 = (int)(w >> 16);
+    for (int len = 10; len <= 16; ++len) {
+        const int c = code16 >> (16 - len);
+        if (c <= h.maxcode[len]) { sym = (int)h.vals[(c + h.delta[len]) & 255]; return len; }
+    }
+    sym = 0;
+    return 0;
+}
+
+struct JhState { uint32_t bit; int blk, k; };     // next symbol starts at `bit`; block `blk` of the MCU; coefficient k (0: DC code next)
+
+// Decodes the symbols that START in [st.bit, limit).  WRITE = false: speculative (errors only re-align), returns the number of
+// blocks completed.  WRITE = true: true state; coefficients go to coef (block index cur, stops at end_block); err is set on
+// anything a sequential decoder rejects.
+template <bool WRITE>
+__device__ __forceinline__ int jh_span(const JhTabs& tabs, const jpeg::DevFrame& F, const uint8_t* clean, JhState& st, uint32_t limit,
+                                       uint32_t end_bit, int16_t* __restrict__ coef, int cur, int end_block, int& err)
+{
+    int done = 0;
+    const int luma = F.luma, bpm = F.bpm;
+    while (st.bit < limit) {
+        if (WRITE && cur >= end_block) break;
+        const int comp = st.blk < luma ? 0 : st.blk - luma + 1;
+        const uint32_t w = jh_peek32(clean, st.bit);
+        int sym;
+        bool block_done = false;
+        if (st.k == 0) {
+            const int len = jh_code(tabs.t[F.tab_dc[comp]], w, sym);
+            if (len == 0 || sym > 11) {
+                if (WRITE) { err |= 2; return done; }
+                st.bit += 1; continue;
+            }
+            if (WRITE && sym) {
+                // T.81 F.2.2.1 receive + extend
+                const int v = (int)((w << len) >> (32 - sym));
+                coef[(size_t)cur * 64] = (int16_t)(v < (1 << (sym - 1)) ? v - (1 << sym) + 1 : v);
+            }
+            st.bit += (uint32_t)(len + sym);
+            st.k = 1;
+        } else {
+            const int len = jh_code(tabs.t[F.tab_ac[comp]], w, sym);
+            if (len == 0) {
+                if (WRITE) { err |= 2; return done; }
+                st.bit += 1; continue;
+            }
+            const int run = sym >> 4, sz = sym & 15;
+            if (sz == 0) {
+                st.bit += (uint32_t)len;
+                if (run != 15) block_done = true;            // EOB
+                else st.k += 16;                             // ZRL
+            } else {
+                const int k = st.k + run;
+                if (k > 63) {
+                    if (WRITE) { err |= 2; return done; }
+                    st.bit += 1; continue;
+                }
+                if (WRITE) {
+                    const int v = (int)((w << len) >> (32 - sz));
+                    coef[(size_t)cur * 64 + c_zigzag[k]] = (int16_t)(v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v);
+                }
+                st.bit += (uint32_t)(len + sz);
+                st.k = k + 1;
+            }
+            if (st.k >= 64) block_done = true;
+        }
+        if (WRITE && st.bit > end_bit) { err |= 4; return done; }          // bits that are not in the interval were consumed
+        if (block_done) {
+            st.k = 0;
+            st.blk = st.blk + 1 == bpm ? 0 : st.blk + 1;
+            ++done; ++cur;
+        }
+    }
+    return done;
+}
+
+__global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ clean_all,
+                                                    const uint32_t* __restrict__ seg_begin_all, JhInfo* __restrict__ info,
+                                                    uint32_t* __restrict__ sub_all, int16_t* __restrict__ coef_all, int* __restrict__ status)
+{
+    __shared__ JhTabs tabs;
+    __shared__ int s_changed, s_err, s_nsub, s_wsum[4], s_carry;
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    jpeg::DevFrame& F = frames[f];
+    JhInfo* I = info + f;
+    if (!F.hdr.valid) return;
+    for (int i = t; i < (int)(sizeof(JhTabs) / 4); i += JH_T) reinterpret_cast<uint32_t*>(&tabs)[i] = reinterpret_cast<const uint32_t*>(F.tabs)[i];
+    const uint8_t* clean = clean_all + F.clean_off;
+    const uint32_t* sb = seg_begin_all + F.seg_off;
+    const int n_seg = I->n_seg;
+    // per-subsequence arrays of this frame: [0] segment, [1] entry bit, [2] entry phase, [3] exit bit, [4] exit phase,
+    // [5] blocks completed, [6] candidate bit, [7] candidate phase, [8] exclusive block prefix
+    const int MS = F.max_sub;
+    uint32_t* S = sub_all + (size_t)F.sub_off;
+    uint32_t *u_seg = S, *u_ebit = S + MS, *u_eph = S + 2 * (size_t)MS, *u_xbit = S + 3 * (size_t)MS, *u_xph = S + 4 * (size_t)MS,
+             *u_nblk = S + 5 * (size_t)MS, *u_cbit = S + 6 * (size_t)MS, *u_cph = S + 7 * (size_t)MS, *u_pre = S + 8 * (size_t)MS;
+    // first subsequence of every interval (prefix over the intervals' subsequence counts), kept behind the segment table
+    uint32_t* sub_first = const_cast<uint32_t*>(sb) + F.max_seg;          // [max_seg + 1]
+    if (t == 0) {
+        int acc = 0;
+        for (int g = 0; g < n_seg; ++g) {
+            sub_first[g] = (uint32_t)acc;
+            const uint32_t len = sb[g + 1] - sb[g];
+            int n = (int)((len + JH_SB - 1) / JH_SB);
+            if (n < 1) n = 1;
+            acc += n;
+        }
+        sub_first[n_seg] = (uint32_t)acc;
+        s_nsub = acc <= MS ? acc : -1;
+        s_err = I->err;
+        s_changed = 0;
+    }
+    __syncthreads();
+    const int n_sub = s_nsub;
+    if (n_sub < 0) { if (t == 0) { F.hdr.valid = 0; status[f] = LF_ERR_DECODE; } return; }
+    for (int g = t; g < n_seg; g += JH_T)
+        for (uint32_t u = sub_first[g]; u < sub_first[g + 1]; ++u) u_seg[u] = (uint32_t)g;
+    __syncthreads();
+    int dummy_err = 0;
+    // ---- pass 0: assumed entry states
+    for (int u = t; u < n_sub; u += JH_T) {
+        const int g = (int)u_seg[u];
+        const uint32_t local = (uint32_t)u - sub_first[g];
+        const uint32_t start = (sb[g] + local * JH_SB) * 8u, seg_end = sb[g + 1] * 8u;
+        uint32_t limit = start + JH_SB * 8u;
+        if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
+        JhState st; st.bit = start; st.blk = 0; st.k = 0;
+        u_ebit[u] = st.bit; u_eph[u] = 0u;
+        const int nb = jh_span<false>(tabs, F, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
+        u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
+    }
+    __syncthreads();
+    // ---- until every subsequence starts from what its predecessor hands over
+    for (int pass = 0; pass < n_sub + 1; ++pass) {
+        for (int u = t; u < n_sub; u += JH_T) {
+            const int g = (int)u_seg[u];
+            if ((uint32_t)u != sub_first[g]) { u_cbit[u] = u_xbit[u - 1]; u_cph[u] = u_xph[u - 1]; }
+        }
+        __syncthreads();
+        bool changed = false;
+        for (int u = t; u < n_sub; u += JH_T) {
+            const int g = (int)u_seg[u];
+            if ((uint32_t)u == sub_first[g]) continue;
+            const uint32_t cb = u_cbit[u], cp = u_cph[u];
+            if (cb == u_ebit[u] && cp == u_eph[u]) continue;
+            changed = true;
+            const uint32_t local = (uint32_t)u - sub_first[g];
+            const uint32_t start = (sb[g] + local * JH_SB) * 8u, seg_end = sb[g + 1] * 8u;
+            uint32_t limit = start + JH_SB * 8u;
+            if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
+            JhState st; st.bit = cb; st.blk = (int)(cp >> 8); st.k = (int)(cp & 255u);
+            u_ebit[u] = cb; u_eph[u] = cp;
+            const int nb = jh_span<false>(tabs, F, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
+            u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        const int any = s_changed;
+        __syncthreads();
+        if (t == 0) s_changed = 0;
+        __syncthreads();
+        if (!any) break;
+    }
+    // ---- blocks completed before every subsequence (exclusive prefix over the frame's subsequences)
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_sub; base += JH_T) {
+        const int u = base + t;
+        const int v = u < n_sub ? (int)u_nblk[u] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(inc, d); if (lane >= d) inc += a; }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int off = s_carry;
+        for (int w = 0; w < wave; ++w) off += s_wsum[w];
+        if (u < n_sub) u_pre[u] = (uint32_t)(off + inc - v);
+        __syncthreads();
+        if (t == JH_T - 1) s_carry = off + inc;
+        __syncthreads();
+    }
+    // ---- the decode that counts: coefficients out, a sequential decoder's checks
+    int16_t* coef = coef_all + (size_t)F.coef_base * 64;
+    int err = 0;
+    for (int u = t; u < n_sub; u += JH_T) {
+        const int g = (int)u_seg[u];
+        const uint32_t local = (uint32_t)u - sub_first[g];
+        const uint32_t start = (sb[g] + local * JH_SB) * 8u, seg_end = sb[g + 1] * 8u;
+        uint32_t limit = start + JH_SB * 8u;
+        const bool last = (uint32_t)u + 1 == sub_first[g + 1];
+        if (limit > seg_end || last) limit = seg_end;
+        const int first_block = F.restart > 0 ? g * F.restart * F.bpm : 0;
+        int end_block = F.restart > 0 ? (g + 1) * F.restart * F.bpm : F.hdr.nblocks;
+        if (end_block > F.hdr.nblocks) end_block = F.hdr.nblocks;
+        const int cur = first_block + (int)(u_pre[u] - u_pre[sub_first[g]]);
+        JhState st; st.bit = u_ebit[u]; st.blk = (int)(u_eph[u] >> 8); st.k = (int)(u_eph[u] & 255u);
+        const int nb = jh_span<true>(tabs, F, clean, st, limit, seg_end, coef, cur, end_block, err);
+        if (last && !err) {
+            if (cur + nb < end_block) err |= 8;                             // the interval ran out before its last block (more data than
+                                                                            // blocks is ignored, as a sequential decoder does)
+            // T.81 E.2.4: an interval that a restart marker follows ends with fewer than 8 padding bits
+            if (g + 1 < n_seg && seg_end - st.bit >= 8u) err |= 8;
+            if (g + 1 == n_seg && end_block != F.hdr.nblocks) err |= 8;
+        }
+    }
+    if (err) atomicOr(&s_err, err);
+    __syncthreads();
+    if (t == 0) {
+        I->n_sub = n_sub;
+        I->err = s_err;
+        if (s_err) { F.hdr.valid = 0; status[f] = LF_ERR_DECODE; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- k_jh_dc
+// DC prediction (T.81 F.2.2.1): DIFF -> DC, per component, restarting at every interval.  One wave per frame walks the MCUs
+// 64 at a time; the blocks of a component inside an MCU chain serially (at most four).
+__global__ __launch_bounds__(64) void k_jh_dc(const jpeg::DevFrame* __restrict__ frames, int16_t* __restrict__ coef_all)
+{
+    const int f = blockIdx.x, lane = threadIdx.x;
+    const jpeg::DevFrame& F = frames[f];
+    if (!F.hdr.valid) return;
+    int16_t* coef = coef_all + (size_t)F.coef_base * 64;
+    const int n_mcu = F.n_mcu, bpm = F.bpm, luma = F.luma, R = F.restart > 0 ? F.restart : n_mcu;
+    const int ncomp = F.hdr.ncomp;
+    int carry[3] = { 0, 0, 0 };
+    for (int base = 0; base < n_mcu; base += 64) {
+        const int m = base + lane;
+        const bool act = m < n_mcu;
+        // sum of this MCU's differences per component
+        int sum[3] = { 0, 0, 0 };
+        if (act) {
+            for (int r = 0; r < bpm; ++r) {
+                const int c = r < luma ? 0 : r - luma + 1;
+                sum[c] += (int)coef[((size_t)m * bpm + r) * 64];
+            }
+        }
+        // segmented inclusive scan over the lanes: a lane whose MCU starts an interval does not take what is below it
+        const bool head = act && (m % R == 0);
+        int inc[3] = { sum[0], sum[1], sum[2] };
+        bool flag = head;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int a0 = __shfl_up(inc[0], d), a1 = __shfl_up(inc[1], d), a2 = __shfl_up(inc[2], d);
+            const bool fl = __shfl_up((int)flag, d) != 0;
+            if (lane >= d) {
+                if (!flag) { inc[0] += a0; inc[1] += a1; inc[2] += a2; }
+                flag = flag || fl;
+            }
+        }
+        // predictor before this MCU: the exclusive sum inside its interval, plus what the previous 64 MCUs carried over
+        // unless an interval starts at or below this lane in this group
+        int pred[3];
+        for (int c = 0; c < 3; ++c) pred[c] = inc[c] - sum[c] + (flag ? 0 : carry[c]);
+        if (act) {
+            for (int r = 0; r < bpm; ++r) {
+                const int c = r < luma ? 0 : r - luma + 1;
+                int16_t* p = coef + ((size_t)m * bpm + r) * 64;
+                pred[c] = (int)((unsigned)pred[c] + (unsigned)(int)*p);
+                *p = (int16_t)pred[c];
+            }
+        }
+        // carry = predictor after the last MCU of this group of 64
+        const int lastl = (n_mcu - base < 64 ? n_mcu - base : 64) - 1;
+        for (int c = 0; c < 3; ++c) carry[c] = __shfl(pred[c], lastl);
+        (void)ncomp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- dense IDCT
+namespace {
+__device__ __forceinline__ int32_t jd_mulw(int32_t a, int32_t c) { return (int32_t)((uint32_t)a * (uint32_t)c); }
+__device__ __forceinline__ int32_t jd_addw(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t jd_subw(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ void jd_idct8(const int32_t in[8], int32_t out[8], int shift)
+{
+    const int32_t z1 = jd_mulw(jd_addw(in[2], in[6]), 4433);
+    const int32_t t2 = jd_addw(z1, jd_mulw(in[6], -15137));
+    const int32_t t3 = jd_addw(z1, jd_mulw(in[2], 6270));
+    const int32_t t0 = (int32_t)((uint32_t)jd_addw(in[0], in[4]) << 13);
+    const int32_t t1 = (int32_t)((uint32_t)jd_subw(in[0], in[4]) << 13);
+    const int32_t e0 = jd_addw(t0, t3), e3 = jd_subw(t0, t3), e1 = jd_addw(t1, t2), e2 = jd_subw(t1, t2);
+    int32_t o0 = in[7], o1 = in[5], o2 = in[3], o3 = in[1];
+    int32_t y1 = jd_addw(o0, o3), y2 = jd_addw(o1, o2), y3 = jd_addw(o0, o2), y4 = jd_addw(o1, o3);
+    const int32_t y5 = jd_mulw(jd_addw(y3, y4), 9633);
+    o0 = jd_mulw(o0, 2446); o1 = jd_mulw(o1, 16819); o2 = jd_mulw(o2, 25172); o3 = jd_mulw(o3, 12299);
+    y1 = jd_mulw(y1, -7373); y2 = jd_mulw(y2, -20995);
+    y3 = jd_addw(jd_mulw(y3, -16069), y5); y4 = jd_addw(jd_mulw(y4, -3196), y5);
+    o0 = jd_addw(o0, jd_addw(y1, y3)); o1 = jd_addw(o1, jd_addw(y2, y4));
+    o2 = jd_addw(o2, jd_addw(y2, y3)); o3 = jd_addw(o3, jd_addw(y1, y4));
+    const int32_t r = (int32_t)1 << (shift - 1);
+    out[0] = jd_addw(jd_addw(e0, o3), r) >> shift; out[7] = jd_addw(jd_subw(e0, o3), r) >> shift;
+    out[1] = jd_addw(jd_addw(e1, o2), r) >> shift; out[6] = jd_addw(jd_subw(e1, o2), r) >> shift;
+    out[2] = jd_addw(jd_addw(e2, o1), r) >> shift; out[5] = jd_addw(jd_subw(e2, o1), r) >> shift;
+    out[3] = jd_addw(jd_addw(e3, o0), r) >> shift; out[4] = jd_addw(jd_subw(e3, o0), r) >> shift;
+}
+__device__ __forceinline__ uint32_t jd_limit(int32_t x)
+{
+    const int idx = (int)((uint32_t)x & 1023u);
+    return idx < 128 ? (uint32_t)(128 + idx) : idx < 512 ? 255u : idx < 896 ? 0u : (uint32_t)(idx - 896);
+}
+constexpr int kDBlocksPerWg = 32, kDStride = 72;
+}
+
+// the dequantisation + inverse DCT of k_jpeg_idct (k_jpeg.hip), reading dense blocks: 8 threads per block, thread k loads
+// row k (16 bytes) and owns column k in pass 1, row k in pass 2
+__global__ __launch_bounds__(256) void k_jpeg_idct_dense(JpegGeom g, const jpeg::DevFrame* __restrict__ frames, const int16_t* __restrict__ coef_all,
+                                                         uint8_t* __restrict__ planes)
+{
+    __shared__ int32_t ws[kDBlocksPerWg * kDStride];
+    const int f = blockIdx.y;
+    const jpeg::DevFrame& F = frames[f];
+    const int t = threadIdx.x, lb = t >> 3, k = t & 7;
+    const int b = blockIdx.x * kDBlocksPerWg + lb;
+    const int nblocks = F.hdr.valid ? F.hdr.nblocks : 0;
+    if ((int)blockIdx.x * kDBlocksPerWg >= nblocks) return;
+    const bool act = b < nblocks;
+    int32_t* w = ws + lb * kDStride;
+    int comp = 0, bx = 0, by = 0;
+    int32_t in[8], res[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) in[c] = 0;
+    if (act) {
+        const int hm = F.hdr.hmax, vm = F.hdr.vmax;
+        const int luma = F.luma, bpm = F.bpm;
+        const int mcu = b / bpm, r = b - mcu * bpm;
+        const int my = mcu / F.hdr.mcux, mx = mcu - my * F.hdr.mcux;
+        if (r < luma) { comp = 0; bx = mx * hm + (r % hm); by = my * vm + (r / hm); }
+        else { comp = r - luma + 1; bx = mx; by = my; }
+        const uint16_t* q = F.hdr.qt[comp] + 8 * k;
+        const uint4 v = *reinterpret_cast<const uint4*>(coef_all + ((size_t)F.coef_base + b) * 64 + 8 * k);
+        const uint32_t wv[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int c = 0; c < 8; ++c) in[c] = jd_mulw((int32_t)(int16_t)((wv[c >> 1] >> (16 * (c & 1))) & 0xffffu), (int32_t)q[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) w[k * 8 + c] = in[c];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) in[r] = w[r * 8 + k];
+    jd_idct8(in, res, 13 - 2);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) w[r * 8 + k] = res[r];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 8; ++c) in[c] = w[k * 8 + c];
+    jd_idct8(in, res, 13 + 2 + 3);
+    if (act) {
+        const uint32_t lo = jd_limit(res[0]) | (jd_limit(res[1]) << 8) | (jd_limit(res[2]) << 16) | (jd_limit(res[3]) << 24);
+        const uint32_t hi = jd_limit(res[4]) | (jd_limit(res[5]) << 8) | (jd_limit(res[6]) << 16) | (jd_limit(res[7]) << 24);
+        uint8_t* pl = planes + ((size_t)f * 3 + comp) * g.Hp * g.Wp;
+        *reinterpret_cast<uint2*>(pl + (size_t)(by * 8 + k) * g.Wp + bx * 8) = make_uint2(lo, hi);
+    }
+}
+
+void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, jpeg::DevFrame* frames, const uint8_t* bytes, uint8_t* clean,
+                      uint32_t* seg_begin, void* info, uint32_t* sub, int16_t* coef, int* status, uint8_t* planes, hipStream_t s)
+{
+    JhInfo* I = static_cast<JhInfo*>(info);
+    hipLaunchKernelGGL(k_jh_unstuff, dim3(n_frames), dim3(JH_T), 0, s, frames, bytes, clean, seg_begin, I);
+    hipLaunchKernelGGL(k_jh_decode, dim3(n_frames), dim3(JH_T), 0, s, frames, clean, seg_begin, I, sub, coef, status);
+    hipLaunchKernelGGL(k_jh_dc, dim3(n_frames), dim3(64), 0, s, frames, coef);
+    if (max_blocks > 0) {
+        const dim3 grid((unsigned)((max_blocks + kDBlocksPerWg - 1) / kDBlocksPerWg), (unsigned)n_frames);
+        hipLaunchKernelGGL(k_jpeg_idct_dense, grid, dim3(256), 0, s, g, frames, coef, planes);
+    }
+}
+
+size_t jh_info_bytes() { return sizeof(JhInfo); }
+
+}  // namespace lf

@@ -187,13 +187,14 @@ __device__ __forceinline__ void chroma8(const uint8_t* pl, int Wp, int hm, int v
 }  // namespace
 
 // frames: [frame][rows][cols][3] u8 BGR.  One thread = 8 horizontally adjacent pixels (24 output bytes).
-__global__ __launch_bounds__(256) void k_jpeg_color(JpegGeom g, const jpeg::FrameHeader* __restrict__ hdrs,
+// hdr_stride: bytes between the headers of consecutive frames (FrameHeader alone, or the head of a DevFrame)
+__global__ __launch_bounds__(256) void k_jpeg_color(JpegGeom g, const jpeg::FrameHeader* __restrict__ hdrs, size_t hdr_stride,
                                                     const uint8_t* __restrict__ planes, uint8_t* __restrict__ frames)
 {
     const int f = blockIdx.z, y = blockIdx.y;
     const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (x0 >= g.cols) return;
-    const jpeg::FrameHeader* H = hdrs + f;
+    const jpeg::FrameHeader* H = reinterpret_cast<const jpeg::FrameHeader*>(reinterpret_cast<const char*>(hdrs) + (size_t)f * hdr_stride);
     uint8_t* out = frames + ((size_t)f * g.rows + y) * g.cols * 3 + (size_t)x0 * 3;
     const int npx = g.cols - x0 < 8 ? g.cols - x0 : 8;
     uint32_t px[8][3];
@@ -269,9 +270,14 @@ void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const j
         const dim3 grid((unsigned)((max_blocks + kBlocksPerWg - 1) / kBlocksPerWg), (unsigned)n_frames);
         hipLaunchKernelGGL(k_jpeg_idct, grid, dim3(256), 0, s, g, hdrs, entries, block_end, planes);
     }
+    launch_jpeg_color(g, n_frames, hdrs, sizeof(jpeg::FrameHeader), planes, frames, s);
+}
+
+void launch_jpeg_color(const JpegGeom& g, int n_frames, const void* hdrs, size_t hdr_stride, const uint8_t* planes, uint8_t* frames, hipStream_t s)
+{
     const int tx = 64;
     const dim3 cgrid((unsigned)((g.cols + 8 * tx - 1) / (8 * tx)), (unsigned)g.rows, (unsigned)n_frames);
-    hipLaunchKernelGGL(k_jpeg_color, cgrid, dim3(tx), 0, s, g, hdrs, planes, frames);
+    hipLaunchKernelGGL(k_jpeg_color, cgrid, dim3(tx), 0, s, g, static_cast<const jpeg::FrameHeader*>(hdrs), hdr_stride, planes, frames);
 }
 
 }  // namespace lf

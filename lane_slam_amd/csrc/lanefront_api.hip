@@ -34,6 +34,8 @@ struct JpegState {
     std::vector<lf::jpeg::FrameCoefs> frames;       // per-frame host coefficient lists (capacity is kept)
     int rows = 0, cols = 0, max_frames = 0;         // geometry the planes were sized for
     DevBuf planes, entries, block_end, hdrs, out;   // device
+    DevBuf gh_clean, gh_sub, gh_seg, gh_info, gh_coef;   // entropy decoding on the device (k_jhuff.hip)
+    std::vector<int> h_status;
     void* h_stage = nullptr;                        // pinned staging: headers | block_end | entries
     size_t h_stage_bytes = 0;
     hipEvent_t staged = nullptr;                    // the last H2D out of h_stage has completed
@@ -464,7 +466,7 @@ extern "C" void lf_destroy(lf_handle* h)
         if (b->p) (void)hipFree(b->p);
     if (h->jpeg) {
         JpegState* j = h->jpeg;
-        for (DevBuf* b : { &j->planes, &j->entries, &j->block_end, &j->hdrs, &j->out }) if (b->p) (void)hipFree(b->p);
+        for (DevBuf* b : { &j->planes, &j->entries, &j->block_end, &j->hdrs, &j->out, &j->gh_clean, &j->gh_sub, &j->gh_seg, &j->gh_info, &j->gh_coef }) if (b->p) (void)hipFree(b->p);
         if (j->h_stage) (void)hipHostFree(j->h_stage);
         if (j->staged) (void)hipEventDestroy(j->staged);
         delete j;
@@ -1360,3 +1362,4 @@ extern "C" int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int 
 }
 
 #include "lanefront_keylines.inc"
+#include "lanefront_jpeg_gpu.inc"

@@ -318,10 +318,12 @@ class FrontEnd(object):
         return a
 
     # ------------------------------------------------------------------ host ingest (JPEG)
-    def decode_jpeg_batch(self, streams, rows=None, cols=None, n_threads=0, device_ptr=None):
+    def decode_jpeg_batch(self, streams, rows=None, cols=None, n_threads=0, device_ptr=None, entropy="gpu"):
         """Decode a list of JPEG byte strings (what CompressedImage.data carries) into BGR frames --
         the batched form of duckietown_utils.jpg.image_cv_from_jpg = cv2.imdecode(data, IMREAD_COLOR)
-        (ref: duckietown_utils/jpg.py:21-31).  Huffman decoding on host threads, everything else on the GPU.
+        (ref: duckietown_utils/jpg.py:21-31).  entropy="gpu" (default): the host parses headers only, Huffman decoding
+        and everything after it run on the GPU (lf_jpeg_decode_batch_gpu); entropy="host": Huffman decoding on n_threads
+        host threads (lf_jpeg_decode_batch).  Same output either way.
 
         device_ptr None: returns (frames u8 [n, rows, cols, 3] on the host, status int32 [n]);
         device_ptr = a device address: frames are written there (asynchronously on the handle's stream)
@@ -334,12 +336,14 @@ class FrontEnd(object):
         sizes = (ctypes.c_size_t * n)(*[b.size for b in bufs])
         status = np.zeros(n, np.int32)
         st = status.ctypes.data_as(ctypes.POINTER(ctypes.c_int))
+        if entropy not in ("gpu", "host"):
+            raise ValueError("entropy must be 'gpu' or 'host'")
+        fn = self.lib.lf_jpeg_decode_batch_gpu if entropy == "gpu" else self.lib.lf_jpeg_decode_batch
         if device_ptr is None:
             out = np.empty((n, rows, cols, 3), np.uint8)
-            self._check(self.lib.lf_jpeg_decode_batch(self.h, ptrs, sizes, n, rows, cols, _ptr(out), 0, n_threads, st))
+            self._check(fn(self.h, ptrs, sizes, n, rows, cols, _ptr(out), 0, n_threads, st))
             return out, status
-        self._check(self.lib.lf_jpeg_decode_batch(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), 1,
-                                                  n_threads, st))
+        self._check(fn(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), 1, n_threads, st))
         return status
 
     def frames_buffer(self):
