@@ -220,7 +220,7 @@ void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const j
 void launch_jpeg_color(const JpegGeom& g, int n_frames, const void* hdrs, size_t hdr_stride, const uint8_t* planes, uint8_t* frames, hipStream_t s);
 // entropy decoding on the device (k_jhuff.hip)
 namespace jpeg { struct DevFrame; }
-void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, jpeg::DevFrame* frames, const uint8_t* bytes, uint8_t* clean,
+void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, size_t max_scan_len, jpeg::DevFrame* frames, const uint8_t* bytes, uint8_t* clean,
                       uint32_t* seg_begin, void* info, uint32_t* sub, int16_t* coef, int* status, uint8_t* planes, hipStream_t s);
 size_t jh_info_bytes();
 

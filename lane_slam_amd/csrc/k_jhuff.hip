@@ -22,13 +22,17 @@
 //   k_jh_dc        DC prediction: running sum per component over the blocks of a restart interval
 //   k_jpeg_idct_dense  dequantisation + the 13-bit integer inverse DCT of k_jpeg.hip on the dense blocks
 // Chroma upsampling and colour conversion are k_jpeg.hip's k_jpeg_color, unchanged.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 #include "jpeg_entropy.h"
 
 namespace lf {
 
-constexpr int JH_T = 256;
-constexpr int JH_SB = 128;         // clean bytes per subsequence
+constexpr int JH_T = 256;          // k_jh_unstuff
+constexpr int JH_TD = 1024;        // k_jh_decode: one thread per subsequence of a typical camera frame (~300)
+constexpr int JH_LDS_CLEAN = 96 * 1024;     // scans up to this many clean bytes are decoded out of LDS
+constexpr int JH_SB = 64;          // clean bytes per subsequence
 
 struct JhInfo { int clean_len, n_seg, n_sub, err; };
 
@@ -38,38 +42,42 @@ __constant__ uint8_t c_zigzag[64] = {
 
 // ---------------------------------------------------------------------------------------------- k_jh_unstuff
 // classification of raw byte i: 0 dropped (stuffed zero / marker byte), 1 kept, 2 first byte of an RSTn marker, 3 terminal
+// PAD: the raw scan staged in LDS with one spare dword after every 32 (byte b at b + 4 * (b / 128)): the lanes of a wave
+// walk chunks 128 bytes apart, without the padding all in one bank
+template <bool PAD>
+__device__ __forceinline__ uint32_t jh_raw(const uint8_t* raw, uint32_t i) { return raw[PAD ? i + ((i >> 7) << 2) : i]; }
+
+template <bool PAD>
 __device__ __forceinline__ int jh_classify(const uint8_t* raw, uint32_t i, uint32_t L, int restart)
 {
-    const uint32_t cur = raw[i];
+    const uint32_t cur = jh_raw<PAD>(raw, i);
     if (cur == 0xFFu) {
-        const uint32_t nxt = i + 1 < L ? raw[i + 1] : 0xD9u;
+        const uint32_t nxt = i + 1 < L ? jh_raw<PAD>(raw, i + 1) : 0xD9u;
         if (nxt == 0u) return 1;
         if (restart && nxt >= 0xD0u && nxt <= 0xD7u) return 2;
         return 3;
     }
-    if (i > 0 && raw[i - 1] == 0xFFu && (cur == 0u || (restart && cur >= 0xD0u && cur <= 0xD7u))) return 0;
+    if (i > 0 && (cur == 0u || (restart && cur >= 0xD0u && cur <= 0xD7u)) && jh_raw<PAD>(raw, i - 1) == 0xFFu) return 0;
     return 1;
 }
 
-__global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ bytes,
-                                                     uint8_t* __restrict__ clean, uint32_t* __restrict__ seg_begin, JhInfo* __restrict__ info)
+extern __shared__ uint32_t jh_dyn[];                         // k_jh_unstuff: the raw scan; k_jh_decode: the clean scan (when they fit)
+
+struct JhUShared { uint32_t s_term; int s_wk[4], s_wm[4], s_ck, s_cm, s_err; };
+
+template <bool PAD>
+__device__ __forceinline__ void jh_unstuff_body(JhUShared& sh, const jpeg::DevFrame& F, JhInfo* I, const uint8_t* raw, uint8_t* __restrict__ out,
+                                                uint32_t* __restrict__ sb)
 {
-    __shared__ uint32_t s_term;
-    __shared__ int s_wk[4], s_wm[4], s_ck, s_cm, s_err;
-    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const jpeg::DevFrame& F = frames[f];
-    JhInfo* I = info + f;
-    if (!F.hdr.valid) { if (t == 0) { I->clean_len = 0; I->n_seg = 0; I->n_sub = 0; I->err = 0; } return; }
-    const uint8_t* raw = bytes + F.scan_off;
+    uint32_t& s_term = sh.s_term; int* s_wk = sh.s_wk; int* s_wm = sh.s_wm; int& s_ck = sh.s_ck; int& s_cm = sh.s_cm; int& s_err = sh.s_err;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint32_t L = F.scan_len;
-    uint8_t* out = clean + F.clean_off;
-    uint32_t* sb = seg_begin + F.seg_off;
     if (t == 0) { s_term = L; s_ck = 0; s_cm = 0; s_err = 0; }
     __syncthreads();
     // the scan ends at the first marker that is not a restart marker (EOI, normally)
     uint32_t term = L;
     for (uint32_t i = t; i < L; i += JH_T)
-        if (raw[i] == 0xFFu && jh_classify(raw, i, L, F.restart) == 3) { term = i; break; }
+        if (jh_raw<PAD>(raw, i) == 0xFFu && jh_classify<PAD>(raw, i, L, F.restart) == 3) { term = i; break; }
     atomicMin(&s_term, term);
     __syncthreads();
     const uint32_t T = s_term;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __res
         const uint32_t c0 = base + (uint32_t)t * 128u;
         const uint32_t c1 = c0 + 128u < T ? c0 + 128u : T;
         int kept = 0, marks = 0;
-        for (uint32_t i = c0; i < c1; ++i) { const int cl = jh_classify(raw, i, L, F.restart); kept += cl == 1; marks += cl == 2; }
+        for (uint32_t i = c0; i < c1; ++i) { const int cl = jh_classify<PAD>(raw, i, L, F.restart); kept += cl == 1; marks += cl == 2; }
         int ik = kept, im = marks;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ik, d), b = __shfl_up(im, d); if (lane >= d) { ik += a; im += b; } }
@@ -89,11 +97,11 @@ __global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __res
         for (int w = 0; w < wave; ++w) { pos += s_wk[w]; ord += s_wm[w]; }
         pos += ik - kept; ord += im - marks;
         for (uint32_t i = c0; i < c1; ++i) {
-            const int cl = jh_classify(raw, i, L, F.restart);
-            if (cl == 1) out[pos++] = raw[i];
+            const int cl = jh_classify<PAD>(raw, i, L, F.restart);
+            if (cl == 1) out[pos++] = (uint8_t)jh_raw<PAD>(raw, i);
             else if (cl == 2) {
                 // RSTm: m counts modulo 8 (T.81 E.1.4); the next interval starts at the next clean byte
-                if ((int)raw[i + 1] != 0xD0 + (ord & 7)) atomicOr(&s_err, 1);
+                if ((int)jh_raw<PAD>(raw, i + 1) != 0xD0 + (ord & 7)) atomicOr(&s_err, 1);
                 if (ord + 1 < F.max_seg) sb[ord + 1] = (uint32_t)pos;
                 ++ord;
             }
@@ -117,15 +125,46 @@ __global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __res
     }
 }
 
+__global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ bytes,
+                                                     uint8_t* __restrict__ clean, uint32_t* __restrict__ seg_begin, JhInfo* __restrict__ info,
+                                                     int lds_raw_bytes)
+{
+    __shared__ JhUShared sh;
+    const int f = blockIdx.x, t = threadIdx.x;
+    const jpeg::DevFrame& F = frames[f];
+    JhInfo* I = info + f;
+    if (!F.hdr.valid) { if (t == 0) { I->clean_len = 0; I->n_seg = 0; I->n_sub = 0; I->err = 0; } return; }
+    const uint8_t* raw = bytes + F.scan_off;
+    uint8_t* out = clean + F.clean_off;
+    uint32_t* sb = seg_begin + F.seg_off;
+    const uint32_t L = F.scan_len;
+    if (lds_raw_bytes > 0 && (int)(L + L / 32 + 64) <= lds_raw_bytes) {
+        // the raw scan into LDS once (coalesced dwords; scan_off is a multiple of 16): three passes read it byte by byte
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(raw);
+        const int n4 = (int)((L + 3) / 4);
+        for (int i = t; i < n4; i += JH_T) jh_dyn[i + (i >> 5)] = src[i];
+        __syncthreads();
+        jh_unstuff_body<true>(sh, F, I, reinterpret_cast<const uint8_t*>(jh_dyn), out, sb);
+    } else {
+        jh_unstuff_body<false>(sh, F, I, raw, out, sb);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- k_jh_decode
 struct JhTabs { jpeg::HuffDev t[8]; };
 
+// 32 bits of the clean stream from bit position `bit` on, MSB first: three aligned dwords (the stream sits in LDS for
+// camera-sized frames: a flat pointer serves both), byte-swapped and funnel-shifted
+// PAD: the stream sits in LDS with one spare dword after every 32 (dword d at d + d / 32): the 64 lanes of a wave read
+// from subsequences 128 bytes = 32 dwords apart, which without the padding is the SAME bank for all of them
+template <bool PAD>
 __device__ __forceinline__ uint32_t jh_peek32(const uint8_t* clean, uint32_t bit)
 {
-    uint64_t v;
-    __builtin_memcpy(&v, clean + (bit >> 3), 8);
-    v = __builtin_bswap64(v);
-    return (uint32_t)((v << (bit & 7u)) >> 32);
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(clean);
+    const uint32_t d0 = bit >> 5, d1 = d0 + 1;
+    const uint32_t w0 = __builtin_bswap32(p[PAD ? d0 + (d0 >> 5) : d0]), w1 = __builtin_bswap32(p[PAD ? d1 + (d1 >> 5) : d1]);
+    const uint32_t sh = bit & 31u;
+    return sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
 }
 
 // one Huffman code from the top of w: returns length (0: no code of up to 16 bits matches) and the symbol
@@ -147,81 +186,68 @@ struct JhState { uint32_t bit; int blk, k; };     // next symbol starts at `bit`
 // Decodes the symbols that START in [st.bit, limit).  WRITE = false: speculative (errors only re-align), returns the number of
 // blocks completed.  WRITE = true: true state; coefficients go to coef (block index cur, stops at end_block); err is set on
 // anything a sequential decoder rejects.
-template <bool WRITE>
-__device__ __forceinline__ int jh_span(const JhTabs& tabs, const jpeg::DevFrame& F, const uint8_t* clean, JhState& st, uint32_t limit,
+struct JhSel { int luma, bpm; uint32_t tsel; };   // tsel: DC table of component c in bits 4c .. 4c+3, AC table in bits 12 + 4c ..
+
+template <bool WRITE, bool PAD>
+__device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, const uint8_t* clean, JhState& st, uint32_t limit,
                                        uint32_t end_bit, int16_t* __restrict__ coef, int cur, int end_block, int& err)
 {
     int done = 0;
-    const int luma = F.luma, bpm = F.bpm;
-    while (st.bit < limit) {
+    uint32_t bit = st.bit;
+    int blk = st.blk, k = st.k;
+    while (bit < limit) {
         if (WRITE && cur >= end_block) break;
-        const int comp = st.blk < luma ? 0 : st.blk - luma + 1;
-        const uint32_t w = jh_peek32(clean, st.bit);
+        // one symbol = one Huffman code + its magnitude bits (at most 16 + 15 bits: one 32-bit look).  DC and AC share the
+        // path: DC is "run 0, size = the symbol" (T.81 F.2.2.1), AC "run = high nibble, size = low nibble" with EOB / ZRL
+        const int comp = blk < sel.luma ? 0 : blk - sel.luma + 1;
+        const bool dc = k == 0;
+        const uint32_t w = jh_peek32<PAD>(clean, bit);
         int sym;
-        bool block_done = false;
-        if (st.k == 0) {
-            const int len = jh_code(tabs.t[F.tab_dc[comp]], w, sym);
-            if (len == 0 || sym > 11) {
-                if (WRITE) { err |= 2; return done; }
-                st.bit += 1; continue;
-            }
-            if (WRITE && sym) {
-                // T.81 F.2.2.1 receive + extend
-                const int v = (int)((w << len) >> (32 - sym));
-                coef[(size_t)cur * 64] = (int16_t)(v < (1 << (sym - 1)) ? v - (1 << sym) + 1 : v);
-            }
-            st.bit += (uint32_t)(len + sym);
-            st.k = 1;
-        } else {
-            const int len = jh_code(tabs.t[F.tab_ac[comp]], w, sym);
-            if (len == 0) {
-                if (WRITE) { err |= 2; return done; }
-                st.bit += 1; continue;
-            }
-            const int run = sym >> 4, sz = sym & 15;
-            if (sz == 0) {
-                st.bit += (uint32_t)len;
-                if (run != 15) block_done = true;            // EOB
-                else st.k += 16;                             // ZRL
-            } else {
-                const int k = st.k + run;
-                if (k > 63) {
-                    if (WRITE) { err |= 2; return done; }
-                    st.bit += 1; continue;
-                }
-                if (WRITE) {
-                    const int v = (int)((w << len) >> (32 - sz));
-                    coef[(size_t)cur * 64 + c_zigzag[k]] = (int16_t)(v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v);
-                }
-                st.bit += (uint32_t)(len + sz);
-                st.k = k + 1;
-            }
-            if (st.k >= 64) block_done = true;
+        const int len = jh_code(tabs.t[(sel.tsel >> (4 * comp + (dc ? 0 : 12))) & 15u], w, sym);
+        const int run = dc ? 0 : sym >> 4, sz = dc ? sym : sym & 15;
+        const int kn = k + run;
+        const bool bad = len == 0 || (dc && sym > 11) || (!dc && sz != 0 && kn > 63);
+        if (bad) {
+            if (WRITE) { err |= 2; break; }
+            bit += 1;                                   // speculative decode out of step: slide on, the true state arrives later
+            continue;
         }
-        if (WRITE && st.bit > end_bit) { err |= 4; return done; }          // bits that are not in the interval were consumed
-        if (block_done) {
-            st.k = 0;
-            st.blk = st.blk + 1 == bpm ? 0 : st.blk + 1;
+        if (WRITE && sz) {
+            const int v = (int)((w << len) >> (32 - sz));
+            coef[(size_t)cur * 64 + c_zigzag[kn]] = (int16_t)(v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v);
+        }
+        bit += (uint32_t)(len + sz);
+        k = (!dc && sz == 0) ? (run == 15 ? k + 16 : 64) : kn + 1;           // ZRL / EOB / a coefficient
+        if (WRITE && bit > end_bit) { err |= 4; break; }                      // bits that are not in the interval were consumed
+        if (k >= 64) {
+            k = 0;
+            blk = blk + 1 == sel.bpm ? 0 : blk + 1;
             ++done; ++cur;
         }
     }
+    st.bit = bit; st.blk = blk; st.k = k;
     return done;
 }
 
-__global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ clean_all,
-                                                    const uint32_t* __restrict__ seg_begin_all, JhInfo* __restrict__ info,
-                                                    uint32_t* __restrict__ sub_all, int16_t* __restrict__ coef_all, int* __restrict__ status)
+struct JhShared { JhTabs tabs; int s_changed, s_err, s_nsub, s_wsum[JH_TD / 64], s_carry; int s_dc[JH_TD / 64][4], s_dcc[JH_TD / 64 + 1][3]; };
+
+// LDS = true: the clean scan sits in jh_dyn (the compiler sees an LDS address: ds_read instead of flat loads)
+template <bool LDS>
+__device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo* I, const uint8_t* clean_global, const uint32_t* sb,
+                                         uint32_t* __restrict__ sub_all, int16_t* __restrict__ coef_all, int* __restrict__ status,
+                                         int getenv_debug, int f)
 {
-    __shared__ JhTabs tabs;
-    __shared__ int s_changed, s_err, s_nsub, s_wsum[4], s_carry;
-    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    jpeg::DevFrame& F = frames[f];
-    JhInfo* I = info + f;
-    if (!F.hdr.valid) return;
-    for (int i = t; i < (int)(sizeof(JhTabs) / 4); i += JH_T) reinterpret_cast<uint32_t*>(&tabs)[i] = reinterpret_cast<const uint32_t*>(F.tabs)[i];
-    const uint8_t* clean = clean_all + F.clean_off;
-    const uint32_t* sb = seg_begin_all + F.seg_off;
+    constexpr int JH_T = JH_TD;                              // (this kernel's workgroup size)
+    JhTabs& tabs = sh.tabs;
+    int& s_changed = sh.s_changed; int& s_err = sh.s_err; int& s_nsub = sh.s_nsub; int& s_carry = sh.s_carry;
+    int* s_wsum = sh.s_wsum;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint8_t* clean = LDS ? reinterpret_cast<const uint8_t*>(jh_dyn) : clean_global;
     const int n_seg = I->n_seg;
+    JhSel sel;
+    sel.luma = F.luma; sel.bpm = F.bpm;
+    sel.tsel = (uint32_t)F.tab_dc[0] | ((uint32_t)F.tab_dc[1] << 4) | ((uint32_t)F.tab_dc[2] << 8) | ((uint32_t)F.tab_ac[0] << 12) |
+               ((uint32_t)F.tab_ac[1] << 16) | ((uint32_t)F.tab_ac[2] << 20);
     // per-subsequence arrays of this frame: [0] segment, [1] entry bit, [2] entry phase, [3] exit bit, [4] exit phase,
     // [5] blocks completed, [6] candidate bit, [7] candidate phase, [8] exclusive block prefix
     const int MS = F.max_sub;
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__
         if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
         JhState st; st.bit = start; st.blk = 0; st.k = 0;
         u_ebit[u] = st.bit; u_eph[u] = 0u;
-        const int nb = jh_span<false>(tabs, F, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
+        const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
         u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
     }
     __syncthreads();
@@ -284,7 +310,7 @@ __global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__
             if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
             JhState st; st.bit = cb; st.blk = (int)(cp >> 8); st.k = (int)(cp & 255u);
             u_ebit[u] = cb; u_eph[u] = cp;
-            const int nb = jh_span<false>(tabs, F, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
+            const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
             u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
         }
         if (changed) s_changed = 1;
@@ -293,7 +319,7 @@ __global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__
         __syncthreads();
         if (t == 0) s_changed = 0;
         __syncthreads();
-        if (!any) break;
+        if (!any) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d passes %d\n", f, n_sub, pass + 1); break; }
     }
     // ---- blocks completed before every subsequence (exclusive prefix over the frame's subsequences)
     if (t == 0) s_carry = 0;
@@ -328,7 +354,7 @@ __global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__
         if (end_block > F.hdr.nblocks) end_block = F.hdr.nblocks;
         const int cur = first_block + (int)(u_pre[u] - u_pre[sub_first[g]]);
         JhState st; st.bit = u_ebit[u]; st.blk = (int)(u_eph[u] >> 8); st.k = (int)(u_eph[u] & 255u);
-        const int nb = jh_span<true>(tabs, F, clean, st, limit, seg_end, coef, cur, end_block, err);
+        const int nb = jh_span<true, LDS>(tabs, sel, clean, st, limit, seg_end, coef, cur, end_block, err);
         if (last && !err) {
             if (cur + nb < end_block) err |= 8;                             // the interval ran out before its last block (more data than
                                                                             // blocks is ignored, as a sequential decoder does)
@@ -338,11 +364,85 @@ __global__ __launch_bounds__(JH_T) void k_jh_decode(jpeg::DevFrame* __restrict__
         }
     }
     if (err) atomicOr(&s_err, err);
+    __threadfence_block();
     __syncthreads();
     if (t == 0) {
         I->n_sub = n_sub;
         I->err = s_err;
         if (s_err) { F.hdr.valid = 0; status[f] = LF_ERR_DECODE; }
+    }
+    if (s_err) return;
+    // ---- DC prediction (T.81 F.2.2.1): DIFF -> DC per component, restarting with every interval.  One thread per MCU;
+    // segmented scan inside a wave, the waves' carries chained through LDS
+    {
+        const int n_mcu = F.n_mcu, bpm = sel.bpm, luma = sel.luma, R = F.restart > 0 ? F.restart : n_mcu;
+        if (t < 3) sh.s_dcc[0][t] = 0;
+        __syncthreads();
+        for (int base = 0; base < n_mcu; base += JH_T) {
+            const int m = base + t;
+            const bool act = m < n_mcu;
+            int sum[3] = { 0, 0, 0 };
+            if (act)
+                for (int r = 0; r < bpm; ++r) sum[r < luma ? 0 : r - luma + 1] += (int)coef[((size_t)m * bpm + r) * 64];
+            const bool head = act && (m % R == 0);
+            int inc[3] = { sum[0], sum[1], sum[2] };
+            bool flag = head;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int a0 = __shfl_up(inc[0], d), a1 = __shfl_up(inc[1], d), a2 = __shfl_up(inc[2], d);
+                const bool fl = __shfl_up((int)flag, d) != 0;
+                if (lane >= d) {
+                    if (!flag) { inc[0] += a0; inc[1] += a1; inc[2] += a2; }
+                    flag = flag || fl;
+                }
+            }
+            if (lane == 63) { sh.s_dc[wave][0] = inc[0]; sh.s_dc[wave][1] = inc[1]; sh.s_dc[wave][2] = inc[2]; sh.s_dc[wave][3] = flag ? 1 : 0; }
+            __syncthreads();
+            if (t == 0) {
+                // carry into wave w + 1 = what wave w ends with: its own total since its last interval start, on top of
+                // the carry it received unless an interval started inside it
+                for (int w = 0; w < JH_T / 64; ++w)
+                    for (int c = 0; c < 3; ++c) sh.s_dcc[w + 1][c] = sh.s_dc[w][c] + (sh.s_dc[w][3] ? 0 : sh.s_dcc[w][c]);
+            }
+            __syncthreads();
+            if (act) {
+                int pred[3];
+                for (int c = 0; c < 3; ++c) pred[c] = inc[c] - sum[c] + (flag ? 0 : sh.s_dcc[wave][c]);
+                for (int r = 0; r < bpm; ++r) {
+                    const int c = r < luma ? 0 : r - luma + 1;
+                    int16_t* p = coef + ((size_t)m * bpm + r) * 64;
+                    pred[c] = (int)((unsigned)pred[c] + (unsigned)(int)*p);
+                    *p = (int16_t)pred[c];
+                }
+            }
+            __syncthreads();
+            if (t < 3) sh.s_dcc[0][t] = sh.s_dcc[JH_T / 64][t];
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(JH_TD) void k_jh_decode(jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ clean_all,
+                                                    const uint32_t* __restrict__ seg_begin_all, JhInfo* __restrict__ info,
+                                                    uint32_t* __restrict__ sub_all, int16_t* __restrict__ coef_all, int* __restrict__ status, int getenv_debug,
+                                                    int lds_clean_bytes)
+{
+    __shared__ JhShared sh;
+    const int f = blockIdx.x, t = threadIdx.x;
+    jpeg::DevFrame& F = frames[f];
+    JhInfo* I = info + f;
+    if (!F.hdr.valid) return;
+    for (int i = t; i < (int)(sizeof(JhTabs) / 4); i += JH_TD) reinterpret_cast<uint32_t*>(&sh.tabs)[i] = reinterpret_cast<const uint32_t*>(F.tabs)[i];
+    const uint8_t* clean = clean_all + F.clean_off;
+    const uint32_t* sb = seg_begin_all + F.seg_off;
+    if (lds_clean_bytes > 0 && (I->clean_len + 48) + (I->clean_len + 48) / 32 + 16 <= lds_clean_bytes) {
+        // the unstuffed scan into LDS once: every pass reads it again
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(clean);     // clean_off is a multiple of 16
+        const int n4 = (I->clean_len + 32 + 3) / 4;
+        for (int i = t; i < n4; i += JH_TD) jh_dyn[i + (i >> 5)] = src[i];
+        jh_frame<true>(sh, F, I, clean, sb, sub_all, coef_all, status, getenv_debug, f);
+    } else {
+        jh_frame<false>(sh, F, I, clean, sb, sub_all, coef_all, status, getenv_debug, f);
     }
 }
 
@@ -488,13 +588,21 @@ __global__ __launch_bounds__(256) void k_jpeg_idct_dense(JpegGeom g, const jpeg:
     }
 }
 
-void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, jpeg::DevFrame* frames, const uint8_t* bytes, uint8_t* clean,
+void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, size_t max_scan_len, jpeg::DevFrame* frames, const uint8_t* bytes, uint8_t* clean,
                       uint32_t* seg_begin, void* info, uint32_t* sub, int16_t* coef, int* status, uint8_t* planes, hipStream_t s)
 {
     JhInfo* I = static_cast<JhInfo*>(info);
-    hipLaunchKernelGGL(k_jh_unstuff, dim3(n_frames), dim3(JH_T), 0, s, frames, bytes, clean, seg_begin, I);
-    hipLaunchKernelGGL(k_jh_decode, dim3(n_frames), dim3(JH_T), 0, s, frames, clean, seg_begin, I, sub, coef, status);
-    hipLaunchKernelGGL(k_jh_dc, dim3(n_frames), dim3(64), 0, s, frames, coef);
+    int lds_raw = (int)(max_scan_len + max_scan_len / 32 + 64 + 15) & ~15;
+    if (lds_raw > JH_LDS_CLEAN) lds_raw = 0;                             // larger scans are read from global memory
+    if (lds_raw > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jh_unstuff), hipFuncAttributeMaxDynamicSharedMemorySize, lds_raw);
+    hipLaunchKernelGGL(k_jh_unstuff, dim3(n_frames), dim3(JH_T), (size_t)lds_raw, s, frames, bytes, clean, seg_begin, I, lds_raw);
+    static const int dbg = getenv("LF_JH_DEBUG") ? 1 : 0;          // diagnostic: passes until the subsequences agree, per frame
+    // LDS for the largest scan of the batch (clean <= raw), up to JH_LDS_CLEAN; larger scans are read from global memory
+    int lds = (int)(max_scan_len + 64 + (max_scan_len + 64) / 32 + 32 + 15) & ~15;
+    if (lds > JH_LDS_CLEAN) lds = JH_LDS_CLEAN;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jh_decode), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(k_jh_decode, dim3(n_frames), dim3(JH_TD), (size_t)lds, s, frames, clean, seg_begin, I, sub, coef, status, dbg, lds);
+    // (DC prediction happens at the end of k_jh_decode; k_jh_dc is the stand-alone form, kept for scans decoded elsewhere)
     if (max_blocks > 0) {
         const dim3 grid((unsigned)((max_blocks + kDBlocksPerWg - 1) / kDBlocksPerWg), (unsigned)n_frames);
         hipLaunchKernelGGL(k_jpeg_idct_dense, grid, dim3(256), 0, s, g, frames, coef, planes);

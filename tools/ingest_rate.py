@@ -19,6 +19,7 @@ ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--depth", type=int, default=3)
 ap.add_argument("--quality", type=int, default=75)
+ap.add_argument("--entropy", default="gpu,host", help="entropy decoder(s): gpu (k_jhuff.hip) and / or host (threads)")
 ap.add_argument("--feeders", type=int, default=1, help="host threads that each drive their own handles (ctypes releases the GIL inside the library)")
 args = ap.parse_args()
 B, D = args.batch, args.depth
@@ -41,12 +42,12 @@ outs = [{"frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev), "lin
 ptrs = [{k: v.data_ptr() for k, v in o.items()} for o in outs]
 bufs = [fe.frames_buffer()[0] for fe in fes]
 print("640x480 4:2:0 q%d, %.1f KB per stream, batch %d, host cpus %d" % (args.quality, jpeg_bytes / 1024, B, os.cpu_count()))
-for nt in [int(t) for t in args.threads.split(",")]:
+for ent, nt in [(e, int(t)) for e in args.entropy.split(",") for t in args.threads.split(",")]:
     # decode only
-    fes[0].decode_jpeg_batch(streams, n_threads=nt, device_ptr=bufs[0]); fes[0].synchronize()
+    fes[0].decode_jpeg_batch(streams, n_threads=nt, device_ptr=bufs[0], entropy=ent); fes[0].synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        fes[0].decode_jpeg_batch(streams, n_threads=nt, device_ptr=bufs[0])
+        fes[0].decode_jpeg_batch(streams, n_threads=nt, device_ptr=bufs[0], entropy=ent)
     fes[0].synchronize()
     dt = time.perf_counter() - t0
     dec = B * args.steps / dt
@@ -59,7 +60,7 @@ for nt in [int(t) for t in args.threads.split(",")]:
         for k in range(n):
             sl = mine[k % len(mine)]
             if len(infl) == len(mine): fes[infl.pop(0)].wait()
-            fes[sl].decode_jpeg_batch(streams, n_threads=max(1, nt // F), device_ptr=bufs[sl])
+            fes[sl].decode_jpeg_batch(streams, n_threads=max(1, nt // F), device_ptr=bufs[sl], entropy=ent)
             fes[sl].submit_device(bufs[sl], B, ptrs[sl], cap, describe=True)
             infl.append(sl)
         while infl: fes[infl.pop(0)].wait()
@@ -69,11 +70,11 @@ for nt in [int(t) for t in args.threads.split(",")]:
         for x in th: x.join()
     run_all(D)
     t0 = time.perf_counter(); run_all(args.steps); dt = time.perf_counter() - t0
-    print("threads %3d: decode %8.0f frames/s   decode + front end %8.0f frames/s" % (nt, dec, B * args.steps / dt))
+    print("entropy %-4s threads %3d: decode %8.0f frames/s   decode + front end %8.0f frames/s" % (ent, nt, dec, B * args.steps / dt))
 # device time of the ingest kernels (HIP events on the handle's stream), one batch in flight
 fes[0].reset_timing(); fes[0].set_profiling(True)
 for _ in range(5):
-    fes[0].decode_jpeg_batch(streams, n_threads=64, device_ptr=bufs[0]); fes[0].synchronize()
+    fes[0].decode_jpeg_batch(streams, n_threads=8, device_ptr=bufs[0]); fes[0].synchronize()
 fes[0].set_profiling(False)
 ms, n = fes[0].timing()["jpeg(idct+upsample+color)"]
 P = 480 * 640
