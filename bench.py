@@ -294,6 +294,16 @@ def main():
                 e["instruction"] = "v_mfma_scale_f32_32x32x64_f8f6f4 (e2m1 operands)" if fp4 else "v_mfma_i32_32x32x32_i8"
                 e["mfma_peak_Pop_per_s"] = peak
                 e["frac_of_mfma_peak"] = round(ops / (avg * 1e-3) / 1e15 / peak, 3)
+            counted = {"pre(resize+correct+hsv+masks+dilate)": ("k_pre", "lane_slam_amd/csrc/k_pre.hip"), "canny_nms": ("k_canny_nms", "lane_slam_amd/csrc/k_canny.hip"),
+                       "lbd_gray_blur_sobel": ("k_lbd_grad", "lane_slam_amd/csrc/k_lbd.hip")}
+            if name in counted:
+                # what bounds a streaming kernel that sits below the HBM roofline: its vector issue utilisation (rocprofv3 SQ passes,
+                # tools/profile_round.sh), quoted only while the kernel source is the one the counters were measured on
+                kpath = os.path.join(ROOT, "profiles", "r03_kernel_counters.json")
+                if os.path.exists(kpath):
+                    kj = json.load(open(kpath)).get("kernels", {}).get(counted[name][0])
+                    if kj and kj.get("source_digest") == source_digest(counted[name][1]):
+                        e["counters"] = {k_: kj[k_] for k_ in ("valu_issue_utilisation", "avg_resident_waves", "frac_wave_cycles_issue_stalled") if k_ in kj}
             if name == "lsd_grow":
                 # latency / issue bound: no bandwidth or matrix roofline.  What bounds it, as counters: wave-slot
                 # occupancy, vector issue utilisation and where its wave-cycles go (rocprofv3 SQ passes measured offline by

@@ -135,7 +135,9 @@ size_t lsd_grow_reg_stride(const LsdParams& p);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
-                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm, hipStream_t s);
+                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
+                     double* pend_rec, int* pend_tag, int* pend_count, hipStream_t s);
+int lsd_grow_pend_cap(const LsdParams& p);      // entries per problem of the pending-region list (k_lsd_eval)
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, hipStream_t s);
 void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, const int* counts,

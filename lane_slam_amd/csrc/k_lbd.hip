@@ -22,6 +22,7 @@ namespace lf {
 #define LF_LBD_TILE_H 64
 #endif
 constexpr int LT_W = 64, LT_H = LF_LBD_TILE_H;   // 64 rows: 9 % halo rows instead of 38 % at 16, and the three filter phases fill their last pass of 256 lanes better (0.119 -> 0.090 ms)
+static_assert(LT_H % 16 == 0, "the Sobel phase gives every lane LT_H / 16 rows of its column group");
 
 __device__ __forceinline__ int refl101(int p, int n)
 {
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* 
     constexpr int RW = 68, RG = RW / 4;              // row-filtered: 66 columns used (x0-1 .. x0+64)
     constexpr int BW_ = 72, BH = LT_H + 2;           // blurred: column c <-> x0-1+c, 66 used
     __shared__ __attribute__((aligned(16))) uint8_t gray[GH * GW];
-    __shared__ __attribute__((aligned(16))) uint16_t rowf[GH * RW];     // <= 257 * 255 = 65 535: exactly 16 bits
+    __shared__ __attribute__((aligned(16))) uint32_t rowp[(GH / 2) * RW];   // row-filtered, <= 257 * 255 = 65 535 = exactly 16 bits: (row 2m, row 2m + 1) per column
     __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
     int tbx, tby, f;
     lf_xcd_tile(tbx, tby, f);
@@ -47,100 +48,157 @@ __global__ __launch_bounds__(256) void k_lbd_grad(int Hc, int W, const uint8_t* 
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const uint8_t* img = gray_in + (size_t)f * Hc * W;
     // gray tile from k_pre's 1 byte/pixel plane (BGR2GRAY is done there), 4 pixels per lane -> one dword store.
-    // The tile starts at x0 - 3: interior groups take the two aligned dwords around their four bytes and shift,
-    // groups that touch the image border reflect byte by byte (BORDER_REFLECT_101).
-    for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
-        const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
-        const int gy = refl101(y0 + ty - 3, Hc);
-        const int xa = x0 + 4 * g - 4;                   // aligned dword below the group (W is a multiple of 32)
-        uint32_t packed = 0;
-        if (xa >= 0 && xa + 7 < W) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(img + (size_t)gy * W + xa);
-            packed = (q[0] >> 8) | (q[1] << 24);         // bytes xa+1 .. xa+4 = x0 + 4g - 3 .. x0 + 4g
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) packed |= (uint32_t)img[(size_t)gy * W + refl101(x0 + 4 * g + k - 3, W)] << (8 * k);
+    // The tile starts at x0 - 3: a group takes the two aligned dwords around its four bytes and shifts.  Tiles that touch
+    // the left or right image border (two of ten tile columns at 640) reflect byte by byte (BORDER_REFLECT_101); the
+    // others skip every per-pixel border test -- this phase was 40 % of the kernel's vector instructions with the tests
+    // in every group.  Rows reflect once (a tile reaches 3 rows past the image; refl101's loop only runs for images
+    // shorter than that).
+    const bool interior = x0 >= 4 && x0 + 72 <= W;           // wave-uniform: every group's dword pair lies inside the row
+    auto reflect_row = [&](int ty) {
+        int gy = y0 + ty - 3;
+        gy = gy < 0 ? -gy : (gy >= Hc ? 2 * (Hc - 1) - gy : gy);
+        if (gy < 0 || gy >= Hc) gy = refl101(y0 + ty - 3, Hc);
+        return (uint32_t)gy * (uint32_t)W;
+    };
+    if (interior) {
+        const uint8_t* base = img + (x0 - 4);
+        for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
+            const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(base + (reflect_row(ty) + 4u * (uint32_t)g));
+            *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = (q[0] >> 8) | (q[1] << 24);   // bytes xa+1 .. xa+4 = x0 + 4g - 3 .. x0 + 4g
         }
-        *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = packed;
-    }
-    __syncthreads();
-    // horizontal 5-tap {14,63,103,63,14}: outputs c..c+3 (c = 4g) need gray[c .. c+7] = two dwords
-    for (int idx = tid; idx < GH * RG; idx += 256) {
-        const int ty = idx / RG, g = idx - ty * RG;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(gray + ty * GW + 4 * g);
-        const uint32_t lo = src[0], hi = src[1];
-        // two outputs per instruction in 16-bit lanes (the sums stay <= 65 535): E = (b0, b2), O = (b1, b3), ... ; the plane
-        // keeps the pairs as they come out: word 0 = (out0, out2), word 1 = (out1, out3)
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        const us2 E = __builtin_bit_cast(us2, lo & 0x00ff00ffu), O = __builtin_bit_cast(us2, (lo >> 8) & 0x00ff00ffu);
-        const us2 E2 = __builtin_bit_cast(us2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(us2, (hi >> 8) & 0x00ff00ffu);
-        const us2 P24 = { E.y, E2.x }, P35 = { O.y, O2.x };
-        const us2 c14 = { 14, 14 }, c63 = { 63, 63 }, c103 = { 103, 103 };
-        const us2 o02 = c14 * E + c63 * O + c103 * P24 + c63 * P35 + c14 * E2;
-        const us2 o13 = c14 * O + c63 * P24 + c103 * P35 + c63 * E2 + c14 * O2;
-        *reinterpret_cast<uint2*>(rowf + ty * RW + 4 * g) = make_uint2(__builtin_bit_cast(uint32_t, o02), __builtin_bit_cast(uint32_t, o13));
-    }
-    __syncthreads();
-    // vertical 5-tap, (acc + 2^15) >> 16, saturate -> blurred u8
-    for (int idx = tid; idx < BH * RG; idx += 256) {
-        const int ty = idx / RG, g = idx - ty * RG;
-        int r5[5][4];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const uint2 w = *reinterpret_cast<const uint2*>(rowf + (ty + j) * RW + 4 * g);
-            r5[j][0] = (int)(w.x & 0xffffu); r5[j][2] = (int)(w.x >> 16); r5[j][1] = (int)(w.y & 0xffffu); r5[j][3] = (int)(w.y >> 16);
-        }
-        int v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = 14 * r5[0][k] + 63 * r5[1][k] + 103 * r5[2][k] + 63 * r5[3][k] + 14 * r5[4][k];
-        uint32_t q[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int t = (v[k] + (1 << 15)) >> 16;
-            // ROCm 7.2 / gfx950: hipcc fuses "shift, clamp to u8, pack two" into v_ashr_pk_u8_i32 and then
-            // ORs further bytes into the result as if its upper 16 bits were zero; on the MI355X they are
-            // not (byte 2 of the packed word came out wrong, found by the parity test).  The empty asm
-            // keeps the shift and the clamp apart so the fused instruction is never selected.
-            asm volatile("" : "+v"(t));
-            t = t < 0 ? 0 : (t > 255 ? 255 : t);
-            q[k] = (uint32_t)t;
-        }
-        *reinterpret_cast<uint32_t*>(blur + ty * BW_ + 4 * g) = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-    }
-    __syncthreads();
-    // Sobel 3x3 on the blurred tile: 4 outputs per lane from three rows of 6 bytes (two dwords each)
-    for (int r0 = 0; r0 < LT_H; r0 += 16) {
-        const int ry = r0 + (tid >> 4), g = tid & 15;  // 16 rows x 16 groups = 256 lanes per pass
-        const int lx = 4 * g, gx = x0 + lx, gy = y0 + ry;
-        if (gx < W && gy < Hc) {
-            // packed 16-bit lanes again: per row the column pairs P02 = (c0, c2), P13, P24, P35 of its six bytes; column sums
-            // S = r0 + 2 r1 + r2 and differences D = r2 - r0, then vx = S[k+2] - S[k], vy = D[k] + 2 D[k+1] + D[k+2]
-            typedef short s2 __attribute__((ext_vector_type(2)));
-            s2 P[3][4];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const uint32_t* src = reinterpret_cast<const uint32_t*>(blur + (ry + j) * BW_ + lx);   // columns lx .. lx+7 <-> x-1 ..
-                const uint32_t lo = src[0], hi = src[1];
-                const s2 E = __builtin_bit_cast(s2, lo & 0x00ff00ffu), O = __builtin_bit_cast(s2, (lo >> 8) & 0x00ff00ffu);
-                const s2 E2 = __builtin_bit_cast(s2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(s2, (hi >> 8) & 0x00ff00ffu);
-                P[j][0] = E; P[j][1] = O; P[j][2] = s2{ E.y, E2.x }; P[j][3] = s2{ O.y, O2.x };
-            }
-            const s2 two = { 2, 2 };
-            s2 S[4], D[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { S[c] = P[0][c] + two * P[1][c] + P[2][c]; D[c] = P[2][c] - P[0][c]; }
-            const s2 vx02 = S[2] - S[0], vx13 = S[3] - S[1];
-            const s2 vy02 = D[0] + two * D[1] + D[2], vy13 = D[1] + two * D[2] + D[3];
-            const int vx[4] = { vx02.x, vx13.x, vx02.y, vx13.y }, vy[4] = { vy02.x, vy13.x, vy02.y, vy13.y };
-            const size_t o = (size_t)f * Hc * W + (size_t)gy * W + gx;
-            // dx and dy of a pixel share one dword (dx low, dy high): the descriptor kernel fetches both with one gather
-            uint32_t w[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) w[k] = (uint32_t)(uint16_t)vx[k] | ((uint32_t)(uint16_t)vy[k] << 16);
-            if (gx + 3 < W && (W & 3) == 0) {
-                *reinterpret_cast<uint4*>(dxyo + o) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
+            const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
+            const uint32_t row = reflect_row(ty);
+            const int xa = x0 + 4 * g - 4;               // aligned dword below the group (W is a multiple of 32)
+            uint32_t packed = 0;
+            if (xa >= 0 && xa + 7 < W) {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(img + (row + (uint32_t)xa));
+                packed = (q[0] >> 8) | (q[1] << 24);
             } else {
-                for (int k = 0; k < 4 && gx + k < W; ++k) dxyo[o + k] = w[k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) packed |= (uint32_t)img[row + (uint32_t)refl101(x0 + 4 * g + k - 3, W)] << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = packed;
+        }
+    }
+    __syncthreads();
+    // horizontal 5-tap {14,63,103,63,14}: outputs c..c+3 (c = 4g) need gray[c .. c+7] = two dwords.  A lane filters the
+    // SAME four columns of two consecutive rows and stores them paired by row -- rowp[m][c] = (row 2m, row 2m + 1) of
+    // column c as two 16-bit halves -- which is the operand shape of v_dot2_u32_u16 in the vertical pass below.
+    static_assert(GH % 2 == 0 && BH % 2 == 0, "rows are filtered in pairs");
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    for (int idx = tid; idx < (GH / 2) * RG; idx += 256) {
+        const int m = idx / RG, g = idx - m * RG;
+        uint32_t o02[2], o13[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(gray + (2 * m + r) * GW + 4 * g);
+            const uint32_t lo = src[0], hi = src[1];
+            // two outputs per instruction in 16-bit lanes (the sums stay <= 65 535): E = (b0, b2), O = (b1, b3), ...
+            const us2 E = __builtin_bit_cast(us2, lo & 0x00ff00ffu), O = __builtin_bit_cast(us2, (lo >> 8) & 0x00ff00ffu);
+            const us2 E2 = __builtin_bit_cast(us2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(us2, (hi >> 8) & 0x00ff00ffu);
+            const us2 P24 = { E.y, E2.x }, P35 = { O.y, O2.x };
+            const us2 c14 = { 14, 14 }, c63 = { 63, 63 }, c103 = { 103, 103 };
+            o02[r] = __builtin_bit_cast(uint32_t, c14 * E + c63 * O + c103 * P24 + c63 * P35 + c14 * E2);      // (out0, out2)
+            o13[r] = __builtin_bit_cast(uint32_t, c14 * O + c63 * P24 + c103 * P35 + c63 * E2 + c14 * O2);     // (out1, out3)
+        }
+        // (row 2m, row 2m + 1) of each column: low halves / high halves of the two rows' words
+        const uint4 q = make_uint4(__builtin_amdgcn_perm(o02[1], o02[0], 0x05040100u), __builtin_amdgcn_perm(o13[1], o13[0], 0x05040100u),
+                                   __builtin_amdgcn_perm(o02[1], o02[0], 0x07060302u), __builtin_amdgcn_perm(o13[1], o13[0], 0x07060302u));
+        *reinterpret_cast<uint4*>(rowp + m * RW + 4 * g) = q;
+    }
+    __syncthreads();
+    // vertical 5-tap, (acc + 2^15) >> 16, saturate -> blurred u8.  A lane walks DOWN a group of four columns, one row pair
+    // at a time: the output rows 2m and 2m + 1 both live on the pairs m, m + 1, m + 2, three v_dot2_u32_u16 per pixel with
+    // the rounding constant as the first one's accumulator (the kernel is bound by vector instructions,
+    // profiles/r03_kernel_counters.json: this pass was 15 of them per pixel with one multiply-add per tap and unpacking).
+    {
+        constexpr int VPAIRS = 3, VSEG = (BH / 2 + VPAIRS - 1) / VPAIRS;       // 11 segments of 3 row pairs: 187 lanes = three waves
+        static_assert(VSEG * RG <= 256, "one lane per (column group, segment)");
+        const int g = tid % RG, seg = tid / RG;
+        if (seg < VSEG) {
+            const int m0 = seg * VPAIRS;
+            uint4 P[3];
+            auto fetch = [&](int m) { return *reinterpret_cast<const uint4*>(rowp + (m < GH / 2 ? m : GH / 2 - 1) * RW + 4 * g); };
+            P[0] = fetch(m0); P[1] = fetch(m0 + 1);
+#pragma unroll
+            for (int i = 0; i < VPAIRS; ++i) {
+                const int m = m0 + i;
+                P[(i + 2) % 3] = fetch(m + 2);
+                if (2 * m < BH) {
+                    const uint4 A = P[i % 3], B = P[(i + 1) % 3], C = P[(i + 2) % 3];
+                    const uint32_t a[4] = { A.x, A.y, A.z, A.w }, bb[4] = { B.x, B.y, B.z, B.w }, cc[4] = { C.x, C.y, C.z, C.w };
+                    uint32_t even = 0, odd = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        // row 2m: 14 r[2m] + 63 r[2m+1] + 103 r[2m+2] + 63 r[2m+3] + 14 r[2m+4]; row 2m + 1: the same one row down
+                        uint32_t e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), us2{ 14, 63 }, 1u << 15, false);
+                        e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), us2{ 103, 63 }, e, false);
+                        e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), us2{ 14, 0 }, e, false);
+                        uint32_t o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), us2{ 0, 14 }, 1u << 15, false);
+                        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), us2{ 63, 103 }, o, false);
+                        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), us2{ 63, 14 }, o, false);
+                        e >>= 16; o >>= 16;                                     // <= 257: saturate_cast<uchar>
+                        even |= (e > 255u ? 255u : e) << (8 * k);
+                        odd |= (o > 255u ? 255u : o) << (8 * k);
+                    }
+                    *reinterpret_cast<uint32_t*>(blur + (2 * m) * BW_ + 4 * g) = even;
+                    *reinterpret_cast<uint32_t*>(blur + (2 * m + 1) * BW_ + 4 * g) = odd;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // Sobel 3x3 on the blurred tile: 4 outputs per lane and row from three rows of 6 bytes (two dwords each); a lane walks
+    // down LT_H / 16 rows of its column group and unpacks every blurred row once
+    {
+        constexpr int SROWS = LT_H / 16;
+        const int g = tid & 15, seg = tid >> 4;
+        const int lx = 4 * g, gx = x0 + lx, ry0 = seg * SROWS;
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        // packed 16-bit lanes again: per row the column pairs P02 = (c0, c2), P13, P24, P35 of its six bytes; column sums
+        // S = r0 + 2 r1 + r2 and differences D = r2 - r0, then vx = S[k+2] - S[k], vy = D[k] + 2 D[k+1] + D[k+2]
+        s2 P[3][4];
+        auto unpack = [&](int row, s2 (&d)[4]) {
+            const uint32_t* src = reinterpret_cast<const uint32_t*>(blur + row * BW_ + lx);   // columns lx .. lx+7 <-> x-1 ..
+            const uint32_t lo = src[0], hi = src[1];
+            const s2 E = __builtin_bit_cast(s2, lo & 0x00ff00ffu), O = __builtin_bit_cast(s2, (lo >> 8) & 0x00ff00ffu);
+            const s2 E2 = __builtin_bit_cast(s2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(s2, (hi >> 8) & 0x00ff00ffu);
+            d[0] = E; d[1] = O; d[2] = s2{ E.y, E2.x }; d[3] = s2{ O.y, O2.x };
+        };
+        unpack(ry0, P[0]);
+        unpack(ry0 + 1, P[1]);
+        // a + 2 b in both 16-bit halves, one instruction (the compiler emits a shift and an add)
+        auto a_plus_2b = [](s2 a, s2 b) {
+            s2 d;
+            const uint32_t two = 0x00020002u;
+            asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(two), "v"(a));
+            return d;
+        };
+        uint32_t* orow = dxyo + ((size_t)f * Hc + (size_t)(y0 + ry0)) * W + gx;      // one 64-bit address per lane, rows step by W
+#pragma unroll
+        for (int i = 0; i < SROWS; ++i) {
+            const int ry = ry0 + i, gy = y0 + ry;
+            unpack(ry + 2, P[(i + 2) % 3]);
+            if (gx < W && gy < Hc) {
+                s2 S[4], D[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { S[c] = a_plus_2b(P[i % 3][c], P[(i + 1) % 3][c]) + P[(i + 2) % 3][c]; D[c] = P[(i + 2) % 3][c] - P[i % 3][c]; }
+                const s2 vx02 = S[2] - S[0], vx13 = S[3] - S[1];
+                const s2 vy02 = a_plus_2b(D[0], D[1]) + D[2], vy13 = a_plus_2b(D[1], D[2]) + D[3];
+                uint32_t* op = orow + (size_t)i * W;
+                // dx and dy of a pixel share one dword (dx low, dy high): the descriptor kernel fetches both with one gather
+                const uint32_t x02 = __builtin_bit_cast(uint32_t, vx02), x13 = __builtin_bit_cast(uint32_t, vx13);
+                const uint32_t y02 = __builtin_bit_cast(uint32_t, vy02), y13 = __builtin_bit_cast(uint32_t, vy13);
+                const uint32_t w[4] = { __builtin_amdgcn_perm(y02, x02, 0x05040100u), __builtin_amdgcn_perm(y13, x13, 0x05040100u),
+                                        __builtin_amdgcn_perm(y02, x02, 0x07060302u), __builtin_amdgcn_perm(y13, x13, 0x07060302u) };
+                if (gx + 3 < W && (W & 3) == 0) {
+                    *reinterpret_cast<uint4*>(op) = make_uint4(w[0], w[1], w[2], w[3]);
+                } else {
+                    for (int k = 0; k < 4 && gx + k < W; ++k) op[k] = w[k];
+                }
             }
         }
     }

@@ -32,11 +32,14 @@ namespace lf {
 // full" (r02_l .. r02_o): kernel alone 2.95 -> 2.82 ms, six batches in flight 139.3k -> 141.4k frames/s.  Two growers
 // + helper: 3.39 ms, 131.4k (problems with three or more components lose a grower).  r02_l's history: ring + first
 // idle wave of three vs. no ring: longest problem 7.96 -> 6.92 Mcycles, 127.5k -> 130.1k frames/s.
-#ifndef LFG_EVAL_QUEUE
-#define LFG_EVAL_QUEUE 1
-#endif
+//
+// LFG_EVAL_KERNEL=1 (lsd_grow.h; measured in round 3, not the default): the evaluation in a kernel of its own, k_lsd_eval
+// below -- THREE waves per problem, all growing; finished regions go to the problem's pending list in HBM.
 #ifndef LFG_GROW_WAVES
-#define LFG_GROW_WAVES 4
+#define LFG_GROW_WAVES (LFG_EVAL_KERNEL ? 3 : 4)
+#endif
+#ifndef LFG_EVAL_WAVES
+#define LFG_EVAL_WAVES 4        // waves of an evaluation workgroup: pending regions are handed out one at a time
 #endif
 static_assert(LFG_GROW_WAVES >= 2 || !LFG_EVAL_QUEUE, "with the evaluation ring the last wave of a workgroup never grows");
 constexpr int GROW_WAVES = LFG_GROW_WAVES;   // waves per problem: components of the defined-pixel graph are handed out among the growing ones
@@ -49,11 +52,14 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
                                                  const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
                                                  const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
                                                  int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
-                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, const int* __restrict__ perm)
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, const int* __restrict__ perm,
+                                                 double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
 {
     extern __shared__ uint32_t lds[];
-    __shared__ int next_comp, line_count, waves_done;
+    __shared__ int next_comp, line_count, waves_done, pend_n;
+#if LFG_EVAL_QUEUE
     __shared__ grow::EvalQueue evalq;
+#endif
     const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
@@ -71,8 +77,11 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     uint32_t* gu = gused + (size_t)pc * ((Ps + 31) / 32);
     if (n_def > def_lds)
         for (int i = tid; i < (n_def + 31) / 32; i += 64 * GROW_WAVES) gu[i] = 0u;
-    if (tid == 0) { next_comp = 0; line_count = 0; waves_done = 0; evalq.tail = 0; evalq.head = 0; evalq.growers = GROW_WAVES; }
+    if (tid == 0) { next_comp = 0; line_count = 0; waves_done = 0; pend_n = 0; }
+#if LFG_EVAL_QUEUE
+    if (tid == 0) { evalq.tail = 0; evalq.head = 0; evalq.growers = GROW_WAVES; }
     if (tid < LFG_QN) evalq.seq[tid] = 0;
+#endif
     __threadfence_block();
     __syncthreads();
     const int n_comp = comp_count[pc];
@@ -83,7 +92,14 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     const bool use_queue = LFG_EVAL_QUEUE != 0;
     grow::Ctx c;
     c.W = p.Ws; c.H = p.Hs;
-    c.q = use_queue ? &evalq : nullptr;
+#if LFG_EVAL_QUEUE
+    c.q = &evalq;
+#else
+    c.q = nullptr;
+#endif
+    c.pend_rec = pend_rec ? pend_rec + (size_t)pc * pend_cap * 12 : nullptr;
+    c.pend_tag = pend_tag ? pend_tag + (size_t)pc * pend_cap : nullptr;
+    c.pend_n = &pend_n; c.pend_cap = pend_cap;
     c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
     c.deg = c_deg + (size_t)pc * Ps;
     c.mod = c_mod + (size_t)pc * Ps;
@@ -119,7 +135,8 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     // no more components for this wave: help with the deferred evaluations until every growing wave is done and the ring is
     // empty -- or until there has been nothing to take for a while (an idle wave gives its slot back; whatever is pushed
     // after that is taken by the waves that finish later, the last grower always drains the ring)
-    if (use_queue) {
+#if LFG_EVAL_QUEUE
+    {
         if (lane == 0) atomicSub(&evalq.growers, 1);
         // the last wave stays for as long as anyone grows; a wave that has finished its components only drains what is there
         const bool stay = wave == GROW_WAVES - 1;
@@ -140,6 +157,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
             __builtin_amdgcn_s_sleep(64);
         }
     }
+#endif
 #ifdef LFG_STAMPS
     if (lane == 0) {
         // diagnostic: park the phase totals of every wave in the (otherwise unused) tail of the region scratch
@@ -169,8 +187,112 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
         const float4 v = *reinterpret_cast<const float4*>(tl + 4 * i);
         *reinterpret_cast<float4*>(out + 4 * rank) = v;
     }
+    if (lane == 0) {
+        counts[pc] = total;     // may exceed cap_lines: the host reports LF_ERR_CAPACITY
+        if (pend_count) pend_count[pc] = *(volatile int*)&pend_n;
+    }
+}
+
+// K_lsd_eval: rect_improve + final coordinates (grow::evaluate_pending) of every region on a problem's pending list, then
+// the accepted ones into seed order.  One workgroup per problem in the same longest-first order; wave w takes regions
+// w, w + waves, ... (one region = up to 26 rectangle scans of a few dozen rows: a few tens of thousands of cycles), so a
+// problem with r pending regions takes r / waves of them instead of the r the single evaluating wave of the ring form
+// went through.  A region's answer goes back into its own list entry (the line over the first 16 bytes of the
+// rectangle, tag = -1 when the NFA test rejects it) from ALL lanes: no lane-dependent branch in the loop (see
+// evaluate_pending).  Needs of a problem here: its row starts and x lists (LDS, as in the growing kernel) and the
+// angle plane.
+__global__ __launch_bounds__(64 * LFG_EVAL_WAVES) void k_lsd_eval(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+                                                                   const float* __restrict__ c_deg, const int* __restrict__ row_start,
+                                                                   double* pend_rec, int* pend_tag, const int* __restrict__ pend_count,
+                                                                   int pend_cap, float* lines, int* counts, int def_lds,
+                                                                   const int* __restrict__ perm, uint32_t* dbg_reg, size_t dbg_stride)
+{
+    extern __shared__ uint32_t lds[];
+    __shared__ int waves_done;
+    const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_pend = pend_count[pc];
+    if (n_pend == 0) return;                                    // counts[pc] = 0 was written by the growing kernel
+    if (n_pend > pend_cap) {                                    // more finished regions than the list holds: a capacity error of the run
+        if (tid == 0) counts[pc] = p.cap_lines + 1;
+        return;
+    }
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    int* rows = reinterpret_cast<int*>(lds);
+    uint16_t* lxs = reinterpret_cast<uint16_t*>(lds + ((p.Hs + 2) & ~1));
+    const int n_def = norder[pc];
+    const uint32_t* gxy = c_xy + (size_t)pc * Ps;
+    const int* grs = row_start + (size_t)pc * (p.Hs + 1);
+    for (int i = tid; i <= p.Hs; i += 64 * LFG_EVAL_WAVES) rows[i] = grs[i];
+    for (int i = tid; i < n_def && i < def_lds; i += 64 * LFG_EVAL_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
+    if (tid == 0) waves_done = 0;
+    __syncthreads();
+    grow::Ctx c;
+    c.W = p.Ws; c.H = p.Hs;
+    c.q = nullptr;
+    c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
+    c.deg = c_deg + (size_t)pc * Ps;
+    c.mod = nullptr; c.cs = nullptr; c.sn = nullptr; c.usedc = nullptr; c.gused = nullptr; c.used_lds = 0;
+    c.lreg = nullptr; c.greg = nullptr; c.reg_lds = 0;
+    c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
+    c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
+    c.min_reg_size = p.min_reg_size; c.refine = p.refine;
+    c.label = nullptr; c.root = 0;
+    c.tags = nullptr; c.line_count = nullptr;
+    c.pend_rec = nullptr; c.pend_tag = nullptr; c.pend_n = nullptr; c.pend_cap = 0;
+#ifdef LFG_STAMPS
+    for (int k = 0; k < 24; ++k) c.stamps[k] = 0;
+    const unsigned long long tb0 = __builtin_readcyclecounter();
+#endif
+    double* pr = pend_rec + (size_t)pc * pend_cap * 12;
+    int* pt = pend_tag + (size_t)pc * pend_cap;
+    for (int k = wave; k < n_pend; k += LFG_EVAL_WAVES) {
+        double* d = pr + (size_t)k * 12;
+        grow::Rect r;
+        r.x1 = d[0]; r.y1 = d[1]; r.x2 = d[2]; r.y2 = d[3]; r.width = d[4]; r.x = d[5]; r.y = d[6];
+        r.theta = d[7]; r.dx = d[8]; r.dy = d[9]; r.prec = d[10]; r.p = d[11];
+        const int tag = pt[k];
+        float4 line = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = grow::evaluate_pending(c, r, line);
+        *reinterpret_cast<float4*>(d) = line;                   // the same 16 bytes from every lane
+        pt[k] = ok ? tag : -1;
+    }
+#ifdef LFG_STAMPS
+    if (lane == 0) {
+        // diagnostic: the evaluating waves' totals in front of the growing waves' (see k_lsd_grow)
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(dbg_reg + (size_t)pc * dbg_stride + dbg_stride - 64 * GROW_WAVES - 64 * LFG_EVAL_WAVES) + 32 * wave;
+        for (int k = 0; k < 24; ++k) dbg[k] = c.stamps[k];
+        dbg[24] = __builtin_readcyclecounter() - tb0;
+        dbg[25] = (unsigned long long)n_pend;
+    }
+#endif
+    // the last wave to finish puts the accepted lines into the sequential order: a line's place is the number of accepted
+    // lines whose seed comes earlier in the seed list
+    __threadfence();
+    int done = 0;
+    if (lane == 0) done = atomicAdd(&waves_done, 1);
+    done = __builtin_amdgcn_readfirstlane(done);
+    if (done != LFG_EVAL_WAVES - 1) return;
+    __threadfence();
+    float* out = lines + (size_t)pc * p.cap_lines * 4;
+    int total = 0;
+    for (int i = lane; i < n_pend; i += 64) {
+        const int ti = __builtin_nontemporal_load(pt + i);
+        if (ti < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < n_pend; ++j) { const int tj = __builtin_nontemporal_load(pt + j); rank += (tj >= 0 && tj < ti) ? 1 : 0; }
+        ++total;
+        if (rank < p.cap_lines) {
+            const float* v = reinterpret_cast<const float*>(pr + (size_t)i * 12);
+            *reinterpret_cast<float4*>(out + 4 * rank) = make_float4(__builtin_nontemporal_load(v), __builtin_nontemporal_load(v + 1),
+                                                                      __builtin_nontemporal_load(v + 2), __builtin_nontemporal_load(v + 3));
+        }
+    }
+    total = grow::wave_sum_i(total);
     if (lane == 0) counts[pc] = total;     // may exceed cap_lines: the host reports LF_ERR_CAPACITY
 }
+
+int lsd_grow_pend_cap(const LsdParams& p) { return LFG_EVAL_KERNEL ? 2 * p.cap_lines : 0; }
 
 size_t lsd_grow_reg_stride(const LsdParams& p)
 {
@@ -184,7 +306,8 @@ size_t lsd_grow_reg_stride(const LsdParams& p)
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
-                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm, hipStream_t s)
+                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
+                     double* pend_rec, int* pend_tag, int* pend_count, hipStream_t s)
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.
@@ -208,7 +331,14 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
     const size_t lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
     hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
                        c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
-                       tmp_tags, lines, counts, reg_lds, def_lds, perm);
+                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
+#if LFG_EVAL_KERNEL
+    if (p.refine >= 2) {
+        const size_t elds = fixed + (size_t)def_lds * 2 + 8;
+        hipLaunchKernelGGL(k_lsd_eval, dim3(n_frames * 3), dim3(64 * LFG_EVAL_WAVES), elds, s, p, norder, c_xy, c_deg, row_start, pend_rec,
+                           pend_tag, pend_count, lsd_grow_pend_cap(p), lines, counts, def_lds, perm, reg, lsd_grow_reg_stride(p));
+    }
+#endif
 }
 
 }  // namespace lf

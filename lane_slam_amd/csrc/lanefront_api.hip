@@ -90,6 +90,9 @@ struct lf_handle {
     int* d_comp_key = nullptr;
     float* d_tmp_lines = nullptr;                             // lines in completion order + their seed positions (k_lsd_grow)
     int* d_tmp_tags = nullptr;
+    double* d_pend_rec = nullptr;     // pending regions of every LSD problem (k_lsd_grow -> k_lsd_eval): 12 doubles each,
+    int* d_pend_tag = nullptr;        // their seed positions,
+    int* d_pend_count = nullptr;      // and how many per problem
     int* d_seg_frame = nullptr;
     uint32_t* d_dxy = nullptr;          // LBD gradients, dx | dy << 16 per pixel
     DevBuf dbg_dx, dbg_dy;
@@ -411,7 +414,8 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
         dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(h->lsd)) ||
         dalloc(h, &h->d_clabel, nprob * Ps) || dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) || dalloc(h, &h->d_perm, nprob) || dalloc(h, &h->d_comp_key, nprob) ||
-        dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) || dalloc(h, &h->d_norder, nprob) ||
+        dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) ||
+        dalloc(h, &h->d_pend_rec, nprob * (size_t)lsd_grow_pend_cap(h->lsd) * 12 + 2) || dalloc(h, &h->d_pend_tag, nprob * (size_t)lsd_grow_pend_cap(h->lsd) + 1) || dalloc(h, &h->d_pend_count, nprob) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
         dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
@@ -455,7 +459,7 @@ extern "C" void lf_destroy(lf_handle* h)
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_gray, h->dbg_masks.p, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
                      h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
-                     h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
+                     h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
                      h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
@@ -566,7 +570,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         StageTimer t(h, ST_LSD_GROW);
         launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                        h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, s);
+                        h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
@@ -969,7 +973,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                    h->d_slot_lines, h->d_counts, nullptr, s);
+                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, s);
     LF_HIP_CHECK(h, hipGetLastError());
     int n = 0;
     LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->d_counts, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -122,8 +122,18 @@ struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 #ifndef LFG_QN
 #define LFG_QN 16
 #endif
+// LFG_EVAL_KERNEL=1 (round 3, measured and NOT the default): the evaluation in a kernel of its own -- the growing waves
+// append (rectangle, tag) to the problem's PENDING list in HBM and k_lsd_eval (k_lsd_grow.hip), launched behind the
+// growing kernel, evaluates the list with every wave of its workgroup working, so no wave sits through a problem's
+// growth waiting for regions.  Same-call A/B on configs[1] (3 x 3 alternating runs): six batches in flight 139.7 k ->
+// 139.3 k frames/s (+-0: a fifth fewer wave-slot-cycles per problem buy nothing, i.e. the pipelined rate is NOT bound by
+// wave slots), one batch alone 2.77 -> 3.28 ms for growing + evaluation (the evaluation, 0.45 ms = its slowest wave's
+// eleven regions at ~100 k cycles each, no longer hides under the growth).  Kept as a build option.
+#ifndef LFG_EVAL_KERNEL
+#define LFG_EVAL_KERNEL 0
+#endif
 #ifndef LFG_EVAL_QUEUE
-#define LFG_EVAL_QUEUE 1
+#define LFG_EVAL_QUEUE (LFG_EVAL_KERNEL ? 0 : 1)
 #endif
 struct EvalQueue {
     int tail, head;            // tickets reserved by producers / claimed by consumers
@@ -161,6 +171,10 @@ struct Ctx {
     int root;
     int* tags;                // seed position of every emitted line (HBM), or nullptr
     int* line_count;          // shared line counter (GPU: LDS, bumped atomically by the workgroup's waves)
+    double* pend_rec;         // HBM  pending list of the problem: 12 doubles per finished region (LFG_EVAL_KERNEL) ...
+    int* pend_tag;            // HBM  ... and its seed's position
+    int* pend_n;              // LDS  entries appended so far (may pass pend_cap: the evaluation kernel reports it)
+    int pend_cap;
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
     mutable unsigned long long stamps[24];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
                                             // 8 seed fetch, 9 regions, 10 region points, 11 grow batches
@@ -1028,6 +1042,36 @@ LFG_DEV bool evaluate_region(const Ctx& c, Rect& rec, int tag, float* lines, int
 }
 
 #ifndef LF_HOST_SIM
+// k_lsd_eval's form of evaluate_region: rect_improve and the final coordinates of one pending region, WITHOUT any
+// lane-dependent control flow -- every lane returns the same answer and the caller stores it from all lanes.  (A loop
+// whose body ends in `if (lane == 0) { emit }` is not safe: the compiler sent lanes 1..63 straight back to the loop
+// header with their own, never-assigned ticket while lane 0 was still emitting, and the wave never came out again.)
+LFG_DEV bool evaluate_pending(const Ctx& c, Rect& rec, float4& line)
+{
+    const double log_nfa = rect_improve(c, rec);
+    if (log_nfa <= c.log_eps) return false;
+    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+    if (c.scale != 1) {
+        rec.x1 /= c.scale; rec.y1 /= c.scale; rec.x2 /= c.scale; rec.y2 /= c.scale;
+    }
+    line = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
+    return true;
+}
+
+// LFG_EVAL_KERNEL: one more entry of the problem's pending list (lane 0 stores; the rectangle is wave-uniform)
+LFG_DEV void eval_append(const Ctx& c, const Rect& rec, int tag)
+{
+    if (lane_id() == 0) {
+        const int slot = atomicAdd(c.pend_n, 1);
+        if (slot < c.pend_cap) {
+            double2* d = reinterpret_cast<double2*>(c.pend_rec + (size_t)slot * 12);
+            d[0] = make_double2(rec.x1, rec.y1); d[1] = make_double2(rec.x2, rec.y2); d[2] = make_double2(rec.width, rec.x);
+            d[3] = make_double2(rec.y, rec.theta); d[4] = make_double2(rec.dx, rec.dy); d[5] = make_double2(rec.prec, rec.p);
+            c.pend_tag[slot] = tag;
+        }
+    }
+}
+
 LFG_DEV bool eval_push(const Ctx& c, const Rect& rec, int tag)
 {
     EvalQueue* q = c.q;
@@ -1165,7 +1209,11 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         }
         LFG_T1(c, 3)
         if (rejected) continue;
-#if !defined(LF_HOST_SIM) && LFG_EVAL_QUEUE
+#if !defined(LF_HOST_SIM) && LFG_EVAL_KERNEL
+        // rect_improve and the emission happen in k_lsd_eval, from the problem's pending list
+        if (c.refine >= 2) { eval_append(c, rec, tag); continue; }
+        if (!evaluate_region<false>(c, rec, tag, lines, cap, n_lines)) { LFG_T1(c, 6) continue; }
+#elif !defined(LF_HOST_SIM) && LFG_EVAL_QUEUE
         // rect_improve lives in ONE place, the helper loop of k_lsd_grow.hip (a second inlined copy here made the kernel
         // 71 KB of code against a 64 KB instruction cache): regions that need it always go through the ring.  The
         // workgroup's last wave never grows, so a full ring (sixteen regions waiting: the helper would have to fall

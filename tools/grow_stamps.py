@@ -16,8 +16,18 @@ seg = fe.process_batch(frames)
 scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
 Ps = scr.shape[2]
 # GROW_WAVES (4: three growing + the evaluating one) waves per problem, 32 u64 each, in the last 64 * GROW_WAVES words of the problem's region scratch
-GW = 4
+GW = int(os.environ.get("LFG_GW", "4"))
 raw = scr[:, :, Ps - 64 * GW:].copy().view(np.uint64).reshape(n * 3, GW, 32)
+if os.environ.get("LFG_EVAL_KERNEL") == "1":      # library built with -DLFG_EVAL_KERNEL=1 -DLFG_STAMPS (and LFG_GW=3)
+    EW = int(os.environ.get("LFG_EW", "4"))
+    ev = scr[:, :, Ps - 64 * GW - 64 * EW:Ps - 64 * GW].copy().view(np.uint64).reshape(n * 3, EW, 32)
+    et = ev[:, :, 24].astype(np.float64)
+    print("k_lsd_eval waves (kcycles): slowest wave of a problem mean %.0f max %.0f | sum over waves mean %.0f | pending regions mean %.1f max %d" % (
+        et.max(1).mean() / 1e3, et.max() / 1e3, et.sum(1).mean() / 1e3, ev[:, 0, 25].mean(), ev[:, 0, 25].max()))
+    for w in np.argsort(et.max(1))[-4:]:
+        k = et[w].argmax()
+        print("  longest evaluating wave: problem %d, %d pending, total %.0f scan %.0f math %.0f kcycles, nfa calls %d px %d" % (
+            w, ev[w, 0, 25], et[w, k] / 1e3, ev[w, k, 4] / 1e3, ev[w, k, 5] / 1e3, ev[w, k, 7] >> 40, ev[w, k, 7] & ((1 << 40) - 1)))
 tot_w = raw[:, :, 24].astype(np.float64)
 print("wave totals (kcycles): slowest wave mean %.0f max %.0f | sum over waves mean %.0f | components mean %.1f" % (
     tot_w.max(1).mean() / 1e3, tot_w.max() / 1e3, tot_w.sum(1).mean() / 1e3, raw[:, 0, 26].mean()))
@@ -31,7 +41,7 @@ CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
 raw7 = raw[:, :, 7].sum(1)
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
 # the growing waves (0..2) alone: the evaluating wave's total is "until the last grower is done" and hides them
-gtot = tot_w[:, :3]
+gtot = tot_w[:, :min(3, GW)]
 gslow = gtot.argmax(1)
 dg = raw[np.arange(n * 3), gslow][:, :27].astype(np.float64)
 for w in np.argsort(gtot.max(1))[-3:]:

@@ -67,3 +67,22 @@ for tag, suffix in (("one_batch_in_flight", ""), ("six_batches_in_flight", "_d6"
         res[tag] = d
 json.dump(res, open(os.path.join(P, "r03_grow_counters.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
+
+# The streaming kernels below the 40 % HBM line: what bounds them, from the same passes.  valu_issue_utilisation
+# near 1 = every SIMD issues a vector instruction almost every cycle: the kernel is bound by its instruction count, and its
+# HBM fraction can only rise by executing fewer instructions per byte.
+STREAMING = {"k_pre": ["lane_slam_amd/csrc/k_pre.hip"], "k_canny_nms": ["lane_slam_amd/csrc/k_canny.hip"],
+             "k_lbd_grad": ["lane_slam_amd/csrc/k_lbd.hip"], "k_lsd_grad": ["lane_slam_amd/csrc/k_lsd_grad.hip"],
+             "k_lbd": ["lane_slam_amd/csrc/k_lbd.hip"], "k_hysteresis": ["lane_slam_amd/csrc/k_canny.hip"]}
+out = {"source": res["source"], "kernels": {}}
+for kname, files in STREAMING.items():
+    c = {}
+    for part in ("sq", "sq2"):
+        c.update(per_kernel(os.path.join(P, "%s_pmc_grow_%s.csv" % (prefix, part)), kname))
+    d = derive(c)
+    if d:
+        d.pop("wave_slot_occupancy", None)          # that figure is priced at k_lsd_grow's register budget
+        d["source_digest"] = digest(*files)
+        out["kernels"][kname] = d
+json.dump(out, open(os.path.join(P, "r03_kernel_counters.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
