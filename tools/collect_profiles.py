@@ -12,6 +12,8 @@ def one(pattern):
     return f[0]
 
 shutil.copy(os.path.join(T, "bench_n1.json"), os.path.join(P, prefix + "_bench_n1.json"))
+if os.path.exists(os.path.join(T, "bench_driver_form.json")):
+    shutil.copy(os.path.join(T, "bench_driver_form.json"), os.path.join(P, prefix + "_bench_driver_form.json"))
 shutil.copy(os.path.join(T, "bench_d6_rocprof.json"), os.path.join(P, prefix + "_bench_depth6_under_rocprof.json"))
 shutil.copy(os.path.join(T, "bench_d1_rocprof.json"), os.path.join(P, prefix + "_bench_depth1_under_rocprof.json"))
 shutil.copy(one("d6/**/*kernel_stats.csv"), os.path.join(P, prefix + "_kernel_stats_depth6.csv"))

@@ -4,6 +4,8 @@ R=$GRAFT_REPO_ROOT
 T=${1:-r02a}; mkdir -p $R/gpurun_out/$T
 python -m pytest tests -m gpu -x -q > $R/gpurun_out/$T/pytest.log 2>&1; echo "pytest rc=$?"
 python bench.py > $R/gpurun_out/$T/bench_n1.json 2> $R/gpurun_out/$T/bench_n1.err
+# the driver's form of the same run (20 timed steps: the six-deep pipeline's fill and drain weigh more)
+python bench.py --gpus 1 --steps 20 --warmup 5 --secondary none > $R/gpurun_out/$T/bench_driver_form.json 2>/dev/null
 python tools/assoc_rate.py > $R/gpurun_out/$T/assoc_rate.txt 2>&1
 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
 LF_ASSOC_INT8=1 python tools/assoc_rate.py --pairs 16384x50000,65536x262144 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
