@@ -209,3 +209,28 @@ def test_edlines_plugin_matches_the_oracle_composition():
             assert det.detectLines(color).lines == []
     with pytest.raises(ValueError):
         LineDetectorEDLines({"hsv_white1": [0, 0, 0]})
+
+
+def test_keylines_edge_cases_blank_flat_and_mixed_batches():
+    """No structure at all (black, flat grey: no anchors, no KeyLines, every offset 0), and a batch that mixes such frames
+    with ordinary ones: per-frame offsets stay right and the ordinary frames are unaffected by their neighbours."""
+    cfg = default_config("parity")
+    frames = synth.make_batch(2, seed0=77)
+    gray = _gray_frames(cfg, frames)
+    blank = np.zeros_like(gray[0])
+    flat = np.full_like(gray[0], 131)
+    batch = np.stack([blank, gray[0], flat, gray[1], blank])
+    fe = FrontEnd(cfg, max_frames=5, max_lines_per_color=256)
+    k = fe.keylines_batch(batch, n_octaves=3, gray=True)
+    off = k["frame_offset"]
+    assert off[0] == 0 and off[1] == 0 and off[3] == off[2] and off[5] == off[4] and (k["frame_status"] == 0).all()
+    for f, src in ((1, 0), (3, 1)):
+        r = O.octave_keylines(gray[src], 3)
+        a, b = int(off[f]), int(off[f + 1])
+        assert b - a == r["n"] and r["n"] > 0
+        for name in ("start_end", "in_octave", "octave", "class_id", "num_pixels", "code"):
+            assert np.array_equal(k[name][a:b], r[name]), name
+        assert np.array_equal(k["desc"][a:b], r["desc"], equal_nan=True)
+    only_blank = fe.keylines_batch(np.stack([blank, flat]), n_octaves=2, gray=True)
+    assert only_blank["n"] == 0 and list(only_blank["frame_offset"]) == [0, 0, 0]
+    fe.close()

@@ -739,4 +739,10 @@ def test_knn_and_radius_match_follow_the_matcher_semantics():
         fe.knn_match(q, m, 17)
     e_i, e_d = fe.knn_match(q[:3], np.zeros((0, 32), np.uint8), 2)
     assert (e_i == -1).all() and (e_d == -1).all()
+    n_i, n_d = fe.knn_match(np.zeros((0, 32), np.uint8), m, 4)                 # no queries: empty results, no error
+    assert n_i.shape == (0, 4) and n_d.shape == (0, 4)
+    z_o, z_i, z_d = fe.radius_match(np.zeros((0, 32), np.uint8), m, 30.0)
+    assert list(z_o) == [0] and z_i.size == 0 and z_d.size == 0
+    z_o, z_i, z_d = fe.radius_match(q[:5], np.zeros((0, 32), np.uint8), 30.0)
+    assert list(z_o) == [0] * 6 and z_i.size == 0
     fe.close()
