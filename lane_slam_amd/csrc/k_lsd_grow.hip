@@ -45,6 +45,12 @@ static_assert(LFG_GROW_WAVES >= 2 || !LFG_EVAL_QUEUE, "with the evaluation ring 
 constexpr int GROW_WAVES = LFG_GROW_WAVES;   // waves per problem: components of the defined-pixel graph are handed out among the growing ones
 constexpr int GROW_LISTS = LFG_EVAL_QUEUE ? GROW_WAVES - 1 : GROW_WAVES;    // region lists (LDS + scratch slice): one per GROWING wave
 
+// BIG = false: the problems whose defined pixels all fit the LDS slice (every problem of the 640x480 geometries): the context's
+// "how many entries are in LDS" bounds are compile-time infinite, so the USED bits and x lists are plain LDS accesses -- with a
+// run-time bound every access was `e < n ? lds[e] : hbm[e]`, which the compiler turns into ONE flat access through a selected
+// address (the long way to LDS, and a wait for every global load in flight).  BIG = true: the same code with the bounds, for the
+// problems that do not fit; both kernels are launched, each leaves the other's problems alone.
+template <bool BIG>
 __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
     uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_LISTS * reg_lds);
     const int n_def = norder[pc];
+    if ((n_def > def_lds) != BIG) return;                            // the other kernel's problem
     const uint32_t* gxy = c_xy + (size_t)pc * Ps;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
     for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
@@ -100,12 +107,12 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     c.pend_rec = pend_rec ? pend_rec + (size_t)pc * pend_cap * 12 : nullptr;
     c.pend_tag = pend_tag ? pend_tag + (size_t)pc * pend_cap : nullptr;
     c.pend_n = &pend_n; c.pend_cap = pend_cap;
-    c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
+    c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = BIG ? def_lds : 0x7fffffff;
     c.deg = c_deg + (size_t)pc * Ps;
     c.mod = c_mod + (size_t)pc * Ps;
     c.cs = c_cs + (size_t)pc * Ps;
     c.sn = c_sn + (size_t)pc * Ps;
-    c.usedc = usedc; c.gused = gu; c.used_lds = def_lds;
+    c.usedc = usedc; c.gused = gu; c.used_lds = BIG ? def_lds : 0x7fffffff;
     // every wave has its own region list: reg_lds entries in LDS, the rest in its slice of the problem's scratch.
     // Problems too large for k_lsd_label's LDS (> label_items defined pixels) come as ONE component: wave 0 takes it
     // with the whole scratch, the other waves have nothing to do.
@@ -329,7 +336,10 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
     def_lds &= ~31;
     if ((size_t)def_lds > Ps) def_lds = (int)((Ps + 31) & ~(size_t)31);
     const size_t lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
+    hipLaunchKernelGGL(k_lsd_grow<false>, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
+                       c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
+                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
+    hipLaunchKernelGGL(k_lsd_grow<true>, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
                        c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
                        tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
 #if LFG_EVAL_KERNEL

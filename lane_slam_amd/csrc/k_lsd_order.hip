@@ -299,26 +299,30 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
 //   c_label[e]      root of entry e                     (u16; problems of more than label_items entries: all 0)
 //   comp_list[k]    roots of the components with >= min_reg_size pixels, by size descending, root ascending
 //   comp_count      how many
-__device__ __forceinline__ uint32_t uf_find(volatile uint32_t* P, uint32_t x)
+// (the parent array lives in LDS and is addressed as such: a volatile access through a generic pointer is a flat load)
+typedef __attribute__((address_space(3))) uint32_t uf_lds_u32;
+typedef volatile uf_lds_u32 uf_lds_vu32;
+__device__ __forceinline__ uint32_t uf_min(uf_lds_vu32* q, uint32_t v) { return __hip_atomic_fetch_min((uf_lds_u32*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t uf_find(uf_lds_vu32* P, uint32_t x)
 {
     uint32_t p = P[x];
     while (p != x) {
         const uint32_t g = P[p];
-        if (g != p) atomicMin(const_cast<uint32_t*>(&P[x]), g);      // path halving
+        if (g != p) (void)uf_min(&P[x], g);                            // path halving
         x = p;
         p = g;
     }
     return x;
 }
 
-__device__ __forceinline__ void uf_unite(volatile uint32_t* P, uint32_t a, uint32_t b)
+__device__ __forceinline__ void uf_unite(uf_lds_vu32* P, uint32_t a, uint32_t b)
 {
     for (;;) {
         a = uf_find(P, a);
         b = uf_find(P, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }            // a > b: hang a below b
-        const uint32_t old = atomicMin(const_cast<uint32_t*>(&P[a]), b);
+        const uint32_t old = uf_min(&P[a], b);
         if (old == a) return;                                          // a was still a root: done
         a = old;                                                       // somebody re-parented a meanwhile: go on from there
     }
@@ -373,14 +377,14 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
             const int end = rs[y];
             int hi = end;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)xs[mid] < x - 1) lo = mid + 1; else hi = mid; }
-            for (int k = lo; k < end && k < lo + 3 && (int)xs[k] <= x + 1; ++k) uf_unite(parent, (uint32_t)e, (uint32_t)k);
+            for (int k = lo; k < end && k < lo + 3 && (int)xs[k] <= x + 1; ++k) uf_unite((uf_lds_vu32*)parent, (uint32_t)e, (uint32_t)k);
         }
     }
     __syncthreads();
     for (int i = t; i < (n + 1) / 2; i += LT) csize2[i] = 0u;     // the x lists are no longer needed
     __syncthreads();
     for (int e = t; e < n; e += LT) {
-        const uint32_t r = uf_find(parent, (uint32_t)e);
+        const uint32_t r = uf_find((uf_lds_vu32*)parent, (uint32_t)e);
         lab[e] = (uint16_t)r;
         atomicAdd(&csize2[r >> 1], 1u << (16 * (r & 1u)));        // counts stay below 2^16 (n <= 8192): no carry between the halves
     }

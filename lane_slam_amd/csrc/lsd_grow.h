@@ -201,22 +201,41 @@ LFG_DEV int find_e(const Ctx& c, int x, int y)
     return (lo < end && xs_get(c, lo) == x) ? lo : -1;
 }
 
+#ifndef LF_HOST_SIM
+// The USED bits' LDS part and HBM part are reached through pointers of their own address spaces.  Written as
+// `e < n ? lds[..] : hbm[..]` on generic pointers the compiler selects the ADDRESS and issues ONE flat access, which takes the
+// long way to LDS and, counted as a vector-memory operation too, makes the wave wait for every global load in flight.
+// k_lsd_grow<false> (every problem of the 640x480 geometries) sets used_lds to "infinite": the HBM halves fold away and these
+// are plain LDS operations -- kernel alone 2.79 -> 2.61 ms, +3 % frames/s (same-call A/B; the same treatment of the region
+// lists, whose HBM tail is real, measured slower: the per-lane branch costs more than the flat access).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+LFG_DEV lds_u32* as_lds(uint32_t* p) { return (lds_u32*)p; }
+LFG_DEV bool used_get(const Ctx& c, int e)
+{
+    uint32_t w;
+    if (e < c.used_lds) w = as_lds(c.usedc)[e >> 5]; else w = c.gused[e >> 5];
+    return (w >> (e & 31)) & 1u;
+}
+// atomics without return value: no read-modify-write round trip on the sequential path
+LFG_DEV void used_or(const Ctx& c, int e)                // the calling lane's entry
+{
+    if (e < c.used_lds) __hip_atomic_fetch_or(as_lds(c.usedc) + (e >> 5), 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicOr(&c.gused[e >> 5], 1u << (e & 31));
+}
+LFG_DEV void used_set(const Ctx& c, int e) { if (lane_id() == 0) used_or(c, e); }
+LFG_DEV void used_clr(const Ctx& c, int e)
+{
+    if (lane_id() == 0) {
+        if (e < c.used_lds) __hip_atomic_fetch_and(as_lds(c.usedc) + (e >> 5), ~(1u << (e & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else atomicAnd(&c.gused[e >> 5], ~(1u << (e & 31)));
+    }
+}
+#else
 LFG_DEV bool used_get(const Ctx& c, int e)
 {
     const uint32_t w = e < c.used_lds ? c.usedc[e >> 5] : c.gused[e >> 5];
     return (w >> (e & 31)) & 1u;
 }
-#ifndef LF_HOST_SIM
-// atomics without return value: no read-modify-write round trip on the sequential path
-LFG_DEV void used_set(const Ctx& c, int e)
-{
-    if (lane_id() == 0) { if (e < c.used_lds) atomicOr(&c.usedc[e >> 5], 1u << (e & 31)); else atomicOr(&c.gused[e >> 5], 1u << (e & 31)); }
-}
-LFG_DEV void used_clr(const Ctx& c, int e)
-{
-    if (lane_id() == 0) { if (e < c.used_lds) atomicAnd(&c.usedc[e >> 5], ~(1u << (e & 31))); else atomicAnd(&c.gused[e >> 5], ~(1u << (e & 31))); }
-}
-#else
 LFG_DEV void used_set(const Ctx& c, int e) { if (e < c.used_lds) c.usedc[e >> 5] |= 1u << (e & 31); else c.gused[e >> 5] |= 1u << (e & 31); }
 LFG_DEV void used_clr(const Ctx& c, int e) { if (e < c.used_lds) c.usedc[e >> 5] &= ~(1u << (e & 31)); else c.gused[e >> 5] &= ~(1u << (e & 31)); }
 #endif
@@ -421,7 +440,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 if (acc) {
                     const int pos = n + below;
                     if (pos < c.reg_lds) c.lreg[pos] = key; else c.greg[pos] = key;
-                    if (e < c.used_lds) atomicOr(&c.usedc[e >> 5], 1u << (e & 31)); else atomicOr(&c.gused[e >> 5], 1u << (e & 31));
+                    used_or(c, e);
                 }
                 n += __popcll(maskA);
                 // the float sums take the accepted vectors in list order: (float)((double)sum + cos), one by one
