@@ -82,7 +82,11 @@ __global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables 
 // lookup in a 2^ntaps-entry table indexed by the bits under the taps, and the raw tile lives in
 // LDS as one 64-bit window per row.  Angles/sines are evaluated after compacting the tile's defined
 // pixels so the expensive double-precision path runs on full waves.
-__global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
+#ifndef LF_LSD_GRAD_THREADS
+#define LF_LSD_GRAD_THREADS 256
+#endif
+constexpr int LG_T = LF_LSD_GRAD_THREADS;      // threads per tile
+__global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
                                                   const uint32_t* __restrict__ mask_bits, uint32_t* __restrict__ r_addr,
                                                   float* __restrict__ r_deg, double* __restrict__ r_mod,
                                                   double* __restrict__ r_cs, double* __restrict__ r_sn,
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
     const int n_tiles = *list_count;
     const bool use_table = p.ntaps <= 7;
     if (use_table) {
-        for (int m = threadIdx.x; m < (1 << p.ntaps); m += 256) {
+        for (int m = threadIdx.x; m < (1 << p.ntaps); m += LG_T) {
             double s = 0.0;
             bool first = true;
             for (int j = 0; j < p.ntaps; ++j) {
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         // raw rows as bit windows: bit t of rowbits[ty] = edge_color(reflect(sx_lo-h+t), reflect(sy_lo-h+ty))
         const int xs = sx_lo - h;
         const bool interior_x = xs >= 0 && xs + rw <= p.W && rw <= 64;
-        for (int ty = threadIdx.x; ty < rh; ty += 256) {
+        for (int ty = threadIdx.x; ty < rh; ty += LG_T) {
             const int gy = reflect101(sy_lo - h + ty, p.Hc);
             const uint32_t* er = eb + (size_t)gy * p.Ww;
             const uint32_t* mr = mk + (size_t)gy * p.Ww;
@@ -184,13 +188,13 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         const uint32_t m_nsx = (1u << 19) / (uint32_t)nsx + 1u, m_nox = (1u << 19) / (uint32_t)nox + 1u;
         if (use_table && rw <= 64) {
             const int msk = (1 << p.ntaps) - 1;
-            for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
+            for (int idx = threadIdx.x; idx < rh * nsx; idx += LG_T) {
                 const int ry = small ? div_small(idx, m_nsx) : idx / nsx, cx = idx - ry * nsx;
                 const unsigned long long rb = rowbits[ry];
                 F[idx] = rb ? T[(int)(rb >> cx) & msk] : 0.0;
             }
         } else {
-            for (int idx = threadIdx.x; idx < rh * nsx; idx += 256) {
+            for (int idx = threadIdx.x; idx < rh * nsx; idx += LG_T) {
                 int ry = idx / nsx, cx = idx - ry * nsx;
                 const int gy = reflect101(sy_lo - h + ry, p.Hc);
                 double s = 0.0;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         }
         __syncthreads();
         // column filter
-        for (int idx = threadIdx.x; idx < nsy * nsx; idx += 256) {
+        for (int idx = threadIdx.x; idx < nsy * nsx; idx += LG_T) {
             const double* S = F + idx + h * nsx;                  // (by + h, cx) of idx = by * nsx + cx
             // F holds sums of positive constants or +0.0, so an all-zero window gives exactly +0.0 through the same
             // arithmetic (testing the window for zero first cost twice the instructions of the seven multiply-adds)
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         }
         __syncthreads();
         // horizontal resize
-        for (int idx = threadIdx.x; idx < nsy * nox; idx += 256) {
+        for (int idx = threadIdx.x; idx < nsy * nox; idx += LG_T) {
             const int by = small ? div_small(idx, m_nox) : idx / nox, ox = idx - by * nox;
             const int dx = X0 + ox;
             const int sx = t_xofs[ox];
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         }
         __syncthreads();
         // vertical resize
-        for (int idx = threadIdx.x; idx < noy * nox; idx += 256) {
+        for (int idx = threadIdx.x; idx < noy * nox; idx += LG_T) {
             const int oy = small ? div_small(idx, m_nox) : idx / nox, ox = idx - oy * nox;
             const int r0 = t_y0[oy], r1 = t_y1[oy];
             Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)t_yb[2 * oy] + Hb[r1 * (GT + 1) + ox] * (double)t_yb[2 * oy + 1];
@@ -235,12 +239,11 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         __syncthreads();
         // gradient + level-line angle; defined pixels are queued for the trigonometry pass
         double local_max = -1.0;
-        for (int oy = threadIdx.x >> 5; oy < oy_n; oy += 8) {
+        for (int oy = threadIdx.x >> 5; oy < oy_n; oy += LG_T / 32) {
             const int ox = threadIdx.x & 31;
             if (ox >= ox_n) continue;
             int dx = X0 + ox, dy = Y0 + oy;
             size_t a = (size_t)dy * p.Ws + dx;
-            float av = kNotDef;
             double norm = 0.0;
             if (dx < p.Ws - 1 && dy < p.Hs - 1) {
                 const double* q = Sc + oy * (GT + 1) + ox;
@@ -251,10 +254,11 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
                 if (n2 != 0.0) {                                   // sqrt(+0) = +0: flat pixels skip the root
                     norm = dm::dsqrt(n2);
                     if (!(norm <= p.rho)) {
-                        av = dm::fast_atan2_deg((float)gx, (float)(-gy));
+                        // the level-line angle waits for the trigonometry pass: there every lane has a defined pixel (here one
+                        // pixel in six does, and the arc tangent would run for the whole wave)
                         if (norm > local_max) local_max = norm;
                         const int slot = atomicAdd(&n_def, 1);
-                        dl[slot] = make_uint2((uint32_t)a, __float_as_uint(av));
+                        dl[slot] = make_uint2((uint32_t)a, (uint32_t)(oy * (GT + 1) + ox));
                         dln[slot] = norm;
                     }
                 }
@@ -277,9 +281,13 @@ __global__ __launch_bounds__(256) void k_lsd_grad(LsdParams p, ResizeTables rt, 
         // one record per defined pixel; cos/sin of the float-rounded angle (what region growing
         // accumulates) evaluated on full waves.  Record order is arbitrary (k_lsd_order sorts by address).
         const size_t rb = (size_t)pc * Ps + rec_base;
-        for (int e = threadIdx.x; e < nd; e += 256) {
+        for (int e = threadIdx.x; e < nd; e += LG_T) {
             const uint2 it = dl[e];
-            const float av = __uint_as_float(it.y);
+            const double* q = Sc + it.y;                          // the pixel's 2x2 neighbourhood again: the same gx, gy as above
+            const double DA = q[GT + 2] - q[0];
+            const double BC = q[1] - q[GT + 1];
+            const double gx = DA + BC, gy = DA - BC;
+            const float av = dm::fast_atan2_deg((float)gx, (float)(-gy));
             const double arad = (double)av * DEG_TO_RADS;
             double s_, c_;
             dm::dsincos((double)(float)arad, s_, c_);
@@ -310,7 +318,7 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
     hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, list, list_count);
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
-    hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(256), lds, s, p, rt, edge_bits, mask_bits, r_addr, r_deg, r_mod, r_cs,
+    hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(LG_T), lds, s, p, rt, edge_bits, mask_bits, r_addr, r_deg, r_mod, r_cs,
                        r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count);
 }
 
