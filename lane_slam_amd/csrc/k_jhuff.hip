@@ -15,7 +15,8 @@
 //                  1, 2, ...: a thread whose predecessor handed over a different state than the one it started from decodes
 //                  again from that state; when nothing changes any more every subsequence has its true entry state
 //                  (subsequence 0 of an interval is exact from the start, so after pass p the first p + 1 are: at most as
-//                  many passes as subsequences, two or three in practice).  Then the blocks completed per subsequence are
+//                  many passes as subsequences; measured on 640x480 camera-like frames: 14 - 25, because the block's place in the MCU, part of the
+//                  state, never re-synchronises by itself -- DESIGN.md section 8).  Then the blocks completed per subsequence are
 //                  prefix-summed and a last decode writes the quantised coefficients (int16, natural order, dense 64 per
 //                  block; DC still as differences) and performs the checks of a sequential decoder: invalid code, run past
 //                  63, DC size > 11, reading beyond the interval, a restart interval of the wrong length.
@@ -32,7 +33,10 @@ namespace lf {
 constexpr int JH_T = 256;          // k_jh_unstuff
 constexpr int JH_TD = 1024;        // k_jh_decode: one thread per subsequence of a typical camera frame (~300)
 constexpr int JH_LDS_CLEAN = 96 * 1024;     // scans up to this many clean bytes are decoded out of LDS
-constexpr int JH_SB = 64;          // clean bytes per subsequence
+#ifndef LF_JH_SB
+#define LF_JH_SB 48
+#endif
+constexpr int JH_SB = LF_JH_SB;    // clean bytes per subsequence
 
 struct JhInfo { int clean_len, n_seg, n_sub, err; };
 
@@ -229,7 +233,7 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
     return done;
 }
 
-struct JhShared { JhTabs tabs; int s_changed, s_err, s_nsub, s_wsum[JH_TD / 64], s_carry; int s_dc[JH_TD / 64][4], s_dcc[JH_TD / 64 + 1][3]; };
+struct JhShared { JhTabs tabs; int s_changed, s_redo, s_err, s_nsub, s_wsum[JH_TD / 64], s_carry; int s_dc[JH_TD / 64][4], s_dcc[JH_TD / 64 + 1][3]; };
 
 // LDS = true: the clean scan sits in jh_dyn (the compiler sees an LDS address: ds_read instead of flat loads)
 template <bool LDS>
@@ -239,7 +243,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
 {
     constexpr int JH_T = JH_TD;                              // (this kernel's workgroup size)
     JhTabs& tabs = sh.tabs;
-    int& s_changed = sh.s_changed; int& s_err = sh.s_err; int& s_nsub = sh.s_nsub; int& s_carry = sh.s_carry;
+    int& s_changed = sh.s_changed; int& s_redo = sh.s_redo; int& s_err = sh.s_err; int& s_nsub = sh.s_nsub; int& s_carry = sh.s_carry;
     int* s_wsum = sh.s_wsum;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const uint8_t* clean = LDS ? reinterpret_cast<const uint8_t*>(jh_dyn) : clean_global;
@@ -269,6 +273,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         s_nsub = acc <= MS ? acc : -1;
         s_err = I->err;
         s_changed = 0;
+        s_redo = 0;
     }
     __syncthreads();
     const int n_sub = s_nsub;
@@ -304,6 +309,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
             const uint32_t cb = u_cbit[u], cp = u_cph[u];
             if (cb == u_ebit[u] && cp == u_eph[u]) continue;
             changed = true;
+            if (getenv_debug) atomicAdd(&s_redo, 1);
             const uint32_t local = (uint32_t)u - sub_first[g];
             const uint32_t start = (sb[g] + local * JH_SB) * 8u, seg_end = sb[g + 1] * 8u;
             uint32_t limit = start + JH_SB * 8u;
@@ -319,7 +325,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         __syncthreads();
         if (t == 0) s_changed = 0;
         __syncthreads();
-        if (!any) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d passes %d\n", f, n_sub, pass + 1); break; }
+        if (!any) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d redone %d passes %d\n", f, n_sub, s_redo, pass + 1); break; }
     }
     // ---- blocks completed before every subsequence (exclusive prefix over the frame's subsequences)
     if (t == 0) s_carry = 0;
