@@ -157,20 +157,8 @@ __global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __res
 // ---------------------------------------------------------------------------------------------- k_jh_decode
 struct JhTabs { jpeg::HuffDev t[8]; };
 
-// 32 bits of the clean stream from bit position `bit` on, MSB first: three aligned dwords (the stream sits in LDS for
-// camera-sized frames: a flat pointer serves both), byte-swapped and funnel-shifted
-// PAD: the stream sits in LDS with one spare dword after every 32 (dword d at d + d / 32): the 64 lanes of a wave read
-// from subsequences 128 bytes = 32 dwords apart, which without the padding is the SAME bank for all of them
-template <bool PAD>
-__device__ __forceinline__ uint32_t jh_peek32(const uint8_t* clean, uint32_t bit)
-{
-    const uint32_t* p = reinterpret_cast<const uint32_t*>(clean);
-    const uint32_t d0 = bit >> 5, d1 = d0 + 1;
-    const uint32_t w0 = __builtin_bswap32(p[PAD ? d0 + (d0 >> 5) : d0]), w1 = __builtin_bswap32(p[PAD ? d1 + (d1 >> 5) : d1]);
-    const uint32_t sh = bit & 31u;
-    return sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
-}
-
+// PAD (jh_span): the stream sits in LDS with one spare dword after every 32 (dword d at d + d / 32): the 64 lanes of a wave read
+// from subsequences a fixed distance apart, which without the padding is the SAME bank for many of them
 // one Huffman code from the top of w: returns length (0: no code of up to 16 bits matches) and the symbol
 __device__ __forceinline__ int jh_code(const jpeg::HuffDev& h, uint32_t w, int& sym)
 {
@@ -199,34 +187,62 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
     int done = 0;
     uint32_t bit = st.bit;
     int blk = st.blk, k = st.k;
+    // The stream goes through a 64-bit buffer in registers, the next dword always on its way: a symbol's only dependent
+    // trip to LDS is its code-table lookup (a fresh three-dword look per symbol was two trips in a row, ~500 cycles per symbol).
+    // buf: the next `cnt` bits of the stream, left-aligned; nd: the dword that `nextw` holds (clamped to the interval's
+    // last dword + 1: reads never go past what the interval owns plus one dword, as before).
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(clean);
+    const uint32_t dmax = (end_bit >> 5) + 1u;
+    uint32_t nd = bit >> 5;
+    auto fetch = [&](uint32_t d) { const uint32_t dc_ = d < dmax ? d : dmax; return __builtin_bswap32(p[PAD ? dc_ + (dc_ >> 5) : dc_]); };
+    uint64_t buf = ((uint64_t)fetch(nd) << 32) | (uint64_t)fetch(nd + 1);
+    buf <<= (bit & 31u);
+    int cnt = 64 - (int)(bit & 31u);
+    nd += 2;
+    uint32_t nextw = fetch(nd);
+    // the tables of the current block: DC and AC table of its component
+    int comp = blk < sel.luma ? 0 : blk - sel.luma + 1;
+    int tdc = (int)((sel.tsel >> (4 * comp)) & 15u), tac = (int)((sel.tsel >> (4 * comp + 12)) & 15u);
     while (bit < limit) {
         if (WRITE && cur >= end_block) break;
         // one symbol = one Huffman code + its magnitude bits (at most 16 + 15 bits: one 32-bit look).  DC and AC share the
         // path: DC is "run 0, size = the symbol" (T.81 F.2.2.1), AC "run = high nibble, size = low nibble" with EOB / ZRL
-        const int comp = blk < sel.luma ? 0 : blk - sel.luma + 1;
         const bool dc = k == 0;
-        const uint32_t w = jh_peek32<PAD>(clean, bit);
+        const uint32_t w = (uint32_t)(buf >> 32);
         int sym;
-        const int len = jh_code(tabs.t[(sel.tsel >> (4 * comp + (dc ? 0 : 12))) & 15u], w, sym);
+        const int len = jh_code(tabs.t[dc ? tdc : tac], w, sym);
         const int run = dc ? 0 : sym >> 4, sz = dc ? sym : sym & 15;
         const int kn = k + run;
         const bool bad = len == 0 || (dc && sym > 11) || (!dc && sz != 0 && kn > 63);
+        int n;
         if (bad) {
             if (WRITE) { err |= 2; break; }
-            bit += 1;                                   // speculative decode out of step: slide on, the true state arrives later
-            continue;
+            n = 1;                                      // speculative decode out of step: slide on, the true state arrives later
+        } else {
+            if (WRITE && sz) {
+                const int v = (int)((w << len) >> (32 - sz));
+                coef[(size_t)cur * 64 + c_zigzag[kn]] = (int16_t)(v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v);
+            }
+            n = len + sz;
+            k = (!dc && sz == 0) ? (run == 15 ? k + 16 : 64) : kn + 1;           // ZRL / EOB / a coefficient
         }
-        if (WRITE && sz) {
-            const int v = (int)((w << len) >> (32 - sz));
-            coef[(size_t)cur * 64 + c_zigzag[kn]] = (int16_t)(v < (1 << (sz - 1)) ? v - (1 << sz) + 1 : v);
+        bit += (uint32_t)n;
+        buf <<= n;
+        cnt -= n;
+        if (cnt <= 32) {
+            buf |= (uint64_t)nextw << (32 - cnt);
+            cnt += 32;
+            ++nd;
+            nextw = fetch(nd);
         }
-        bit += (uint32_t)(len + sz);
-        k = (!dc && sz == 0) ? (run == 15 ? k + 16 : 64) : kn + 1;           // ZRL / EOB / a coefficient
+        if (bad) continue;
         if (WRITE && bit > end_bit) { err |= 4; break; }                      // bits that are not in the interval were consumed
         if (k >= 64) {
             k = 0;
             blk = blk + 1 == sel.bpm ? 0 : blk + 1;
             ++done; ++cur;
+            comp = blk < sel.luma ? 0 : blk - sel.luma + 1;
+            tdc = (int)((sel.tsel >> (4 * comp)) & 15u); tac = (int)((sel.tsel >> (4 * comp + 12)) & 15u);
         }
     }
     st.bit = bit; st.blk = blk; st.k = k;
