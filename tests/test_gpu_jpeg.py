@@ -181,3 +181,35 @@ def test_device_entropy_decoder_on_camera_frames():
         pil = np.asarray(Image.open(io.BytesIO(streams[i])).convert("RGB"))[..., ::-1]
         assert np.array_equal(g[i], pil), i
     fe2.close()
+
+
+def test_device_entropy_decoder_on_large_frames_and_restart_intervals():
+    """1920x1080 streams: scans of several hundred KB, beyond what the decode kernel stages in LDS (the global-memory form of
+    the same code), thousands of subsequences per frame, with and without restart intervals; against Pillow and the host
+    entropy path."""
+    Image = pytest.importorskip("PIL.Image")
+    cfg = default_config("fullres", in_size=(1080, 1920))
+    fe2 = FrontEnd(cfg, max_frames=4, max_lines_per_color=64)
+    rng = np.random.default_rng(5)
+    streams = []
+    for i in range(4):
+        img = synth.make_batch(1, 40 + i, rows=1080, cols=1920)[0]
+        if i % 2:
+            img = np.clip(img.astype(np.int16) + rng.integers(-25, 26, img.shape, dtype=np.int16), 0, 255).astype(np.uint8)    # noisy: a long scan
+        b = io.BytesIO()
+        kw = {"restart_marker_blocks": 37} if i >= 2 else {}
+        try:
+            Image.fromarray(img[..., ::-1].copy()).save(b, "JPEG", quality=(92, 97)[i % 2], subsampling=(2, 0)[i % 2], **kw)
+        except TypeError:                                   # an older Pillow without restart_marker_blocks
+            b = io.BytesIO()
+            Image.fromarray(img[..., ::-1].copy()).save(b, "JPEG", quality=(92, 97)[i % 2], subsampling=(2, 0)[i % 2])
+        streams.append(b.getvalue())
+    assert max(len(s) for s in streams) > 200 * 1024          # really beyond the 96 KB LDS stage
+    g, gs = fe2.decode_jpeg_batch(streams, entropy="gpu")
+    h, hs = fe2.decode_jpeg_batch(streams, entropy="host", n_threads=4)
+    assert not gs.any() and not hs.any()
+    for i in range(4):
+        pil = np.asarray(Image.open(io.BytesIO(streams[i])).convert("RGB"))[..., ::-1]
+        assert np.array_equal(g[i], pil), i
+        assert np.array_equal(g[i], h[i]), i
+    fe2.close()
