@@ -45,28 +45,34 @@ static_assert(LFG_GROW_WAVES >= 2 || !LFG_EVAL_QUEUE, "with the evaluation ring 
 constexpr int GROW_WAVES = LFG_GROW_WAVES;   // waves per problem: components of the defined-pixel graph are handed out among the growing ones
 constexpr int GROW_LISTS = LFG_EVAL_QUEUE ? GROW_WAVES - 1 : GROW_WAVES;    // region lists (LDS + scratch slice): one per GROWING wave
 
-// BIG = false: the problems whose defined pixels all fit the LDS slice (every problem of the 640x480 geometries): the context's
-// "how many entries are in LDS" bounds are compile-time infinite, so the USED bits and x lists are plain LDS accesses -- with a
-// run-time bound every access was `e < n ? lds[e] : hbm[e]`, which the compiler turns into ONE flat access through a selected
-// address (the long way to LDS, and a wait for every global load in flight).  BIG = true: the same code with the bounds, for the
-// problems that do not fit; both kernels are launched, each leaves the other's problems alone.
+// The workgroup's bookkeeping words (static LDS, file scope so that both instances of the problem code below share them)
+__shared__ int g_next_comp, g_line_count, g_waves_done, g_pend_n;
+#if LFG_EVAL_QUEUE
+__shared__ grow::EvalQueue g_evalq;
+#endif
+
+// One problem.  BIG = false: its defined pixels all fit the LDS slice (every problem of the synthetic 640x480 frames): the
+// context's "how many entries are in LDS" bounds are compile-time infinite, so the USED bits and x lists are plain LDS accesses
+// -- with a run-time bound every access was `e < n ? lds[e] : hbm[e]`, which the compiler turns into ONE flat access through a
+// selected address (the long way to LDS, and a wait for every global load in flight).  BIG = true: the same code with the
+// bounds, for the problems that do not fit.  The kernel picks per workgroup (two launches, one per kind, run the two kinds one
+// after the other: 11 % fewer frames/s on the real camera frames, whose problems are of both kinds).
 template <bool BIG>
-__global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
+__device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
                                                  const double* __restrict__ c_cs, const double* __restrict__ c_sn,
                                                  const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
                                                  const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
                                                  int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
-                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, const int* __restrict__ perm,
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, int pc,
                                                  double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
 {
     extern __shared__ uint32_t lds[];
-    __shared__ int next_comp, line_count, waves_done, pend_n;
+    int& next_comp = g_next_comp; int& line_count = g_line_count; int& waves_done = g_waves_done; int& pend_n = g_pend_n;
 #if LFG_EVAL_QUEUE
-    __shared__ grow::EvalQueue evalq;
+    grow::EvalQueue& evalq = g_evalq;
 #endif
-    const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
@@ -75,7 +81,6 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
     uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_LISTS * reg_lds);
     const int n_def = norder[pc];
-    if ((n_def > def_lds) != BIG) return;                            // the other kernel's problem
     const uint32_t* gxy = c_xy + (size_t)pc * Ps;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
     for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
@@ -200,6 +205,25 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     }
 }
 
+__global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
+                                                 const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+                                                 const float* __restrict__ c_deg, const double* __restrict__ c_mod,
+                                                 const double* __restrict__ c_cs, const double* __restrict__ c_sn,
+                                                 const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
+                                                 const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
+                                                 int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, const int* __restrict__ perm,
+                                                 double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
+{
+    const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
+    if (norder[pc] > def_lds)
+        lsd_grow_problem<true>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
+                               gused, tmp_lines, tmp_tags, lines, counts, reg_lds, def_lds, pc, pend_rec, pend_tag, pend_count, pend_cap);
+    else
+        lsd_grow_problem<false>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
+                                gused, tmp_lines, tmp_tags, lines, counts, reg_lds, def_lds, pc, pend_rec, pend_tag, pend_count, pend_cap);
+}
+
 // K_lsd_eval: rect_improve + final coordinates (grow::evaluate_pending) of every region on a problem's pending list, then
 // the accepted ones into seed order.  One workgroup per problem in the same longest-first order; wave w takes regions
 // w, w + waves, ... (one region = up to 26 rectangle scans of a few dozen rows: a few tens of thousands of cycles), so a
@@ -310,41 +334,57 @@ size_t lsd_grow_reg_stride(const LsdParams& p)
     return Ps > need ? Ps : need;
 }
 
-void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
-                     const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
-                     const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
-                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
-                     double* pend_rec, int* pend_tag, int* pend_count, hipStream_t s)
+// LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.
+// (An x-bucket table for the pixel searches -- 8 buckets per row, 9 KB -- was measured at +-0: the searches are
+// ~6 % of the kernel and the table costs LDS residency.)
+// lds_kb serves the 640x480 geometries (a few thousand defined pixels per problem).  Larger LSD images
+// (1080p: 1536x576) have proportionally more defined pixels and far fewer problems per batch, so latency
+// matters more than residency: grow the slice with the image (~3 % of the pixels defined), up to 64 KB.
+static void lsd_grow_slice(const LsdParams& p, int lds_kb, int& reg_lds, int& def_lds, size_t& lds)
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.
-    // (An x-bucket table for the pixel searches -- 8 buckets per row, 9 KB -- was measured at +-0: the searches are
-    // ~6 % of the kernel and the table costs LDS residency.)
     const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4;
-    // LFG_LDS_KB serves the 640x480 geometries (a few thousand defined pixels per problem).  Larger LSD images
-    // (1080p: 1536x576) have proportionally more defined pixels and far fewer problems per batch, so latency
-    // matters more than residency: grow the slice with the image (~3 % of the pixels defined), up to 64 KB.
-    int reg_lds = LFG_REG_LDS;
+    reg_lds = LFG_REG_LDS;
     const size_t regs = (size_t)GROW_LISTS * reg_lds * 4;
-    size_t budget = LFG_LDS_KB * 1024 + regs - (size_t)reg_lds * 4;
+    size_t budget = (size_t)lds_kb * 1024 + regs - (size_t)reg_lds * 4;
     {
         const size_t want = fixed + regs + 8 + (size_t)((double)Ps * 0.03 * 17.0 / 8.0);
         if (want > budget) budget = want < (size_t)64 * 1024 ? want : (size_t)64 * 1024;
     }
     long long left = (long long)budget - (long long)fixed - (long long)regs - 8;
-    int def_lds = left > 0 ? (int)(left * 8 / 17) : 0;         // 2 B + 1/8 B per entry
+    def_lds = left > 0 ? (int)(left * 8 / 17) : 0;         // 2 B + 1/8 B per entry
     def_lds &= ~31;
     if ((size_t)def_lds > Ps) def_lds = (int)((Ps + 31) & ~(size_t)31);
-    const size_t lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
-    hipLaunchKernelGGL(k_lsd_grow<false>, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
-                       c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
-                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
-    hipLaunchKernelGGL(k_lsd_grow<true>, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
+    lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
+}
+
+int lsd_grow_def_lds(const LsdParams& p, int lds_kb)
+{
+    int reg_lds, def_lds;
+    size_t lds;
+    lsd_grow_slice(p, lds_kb, reg_lds, def_lds, lds);
+    return def_lds;
+}
+
+// lds_kb: the slice size.  13 KB (LFG_LDS_KB) holds every problem of the synthetic lane frames and gives the most resident
+// problems; real camera frames have two to three times the edge pixels, most of their problems overflow 13 KB into the
+// bounded (flat-access, HBM-backed) path, and a 20 / 28 KB slice is worth +11 / +16 % frames/s there (-1 / -6 % on the synthetic
+// frames) -- so the host moves a handle between kGrowLdsKb[] by the share of overflowing problems it saw in the last batch.
+void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
+                     const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
+                     const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
+                     uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
+                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, hipStream_t s)
+{
+    int reg_lds, def_lds;
+    size_t lds;
+    lsd_grow_slice(p, lds_kb > 0 ? lds_kb : LFG_LDS_KB, reg_lds, def_lds, lds);
+    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
                        c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
                        tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
 #if LFG_EVAL_KERNEL
     if (p.refine >= 2) {
-        const size_t elds = fixed + (size_t)def_lds * 2 + 8;
+        const size_t elds = (size_t)((p.Hs + 2) & ~1) * 4 + (size_t)def_lds * 2 + 8;
         hipLaunchKernelGGL(k_lsd_eval, dim3(n_frames * 3), dim3(64 * LFG_EVAL_WAVES), elds, s, p, norder, c_xy, c_deg, row_start, pend_rec,
                            pend_tag, pend_count, lsd_grow_pend_cap(p), lines, counts, def_lds, perm, reg, lsd_grow_reg_stride(p));
     }

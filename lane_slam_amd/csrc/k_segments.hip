@@ -14,8 +14,10 @@
 
 namespace lf {
 
+// overflow[0]: some problem has more lines than cap_lines.  overflow[1], [2]: problems whose defined pixels exceed the region
+// growing kernel's LDS slice at its small / medium size (the host sizes the next batch's slices from them, k_lsd_grow.hip)
 __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict__ counts, int* __restrict__ seg_offset,
-                              int* __restrict__ frame_offset, int* __restrict__ overflow)
+                              int* __restrict__ frame_offset, int* __restrict__ overflow, const int* __restrict__ norder, int cap_small, int cap_medium)
 {
     // single workgroup exclusive scan over n_frames*3 clipped counts
     __shared__ int carry;
@@ -28,7 +30,10 @@ __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict
     for (int base = 0; base < n; base += blockDim.x) {
         int i = base + t;
         int v = 0;
-        if (i < n) { v = counts[i]; if (v > cap_lines) { v = cap_lines; ovf = 1; } }
+        if (i < n) {
+            v = counts[i]; if (v > cap_lines) { v = cap_lines; ovf = 1; }
+            if (norder) { const int nd = norder[i]; if (nd > cap_small) atomicAdd(overflow + 1, 1); if (nd > cap_medium) atomicAdd(overflow + 2, 1); }
+        }
         int inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
@@ -50,10 +55,10 @@ __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict
 }
 
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
-                        int* overflow, hipStream_t s)
+                        int* overflow, const int* norder, int cap_small, int cap_medium, hipStream_t s)
 {
     hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1024), 0, s, n_frames, cap_lines, counts, seg_offset,
-                       frame_offset, overflow);
+                       frame_offset, overflow, norder, cap_small, cap_medium);
 }
 
 __device__ __forceinline__ int check_bounds(int v, int bound) { return v < 0 ? 0 : (v >= bound ? bound - 1 : v); }

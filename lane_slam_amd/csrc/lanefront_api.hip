@@ -114,6 +114,8 @@ struct lf_handle {
     int last_frames = 0;
     bool plugin_ready = false;
     bool pending = false;
+    int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
+    int pending_problems = 0;
     int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
     JpegState* jpeg = nullptr;
@@ -417,7 +419,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) ||
         dalloc(h, &h->d_pend_rec, nprob * (size_t)lsd_grow_pend_cap(h->lsd) * 12 + 2) || dalloc(h, &h->d_pend_tag, nprob * (size_t)lsd_grow_pend_cap(h->lsd) + 1) || dalloc(h, &h->d_pend_count, nprob) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
-        dalloc(h, &h->d_overflow, 1) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
+        dalloc(h, &h->d_overflow, 4) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
@@ -570,7 +572,8 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         StageTimer t(h, ST_LSD_GROW);
         launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                        h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, s);
+                        h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count,
+                        kGrowLdsKb[getenv("LF_GROW_LDS_LEVEL") ? atoi(getenv("LF_GROW_LDS_LEVEL")) % 3 : h->grow_lds_level], s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
@@ -582,9 +585,9 @@ static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
     hipStream_t s = h->stream;
     {
         StageTimer t(h, ST_SEGMENTS);
-        LF_HIP_CHECK(h, hipMemsetAsync(h->d_overflow, 0, sizeof(int), s));
+        LF_HIP_CHECK(h, hipMemsetAsync(h->d_overflow, 0, 4 * sizeof(int), s));
         launch_seg_offsets(n, h->cap_lines, h->d_counts, h->d_seg_offset, dev_out.frame_offset ? dev_out.frame_offset : h->d_frame_offset,
-                           h->d_overflow, s);
+                           h->d_overflow, h->d_norder, lsd_grow_def_lds(h->lsd, kGrowLdsKb[0]), lsd_grow_def_lds(h->lsd, kGrowLdsKb[1]), s);
         launch_segments(h->seg, n, h->d_slot_lines, h->d_counts, h->d_seg_offset, h->d_maskbits, h->Ww, dev_out, h->d_seg_frame,
                         h->d_normals64, h->d_centers, s);
     }
@@ -634,8 +637,9 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
     if (rc != LF_OK) return rc;
     // total + overflow flag travel to pinned host memory behind the kernels
     LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
-    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     h->pending = true;
+    h->pending_problems = n_frames * 3;
     h->pending_capacity = out_dev->capacity;
     return LF_OK;
 }
@@ -649,6 +653,13 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
     h->pending = false;
     const int total = h->h_pinned[0];
     if (n_segments) *n_segments = total;
+    // The next batch's region-growing slices (performance only: the results do not depend on them): 13 KB while nearly every
+    // problem fits it (the synthetic lane frames), 20 KB when more than 5 % overflow it, 28 KB when more than 25 % overflow 20 KB
+    // (real camera frames have two to three times the edge pixels).
+    if (h->pending_problems > 0 && !getenv("LF_GROW_LDS_LEVEL")) {
+        const int over_small = h->h_pinned[2], over_medium = h->h_pinned[3], np = h->pending_problems;
+        h->grow_lds_level = over_medium * 4 > np ? 2 : (over_small * 20 > np ? 1 : 0);
+    }
     if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
     if (total > h->pending_capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, h->pending_capacity); return LF_ERR_CAPACITY; }
     return LF_OK;
@@ -973,7 +984,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, s);
+                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], s);
     LF_HIP_CHECK(h, hipGetLastError());
     int n = 0;
     LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->d_counts, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -746,3 +746,57 @@ def test_knn_and_radius_match_follow_the_matcher_semantics():
     z_o, z_i, z_d = fe.radius_match(q[:5], np.zeros((0, 32), np.uint8), 30.0)
     assert list(z_o) == [0] * 6 and z_i.size == 0
     fe.close()
+
+
+@pytest.mark.parametrize("level", ["0", "1", "2"])
+def test_region_growing_slice_size_does_not_change_results(level):
+    """k_lsd_grow's LDS slice (13 / 20 / 28 KB, normally chosen from the share of problems that overflowed it in the previous
+    batch) decides which problems take the all-in-LDS code and which the bounded one: a matter of speed only.  Every level,
+    forced, on frames whose problems straddle the slice sizes (lane frames, clutter, noise), against the oracle."""
+    from oracle.oracle import Oracle
+    cfg = default_config("fullres")
+    o = Oracle(cfg)
+    frames = _frames(3, seed0=321)
+    rng = np.random.default_rng(8)
+    busy = frames[0].copy()
+    for _ in range(260):                                      # many strokes in lane colours: problems with 6 - 12 k defined pixels
+        y, x = int(rng.integers(170, 470)), int(rng.integers(10, 620))
+        busy[y:y + int(rng.integers(1, 4)), x:x + int(rng.integers(6, 60))] = ((235, 235, 235), (40, 220, 235), (40, 40, 220))[int(rng.integers(0, 3))]
+    frames = np.concatenate([frames, busy[None]])
+    os.environ["LF_GROW_LDS_LEVEL"] = level
+    try:
+        fe = FrontEnd(cfg, max_frames=4, max_lines_per_color=4096)
+        seg = fe.process_batch(frames)
+        seg2 = fe.process_batch(frames)                       # and again: nothing left over from the first batch
+    finally:
+        del os.environ["LF_GROW_LDS_LEVEL"]
+    for f in range(4):
+        r = o.process_frame(frames[f], cap=3 * 4096)
+        for sg in (seg, seg2):
+            s = sg.frame(f)
+            assert s.n == r["n"], (level, f, s.n, r["n"])
+            assert np.array_equal(s.lines, r["lines"]) and np.array_equal(s.color, r["color"]) and np.array_equal(s.keep, r["keep"])
+    fe.close()
+
+
+def test_region_growing_slice_follows_the_workload():
+    """Without the override the handle moves between the slice sizes by what the last batch needed -- and gives the same
+    segments whichever it is on: busy frames, then lane frames, then busy frames again."""
+    from oracle.oracle import Oracle
+    cfg = default_config("fullres")
+    o = Oracle(cfg)
+    lane = synth.make_batch(2, seed0=11)
+    rng = np.random.default_rng(9)
+    busy = lane.copy()
+    for img in busy:
+        for _ in range(300):
+            y, x = int(rng.integers(170, 470)), int(rng.integers(10, 620))
+            img[y:y + int(rng.integers(1, 4)), x:x + int(rng.integers(6, 60))] = ((235, 235, 235), (40, 220, 235), (40, 40, 220))[int(rng.integers(0, 3))]
+    fe = FrontEnd(cfg, max_frames=2, max_lines_per_color=4096)
+    want = {id(lane): [o.process_frame(f, cap=3 * 4096) for f in lane], id(busy): [o.process_frame(f, cap=3 * 4096) for f in busy]}
+    for batch in (busy, busy, lane, lane, busy):
+        seg = fe.process_batch(batch)
+        for f in range(2):
+            s, r = seg.frame(f), want[id(batch)][f]
+            assert s.n == r["n"] and np.array_equal(s.lines, r["lines"]) and np.array_equal(s.keep, r["keep"])
+    fe.close()

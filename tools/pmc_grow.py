@@ -61,7 +61,8 @@ res = {"kernel": "k_lsd_grow", "source_digest": digest("lane_slam_amd/csrc/lsd_g
 for tag, suffix in (("one_batch_in_flight", ""), ("six_batches_in_flight", "_d6")):
     c = {}
     for part in ("sq", "sq2"):
-        c.update(per_kernel(os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix)), "k_lsd_grow<false>"))      # the instance that does the work at 640x480 (<true>: problems beyond the LDS slice, none here)
+        c.update(per_kernel(os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix)), "k_lsd_grow") or
+                 per_kernel(os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix)), "k_lsd_grow<false>"))   # r03_d: two templated kernels
     d = derive(c)
     if d:
         res[tag] = d
