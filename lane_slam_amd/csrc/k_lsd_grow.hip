@@ -205,6 +205,12 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     }
 }
 
+// MODE 2: every problem, the code chosen per workgroup.  MODE 0 / 1: only the problems that fit / do not fit the slice (the other
+// kind returns at once) -- launched one after the other when (nearly) every problem fits: the kernel that then does all the
+// work carries one copy of the problem code instead of two (+1 - 2 % frames/s on the synthetic lane frames); with problems of
+// both kinds in numbers the two launches would run the kinds one after the other (-11 % on real camera frames), so the host
+// picks MODE 2 there (launch_lsd_grow).
+template <int MODE>
 __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow(LsdParams p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
@@ -216,10 +222,13 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
                                                  double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
 {
     const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
-    if (norder[pc] > def_lds)
+    const bool big = norder[pc] > def_lds;
+    if (MODE == 0 && big) return;
+    if (MODE == 1 && !big) return;
+    if (MODE != 0 && big)
         lsd_grow_problem<true>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
                                gused, tmp_lines, tmp_tags, lines, counts, reg_lds, def_lds, pc, pend_rec, pend_tag, pend_count, pend_cap);
-    else
+    if (MODE != 1 && !big)
         lsd_grow_problem<false>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
                                 gused, tmp_lines, tmp_tags, lines, counts, reg_lds, def_lds, pc, pend_rec, pend_tag, pend_count, pend_cap);
 }
@@ -374,14 +383,18 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
                      uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
-                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, hipStream_t s)
+                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, bool mixed, hipStream_t s)
 {
     int reg_lds, def_lds;
     size_t lds;
     lsd_grow_slice(p, lds_kb > 0 ? lds_kb : LFG_LDS_KB, reg_lds, def_lds, lds);
-    hipLaunchKernelGGL(k_lsd_grow, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
-                       c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
-                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
+#define LF_GROW_LAUNCH(MODE)                                                                                                                   \
+    hipLaunchKernelGGL(k_lsd_grow<MODE>, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,        \
+                       c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,               \
+                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p))
+    if (mixed) { LF_GROW_LAUNCH(2); }
+    else { LF_GROW_LAUNCH(0); LF_GROW_LAUNCH(1); }
+#undef LF_GROW_LAUNCH
 #if LFG_EVAL_KERNEL
     if (p.refine >= 2) {
         const size_t elds = (size_t)((p.Hs + 2) & ~1) * 4 + (size_t)def_lds * 2 + 8;

@@ -114,6 +114,7 @@ struct lf_handle {
     int last_frames = 0;
     bool plugin_ready = false;
     bool pending = false;
+    bool grow_mixed = false;     // the last batch had problems beyond the slice in numbers (> 1 %): one launch with both kinds of problem code
     int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
     int pending_problems = 0;
     int pending_capacity = 0;
@@ -573,7 +574,8 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
                         h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count,
-                        kGrowLdsKb[getenv("LF_GROW_LDS_LEVEL") ? atoi(getenv("LF_GROW_LDS_LEVEL")) % 3 : h->grow_lds_level], s);
+                        kGrowLdsKb[getenv("LF_GROW_LDS_LEVEL") ? atoi(getenv("LF_GROW_LDS_LEVEL")) % 3 : h->grow_lds_level],
+                        getenv("LF_GROW_MIXED") ? atoi(getenv("LF_GROW_MIXED")) != 0 : h->grow_mixed, s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
@@ -659,6 +661,7 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
     if (h->pending_problems > 0 && !getenv("LF_GROW_LDS_LEVEL")) {
         const int over_small = h->h_pinned[2], over_medium = h->h_pinned[3], np = h->pending_problems;
         h->grow_lds_level = over_medium * 4 > np ? 2 : (over_small * 20 > np ? 1 : 0);
+        h->grow_mixed = (h->grow_lds_level == 0 ? over_small : over_medium) * 100 > np;
     }
     if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
     if (total > h->pending_capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, h->pending_capacity); return LF_ERR_CAPACITY; }
@@ -984,7 +987,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], s);
+                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], true, s);
     LF_HIP_CHECK(h, hipGetLastError());
     int n = 0;
     LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->d_counts, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -61,8 +61,14 @@ res = {"kernel": "k_lsd_grow", "source_digest": digest("lane_slam_amd/csrc/lsd_g
 for tag, suffix in (("one_batch_in_flight", ""), ("six_batches_in_flight", "_d6")):
     c = {}
     for part in ("sq", "sq2"):
-        c.update(per_kernel(os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix)), "k_lsd_grow") or
-                 per_kernel(os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix)), "k_lsd_grow<false>"))   # r03_d: two templated kernels
+        path = os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix))
+        # the instance that does the work on the synthetic frames: <0> (problems that fit the LDS slice; <1>, launched behind it,
+        # finds nothing to do there); earlier sets: one kernel, or two templated on a bool
+        for name in ("k_lsd_grow<0>", "k_lsd_grow", "k_lsd_grow<false>"):
+            got = per_kernel(path, name)
+            if got:
+                c.update(got)
+                break
     d = derive(c)
     if d:
         res[tag] = d
