@@ -11,7 +11,10 @@ namespace lf {
 constexpr int kMaxKsize = 9;        // dilation structuring element
 constexpr int kMaxGaussTaps = 15;   // LSD Gaussian
 constexpr float kNotDef = -1024.0f; // LSD NOTDEF marker (angle plane, degrees)
-constexpr int kLabelItems = 8192;   // problems up to this many defined pixels are split into connected components (LsdParams::label_items;
+#ifndef LF_LABEL_ITEMS
+#define LF_LABEL_ITEMS 8192
+#endif
+constexpr int kLabelItems = LF_LABEL_ITEMS;   // problems up to this many defined pixels are split into connected components (LsdParams::label_items;
                                     // 32768 for LSD images of more than 400 k pixels, i.e. 1080p frames)
 constexpr int kCompCap = 1024;      // component list entries per problem (more eligible components: one component)
 
@@ -50,6 +53,7 @@ struct LsdParams {
     int min_reg_size, n_bins, refine;
     int cap_lines;
     int label_items;    // k_lsd_label's capacity: problems with more defined pixels are grown as one component
+    int label_items_max; // ... the largest value a handle moves it to (sizes the region scratch)
 };
 
 struct SegParams {

@@ -339,7 +339,7 @@ size_t lsd_grow_reg_stride(const LsdParams& p)
     // region scratch per problem: the whole scaled image for a single-component problem (one wave), or one
     // slice per wave -- components come from k_lsd_label only for problems of <= label_items defined pixels
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    const size_t need = (size_t)GROW_LISTS * p.label_items;
+    const size_t need = (size_t)GROW_LISTS * (p.label_items_max > p.label_items ? p.label_items_max : p.label_items);
     return Ps > need ? Ps : need;
 }
 

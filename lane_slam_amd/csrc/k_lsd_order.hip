@@ -329,6 +329,7 @@ __device__ __forceinline__ void uf_unite(uf_lds_vu32* P, uint32_t a, uint32_t b)
 }
 
 constexpr int LT = 512;
+constexpr int kCompTop = 8;       // components that get a pass over the seed list of their own; the rest share one
 
 __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                   const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + LI);                 // [label_items], the union phase's x lists ...
     uint32_t* csize2 = dyn_lds + LI;                          // ... then the component sizes, two u16 counters per word
     __shared__ uint16_t roots[kCompCap];
-    __shared__ int n_roots;
+    __shared__ int n_roots, rest_total;
     const int pc = blockIdx.x, t = threadIdx.x;
     const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps;
     const int n = norder[pc];
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     }
     const int* rs = row_start + (size_t)pc * (p.Hs + 1);
     for (int e = t; e < n; e += LT) xs[e] = (uint16_t)(c_xy[o + e] & 0xffffu);
-    if (t == 0) n_roots = 0;
+    if (t == 0) { n_roots = 0; rest_total = 0; }
     __syncthreads();
     // horizontal runs first, without atomics: every entry starts as a child of the first entry of its run of
     // consecutive x (a forest of depth one whose roots are the smallest indices), so the union phase below only has
@@ -412,9 +413,35 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
             rank += (sj > si || (sj == si && rj < ri)) ? 1 : 0;
         }
         list[rank] = (uint16_t)ri;
+        parent[ri] = (uint32_t)rank;                             // (the union-find is done with: a root's slot now holds its rank)
         if (rank == 0) comp_key[pc] = (int)si;                   // launch-order key (k_lsd_rank): the largest component = the longest wave
+        if (rank >= kCompTop) atomicAdd(&rest_total, (int)si);
     }
-    if (t == 0) { comp_count[pc] = C; if (C == 0) comp_key[pc] = 0; }
+    __syncthreads();
+    if (C <= kCompTop) {
+        if (t == 0) { comp_count[pc] = C; if (C == 0) comp_key[pc] = 0; }
+        return;
+    }
+    // Many components (speckle, texture): every listed component costs the wave that takes it a pass over the whole seed list,
+    // so only the kCompTop largest stand alone; the others are grown TOGETHER, as one sub-problem under the label of the
+    // largest of them (independent components may be worked through in any interleaving -- one wave going through several of
+    // them in seed order is the sequential algorithm restricted to them).  The group comes first when it is the biggest piece.
+    __threadfence_block();
+    const uint16_t rest_root = list[kCompTop];
+    for (int e = t; e < n; e += LT) {
+        const uint32_t r = lab[e];
+        if (csize(r) >= minsz && parent[r] >= (uint32_t)kCompTop) lab[e] = rest_root;
+    }
+    if (t == 0) {
+        const int rest = rest_total;
+        const int top0 = (int)csize((uint32_t)list[0]);
+        if (rest > top0) {
+            for (int k = kCompTop; k > 0; --k) list[k] = list[k - 1];
+            list[0] = rest_root;
+            comp_key[pc] = rest;
+        }
+        comp_count[pc] = kCompTop + 1;
+    }
 }
 
 // Launch order of k_lsd_grow's workgroups: problems with the largest connected component first (k_lsd_label's comp_key;

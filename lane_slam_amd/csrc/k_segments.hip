@@ -15,7 +15,8 @@
 namespace lf {
 
 // overflow[0]: some problem has more lines than cap_lines.  overflow[1], [2]: problems whose defined pixels exceed the region
-// growing kernel's LDS slice at its small / medium size (the host sizes the next batch's slices from them, k_lsd_grow.hip)
+// growing kernel's LDS slice at its small / medium size (the host sizes the next batch's slices from them, k_lsd_grow.hip);
+// overflow[3]: the largest problem's defined pixels (the host sizes the component labelling from it)
 __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict__ counts, int* __restrict__ seg_offset,
                               int* __restrict__ frame_offset, int* __restrict__ overflow, const int* __restrict__ norder, int cap_small, int cap_medium)
 {
@@ -32,7 +33,7 @@ __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict
         int v = 0;
         if (i < n) {
             v = counts[i]; if (v > cap_lines) { v = cap_lines; ovf = 1; }
-            if (norder) { const int nd = norder[i]; if (nd > cap_small) atomicAdd(overflow + 1, 1); if (nd > cap_medium) atomicAdd(overflow + 2, 1); }
+            if (norder) { const int nd = norder[i]; if (nd > cap_small) atomicAdd(overflow + 1, 1); if (nd > cap_medium) atomicAdd(overflow + 2, 1); atomicMax(overflow + 3, nd); }
         }
         int inc = v;
 #pragma unroll

@@ -284,7 +284,12 @@ static int build_params(lf_handle* h)
     L.n_bins = c.lsd_n_bins; L.refine = c.lsd_refine; L.cap_lines = h->cap_lines;
     // component labelling capacity: 8192 entries (48 KB of LDS, three problems per CU) for 640x480-class images,
     // 24576 (144 KB, one problem per CU) for 1080p-class ones, whose problems hold 10-20 k defined pixels
+    // ... and in between a handle follows its workload: real camera frames have problems of 9 - 16 k defined pixels, which
+    // without labelling are grown by ONE wave (70 M cycles) -- lf_wait moves label_items to what the last batch's largest problem
+    // needed (in steps of 4096 up to label_items_max; results do not depend on it, only how many waves share a problem)
     L.label_items = h->Ps > 400000 ? 24576 : kLabelItems;
+    L.label_items_max = 24576;
+    while (L.label_items_max > kLabelItems && (size_t)(L.label_items_max - 4096) >= h->Ps) L.label_items_max -= 4096;      // no problem has more pixels than the image
     // ---- segments
     SegParams& S = h->seg;
     memset(&S, 0, sizeof(S));
@@ -639,7 +644,7 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
     if (rc != LF_OK) return rc;
     // total + overflow flag travel to pinned host memory behind the kernels
     LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
-    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     h->pending = true;
     h->pending_problems = n_frames * 3;
     h->pending_capacity = out_dev->capacity;
@@ -662,6 +667,11 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
         const int over_small = h->h_pinned[2], over_medium = h->h_pinned[3], np = h->pending_problems;
         h->grow_lds_level = over_medium * 4 > np ? 2 : (over_small * 20 > np ? 1 : 0);
         h->grow_mixed = (h->grow_lds_level == 0 ? over_small : over_medium) * 100 > np;
+        if (h->Ps <= 400000 && !getenv("LF_LABEL_ITEMS_FIXED")) {
+            int li = kLabelItems;
+            while (li < h->h_pinned[4] && li < h->lsd.label_items_max) li += 4096;
+            h->lsd.label_items = li;
+        }
     }
     if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
     if (total > h->pending_capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, h->pending_capacity); return LF_ERR_CAPACITY; }
