@@ -223,6 +223,11 @@ LFG_DEV void used_or(const Ctx& c, int e)                // the calling lane's e
     else atomicOr(&c.gused[e >> 5], 1u << (e & 31));
 }
 LFG_DEV void used_set(const Ctx& c, int e) { if (lane_id() == 0) used_or(c, e); }
+LFG_DEV void used_and(const Ctx& c, int e)               // the calling lane's entry
+{
+    if (e < c.used_lds) __hip_atomic_fetch_and(as_lds(c.usedc) + (e >> 5), ~(1u << (e & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else atomicAnd(&c.gused[e >> 5], ~(1u << (e & 31)));
+}
 LFG_DEV void used_clr(const Ctx& c, int e)
 {
     if (lane_id() == 0) {
@@ -588,9 +593,77 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
 // region2rect are instantiated once (they are the two largest inlined bodies; every copy is instruction-cache footprint).
 //
 // One radius-reduction step: shrink the radius by 0.75 and drop the region points beyond it (USED cleared).
+#ifndef LF_HOST_SIM
+LFG_DEV void reg_put(const Ctx& c, int i, uint32_t v) { if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v; }      // the calling lane's slot
+// dense-from-sparse inside a wave: the lanes of `mask` hand `v` to lanes 0, 1, 2, ... in lane order (the other lanes' values
+// land behind them); one ds_permute
+LFG_DEV int wave_compact(int v, unsigned long long mask)
+{
+    const int lane = lane_id();
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const bool set = (mask >> lane) & 1ull;
+    const int dest = set ? __popcll(mask & below) : __popcll(mask) + __popcll(~mask & below);
+    return __builtin_amdgcn_ds_permute(dest << 2, v);
+}
+#endif
+
 LFG_DEV void reduce_radius_step(const Ctx& c, int& reg_size, double xc, double yc, double& radSq)
 {
     radSq *= 0.75 * 0.75;
+#ifndef LF_HOST_SIM
+    // The reference walks the list once and overwrites every point beyond the radius with the list's current last point
+    // (which is tested next).  What comes out: m = the points that stay; those of them in the first m places keep their
+    // places; the places of the first m that fall free are taken, in ascending order, by the staying points from behind place
+    // m, in DESCENDING order.  (Checked against the sequential loop on random lists.)  So: one pass that tests all points
+    // and releases the dropped ones, lane-parallel, and one that pairs holes and fillers through two small queues in registers.
+    const int n = reg_size, lane = lane_id();
+    int m = 0;
+    for (int base = 0; base < n; base += LFG_NL) {
+        const int i = base + lane;
+        const bool v = i < n;
+        const uint32_t pk = v ? reg_get(c, i) : 0u;
+        const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+        const bool out = v && dist_sq(xc, yc, (double)px, (double)py) > radSq;
+        if (out) used_and(c, find_e(c, px, py));
+        m += __popcll(__ballot(v && !out));
+    }
+    if (m == n) return;
+    int hb = 0, fb = n;                 // front places scanned so far: [0, hb); back places scanned so far: [fb, n)
+    int hq = 0, fq = 0, nh = 0, nf = 0; // lane j: the j-th waiting hole (a place) / the j-th waiting filler (a point)
+    for (;;) {
+        if (nh == 0) {
+            if (hb >= m) break;         // no hole left (the fillers are used up with them)
+            const int i = hb + lane;
+            const bool v = i < m;
+            const uint32_t pk = v ? reg_get(c, i) : 0u;
+            const bool out = v && dist_sq(xc, yc, (double)(int)(pk & 0xffffu), (double)(int)(pk >> 16)) > radSq;
+            const unsigned long long mk = __ballot(out);
+            hq = wave_compact(i, mk);
+            nh = __popcll(mk);
+            hb += LFG_NL;
+            if (nh == 0) continue;
+        }
+        if (nf == 0) {
+            if (fb <= m) break;                             // cannot happen (as many fillers as holes): never spin
+            const int i = fb - 1 - lane;                    // descending with the lane
+            const bool v = i >= m;
+            const uint32_t pk = v ? reg_get(c, i) : 0u;
+            const bool keep = v && !(dist_sq(xc, yc, (double)(int)(pk & 0xffffu), (double)(int)(pk >> 16)) > radSq);
+            const unsigned long long mk = __ballot(keep);
+            fq = wave_compact((int)pk, mk);
+            nf = __popcll(mk);
+            fb -= LFG_NL;
+            if (nf == 0) continue;
+        }
+        const int t = nh < nf ? nh : nf;
+        if (lane < t) reg_put(c, hq, (uint32_t)fq);
+        hq = __builtin_amdgcn_ds_bpermute(((lane + t) & 63) << 2, hq);
+        fq = __builtin_amdgcn_ds_bpermute(((lane + t) & 63) << 2, fq);
+        nh -= t; nf -= t;
+    }
+    mem_fence();
+    reg_size = m;
+#else
     for (int i = 0; i < reg_size; ++i) {
         const uint32_t pk = reg_get(c, i);
         const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
@@ -604,6 +677,7 @@ LFG_DEV void reduce_radius_step(const Ctx& c, int& reg_size, double xc, double y
             --i;
         }
     }
+#endif
 }
 
 // First half of refine(): the region's points are released (USED cleared) and the tolerance tau for the second
@@ -626,10 +700,15 @@ LFG_DEV double refine_tau(const Ctx& c, int reg_size, const Rect& rec, int& x0, 
         const int ei = v ? find_e(c, px, py) : 0;
         const float af = v ? c.deg[ei] : NOTDEF_F;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
+#ifndef LF_HOST_SIM
+        if (v) used_and(c, ei);                        // every lane releases its own point: the order of the releases means nothing
+#endif
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
             const int qx = (int)(q & 0xffffu), qy = (int)(q >> 16);
+#ifdef LF_HOST_SIM
             used_clr(c, rl_i(ei, j));
+#endif
             if (dist_(xc, yc, (double)qx, (double)qy) < rec.width) {
                 const double angle = angle_of(rl_f(af, j));
                 const double ang_d = angle_diff_signed(angle, ang_c);
@@ -1202,16 +1281,17 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         for (;;) {
             if (phase < 2) {
                 region_grow(c, gx, gy, ge, reg_size, reg_angle, grow_prec);
-                if (phase == 0) { LFG_T1(c, 1) LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size) }
+                if (phase == 0) { LFG_T1(c, 1) LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size) } else { LFG_T1(c, 22) }
                 if (reg_size < (phase == 0 ? c.min_reg_size : 2)) { rejected = true; break; }
             }
             region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
-            if (phase == 0) { LFG_T1(c, 2) }
+            if (phase == 0) { LFG_T1(c, 2) } else { LFG_T1(c, 17) }
             if (c.refine <= 0) break;
             const double density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
             if (density >= c.density_th) break;
             if (phase == 0) {
                 grow_prec = refine_tau(c, reg_size, rec, gx, gy, ge);
+                LFG_T1(c, 21)
                 phase = 1;
                 continue;
             }
@@ -1224,6 +1304,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
                 phase = 2;
             }
             reduce_radius_step(c, reg_size, xc, yc, radSq);
+            LFG_T1(c, 23) LFG_CNT(c, 20, 0)
             if (reg_size < 2) { rejected = true; break; }
         }
         LFG_T1(c, 3)

@@ -40,8 +40,8 @@ worst = np.argsort(tot_w.max(1))[-4:]
 print("waves of the four longest problems (kcycles):", [[int(v / 1e3) for v in tot_w[w]] for w in worst])
 d = raw[np.arange(n * 3), slow][:, :27].astype(np.float64)          # the slowest wave of every problem
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
-         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "tail_iters", "bulk_acc", "exact_acc", "isolated_seeds"] + ["-"] * 3 + ["total", "n_order", "n_comp"]
-CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 24}
+         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "refine_rect", "bulk_acc", "exact_acc", "isolated_seeds", "refine_tau", "refine_regrow", "refine_reduce"] + ["total", "n_order", "n_comp"]
+CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 17, 21, 22, 23, 24}
 raw7 = raw[:, :, 7].sum(1)
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
 # the growing waves (0..2) alone: the evaluating wave's total is "until the last grower is done" and hides them
