@@ -142,7 +142,7 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
                      uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
                      double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, bool mixed, hipStream_t s);
 int lsd_grow_def_lds(const LsdParams& p, int lds_kb);   // defined pixels of a problem that fit k_lsd_grow's LDS slice of lds_kb KB
-constexpr int kGrowLdsKb[3] = { 13, 20, 28 };           // the slice sizes a handle moves between (k_lsd_grow.hip)
+constexpr int kGrowLdsKb[3] = { 13, 28, 40 };           // the slice sizes a handle moves between (k_lsd_grow.hip)
 int lsd_grow_pend_cap(const LsdParams& p);      // entries per problem of the pending-region list (k_lsd_eval)
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, const int* norder, int cap_small, int cap_medium, hipStream_t s);

@@ -376,9 +376,10 @@ int lsd_grow_def_lds(const LsdParams& p, int lds_kb)
 }
 
 // lds_kb: the slice size.  13 KB (LFG_LDS_KB) holds every problem of the synthetic lane frames and gives the most resident
-// problems; real camera frames have two to three times the edge pixels, most of their problems overflow 13 KB into the
-// bounded (flat-access, HBM-backed) path, and a 20 / 28 KB slice is worth +11 / +16 % frames/s there (-1 / -6 % on the synthetic
-// frames) -- so the host moves a handle between kGrowLdsKb[] by the share of overflowing problems it saw in the last batch.
+// problems; real camera frames have two to three times the edge pixels, many of their problems overflow 13 KB into the
+// bounded (flat-access, HBM-backed) path, and a 28 KB slice is worth +13 - 30 % frames/s there (-7 % on the synthetic frames;
+// 20 KB: half of that, 40 KB: no more) -- so the host moves a handle between kGrowLdsKb[] by the share of overflowing problems
+// it saw in the last batch.
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,

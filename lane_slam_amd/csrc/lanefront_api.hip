@@ -661,9 +661,9 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
     const int total = h->h_pinned[0];
     if (n_segments) *n_segments = total;
     // The next batch's region-growing slices (performance only: the results do not depend on them): 13 KB while nearly every
-    // problem fits it (the synthetic lane frames), 20 KB when more than 5 % overflow it, 28 KB when more than 25 % overflow 20 KB
-    // (real camera frames have two to three times the edge pixels).
-    if (h->pending_problems > 0 && !getenv("LF_GROW_LDS_LEVEL")) {
+    // problem fits it (the synthetic lane frames), 28 KB when more than 5 % overflow it (real camera frames have two to three
+    // times the edge pixels), 40 KB when more than 25 % overflow 28 KB.
+    if (h->pending_problems > 0) {
         const int over_small = h->h_pinned[2], over_medium = h->h_pinned[3], np = h->pending_problems;
         h->grow_lds_level = over_medium * 4 > np ? 2 : (over_small * 20 > np ? 1 : 0);
         h->grow_mixed = (h->grow_lds_level == 0 ? over_small : over_medium) * 100 > np;
