@@ -329,7 +329,10 @@ __device__ __forceinline__ void uf_unite(uf_lds_vu32* P, uint32_t a, uint32_t b)
 }
 
 constexpr int LT = 512;
-constexpr int kCompTop = 8;       // components that get a pass over the seed list of their own; the rest share one
+#ifndef LF_COMP_TOP
+#define LF_COMP_TOP 8
+#endif
+constexpr int kCompTop = LF_COMP_TOP;       // components that get a pass over the seed list of their own; the rest share one
 
 __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                   const int* __restrict__ row_start, uint16_t* __restrict__ c_label,

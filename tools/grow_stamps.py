@@ -38,6 +38,10 @@ print("wave totals (kcycles): slowest wave mean %.0f max %.0f | sum over waves m
 slow = tot_w.argmax(1)
 worst = np.argsort(tot_w.max(1))[-4:]
 print("waves of the four longest problems (kcycles):", [[int(v / 1e3) for v in tot_w[w]] for w in worst])
+if GW == 4:
+    for w in worst:
+        print("  problem %d evaluating wave: busy %.0f kcycles (scan %.0f + math %.0f) of %.0f, %d nfa calls" % (
+            w, (raw[w, 3, 4] + raw[w, 3, 5]) / 1e3, raw[w, 3, 4] / 1e3, raw[w, 3, 5] / 1e3, tot_w[w, 3] / 1e3, raw[w, 3, 7] >> 40))
 d = raw[np.arange(n * 3), slow][:, :27].astype(np.float64)          # the slowest wave of every problem
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
          "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "refine_rect", "bulk_acc", "exact_acc", "isolated_seeds", "refine_tau", "refine_regrow", "refine_reduce"] + ["total", "n_order", "n_comp"]
