@@ -59,29 +59,61 @@ LFG_DEV double rl_d(double v, int src)
     int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// (sums and maxima over the wave use DPP exchanges inside the rows of 16 lanes and scalar registers across the four rows; see
+// wave_max_d below)
+template <int CTRL>
+LFG_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 LFG_DEV int wave_sum_i(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    v += dpp_i<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp_i<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += dpp_i<0x141>(v);           // row_half_mirror
+    v += dpp_i<0x140>(v);           // row_mirror: every lane of a row holds the row's sum
+    return rl_i(v, 0) + rl_i(v, 16) + rl_i(v, 32) + rl_i(v, 48);
+}
+// Maximum / minimum of a double over the wave: four DPP exchanges inside the rows of 16 lanes (lane pairs, pairs of pairs,
+// mirrored halves, mirrored rows: afterwards every lane of a row holds the row's value), then the four rows through scalar
+// registers.  (The butterfly of six __shfl_xor is twelve trips through the LDS crossbar per call; region2rect makes four calls
+// per region and most regions are a dozen pixels.)  Order free: the operands are finite.
+template <int CTRL>
+LFG_DEV double dpp_d(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 LFG_DEV double wave_max_d(double v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d); v = o > v ? o : v; }
-    return v;
+    double o;
+    o = dpp_d<0xB1>(v); v = o > v ? o : v;           // quad_perm [1,0,3,2]
+    o = dpp_d<0x4E>(v); v = o > v ? o : v;           // quad_perm [2,3,0,1]
+    o = dpp_d<0x141>(v); v = o > v ? o : v;          // row_half_mirror
+    o = dpp_d<0x140>(v); v = o > v ? o : v;          // row_mirror
+    const double r0 = rl_d(v, 0), r1 = rl_d(v, 16), r2 = rl_d(v, 32), r3 = rl_d(v, 48);
+    const double a = r1 > r0 ? r1 : r0, b = r3 > r2 ? r3 : r2;
+    return b > a ? b : a;
 }
 LFG_DEV double wave_min_d(double v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { double o = __shfl_xor(v, d); v = o < v ? o : v; }
-    return v;
+    double o;
+    o = dpp_d<0xB1>(v); v = o < v ? o : v;
+    o = dpp_d<0x4E>(v); v = o < v ? o : v;
+    o = dpp_d<0x141>(v); v = o < v ? o : v;
+    o = dpp_d<0x140>(v); v = o < v ? o : v;
+    const double r0 = rl_d(v, 0), r1 = rl_d(v, 16), r2 = rl_d(v, 32), r3 = rl_d(v, 48);
+    const double a = r1 < r0 ? r1 : r0, b = r3 < r2 ? r3 : r2;
+    return b < a ? b : a;
 }
 LFG_DEV int wave_max_i(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d); v = o > v ? o : v; }
-    return v;
+    int o;
+    o = dpp_i<0xB1>(v); v = o > v ? o : v;
+    o = dpp_i<0x4E>(v); v = o > v ? o : v;
+    o = dpp_i<0x141>(v); v = o > v ? o : v;
+    o = dpp_i<0x140>(v); v = o > v ? o : v;
+    const int a = max(rl_i(v, 0), rl_i(v, 16)), b = max(rl_i(v, 32), rl_i(v, 48));
+    return max(a, b);
 }
 LFG_DEV void mem_fence() { __threadfence_block(); }
 #else
