@@ -1146,15 +1146,14 @@ LFG_DEV bool evaluate_region(const Ctx& c, Rect& rec, int tag, float* lines, int
     }
 #ifndef LF_HOST_SIM
     (void)n_lines;
-    if (lane_id() == 0) {
-        const int slot = atomicAdd(c.line_count, 1);          // any order: the tags restore the sequential one
-        if (slot < cap) {
-            lines[4 * slot + 0] = (float)rec.x1;
-            lines[4 * slot + 1] = (float)rec.y1;
-            lines[4 * slot + 2] = (float)rec.x2;
-            lines[4 * slot + 3] = (float)rec.y2;
-            c.tags[slot] = tag;
-        }
+    // lane 0 takes the slot, EVERY lane stores the (same) line: a function that ends in lane-0-only code is not safe at the end
+    // of a loop body (see evaluate_pending)
+    int slot = 0;
+    if (lane_id() == 0) slot = atomicAdd(c.line_count, 1);     // any order: the tags restore the sequential one
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot < cap) {
+        *reinterpret_cast<float4*>(lines + 4 * slot) = make_float4((float)rec.x1, (float)rec.y1, (float)rec.x2, (float)rec.y2);
+        c.tags[slot] = tag;
     }
 #else
     {
@@ -1191,14 +1190,14 @@ LFG_DEV bool evaluate_pending(const Ctx& c, Rect& rec, float4& line)
 // LFG_EVAL_KERNEL: one more entry of the problem's pending list (lane 0 stores; the rectangle is wave-uniform)
 LFG_DEV void eval_append(const Ctx& c, const Rect& rec, int tag)
 {
-    if (lane_id() == 0) {
-        const int slot = atomicAdd(c.pend_n, 1);
-        if (slot < c.pend_cap) {
-            double2* d = reinterpret_cast<double2*>(c.pend_rec + (size_t)slot * 12);
-            d[0] = make_double2(rec.x1, rec.y1); d[1] = make_double2(rec.x2, rec.y2); d[2] = make_double2(rec.width, rec.x);
-            d[3] = make_double2(rec.y, rec.theta); d[4] = make_double2(rec.dx, rec.dy); d[5] = make_double2(rec.prec, rec.p);
-            c.pend_tag[slot] = tag;
-        }
+    int slot = 0;
+    if (lane_id() == 0) slot = atomicAdd(c.pend_n, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot < c.pend_cap) {                                   // every lane stores the same entry (no lane-0-only tail)
+        double2* d = reinterpret_cast<double2*>(c.pend_rec + (size_t)slot * 12);
+        d[0] = make_double2(rec.x1, rec.y1); d[1] = make_double2(rec.x2, rec.y2); d[2] = make_double2(rec.width, rec.x);
+        d[3] = make_double2(rec.y, rec.theta); d[4] = make_double2(rec.dx, rec.dy); d[5] = make_double2(rec.prec, rec.p);
+        c.pend_tag[slot] = tag;
     }
 }
 
