@@ -191,65 +191,183 @@ void launch_pyrdown(int H, int W, int n_frames, const uint8_t* src, uint8_t* dst
 // ------------------------------------------------------------------------------------------------ k_ed_detect
 enum { UpDir = 1, RightDir = 2, DownDir = 3, LeftDir = 4 };
 
-struct EdWalk {
-    const uint16_t* g; uint32_t* marks;
-    int W, H;
-    unsigned lastX, lastY;
+typedef __attribute__((address_space(3))) uint32_t ed_lds_u32;
+
+// the edge marks: a bit plane in LDS (reached through the LDS address space: a flat access to LDS takes the slow path and
+// waits on both memory counters), or in global memory for octave images beyond the LDS budget (there every access is an
+// agent-scope atomic, so that none is served from a stale line of the vector L1).  A wave's LDS operations and its
+// atomics on one address execute in order: a read after a set sees it.
+struct EdMarks {
+    uint32_t* p; bool in_lds;
+    __device__ __forceinline__ bool get(int i) const
+    {
+        const uint32_t w = in_lds ? ((ed_lds_u32*)p)[i >> 5] : __hip_atomic_load(p + (i >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (w >> (i & 31)) & 1u;
+    }
+    // per-lane i (the lanes of a wave may name bits of one word)
+    __device__ __forceinline__ void set(int i) const
+    {
+        if (in_lds) __hip_atomic_fetch_or((ed_lds_u32*)p + (i >> 5), 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_or(p + (i >> 5), 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void clear(int i) const
+    {
+        if (in_lds) __hip_atomic_fetch_and((ed_lds_u32*)p + (i >> 5), ~(1u << (i & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_and(p + (i >> 5), ~(1u << (i & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 };
 
-__device__ __forceinline__ bool ed_marked(const uint32_t* m, int i) { return (m[i >> 5] >> (i & 31)) & 1u; }
+struct EdWalk {
+    const uint16_t* g; EdMarks marks;
+    int W, H;
+    unsigned lastX, lastY;
+#ifdef ED_STAMPS
+    long long t_fetch, t_loop; int n_fetch, n_step, n_walk;
+#endif
+};
 
 // one walk of the smart routing (:1577-1720 and its three copies), executed uniformly by the wave; pixels go to out[]
-// from *off on (packed x | y << 16).  Returns false when the part array would overflow.
-__device__ bool ed_walk(EdWalk& c, unsigned x, unsigned y, int lastDirection, uint32_t* __restrict__ out, unsigned base, unsigned& off,
-                        unsigned cap)
+// from off on (packed x | y << 16).  Returns false when the part array would overflow.
+//
+// The walk is a chain of dependent decisions, one pixel per step, and ONE wave per frame executes it: what it costs is
+// the number of instructions per step (a lone wave issues one every 5-10 cycles) and the round trips to the gradient
+// plane.  Both are taken out of the step:
+//   * the wave keeps an 8 x 8 WINDOW of the plane, one pixel per lane (lane = row * 8 + column), placed so that the
+//     walk runs into it -- one column / row behind the current pixel, six ahead, shifted sideways when the last window
+//     was left sideways;
+//   * when a window is fetched, every lane works out FOR ITS PIXEL what a walk standing there would do: its pixel is a
+//     horizontal-edge one (the walk goes right or left) or a vertical-edge one (down or up), and for both signs the
+//     lane compares the three pixels ahead (neighbour values by two DPP row shifts and two ds_bpermute) and records
+//     the step to the winner as (dx + 1) | (dy + 1) << 2, or 3 when the reference stops at the image border first, 7
+//     when the three are not all inside the window.  The result is one `info` word per lane:
+//     gradient | direction bit | step(+) << 16 | step(-) << 20 | marked << 24;
+//   * inside a window the walk is a walk over LANES: a step reads the current lane's info (v_readlane), settles the
+//     sign from the kind of the pixel and the step before (x > lastX is "the last step went right"), and adds the
+//     step to the lane number -- ~30 scalar instructions, no memory access, no coordinates.  The lane it visits notes
+//     its place in the order of the visit;
+//   * when the walk leaves the window (or ends), the visited lanes store their pixels at their places of the output
+//     and set their edge marks in the bit plane, all at once.
+__device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int lastDirection, uint32_t* __restrict__ out, unsigned base,
+                                        unsigned& off_io, unsigned cap)
 {
     const int W = c.W, H = c.H;
     const uint16_t* pg = c.g;
-    int i = (int)(y * W + x);
-    uint32_t gv = pg[i];
-    while ((gv & 0x7fffu) > 0 && !ed_marked(c.marks, i)) {
-        c.marks[i >> 5] |= 1u << (i & 31);
-        if (off >= cap) return false;
-        out[base + off] = x | (y << 16);
-        ++off;
-        int should = 0, go = 0;
-        if (gv & kHorizontal) {
-            if (lastDirection == UpDir || lastDirection == DownDir) should = x > c.lastX ? RightDir : LeftDir;
-            c.lastX = x; c.lastY = y;
-            if (lastDirection == RightDir || should == RightDir) go = RightDir;
-            else if (lastDirection == LeftDir || should == LeftDir) go = LeftDir;
-        } else {
-            if (lastDirection == RightDir || lastDirection == LeftDir) should = y > c.lastY ? DownDir : UpDir;
-            c.lastX = x; c.lastY = y;
-            if (lastDirection == DownDir || should == DownDir) go = DownDir;
-            else if (lastDirection == UpDir || should == UpDir) go = UpDir;
+    const int lane = (int)(threadIdx.x & 63u), ldx = lane & 7, ldy = lane >> 3;
+    int x = __builtin_amdgcn_readfirstlane((int)x0), y = __builtin_amdgcn_readfirstlane((int)y0);
+    const int ld = __builtin_amdgcn_readfirstlane(lastDirection);
+    // the walk's direction: its kind (1: right / left) and its sign (1: right / down); bit 1: x > lastX, bit 0: y > lastY of
+    // the reference.  Plain 0 / 1 integers and bit operations: the step stays on the scalar unit
+    uint32_t last_h = (ld & 1) ^ 1, plus = (ld == RightDir || ld == DownDir) ? 1u : 0u;
+    uint32_t went = (x > (int)c.lastX ? 2u : 0u) | (y > (int)c.lastY ? 1u : 0u);
+    unsigned off = off_io;
+    int wx0 = 0, wy0 = 0, fx = 0, fy = 0, fgo = 0;
+    uint32_t info = 0u;
+    int ord = -1, cnt = 0;                                  // this lane's place in the visit of the window; pixels visited in it
+    int Lv = -1;                                            // the lane visited last
+    bool ok = true;
+    const bool inner_x = ldx >= 1 && ldx <= 6, inner_y = ldy >= 1 && ldy <= 6;
+    // the visited pixels of the window -> output and bit plane
+    auto retire = [&]() {
+        if (off + (unsigned)cnt > cap) { ok = false; return; }
+        if (ord >= 0) {
+            const int px = wx0 + ldx, py = wy0 + ldy;
+            out[base + off + (unsigned)ord] = (uint32_t)px | ((uint32_t)py << 16);
+            c.marks.set(py * W + px);
         }
-        // the three pixels ahead: i1 / i3 diagonal, i2 straight; gradient values compared as (unsigned char) (:1607-1609)
-        int i1, i2, i3;
-        if (go == RightDir) {
-            if (x == (unsigned)W - 1 || y == 0 || y == (unsigned)H - 1) break;
-            i1 = i - W + 1; i2 = i + 1; i3 = i + W + 1;
-        } else if (go == LeftDir) {
-            if (x == 0 || y == 0 || y == (unsigned)H - 1) break;
-            i1 = i - W - 1; i2 = i - 1; i3 = i + W - 1;
-        } else if (go == DownDir) {
-            if (x == 0 || x == (unsigned)W - 1 || y == (unsigned)H - 1) break;
-            i1 = i + W + 1; i2 = i + W; i3 = i + W - 1;
-        } else if (go == UpDir) {
-            if (x == 0 || x == (unsigned)W - 1 || y == 0) break;
-            i1 = i - W + 1; i2 = i - W; i3 = i - W - 1;
-        } else break;                                  // (cannot happen: one of the four always applies)
-        const uint32_t v1 = pg[i1], v2 = pg[i2], v3 = pg[i3];
-        const unsigned g1 = v1 & 0xffu, g2 = v2 & 0xffu, g3 = v3 & 0xffu;
-        if (g1 >= g2 && g1 >= g3) { i = i1; gv = v1; }
-        else if (g3 >= g2 && g3 >= g1) { i = i3; gv = v3; }
-        else { i = i2; gv = v2; }
-        y = (unsigned)i / (unsigned)W;
-        x = (unsigned)i - y * (unsigned)W;
-        lastDirection = go;
+        off += (unsigned)cnt;
+        ord = -1; cnt = 0;
+    };
+    // a new window for a walk standing at (x, y), of direction (gh, plus)
+    auto fetch = [&](uint32_t gh) {
+#ifdef ED_STAMPS
+        const long long tf0 = __builtin_readcyclecounter();
+#endif
+        const int go = gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir);
+        int drift = 0;
+        if (go == fgo) drift = gh ? y - fy : x - fx;
+        const int side = drift >= 2 ? 1 : (drift <= -2 ? 6 : 3);
+        const int back = plus ? 1 : 6;
+        wx0 = x - (gh ? back : side);
+        wy0 = y - (gh ? side : back);
+        fx = x; fy = y; fgo = go;
+        const int px = wx0 + ldx, py = wy0 + ldy;
+        const bool in = px >= 0 && px < W && py >= 0 && py < H;
+        const int idx = in ? py * W + px : 0;
+        uint32_t v = pg[idx];
+        bool mk = c.marks.get(idx);
+        v = in ? v : 0u;
+        mk = in && mk;
+        // the eight neighbours' gradients (as unsigned char, :1607-1609): west | own | east of this row in one word,
+        // then the same word of the rows above and below.  Values from beyond the window's edge are never used (step 7)
+        const int g8 = (int)(v & 0xffu);
+        const int gW = __builtin_amdgcn_update_dpp(0, g8, 0x111, 0xf, 0xf, true);     // row_shr:1: from lane - 1
+        const int gE = __builtin_amdgcn_update_dpp(0, g8, 0x101, 0xf, 0xf, true);     // row_shl:1: from lane + 1
+        const int R = gW | (g8 << 8) | (gE << 16);
+        const int RN = __builtin_amdgcn_ds_bpermute(((lane - 8) & 63) << 2, R), RS = __builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, R);
+        const int nNW = RN & 0xff, nN = (RN >> 8) & 0xff, nNE = (RN >> 16) & 0xff, nSW = RS & 0xff, nS = (RS >> 8) & 0xff, nSE = (RS >> 16) & 0xff;
+        const bool hz = (v & kHorizontal) != 0;
+        // pixels 1 / 2 / 3 ahead: right NE E SE, left NW W SW, down SE S SW, up NE N NW; t = +1: pixel 1 wins, -1: pixel 3
+        const int a1 = hz ? nNE : nSE, a2 = hz ? gE : nS, a3 = hz ? nSE : nSW;
+        const int b1 = hz ? nNW : nNE, b2 = hz ? gW : nN, b3 = hz ? nSW : nNW;
+        const int ta = (a1 >= a2 && a1 >= a3) ? 1 : ((a3 >= a2 && a3 >= a1) ? -1 : 0);
+        const int tb = (b1 >= b2 && b1 >= b3) ? 1 : ((b3 >= b2 && b3 >= b1) ? -1 : 0);
+        // right / left: (+-1, -t); down / up: (t, +-1)
+        const int stepA = hz ? (2 | ((1 - ta) << 2)) : ((1 + ta) | (2 << 2));
+        const int stepB = hz ? (0 | ((1 - tb) << 2)) : ((1 + tb) | (0 << 2));
+        const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
+        const bool brkA = hz ? (x_hi || y_lo || y_hi) : (x_lo || x_hi || y_hi);
+        const bool brkB = hz ? (x_lo || y_lo || y_hi) : (x_lo || x_hi || y_lo);
+        const bool reachA = hz ? (ldx <= 6 && inner_y) : (ldy <= 6 && inner_x);
+        const bool reachB = hz ? (ldx >= 1 && inner_y) : (ldy >= 1 && inner_x);
+        const int fA = brkA ? 3 : (reachA ? stepA : 7), fB = brkB ? 3 : (reachB ? stepB : 7);
+        info = v | ((uint32_t)fA << 16) | ((uint32_t)fB << 20) | (mk ? 1u << 24 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 25 : 0u);
+#ifdef ED_STAMPS
+        c.t_fetch += (long long)__builtin_readcyclecounter() - tf0; c.n_fetch++;
+#endif
+    };
+    fetch(last_h);
+    int L = (y - wy0) * 8 + (x - wx0);
+    uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
+#ifdef ED_STAMPS
+    c.n_walk++;
+    const long long tl0 = __builtin_readcyclecounter();
+#endif
+    while ((s & (3u << 24)) == 0u) {                          // neither marked nor without gradient
+#ifdef ED_STAMPS
+        c.n_step++;
+#endif
+        const bool here = lane == L;
+        info |= here ? 1u << 24 : 0u;
+        ord = here ? cnt : ord;
+        ++cnt;
+        Lv = L;
+        // the direction: a pixel keeps the walk's direction when it is of its kind, else turns by where the walk came from
+        const uint32_t hz = (s >> 15) & 1u;
+        plus ^= (hz ^ last_h) & (plus ^ ((went >> hz) & 1u));
+        last_h = hz;
+        uint32_t f = (s >> (20u - 4u * plus)) & 15u;
+        if ((f & 3u) == 3u) {
+            if (f == 3u) break;                                // the image border ahead (:1583, :1620, ...)
+            x = wx0 + (L & 7); y = wy0 + (L >> 3);
+            retire();
+            if (!ok) break;
+            fetch(hz);
+            L = (y - wy0) * 8 + (x - wx0);
+            Lv = L;
+            f = ((uint32_t)__builtin_amdgcn_readlane((int)info, L) >> (20u - 4u * plus)) & 15u;
+            if ((f & 3u) == 3u) break;                         // (cannot happen: the window was placed around the three ahead)
+        }
+        went = (f & 2u) | (f >> 3);                            // dx + 1 == 2, dy + 1 == 2
+        L += (int)((f & 3u) + ((f & 12u) << 1)) - 9;
+        s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
     }
-    return true;
+#ifdef ED_STAMPS
+    c.t_loop += (long long)__builtin_readcyclecounter() - tl0;
+#endif
+    if (Lv >= 0) { c.lastX = (unsigned)(wx0 + (Lv & 7)); c.lastY = (unsigned)(wy0 + (Lv >> 3)); }
+    if (ok) retire();
+    off_io = off;
+    return ok;
 }
 
 // ---- NFA (descriptor_custom.hpp:630-813), lane-uniform
@@ -303,18 +421,39 @@ __device__ __noinline__ double ed_nfa(int n, int k, double p, double logNT)
     return -dm::dlog10(bin_tail) - logNT;
 }
 
-__device__ __forceinline__ long long wave_sum_ll(long long v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
+// sums over the wave: four DPP exchanges inside the rows of 16 lanes (lane pairs, pairs of pairs, mirrored halves, mirrored
+// rows), then the four rows through scalar registers -- the six-step __shfl_xor butterfly is twelve trips through the LDS
+// crossbar per 64-bit sum, and a line fit makes four of them
+template <int CTRL>
+__device__ __forceinline__ int ed_dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ int wave_sum_i(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    v += ed_dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += ed_dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += ed_dpp<0x141>(v);           // row_half_mirror
+    v += ed_dpp<0x140>(v);           // row_mirror: every lane of a row holds the row's sum
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
+template <int CTRL>
+__device__ __forceinline__ long long ed_dpp_ll(long long v)
+{
+    const int lo = ed_dpp<CTRL>((int)(v & 0xffffffffll)), hi = ed_dpp<CTRL>((int)(v >> 32));
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long ed_readlane_ll(long long v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+    v += ed_dpp_ll<0xB1>(v);
+    v += ed_dpp_ll<0x4E>(v);
+    v += ed_dpp_ll<0x141>(v);
+    v += ed_dpp_ll<0x140>(v);
+    return ed_readlane_ll(v, 0) + ed_readlane_ll(v, 16) + ed_readlane_ll(v, 32) + ed_readlane_ll(v, 48);
+}
+__device__ __forceinline__ double ed_readlane_d(double v, int l) { return __longlong_as_double(ed_readlane_ll(__double_as_longlong(v), l)); }
 
 struct EdFit { float ATA[4], ATV[2]; };
 
@@ -344,6 +483,9 @@ __device__ __forceinline__ void ed_solve(const EdFit& f, double& e0, double& e1)
 __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, int n_octaves)
 {
     extern __shared__ uint32_t lds[];
+#ifdef ED_STAMPS
+    const long long t_begin = __builtin_readcyclecounter();
+#endif
     __shared__ int s_wave_count[4];
     __shared__ int s_base;
     const int oc = blockIdx.y, f = blockIdx.x;
@@ -356,23 +498,40 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
     const int n_cand = nW * nH, n_cwords = (n_cand + 31) / 32;
     const int n_mwords = (int)((P + 31) / 32);
     uint32_t* flags = lds;                                   // candidate bits, column-major
-    uint32_t* marks = o.marks_in_lds ? lds + n_cwords : o.gmarks + (size_t)f * n_mwords;
+    uint32_t* fhz = lds + n_cwords;                          // ... and whether the candidate's pixel is a horizontal-edge one
+    uint32_t* ahz = lds + 2 * n_cwords;                      // the same bit per listed anchor
+    uint32_t* marks = o.marks_in_lds ? lds + 3 * n_cwords : o.gmarks + (size_t)f * n_mwords;
     int* cnt = o.counts + 4 * (size_t)f;
-    for (int i = tid; i < n_cwords; i += 256) flags[i] = 0u;
+    for (int i = tid; i < 3 * n_cwords; i += 256) flags[i] = 0u;
     for (int i = tid; i < n_mwords; i += 256) marks[i] = 0u;
     if (tid == 0) s_base = 0;
     __syncthreads();
-    // ---- anchors (:1504-1532): tested row-major, recorded column-major
-    for (int i = tid; i < n_cand; i += 256) {
-        const int ch = i / nW, cw = i - ch * nW;
-        const int w = 1 + scan * cw, h = 1 + scan * ch;
-        const int idx = h * W + w;
-        const uint32_t v = g[idx];
-        const int gv = (int)(v & 0x7fffu);
-        bool ok;
-        if (v & kHorizontal) ok = gv >= (int)(g[idx - W] & 0x7fffu) + fp.anchor_threshold && gv >= (int)(g[idx + W] & 0x7fffu) + fp.anchor_threshold;
-        else ok = gv >= (int)(g[idx - 1] & 0x7fffu) + fp.anchor_threshold && gv >= (int)(g[idx + 1] & 0x7fffu) + fp.anchor_threshold;
-        if (ok) { const int b = cw * nH + ch; atomicOr(&flags[b >> 5], 1u << (b & 31)); }
+    // ---- anchors (:1504-1532): tested row-major, recorded column-major.  All five loads of a candidate are issued
+    // whatever its direction, eight candidates per thread in flight: the phase is bound by the latency of the plane
+    for (int i0 = tid; i0 < n_cand; i0 += 256 * 8) {
+        uint32_t v[8], va[8], vb[8], vl[8], vr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            const int ic = i < n_cand ? i : n_cand - 1;
+            const int ch = ic / nW, cw = ic - ch * nW;
+            const int idx = (1 + scan * ch) * W + 1 + scan * cw;
+            v[u] = g[idx]; va[u] = g[idx - W]; vb[u] = g[idx + W]; vl[u] = g[idx - 1]; vr[u] = g[idx + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            if (i >= n_cand) break;
+            const int ch = i / nW, cw = i - ch * nW;
+            const int gv = (int)(v[u] & 0x7fffu);
+            const bool hz = (v[u] & kHorizontal) != 0;
+            const int n1 = (int)((hz ? va[u] : vl[u]) & 0x7fffu), n2 = (int)((hz ? vb[u] : vr[u]) & 0x7fffu);
+            if (gv >= n1 + fp.anchor_threshold && gv >= n2 + fp.anchor_threshold) {
+                const int b = cw * nH + ch;
+                atomicOr(&flags[b >> 5], 1u << (b & 31));
+                if (hz) atomicOr(&fhz[b >> 5], 1u << (b & 31));
+            }
+        }
     }
     __syncthreads();
     uint32_t* anchors = o.anchors + (size_t)f * o.cap;
@@ -394,15 +553,21 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
             bits &= bits - 1;
             const int bi = wi * 32 + b;
             const int cw = bi / nH, ch = bi - cw * nH;
-            if (off < o.cap) anchors[off] = (uint32_t)(1 + scan * cw) | ((uint32_t)(1 + scan * ch) << 16);
+            if (off < o.cap) {
+                anchors[off] = (uint32_t)(1 + scan * cw) | ((uint32_t)(1 + scan * ch) << 16);
+                if ((fhz[wi] >> b) & 1u) atomicOr(&ahz[off >> 5], 1u << (off & 31));
+            }
             ++off;
         }
         __syncthreads();
         if (tid == 255) s_base = off;
         __syncthreads();
     }
-    const int n_anchors = s_base;
+    const int n_anchors = __builtin_amdgcn_readfirstlane(s_base);
     if (wave != 0) return;
+#ifdef ED_STAMPS
+    const long long t_anch = __builtin_readcyclecounter();
+#endif
     // ================= one wave from here on =================
     if (n_anchors > o.cap) {                                  // the reference returns -1 ("anchor size is larger than its maximal size")
         if (lane == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = 1; }
@@ -411,21 +576,27 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
     uint32_t* part = o.part + (size_t)f * o.cap;
     uint32_t* chain = o.chain + (size_t)f * 2 * o.cap;
     uint32_t* sid = o.sid + (size_t)f * (o.max_edges + 2);
-    EdWalk wk; wk.g = g; wk.marks = marks; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0;
+    EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0;
+#ifdef ED_STAMPS
+    wk.t_fetch = 0; wk.t_loop = 0; wk.n_fetch = 0; wk.n_step = 0; wk.n_walk = 0;
+#endif
     const unsigned cap = (unsigned)o.cap;
     unsigned offF = 0, offS = 0, ps = 0, cpos = 0;            // kept first / second part pixels, edges, chain pixels
     bool fail = false;
+    uint32_t ablk = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     for (int a = 0; a < n_anchors; ++a) {
-        const uint32_t an = anchors[a];
+        if ((a & 63) == 0) ablk = a + lane < n_anchors ? anchors[a + lane] : 0u;      // the list, 64 anchors per load
+        const uint32_t an = (uint32_t)__builtin_amdgcn_readlane((int)ablk, a & 63);
         const unsigned x = an & 0xffffu, y = an >> 16;
         const int i = (int)(y * W + x);
-        if (ed_marked(marks, i)) continue;
+        if (__builtin_amdgcn_readfirstlane((int)wk.marks.get(i))) continue;
         if (ps > (unsigned)o.max_edges) { fail = true; break; }
-        const bool horizontal = (g[i] & kHorizontal) != 0;
+        const bool horizontal = (__builtin_amdgcn_readfirstlane((int)ahz[a >> 5]) >> (a & 31)) & 1;
         unsigned nF = offF;
         if (!ed_walk(wk, x, y, horizontal ? RightDir : DownDir, part, 0u - offF, nF, cap)) { fail = true; break; }
         const unsigned lenF = nF - offF;
-        marks[i >> 5] &= ~(1u << (i & 31));                    // the anchor starts the second part as well
+        wk.marks.clear(i);                                     // the anchor starts the second part as well
         // second part straight into the chain, behind the (still to be reversed) first part: entry t of the second
         // part lands at cpos + lenF + t - 1, i.e. its entry 0 (the anchor again) on top of the first part's last slot,
         // which the reversal below overwrites with the anchor anyway
@@ -448,6 +619,9 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
     }
     sid[ps] = cpos;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef ED_STAMPS
+    const long long t_walk = __builtin_readcyclecounter();
+#endif
     // ---- EDline (:2242-2482): chain by chain on this wave
     const uint32_t* dxy = o.dxy + (size_t)f * P;
     const int n_edges = (int)ps;
@@ -466,14 +640,26 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
     fit.ATV[0] = fit.ATV[1] = 0.f;
     double lineFitErr = 0, e0 = 0, e1 = 0;
     int status = 0;
+#ifdef ED_STAMPS
+    long long t_init = 0, t_ext = 0, t_val = 0, t_nfa = 0, t_mark; int n_init = 0, n_nfa = 0;
+#define ED_T0() t_mark = __builtin_readcyclecounter()
+#define ED_T1(acc) acc += (long long)__builtin_readcyclecounter() - t_mark
+#else
+#define ED_T0()
+#define ED_T1(acc)
+#endif
     for (int edgeID = 0; edgeID < n_edges && status == 0; ++edgeID) {
-        unsigned S = sid[edgeID];
-        const unsigned E = sid[edgeID + 1];
+        unsigned S = (unsigned)__builtin_amdgcn_readfirstlane((int)sid[edgeID]);
+        const unsigned E = (unsigned)__builtin_amdgcn_readfirstlane((int)sid[edgeID + 1]);
         while (E > S + (unsigned)minLen) {
             // an initial segment of minLen pixels that fits
+            ED_T0();
             while (E > S + (unsigned)minLen) {
-                const uint32_t p0 = chain[S];
-                const bool hz = (g[(p0 >> 16) * W + (p0 & 0xffffu)] & kHorizontal) != 0;
+#ifdef ED_STAMPS
+                n_init++;
+#endif
+                const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain[S]);
+                const bool hz = (__builtin_amdgcn_readfirstlane((int)g[(p0 >> 16) * W + (p0 & 0xffffu)]) & kHorizontal) != 0;
                 ed_sums(chain, S, minLen, hz, lane, fit.ATA, fit.ATV);
                 ed_solve(fit, e0, e1);
                 // ordered sum of the squared residuals (:2519-2525)
@@ -485,16 +671,18 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                     c2 = c * c;
                 }
                 double err = 0;
-                for (int i = 0; i < minLen; ++i) err += __shfl(c2, i);
+                for (int i = 0; i < minLen; ++i) err += ed_readlane_d(c2, __builtin_amdgcn_readfirstlane(i));
                 lineFitErr = dm::dsqrt(err);
                 if (lineFitErr <= thr) break;
                 S += 2;
             }
+            ED_T1(t_init);
             if (lineFitErr > thr) break;
             if (numOfLines >= limit) { status = 3; break; }
+            ED_T0();
             const unsigned lstart = S;
-            const uint32_t pl = chain[S];
-            const bool horizontal = (g[(pl >> 16) * W + (pl & 0xffffu)] & kHorizontal) != 0;
+            const uint32_t pl = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain[S]);
+            const bool horizontal = (__builtin_amdgcn_readfirstlane((int)g[(pl >> 16) * W + (pl & 0xffffu)]) & kHorizontal) != 0;
             double coef1 = 0;
             bool bExtended = true, bFirstTry = true;
             int numOfOutlier, tryTimes = 0;
@@ -544,6 +732,8 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                 S -= (unsigned)numOfOutlier;
                 if (!(S > newS && tryTimes < 6)) bExtended = false;
             }
+            ED_T1(t_ext);
+            ED_T0();
             double q0, q1, q2;
             if (horizontal) { q0 = e0 * coef1; q1 = -1 * coef1; q2 = e1 * coef1; }
             else { q0 = 1 * coef1; q1 = -e0 * coef1; q2 = -e1 * coef1; }
@@ -580,7 +770,14 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                         if (fabs(2 * PI - dis) < 0.392699 || dis < 0.392699) kk++;
                     }
                     kk = wave_sum_i(kk);
-                    ok = ed_nfa(n, kk, 0.125, logNT) > 0;
+                    ED_T1(t_val);
+                    ED_T0();
+                    ok = __builtin_amdgcn_readfirstlane((int)(ed_nfa(n, kk, 0.125, logNT) > 0)) != 0;
+                    ED_T1(t_nfa);
+                    ED_T0();
+#ifdef ED_STAMPS
+                    n_nfa++;
+#endif
                 }
             }
             if (ok) {
@@ -612,8 +809,14 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                 }
                 numOfLines++;
             }
+            ED_T1(t_val);
         }
     }
+#ifdef ED_STAMPS
+    if (lane == 0 && (f & 63) == 0) printf("f %d fit: init %lld (%d attempts) extend %lld validate %lld nfa %lld (%d)\n", f, t_init, n_init, t_ext, t_val, t_nfa, n_nfa);
+    if (lane == 0 && (f & 63) == 0) printf("f %d oc %d: anchors %d edges %d chainpx %u lines %u walks %d steps %d fetches %d (%lld cycles) loop %lld | anchor %lld walk %lld fit %lld cycles\n", f, oc, n_anchors, n_edges, cpos, numOfLines, wk.n_walk, wk.n_step, wk.n_fetch, wk.t_fetch, wk.t_loop,
+                                    t_anch - t_begin, t_walk - t_anch, (long long)__builtin_readcyclecounter() - t_walk);
+#endif
     if (lane == 0) {
         cnt[0] = n_anchors;
         cnt[1] = status ? -1 : n_edges;
@@ -625,7 +828,7 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
 size_t ed_detect_lds_bytes(int W, int H, int scan, bool* marks_in_lds)
 {
     const int nW = W > 2 ? (W - 2 + scan - 1) / scan : 0, nH = H > 2 ? (H - 2 + scan - 1) / scan : 0;
-    const size_t cw = ((size_t)nW * nH + 31) / 32, mw = ((size_t)W * H + 31) / 32;
+    const size_t cw = 3 * (((size_t)nW * nH + 31) / 32), mw = ((size_t)W * H + 31) / 32;      // candidate bits, their directions, the anchors' directions
     const bool fits = (cw + mw) * 4 <= 150 * 1024;
     if (marks_in_lds) *marks_in_lds = fits;
     return (fits ? cw + mw : cw) * 4;
