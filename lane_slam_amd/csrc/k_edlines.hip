@@ -221,9 +221,6 @@ struct EdWalk {
     const uint16_t* g; EdMarks marks;
     int W, H;
     unsigned lastX, lastY;
-#ifdef ED_STAMPS
-    long long t_fetch, t_loop; int n_fetch, n_step, n_walk;
-#endif
 };
 
 // one walk of the smart routing (:1577-1720 and its three copies), executed uniformly by the wave; pixels go to out[]
@@ -279,9 +276,6 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
     };
     // a new window for a walk standing at (x, y), of direction (gh, plus)
     auto fetch = [&](uint32_t gh) {
-#ifdef ED_STAMPS
-        const long long tf0 = __builtin_readcyclecounter();
-#endif
         const int go = gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir);
         int drift = 0;
         if (go == fgo) drift = gh ? y - fy : x - fx;
@@ -321,21 +315,11 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         const bool reachB = hz ? (ldx >= 1 && inner_y) : (ldy >= 1 && inner_x);
         const int fA = brkA ? 3 : (reachA ? stepA : 7), fB = brkB ? 3 : (reachB ? stepB : 7);
         info = v | ((uint32_t)fA << 16) | ((uint32_t)fB << 20) | (mk ? 1u << 24 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 25 : 0u);
-#ifdef ED_STAMPS
-        c.t_fetch += (long long)__builtin_readcyclecounter() - tf0; c.n_fetch++;
-#endif
     };
     fetch(last_h);
     int L = (y - wy0) * 8 + (x - wx0);
     uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
-#ifdef ED_STAMPS
-    c.n_walk++;
-    const long long tl0 = __builtin_readcyclecounter();
-#endif
     while ((s & (3u << 24)) == 0u) {                          // neither marked nor without gradient
-#ifdef ED_STAMPS
-        c.n_step++;
-#endif
         const bool here = lane == L;
         info |= here ? 1u << 24 : 0u;
         ord = here ? cnt : ord;
@@ -361,9 +345,6 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         L += (int)((f & 3u) + ((f & 12u) << 1)) - 9;
         s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
     }
-#ifdef ED_STAMPS
-    c.t_loop += (long long)__builtin_readcyclecounter() - tl0;
-#endif
     if (Lv >= 0) { c.lastX = (unsigned)(wx0 + (Lv & 7)); c.lastY = (unsigned)(wy0 + (Lv >> 3)); }
     if (ok) retire();
     off_io = off;
@@ -480,14 +461,23 @@ __device__ __forceinline__ void ed_solve(const EdFit& f, double& e0, double& e1)
     e1 = coef * ((double)A[0] * (double)f.ATV[1] - (double)A[2] * (double)f.ATV[0]);
 }
 
-__global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, int n_octaves)
+constexpr int ED_THREADS = 512, ED_WAVES = ED_THREADS / 64;
+
+// the line records the fitting waves produce, in the order they finish them: per frame [max_lines] of each field
+struct EdTemp {
+    double* c; float* ep; float* dir; float* sal; int* npx; int* edge; int* idx;
+    __device__ EdTemp(uint8_t* base, int n)
+    {
+        c = (double*)base; ep = (float*)(c + n); dir = ep + 4 * (size_t)n; sal = dir + n;
+        npx = (int*)(sal + n); edge = npx + n; idx = edge + n;
+    }
+};
+
+__global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams fp, int n_octaves)
 {
     extern __shared__ uint32_t lds[];
-#ifdef ED_STAMPS
-    const long long t_begin = __builtin_readcyclecounter();
-#endif
-    __shared__ int s_wave_count[4];
-    __shared__ int s_base;
+    __shared__ int s_wave_count[ED_WAVES];
+    __shared__ int s_base, s_edges, s_fail, s_next_edge, s_temp_next, s_total;
     const int oc = blockIdx.y, f = blockIdx.x;
     const EdOct& o = all.o[oc];
     const int W = o.W, H = o.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -502,17 +492,17 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
     uint32_t* ahz = lds + 2 * n_cwords;                      // the same bit per listed anchor
     uint32_t* marks = o.marks_in_lds ? lds + 3 * n_cwords : o.gmarks + (size_t)f * n_mwords;
     int* cnt = o.counts + 4 * (size_t)f;
-    for (int i = tid; i < 3 * n_cwords; i += 256) flags[i] = 0u;
-    for (int i = tid; i < n_mwords; i += 256) marks[i] = 0u;
+    for (int i = tid; i < 3 * n_cwords; i += ED_THREADS) flags[i] = 0u;
+    for (int i = tid; i < n_mwords; i += ED_THREADS) marks[i] = 0u;
     if (tid == 0) s_base = 0;
     __syncthreads();
     // ---- anchors (:1504-1532): tested row-major, recorded column-major.  All five loads of a candidate are issued
     // whatever its direction, eight candidates per thread in flight: the phase is bound by the latency of the plane
-    for (int i0 = tid; i0 < n_cand; i0 += 256 * 8) {
+    for (int i0 = tid; i0 < n_cand; i0 += ED_THREADS * 8) {
         uint32_t v[8], va[8], vb[8], vl[8], vr[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
+            const int i = i0 + ED_THREADS * u;
             const int ic = i < n_cand ? i : n_cand - 1;
             const int ch = ic / nW, cw = ic - ch * nW;
             const int idx = (1 + scan * ch) * W + 1 + scan * cw;
@@ -520,7 +510,7 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int i = i0 + 256 * u;
+            const int i = i0 + ED_THREADS * u;
             if (i >= n_cand) break;
             const int ch = i / nW, cw = i - ch * nW;
             const int gv = (int)(v[u] & 0x7fffu);
@@ -535,7 +525,7 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
     }
     __syncthreads();
     uint32_t* anchors = o.anchors + (size_t)f * o.cap;
-    for (int start = 0; start < n_cwords; start += 256) {
+    for (int start = 0; start < n_cwords; start += ED_THREADS) {
         const int wi = start + tid;
         const uint32_t word = wi < n_cwords ? flags[wi] : 0u;
         const int c = __popc(word);
@@ -560,104 +550,89 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
             ++off;
         }
         __syncthreads();
-        if (tid == 255) s_base = off;
+        if (tid == ED_THREADS - 1) s_base = off;
         __syncthreads();
     }
     const int n_anchors = __builtin_amdgcn_readfirstlane(s_base);
-    if (wave != 0) return;
-#ifdef ED_STAMPS
-    const long long t_anch = __builtin_readcyclecounter();
-#endif
-    // ================= one wave from here on =================
-    if (n_anchors > o.cap) {                                  // the reference returns -1 ("anchor size is larger than its maximal size")
-        if (lane == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = 1; }
-        return;
-    }
     uint32_t* part = o.part + (size_t)f * o.cap;
     uint32_t* chain = o.chain + (size_t)f * 2 * o.cap;
     uint32_t* sid = o.sid + (size_t)f * (o.max_edges + 2);
-    EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0;
-#ifdef ED_STAMPS
-    wk.t_fetch = 0; wk.t_loop = 0; wk.n_fetch = 0; wk.n_step = 0; wk.n_walk = 0;
-#endif
-    const unsigned cap = (unsigned)o.cap;
-    unsigned offF = 0, offS = 0, ps = 0, cpos = 0;            // kept first / second part pixels, edges, chain pixels
-    bool fail = false;
-    uint32_t ablk = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    for (int a = 0; a < n_anchors; ++a) {
-        if ((a & 63) == 0) ablk = a + lane < n_anchors ? anchors[a + lane] : 0u;      // the list, 64 anchors per load
-        const uint32_t an = (uint32_t)__builtin_amdgcn_readlane((int)ablk, a & 63);
-        const unsigned x = an & 0xffffu, y = an >> 16;
-        const int i = (int)(y * W + x);
-        if (__builtin_amdgcn_readfirstlane((int)wk.marks.get(i))) continue;
-        if (ps > (unsigned)o.max_edges) { fail = true; break; }
-        const bool horizontal = (__builtin_amdgcn_readfirstlane((int)ahz[a >> 5]) >> (a & 31)) & 1;
-        unsigned nF = offF;
-        if (!ed_walk(wk, x, y, horizontal ? RightDir : DownDir, part, 0u - offF, nF, cap)) { fail = true; break; }
-        const unsigned lenF = nF - offF;
-        wk.marks.clear(i);                                     // the anchor starts the second part as well
-        // second part straight into the chain, behind the (still to be reversed) first part: entry t of the second
-        // part lands at cpos + lenF + t - 1, i.e. its entry 0 (the anchor again) on top of the first part's last slot,
-        // which the reversal below overwrites with the anchor anyway
-        unsigned nS = offS;
-        if (!ed_walk(wk, x, y, horizontal ? LeftDir : UpDir, chain, cpos + lenF - 1u - offS, nS, cap)) { fail = true; break; }
-        const unsigned lenS = nS - offS;
-        if ((int)(lenF + lenS) < fp.min_line_len + 1) continue;               // short chain: dropped, its marks stay
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        for (unsigned t = lane; t < lenF; t += 64) chain[cpos + t] = part[lenF - 1 - t];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        sid[ps] = cpos;
-        cpos += lenF + lenS - 1;
-        offF = nF; offS = nS;
-        ++ps;
+    // ================= smart routing: one wave (a walk stops at pixels earlier walks marked) =================
+    if (wave == 0) {
+        int st = 0;
+        unsigned ps = 0, cpos = 0;                            // edges, chain pixels
+        if (n_anchors > o.cap) st = 1;                        // the reference returns -1 ("anchor size is larger than its maximal size")
+        else {
+            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0;
+            const unsigned cap = (unsigned)o.cap;
+            unsigned offF = 0, offS = 0;                      // kept first / second part pixels
+            uint32_t ablk = 0u;
+            for (int a = 0; a < n_anchors; ++a) {
+                if ((a & 63) == 0) ablk = a + lane < n_anchors ? anchors[a + lane] : 0u;      // the list, 64 anchors per load
+                const uint32_t an = (uint32_t)__builtin_amdgcn_readlane((int)ablk, a & 63);
+                const unsigned x = an & 0xffffu, y = an >> 16;
+                const int i = (int)(y * W + x);
+                if (__builtin_amdgcn_readfirstlane((int)wk.marks.get(i))) continue;
+                if (ps > (unsigned)o.max_edges) { st = 2; break; }
+                const bool horizontal = (__builtin_amdgcn_readfirstlane((int)ahz[a >> 5]) >> (a & 31)) & 1;
+                unsigned nF = offF;
+                if (!ed_walk(wk, x, y, horizontal ? RightDir : DownDir, part, 0u - offF, nF, cap)) { st = 2; break; }
+                const unsigned lenF = nF - offF;
+                wk.marks.clear(i);                                     // the anchor starts the second part as well
+                // second part straight into the chain, behind the (still to be reversed) first part: entry t of the second
+                // part lands at cpos + lenF + t - 1, i.e. its entry 0 (the anchor again) on top of the first part's last slot,
+                // which the reversal below overwrites with the anchor anyway
+                unsigned nS = offS;
+                if (!ed_walk(wk, x, y, horizontal ? LeftDir : UpDir, chain, cpos + lenF - 1u - offS, nS, cap)) { st = 2; break; }
+                const unsigned lenS = nS - offS;
+                if ((int)(lenF + lenS) < fp.min_line_len + 1) continue;               // short chain: dropped, its marks stay
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (unsigned t = lane; t < lenF; t += 64) chain[cpos + t] = part[lenF - 1 - t];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                sid[ps] = cpos;
+                cpos += lenF + lenS - 1;
+                offF = nF; offS = nS;
+                ++ps;
+            }
+            if (!st && ps > (unsigned)o.max_edges) st = 2;
+        }
+        if (!st) sid[ps] = cpos;
+        if (lane == 0) { s_edges = st ? 0 : (int)ps; s_fail = st; s_next_edge = 0; s_temp_next = 0; }
     }
-    if (!fail && ps > (unsigned)o.max_edges) fail = true;
-    if (fail) {
-        if (lane == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = 2; }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = s_fail; }
         return;
     }
-    sid[ps] = cpos;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef ED_STAMPS
-    const long long t_walk = __builtin_readcyclecounter();
-#endif
-    // ---- EDline (:2242-2482): chain by chain on this wave
+    // ================= EDline (:2242-2482): the chains are independent -- every wave takes the next one =================
+    // A wave appends its lines to the frame's temporary records as it validates them and notes, per chain, how many it
+    // kept and how many it had kept when it last set out on a line (what the reference's "too many lines" test looks
+    // at); the records are put in chain order afterwards.
     const uint32_t* dxy = o.dxy + (size_t)f * P;
-    const int n_edges = (int)ps;
+    const int n_edges = __builtin_amdgcn_readfirstlane(s_edges);
     const int minLen = fp.min_line_len;
     const double thr = fp.fit_err;
     const double logNT = 2.0 * (dm::dlog10((double)(unsigned)W) + dm::dlog10((double)(unsigned)H));
     const unsigned limit = min(5u * (unsigned)n_edges, (unsigned)o.max_lines);
-    float* l_ep = o.l_ep + (size_t)f * o.max_lines * 4;
-    double* l_c = o.l_c + (size_t)f * o.max_lines;
-    float* l_dir = o.l_dir + (size_t)f * o.max_lines;
-    int* l_npx = o.l_npx + (size_t)f * o.max_lines;
-    float* l_sal = o.l_sal + (size_t)f * o.max_lines;
-    unsigned numOfLines = 0;
-    EdFit fit;
-    for (int k = 0; k < 4; ++k) fit.ATA[k] = 0.f;
-    fit.ATV[0] = fit.ATV[1] = 0.f;
-    double lineFitErr = 0, e0 = 0, e1 = 0;
-    int status = 0;
-#ifdef ED_STAMPS
-    long long t_init = 0, t_ext = 0, t_val = 0, t_nfa = 0, t_mark; int n_init = 0, n_nfa = 0;
-#define ED_T0() t_mark = __builtin_readcyclecounter()
-#define ED_T1(acc) acc += (long long)__builtin_readcyclecounter() - t_mark
-#else
-#define ED_T0()
-#define ED_T1(acc)
-#endif
-    for (int edgeID = 0; edgeID < n_edges && status == 0; ++edgeID) {
+    const EdTemp tl(o.tl + (size_t)f * o.tl_stride, o.max_lines);
+    int* e_kept = (int*)part;                                // the first-part scratch is free now: per chain lines kept,
+    int* e_last = e_kept + n_edges;                          // lines kept before the last line was begun (-1: none begun),
+    int* e_base = e_last + n_edges;                          // index of the chain's first line in the frame
+    for (;;) {
+        int edgeID = 0;
+        if (lane == 0) edgeID = atomicAdd(&s_next_edge, 1);
+        edgeID = __builtin_amdgcn_readfirstlane(edgeID);
+        if (edgeID >= n_edges) break;
         unsigned S = (unsigned)__builtin_amdgcn_readfirstlane((int)sid[edgeID]);
         const unsigned E = (unsigned)__builtin_amdgcn_readfirstlane((int)sid[edgeID + 1]);
+        int kept = 0, kept_at_last = -1;
+        EdFit fit;
+        for (int k = 0; k < 4; ++k) fit.ATA[k] = 0.f;
+        fit.ATV[0] = fit.ATV[1] = 0.f;
+        double lineFitErr = 0, e0 = 0, e1 = 0;
         while (E > S + (unsigned)minLen) {
             // an initial segment of minLen pixels that fits
-            ED_T0();
             while (E > S + (unsigned)minLen) {
-#ifdef ED_STAMPS
-                n_init++;
-#endif
                 const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain[S]);
                 const bool hz = (__builtin_amdgcn_readfirstlane((int)g[(p0 >> 16) * W + (p0 & 0xffffu)]) & kHorizontal) != 0;
                 ed_sums(chain, S, minLen, hz, lane, fit.ATA, fit.ATV);
@@ -676,10 +651,8 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                 if (lineFitErr <= thr) break;
                 S += 2;
             }
-            ED_T1(t_init);
             if (lineFitErr > thr) break;
-            if (numOfLines >= limit) { status = 3; break; }
-            ED_T0();
+            kept_at_last = kept;                               // (:2290: the reference gives up when numOfLines >= limit here)
             const unsigned lstart = S;
             const uint32_t pl = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain[S]);
             const bool horizontal = (__builtin_amdgcn_readfirstlane((int)g[(pl >> 16) * W + (pl & 0xffffu)]) & kHorizontal) != 0;
@@ -732,19 +705,23 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                 S -= (unsigned)numOfOutlier;
                 if (!(S > newS && tryTimes < 6)) bExtended = false;
             }
-            ED_T1(t_ext);
-            ED_T0();
             double q0, q1, q2;
             if (horizontal) { q0 = e0 * coef1; q1 = -1 * coef1; q2 = e1 * coef1; }
             else { q0 = 1 * coef1; q1 = -e0 * coef1; q2 = -e1 * coef1; }
-            // ---- LineValidation_ (:2645-2726)
+            // ---- LineValidation_ (:2645-2726).  One pass over the line's pixels gathers the gradient sums AND the
+            // salience (:2728-2751: the CV_16S plane sumDxDy / 4 read through an unsigned char pointer with a PIXEL index
+            // -- byte (i & 1) of element i >> 1), so that the two gathers from the plane are in flight together
             const int n = (int)(S - lstart);
-            int mgx = 0, mgy = 0;
+            int mgx = 0, mgy = 0, sal = 0;
             for (int i = lane; i < n; i += 64) {
                 const uint32_t p = chain[lstart + i];
-                const uint32_t d = dxy[(p >> 16) * W + (p & 0xffffu)];
+                const unsigned bi = (p >> 16) * (unsigned)W + (p & 0xffffu);
+                const uint32_t d = dxy[bi], d2 = dxy[bi >> 1];
                 mgx += (int)(int16_t)(d & 0xffffu);
                 mgy += (int)d >> 16;
+                const int vx = (int)(int16_t)(d2 & 0xffffu), vy = (int)d2 >> 16;
+                const int gwo = ed_div4_half_even((vx < 0 ? -vx : vx) + (vy < 0 ? -vy : vy));
+                sal += (bi & 1u) ? ((gwo >> 8) & 0xff) : (gwo & 0xff);
             }
             mgx = wave_sum_i(mgx); mgy = wave_sum_i(mgy);
             const double adx = fabs(q1), ady = fabs(q0);
@@ -770,59 +747,78 @@ __global__ __launch_bounds__(256) void k_ed_detect(EdAll all, EdFitParams fp, in
                         if (fabs(2 * PI - dis) < 0.392699 || dis < 0.392699) kk++;
                     }
                     kk = wave_sum_i(kk);
-                    ED_T1(t_val);
-                    ED_T0();
                     ok = __builtin_amdgcn_readfirstlane((int)(ed_nfa(n, kk, 0.125, logNT) > 0)) != 0;
-                    ED_T1(t_nfa);
-                    ED_T0();
-#ifdef ED_STAMPS
-                    n_nfa++;
-#endif
                 }
             }
             if (ok) {
                 const double a1 = q1 * q1, a2 = q0 * q0, a3 = q0 * q1, a4 = q2 * q0, a5 = q2 * q1;
                 const uint32_t pa = chain[lstart], pb = chain[S - 1];
-                // salience (:2728-2751): the CV_16S plane sumDxDy / 4 read through an unsigned char pointer with a PIXEL
-                // index -- byte (i & 1) of element i >> 1
-                int sal = 0;
-                for (int i = lane; i < n; i += 64) {
-                    const uint32_t p = chain[lstart + i];
-                    const unsigned bi = (p >> 16) * (unsigned)W + (p & 0xffffu);
-                    const uint32_t d = dxy[bi >> 1];
-                    const int vx = (int)(int16_t)(d & 0xffffu), vy = (int)d >> 16;
-                    const int gwo = ed_div4_half_even((vx < 0 ? -vx : vx) + (vy < 0 ? -vy : vy));
-                    sal += (bi & 1u) ? ((gwo >> 8) & 0xff) : (gwo & 0xff);
-                }
                 sal = wave_sum_i(sal);
-                if (lane == 0) {
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(&s_temp_next, 1);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                // (every lane stores the same record: a loop body that ends in work of lane 0 alone can be compiled so that
+                // the other lanes run ahead to the loop's head, where the wave-uniform reads then see THEIR values)
+                if (slot < o.max_lines) {                      // (more than max_lines: the frame fails below)
                     const unsigned Px = pa & 0xffffu, Py = pa >> 16, Qx = pb & 0xffffu, Qy = pb >> 16;
-                    float* ep = l_ep + 4 * (size_t)numOfLines;
+                    float* ep = tl.ep + 4 * (size_t)slot;
                     ep[0] = (float)(a1 * Px - a3 * Py - a4);
                     ep[1] = (float)(a2 * Py - a3 * Px - a5);
                     ep[2] = (float)(a1 * Qx - a3 * Qy - a4);
                     ep[3] = (float)(a2 * Qy - a3 * Qx - a5);
-                    l_c[numOfLines] = q2;
-                    l_dir[numOfLines] = direction;
-                    l_npx[numOfLines] = n;
-                    l_sal[numOfLines] = (float)sal;
+                    tl.c[slot] = q2;
+                    tl.dir[slot] = direction;
+                    tl.npx[slot] = n;
+                    tl.sal[slot] = (float)sal;
+                    tl.edge[slot] = edgeID;
+                    tl.idx[slot] = kept;
                 }
-                numOfLines++;
+                kept++;
             }
-            ED_T1(t_val);
         }
+        e_kept[edgeID] = kept; e_last[edgeID] = kept_at_last;
     }
-#ifdef ED_STAMPS
-    if (lane == 0 && (f & 63) == 0) printf("f %d fit: init %lld (%d attempts) extend %lld validate %lld nfa %lld (%d)\n", f, t_init, n_init, t_ext, t_val, t_nfa, n_nfa);
-    if (lane == 0 && (f & 63) == 0) printf("f %d oc %d: anchors %d edges %d chainpx %u lines %u walks %d steps %d fetches %d (%lld cycles) loop %lld | anchor %lld walk %lld fit %lld cycles\n", f, oc, n_anchors, n_edges, cpos, numOfLines, wk.n_walk, wk.n_step, wk.n_fetch, wk.t_fetch, wk.t_loop,
-                                    t_anch - t_begin, t_walk - t_anch, (long long)__builtin_readcyclecounter() - t_walk);
-#endif
-    if (lane == 0) {
-        cnt[0] = n_anchors;
-        cnt[1] = status ? -1 : n_edges;
-        cnt[2] = status ? 0 : (int)numOfLines;
-        cnt[3] = status;
+    __syncthreads();
+    // ---- chain order: where each chain's lines start; the reference's test of the running count (:2290)
+    if (wave == 0) {
+        int run = 0;
+        bool bad = s_temp_next > o.max_lines;
+        for (int e0i = 0; e0i < n_edges; e0i += 64) {
+            const int e = e0i + lane;
+            const int c = e < n_edges ? e_kept[e] : 0;
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            const int base = run + incl - c;
+            bool over = false;
+            if (e < n_edges) {
+                e_base[e] = base;
+                const int kl = e_last[e];
+                over = kl >= 0 && (unsigned)(base + kl) >= limit;
+            }
+            if (__ballot(over) != 0ull) bad = true;
+            run += __shfl(incl, 63);
+        }
+        if (lane == 0) { s_total = run; s_fail = bad ? 3 : 0; }
     }
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = s_fail; }
+        return;
+    }
+    float* l_ep = o.l_ep + (size_t)f * o.max_lines * 4;
+    double* l_c = o.l_c + (size_t)f * o.max_lines;
+    float* l_dir = o.l_dir + (size_t)f * o.max_lines;
+    int* l_npx = o.l_npx + (size_t)f * o.max_lines;
+    float* l_sal = o.l_sal + (size_t)f * o.max_lines;
+    const int total = s_total;
+    for (int t = tid; t < total; t += ED_THREADS) {
+        const int d = e_base[tl.edge[t]] + tl.idx[t];
+        const float4 ep = *reinterpret_cast<const float4*>(tl.ep + 4 * (size_t)t);
+        *reinterpret_cast<float4*>(l_ep + 4 * (size_t)d) = ep;
+        l_c[d] = tl.c[t]; l_dir[d] = tl.dir[t]; l_npx[d] = tl.npx[t]; l_sal[d] = tl.sal[t];
+    }
+    if (tid == 0) { cnt[0] = n_anchors; cnt[1] = n_edges; cnt[2] = total; cnt[3] = 0; }
 }
 
 size_t ed_detect_lds_bytes(int W, int H, int scan, bool* marks_in_lds)
@@ -840,7 +836,7 @@ int launch_ed_detect(const EdAll& all, const EdFitParams& fp, int n_octaves, int
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ed_detect), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_ed_detect, dim3(n_frames, n_octaves), dim3(256), lds_bytes, s, all, fp, n_octaves);
+    hipLaunchKernelGGL(k_ed_detect, dim3(n_frames, n_octaves), dim3(ED_THREADS), lds_bytes, s, all, fp, n_octaves);
     return 0;
 }
 

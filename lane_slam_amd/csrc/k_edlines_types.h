@@ -23,6 +23,8 @@ struct EdOct {
     float* l_dir;          // [B][max_lines]
     int* l_npx;            // [B][max_lines]
     float* l_sal;          // [B][max_lines]
+    uint8_t* tl;           // [B][tl_stride] the line records in the order the fitting waves finish them (EdTemp)
+    size_t tl_stride;      // bytes per frame: max_lines * 48 (8 + 16 + 5 * 4, rounded up to 8)
 };
 
 struct EdAll { EdOct o[LF_MAX_OCTAVES]; };
