@@ -28,7 +28,7 @@
 
 namespace lf {
 
-constexpr int ET_W = 64, ET_H = 16;                 // k_ed_grad tile
+constexpr int ET_W = 64, ET_H = 64;                 // k_ed_grad tile
 constexpr int kHorizontal = 0x8000;                 // bit 15 of the g plane: |dx| < |dy|
 
 __device__ __forceinline__ int ed_reflect101(int p, int n)
@@ -44,80 +44,173 @@ __device__ __forceinline__ int ed_div4_half_even(int v)
     return r < 2 ? q : (r == 3 ? q + 1 : q + (q & 1));
 }
 
-// src u8 [B][H][W] -> blur u8, dxy u32, g u16.  taps: 5 ints (sum ~ 256).
+// src u8 [B][H][W] -> blur u8, dxy u32, g u16.  taps: 5 ints, sum <= 257 (the row sums then fit 16 bits).
+// Built like k_lbd_grad (k_lbd.hip), which computes the same blur + Sobel for the LSD path's descriptor: 64 x 64 tiles,
+// four horizontally adjacent pixels per lane in every phase, two values per instruction in packed 16-bit halves, the
+// row-filtered tile stored as ROW PAIRS per column -- the operand of v_dot2_u32_u16 in the column filter.  What differs:
+// the taps are the octave's (run-time), the image is any size (octave widths are not multiples of four: rows are not
+// dword-aligned, so the source is read with unaligned dword loads and the outputs fall back to narrower stores), and
+// two more planes are written -- the blurred image (the next octave is resized from it) and the thresholded gradient
+// magnitude / 4 (round half to even) with the direction in bit 15.  The blurred ring outside the image is the blur of the
+// reflected source, which for a symmetric kernel IS the reflected blurred image the Sobel's BORDER_REFLECT_101 asks for.
 __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __restrict__ src, int t0, int t1, int t2, int t3, int t4,
-                                                 int grad_threshold, uint8_t* __restrict__ blur, uint32_t* __restrict__ dxy,
-                                                 uint16_t* __restrict__ g)
+                                                 int grad_threshold, uint8_t* __restrict__ bluro, uint32_t* __restrict__ dxyo,
+                                                 uint16_t* __restrict__ go)
 {
-    // rows ty-3 .. ty+ET_H+2, cols tx-3 .. tx+ET_W+2 of the source (in-image part), then the row filter, then the blurred
-    // tile with a 1-pixel ring (in-image part; the Sobel reflects INTO it: BORDER_REFLECT_101 of the blurred image)
-    __shared__ uint8_t s_src[ET_H + 6][ET_W + 8];
-    __shared__ int s_row[ET_H + 6][ET_W + 2];
-    __shared__ uint8_t s_blur[ET_H + 2][ET_W + 4];
-    const int tx = blockIdx.x * ET_W, ty = blockIdx.y * ET_H;
-    const size_t fo = (size_t)blockIdx.z * H * W;
-    const uint8_t* S = src + fo;
+    constexpr int GW = 72, GH = ET_H + 6;            // source tile: 70 columns used (x0-3 .. x0+66), rows padded to dwords
+    constexpr int RW = 68, RG = RW / 4;              // row-filtered: 66 columns used (x0-1 .. x0+64)
+    constexpr int BW_ = 72, BH = ET_H + 2;           // blurred: column c <-> x0-1+c, 66 used
+    __shared__ __attribute__((aligned(16))) uint8_t gray[GH * GW];
+    __shared__ __attribute__((aligned(16))) uint32_t rowp[(GH / 2) * RW];   // (row 2m, row 2m + 1) per column, 16 bits each
+    __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
+    int tbx, tby, f;
+    lf_xcd_tile(tbx, tby, f);
+    const int x0 = tbx * ET_W, y0 = tby * ET_H;
     const int tid = threadIdx.x;
-    const int k[5] = { t0, t1, t2, t3, t4 };
-    // source region: LDS (r, c) <-> image (ty - 3 + r, tx - 3 + c); out-of-image entries are never read (all readers
-    // reflect first)
-    for (int i = tid; i < (ET_H + 6) * (ET_W + 6); i += 256) {
-        const int r = i / (ET_W + 6), c = i - r * (ET_W + 6);
-        const int y = ty - 3 + r, x = tx - 3 + c;
-        s_src[r][c] = (y >= 0 && y < H && x >= 0 && x < W) ? S[(size_t)y * W + x] : (uint8_t)0;
+    const size_t fo = (size_t)f * H * W;
+    const uint8_t* img = src + fo;
+    auto reflect_row = [&](int ty) { return (uint32_t)ed_reflect101(y0 + ty - 3, H) * (uint32_t)W; };
+    const bool interior = x0 >= 3 && x0 + 69 <= W;           // wave-uniform: all 72 columns x0-3 .. x0+68 lie inside the row
+    if (interior) {
+        const uint8_t* base = img + (x0 - 3);
+        for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
+            const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
+            uint32_t packed;
+            __builtin_memcpy(&packed, base + (reflect_row(ty) + 4u * (uint32_t)g), 4);      // (not dword-aligned: W is any number)
+            *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = packed;
+        }
+    } else {
+        for (int idx = tid; idx < GH * (GW / 4); idx += 256) {
+            const int ty = idx / (GW / 4), g = idx - ty * (GW / 4);
+            const uint32_t row = reflect_row(ty);
+            const int xa = x0 + 4 * g - 3;
+            uint32_t packed = 0;
+            if (xa >= 0 && xa + 3 < W) __builtin_memcpy(&packed, img + (row + (uint32_t)xa), 4);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) packed |= (uint32_t)img[row + (uint32_t)ed_reflect101(xa + k, W)] << (8 * k);
+            }
+            *reinterpret_cast<uint32_t*>(gray + ty * GW + 4 * g) = packed;
+        }
     }
     __syncthreads();
-    // row filter at (y, x), x in tx-1 .. tx+ET_W, y in ty-3 .. ty+ET_H+2 (in-image positions only)
-    for (int i = tid; i < (ET_H + 6) * (ET_W + 2); i += 256) {
-        const int r = i / (ET_W + 2), c = i - r * (ET_W + 2);
-        const int y = ty - 3 + r, x = tx - 1 + c;
-        int s = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
+    // horizontal 5-tap: outputs c..c+3 (c = 4g) need gray[c .. c+7] = two dwords; the same four columns of two consecutive rows
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 c0 = { (unsigned short)t0, (unsigned short)t0 }, c1 = { (unsigned short)t1, (unsigned short)t1 }, c2 = { (unsigned short)t2, (unsigned short)t2 },
+              c3 = { (unsigned short)t3, (unsigned short)t3 }, c4 = { (unsigned short)t4, (unsigned short)t4 };
+    for (int idx = tid; idx < (GH / 2) * RG; idx += 256) {
+        const int m = idx / RG, g = idx - m * RG;
+        uint32_t o02[2], o13[2];
 #pragma unroll
-            for (int j = -2; j <= 2; ++j) {
-                const int xx = ed_reflect101(x + j, W);
-                s += k[j + 2] * (int)s_src[r][xx - (tx - 3)];
+        for (int r = 0; r < 2; ++r) {
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(gray + (2 * m + r) * GW + 4 * g);
+            const uint32_t lo = sp[0], hi = sp[1];
+            const us2 E = __builtin_bit_cast(us2, lo & 0x00ff00ffu), O = __builtin_bit_cast(us2, (lo >> 8) & 0x00ff00ffu);
+            const us2 E2 = __builtin_bit_cast(us2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(us2, (hi >> 8) & 0x00ff00ffu);
+            const us2 P24 = { E.y, E2.x }, P35 = { O.y, O2.x };
+            o02[r] = __builtin_bit_cast(uint32_t, c0 * E + c1 * O + c2 * P24 + c3 * P35 + c4 * E2);      // (out0, out2)
+            o13[r] = __builtin_bit_cast(uint32_t, c0 * O + c1 * P24 + c2 * P35 + c3 * E2 + c4 * O2);     // (out1, out3)
+        }
+        const uint4 q = make_uint4(__builtin_amdgcn_perm(o02[1], o02[0], 0x05040100u), __builtin_amdgcn_perm(o13[1], o13[0], 0x05040100u),
+                                   __builtin_amdgcn_perm(o02[1], o02[0], 0x07060302u), __builtin_amdgcn_perm(o13[1], o13[0], 0x07060302u));
+        *reinterpret_cast<uint4*>(rowp + m * RW + 4 * g) = q;
+    }
+    __syncthreads();
+    // vertical 5-tap, (acc + 2^15) >> 16, saturate -> blurred u8: rows 2m and 2m + 1 from the pairs m, m + 1, m + 2
+    {
+        constexpr int VPAIRS = 3, VSEG = (BH / 2 + VPAIRS - 1) / VPAIRS;
+        static_assert(VSEG * RG <= 256, "one lane per (column group, segment)");
+        const us2 k01 = { (unsigned short)t0, (unsigned short)t1 }, k23 = { (unsigned short)t2, (unsigned short)t3 }, k4_ = { (unsigned short)t4, 0 };
+        const us2 k_0 = { 0, (unsigned short)t0 }, k12 = { (unsigned short)t1, (unsigned short)t2 }, k34 = { (unsigned short)t3, (unsigned short)t4 };
+        const int g = tid % RG, seg = tid / RG;
+        if (seg < VSEG) {
+            const int m0 = seg * VPAIRS;
+            uint4 Pp[3];
+            auto fetch = [&](int m) { return *reinterpret_cast<const uint4*>(rowp + (m < GH / 2 ? m : GH / 2 - 1) * RW + 4 * g); };
+            Pp[0] = fetch(m0); Pp[1] = fetch(m0 + 1);
+#pragma unroll
+            for (int i = 0; i < VPAIRS; ++i) {
+                const int m = m0 + i;
+                Pp[(i + 2) % 3] = fetch(m + 2);
+                if (2 * m < BH) {
+                    const uint4 A = Pp[i % 3], B = Pp[(i + 1) % 3], C = Pp[(i + 2) % 3];
+                    const uint32_t a[4] = { A.x, A.y, A.z, A.w }, bb[4] = { B.x, B.y, B.z, B.w }, cc[4] = { C.x, C.y, C.z, C.w };
+                    uint32_t even = 0, odd = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        uint32_t e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), k01, 1u << 15, false);
+                        e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), k23, e, false);
+                        e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), k4_, e, false);
+                        uint32_t o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), k_0, 1u << 15, false);
+                        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), k12, o, false);
+                        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), k34, o, false);
+                        e >>= 16; o >>= 16;
+                        even |= (e > 255u ? 255u : e) << (8 * k);
+                        odd |= (o > 255u ? 255u : o) << (8 * k);
+                    }
+                    *reinterpret_cast<uint32_t*>(blur + (2 * m) * BW_ + 4 * g) = even;
+                    *reinterpret_cast<uint32_t*>(blur + (2 * m + 1) * BW_ + 4 * g) = odd;
+                }
             }
         }
-        s_row[r][c] = s;
     }
     __syncthreads();
-    // column filter -> blurred value at (y, x), y in ty-1 .. ty+ET_H, x in tx-1 .. tx+ET_W
-    for (int i = tid; i < (ET_H + 2) * (ET_W + 2); i += 256) {
-        const int r = i / (ET_W + 2), c = i - r * (ET_W + 2);
-        const int y = ty - 1 + r, x = tx - 1 + c;
-        int v = 0;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            int s = 0;
+    // Sobel 3x3 on the blurred tile, 4 outputs per lane and row; the three planes
+    {
+        constexpr int SROWS = ET_H / 16;
+        const int g = tid & 15, seg = tid >> 4;
+        const int lx = 4 * g, gx = x0 + lx, ry0 = seg * SROWS;
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        s2 Pq[3][4];
+        uint32_t mid[3];                                    // the row's own four blurred bytes (columns lx+1 .. lx+4)
+        auto unpack = [&](int row, s2 (&d)[4], uint32_t& centre) {
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(blur + row * BW_ + lx);   // columns lx .. lx+7 <-> x-1 ..
+            const uint32_t lo = sp[0], hi = sp[1];
+            const s2 E = __builtin_bit_cast(s2, lo & 0x00ff00ffu), O = __builtin_bit_cast(s2, (lo >> 8) & 0x00ff00ffu);
+            const s2 E2 = __builtin_bit_cast(s2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(s2, (hi >> 8) & 0x00ff00ffu);
+            d[0] = E; d[1] = O; d[2] = s2{ E.y, E2.x }; d[3] = s2{ O.y, O2.x };
+            centre = (lo >> 8) | (hi << 24);
+        };
+        unpack(ry0, Pq[0], mid[0]);
+        unpack(ry0 + 1, Pq[1], mid[1]);
+        auto a_plus_2b = [](s2 a, s2 b) {
+            s2 d;
+            const uint32_t two = 0x00020002u;
+            asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(two), "v"(a));
+            return d;
+        };
+        const bool wide = (W & 3) == 0;                      // rows of the output planes are 4-pixel aligned
+        const size_t o00 = fo + (size_t)(y0 + ry0) * W + gx;
 #pragma unroll
-            for (int j = -2; j <= 2; ++j) {
-                const int yy = ed_reflect101(y + j, H);
-                s += k[j + 2] * s_row[yy - (ty - 3)][c];
+        for (int i = 0; i < SROWS; ++i) {
+            const int ry = ry0 + i, gy = y0 + ry;
+            unpack(ry + 2, Pq[(i + 2) % 3], mid[(i + 2) % 3]);
+            if (gx < W && gy < H) {
+                s2 S[4], D[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { S[c] = a_plus_2b(Pq[i % 3][c], Pq[(i + 1) % 3][c]) + Pq[(i + 2) % 3][c]; D[c] = Pq[(i + 2) % 3][c] - Pq[i % 3][c]; }
+                const s2 vx02 = S[2] - S[0], vx13 = S[3] - S[1];
+                const s2 vy02 = a_plus_2b(D[0], D[1]) + D[2], vy13 = a_plus_2b(D[1], D[2]) + D[3];
+                const int vx[4] = { vx02.x, vx13.x, vx02.y, vx13.y }, vy[4] = { vy02.x, vy13.x, vy02.y, vy13.y };
+                uint32_t w[4], gq[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    w[k] = ((uint32_t)vx[k] & 0xffffu) | ((uint32_t)vy[k] << 16);
+                    const int ax = vx[k] < 0 ? -vx[k] : vx[k], ay = vy[k] < 0 ? -vy[k] : vy[k];
+                    const int sum = ax + ay;
+                    gq[k] = (uint32_t)(ed_div4_half_even(sum > grad_threshold + 1 ? sum : 0) | (ax < ay ? kHorizontal : 0));
+                }
+                const size_t o = o00 + (size_t)i * W;
+                const uint32_t bl = mid[(i + 1) % 3];
+                if (wide && gx + 3 < W) {
+                    *reinterpret_cast<uint4*>(dxyo + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    *reinterpret_cast<uint2*>(go + o) = make_uint2(gq[0] | (gq[1] << 16), gq[2] | (gq[3] << 16));
+                    *reinterpret_cast<uint32_t*>(bluro + o) = bl;
+                } else {
+                    for (int k = 0; k < 4 && gx + k < W; ++k) { dxyo[o + k] = w[k]; go[o + k] = (uint16_t)gq[k]; bluro[o + k] = (uint8_t)(bl >> (8 * k)); }
+                }
             }
-            v = (s + (1 << 15)) >> 16;
-            v = v < 0 ? 0 : (v > 255 ? 255 : v);
         }
-        s_blur[r][c] = (uint8_t)v;
-    }
-    __syncthreads();
-    for (int i = tid; i < ET_H * ET_W; i += 256) {
-        const int r = i / ET_W, c = i - r * ET_W;
-        const int y = ty + r, x = tx + c;
-        if (y >= H || x >= W) continue;
-        // neighbours of the blurred image with BORDER_REFLECT_101
-        const int ym = ed_reflect101(y - 1, H) - (ty - 1), y0 = r + 1, yp = ed_reflect101(y + 1, H) - (ty - 1);
-        const int xm = ed_reflect101(x - 1, W) - (tx - 1), x0 = c + 1, xp = ed_reflect101(x + 1, W) - (tx - 1);
-#define B_(yy, xx) ((int)s_blur[yy][xx])
-        const int vx = (B_(ym, xp) - B_(ym, xm)) + 2 * (B_(y0, xp) - B_(y0, xm)) + (B_(yp, xp) - B_(yp, xm));
-        const int vy = (B_(yp, xm) - B_(ym, xm)) + 2 * (B_(yp, x0) - B_(ym, x0)) + (B_(yp, xp) - B_(ym, xp));
-        const size_t o = fo + (size_t)y * W + x;
-        blur[o] = (uint8_t)B_(y0, x0);
-#undef B_
-        dxy[o] = ((uint32_t)vx & 0xffffu) | ((uint32_t)vy << 16);
-        const int ax = vx < 0 ? -vx : vx, ay = vy < 0 ? -vy : vy;
-        const int sum = ax + ay;
-        const int gv = ed_div4_half_even(sum > grad_threshold + 1 ? sum : 0);
-        g[o] = (uint16_t)(gv | (ax < ay ? kHorizontal : 0));
     }
 }
 
@@ -227,21 +320,24 @@ struct EdWalk {
 // from off on (packed x | y << 16).  Returns false when the part array would overflow.
 //
 // The walk is a chain of dependent decisions, one pixel per step, and ONE wave per frame executes it: what it costs is
-// the number of instructions per step (a lone wave issues one every 5-10 cycles) and the round trips to the gradient
+// the number of instructions per step (a lone wave issues one every ~10 cycles) and the round trips to the gradient
 // plane.  Both are taken out of the step:
 //   * the wave keeps an 8 x 8 WINDOW of the plane, one pixel per lane (lane = row * 8 + column), placed so that the
 //     walk runs into it -- one column / row behind the current pixel, six ahead, shifted sideways when the last window
 //     was left sideways;
-//   * when a window is fetched, every lane works out FOR ITS PIXEL what a walk standing there would do: its pixel is a
-//     horizontal-edge one (the walk goes right or left) or a vertical-edge one (down or up), and for both signs the
-//     lane compares the three pixels ahead (neighbour values by two DPP row shifts and two ds_bpermute) and records
-//     the step to the winner as (dx + 1) | (dy + 1) << 2, or 3 when the reference stops at the image border first, 7
-//     when the three are not all inside the window.  The result is one `info` word per lane:
-//     gradient | direction bit | step(+) << 16 | step(-) << 20 | marked << 24;
-//   * inside a window the walk is a walk over LANES: a step reads the current lane's info (v_readlane), settles the
-//     sign from the kind of the pixel and the step before (x > lastX is "the last step went right"), and adds the
-//     step to the lane number -- ~30 scalar instructions, no memory access, no coordinates.  The lane it visits notes
-//     its place in the order of the visit;
+//   * the reference's direction logic needs, at a pixel, the walk's direction and whether the last step went right /
+//     down (x > lastX, y > lastY).  That is two bits of STATE: the sign (right / down = 1) the walk takes at a
+//     horizontal-edge pixel and the sign it takes at a vertical-edge one.  A step from a horizontal-edge pixel with sign
+//     s leaves (s, dy > 0), one from a vertical-edge pixel (dx > 0, s);
+//   * when a window is fetched, every lane works out FOR ITS PIXEL what a walk standing there in the current state
+//     would do: it compares the three pixels ahead (neighbour values by two DPP row shifts and two ds_bpermute) and
+//     records the step to the winner as a lane offset (dx + 1) + 8 (dy + 1) together with the state after it, or 31
+//     when the reference stops at the image border first, 30 when the three are not all inside the window.  The result
+//     is one `info` word per lane: gradient | direction bit | step << 16 | state after << 21 | the sign the step is
+//     for << 23 | marked << 30 | no gradient << 31;
+//   * inside a window the walk is a walk over LANES: a step reads the current lane's info (v_readlane), checks that the
+//     recorded step is for the sign the state asks for (else: a new window), and adds it to the lane number -- ~25
+//     scalar instructions, no memory access, no coordinates.  The lane it visits notes its place in the order of the visit;
 //   * when the walk leaves the window (or ends), the visited lanes store their pixels at their places of the output
 //     and set their edge marks in the bit plane, all at once.
 __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int lastDirection, uint32_t* __restrict__ out, unsigned base,
@@ -252,10 +348,14 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
     const int lane = (int)(threadIdx.x & 63u), ldx = lane & 7, ldy = lane >> 3;
     int x = __builtin_amdgcn_readfirstlane((int)x0), y = __builtin_amdgcn_readfirstlane((int)y0);
     const int ld = __builtin_amdgcn_readfirstlane(lastDirection);
-    // the walk's direction: its kind (1: right / left) and its sign (1: right / down); bit 1: x > lastX, bit 0: y > lastY of
-    // the reference.  Plain 0 / 1 integers and bit operations: the step stays on the scalar unit
-    uint32_t last_h = (ld & 1) ^ 1, plus = (ld == RightDir || ld == DownDir) ? 1u : 0u;
-    uint32_t went = (x > (int)c.lastX ? 2u : 0u) | (y > (int)c.lastY ? 1u : 0u);
+    // bit 1: the sign at a horizontal-edge pixel, bit 0: at a vertical-edge one.  Plain integers and bit operations: the
+    // step stays on the scalar unit
+    uint32_t st;
+    {
+        const uint32_t plus = (ld == RightDir || ld == DownDir) ? 1u : 0u;
+        const uint32_t went_right = x > (int)c.lastX ? 1u : 0u, went_down = y > (int)c.lastY ? 1u : 0u;
+        st = (ld & 1) == 0 ? (plus << 1) | went_down : (went_right << 1) | plus;
+    }
     unsigned off = off_io;
     int wx0 = 0, wy0 = 0, fx = 0, fy = 0, fgo = 0;
     uint32_t info = 0u;
@@ -274,8 +374,9 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         off += (unsigned)cnt;
         ord = -1; cnt = 0;
     };
-    // a new window for a walk standing at (x, y), of direction (gh, plus)
+    // a new window for a walk standing at (x, y) on a pixel of kind gh (1: horizontal-edge), in state st
     auto fetch = [&](uint32_t gh) {
+        const uint32_t plus = (st >> gh) & 1u;
         const int go = gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir);
         int drift = 0;
         if (go == fgo) drift = gh ? y - fy : x - fx;
@@ -292,57 +393,62 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         v = in ? v : 0u;
         mk = in && mk;
         // the eight neighbours' gradients (as unsigned char, :1607-1609): west | own | east of this row in one word,
-        // then the same word of the rows above and below.  Values from beyond the window's edge are never used (step 7)
+        // then the same word of the rows above and below.  Values from beyond the window's edge are never used (step 30)
         const int g8 = (int)(v & 0xffu);
         const int gW = __builtin_amdgcn_update_dpp(0, g8, 0x111, 0xf, 0xf, true);     // row_shr:1: from lane - 1
         const int gE = __builtin_amdgcn_update_dpp(0, g8, 0x101, 0xf, 0xf, true);     // row_shl:1: from lane + 1
         const int R = gW | (g8 << 8) | (gE << 16);
         const int RN = __builtin_amdgcn_ds_bpermute(((lane - 8) & 63) << 2, R), RS = __builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, R);
-        const int nNW = RN & 0xff, nN = (RN >> 8) & 0xff, nNE = (RN >> 16) & 0xff, nSW = RS & 0xff, nS = (RS >> 8) & 0xff, nSE = (RS >> 16) & 0xff;
         const bool hz = (v & kHorizontal) != 0;
-        // pixels 1 / 2 / 3 ahead: right NE E SE, left NW W SW, down SE S SW, up NE N NW; t = +1: pixel 1 wins, -1: pixel 3
-        const int a1 = hz ? nNE : nSE, a2 = hz ? gE : nS, a3 = hz ? nSE : nSW;
-        const int b1 = hz ? nNW : nNE, b2 = hz ? gW : nN, b3 = hz ? nSW : nNW;
-        const int ta = (a1 >= a2 && a1 >= a3) ? 1 : ((a3 >= a2 && a3 >= a1) ? -1 : 0);
-        const int tb = (b1 >= b2 && b1 >= b3) ? 1 : ((b3 >= b2 && b3 >= b1) ? -1 : 0);
-        // right / left: (+-1, -t); down / up: (t, +-1)
-        const int stepA = hz ? (2 | ((1 - ta) << 2)) : ((1 + ta) | (2 << 2));
-        const int stepB = hz ? (0 | ((1 - tb) << 2)) : ((1 + tb) | (0 << 2));
-        const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
-        const bool brkA = hz ? (x_hi || y_lo || y_hi) : (x_lo || x_hi || y_hi);
-        const bool brkB = hz ? (x_lo || y_lo || y_hi) : (x_lo || x_hi || y_lo);
-        const bool reachA = hz ? (ldx <= 6 && inner_y) : (ldy <= 6 && inner_x);
-        const bool reachB = hz ? (ldx >= 1 && inner_y) : (ldy >= 1 && inner_x);
-        const int fA = brkA ? 3 : (reachA ? stepA : 7), fB = brkB ? 3 : (reachB ? stepB : 7);
-        info = v | ((uint32_t)fA << 16) | ((uint32_t)fB << 20) | (mk ? 1u << 24 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 25 : 0u);
+        const bool sg = ((st >> (hz ? 1 : 0)) & 1u) != 0;       // the sign a walk in this state takes at this pixel
+        // pixels 1 / 2 / 3 ahead: right NE E SE, left NW W SW, down SE S SW, up NE N NW: the row word that holds two or three
+        // of them, then the bytes
+        const int Rrow = hz ? R : (sg ? RS : RN);
+        const int nE = (Rrow >> 16) & 0xff, nM = (Rrow >> 8) & 0xff, nW = Rrow & 0xff;
+        int p1, p2, p3;
+        if (hz) {
+            const int sh = sg ? 16 : 0;                       // the column ahead: east or west
+            p1 = (RN >> sh) & 0xff; p2 = sg ? nE : nW; p3 = (RS >> sh) & 0xff;
+        } else { p1 = nE; p2 = nM; p3 = nW; }
+        const int t = (p1 >= p2 && p1 >= p3) ? 1 : ((p3 >= p2 && p3 >= p1) ? -1 : 0);   // +1: pixel 1 wins, -1: pixel 3
+        // right / left: (+-1, -t); down / up: (t, +-1); the state after: (sign, dy > 0) resp. (dx > 0, sign)
+        const int s2 = sg ? 2 : 0;
+        const int step = hz ? s2 + 8 * (1 - t) : (1 + t) + 8 * s2;
+        const int after = hz ? (sg ? 2 : 0) | (t < 0 ? 1 : 0) : (t > 0 ? 2 : 0) | (sg ? 1 : 0);
+        bool brk = false;
+        if (wx0 <= 0 || wy0 <= 0 || wx0 + 7 >= W - 1 || wy0 + 7 >= H - 1) {       // the window touches the image border
+            const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
+            brk = hz ? ((sg ? x_hi : x_lo) || y_lo || y_hi) : (x_lo || x_hi || (sg ? y_hi : y_lo));
+        }
+        const bool reach = hz ? ((sg ? ldx <= 6 : ldx >= 1) && inner_y) : ((sg ? ldy <= 6 : ldy >= 1) && inner_x);
+        const int fld = brk ? 31 : (reach ? step | (after << 5) : 30);
+        info = v | ((uint32_t)fld << 16) | (sg ? 1u << 23 : 0u) | (mk ? 1u << 30 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 31 : 0u);
     };
-    fetch(last_h);
+    fetch((ld & 1) ^ 1);
     int L = (y - wy0) * 8 + (x - wx0);
     uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
-    while ((s & (3u << 24)) == 0u) {                          // neither marked nor without gradient
+    while ((s >> 30) == 0u) {                                 // neither marked nor without gradient
         const bool here = lane == L;
-        info |= here ? 1u << 24 : 0u;
+        info |= here ? 1u << 30 : 0u;
         ord = here ? cnt : ord;
         ++cnt;
         Lv = L;
-        // the direction: a pixel keeps the walk's direction when it is of its kind, else turns by where the walk came from
         const uint32_t hz = (s >> 15) & 1u;
-        plus ^= (hz ^ last_h) & (plus ^ ((went >> hz) & 1u));
-        last_h = hz;
-        uint32_t f = (s >> (20u - 4u * plus)) & 15u;
-        if ((f & 3u) == 3u) {
-            if (f == 3u) break;                                // the image border ahead (:1583, :1620, ...)
+        uint32_t fld = (s >> 16) & 127u;
+        // the recorded step is for the other sign, or leaves the window, or the image ends
+        if ((((fld & 31u) + 2u) >> 5 | (((s >> 23) ^ (st >> hz)) & 1u)) != 0u) {
+            if ((fld & 31u) == 31u && (((s >> 23) ^ (st >> hz)) & 1u) == 0u) break;      // the image border ahead (:1583, :1620, ...)
             x = wx0 + (L & 7); y = wy0 + (L >> 3);
             retire();
             if (!ok) break;
             fetch(hz);
             L = (y - wy0) * 8 + (x - wx0);
             Lv = L;
-            f = ((uint32_t)__builtin_amdgcn_readlane((int)info, L) >> (20u - 4u * plus)) & 15u;
-            if ((f & 3u) == 3u) break;                         // (cannot happen: the window was placed around the three ahead)
+            fld = ((uint32_t)__builtin_amdgcn_readlane((int)info, L) >> 16) & 127u;
+            if ((fld & 31u) >= 30u) break;                     // the border (30 cannot happen: the window was placed around the three ahead)
         }
-        went = (f & 2u) | (f >> 3);                            // dx + 1 == 2, dy + 1 == 2
-        L += (int)((f & 3u) + ((f & 12u) << 1)) - 9;
+        st = fld >> 5;
+        L += (int)(fld & 31u) - 9;
         s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
     }
     if (Lv >= 0) { c.lastX = (unsigned)(wx0 + (Lv & 7)); c.lastY = (unsigned)(wy0 + (Lv >> 3)); }
