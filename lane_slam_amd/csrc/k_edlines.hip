@@ -202,10 +202,17 @@ __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __
                 }
                 const size_t o = o00 + (size_t)i * W;
                 const uint32_t bl = mid[(i + 1) % 3];
-                if (wide && gx + 3 < W) {
-                    *reinterpret_cast<uint4*>(dxyo + o) = make_uint4(w[0], w[1], w[2], w[3]);
-                    *reinterpret_cast<uint2*>(go + o) = make_uint2(gq[0] | (gq[1] << 16), gq[2] | (gq[3] << 16));
-                    *reinterpret_cast<uint32_t*>(bluro + o) = bl;
+                if (gx + 3 < W) {
+                    if (wide) {
+                        *reinterpret_cast<uint4*>(dxyo + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                        *reinterpret_cast<uint2*>(go + o) = make_uint2(gq[0] | (gq[1] << 16), gq[2] | (gq[3] << 16));
+                        *reinterpret_cast<uint32_t*>(bluro + o) = bl;
+                    } else {                                   // the same stores at addresses that are not multiples of their size
+                        const uint2 g2 = make_uint2(gq[0] | (gq[1] << 16), gq[2] | (gq[3] << 16));
+                        __builtin_memcpy(dxyo + o, w, 16);
+                        __builtin_memcpy(go + o, &g2, 8);
+                        __builtin_memcpy(bluro + o, &bl, 4);
+                    }
                 } else {
                     for (int k = 0; k < 4 && gx + k < W; ++k) { dxyo[o + k] = w[k]; go[o + k] = (uint16_t)gq[k]; bluro[o + k] = (uint8_t)(bl >> (8 * k)); }
                 }
@@ -222,37 +229,74 @@ void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* t
                        blur, dxy, g);
 }
 
-// cv::resize(src, dst, Size(), inv, inv), INTER_LINEAR, u8: 11-bit coefficients from float weights
-__global__ void k_ed_resize(int H, int W, int DH, int DW, double scale, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst)
+// cv::resize(src, dst, Size(), inv, inv), INTER_LINEAR, u8: 11-bit coefficients from float weights.  The coefficient
+// tables -- per destination column (source column, its right neighbour, the two weights), per destination row (offsets of
+// the two source rows, the two weights) -- depend on the sizes alone: the host computes them once per octave
+// (ed_resize_tables, the reference's arithmetic) and the kernel is integer work: a thread makes four adjacent pixels of
+// RS_ROWS rows and stores each row's four bytes as one dword.
+void ed_resize_tables(int H, int W, int DH, int DW, double scale, int* tab)
 {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= DW) return;
-    const uint8_t* S = src + (size_t)blockIdx.z * H * W;
-    float fx = (float)(((double)dx + 0.5) * scale - 0.5);
-    int sx = dm::ifloor((double)fx);
-    fx -= (float)sx;
-    if (sx < 0) { fx = 0.f; sx = 0; }
-    if (sx >= W - 1) { fx = 0.f; sx = W - 1; }
-    const int a0 = dm::round_half_even((double)((1.f - fx) * 2048.f)), a1 = dm::round_half_even((double)(fx * 2048.f));
-    float fy = (float)(((double)dy + 0.5) * scale - 0.5);
-    const int sy = dm::ifloor((double)fy);
-    fy -= (float)sy;
-    const int b0 = dm::round_half_even((double)((1.f - fy) * 2048.f)), b1 = dm::round_half_even((double)(fy * 2048.f));
-    int y0 = sy, y1 = sy + 1;
-    y0 = y0 >= 0 ? (y0 < H ? y0 : H - 1) : 0;
-    y1 = y1 >= 0 ? (y1 < H ? y1 : H - 1) : 0;
-    const int sx1 = sx + 1 < W ? sx + 1 : sx;
-    const int S0 = (int)S[(size_t)y0 * W + sx] * a0 + (int)S[(size_t)y0 * W + sx1] * a1;
-    const int S1 = (int)S[(size_t)y1 * W + sx] * a0 + (int)S[(size_t)y1 * W + sx1] * a1;
-    int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
-    v = v < 0 ? 0 : (v > 255 ? 255 : v);
-    dst[((size_t)blockIdx.z * DH + dy) * DW + dx] = (uint8_t)v;
+    for (int dx = 0; dx < DW; ++dx) {
+        float fx = (float)(((double)dx + 0.5) * scale - 0.5);
+        int x = dm::ifloor((double)fx);
+        fx -= (float)x;
+        if (x < 0) { fx = 0.f; x = 0; }
+        if (x >= W - 1) { fx = 0.f; x = W - 1; }
+        int* t = tab + 4 * dx;
+        t[0] = x; t[1] = x + 1 < W ? x + 1 : x;
+        t[2] = dm::round_half_even((double)((1.f - fx) * 2048.f)); t[3] = dm::round_half_even((double)(fx * 2048.f));
+    }
+    for (int dy = 0; dy < DH; ++dy) {
+        float fy = (float)(((double)dy + 0.5) * scale - 0.5);
+        const int sy = dm::ifloor((double)fy);
+        fy -= (float)sy;
+        int y0 = sy, y1 = sy + 1;
+        y0 = y0 >= 0 ? (y0 < H ? y0 : H - 1) : 0;
+        y1 = y1 >= 0 ? (y1 < H ? y1 : H - 1) : 0;
+        int* t = tab + 4 * (DW + dy);
+        t[0] = y0 * W; t[1] = y1 * W;
+        t[2] = dm::round_half_even((double)((1.f - fy) * 2048.f)); t[3] = dm::round_half_even((double)(fy * 2048.f));
+    }
 }
 
-void launch_ed_resize(int H, int W, int DH, int DW, double scale, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s)
+constexpr int RS_ROWS = 4, RS_THREADS = 128;
+__global__ __launch_bounds__(RS_THREADS) void k_ed_resize(int H, int W, int DH, int DW, const int4* __restrict__ tab, const uint8_t* __restrict__ src,
+                                                          uint8_t* __restrict__ dst)
 {
-    dim3 grid((DW + 255) / 256, DH, n_frames);
-    hipLaunchKernelGGL(k_ed_resize, grid, dim3(256), 0, s, H, W, DH, DW, scale, src, dst);
+    const int tid = threadIdx.x, dy0 = blockIdx.y * RS_ROWS;
+    const int dx0 = (blockIdx.x * RS_THREADS + tid) * 4;
+    if (dx0 >= DW) return;
+    int4 cx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cx[k] = tab[dx0 + k < DW ? dx0 + k : DW - 1];
+    const uint8_t* S = src + (size_t)blockIdx.z * H * W;
+    uint8_t* D = dst + (size_t)blockIdx.z * DH * DW;
+    const int rows = DH - dy0 < RS_ROWS ? DH - dy0 : RS_ROWS;
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+        if (r >= rows) break;
+        const int4 cy = tab[DW + dy0 + r];                     // (wave-uniform: a scalar load)
+        const uint8_t* p0 = S + cy.x;
+        const uint8_t* p1 = S + cy.y;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int S0 = (int)p0[cx[k].x] * cx[k].z + (int)p0[cx[k].y] * cx[k].w;
+            const int S1 = (int)p1[cx[k].x] * cx[k].z + (int)p1[cx[k].y] * cx[k].w;
+            int v = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            out |= (uint32_t)v << (8 * k);
+        }
+        uint8_t* q = D + (size_t)(dy0 + r) * DW + dx0;
+        if (dx0 + 3 < DW) __builtin_memcpy(q, &out, 4);             // (rows of an octave image are not dword-aligned)
+        else for (int k = 0; k < 4 && dx0 + k < DW; ++k) q[k] = (uint8_t)(out >> (8 * k));
+    }
+}
+
+void launch_ed_resize(int H, int W, int DH, int DW, const int* tab, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s)
+{
+    dim3 grid((DW + 4 * RS_THREADS - 1) / (4 * RS_THREADS), (DH + RS_ROWS - 1) / RS_ROWS, n_frames);
+    hipLaunchKernelGGL(k_ed_resize, grid, dim3(RS_THREADS), 0, s, H, W, DH, DW, reinterpret_cast<const int4*>(tab), src, dst);
 }
 
 // cv::pyrDown u8 -> (H/2, W/2): [1 4 6 4 1]^2, (sum + 128) >> 8, BORDER_REFLECT_101 (compute-only pyramid, :350-371)
