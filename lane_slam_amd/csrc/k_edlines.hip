@@ -6,21 +6,30 @@
 // re-designed for the MI355X; oracle/lf_oracle_edlines.c is the sequential statement these kernels are held to, bit
 // for bit (tests/test_gpu_edlines.py).
 //
-//   k_ed_grad     streaming, one 64x16 tile per workgroup: 5x5 fixed-point Gaussian (taps from the host) -> blurred u8
+//   k_ed_grad     streaming, one 64x64 tile per workgroup, built like k_lbd_grad (four pixels per lane, packed 16-bit
+//                 filters, v_dot2 column filter) with the octave's run-time taps: 5x5 fixed-point Gaussian -> blurred u8
 //                 plane (the next octave is resized from it), Sobel 3x3 -> dx | dy << 16 per pixel (the plane k_lbd
 //                 gathers from: the descriptor of a detected line uses the DETECTOR's gradients, :1079-1090), and the
 //                 thresholded gradient / 4 (round half to even) with the pixel's direction in bit 15 (u16 plane).
 //                 HBM bound: reads P, writes P + 4P + 2P.
-//   k_ed_resize   cv::resize INTER_LINEAR by 1/sqrt 2 on u8 (11-bit fixed-point weights), one thread per pixel.
-//   k_ed_detect   one workgroup per (frame, octave).  Anchors: every wave tests candidates row-major (coalesced) into a
-//                 bit plane in LDS indexed COLUMN-major -- the order the reference scans them in, which decides which
-//                 anchor draws which edge -- then a ballot / prefix pass lists them.  Smart routing is sequential by
-//                 definition (a walk stops at pixels earlier walks marked): ONE wave walks, edge marks are a bit plane
-//                 in LDS (global memory for octave images beyond the LDS budget), the chain is assembled in place
-//                 (first part reversed by all 64 lanes, second part written behind it as it is walked).  Line fitting
-//                 then runs on the same wave, chain by chain: the 64 lanes take the pixels of a run at once (distance
-//                 tests by ballot and bit tricks, exact integer sums for the normal equations, ordered f64 sums where
-//                 the reference's order matters), one lane-uniform evaluation of the NFA.
+//   k_ed_resize   cv::resize INTER_LINEAR by 1/sqrt 2 on u8 (11-bit fixed-point weights from host-made tables), four
+//                 pixels x four rows per thread.
+//   k_ed_detect   one 512-thread workgroup per (frame, octave), three phases:
+//                 ANCHORS by all waves: candidates tested row-major (coalesced, eight in flight per thread) into a bit
+//                 plane in LDS indexed COLUMN-major -- the order the reference scans them in, which decides which anchor
+//                 draws which edge -- then a ballot / prefix pass lists them.
+//                 SMART ROUTING on ONE wave (sequential by definition: a walk stops at pixels earlier walks marked).  A
+//                 lone wave pays ~13 cycles per dependent scalar instruction and 25 - 45 per taken branch (tools/probe/
+//                 lone_wave_issue.hip), so the walk is organised to execute few of them: the wave holds an 8x8 window of
+//                 the gradient plane, every lane precomputes the step a walk standing on its pixel would take, and the walk
+//                 itself is a loop over lane numbers (ed_walk below); edge marks are a bit plane in LDS (global memory for
+//                 octave images beyond the LDS budget), the chain is assembled in place (first part reversed by all 64
+//                 lanes, second part written behind it as it is walked).
+//                 LINE FITTING on ALL waves: the chains are independent, every wave takes the next one from a shared
+//                 counter; the 64 lanes take the pixels of a run at once (distance tests by ballot and bit tricks, exact
+//                 integer sums for the normal equations, ordered f64 sums where the reference's order matters), one
+//                 lane-uniform evaluation of the NFA; lines go to temporary records and are put in chain order at the end,
+//                 where the reference's running "too many lines" test is applied to the per-chain counts.
 //   k_kl_assemble one workgroup per frame: groups the octaves' lines (each line of octave o against all lines of the
 //                 octaves below, lanes = lines), orders KeyLines by (class, octave) and fills the output rows.
 #include "common.h"
@@ -53,6 +62,9 @@ __device__ __forceinline__ int ed_div4_half_even(int v)
 // two more planes are written -- the blurred image (the next octave is resized from it) and the thresholded gradient
 // magnitude / 4 (round half to even) with the direction in bit 15.  The blurred ring outside the image is the blur of the
 // reflected source, which for a symmetric kernel IS the reflected blurred image the Sobel's BORDER_REFLECT_101 asks for.
+// PACKED: the taps sum to <= 257, so a row sum (<= 255 * 257 = 65 535) fits 16 bits.  Rounding can make them sum to 258
+// (sigma sqrt 2, the third octave: 29 61 78 61 29) -- those octaves take the copy with 32-bit row sums.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __restrict__ src, int t0, int t1, int t2, int t3, int t4,
                                                  int grad_threshold, uint8_t* __restrict__ bluro, uint32_t* __restrict__ dxyo,
                                                  uint16_t* __restrict__ go)
@@ -61,7 +73,7 @@ __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __
     constexpr int RW = 68, RG = RW / 4;              // row-filtered: 66 columns used (x0-1 .. x0+64)
     constexpr int BW_ = 72, BH = ET_H + 2;           // blurred: column c <-> x0-1+c, 66 used
     __shared__ __attribute__((aligned(16))) uint8_t gray[GH * GW];
-    __shared__ __attribute__((aligned(16))) uint32_t rowp[(GH / 2) * RW];   // (row 2m, row 2m + 1) per column, 16 bits each
+    __shared__ __attribute__((aligned(16))) uint32_t rowp[PACKED ? (GH / 2) * RW : GH * RW];   // PACKED: (row 2m, row 2m + 1) per column, 16 bits each; else a row sum per word
     __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
     int tbx, tby, f;
     lf_xcd_tile(tbx, tby, f);
@@ -94,64 +106,98 @@ __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __
         }
     }
     __syncthreads();
-    // horizontal 5-tap: outputs c..c+3 (c = 4g) need gray[c .. c+7] = two dwords; the same four columns of two consecutive rows
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    const us2 c0 = { (unsigned short)t0, (unsigned short)t0 }, c1 = { (unsigned short)t1, (unsigned short)t1 }, c2 = { (unsigned short)t2, (unsigned short)t2 },
-              c3 = { (unsigned short)t3, (unsigned short)t3 }, c4 = { (unsigned short)t4, (unsigned short)t4 };
-    for (int idx = tid; idx < (GH / 2) * RG; idx += 256) {
-        const int m = idx / RG, g = idx - m * RG;
-        uint32_t o02[2], o13[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const uint32_t* sp = reinterpret_cast<const uint32_t*>(gray + (2 * m + r) * GW + 4 * g);
-            const uint32_t lo = sp[0], hi = sp[1];
-            const us2 E = __builtin_bit_cast(us2, lo & 0x00ff00ffu), O = __builtin_bit_cast(us2, (lo >> 8) & 0x00ff00ffu);
-            const us2 E2 = __builtin_bit_cast(us2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(us2, (hi >> 8) & 0x00ff00ffu);
-            const us2 P24 = { E.y, E2.x }, P35 = { O.y, O2.x };
-            o02[r] = __builtin_bit_cast(uint32_t, c0 * E + c1 * O + c2 * P24 + c3 * P35 + c4 * E2);      // (out0, out2)
-            o13[r] = __builtin_bit_cast(uint32_t, c0 * O + c1 * P24 + c2 * P35 + c3 * E2 + c4 * O2);     // (out1, out3)
+    if constexpr (PACKED) {
+        // horizontal 5-tap: outputs c..c+3 (c = 4g) need gray[c .. c+7] = two dwords; the same four columns of two consecutive rows
+        const us2 c0 = { (unsigned short)t0, (unsigned short)t0 }, c1 = { (unsigned short)t1, (unsigned short)t1 }, c2 = { (unsigned short)t2, (unsigned short)t2 },
+                  c3 = { (unsigned short)t3, (unsigned short)t3 }, c4 = { (unsigned short)t4, (unsigned short)t4 };
+        for (int idx = tid; idx < (GH / 2) * RG; idx += 256) {
+            const int m = idx / RG, g = idx - m * RG;
+            uint32_t o02[2], o13[2];
+    #pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint32_t* sp = reinterpret_cast<const uint32_t*>(gray + (2 * m + r) * GW + 4 * g);
+                const uint32_t lo = sp[0], hi = sp[1];
+                const us2 E = __builtin_bit_cast(us2, lo & 0x00ff00ffu), O = __builtin_bit_cast(us2, (lo >> 8) & 0x00ff00ffu);
+                const us2 E2 = __builtin_bit_cast(us2, hi & 0x00ff00ffu), O2 = __builtin_bit_cast(us2, (hi >> 8) & 0x00ff00ffu);
+                const us2 P24 = { E.y, E2.x }, P35 = { O.y, O2.x };
+                o02[r] = __builtin_bit_cast(uint32_t, c0 * E + c1 * O + c2 * P24 + c3 * P35 + c4 * E2);      // (out0, out2)
+                o13[r] = __builtin_bit_cast(uint32_t, c0 * O + c1 * P24 + c2 * P35 + c3 * E2 + c4 * O2);     // (out1, out3)
+            }
+            const uint4 q = make_uint4(__builtin_amdgcn_perm(o02[1], o02[0], 0x05040100u), __builtin_amdgcn_perm(o13[1], o13[0], 0x05040100u),
+                                       __builtin_amdgcn_perm(o02[1], o02[0], 0x07060302u), __builtin_amdgcn_perm(o13[1], o13[0], 0x07060302u));
+            *reinterpret_cast<uint4*>(rowp + m * RW + 4 * g) = q;
         }
-        const uint4 q = make_uint4(__builtin_amdgcn_perm(o02[1], o02[0], 0x05040100u), __builtin_amdgcn_perm(o13[1], o13[0], 0x05040100u),
-                                   __builtin_amdgcn_perm(o02[1], o02[0], 0x07060302u), __builtin_amdgcn_perm(o13[1], o13[0], 0x07060302u));
-        *reinterpret_cast<uint4*>(rowp + m * RW + 4 * g) = q;
+    } else {
+        // the same with one 32-bit sum per pixel
+        const uint32_t t[5] = { (uint32_t)t0, (uint32_t)t1, (uint32_t)t2, (uint32_t)t3, (uint32_t)t4 };
+        for (int idx = tid; idx < GH * RG; idx += 256) {
+            const int r = idx / RG, g = idx - r * RG;
+            const uint32_t* sp = reinterpret_cast<const uint32_t*>(gray + r * GW + 4 * g);
+            const uint32_t lo = sp[0], hi = sp[1];
+            uint32_t bt[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { bt[k] = (lo >> (8 * k)) & 0xffu; bt[4 + k] = (hi >> (8 * k)) & 0xffu; }
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = t[0] * bt[k] + t[1] * bt[k + 1] + t[2] * bt[k + 2] + t[3] * bt[k + 3] + t[4] * bt[k + 4];
+            *reinterpret_cast<uint4*>(rowp + r * RW + 4 * g) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     }
     __syncthreads();
-    // vertical 5-tap, (acc + 2^15) >> 16, saturate -> blurred u8: rows 2m and 2m + 1 from the pairs m, m + 1, m + 2
-    {
-        constexpr int VPAIRS = 3, VSEG = (BH / 2 + VPAIRS - 1) / VPAIRS;
-        static_assert(VSEG * RG <= 256, "one lane per (column group, segment)");
-        const us2 k01 = { (unsigned short)t0, (unsigned short)t1 }, k23 = { (unsigned short)t2, (unsigned short)t3 }, k4_ = { (unsigned short)t4, 0 };
-        const us2 k_0 = { 0, (unsigned short)t0 }, k12 = { (unsigned short)t1, (unsigned short)t2 }, k34 = { (unsigned short)t3, (unsigned short)t4 };
-        const int g = tid % RG, seg = tid / RG;
-        if (seg < VSEG) {
-            const int m0 = seg * VPAIRS;
-            uint4 Pp[3];
-            auto fetch = [&](int m) { return *reinterpret_cast<const uint4*>(rowp + (m < GH / 2 ? m : GH / 2 - 1) * RW + 4 * g); };
-            Pp[0] = fetch(m0); Pp[1] = fetch(m0 + 1);
-#pragma unroll
-            for (int i = 0; i < VPAIRS; ++i) {
-                const int m = m0 + i;
-                Pp[(i + 2) % 3] = fetch(m + 2);
-                if (2 * m < BH) {
-                    const uint4 A = Pp[i % 3], B = Pp[(i + 1) % 3], C = Pp[(i + 2) % 3];
-                    const uint32_t a[4] = { A.x, A.y, A.z, A.w }, bb[4] = { B.x, B.y, B.z, B.w }, cc[4] = { C.x, C.y, C.z, C.w };
-                    uint32_t even = 0, odd = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        uint32_t e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), k01, 1u << 15, false);
-                        e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), k23, e, false);
-                        e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), k4_, e, false);
-                        uint32_t o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), k_0, 1u << 15, false);
-                        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), k12, o, false);
-                        o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), k34, o, false);
-                        e >>= 16; o >>= 16;
-                        even |= (e > 255u ? 255u : e) << (8 * k);
-                        odd |= (o > 255u ? 255u : o) << (8 * k);
+    if constexpr (PACKED) {
+        // vertical 5-tap, (acc + 2^15) >> 16, saturate -> blurred u8: rows 2m and 2m + 1 from the pairs m, m + 1, m + 2
+        {
+            constexpr int VPAIRS = 3, VSEG = (BH / 2 + VPAIRS - 1) / VPAIRS;
+            static_assert(VSEG * RG <= 256, "one lane per (column group, segment)");
+            const us2 k01 = { (unsigned short)t0, (unsigned short)t1 }, k23 = { (unsigned short)t2, (unsigned short)t3 }, k4_ = { (unsigned short)t4, 0 };
+            const us2 k_0 = { 0, (unsigned short)t0 }, k12 = { (unsigned short)t1, (unsigned short)t2 }, k34 = { (unsigned short)t3, (unsigned short)t4 };
+            const int g = tid % RG, seg = tid / RG;
+            if (seg < VSEG) {
+                const int m0 = seg * VPAIRS;
+                uint4 Pp[3];
+                auto fetch = [&](int m) { return *reinterpret_cast<const uint4*>(rowp + (m < GH / 2 ? m : GH / 2 - 1) * RW + 4 * g); };
+                Pp[0] = fetch(m0); Pp[1] = fetch(m0 + 1);
+    #pragma unroll
+                for (int i = 0; i < VPAIRS; ++i) {
+                    const int m = m0 + i;
+                    Pp[(i + 2) % 3] = fetch(m + 2);
+                    if (2 * m < BH) {
+                        const uint4 A = Pp[i % 3], B = Pp[(i + 1) % 3], C = Pp[(i + 2) % 3];
+                        const uint32_t a[4] = { A.x, A.y, A.z, A.w }, bb[4] = { B.x, B.y, B.z, B.w }, cc[4] = { C.x, C.y, C.z, C.w };
+                        uint32_t even = 0, odd = 0;
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            uint32_t e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), k01, 1u << 15, false);
+                            e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), k23, e, false);
+                            e = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), k4_, e, false);
+                            uint32_t o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, a[k]), k_0, 1u << 15, false);
+                            o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, bb[k]), k12, o, false);
+                            o = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, cc[k]), k34, o, false);
+                            e >>= 16; o >>= 16;
+                            even |= (e > 255u ? 255u : e) << (8 * k);
+                            odd |= (o > 255u ? 255u : o) << (8 * k);
+                        }
+                        *reinterpret_cast<uint32_t*>(blur + (2 * m) * BW_ + 4 * g) = even;
+                        *reinterpret_cast<uint32_t*>(blur + (2 * m + 1) * BW_ + 4 * g) = odd;
                     }
-                    *reinterpret_cast<uint32_t*>(blur + (2 * m) * BW_ + 4 * g) = even;
-                    *reinterpret_cast<uint32_t*>(blur + (2 * m + 1) * BW_ + 4 * g) = odd;
                 }
             }
+        }
+    } else {
+        const uint32_t t[5] = { (uint32_t)t0, (uint32_t)t1, (uint32_t)t2, (uint32_t)t3, (uint32_t)t4 };
+        for (int idx = tid; idx < BH * RG; idx += 256) {
+            const int r = idx / RG, g = idx - r * RG;
+            uint32_t acc[4] = { 1u << 15, 1u << 15, 1u << 15, 1u << 15 };
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const uint4 q = *reinterpret_cast<const uint4*>(rowp + (r + j) * RW + 4 * g);
+                acc[0] += t[j] * q.x; acc[1] += t[j] * q.y; acc[2] += t[j] * q.z; acc[3] += t[j] * q.w;
+            }
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const uint32_t e = acc[k] >> 16; out |= (e > 255u ? 255u : e) << (8 * k); }
+            *reinterpret_cast<uint32_t*>(blur + r * BW_ + 4 * g) = out;
         }
     }
     __syncthreads();
@@ -225,8 +271,11 @@ void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* t
                     uint32_t* dxy, uint16_t* g, hipStream_t s)
 {
     dim3 grid((W + ET_W - 1) / ET_W, (H + ET_H - 1) / ET_H, n_frames);
-    hipLaunchKernelGGL(k_ed_grad, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold,
-                       blur, dxy, g);
+    const int sum = taps5[0] + taps5[1] + taps5[2] + taps5[3] + taps5[4];
+    if (sum <= 257)
+        hipLaunchKernelGGL(k_ed_grad<true>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g);
+    else
+        hipLaunchKernelGGL(k_ed_grad<false>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g);
 }
 
 // cv::resize(src, dst, Size(), inv, inv), INTER_LINEAR, u8: 11-bit coefficients from float weights.  The coefficient

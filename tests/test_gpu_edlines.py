@@ -116,6 +116,9 @@ def test_keylines_on_clutter_shapes_and_real_frames(golden_dir):
     imgs.append(sq)
     imgs.append(np.full((rows, cols), 99, np.uint8))                                                      # nothing at all
     imgs.append((np.hypot(xx - 300, yy - 150) < 100).astype(np.uint8) * 180 + 30)                         # a disc: chains that turn
+    # saturated white against black: the third octave's taps (29 61 78 61 29) sum to 258, so a row sum over five 255s is
+    # 65 790 -- one more bit than the packed 16-bit filter of k_ed_grad holds (it must take its wide path there)
+    imgs.append(np.where(((xx // 40) + (yy // 30)) % 2 == 0, 255, 0).astype(np.uint8))
     real = np.load(os.path.join(golden_dir, "real_frames.npz"))
     o = O.Oracle(cfg)
     for name in real.files:
