@@ -676,7 +676,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
 {
     extern __shared__ uint32_t lds[];
     __shared__ int s_wave_count[ED_WAVES];
-    __shared__ int s_base, s_edges, s_fail, s_next_edge, s_temp_next, s_total;
+    __shared__ int s_base, s_edges, s_walked, s_fail, s_next_edge, s_temp_next, s_total;
     const int oc = blockIdx.y, f = blockIdx.x;
     const EdOct& o = all.o[oc];
     const int W = o.W, H = o.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
     int* cnt = o.counts + 4 * (size_t)f;
     for (int i = tid; i < 3 * n_cwords; i += ED_THREADS) flags[i] = 0u;
     for (int i = tid; i < n_mwords; i += ED_THREADS) marks[i] = 0u;
-    if (tid == 0) s_base = 0;
+    if (tid == 0) { s_base = 0; s_edges = 0; s_walked = 0; s_fail = 0; s_next_edge = 0; s_temp_next = 0; }
     __syncthreads();
     // ---- anchors (:1504-1532): tested row-major, recorded column-major.  All five loads of a candidate are issued
     // whatever its direction, eight candidates per thread in flight: the phase is bound by the latency of the plane
@@ -792,36 +792,48 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
                 cpos += lenF + lenS - 1;
                 offF = nF; offS = nS;
                 ++ps;
+                sid[ps] = cpos;
+                // the chain is complete: the fitting waves may have it
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __hip_atomic_store(&s_edges, (int)ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (!st && ps > (unsigned)o.max_edges) st = 2;
         }
         if (!st) sid[ps] = cpos;
-        if (lane == 0) { s_edges = st ? 0 : (int)ps; s_fail = st; s_next_edge = 0; s_temp_next = 0; }
-    }
-    __syncthreads();
-    if (s_fail) {
-        if (tid == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = s_fail; }
-        return;
+        __hip_atomic_store(&s_fail, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __hip_atomic_store(&s_walked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // ================= EDline (:2242-2482): the chains are independent -- every wave takes the next one =================
-    // A wave appends its lines to the frame's temporary records as it validates them and notes, per chain, how many it
-    // kept and how many it had kept when it last set out on a line (what the reference's "too many lines" test looks
-    // at); the records are put in chain order afterwards.
+    // ... WHILE the first wave is still walking: a chain is published (s_edges) as soon as it is complete, the other seven
+    // waves fit it, and the walking wave joins them when it is done.  A wave appends its lines to the frame's temporary
+    // records as it validates them and notes, per chain, how many it kept and how many it had kept when it last set out
+    // on a line (what the reference's "too many lines" test looks at); the records are put in chain order afterwards.
     const uint32_t* dxy = o.dxy + (size_t)f * P;
-    const int n_edges = __builtin_amdgcn_readfirstlane(s_edges);
     const int minLen = fp.min_line_len;
     const double thr = fp.fit_err;
     const double logNT = 2.0 * (dm::dlog10((double)(unsigned)W) + dm::dlog10((double)(unsigned)H));
-    const unsigned limit = min(5u * (unsigned)n_edges, (unsigned)o.max_lines);
     const EdTemp tl(o.tl + (size_t)f * o.tl_stride, o.max_lines);
-    int* e_kept = (int*)part;                                // the first-part scratch is free now: per chain lines kept,
-    int* e_last = e_kept + n_edges;                          // lines kept before the last line was begun (-1: none begun),
-    int* e_base = e_last + n_edges;                          // index of the chain's first line in the frame
+    int* e_kept = o.ework + (size_t)f * 3 * (o.max_edges + 2);   // per chain: lines kept,
+    int* e_last = e_kept + (o.max_edges + 2);                 // lines kept before the last line was begun (-1: none begun),
+    int* e_base = e_last + (o.max_edges + 2);                 // index of the chain's first line in the frame
     for (;;) {
         int edgeID = 0;
         if (lane == 0) edgeID = atomicAdd(&s_next_edge, 1);
         edgeID = __builtin_amdgcn_readfirstlane(edgeID);
-        if (edgeID >= n_edges) break;
+        // until the chain is published, or the walk is over without it
+        int ready;
+        for (;;) {
+            ready = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (edgeID < ready) break;
+            if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) {
+                ready = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&s_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (edgeID >= ready) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         unsigned S = (unsigned)__builtin_amdgcn_readfirstlane((int)sid[edgeID]);
         const unsigned E = (unsigned)__builtin_amdgcn_readfirstlane((int)sid[edgeID + 1]);
         int kept = 0, kept_at_last = -1;
@@ -978,6 +990,13 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
         e_kept[edgeID] = kept; e_last[edgeID] = kept_at_last;
     }
     __syncthreads();
+    if (s_fail) {
+        if (tid == 0) { cnt[0] = n_anchors; cnt[1] = -1; cnt[2] = 0; cnt[3] = s_fail; }
+        return;
+    }
+    const int n_edges = __builtin_amdgcn_readfirstlane(s_edges);
+    const unsigned limit = min(5u * (unsigned)n_edges, (unsigned)o.max_lines);
+    __syncthreads();                                          // (s_fail is written again below)
     // ---- chain order: where each chain's lines start; the reference's test of the running count (:2290)
     if (wave == 0) {
         int run = 0;

@@ -25,6 +25,7 @@ struct EdOct {
     float* l_sal;          // [B][max_lines]
     uint8_t* tl;           // [B][tl_stride] the line records in the order the fitting waves finish them (EdTemp)
     size_t tl_stride;      // bytes per frame: max_lines * 48 (8 + 16 + 5 * 4, rounded up to 8)
+    int* ework;            // [B][3][max_edges + 2] per chain: lines kept, lines kept before the last one was begun, first line's index
 };
 
 struct EdAll { EdOct o[LF_MAX_OCTAVES]; };
