@@ -407,34 +407,40 @@ struct EdWalk {
     const uint16_t* g; EdMarks marks;
     int W, H;
     unsigned lastX, lastY;
+    int wx0, wy0;           // the window the last walk ended in (an anchor's second walk starts in its first walk's window
+    uint32_t info;          //   when that walk never left it: most walks are a few pixels long)
+    bool have;
 };
 
 // one walk of the smart routing (:1577-1720 and its three copies), executed uniformly by the wave; pixels go to out[]
 // from off on (packed x | y << 16).  Returns false when the part array would overflow.
 //
 // The walk is a chain of dependent decisions, one pixel per step, and ONE wave per frame executes it: what it costs is
-// the number of instructions per step (a lone wave issues one every ~10 cycles) and the round trips to the gradient
-// plane.  Both are taken out of the step:
+// the number of instructions per step (a lone wave pays 13 cycles per dependent scalar instruction, 5 per vector one, 25 -
+// 45 per taken branch: tools/probe/lone_wave_issue.hip) and the round trips to the gradient plane.  Both are taken out
+// of the step:
 //   * the wave keeps an 8 x 8 WINDOW of the plane, one pixel per lane (lane = row * 8 + column), placed so that the
 //     walk runs into it -- one column / row behind the current pixel, six ahead, shifted sideways when the last window
-//     was left sideways;
+//     was left sideways; an anchor's FIRST walk starts in the middle of its window (three behind, four ahead), so that
+//     the second walk, which leaves the anchor the other way, can start in the same window;
 //   * the reference's direction logic needs, at a pixel, the walk's direction and whether the last step went right /
 //     down (x > lastX, y > lastY).  That is two bits of STATE: the sign (right / down = 1) the walk takes at a
 //     horizontal-edge pixel and the sign it takes at a vertical-edge one.  A step from a horizontal-edge pixel with sign
 //     s leaves (s, dy > 0), one from a vertical-edge pixel (dx > 0, s);
-//   * when a window is fetched, every lane works out FOR ITS PIXEL what a walk standing there in the current state
-//     would do: it compares the three pixels ahead (neighbour values by two DPP row shifts and two ds_bpermute) and
-//     records the step to the winner as a lane offset (dx + 1) + 8 (dy + 1) together with the state after it, or 31
-//     when the reference stops at the image border first, 30 when the three are not all inside the window.  The result
-//     is one `info` word per lane: gradient | direction bit | step << 16 | state after << 21 | the sign the step is
-//     for << 23 | marked << 30 | no gradient << 31;
-//   * inside a window the walk is a walk over LANES: a step reads the current lane's info (v_readlane), checks that the
-//     recorded step is for the sign the state asks for (else: a new window), and adds it to the lane number -- ~25
-//     scalar instructions, no memory access, no coordinates.  The lane it visits notes its place in the order of the visit;
+//   * when a window is fetched, every lane works out FOR ITS PIXEL what a walk standing there would do, for both signs:
+//     it compares the three pixels ahead (neighbour values by two DPP row shifts and two ds_bpermute) and records the
+//     step to the winner as a lane offset (dx + 1) + 8 (dy + 1) together with the state after it, or 31 when the
+//     reference stops at the image border first, 30 when the three are not all inside the window.  The result is one
+//     `info` word per lane: gradient | direction bit | (step | state after << 5) for + << 16, for - << 23 |
+//     marked << 30 | no gradient << 31;
+//   * inside a window the walk is a walk over LANES: a step reads the current lane's info (v_readlane), picks the
+//     record of the sign the state asks for, and adds the step to the lane number -- ~25 scalar instructions, no memory
+//     access, no coordinates.  The lane it visits notes its place in the order of the visit;
 //   * when the walk leaves the window (or ends), the visited lanes store their pixels at their places of the output
 //     and set their edge marks in the bit plane, all at once.
-__device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int lastDirection, uint32_t* __restrict__ out, unsigned base,
-                                        unsigned& off_io, unsigned cap)
+// first: an anchor's first walk (its window is centred); else the walk may start in the window c holds.
+__device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int lastDirection, bool first, uint32_t* __restrict__ out,
+                                        unsigned base, unsigned& off_io, unsigned cap)
 {
     const int W = c.W, H = c.H;
     const uint16_t* pg = c.g;
@@ -450,8 +456,8 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         st = (ld & 1) == 0 ? (plus << 1) | went_down : (went_right << 1) | plus;
     }
     unsigned off = off_io;
-    int wx0 = 0, wy0 = 0, fx = 0, fy = 0, fgo = 0;
-    uint32_t info = 0u;
+    int wx0 = c.wx0, wy0 = c.wy0, fx = 0, fy = 0, fgo = 0;
+    uint32_t info = c.info;
     int ord = -1, cnt = 0;                                  // this lane's place in the visit of the window; pixels visited in it
     int Lv = -1;                                            // the lane visited last
     bool ok = true;
@@ -468,13 +474,13 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         ord = -1; cnt = 0;
     };
     // a new window for a walk standing at (x, y) on a pixel of kind gh (1: horizontal-edge), in state st
-    auto fetch = [&](uint32_t gh) {
+    auto fetch = [&](uint32_t gh, bool centred) {
         const uint32_t plus = (st >> gh) & 1u;
         const int go = gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir);
         int drift = 0;
         if (go == fgo) drift = gh ? y - fy : x - fx;
         const int side = drift >= 2 ? 1 : (drift <= -2 ? 6 : 3);
-        const int back = plus ? 1 : 6;
+        const int back = centred ? (plus ? 3 : 4) : (plus ? 1 : 6);
         wx0 = x - (gh ? back : side);
         wy0 = y - (gh ? side : back);
         fx = x; fy = y; fgo = go;
@@ -492,34 +498,47 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         const int gE = __builtin_amdgcn_update_dpp(0, g8, 0x101, 0xf, 0xf, true);     // row_shl:1: from lane + 1
         const int R = gW | (g8 << 8) | (gE << 16);
         const int RN = __builtin_amdgcn_ds_bpermute(((lane - 8) & 63) << 2, R), RS = __builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, R);
+        const int nNW = RN & 0xff, nN = (RN >> 8) & 0xff, nNE = (RN >> 16) & 0xff, nSW = RS & 0xff, nS = (RS >> 8) & 0xff, nSE = (RS >> 16) & 0xff;
         const bool hz = (v & kHorizontal) != 0;
-        const bool sg = ((st >> (hz ? 1 : 0)) & 1u) != 0;       // the sign a walk in this state takes at this pixel
-        // pixels 1 / 2 / 3 ahead: right NE E SE, left NW W SW, down SE S SW, up NE N NW: the row word that holds two or three
-        // of them, then the bytes
-        const int Rrow = hz ? R : (sg ? RS : RN);
-        const int nE = (Rrow >> 16) & 0xff, nM = (Rrow >> 8) & 0xff, nW = Rrow & 0xff;
-        int p1, p2, p3;
-        if (hz) {
-            const int sh = sg ? 16 : 0;                       // the column ahead: east or west
-            p1 = (RN >> sh) & 0xff; p2 = sg ? nE : nW; p3 = (RS >> sh) & 0xff;
-        } else { p1 = nE; p2 = nM; p3 = nW; }
-        const int t = (p1 >= p2 && p1 >= p3) ? 1 : ((p3 >= p2 && p3 >= p1) ? -1 : 0);   // +1: pixel 1 wins, -1: pixel 3
+        // pixels 1 / 2 / 3 ahead: right NE E SE, left NW W SW, down SE S SW, up NE N NW; t = +1: pixel 1 wins, -1: pixel 3
+        const int a1 = hz ? nNE : nSE, a2 = hz ? gE : nS, a3 = hz ? nSE : nSW;
+        const int b1 = hz ? nNW : nNE, b2 = hz ? gW : nN, b3 = hz ? nSW : nNW;
+        const int ta = (a1 >= a2 && a1 >= a3) ? 1 : ((a3 >= a2 && a3 >= a1) ? -1 : 0);
+        const int tb = (b1 >= b2 && b1 >= b3) ? 1 : ((b3 >= b2 && b3 >= b1) ? -1 : 0);
         // right / left: (+-1, -t); down / up: (t, +-1); the state after: (sign, dy > 0) resp. (dx > 0, sign)
-        const int s2 = sg ? 2 : 0;
-        const int step = hz ? s2 + 8 * (1 - t) : (1 + t) + 8 * s2;
-        const int after = hz ? (sg ? 2 : 0) | (t < 0 ? 1 : 0) : (t > 0 ? 2 : 0) | (sg ? 1 : 0);
-        bool brk = false;
+        const int stepA = hz ? (2 + 8 * (1 - ta)) | (((ta < 0 ? 1 : 0) | 2) << 5) : ((1 + ta) + 16) | (((ta > 0 ? 2 : 0) | 1) << 5);
+        const int stepB = hz ? (0 + 8 * (1 - tb)) | ((tb < 0 ? 1 : 0) << 5) : ((1 + tb) + 0) | ((tb > 0 ? 2 : 0) << 5);
+        bool brkA = false, brkB = false;
         if (wx0 <= 0 || wy0 <= 0 || wx0 + 7 >= W - 1 || wy0 + 7 >= H - 1) {       // the window touches the image border
             const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
-            brk = hz ? ((sg ? x_hi : x_lo) || y_lo || y_hi) : (x_lo || x_hi || (sg ? y_hi : y_lo));
+            brkA = hz ? (x_hi || y_lo || y_hi) : (x_lo || x_hi || y_hi);
+            brkB = hz ? (x_lo || y_lo || y_hi) : (x_lo || x_hi || y_lo);
         }
-        const bool reach = hz ? ((sg ? ldx <= 6 : ldx >= 1) && inner_y) : ((sg ? ldy <= 6 : ldy >= 1) && inner_x);
-        const int fld = brk ? 31 : (reach ? step | (after << 5) : 30);
-        info = v | ((uint32_t)fld << 16) | (sg ? 1u << 23 : 0u) | (mk ? 1u << 30 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 31 : 0u);
+        const bool reachA = hz ? (ldx <= 6 && inner_y) : (ldy <= 6 && inner_x);
+        const bool reachB = hz ? (ldx >= 1 && inner_y) : (ldy >= 1 && inner_x);
+        const int fA = brkA ? 31 : (reachA ? stepA : 30), fB = brkB ? 31 : (reachB ? stepB : 30);
+        info = v | ((uint32_t)fA << 16) | ((uint32_t)fB << 23) | (mk ? 1u << 30 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 31 : 0u);
     };
-    fetch((ld & 1) ^ 1);
-    int L = (y - wy0) * 8 + (x - wx0);
-    uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
+    // the record of the walk's sign at a pixel of kind hz
+    auto record = [&](uint32_t s_, uint32_t hz_) { return (s_ >> (((st >> hz_) & 1u) ? 16 : 23)) & 127u; };
+    int L;
+    uint32_t s;
+    {
+        bool reuse = false;
+        if (!first && c.have && (unsigned)(x - wx0) < 8u && (unsigned)(y - wy0) < 8u) {
+            // the anchor lies in the window the first walk ended in: start there unless its first step leaves the window.
+            // The caller has cleared the anchor's mark in the bit plane: the same here
+            L = (y - wy0) * 8 + (x - wx0);
+            info &= lane == L ? ~(1u << 30) : ~0u;
+            s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
+            reuse = (record(s, (s >> 15) & 1u) & 31u) != 30u;
+        }
+        if (!reuse) {
+            fetch((ld & 1) ^ 1, first);
+            L = (y - wy0) * 8 + (x - wx0);
+            s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
+        }
+    }
     while ((s >> 30) == 0u) {                                 // neither marked nor without gradient
         const bool here = lane == L;
         info |= here ? 1u << 30 : 0u;
@@ -527,17 +546,16 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         ++cnt;
         Lv = L;
         const uint32_t hz = (s >> 15) & 1u;
-        uint32_t fld = (s >> 16) & 127u;
-        // the recorded step is for the other sign, or leaves the window, or the image ends
-        if ((((fld & 31u) + 2u) >> 5 | (((s >> 23) ^ (st >> hz)) & 1u)) != 0u) {
-            if ((fld & 31u) == 31u && (((s >> 23) ^ (st >> hz)) & 1u) == 0u) break;      // the image border ahead (:1583, :1620, ...)
-            x = wx0 + (L & 7); y = wy0 + (L >> 3);
+        uint32_t fld = record(s, hz);
+        if ((fld & 31u) >= 30u) {
+            if ((fld & 31u) == 31u) break;                     // the image border ahead (:1583, :1620, ...)
+            x = wx0 + (L & 7); y = wy0 + (L >> 3);             // the three ahead are not all in the window
             retire();
             if (!ok) break;
-            fetch(hz);
+            fetch(hz, false);
             L = (y - wy0) * 8 + (x - wx0);
             Lv = L;
-            fld = ((uint32_t)__builtin_amdgcn_readlane((int)info, L) >> 16) & 127u;
+            fld = record((uint32_t)__builtin_amdgcn_readlane((int)info, L), hz);
             if ((fld & 31u) >= 30u) break;                     // the border (30 cannot happen: the window was placed around the three ahead)
         }
         st = fld >> 5;
@@ -546,6 +564,7 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
     }
     if (Lv >= 0) { c.lastX = (unsigned)(wx0 + (Lv & 7)); c.lastY = (unsigned)(wy0 + (Lv >> 3)); }
     if (ok) retire();
+    c.wx0 = wx0; c.wy0 = wy0; c.info = info; c.have = true;
     off_io = off;
     return ok;
 }
@@ -762,7 +781,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
         unsigned ps = 0, cpos = 0;                            // edges, chain pixels
         if (n_anchors > o.cap) st = 1;                        // the reference returns -1 ("anchor size is larger than its maximal size")
         else {
-            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0;
+            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0; wk.wx0 = 0; wk.wy0 = 0; wk.info = 0u; wk.have = false;
             const unsigned cap = (unsigned)o.cap;
             unsigned offF = 0, offS = 0;                      // kept first / second part pixels
             uint32_t ablk = 0u;
@@ -775,14 +794,14 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
                 if (ps > (unsigned)o.max_edges) { st = 2; break; }
                 const bool horizontal = (__builtin_amdgcn_readfirstlane((int)ahz[a >> 5]) >> (a & 31)) & 1;
                 unsigned nF = offF;
-                if (!ed_walk(wk, x, y, horizontal ? RightDir : DownDir, part, 0u - offF, nF, cap)) { st = 2; break; }
+                if (!ed_walk(wk, x, y, horizontal ? RightDir : DownDir, true, part, 0u - offF, nF, cap)) { st = 2; break; }
                 const unsigned lenF = nF - offF;
                 wk.marks.clear(i);                                     // the anchor starts the second part as well
                 // second part straight into the chain, behind the (still to be reversed) first part: entry t of the second
                 // part lands at cpos + lenF + t - 1, i.e. its entry 0 (the anchor again) on top of the first part's last slot,
                 // which the reversal below overwrites with the anchor anyway
                 unsigned nS = offS;
-                if (!ed_walk(wk, x, y, horizontal ? LeftDir : UpDir, chain, cpos + lenF - 1u - offS, nS, cap)) { st = 2; break; }
+                if (!ed_walk(wk, x, y, horizontal ? LeftDir : UpDir, false, chain, cpos + lenF - 1u - offS, nS, cap)) { st = 2; break; }
                 const unsigned lenS = nS - offS;
                 if ((int)(lenF + lenS) < fp.min_line_len + 1) continue;               // short chain: dropped, its marks stay
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
