@@ -74,4 +74,9 @@ for n_oct in (int(v) for v in args.octaves.split(",")):
     stages = ", ".join("%s %.3f ms" % (k.split("(")[0], v[0] / args.reps) for k, v in t.items() if v[1])
     print("octaves=%d: %d KeyLines per %d-frame batch (%.1f per frame), %.3f ms per batch = %.1f k frames/s (synchronous call); %s"
           % (n_oct, total.value, B, total.value / B, dt * 1e3, B / dt / 1e3, stages))
+    cnt = fe.keylines_fetch(0, 6, B)
+    sid = fe.keylines_fetch(0, 5, B)
+    chain_px = [int(sid[f][cnt[f, 1]]) if cnt[f, 1] >= 0 else 0 for f in range(B)]
+    print("    octave 0 per frame: %.0f anchors, %.1f chains, %.0f chain pixels, %.1f lines (max %d anchors, %d chains, %d chain pixels)"
+          % (cnt[:, 0].mean(), cnt[:, 1].mean(), np.mean(chain_px), cnt[:, 2].mean(), cnt[:, 0].max(), cnt[:, 1].max(), max(chain_px)))
 fe.close()
