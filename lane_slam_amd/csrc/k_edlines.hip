@@ -330,9 +330,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_ed_resize(int H, int W, int DH, 
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int S0 = (int)p0[cx[k].x] * cx[k].z + (int)p0[cx[k].y] * cx[k].w;
-            const int S1 = (int)p1[cx[k].x] * cx[k].z + (int)p1[cx[k].y] * cx[k].w;
-            int v = (((cy.z * (S0 >> 4)) >> 16) + ((cy.w * (S1 >> 4)) >> 16) + 2) >> 2;
+            // 24-bit multiplies (full rate; a 32-bit one is a quarter of that): pixels <= 255, weights <= 2048, S >> 4 <= 32 640
+            const int S0 = __mul24((int)p0[cx[k].x], cx[k].z) + __mul24((int)p0[cx[k].y], cx[k].w);
+            const int S1 = __mul24((int)p1[cx[k].x], cx[k].z) + __mul24((int)p1[cx[k].y], cx[k].w);
+            int v = ((__mul24(cy.z, S0 >> 4) >> 16) + (__mul24(cy.w, S1 >> 4) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
             out |= (uint32_t)v << (8 * k);
         }
