@@ -309,30 +309,58 @@ void ed_resize_tables(int H, int W, int DH, int DW, double scale, int* tab)
 }
 
 constexpr int RS_ROWS = 4, RS_THREADS = 128;
+constexpr int RS_SPAN = 736;                     // source columns under RS_THREADS * 4 destination columns (sqrt 2 each) + slack, a multiple of 4
+// The source rows of the workgroup's RS_ROWS destination rows (two each, as the row table names them) are staged in LDS
+// with coalesced dword loads; the four samples of a pixel are LDS bytes.  (Gathering them from global memory one byte per
+// lane made the kernel three times slower than its traffic.)
 __global__ __launch_bounds__(RS_THREADS) void k_ed_resize(int H, int W, int DH, int DW, const int4* __restrict__ tab, const uint8_t* __restrict__ src,
                                                           uint8_t* __restrict__ dst)
 {
+    __shared__ __attribute__((aligned(4))) uint8_t rows[RS_ROWS][2][RS_SPAN];
     const int tid = threadIdx.x, dy0 = blockIdx.y * RS_ROWS;
-    const int dx0 = (blockIdx.x * RS_THREADS + tid) * 4;
+    const int bx0 = blockIdx.x * RS_THREADS * 4;
+    const int bx1 = min(bx0 + RS_THREADS * 4, DW) - 1;          // the workgroup's destination columns
+    const int xlo = tab[bx0].x, xhi = tab[bx1].y;               // ... and the source columns under them
+    const int span = xhi - xlo + 1;
+    const uint8_t* S = src + (size_t)blockIdx.z * H * W;
+    const int nrows = DH - dy0 < RS_ROWS ? DH - dy0 : RS_ROWS;
+    if (span <= RS_SPAN) {
+        for (int r = 0; r < nrows; ++r) {
+            const int4 cy = tab[DW + dy0 + r];
+            for (int h = 0; h < 2; ++h) {
+                const uint8_t* p = S + (h ? cy.y : cy.x) + xlo;
+                for (int i = 4 * tid; i < span; i += 4 * RS_THREADS) {
+                    uint32_t w = 0;
+                    if (i + 3 < span) __builtin_memcpy(&w, p + i, 4);      // (not dword-aligned: any width, any column)
+                    else for (int k = 0; i + k < span; ++k) w |= (uint32_t)p[i + k] << (8 * k);
+                    *reinterpret_cast<uint32_t*>(&rows[r][h][i]) = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int dx0 = bx0 + tid * 4;
     if (dx0 >= DW) return;
     int4 cx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) cx[k] = tab[dx0 + k < DW ? dx0 + k : DW - 1];
-    const uint8_t* S = src + (size_t)blockIdx.z * H * W;
     uint8_t* D = dst + (size_t)blockIdx.z * DH * DW;
-    const int rows = DH - dy0 < RS_ROWS ? DH - dy0 : RS_ROWS;
 #pragma unroll
     for (int r = 0; r < RS_ROWS; ++r) {
-        if (r >= rows) break;
+        if (r >= nrows) break;
         const int4 cy = tab[DW + dy0 + r];                     // (wave-uniform: a scalar load)
-        const uint8_t* p0 = S + cy.x;
-        const uint8_t* p1 = S + cy.y;
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            int a, b_, c_, d;
+            if (span <= RS_SPAN) {
+                a = rows[r][0][cx[k].x - xlo]; b_ = rows[r][0][cx[k].y - xlo]; c_ = rows[r][1][cx[k].x - xlo]; d = rows[r][1][cx[k].y - xlo];
+            } else {                                           // (a scale far from sqrt 2: straight from the image)
+                a = S[cy.x + cx[k].x]; b_ = S[cy.x + cx[k].y]; c_ = S[cy.y + cx[k].x]; d = S[cy.y + cx[k].y];
+            }
             // 24-bit multiplies (full rate; a 32-bit one is a quarter of that): pixels <= 255, weights <= 2048, S >> 4 <= 32 640
-            const int S0 = __mul24((int)p0[cx[k].x], cx[k].z) + __mul24((int)p0[cx[k].y], cx[k].w);
-            const int S1 = __mul24((int)p1[cx[k].x], cx[k].z) + __mul24((int)p1[cx[k].y], cx[k].w);
+            const int S0 = __mul24(a, cx[k].z) + __mul24(b_, cx[k].w);
+            const int S1 = __mul24(c_, cx[k].z) + __mul24(d, cx[k].w);
             int v = ((__mul24(cy.z, S0 >> 4) >> 16) + (__mul24(cy.w, S1 >> 4) >> 16) + 2) >> 2;
             v = v < 0 ? 0 : (v > 255 ? 255 : v);
             out |= (uint32_t)v << (8 * k);
