@@ -143,6 +143,22 @@ def test_keylines_on_clutter_shapes_and_real_frames(golden_dir):
     fe.close()
 
 
+def test_keylines_on_1080p_frames_with_the_edge_marks_in_global_memory():
+    """1920x1080 frames -> a 1920x720 working image: octave 0's edge-mark bit plane (1.38 M bits + the anchor planes) is beyond
+    the detector's LDS budget and lives in global memory (agent-scope atomics); octave 1 (1358x509) fits LDS again."""
+    cfg = default_config("fullres", in_size=(1080, 1920))
+    frames = synth.make_batch(2, 70, rows=1080, cols=1920)
+    rng = np.random.default_rng(7)
+    frames[1, 400:700, 300:900] = rng.integers(0, 256, (300, 600, 3), dtype=np.uint8)     # a noisy patch: thousands of short chains
+    gray = _gray_frames(cfg, frames)
+    fe = FrontEnd(cfg, max_frames=2, max_lines_per_color=8192)
+    k = fe.keylines_batch(frames, n_octaves=2, capacity=60000)
+    _check_stages(fe, gray, 2)
+    n = _check_keylines(k, gray, 2)
+    assert n > 100
+    fe.close()
+
+
 def test_describe_given_keylines_on_the_pyrdown_pyramid():
     """BinaryDescriptor::compute with KeyLines that live on computeGaussianPyramid's levels (scale 2 per octave, what
     LSDDetector_custom.cpp:130-215 produces): descriptors from blur(sigma 1) -> pyrDown -> Sobel per level."""
