@@ -152,7 +152,7 @@ void launch_segments(const SegParams& p, int n_frames, const float* slot_lines, 
 void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* gray, uint32_t* dxy, hipStream_t s);
 // gradient planes of the octaves of a KeyLine batch: [B][H*W] dx | dy << 16 each
 struct LbdPlanes { const uint32_t* base[LF_MAX_OCTAVES]; int W[LF_MAX_OCTAVES], H[LF_MAX_OCTAVES]; };
-void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
+void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, int n_frames, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
                          const int* octave, const int* frame, const float* gauss_g, const float* gauss_l, float* desc, uint8_t* code,
                          hipStream_t s);
 void launch_lbd_split_debug(size_t n, const uint32_t* dxy, int16_t* dx, int16_t* dy, hipStream_t s);

@@ -1335,6 +1335,7 @@ __global__ void k_kl_offsets(int n_frames, const int* __restrict__ frame_count, 
     frame_offset[n_frames] = acc;
     totals[0] = acc;
     totals[1] = acc > capacity ? 1 : 0;
+    totals[2] = acc > capacity ? 0 : acc;        // what the descriptor stage may walk: nothing when the output overflows
 }
 
 void launch_kl_offsets(int n_frames, const int* frame_count, int capacity, int* frame_offset, int* totals, hipStream_t s)

@@ -228,12 +228,13 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restr
                                              const float* __restrict__ gauss_g /*63*/, const float* __restrict__ gauss_l /*21*/,
                                              float* __restrict__ desc, uint8_t* __restrict__ code,
                                              LbdPlanes planes, const float* __restrict__ kl_angle, const int* __restrict__ kl_npx,
-                                             const int* __restrict__ kl_octave)
+                                             const int* __restrict__ kl_octave, int n_cap, int n_frames)
 {
     __shared__ float rows[4][LSP_H][4];      // per wave: row sums pgdL, ngdL, pgdO, ngdO (already * coefG)
     __shared__ float dsc[4][72];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n_seg = *n_seg_ptr;
+    // never past the capacity the buffers were sized for: a count beyond it is the caller's LF_ERR_CAPACITY case
+    const int n_seg = min(*n_seg_ptr, n_cap);
     // the segment count is only known on the device: a fixed grid of waves strides over the segments
   for (int seg = blockIdx.x * 4 + wave; seg < n_seg; seg += gridDim.x * 4) {
     __builtin_amdgcn_wave_barrier();
@@ -246,6 +247,13 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restr
     float direction;
     if (KL) {
         const int oc = kl_octave[seg];
+        // caller-supplied KeyLines (lf_describe_keylines with device arrays) are not validated on the host: a line that
+        // names a plane that was not built gets a zero descriptor instead of a wild read
+        if (oc < 0 || oc >= LF_MAX_OCTAVES || planes.base[oc] == nullptr || f < 0 || f >= n_frames) {
+            if (desc) for (int i = lane; i < 72; i += 64) desc[(size_t)seg * 72 + i] = 0.f;
+            if (code && lane < 32) code[(size_t)seg * 32 + lane] = 0;
+            continue;
+        }
         Hc = planes.H[oc]; W = planes.W[oc];
         pdxy = planes.base[oc] + (size_t)f * Hc * W;
         lengthOfLSP = (int)(short)kl_npx[seg];                  // `short lengthOfLSP` (:1106)
@@ -412,10 +420,10 @@ void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lin
     LbdPlanes none;
     for (int i = 0; i < LF_MAX_OCTAVES; ++i) { none.base[i] = nullptr; none.W[i] = 0; none.H[i] = 0; }
     hipLaunchKernelGGL(k_lbd<false>, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
-                       gauss_g, gauss_l, desc, code, none, nullptr, nullptr, nullptr);
+                       gauss_g, gauss_l, desc, code, none, nullptr, nullptr, nullptr, n_seg_cap, 0);
 }
 
-void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
+void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, int n_frames, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
                          const int* octave, const int* frame, const float* gauss_g, const float* gauss_l, float* desc, uint8_t* code,
                          hipStream_t s)
 {
@@ -423,7 +431,7 @@ void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, const int* n_lines,
     int blocks = (n_cap + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_lbd<true>, dim3(blocks), dim3(256), 0, s, 0, 0, n_lines, in_octave4, frame, nullptr, gauss_g, gauss_l, desc, code,
-                       planes, angle, npx, octave);
+                       planes, angle, npx, octave, n_cap, n_frames);
 }
 
 // Debug only: the two s16 planes tests compare with the oracle's Sobel output.

@@ -116,6 +116,8 @@ struct lf_handle {
     bool pending = false;
     bool grow_mixed = false;     // the last batch had problems beyond the slice in numbers (> 1 %): one launch with both kinds of problem code
     int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
+    int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
+    int env_mixed = -1;
     int pending_problems = 0;
     int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
@@ -513,6 +515,8 @@ extern "C" int lf_create(const lf_config* cfg, int device_id, int max_frames, in
     h->cfg = *cfg; h->device = device_id; h->max_frames = max_frames; h->cap_lines = max_lines_per_color;
     h->err[0] = 0;
     memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches));
+    if (const char* ev = getenv("LF_GROW_LDS_LEVEL")) { const int v = atoi(ev); h->env_lds_level = v < 0 ? 0 : (v > 2 ? 2 : v); }
+    if (const char* ev = getenv("LF_GROW_MIXED")) h->env_mixed = atoi(ev) != 0 ? 1 : 0;
     int rc = LF_OK;
     do {
         if (hipSetDevice(device_id) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipSetDevice(%d) failed", device_id); rc = LF_ERR_HIP; break; }
@@ -576,11 +580,13 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     if (diag_skip && strstr(diag_skip, "grow")) LF_HIP_CHECK(h, hipMemsetAsync(h->d_counts, 0, (size_t)n * 3 * sizeof(int), s));
     else {
         StageTimer t(h, ST_LSD_GROW);
+        static const bool no_rank = getenv("LF_DIAG_NO_RANK") != nullptr;
+        const int env_lds_level = h->env_lds_level, env_mixed = h->env_mixed;
         launch_lsd_grow(h->lsd, n, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                        h->d_slot_lines, h->d_counts, getenv("LF_DIAG_NO_RANK") ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count,
-                        kGrowLdsKb[getenv("LF_GROW_LDS_LEVEL") ? atoi(getenv("LF_GROW_LDS_LEVEL")) % 3 : h->grow_lds_level],
-                        getenv("LF_GROW_MIXED") ? atoi(getenv("LF_GROW_MIXED")) != 0 : h->grow_mixed, s);
+                        h->d_slot_lines, h->d_counts, no_rank ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count,
+                        kGrowLdsKb[env_lds_level >= 0 ? env_lds_level : h->grow_lds_level],
+                        env_mixed >= 0 ? env_mixed != 0 : h->grow_mixed, s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;

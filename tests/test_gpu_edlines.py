@@ -143,6 +143,23 @@ def test_keylines_on_clutter_shapes_and_real_frames(golden_dir):
     fe.close()
 
 
+def test_small_capacity_on_a_fresh_handle_is_a_clean_error():
+    """with describe=True and an output smaller than the KeyLine total, the descriptor stage used to walk the
+    unclamped total past buffers sized for `capacity`.  A FRESH handle (internal buffers never grown by an earlier call), a tiny
+    capacity: LF_ERR_CAPACITY, and the same handle still gives the oracle's result afterwards."""
+    cfg = default_config("fullres")
+    frames = synth.make_batch(3, 91)
+    o = O.Oracle(cfg)
+    gray = np.stack([o.bgr2gray(o.preprocess(f)) for f in frames])
+    for cap in (1, 7):
+        fe = FrontEnd(cfg, max_frames=3, max_lines_per_color=256)
+        with pytest.raises(LanefrontError):
+            fe.keylines_batch(gray, n_octaves=2, gray=True, describe=True, capacity=cap)
+        k = fe.keylines_batch(gray, n_octaves=2, gray=True, describe=True, capacity=3 * 2048)
+        assert _check_keylines(k, gray, 2) > 0
+        fe.close()
+
+
 def test_keylines_on_1080p_frames_with_the_edge_marks_in_global_memory():
     """1920x1080 frames -> a 1920x720 working image: octave 0's edge-mark bit plane (1.38 M bits + the anchor planes) is beyond
     the detector's LDS budget and lives in global memory (agent-scope atomics); octave 1 (1358x509) fits LDS again."""
