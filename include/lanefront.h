@@ -162,11 +162,22 @@ int lf_wait(lf_handle* h, int* n_segments);
 /* ---- association: replaces BinaryDescriptorMatcher::match ------------------
  * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
  * each 256-bit query code in the map; idx = -1 and dist = -1 when the nearest
- * neighbour is farther than 128 bits (:721); ties -> lowest map index.
+ * neighbour is farther than 128 bits (:721).
  * Computed as an exact matrix-core contraction (FP4 e2m1 +-1 operands with f32 accumulation on gfx950), one kernel launch per call.  on_device applies to all four arrays.
+ *
+ * Which of several EQUALLY near map codes is returned (the distance never depends on it) is the tie rule:
+ *   LF_TIE_MIHASHER  the reference's: the candidate Mihasher::query meets first (binary_descriptor_matcher.cpp:635-753) --
+ *                    by search radius, then substring, then the position of the differing bits in its enumeration
+ *                    (:681-741), then train index.  Costs a second matrix pass that ranks only the ties (k_assoc_ties.hip).
+ *                    THE DEFAULT of lf_associate: it is what BinaryDescriptorMatcher::match returns.
+ *   LF_TIE_LOWEST    the lowest map index; one pass.  The default of the live map (lf_map_*, this package's own contract).
  */
+#define LF_TIE_LOWEST 0
+#define LF_TIE_MIHASHER 1
 int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
                  int32_t* idx, float* dist, int on_device);
+/* tie rule of this handle's lf_associate (LF_TIE_MIHASHER unless set) */
+int lf_set_tie_rule(lf_handle* h, int tie_rule);
 /* float LBD (72-d, unit norm) Euclidean nearest neighbour on fp32 MFMA */
 int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
                        int32_t* idx, float* dist, int on_device);
@@ -270,6 +281,9 @@ int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_
  * on_device applies to all four arrays; with host arrays the call returns when idx / dist are in place. */
 int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, const uint8_t* color, int n,
                      int32_t* idx, float* dist, int on_device);
+/* tie rule of the map's associations (lf_map_associate, lf_map_step*): LF_TIE_LOWEST unless set; with LF_TIE_MIHASHER and
+ * colour gating the reference's discovery order applies among the entries the query may match */
+int lf_map_set_tie_rule(lf_map* m, int tie_rule);
 /* Device arrays of `segs` (frame_offset, code, color, keep, ground; capacity ignored) + idx / dist -> one block in
  * device memory.  block_rows < n + 1: LF_ERR_CAPACITY -- never truncated: the block is then ONLY a header with the
  * overflow marker, which a rank of a multi-GPU step still all-gathers so that every replica skips that step's update

@@ -188,6 +188,9 @@ void assoc_scratch_free(AssocScratch& w);
 void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int fp4, int8_t* x, int8_t* cx, hipStream_t s);
 hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const int8_t* mcx, int nm,
                              const int* nm_dev, int gating, int max_distance, AssocScratch& w, int32_t* idx, float* dist, hipStream_t s);
+// the reference's tie rule as a second pass over the packed map (k_assoc_ties.hip); after launch_assoc_core on the same stream
+hipError_t launch_assoc_ties(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const uint8_t* mcode, const uint8_t* mcolor,
+                             int nm, const int* nm_dev, int gating, unsigned long long* res, int32_t* idx, const float* dist, hipStream_t s);
 hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
                         float* dist, hipStream_t s);
 void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);

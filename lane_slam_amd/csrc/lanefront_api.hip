@@ -116,6 +116,7 @@ struct lf_handle {
     bool pending = false;
     bool grow_mixed = false;     // the last batch had problems beyond the slice in numbers (> 1 %): one launch with both kinds of problem code
     int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
+    int tie_rule = LF_TIE_MIHASHER;   // lf_associate: the reference's rule unless lf_set_tie_rule says otherwise
     int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
     int env_mixed = -1;
     int pending_problems = 0;
@@ -802,6 +803,10 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
     const size_t nm_pad = assoc_rows_padded_m(nm);
     int rc;
     if ((rc = ensure(h, h->a_mx, nm_pad * 256)) || (rc = ensure(h, h->a_mcx, nm_pad * 32))) return rc;
+    if (h->tie_rule == LF_TIE_MIHASHER) {
+        if (getenv("LF_ASSOC_INT8")) { lf_set_error(h, LF_ERR_UNSUPPORTED, "LF_ASSOC_INT8 (the int8 A/B kernels) supports LF_TIE_LOWEST only"); return LF_ERR_UNSUPPORTED; }
+        if ((rc = ensure(h, h->a_best, (size_t)nq * 8)) != LF_OK) return rc;
+    }
     const uint8_t *dq = query32, *dmp = map32;
     int32_t* didx = idx; float* ddist = dist;
     if (!on_device) {
@@ -814,6 +819,9 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
     {
         StageTimer t(h, ST_ASSOC);
         LF_HIP_CHECK(h, launch_assoc(dq, nq, dmp, nm, (int8_t*)h->a_mx.p, (int8_t*)h->a_mcx.p, h->a_ws, didx, ddist, s));
+        if (h->tie_rule == LF_TIE_MIHASHER)
+            LF_HIP_CHECK(h, launch_assoc_ties(dq, nullptr, nq, (const int8_t*)h->a_mx.p, dmp, nullptr, nm, nullptr, 0,
+                                              static_cast<unsigned long long*>(h->a_best.p), didx, ddist, s));
     }
     LF_HIP_CHECK(h, hipGetLastError());
     if (!on_device) {
@@ -821,6 +829,14 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
         LF_HIP_CHECK(h, hipMemcpyAsync(dist, ddist, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
         LF_HIP_CHECK(h, hipStreamSynchronize(s));
     }
+    return LF_OK;
+}
+
+extern "C" int lf_set_tie_rule(lf_handle* h, int tie_rule)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (tie_rule != LF_TIE_LOWEST && tie_rule != LF_TIE_MIHASHER) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_set_tie_rule: unknown rule %d", tie_rule); return LF_ERR_BAD_ARG; }
+    h->tie_rule = tie_rule;
     return LF_OK;
 }
 

@@ -15,6 +15,7 @@ struct Buf { void* p = nullptr; size_t bytes = 0; };
 
 struct lf_map {
     lf_map_config cfg;
+    int tie_rule = LF_TIE_LOWEST;
     int device = 0;
     hipStream_t stream = nullptr;
     char err[512];
@@ -27,7 +28,7 @@ struct lf_map {
     bool state_pending = false;
     long long rows_in_flight = 0;            // rows handed to updates whose state copy has not been seen yet
     AssocScratch ws;
-    Buf act, own_block, pose, q_in, c_in, idx_out, dist_out, seed_code, seed_color, seed_ground;
+    Buf act, own_block, pose, q_in, c_in, idx_out, dist_out, seed_code, seed_color, seed_ground, tie_res;
     Buf st_fo, st_code, st_color, st_keep, st_ground, st_idx, st_dist;     // staging of lf_map_step_host
     std::vector<double> h_pose;
     // per-stage timing with HIP events on the map's stream (resolved by lf_map_get_timing)
@@ -183,7 +184,7 @@ extern "C" void lf_map_destroy(lf_map* m)
     void* ptrs[] = { m->d.code, m->d.color, m->d.ground, m->d.hits, m->d.last_seen, m->d.winner, m->d.mx, m->d.mcx, m->d.state, m->d.totals };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     assoc_scratch_free(m->ws);
-    for (Buf* b : { &m->act, &m->own_block, &m->pose, &m->q_in, &m->c_in, &m->idx_out, &m->dist_out, &m->seed_code, &m->seed_color, &m->seed_ground,
+    for (Buf* b : { &m->act, &m->own_block, &m->pose, &m->q_in, &m->c_in, &m->idx_out, &m->dist_out, &m->seed_code, &m->seed_color, &m->seed_ground, &m->tie_res,
                      &m->st_fo, &m->st_code, &m->st_color, &m->st_keep, &m->st_ground, &m->st_idx, &m->st_dist })
         if (b->p) (void)hipFree(b->p);
     if (m->h_state) (void)hipHostFree(m->h_state);
@@ -377,6 +378,7 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
         }
         didx = static_cast<int32_t*>(m->idx_out.p); ddist = static_cast<float*>(m->dist_out.p);
     }
+    if (m->tie_rule == LF_TIE_MIHASHER && (rc = grow(m, m->tie_res, (size_t)n * 8)) != LF_OK) return rc;
     if (size == 0) {
         // descriptor matrices cannot be void (binary_descriptor_matcher.cpp:201-205): report "no match"
         launch_assoc_nomatch(n, didx, ddist, s);
@@ -386,6 +388,9 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
             MapTimer t(m, 1);
             MAP_HIP(m, launch_assoc_core(dq, m->cfg.color_gating ? dc : nullptr, n, m->d.mx, m->d.mcx, size, m->d.state, m->cfg.color_gating,
                                          m->cfg.max_distance, m->ws, didx, ddist, s));
+            if (m->tie_rule == LF_TIE_MIHASHER)       // second pass: among the equally near entries, the one the reference's search meets first
+                MAP_HIP(m, launch_assoc_ties(dq, m->cfg.color_gating ? dc : nullptr, n, m->d.mx, m->d.code, m->d.color, size, m->d.state,
+                                             m->cfg.color_gating, static_cast<unsigned long long*>(m->tie_res.p), didx, ddist, s));
         }
     }
     MAP_HIP(m, hipGetLastError());
@@ -395,6 +400,15 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
         MAP_HIP(m, hipMemcpyAsync(dist, ddist, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         MAP_HIP(m, hipStreamSynchronize(s));
     }
+    return LF_OK;
+}
+
+extern "C" int lf_map_set_tie_rule(lf_map* m, int tie_rule)
+{
+    if (!m) return LF_ERR_NOT_INITIALISED;
+    if (tie_rule != LF_TIE_LOWEST && tie_rule != LF_TIE_MIHASHER) { map_error(m, "lf_map_set_tie_rule: unknown rule"); return LF_ERR_BAD_ARG; }
+    if (tie_rule == LF_TIE_MIHASHER && !m->d.fp4) { map_error(m, "LF_ASSOC_INT8 (the int8 A/B kernels) supports LF_TIE_LOWEST only"); return LF_ERR_UNSUPPORTED; }
+    m->tie_rule = tie_rule;
     return LF_OK;
 }
 

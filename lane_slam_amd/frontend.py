@@ -177,9 +177,17 @@ class FrontEnd(object):
         return total.value
 
     # ------------------------------------------------------------------ association
+    def set_tie_rule(self, rule):
+        """Which of several equally near map codes `associate` returns: "mihasher" (the default: the one the reference's
+        Mihasher::query discovers first, binary_descriptor_matcher.cpp:635-753) or "lowest" (lowest index, one pass)."""
+        if rule not in _lib.TIE_RULES:
+            raise ValueError("tie rule must be one of %r" % (sorted(_lib.TIE_RULES),))
+        self._check(self.lib.lf_set_tie_rule(self.h, _lib.TIE_RULES[rule]))
+
     def associate(self, query_codes, map_codes):
         """Exact Hamming NN (binary_descriptor_matcher.cpp:197-254).  Returns (idx int32, dist float32);
-        idx == -1 where the nearest map entry is farther than 128 bits or the map is empty."""
+        idx == -1 where the nearest map entry is farther than 128 bits or the map is empty.  Equally near codes: see
+        set_tie_rule."""
         q = np.ascontiguousarray(query_codes, dtype=np.uint8).reshape(-1, 32)
         m = np.ascontiguousarray(map_codes, dtype=np.uint8).reshape(-1, 32)
         idx = np.empty(q.shape[0], np.int32)

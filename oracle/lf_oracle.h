@@ -115,6 +115,7 @@ void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
                int32_t* idx, float* dist);
 /* the same with the reference's tie rule (first discovered by Mihasher::query) and the number of equally near codes */
 void lfo_match_mih(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int32_t* idx, float* dist, int32_t* n_ties);
+long long lfo_mih_discovery_key(const uint8_t* query32, const uint8_t* train32);
 void lfo_knn_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int k, int32_t* idx, float* dist);
 int lfo_radius_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt, float max_distance, int32_t* offsets, int32_t* idx,
                      float* dist);
@@ -193,6 +194,8 @@ const double* lfo_map_ground(const lfo_map* m);
 const int32_t* lfo_map_hits(const lfo_map* m);
 const int32_t* lfo_map_last_seen(const lfo_map* m);
 void lfo_map_seed(lfo_map* m, const uint8_t* code32, const uint8_t* color, const double* ground4, int n);
+/* 0 (default): ties -> lowest index; 1: the reference's rule, the candidate Mihasher::query discovers first (lfo_match_mih) */
+void lfo_map_set_tie_rule(lfo_map* m, int rule);
 void lfo_map_associate(const lfo_map* m, const uint8_t* code32, const uint8_t* color, int n, int32_t* idx, float* dist);
 void lfo_map_to_map_frame(const double* ground4, int n, const int32_t* frame_offset, int n_frames, const double* pose3,
                           double* out4);

@@ -272,6 +272,21 @@ static void mih_build_ranks(void)
     mih_rank_ready = 1;
 }
 
+/* when Mihasher::query first meets train code b while searching for a (see above): (radius, substring, position of the
+ * bit string in the enumeration); -1 when no substring is within 4 bits (the code is then farther than 128 bits) */
+long long lfo_mih_discovery_key(const uint8_t* a, const uint8_t* b)
+{
+    if (!mih_rank_ready) mih_build_ranks();
+    long long key = -1;
+    for (int k = 0; k < 32; ++k) {
+        const int x = a[k] ^ b[k], h = __builtin_popcount((unsigned)x);
+        if (h > 4) continue;
+        const long long kk = (((long long)h * 32 + k) * 256 + mih_rank[h][x]);
+        if (key < 0 || kk < key) key = kk;
+    }
+    return key;
+}
+
 void lfo_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, float* dist, int32_t* n_ties)
 {
     if (!mih_rank_ready) mih_build_ranks();

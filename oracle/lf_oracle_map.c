@@ -18,6 +18,7 @@
 
 struct lfo_map {
     lfo_map_config cfg;
+    int tie_rule;
     int size, head, overflow;
     long long total_appended, total_refreshed;
     uint8_t* code;      /* capacity * 32 */
@@ -113,6 +114,8 @@ static int hamming256(const uint8_t* a, const uint8_t* b)
 
 /* nearest entry of each query; with gating only entries of the query's colour (a colour >= 3 on either side matches
  * everything); farther than max_distance -> idx -1, dist -1; ties -> lowest index */
+void lfo_map_set_tie_rule(lfo_map* m, int rule) { m->tie_rule = rule; }
+
 void lfo_map_associate(const lfo_map* m, const uint8_t* code32, const uint8_t* color, int n, int32_t* idx, float* dist)
 {
     for (int q = 0; q < n; ++q) {
@@ -122,6 +125,16 @@ void lfo_map_associate(const lfo_map* m, const uint8_t* code32, const uint8_t* c
             if (m->cfg.color_gating && qc < 3 && m->color[j] < 3 && m->color[j] != qc) continue;
             const int d = hamming256(code32 + (size_t)q * 32, m->code + (size_t)j * 32);
             if (d < best) { best = d; arg = j; }
+        }
+        if (m->tie_rule == 1 && arg >= 0 && best <= 128) {
+            /* among the equally near (and eligible) entries: the one the reference's search meets first */
+            long long bkey = -1;
+            for (int j = 0; j < m->size; ++j) {
+                if (m->cfg.color_gating && qc < 3 && m->color[j] < 3 && m->color[j] != qc) continue;
+                if (hamming256(code32 + (size_t)q * 32, m->code + (size_t)j * 32) != best) continue;
+                const long long key = lfo_mih_discovery_key(code32 + (size_t)q * 32, m->code + (size_t)j * 32);
+                if (bkey < 0 || key < bkey) { bkey = key; arg = j; }
+            }
         }
         if (arg >= 0 && best <= m->cfg.max_distance) { idx[q] = arg; dist[q] = (float)best; }
         else { idx[q] = -1; dist[q] = -1.f; }

@@ -383,7 +383,7 @@ class OracleMap(object):
     lane_slam_amd.LineAssociator."""
 
     def __init__(self, capacity=65536, color_gating=False, max_distance=128, policy="append", kept_only=True,
-                 merge_distance=0, when_full="ring"):
+                 merge_distance=0, when_full="ring", tie_rule="lowest"):
         build()
         self.lib = ctypes.CDLL(_SO)
         self.lib.lfo_map_create.restype = ctypes.c_void_p
@@ -394,6 +394,8 @@ class OracleMap(object):
                          int(bool(kept_only)), int(merge_distance), {"ring": 0, "error": 1}[when_full])
         self.capacity = int(capacity)
         self.m = ctypes.c_void_p(self.lib.lfo_map_create(ctypes.byref(c)))
+        self.lib.lfo_map_set_tie_rule.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        self.lib.lfo_map_set_tie_rule(self.m, {"lowest": 0, "mihasher": 1}[tie_rule])
 
     def __del__(self):
         try:

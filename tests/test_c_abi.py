@@ -87,7 +87,7 @@ def test_c_client_matches_python_binding_and_oracle(tmp_path):
     assert np.array_equal(lines, seg.lines) and np.array_equal(ground, seg.ground)
     assert np.array_equal(keep, seg.keep) and np.array_equal(code, seg.code)
     o = Oracle(cfg)
-    oi, od = o.match(code, code[::-1].copy())
+    oi, od, _ = o.match_mih(code, code[::-1].copy())          # lf_associate's default tie rule: the reference's
     assert np.array_equal(idx, oi) and np.array_equal(dist, od)
     ref_body, ref_off = sm.serialize_segments(fe, seg, sm.FILTERED)
     assert np.array_equal(boff, ref_off) and np.array_equal(body, ref_body)

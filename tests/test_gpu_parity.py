@@ -190,6 +190,21 @@ def test_plugin_matches_reference_interface():
         assert det.detectLines(color).lines == []
 
 
+def _associate_both_rules(fe, o, q, m):
+    """lf_associate under both tie rules against the oracle's two statements: the reference's first-discovered rule (the
+    default, lfo_match_mih) and the lowest index (lfo_match).  Returns the lowest-index result."""
+    fe.set_tie_rule("mihasher")
+    gi, gd = fe.associate(q, m)
+    wi, wd, _ = o.match_mih(q, m)
+    assert np.array_equal(gd, wd) and np.array_equal(gi, wi), ("mihasher", int((gi != wi).sum()))
+    fe.set_tie_rule("lowest")
+    idx, dist = fe.associate(q, m)
+    oi, od = o.match(q, m)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi), ("lowest", int((idx != oi).sum()))
+    assert np.array_equal(gd, dist)                # the distance never depends on the rule
+    return idx, dist
+
+
 def test_associate_matches_matcher_semantics():
     from oracle.oracle import Oracle
     o = Oracle(default_config("parity"))
@@ -207,25 +222,20 @@ def test_associate_matches_matcher_semantics():
         q[i] = src
     m[10] = m[5]
     q[300] = m[5]
-    idx, dist = fe.associate(q, m)
-    oi, od = o.match(q, m)
-    assert np.array_equal(dist, od)
-    assert np.array_equal(idx, oi)                 # both sides resolve ties to the lowest index
+    idx, dist = _associate_both_rules(fe, o, q, m)
     assert idx[300] == 5 and dist[300] == 0
     assert (idx >= 0).all()       # 3000 random codes: every random query has a neighbour within 128 bits
     # farther than D = 128 -> "no match" (binary_descriptor_matcher.cpp:721)
     far_q = np.concatenate([~m[:1], m[:1]])
-    i_far, d_far = fe.associate(far_q, m[:1])
+    i_far, d_far = _associate_both_rules(fe, o, far_q, m[:1])
     assert i_far.tolist() == [-1, 0] and d_far.tolist() == [-1.0, 0.0]
-    o_far, e_far = o.match(far_q, m[:1])
-    assert np.array_equal(i_far, o_far) and np.array_equal(d_far, e_far)
     # ragged sizes and the empty map
     for a, b in [(1, 1), (5, 63), (129, 64), (33, 65), (128, 1000)]:
-        i2, d2 = fe.associate(q[:a], m[:b])
-        o2, e2 = o.match(q[:a], m[:b])
-        assert np.array_equal(i2, o2) and np.array_equal(d2, e2)
-    i3, d3 = fe.associate(q[:7], m[:0])
-    assert (i3 == -1).all() and (d3 == -1).all()
+        _associate_both_rules(fe, o, q[:a], m[:b])
+    for rule in ("mihasher", "lowest"):
+        fe.set_tie_rule(rule)
+        i3, d3 = fe.associate(q[:7], m[:0])
+        assert (i3 == -1).all() and (d3 == -1).all()
     # float LBD distances within the north-star tolerance
     qd = rng.random((200, 72)).astype(np.float32)
     md = rng.random((900, 72)).astype(np.float32)
@@ -602,9 +612,7 @@ def test_associate_large_map_and_many_ties():
     m = base[rng.integers(0, 500, nm)]                      # every code occurs ~300 times
     q = base[rng.integers(0, 500, nq)].copy()
     q[::3, 5] ^= 0x11                                        # a third of the queries two bits away
-    idx, dist = fe.associate(q, m)
-    oi, od = o.match(q, m)
-    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    idx, dist = _associate_both_rules(fe, o, q, m)
     assert (dist <= 2).all() and (np.diff(np.sort(idx)) >= 0).all()
 
 
@@ -657,9 +665,7 @@ def test_associate_odd_sizes_match_matcher_semantics():
             for b in bits:
                 src[b >> 3] ^= 1 << (b & 7)
             q[i] = src
-        idx, dist = fe.associate(q, m)
-        oi, od = o.match(q, m)
-        assert np.array_equal(dist, od) and np.array_equal(idx, oi), (nq, nm)
+        _associate_both_rules(fe, o, q, m)
 
 
 @pytest.mark.gpu

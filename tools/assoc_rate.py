@@ -15,6 +15,7 @@ from lane_slam_amd import LineAssociator, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--pairs", default="4096x50000,16384x50000,65536x50000,65536x262144")
 ap.add_argument("--gating", action="store_true", help="colour-gated association (same kernel, colour terms in the ninth MFMA step)")
+ap.add_argument("--tie-rule", default="lowest", choices=("lowest", "mihasher"), help="mihasher: + the tie-ranking pass (k_assoc_ties.hip)")
 ap.add_argument("--reps", type=int, default=20)
 args = ap.parse_args()
 torch.cuda.init()
@@ -22,7 +23,7 @@ PEAK = 5.0e15          # dense int8 MFMA peak (ops/s); the FP4 peak is twice tha
 int8_forced = os.environ.get("LF_ASSOC_INT8") is not None
 for pair in args.pairs.split(","):
     n, m = (int(v) for v in pair.split("x"))
-    am = LineAssociator(capacity=max(64, m), color_gating=args.gating, kept_only=False)
+    am = LineAssociator(capacity=max(64, m), color_gating=args.gating, kept_only=False, tie_rule=args.tie_rule)
     rng = np.random.default_rng(3)
     am.seed(synth.random_codes(m, 2), rng.integers(0, 3, m).astype(np.uint8))
     q = torch.from_numpy(synth.random_codes(n, 1)).cuda()
@@ -45,8 +46,8 @@ for pair in args.pairs.split(","):
     ops = 2.0 * n * m * 256
     fp4 = not int8_forced          # v_mfma_scale_f32_32x32x64_f8f6f4 with e2m1 operands (LF_ASSOC_INT8=1: the int8 kernels, for A/B)
     rate = ops / (core * 1e-3)
-    print("N=%6d M=%7d%s: assoc %.4f ms (one launch: query expansion, MFMA, merge, report)  %.2f Pop/s  %s"
-          % (n, m, " gated" if args.gating else "", core, rate / 1e15,
+    print("N=%6d M=%7d%s%s: assoc %.4f ms (one launch: query expansion, MFMA, merge, report)  %.2f Pop/s  %s"
+          % (n, m, " gated" if args.gating else "", " tie_rule=mihasher (two passes)" if args.tie_rule == "mihasher" else "", core, rate / 1e15,
              ("FP4 kernel: %.1f %% of the 10 Pop/s dense FP4 peak (= %.1f %% of the 5 Pop/s int8 peak the int8 kernel is priced against)" % (100 * rate / (2 * PEAK), 100 * rate / PEAK))
              if fp4 else ("int8 kernel: %.1f %% of the 5 Pop/s dense int8 MFMA peak" % (100 * rate / PEAK))))
     am.close()
