@@ -13,8 +13,8 @@
 // On the MI355X the distance pass (k_assoc.hip) has already produced every query's minimum distance.  This second pass
 // recomputes the N x M dot products on the FP4 matrix instruction from the SAME packed map operands, compares every
 // accumulator value with its row's known optimum (one v_cmp per register, masks OR-ed on the scalar side), and only the
-// (rare) equal ones -- the ties -- leave the matrix pipeline: their discovery key is worked out from the raw codes and
-// folded with a 64-bit atomic minimum (key << 32 | index), first in LDS, then once per query and map chunk in memory.
+// (rare) equal ones -- the ties -- leave the matrix pipeline: their discovery key is worked out from the query's raw code and
+// the map row's nibbles, both in LDS, and folded with a 64-bit atomic minimum (key << 32 | index), first in LDS, then once per query and map chunk in memory.
 #include "common.h"
 
 namespace lf {
@@ -58,37 +58,71 @@ void mih_rank_host(uint8_t out[5][256])
     for (int s = 0; s < 5; ++s) for (int i = 0; i < 256; ++i) out[s][i] = t.r[s][i];
 }
 
-__device__ __noinline__ uint32_t mih_discovery_key(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b)
+constexpr int TQW = 256;          // queries per workgroup: 4 waves x 2 row blocks x 32
+constexpr int TGROUP = 4;         // 64-row map tiles (8 KB of e2m1 rows each) per LDS buffer: a group's matrix work (~1.5 us) covers the next group's fetch
+constexpr int TSETS = TGROUP * 4; // accumulator sets per group: tile x column block x row block
+
+// eight e2m1 nibbles (0x2 = bit 0, 0xA = bit 1) -> the code byte they were expanded from (assoc_fp4_expand's inverse)
+__device__ __forceinline__ uint32_t fp4_collapse(uint32_t w)
 {
-    const uint4 a0 = *reinterpret_cast<const uint4*>(a), a1 = *reinterpret_cast<const uint4*>(a + 16);
-    const uint4 b0 = *reinterpret_cast<const uint4*>(b), b1 = *reinterpret_cast<const uint4*>(b + 16);
-    const uint32_t x[8] = { a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w, a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w };
-    uint32_t best = 0xffffffffu;
-#pragma unroll
-    for (int d = 0; d < 8; ++d)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const uint32_t xb = (x[d] >> (8 * t)) & 255u;
-            const int h = __popc(xb);
-            if (h <= 4) {
-                const uint32_t kk = ((uint32_t)(h * 32 + 4 * d + t) << 8) | c_mih_rank.r[h][xb];
-                best = kk < best ? kk : best;
-            }
-        }
-    return best;
+    uint32_t t = (w >> 3) & 0x11111111u;
+    t = (t | (t >> 3)) & 0x03030303u;
+    t = (t | (t >> 6)) & 0x000f000fu;
+    return (t | (t >> 12)) & 0xffu;
 }
 
-constexpr int TQW = 256;          // queries per workgroup: 4 waves x 2 row blocks x 32
-constexpr int TGROUP = 2;         // 64-row map tiles (8 KB of e2m1 rows each) per LDS buffer
+// The lanes whose bit is set in `hits` hold, in accumulator register r, a candidate as near as its row's optimum: work out
+// its discovery key -- the smallest (weight, substring) over the 32 byte substrings, then ONE table lookup for the place of that
+// substring's difference in the enumeration -- from the query's raw code (LDS copy) and the map row's nibbles in the LDS tile,
+// and fold it into the query's running minimum.  Rare; kept out of line so the matrix loop stays small.
+template <bool GATED>
+__device__ __noinline__ void ties_fold(uint32_t hits, int col, int col_in_tile, int row_base, const uint8_t* tile, const uint32_t* qraw,
+                                       const uint8_t* __restrict__ qcolor, const uint8_t* __restrict__ mcolor, int q_first, int nq,
+                                       unsigned long long* s_res)
+{
+    while (hits) {
+        const int r = __ffs(hits) - 1;
+        hits &= hits - 1;
+        const int ql = row_base + (r & 3) + 8 * (r >> 2);
+        const int qg = q_first + ql;
+        if (qg >= nq) continue;
+        if (GATED) {
+            const int qc = qcolor[qg], mc = mcolor[col];
+            if (qc < 3 && mc < 3 && qc != mc) continue;
+        }
+        uint32_t best = 0xffffffffu, bx = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {                            // 16-byte chunk c of the row's 128 bytes = code bytes 4 c .. 4 c + 3
+            const uint4 w = *reinterpret_cast<const uint4*>(tile + c * 1024 + col_in_tile * 16);
+            const uint32_t mb = fp4_collapse(w.x) | (fp4_collapse(w.y) << 8) | (fp4_collapse(w.z) << 16) | (fp4_collapse(w.w) << 24);
+            const uint32_t x = mb ^ qraw[ql * 8 + c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t xb = (x >> (8 * t)) & 255u;
+                const uint32_t hk = (uint32_t)__popc(xb) * 32u + (uint32_t)(4 * c + t);        // (weight, substring)
+                if (hk < best) { best = hk; bx = xb; }
+            }
+        }
+        const uint32_t h = best >> 5;
+        if (h > 4) continue;                                     // cannot happen within 128 bits; the reference would never meet it
+        const uint32_t key = (best << 8) | c_mih_rank.r[h][bx];
+        atomicMin(&s_res[ql], ((unsigned long long)key << 32) | (uint32_t)col);
+    }
+}
 
 template <bool GATED>
-__global__ __launch_bounds__(256) void k_assoc_ties(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
-                                                    const int8_t* __restrict__ mx, const uint8_t* __restrict__ mcode,
-                                                    const uint8_t* __restrict__ mcolor, int nm_bound, const int* __restrict__ nm_dev,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_ties(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
+                                                    const int8_t* __restrict__ mx, const uint8_t* __restrict__ mcolor,
+                                                    int nm_bound, const int* __restrict__ nm_dev,
                                                     int nm_pad, int m_chunk, const float* __restrict__ dist,
                                                     unsigned long long* __restrict__ res)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t tiles[2][TGROUP * 8192];
+    // two buffers of TGROUP map tiles, filled by LDS-DMA (global_load_lds: 64 lanes x 16 bytes = 1 KB of a tile per instruction
+    // and wave, no staging registers); separate arrays and a loop unrolled by two, so that the compiler can tell the buffer being
+    // filled from the one being read
+    __shared__ __attribute__((aligned(1024))) uint8_t tiles_a[TGROUP * 8192];
+    __shared__ __attribute__((aligned(1024))) uint8_t tiles_b[TGROUP * 8192];
+    __shared__ __attribute__((aligned(16))) uint32_t qraw[TQW * 8];
     __shared__ unsigned long long s_res[TQW];
     __shared__ uint32_t xtab[256];
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
@@ -97,105 +131,109 @@ __global__ __launch_bounds__(256) void k_assoc_ties(const uint8_t* __restrict__ 
     const int r32 = lane & 31, half = lane >> 5;
     const int m_begin = blockIdx.y * m_chunk;
     const int m_end = min(nm_pad, m_begin + m_chunk);
-    const int n_tiles = (m_end - m_begin) / 64;
+    const int n_tiles = __builtin_amdgcn_readfirstlane((m_end - m_begin) / 64);
     if (n_tiles <= 0 || m_begin >= nm) return;
-    xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
-    s_res[threadIdx.x] = ~0ull;
-    // first group of tiles on its way while the query side is set up
     const uint8_t* src = reinterpret_cast<const uint8_t*>(mx) + (size_t)(m_begin / 64) * 8192;
     const int n_groups = (n_tiles + TGROUP - 1) / TGROUP;
-    uint4 stage[TGROUP * 2];
-    auto fetch = [&](int g) {
+    auto fetch = [&](int g, uint8_t* dst) {
 #pragma unroll
         for (int k = 0; k < TGROUP * 2; ++k) {
-            const int off = k * 4096 + threadIdx.x * 16;
-            stage[k] = (g * TGROUP + (off >> 13)) < n_tiles ? *reinterpret_cast<const uint4*>(src + (size_t)g * (TGROUP * 8192) + off) : make_uint4(0, 0, 0, 0);
+            const int off = k * 4096 + wave * 1024;
+            if (g * TGROUP + (off >> 13) < n_tiles)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * (TGROUP * 8192) + off + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
         }
     };
-    auto park = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < TGROUP * 2; ++k) *reinterpret_cast<uint4*>(&tiles[buf][k * 4096 + threadIdx.x * 16]) = stage[k];
-    };
-    fetch(0);
+    fetch(0, tiles_a);
+    xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
+    s_res[threadIdx.x] = ~0ull;
+    {
+        // the workgroup's 256 raw query codes (8 KB): thread t copies query t
+        const int qi = blockIdx.x * TQW + threadIdx.x;
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+        if (qi < nq) { c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32); c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16); }
+        *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8]) = c0;
+        *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8 + 4]) = c1;
+    }
     __syncthreads();
     // query operands: step s, k-half `half` = code dword 2 s + half, eight e2m1 nibbles per code byte (k_assoc.hip)
     v8i A[2][4];
-    float tgt[2][16];
+    // Every chain STARTS at 0.5 - (the dot product a tie has = 256 - 2 * the row's minimum distance), so a tie ends at exactly
+    // +0.5, every other candidate at k + 0.5 with k a non-zero integer (all exact in f32), and rows without a match near -3e38.
+    // Read as unsigned integers, +0.5 (0x3f000000) is then the SMALLEST value an accumulator can hold -- positive floats order
+    // like their bit patterns, negative ones lie above them all -- so "is there a tie among these registers" is an unsigned
+    // minimum (v_min3_u32: two registers per instruction) and one compare, instead of a compare and a scalar OR per register.
+    v16f start[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-        const int qi = q0 + 32 * b + r32;
-        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-        if (qi < nq) {
-            c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32);
-            c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16);
-        }
-        const uint32_t w4[4] = { half ? c0.y : c0.x, half ? c0.w : c0.z, half ? c1.y : c1.x, half ? c1.w : c1.z };
+        const uint32_t* c = &qraw[(wave * 64 + 32 * b + r32) * 8];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const uint32_t w = w4[s];
+            const uint32_t w = c[2 * s + half];
             A[b][s] = v8i{ (int)xtab[w & 0xffu], (int)xtab[(w >> 8) & 0xffu], (int)xtab[(w >> 16) & 0xffu], (int)xtab[w >> 24], 0, 0, 0, 0 };
         }
-        // the dot product a tie has: 256 - 2 * (the row's minimum distance); rows without a match never compare equal
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = q0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
             const float d = qr < nq ? dist[qr] : -1.f;
-            tgt[b][r] = d >= 0.f ? 256.f - 2.f * d : 3.0e38f;
+            start[b][r] = d >= 0.f ? 0.5f - (256.f - 2.f * d) : -3.0e38f;
         }
     }
-    park(0);
-    __syncthreads();
-    for (int g = 0; g < n_groups; ++g) {
-        const int buf = g & 1;
-        if (g + 1 < n_groups) fetch(g + 1);
+    // accumulator sets: (tile tl of the group, column block cb, row block b) -> 16 dot products per lane; the two row blocks of a
+    // column block share its fragments and run as two interleaved chains
+    auto dots2 = [&](const uint8_t* tiles, int tl, int cb, v16f& acc0, v16f& acc1) {
+        const uint8_t* fb = tiles + tl * 8192 + half * 1024 + (cb * 32 + r32) * 16;
+        acc0 = start[0]; acc1 = start[1];
 #pragma unroll
-        for (int tl = 0; tl < TGROUP; ++tl) {
-            if (g * TGROUP + tl < n_tiles)
+        for (int s = 0; s < 4; ++s) {
+            const v4i f = *reinterpret_cast<const v4i*>(fb + s * 2048);
+            const v8i B = v8i{ f.x, f.y, f.z, f.w, 0, 0, 0, 0 };
+            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0][s], B, acc0, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[1][s], B, acc1, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+    };
+    constexpr uint32_t kTie = 0x3f000000u;          // +0.5
+    auto umin16 = [](const v16f& a, uint32_t m) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const uint8_t* fb = &tiles[buf][tl * 8192 + half * 1024 + (cb * 32 + r32) * 16];
-                v8i B[4];
+        for (int r = 0; r < 16; r += 2) m = min(m, min(__float_as_uint(a[r]), __float_as_uint(a[r + 1])));
+        return m;
+    };
+    auto group = [&](int g, const uint8_t* tiles, uint8_t* next) {
+        if (g + 1 < n_groups) fetch(g + 1, next);
+        // the matrix loop proper: no branch inside -- which column blocks saw a tie anywhere in the wave is kept as a scalar bit mask
+        uint32_t sets = 0;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const v4i f = *reinterpret_cast<const v4i*>(fb + s * 2048);
-                    B[s] = v8i{ f.x, f.y, f.z, f.w, 0, 0, 0, 0 };
-                }
+        for (int pair = 0; pair < TSETS / 2; ++pair) {
+            v16f acc0, acc1;
+            dots2(tiles, pair >> 1, pair & 1, acc0, acc1);
+            const uint32_t m = umin16(acc1, umin16(acc0, 0xffffffffu));
+            sets |= (__builtin_amdgcn_ballot_w64(m == kTie) != 0 ? 3u : 0u) << (2 * pair);
+        }
+        if (g * TGROUP + TGROUP > n_tiles) sets &= (1u << (4 * (n_tiles - g * TGROUP))) - 1u;      // a group's tiles past the chunk's end
+        if (sets) {
+            // candidates as near as their row's optimum (rare): recompute the set, find the registers, fold the keys
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    v16f acc = { 0 };
+            for (int set = 0; set < TSETS; ++set) {
+                if (!(sets & (1u << set))) continue;
+                const int tl = set >> 2, cb = (set >> 1) & 1, b = set & 1;
+                v16f acc0, acc1;
+                dots2(tiles, tl, cb, acc0, acc1);
+                const v16f acc = b ? acc1 : acc0;
+                uint32_t hits = 0;
 #pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[b][s], B[s], acc, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                    unsigned long long any = 0;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) any |= __builtin_amdgcn_ballot_w64(acc[r] == tgt[b][r]);
-                    if (any) {
-                        // candidates as near as their row's optimum: which registers of this lane, then one at a time
-                        uint32_t hits = 0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) hits |= (acc[r] == tgt[b][r] ? 1u : 0u) << r;
-                        const int col = m_begin + (g * TGROUP + tl) * 64 + cb * 32 + r32;
-                        if (col >= nm) hits = 0;
-                        while (hits) {
-                            const int r = __ffs(hits) - 1;
-                            hits &= hits - 1;
-                            const int ql = wave * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const int qg = blockIdx.x * TQW + ql;
-                            if (qg >= nq) continue;
-                            if (GATED) {
-                                const int qc = qcolor[qg], mc = mcolor[col];
-                                if (qc < 3 && mc < 3 && qc != mc) continue;
-                            }
-                            // its discovery key, from the raw codes
-                            const uint32_t key = mih_discovery_key(q + (size_t)qg * 32, mcode + (size_t)col * 32);
-                            atomicMin(&s_res[ql], ((unsigned long long)key << 32) | (uint32_t)col);
-                        }
-                    }
-                }
+                for (int r = 0; r < 16; ++r) hits |= (__float_as_uint(acc[r]) == kTie ? 1u : 0u) << r;
+                const int col = m_begin + (g * TGROUP + tl) * 64 + cb * 32 + r32;
+                if (col >= nm) hits = 0;
+                if (__builtin_amdgcn_ballot_w64(hits != 0))
+                    ties_fold<GATED>(hits, col, cb * 32 + r32, wave * 64 + 32 * b + 4 * half, tiles + tl * 8192, qraw, qcolor, mcolor,
+                                     blockIdx.x * TQW, nq, s_res);
             }
         }
-        if (g + 1 < n_groups) park(buf ^ 1);
         __syncthreads();
+    };
+    for (int g = 0; g < n_groups; g += 2) {
+        group(g, tiles_a, tiles_b);
+        if (g + 1 < n_groups) group(g + 1, tiles_b, tiles_a);
     }
     const unsigned long long mine = s_res[threadIdx.x];
     const int qg = blockIdx.x * TQW + threadIdx.x;
@@ -211,7 +249,8 @@ __global__ void k_assoc_ties_finish(int nq, const unsigned long long* __restrict
 }
 
 // After launch_assoc_core on the same stream: replaces idx (the lowest index among the equally near) by the index the
-// reference's search finds first.  mcode / mcolor: the map's RAW codes and colours (colours only with gating).  res: nq u64.
+// reference's search finds first.  mx: the map's packed e2m1 rows (the raw bits are read back from them); mcolor: the map's raw
+// colours (gating only; mcode is not read).  res: nq u64.
 hipError_t launch_assoc_ties(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const uint8_t* mcode, const uint8_t* mcolor,
                              int nm, const int* nm_dev, int gating, unsigned long long* res, int32_t* idx, const float* dist, hipStream_t s)
 {
@@ -228,8 +267,8 @@ hipError_t launch_assoc_ties(const uint8_t* q, const uint8_t* qcolor, int nq, co
     splits = (nm_pad + m_chunk - 1) / m_chunk;
     hipError_t e = hipMemsetAsync(res, 0xff, (size_t)nq * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    if (gating) hipLaunchKernelGGL(k_assoc_ties<true>, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, dist, res);
-    else hipLaunchKernelGGL(k_assoc_ties<false>, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, dist, res);
+    if (gating) hipLaunchKernelGGL(k_assoc_ties<true>, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcolor, nm, nm_dev, nm_pad, m_chunk, dist, res);
+    else hipLaunchKernelGGL(k_assoc_ties<false>, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcolor, nm, nm_dev, nm_pad, m_chunk, dist, res);
     hipLaunchKernelGGL(k_assoc_ties_finish, dim3((nq + 255) / 256), dim3(256), 0, s, nq, res, idx);
     return hipGetLastError();
 }
