@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define LF_ABI_VERSION 4   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages; 3: live map (lf_map_*); 4: EDLines / KeyLines, block overflow marker */
+#define LF_ABI_VERSION 5   /* 2: JPEG ingest, SegmentList glue, LF_ERR_DECODE, 13 timing stages; 3: live map (lf_map_*); 4: EDLines / KeyLines, block overflow marker; 5: lf_config.lsd_seed_order, tie rules */
 
 typedef enum lf_status {
     LF_OK = 0,
@@ -76,7 +76,18 @@ typedef struct lf_config {
     double H[9], K[9], D[5], R[9], P[12];
     int32_t cam_w, cam_h;
     double lanewidth, linewidth_white, linewidth_yellow, d_min, d_max, phi_min, phi_max;
+    /* Which OpenCV's LSD seed order (line_detector_lsd.py:64-72 calls cv2's detector; region growing depends on the order in
+     * which equally strong pixels seed regions):
+     *   LF_LSD_SEED_OPENCV30  3.0 / 3.1: per-bin lists, raster order inside a gradient bin (one counting sort).
+     *   LF_LSD_SEED_OPENCV32  3.2 ... 3.4.5 -- ROS Kinetic's 3.3.1, the stack the reference names (README.md:54): every pixel of
+     *                         the gradient image sorted with std::sort(compare_norm); inside a bin the order is what libstdc++'s
+     *                         introsort leaves, reproduced on the device move for move (k_lsd_seed32.hip).  Working images up
+     *                         to 2^18 LSD pixels (640x480 and below); larger ones: LF_ERR_UNSUPPORTED at lf_create. */
+    int32_t lsd_seed_order;
+    int32_t reserved0;             /* 0 */
 } lf_config;
+#define LF_LSD_SEED_OPENCV30 0
+#define LF_LSD_SEED_OPENCV32 1
 
 typedef struct lf_handle lf_handle;
 
@@ -479,6 +490,10 @@ int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps);
 /* LSD stages alone on a binary image of the handle's working size (non-zero = edge pixel, colour
  * mask forced to all ones); host pointers; lines before normal-based endpoint ordering */
 int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out);
+/* the sort emulation behind lsd_seed_order = LF_LSD_SEED_OPENCV32 alone: order[i] = index of the element that
+ * std::sort(begin, end, [](a, b) { return a.key > b.key; }) of libstdc++ leaves at place i, for n keys in [0, 1023] in their
+ * initial order (host pointers; n < 2^20) */
+int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order);
 /* scaled LSD image size for this handle */
 int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
 

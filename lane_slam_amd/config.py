@@ -15,6 +15,9 @@ Every default below is a constant of the reference, cited by file:line
 import copy
 import ctypes
 
+# LSD seed order inside a gradient bin (include/lanefront.h, lf_config.lsd_seed_order): OpenCV 3.0 / 3.1 keep raster order,
+# 3.2 ... 3.4.5 (ROS Kinetic's 3.3.1) leave what std::sort leaves
+LSD_SEED_ORDERS = {"opencv30": 0, "opencv32": 1}
 WHITE, YELLOW, RED = 0, 1, 2          # src/duckietown_msgs/msg/Segment.msg:1-3
 COLOR_NAMES = ("white", "yellow", "red")
 
@@ -107,6 +110,7 @@ class LfConfig(ctypes.Structure):
         ("lanewidth", ctypes.c_double), ("linewidth_white", ctypes.c_double),
         ("linewidth_yellow", ctypes.c_double), ("d_min", ctypes.c_double),
         ("d_max", ctypes.c_double), ("phi_min", ctypes.c_double), ("phi_max", ctypes.c_double),
+        ("lsd_seed_order", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -139,6 +143,10 @@ def fill_struct(s, cfg):
     s.cam_h, s.cam_w = cfg["cam_size"]
     for k, v in cfg["sanity"].items():
         setattr(s, k, float(v))
+    order = lsd.get("seed_order", "opencv30")
+    if order not in LSD_SEED_ORDERS:
+        raise ValueError("lsd.seed_order must be one of %r" % (sorted(LSD_SEED_ORDERS),))
+    s.lsd_seed_order = LSD_SEED_ORDERS[order]
     return s
 
 

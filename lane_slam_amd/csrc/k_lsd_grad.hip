@@ -92,12 +92,13 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
                                                   double* __restrict__ r_cs, double* __restrict__ r_sn,
                                                   int* __restrict__ n_rec, unsigned long long* __restrict__ maxgrad,
                                                   int max_nsx, int max_nsy, const uint32_t* __restrict__ list,
-                                                  const int* __restrict__ list_count)
+                                                  const int* __restrict__ list_count,
+                                                  uint32_t* __restrict__ l_addr, double* __restrict__ l_mod, int* __restrict__ n_low)
 {
     extern __shared__ double lds_d[];
     __shared__ double T[128];                     // ordered partial sums of k[j]*255 per 7-bit pattern
     __shared__ unsigned long long rowbits[GT * 2 + 2 * kMaxGaussTaps];
-    __shared__ int n_def, rec_base;
+    __shared__ int n_def, rec_base, n_lo, low_base;
     __shared__ unsigned long long tile_max;
     __shared__ int t_xofs[GT + 1], t_y0[GT + 1], t_y1[GT + 1];
     __shared__ float t_xa[2 * (GT + 1)], t_yb[2 * (GT + 1)];
@@ -118,13 +119,18 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
     const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx;
     const size_t szHb = (size_t)max_nsy * (GT + 1);
     size_t regA = szF > szHb ? szF : szHb;
-    if (regA < (size_t)2 * GT * GT) regA = (size_t)2 * GT * GT;      // also hosts the defined-pixel list (8 + 8 B entries)
+    // also hosts the defined-pixel list (8 + 8 B entries) and, for the OpenCV >= 3.2 seed order (k_lsd_seed32.hip), the list of the
+    // pixels whose gradient is NOT defined but not zero either (8 + 4 B entries): std::sort there orders every pixel
+    const size_t min_a = (size_t)(l_addr ? 4 : 2) * GT * GT;
+    if (regA < min_a) regA = min_a;
     double* F = lds_d;                                   // [rh][nsx]     row-filtered
     double* Bl = lds_d + regA;                           // [nsy][nsx]    blurred
     double* Hb = lds_d;                                  // [nsy][GT+1]   h-resized   (reuses F)
     double* Sc = lds_d + regA;                           // [GT+1][GT+1]  v-resized   (reuses Bl)
     uint2* dl = reinterpret_cast<uint2*>(lds_d);         // defined pixels (address, angle): reuses F/Hb once Sc is built
     double* dln = lds_d + (size_t)GT * GT;               // their gradient magnitudes
+    double* lln = lds_d + (size_t)2 * GT * GT;           // "low" pixels: magnitude, address
+    uint32_t* lla = reinterpret_cast<uint32_t*>(lds_d + (size_t)3 * GT * GT);
     const size_t Ps = (size_t)p.Hs * p.Ws;
     const double DEG_TO_RADS = 3.14159265358979323846 / 180;
 
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         const int rw = nsx + 2 * h, rh = nsy + 2 * h;
         const uint32_t* mk = mask_bits + (size_t)pc * p.Hc * p.Ww;
         const uint32_t* eb = edge_bits + (size_t)f * p.Hc * p.Ww;
-        if (threadIdx.x == 0) { n_def = 0; tile_max = 0ull; }
+        if (threadIdx.x == 0) { n_def = 0; n_lo = 0; tile_max = 0ull; }
         // this tile's slice of the resize tables -> LDS (no dependent global loads in the passes below)
         if (threadIdx.x < nox) {
             const int dx = X0 + threadIdx.x;
@@ -260,6 +266,10 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
                         const int slot = atomicAdd(&n_def, 1);
                         dl[slot] = make_uint2((uint32_t)a, (uint32_t)(oy * (GT + 1) + ox));
                         dln[slot] = norm;
+                    } else if (l_addr) {
+                        const int slot = atomicAdd(&n_lo, 1);
+                        lla[slot] = (uint32_t)a;
+                        lln[slot] = norm;
                     }
                 }
             }
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         if (threadIdx.x == 0) {
             if (tile_max) atomicMax(maxgrad + pc, tile_max);
             rec_base = nd ? atomicAdd(n_rec + pc, nd) : 0;        // reserve this tile's slots in the problem's record list
+            low_base = (l_addr && n_lo) ? atomicAdd(n_low + pc, n_lo) : 0;
         }
         __syncthreads();
         // one record per defined pixel; cos/sin of the float-rounded angle (what region growing
@@ -297,29 +308,35 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
             r_cs[rb + e] = c_;
             r_sn[rb + e] = s_;
         }
+        if (l_addr) {
+            const size_t lb = (size_t)pc * Ps + low_base;
+            for (int e = threadIdx.x; e < n_lo; e += LG_T) { l_addr[lb + e] = lla[e]; l_mod[lb + e] = lln[e]; }
+        }
     }
 }
 
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
                      const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
                      int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
-                     hipStream_t s)
+                     uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s)
 {
     const int h = p.half;
     const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
     const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
     size_t regA = szF > szHb ? szF : szHb;
-    if (regA < (size_t)2 * GT * GT) regA = (size_t)2 * GT * GT;
+    const size_t min_a = (size_t)(l_addr ? 4 : 2) * GT * GT;
+    if (regA < min_a) regA = min_a;
     const size_t regB = szBl > szSc ? szBl : szSc;
     const size_t lds = sizeof(double) * (regA + regB);
     dim3 grid((p.Hs + GT - 1) / GT, n_frames * 3);
     (void)hipMemsetAsync(list_count, 0, sizeof(int), s);
     (void)hipMemsetAsync(n_rec, 0, (size_t)n_frames * 3 * sizeof(int), s);
+    if (n_low) (void)hipMemsetAsync(n_low, 0, (size_t)n_frames * 3 * sizeof(int), s);
     hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, list, list_count);
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(LG_T), lds, s, p, rt, edge_bits, mask_bits, r_addr, r_deg, r_mod, r_cs,
-                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count);
+                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low);
 }
 
 }  // namespace lf

@@ -1,0 +1,485 @@
+// K_lsd_seed32: the LSD seed order of OpenCV 3.2 ... 3.4.5 (the reference's stack: ROS Kinetic = 3.3.1) on the device.
+//
+// Reference call site: /root/reference/src/line_detector/include/line_detector/line_detector_lsd.py:64-72 (cv2
+// createLineSegmentDetector(REFINE_ADV).detect).  From 3.2 on ll_angle pushes one normPoint {x, y, norm = int(modgrad *
+// bin_coef)} per pixel of the (H-1) x (W-1) gradient image in raster order -- pixels WITHOUT a defined gradient included -- and
+// orders the list with   std::sort(ordered_points.begin(), ordered_points.end(), compare_norm)   (n1.norm > n2.norm).
+// std::sort is not stable: inside a bin the seeds come in whatever order libstdc++'s introsort leaves them in, and region
+// growing depends on the seed order.  (OpenCV 3.0 / 3.1 kept per-bin lists in raster order: k_lsd_order.hip, the other setting.)
+//
+// What libstdc++ does (bits/stl_algo.h: __sort = __introsort_loop(first, last, 2 * floor(log2 n)) + __final_insertion_sort):
+//   introsort loop   while a range holds more than 16 elements: (depth limit used up: heap sort the range, done); the median of
+//                    first + 1, middle, last - 1 goes to `first` (__move_median_to_first), __unguarded_partition of
+//                    [first + 1, last) around it returns `cut`; recurse into [cut, last), go on with [first, cut).
+//   final insertion  a plain insertion sort of the whole array = a STABLE sort by key of what the loop left.
+// The ranges of the loop are disjoint, so they may be partitioned in any order or at the same time; only each partition has
+// to move exactly the elements the sequential one moves.  __unguarded_partition:
+//       for (;;) { while (comp(*first, pivot)) ++first;  --last;  while (comp(pivot, *last)) --last;
+//                  if (!(first < last)) return first;  iter_swap(first, last);  ++first; }
+// The left scan only ever stops on elements with !comp(x, pivot) (key <= pivot's: "L" elements), the right scan on elements
+// with !comp(pivot, x) (key >= pivot's: "R"), and until the pointers cross neither sees an element the other has moved.  So
+// the k-th L element from the left is swapped with the k-th R element from the right for k = 1 .. K, K = the number of k
+// with L_k < R_k, and cut = L_1 when K = 0, else min(L_{K+1}, R_K)  (after the K-th swap the left pointer stops at the next
+// L element or at R_K, which now holds one).  Ranks come from ballots and prefix sums; the partner R_k of a swapped L_k is
+// found by a binary search in the suffix counts and a bit select in its row's ballot word.
+//
+// One workgroup per problem (frame, colour).  Elements are u32: bin << 20 | payload (compact index + 1 of a pixel with a
+// defined gradient, 0 for the others: only seeds need to be told apart, the sort's decisions depend on keys alone).
+//   phase 0  the array: zeros (flat pixels: bin 0), the defined pixels from the compact arrays of k_lsd_order, the
+//            undefined pixels with a non-zero gradient from k_lsd_grad's "low" records
+//   phase 1  ranges of more than kSmall elements: the whole workgroup partitions one range at a time (rows of 64 elements
+//            dealt to the waves, row tables in LDS)
+//   phase 2  every wave takes ranges of at most kSmall elements from a list and works off their whole subtree alone
+//   phase 3  the seeds in the order the loop left them, compacted, then the final insertion sort as stable 4-bit counting
+//            passes over the bin key -> order_a, the seed list k_lsd_grow reads
+// The heap sort of a range that used up the depth limit (never seen on image data; tested with adversarial keys through
+// lf_debug_std_sort) is libstdc++'s __heap_select + __sort_heap replayed by one lane.
+#include <cstdlib>
+#include "common.h"
+
+namespace lf {
+
+constexpr int ST = 512;              // threads: 8 waves
+constexpr int SW = ST / 64;
+constexpr int kSmall = 2048;         // ranges up to this size are one wave's work (32 rows)
+constexpr int kSortThreshold = 16;   // libstdc++ _S_threshold
+constexpr int kMaxLdsBytes = 150 * 1024;
+constexpr int SNB = 16;              // buckets of the final counting passes
+constexpr int kWaveWords = 2 * 34 * 2 + 34 + 36 + 4 + 128 + 2;      // one wave's private row tables + range stack (phase 2), 32-bit words
+
+__device__ __forceinline__ uint32_t key_of(uint32_t v) { return v >> 20; }
+// compare_norm(a, b) = a.norm > b.norm
+__device__ __forceinline__ bool comp(uint32_t a, uint32_t b) { return key_of(a) > key_of(b); }
+
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int n = __shfl_up(v, d);
+        if (lane >= d) v += n;
+    }
+    return v;
+}
+
+// position of the t-th (1-based) set bit of b counted from bit 63 downwards: the largest p with popcount(b >> p) >= t
+__device__ __forceinline__ int select_from_top(unsigned long long b, int t)
+{
+    int pos = 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1)
+        if (__popcll(b >> (pos + s)) >= t) pos += s;
+    return pos;
+}
+
+// __move_median_to_first(result = f, a = f + 1, b = mid, c = l - 1)
+__device__ __forceinline__ void median_to_first(uint32_t* E, int f, int l)
+{
+    const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+    const uint32_t a = E[ia], b = E[ib], c = E[ic];
+    int pick;
+    if (comp(a, b)) pick = comp(b, c) ? ib : (comp(a, c) ? ic : ia);
+    else pick = comp(a, c) ? ia : (comp(b, c) ? ic : ib);
+    const uint32_t r = E[f], p = E[pick];
+    E[f] = p;
+    E[pick] = r;
+}
+
+// ---- libstdc++'s heap sort of [f, l) (std::__partial_sort(first, last, last)), one lane -----------------------------------
+__device__ void push_heap_(uint32_t* A, int hole, int top, uint32_t value)
+{
+    int parent = (hole - 1) / 2;
+    while (hole > top && comp(A[parent], value)) {
+        A[hole] = A[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    A[hole] = value;
+}
+__device__ void adjust_heap_(uint32_t* A, int hole, int len, uint32_t value)
+{
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (comp(A[child], A[child - 1])) --child;
+        A[hole] = A[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        A[hole] = A[child - 1];
+        hole = child - 1;
+    }
+    push_heap_(A, hole, top, value);
+}
+__device__ __noinline__ void heap_sort_range(uint32_t* E, int f, int l)
+{
+    uint32_t* A = E + f;
+    const int len = l - f;
+    if (len < 2) return;
+    for (int parent = (len - 2) / 2;; --parent) {            // __make_heap
+        adjust_heap_(A, parent, len, A[parent]);
+        if (parent == 0) break;
+    }
+    for (int last = len - 1; last > 0; --last) {              // __sort_heap: __pop_heap(first, last, last)
+        const uint32_t value = A[last];
+        A[last] = A[0];
+        adjust_heap_(A, 0, last, value);
+    }
+}
+
+// Row tables of one partition: BL / BR the ballots of the L and R elements of every 64-element row of [lo, hi), PL[r] the L
+// elements in rows < r, SX[r] the R elements in rows >= r (SX[R] = 0).
+struct RowTables { unsigned long long* BL; unsigned long long* BR; int* PL; int* SX; int* acc; /* [0] K [1] first L [2] first unswapped L [3] lowest partner */ };
+
+// __unguarded_partition of [f + 1, l) around E[f] (already the median) by `nw` waves of which this is number `w`
+// (COOP: the workgroup's eight with barriers in between; otherwise one wave alone).  Returns the cut.
+template <bool COOP>
+__device__ __forceinline__ int partition_range(uint32_t* E, int f, int l, const RowTables& T, int w, int nw, int lane)
+{
+    const int lo = f + 1, hi = l;
+    const int R = (hi - lo + 63) >> 6;
+    const uint32_t pivot = E[f];
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
+    if ((COOP ? threadIdx.x : lane) == 0) { T.acc[0] = 0; T.acc[1] = 0x7fffffff; T.acc[2] = 0x7fffffff; T.acc[3] = 0x7fffffff; }
+    for (int r = w; r < R; r += nw) {
+        const int i = lo + r * 64 + lane;
+        const bool valid = i < hi;
+        const uint32_t v = valid ? E[i] : 0u;
+        const unsigned long long bl = __ballot(valid && !comp(v, pivot));
+        const unsigned long long br = __ballot(valid && !comp(pivot, v));
+        if (lane == 0) { T.BL[r] = bl; T.BR[r] = br; T.PL[r] = __popcll(bl); T.SX[r] = __popcll(br); }
+    }
+    if (COOP) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    // exclusive prefix of the L counts (first wave of the team), inclusive suffix of the R counts (its second wave, or the same)
+    if (w == 0) {
+        int carry = 0;
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            const int r = r0 + lane;
+            const int c = r < R ? T.PL[r] : 0;
+            const int inc = wave_incl_scan_i(c, lane);
+            if (r < R) T.PL[r] = carry + inc - c;
+            carry += __shfl(inc, 63);
+        }
+    }
+    if (w == (COOP ? 1 : 0)) {
+        int carry = 0;
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            const int r = R - 1 - (r0 + lane);                 // from the last row backwards
+            const int c = r >= 0 ? T.SX[r] : 0;
+            const int inc = wave_incl_scan_i(c, lane);
+            if (r >= 0) T.SX[r] = carry + inc;
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) T.SX[R] = 0;
+    }
+    if (COOP) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    for (int r = w; r < R; r += nw) {
+        const int i = lo + r * 64 + lane;
+        const unsigned long long bl = T.BL[r], br = T.BR[r];
+        const bool isL = (bl >> lane) & 1ull;
+        const int k = T.PL[r] + __popcll(bl & le);                              // rank of this L element, from 1
+        const int after = T.SX[r + 1] + __popcll(br & ~le);                     // R elements to its right
+        const bool sw = isL && after >= k;                                      // L_k < R_k
+        int j = 0x7fffffff;
+        if (sw) {
+            int a = 0, b = R - 1;                                               // the last row r2 with SX[r2] >= k holds R_k
+            while (a < b) { const int m = (a + b + 1) >> 1; if (T.SX[m] >= k) a = m; else b = m - 1; }
+            j = lo + a * 64 + select_from_top(T.BR[a], k - T.SX[a + 1]);
+            const uint32_t mine = E[i], theirs = E[j];
+            E[i] = theirs;
+            E[j] = mine;
+        }
+        const unsigned long long bs = __ballot(sw);
+        const unsigned long long un = bl & ~bs;                                 // L elements of the row that stay
+        int jm = j;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) jm = min(jm, __shfl_xor(jm, d));
+        if (lane == 0) {
+            if (bs) { atomicAdd(&T.acc[0], __popcll(bs)); atomicMin(&T.acc[3], jm); }
+            if (bl) atomicMin(&T.acc[1], lo + r * 64 + __ffsll((long long)bl) - 1);
+            if (un) atomicMin(&T.acc[2], lo + r * 64 + __ffsll((long long)un) - 1);
+        }
+    }
+    if (COOP) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    const int K = T.acc[0];
+    const int cut = K == 0 ? T.acc[1] : min(T.acc[2], T.acc[3]);
+    if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();             // acc[] is reset by the next partition
+    return cut;
+}
+
+// The introsort loop over E[0, n): phases 1 and 2 of the header.  small_list: global scratch, n / 16 + 64 entries.
+__device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned long long* small_list, uint32_t* lds, int rows_cap)
+{
+    // LDS carve-up: row tables for the cooperative partitions, then one small set per wave
+    unsigned long long* BL = reinterpret_cast<unsigned long long*>(lds);
+    unsigned long long* BR = BL + rows_cap;
+    int* PL = reinterpret_cast<int*>(BR + rows_cap);
+    int* SX = PL + rows_cap;                              // rows_cap + 1 entries
+    int* wtab = SX + rows_cap + 64;                       // per wave: BL[34] BR[34] (as u64) PL[34] SX[36] acc[4] stack[64 x 2]
+    __shared__ int acc[4];
+    __shared__ int big_stack[3 * 72];
+    __shared__ int n_big, n_small, next_small;
+    __shared__ int cur[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) {
+        n_big = 0; n_small = 0; next_small = 0;
+        const int depth0 = 2 * (31 - __clz(n));
+        if (n > kSortThreshold) {
+            if (n > kSmall) { big_stack[0] = 0; big_stack[1] = n; big_stack[2] = depth0; n_big = 1; }
+            else { small_list[0] = (unsigned long long)0 | ((unsigned long long)n << 20) | ((unsigned long long)depth0 << 40); n_small = 1; }
+        }
+    }
+    __syncthreads();
+    RowTables T{ BL, BR, PL, SX, acc };
+    // ---- phase 1
+    for (;;) {
+        if (t == 0) {
+            if (n_big > 0) { --n_big; cur[0] = big_stack[3 * n_big]; cur[1] = big_stack[3 * n_big + 1]; cur[2] = big_stack[3 * n_big + 2]; cur[3] = 1; }
+            else cur[3] = 0;
+        }
+        __syncthreads();
+        if (!cur[3]) break;
+        int f = cur[0], l = cur[1], depth = cur[2];
+        __syncthreads();
+        // the libstdc++ loop on this range: go on with the left part while it is big, park the right part
+        while (l - f > kSmall) {
+            if (depth == 0) {
+                if (t == 0) heap_sort_range(E, f, l);
+                __syncthreads();
+                l = f;
+                break;
+            }
+            --depth;
+            if (t == 0) median_to_first(E, f, l);
+            __syncthreads();
+            const int cut = partition_range<true>(E, f, l, T, w, SW, lane);
+            if (t == 0) {
+                const int rs = l - cut;
+                if (rs > kSmall) { big_stack[3 * n_big] = cut; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = depth; ++n_big; }
+                else if (rs > kSortThreshold) small_list[n_small++] = (unsigned long long)cut | ((unsigned long long)l << 20) | ((unsigned long long)depth << 40);
+            }
+            l = cut;
+            __syncthreads();
+        }
+        if (t == 0 && l - f > kSortThreshold) small_list[n_small++] = (unsigned long long)f | ((unsigned long long)l << 20) | ((unsigned long long)depth << 40);
+        __syncthreads();
+    }
+    // ---- phase 2: a wave per listed range, its subtree on a private stack
+    int* mine = wtab + w * kWaveWords;
+    RowTables W;
+    W.BL = reinterpret_cast<unsigned long long*>(mine);
+    W.BR = W.BL + 34;
+    W.PL = reinterpret_cast<int*>(W.BR + 34);
+    W.SX = W.PL + 34;
+    W.acc = W.SX + 36;
+    int* stack = W.acc + 4;                                   // 64 x (f, l | depth << 24 is too tight: two ints per entry)
+    const int total = n_small;
+    for (;;) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&next_small, 1);
+        idx = __shfl(idx, 0);
+        if (idx >= total) break;
+        const unsigned long long it = small_list[idx];
+        int sp = 0;
+        int f = (int)(it & 0xfffffu), l = (int)((it >> 20) & 0xfffffu), depth = (int)(it >> 40);
+        for (;;) {
+            while (l - f > kSortThreshold) {
+                if (depth == 0) {
+                    if (lane == 0) heap_sort_range(E, f, l);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    break;
+                }
+                --depth;
+                if (lane == 0) median_to_first(E, f, l);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const int cut = partition_range<false>(E, f, l, W, 0, 1, lane);
+                if (l - cut > kSortThreshold) {
+                    if (lane == 0) { stack[2 * sp] = cut; stack[2 * sp + 1] = l | (depth << 24); }
+                    ++sp;
+                }
+                l = cut;
+            }
+            if (sp == 0) break;
+            --sp;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            f = stack[2 * sp];
+            l = stack[2 * sp + 1] & 0xffffff;
+            depth = stack[2 * sp + 1] >> 24;
+        }
+    }
+    __syncthreads();
+}
+
+
+// one stable 4-bit counting pass (same scheme as k_lsd_order.hip's radix_pass: every thread owns a contiguous run)
+__device__ __forceinline__ void seed_radix_pass(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n, int shift,
+                                                uint32_t* cnt /*[SNB][ST]*/, int* tot, int* base)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int seg = (n + ST - 1) / ST;
+    const int i0 = min(n, t * seg), i1 = min(n, i0 + seg);
+    for (int b = 0; b < SNB; ++b) cnt[b * ST + t] = 0;
+    for (int i = i0; i < i1; ++i) cnt[(int)((src[i] >> shift) & (SNB - 1)) * ST + t]++;
+    __syncthreads();
+    for (int bb = 0; bb < SNB / SW; ++bb) {
+        const int b = wave * (SNB / SW) + bb;
+        int carry = 0;
+        for (int c = 0; c < ST / 64; ++c) {
+            const int v = (int)cnt[b * ST + c * 64 + lane];
+            const int inc = wave_incl_scan_i(v, lane);
+            cnt[b * ST + c * 64 + lane] = (uint32_t)(carry + inc - v);
+            carry += __shfl(inc, 63);
+        }
+        if (lane == 0) tot[b] = carry;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int v = lane < SNB ? tot[lane] : 0;
+        const int inc = wave_incl_scan_i(v, lane);
+        if (lane < SNB) base[lane] = inc - v;
+    }
+    __syncthreads();
+    for (int i = i0; i < i1; ++i) {
+        const uint32_t it = src[i];
+        const int b = (int)((it >> shift) & (SNB - 1));
+        dst[(uint32_t)base[b] + cnt[b * ST + t]++] = it;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __restrict__ n_rec, const unsigned long long* __restrict__ maxgrad,
+                                                   const uint32_t* __restrict__ c_xy, const double* __restrict__ c_mod,
+                                                   const uint32_t* __restrict__ l_addr, const double* __restrict__ l_mod, const int* __restrict__ n_low,
+                                                   unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
+                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b, int rows_cap)
+{
+    extern __shared__ uint32_t seed_lds[];
+    __shared__ int tot[SNB];
+    __shared__ int base[SNB];
+    const int pc = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t o = (size_t)pc * Ps;
+    const int nd = n_rec[pc];
+    if (nd == 0) return;
+    uint32_t* E = reinterpret_cast<uint32_t*>(sort_a + o);
+    unsigned long long* small_list = sort_b + o;
+    uint32_t* A = order_a + o;
+    uint32_t* B = order_b + o;
+    const int Wg = p.Ws - 1, Hg = p.Hs - 1;
+    const int n = Wg * Hg;
+    const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
+    const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
+    // ---- phase 0
+    for (int i = t; i < n; i += ST) E[i] = 0u;
+    __syncthreads();
+    for (int e = t; e < nd; e += ST) {
+        const uint32_t xy = c_xy[o + e];
+        const int bin = (int)(c_mod[o + e] * bin_coef);
+        E[(int)(xy >> 16) * Wg + (int)(xy & 0xffffu)] = ((uint32_t)bin << 20) | (uint32_t)(e + 1);
+    }
+    const int nl = n_low[pc];
+    for (int j = t; j < nl; j += ST) {
+        const uint32_t a = l_addr[o + j];
+        const int y = (int)(a / (uint32_t)p.Ws), x = (int)(a - (uint32_t)y * (uint32_t)p.Ws);
+        E[y * Wg + x] = (uint32_t)(int)(l_mod[o + j] * bin_coef) << 20;
+    }
+    __syncthreads();
+    // ---- phases 1, 2
+    introsort_loop_wg(E, n, small_list, seed_lds, rows_cap);
+    // ---- phase 3: the seeds in array order ...
+    int* rowc = reinterpret_cast<int*>(seed_lds);                  // [rows + 1]
+    const int R = (n + 63) >> 6;
+    for (int r = w; r < R; r += SW) {
+        const int i = r * 64 + lane;
+        const unsigned long long b = __ballot(i < n && (E[i] & 0xfffffu) != 0u);
+        if (lane == 0) rowc[r] = __popcll(b);
+    }
+    __syncthreads();
+    if (w == 0) {
+        int carry = 0;
+        for (int r0 = 0; r0 < R; r0 += 64) {
+            const int r = r0 + lane;
+            const int c = r < R ? rowc[r] : 0;
+            const int inc = wave_incl_scan_i(c, lane);
+            if (r < R) rowc[r] = carry + inc - c;
+            carry += __shfl(inc, 63);
+        }
+    }
+    __syncthreads();
+    for (int r = w; r < R; r += SW) {
+        const int i = r * 64 + lane;
+        const uint32_t v = i < n ? E[i] : 0u;
+        const bool seed = (v & 0xfffffu) != 0u;
+        const unsigned long long b = __ballot(seed);
+        if (seed) B[rowc[r] + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)((p.n_bins - 1) - (int)key_of(v)) << 20) | ((v & 0xfffffu) - 1u);
+    }
+    __syncthreads();
+    // ... and the final insertion sort: stable by bin, highest bin first (n_seeds == nd: every defined pixel is in the array once)
+    uint32_t* cnt = seed_lds;
+    seed_radix_pass(B, A, nd, 20, cnt, tot, base);
+    seed_radix_pass(A, B, nd, 24, cnt, tot, base);
+    seed_radix_pass(B, A, nd, 28, cnt, tot, base);
+}
+
+// debug / test entry: std::sort(compare_norm) of n elements (key << 20 | index + 1) given in E; leaves E as the introsort loop
+// + final insertion sort leave it (the insertion sort as stable passes).  One workgroup.
+__global__ __launch_bounds__(ST) void k_std_sort_debug(uint32_t* __restrict__ E, uint32_t* __restrict__ tmp, unsigned long long* __restrict__ small_list, int n, int rows_cap)
+{
+    extern __shared__ uint32_t seed_lds[];
+    __shared__ int tot[SNB];
+    __shared__ int base[SNB];
+    introsort_loop_wg(E, n, small_list, seed_lds, rows_cap);
+    // stable by key DESCENDING: passes over (1023 - key)
+    for (int i = threadIdx.x; i < n; i += ST) { const uint32_t v = E[i]; E[i] = ((1023u - key_of(v)) << 20) | (v & 0xfffffu); }
+    __syncthreads();
+    uint32_t* cnt = seed_lds;
+    seed_radix_pass(E, tmp, n, 20, cnt, tot, base);
+    seed_radix_pass(tmp, E, n, 24, cnt, tot, base);
+    seed_radix_pass(E, tmp, n, 28, cnt, tot, base);
+    for (int i = threadIdx.x; i < n; i += ST) { const uint32_t v = tmp[i]; E[i] = ((1023u - key_of(v)) << 20) | (v & 0xfffffu); }
+}
+
+// rows of 64 elements the row tables must hold for an n-element array (a multiple of 64, so that the tables stay 8-byte aligned)
+static int seed_rows_cap(long long n) { return (int)(((n + 63) / 64 + 1 + 63) / 64 * 64); }
+static size_t seed_lds_bytes(int rows_cap)
+{
+    size_t words = (size_t)rows_cap * 6 + 128 + (size_t)SW * kWaveWords;
+    if (words < (size_t)SNB * ST) words = (size_t)SNB * ST;
+    return words * sizeof(uint32_t);
+}
+
+bool lsd_seed32_supported(const LsdParams& p)
+{
+    const long long n = (long long)(p.Hs - 1) * (p.Ws - 1);
+    return p.n_bins <= 1024 && (long long)p.Hs * p.Ws < (1 << 20) && n >= 1 && seed_lds_bytes(seed_rows_cap(n)) <= (size_t)kMaxLdsBytes;
+}
+
+void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const unsigned long long* maxgrad, const uint32_t* c_xy,
+                       const double* c_mod, const uint32_t* l_addr, const double* l_mod, const int* n_low,
+                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b, hipStream_t s)
+{
+    const int rows_cap = seed_rows_cap((long long)(p.Hs - 1) * (p.Ws - 1));
+    const size_t lds = seed_lds_bytes(rows_cap);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_lsd_seed32, dim3(n_frames * 3), dim3(ST), lds, s, p, n_rec, maxgrad, c_xy, c_mod, l_addr, l_mod, n_low,
+                       sort_a, sort_b, order_a, order_b, rows_cap);
+}
+
+// n < 2^20 and at most kMaxLdsBytes of row tables: false otherwise
+bool launch_std_sort_debug(uint32_t* E, uint32_t* tmp, unsigned long long* small_list, int n, hipStream_t s)
+{
+    const int rows_cap = seed_rows_cap(n);
+    const size_t lds = seed_lds_bytes(rows_cap);
+    if (n < 1 || n >= (1 << 20) || lds > (size_t)kMaxLdsBytes) return false;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_std_sort_debug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_std_sort_debug, dim3(1), dim3(ST), lds, s, E, tmp, small_list, n, rows_cap);
+    return true;
+}
+
+}  // namespace lf

@@ -72,6 +72,8 @@ struct lf_handle {
     float* d_rdeg = nullptr;
     double *d_rmod = nullptr, *d_rcs = nullptr, *d_rsn = nullptr;
     int* d_nrec = nullptr;
+    // lsd_seed_order = OPENCV32 only: pixels with a non-zero but undefined gradient (k_lsd_grad -> k_lsd_seed32)
+    uint32_t* d_laddr = nullptr; double* d_lmod = nullptr; int* d_nlow = nullptr;
     unsigned long long *d_sort_a = nullptr, *d_sort_b = nullptr;
     DevBuf dbg_ang, dbg_mod;
     unsigned long long* d_maxgrad = nullptr;
@@ -285,6 +287,8 @@ static int build_params(lf_handle* h)
     L.min_reg_size = (int)(-L.log_nt / dm::dlog10(L.p));
     L.log_eps = c.lsd_log_eps; L.density_th = c.lsd_density_th;
     L.n_bins = c.lsd_n_bins; L.refine = c.lsd_refine; L.cap_lines = h->cap_lines;
+    if (c.lsd_seed_order != LF_LSD_SEED_OPENCV30 && c.lsd_seed_order != LF_LSD_SEED_OPENCV32) { lf_set_error(h, LF_ERR_BAD_ARG, "lsd_seed_order %d: LF_LSD_SEED_OPENCV30 or LF_LSD_SEED_OPENCV32", c.lsd_seed_order); return LF_ERR_BAD_ARG; }
+    if (c.lsd_seed_order == LF_LSD_SEED_OPENCV32 && !lsd_seed32_supported(L)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_seed_order OPENCV32: the %dx%d LSD image exceeds the row tables of the sort emulation (k_lsd_seed32.hip)", L.Ws, L.Hs); return LF_ERR_UNSUPPORTED; }
     // component labelling capacity: 8192 entries (48 KB of LDS, three problems per CU) for 640x480-class images,
     // 24576 (144 KB, one problem per CU) for 1080p-class ones, whose problems hold 10-20 k defined pixels
     // ... and in between a handle follows its workload: real camera frames have problems of 9 - 16 k defined pixels, which
@@ -432,6 +436,9 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
+    if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32 &&
+        (dalloc(h, &h->d_laddr, nprob * Ps) || dalloc(h, &h->d_lmod, nprob * Ps) || dalloc(h, &h->d_nlow, nprob)))
+        return LF_ERR_HIP;
     h->out_capacity = (int)cap;
     lf_segments& o = h->d_out;
     memset(&o, 0, sizeof(o));
@@ -568,9 +575,15 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         StageTimer t(h, ST_LSD_GRAD);
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, (size_t)n * 3 * sizeof(unsigned long long), s));
         launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec,
-                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
+                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, s);
     }
-    { StageTimer t(h, ST_LSD_ORDER); launch_lsd_order(h->lsd, n, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s); }
+    {
+        StageTimer t(h, ST_LSD_ORDER);
+        launch_lsd_order(h->lsd, n, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
+        // OpenCV >= 3.2: the seeds in the order std::sort leaves them in (the compact arrays and row starts stay as they are)
+        if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
+            launch_lsd_seed32(h->lsd, n, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, s);
+    }
     {
         StageTimer t(h, ST_LSD_ORDER);
         launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
@@ -998,6 +1011,30 @@ extern "C" int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_
     return LF_OK;
 }
 
+extern "C" int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!keys || !order || n < 1 || n >= (1 << 20)) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_debug_std_sort: bad argument (1 <= n < 2^20)"); return LF_ERR_BAD_ARG; }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    std::vector<uint32_t> e((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (keys[i] < 0 || keys[i] > 1023) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_debug_std_sort: keys must be in [0, 1023]"); return LF_ERR_BAD_ARG; }
+        e[i] = ((uint32_t)keys[i] << 20) | (uint32_t)(i + 1);
+    }
+    int rc;
+    if ((rc = ensure(h, h->a_q, (size_t)n * 4)) || (rc = ensure(h, h->a_m, (size_t)n * 4)) || (rc = ensure(h, h->a_best, ((size_t)n / 16 + 64) * 8))) return rc;
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, e.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    if (!launch_std_sort_debug(static_cast<uint32_t*>(h->a_q.p), static_cast<uint32_t*>(h->a_m.p), static_cast<unsigned long long*>(h->a_best.p), n, s)) {
+        lf_set_error(h, LF_ERR_UNSUPPORTED, "lf_debug_std_sort: %d elements exceed the row tables", n); return LF_ERR_UNSUPPORTED;
+    }
+    LF_HIP_CHECK(h, hipGetLastError());
+    LF_HIP_CHECK(h, hipMemcpyAsync(e.data(), h->a_q.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) order[i] = (int32_t)(e[i] & 0xfffffu) - 1;
+    return LF_OK;
+}
+
 extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
@@ -1013,9 +1050,11 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     LF_HIP_CHECK(h, hipMemcpyAsync(h->d_maskbits, ones.data(), nw * 12, hipMemcpyHostToDevice, s));
     LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, 3 * sizeof(unsigned long long), s));
     launch_lsd_grad(h->lsd, h->rt, 1, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad,
-                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, s);
+                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, s);
     launch_lsd_order(h->lsd, 1, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder,
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
+    if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
+        launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, s);
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,

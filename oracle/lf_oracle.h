@@ -53,6 +53,9 @@ typedef struct lfo_config {
     int32_t cam_w, cam_h;
     /* line_sanity_node.py:17-23 */
     double lanewidth, linewidth_white, linewidth_yellow, d_min, d_max, phi_min, phi_max;
+    /* 0: seeds in raster order inside a bin (OpenCV 3.0 / 3.1); 1: std::sort's order (3.2+, lf_oracle_sort.cpp) */
+    int32_t lsd_seed_order;
+    int32_t reserved0;
 } lfo_config;
 
 /* working image size after resize+crop */
@@ -86,6 +89,10 @@ int lfo_lsd_ll_angle(const lfo_config* c, const double* scaled, int srows, int s
                      double* angles, double* modgrad, int32_t* order);
 /* seed order inside a gradient bin: 0 raster (default), 1 libstdc++ std::sort as the later OpenCV 3.x (lf_oracle_sort.cpp) */
 void lfo_lsd_set_seed_order(int mode);
+/* test helpers (lf_oracle_sort.cpp): the real std::sort(compare_norm) on a key array (returns its comparison count), and a
+ * killer input for it (McIlroy's adversary) that drives it into the heap-sort fallback */
+long long lfo_std_sort_keys(const int32_t* keys, int n, int32_t* order);
+void lfo_antiqsort_keys(int n, int32_t* keys);
 /* full detector: lines (x1,y1,x2,y2) float32, returns count (<= cap); extra = width,prec,nfa per line or NULL */
 int lfo_lsd_detect(const lfo_config* c, const uint8_t* img, int rows, int cols,
                    float* lines4, double* extra3, int cap);

@@ -199,7 +199,7 @@ int lfo_lsd_ll_angle(const lfo_config* c, const double* scaled, int H, int W,
             order[start[i]++] = y * W + x;
         }
     free(count); free(start);
-    if (g_seed_order == 1) {
+    if (g_seed_order == 1 || c->lsd_seed_order == 1) {
         int32_t* bins = (int32_t*)malloc(sizeof(int32_t) * (size_t)(H - 1) * (W - 1));
         size_t k = 0;
         for (int y = 0; y < H - 1; ++y)

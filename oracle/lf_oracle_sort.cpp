@@ -33,3 +33,39 @@ extern "C" void lfo_std_sort_seed_order(const int32_t* bin_of_pixel /* raster ov
     std::sort(pts.begin(), pts.end(), compare_norm);
     for (size_t i = 0; i < pts.size(); ++i) order[i] = pts[i].p.y * W + pts[i].p.x;
 }
+
+/* ---- test helpers for the device's sort emulation (lane_slam_amd/csrc/k_lsd_seed32.hip, lf_debug_std_sort) ------------- */
+
+/* std::sort(compare_norm) of n keys in their given order: order[i] = index of the element left at place i; returns the number
+ * of comparisons made */
+extern "C" long long lfo_std_sort_keys(const int32_t* keys, int n, int32_t* order)
+{
+    std::vector<normPoint> pts((size_t)n);
+    for (int i = 0; i < n; ++i) { pts[i].p.x = i; pts[i].p.y = 0; pts[i].norm = keys[i]; }
+    long long ncmp = 0;
+    std::sort(pts.begin(), pts.end(), [&ncmp](const normPoint& a, const normPoint& b) { ++ncmp; return a.norm > b.norm; });
+    for (int i = 0; i < n; ++i) order[i] = pts[i].p.x;
+    return ncmp;
+}
+
+/* M. D. McIlroy, "A Killer Adversary for Quicksort" (1999), played against THIS library's std::sort with the descending
+ * comparator: the comparator decides the values while the sort runs ("gas" items are frozen to the next solid value when two of
+ * them meet), which yields n distinct keys on which the same sort runs into its depth limit and finishes with heap sort.
+ * keys[i] in [0, n): n <= 1024 for the bin range of the detector. */
+extern "C" void lfo_antiqsort_keys(int n, int32_t* keys)
+{
+    std::vector<int> val((size_t)n, n - 1), ptr((size_t)n);
+    const int gas = n - 1;
+    int nsolid = 0, candidate = 0;
+    for (int i = 0; i < n; ++i) ptr[i] = i;
+    /* solid values count DOWN from the top for a descending sort: the adversary hands out the values the sort wants to see
+     * first, so every pivot ends up at one end of its range */
+    auto greater = [&](int x, int y) {
+        if (val[x] == gas && val[y] == gas) { if (x == candidate) val[x] = nsolid++; else val[y] = nsolid++; }
+        if (val[x] == gas) candidate = x; else if (val[y] == gas) candidate = y;
+        return val[x] < val[y];            /* "x sorts before y": frozen (small) before gas, in the order of freezing */
+    };
+    std::sort(ptr.begin(), ptr.end(), greater);
+    /* the order the adversary fixed is ascending in val; as keys for compare_norm (a.norm > b.norm) that is descending in key */
+    for (int i = 0; i < n; ++i) keys[i] = (n - 1) - val[i];
+}

@@ -45,6 +45,7 @@ class LfoConfig(ctypes.Structure):
         ("lanewidth", ctypes.c_double), ("linewidth_white", ctypes.c_double),
         ("linewidth_yellow", ctypes.c_double), ("d_min", ctypes.c_double),
         ("d_max", ctypes.c_double), ("phi_min", ctypes.c_double), ("phi_max", ctypes.c_double),
+        ("lsd_seed_order", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -90,6 +91,7 @@ def _struct_from_dict(cfg):
     s.cam_h, s.cam_w = cfg["cam_size"]
     for k, v in cfg["sanity"].items():
         setattr(s, k, float(v))
+    s.lsd_seed_order = {"opencv30": 0, "opencv32": 1}[lsd.get("seed_order", "opencv30")]
     return s
 
 

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "liblanefront.so lacks %s" % n
     assert set(names) == set(_lib.EXPORTS), (set(names) ^ set(_lib.EXPORTS))
-    assert lib.lf_abi_version() == 4
+    assert lib.lf_abi_version() == 5
 
 
 def test_config_struct_matches_header_field_order():
