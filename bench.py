@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
     ap.add_argument("--depth", type=int, default=0, help="independent batches in flight (handles/streams); 0: 6")
+    ap.add_argument("--seed-order", default="opencv30", choices=["opencv30", "opencv32"],
+                    help="LSD seed order inside a gradient bin (lf_config.lsd_seed_order): opencv32 = std::sort's, as on ROS Kinetic's 3.3.1")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     ap.add_argument("--secondary", default="auto", choices=["auto", "all", "none"],
@@ -146,6 +148,7 @@ def main():
     in_rows, in_cols = (1080, 1920) if hd else (480, 640)
     cfg = default_config("fullres", in_size=(in_rows, in_cols)) if hd else default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
+    cfg["lsd"]["seed_order"] = args.seed_order
     # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers)
     fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D)]
     fe = fes[0]
@@ -352,6 +355,7 @@ def main():
                                    % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",
                                       B, in_cols, in_rows, uniq, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M, D),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0], "live_map": map_state,
+                       "lsd_seed_order": args.seed_order,
                        "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, one all-gather of segment blocks per step, replicated map" % world},
             "roofline": roofline,

@@ -25,11 +25,18 @@
 //
 // One workgroup per problem (frame, colour).  Elements are u32: bin << 20 | payload (compact index + 1 of a pixel with a
 // defined gradient, 0 for the others: only seeds need to be told apart, the sort's decisions depend on keys alone).
+// A RANGE WITHOUT A SEED IS NEVER PARTITIONED: the loop only permutes a range within itself, so what it does to a range that
+// holds no seed cannot be seen in the result.  That prunes most of the work: the gradient image is flat almost everywhere (bin
+// 0), the median of three is then 0, a partition around 0 leaves nothing but zeros to the right of the cut -- the top levels
+// shed half of their elements each, and the ranges that remain are the few thousand pixels near an edge.
 //   phase 0  the array: zeros (flat pixels: bin 0), the defined pixels from the compact arrays of k_lsd_order, the
 //            undefined pixels with a non-zero gradient from k_lsd_grad's "low" records
-//   phase 1  ranges of more than kSmall elements: the whole workgroup partitions one range at a time (rows of 64 elements
-//            dealt to the waves, row tables in LDS)
-//   phase 2  every wave takes ranges of at most kSmall elements from a list and works off their whole subtree alone
+//   phase 1  ranges of more than kSmall elements, in global memory: the whole workgroup partitions one range at a time in
+//            four streaming passes -- (1) L / R ballots and counts of every 64-element row, eight rows in flight per wave;
+//            (2) prefix / suffix sums of the row counts; (3) every swapped L and R element publishes its place under its rank;
+//            (4) the pairs are swapped, eight in flight per lane.  No pass waits for a search or for another lane's element.
+//   phase 2  every wave takes ranges of at most kSmall elements from a list, copies one into LDS and works off its whole
+//            subtree there, alone (same four passes, private stack), then copies it back
 //   phase 3  the seeds in the order the loop left them, compacted, then the final insertion sort as stable 4-bit counting
 //            passes over the bin key -> order_a, the seed list k_lsd_grow reads
 // The heap sort of a range that used up the depth limit (never seen on image data; tested with adversarial keys through
@@ -39,13 +46,16 @@
 
 namespace lf {
 
-constexpr int ST = 512;              // threads: 8 waves
+constexpr int ST = 1024;             // threads: 16 waves
 constexpr int SW = ST / 64;
-constexpr int kSmall = 2048;         // ranges up to this size are one wave's work (32 rows)
+constexpr int SW2 = 8;               // waves that work in phase 2 (each with a private LDS range)
+constexpr int kSmall = 1024;         // ranges up to this size are one wave's work, in LDS (16 rows)
 constexpr int kSortThreshold = 16;   // libstdc++ _S_threshold
 constexpr int kMaxLdsBytes = 150 * 1024;
 constexpr int SNB = 16;              // buckets of the final counting passes
-constexpr int kWaveWords = 2 * 34 * 2 + 34 + 36 + 4 + 128 + 2;      // one wave's private row tables + range stack (phase 2), 32-bit words
+constexpr int kU = 8;                // rows / pairs in flight per wave / lane in the streaming passes
+// one wave's private LDS in phase 2, 32-bit words: the range, the two place lists (u16), row tables, accumulators, range stack
+constexpr int kWaveWords = kSmall + kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
 
 __device__ __forceinline__ uint32_t key_of(uint32_t v) { return v >> 20; }
 // compare_norm(a, b) = a.norm > b.norm
@@ -130,35 +140,31 @@ __device__ __noinline__ void heap_sort_range(uint32_t* E, int f, int l)
 
 // Row tables of one partition: BL / BR the ballots of the L and R elements of every 64-element row of [lo, hi), PL[r] the L
 // elements in rows < r, SX[r] the R elements in rows >= r (SX[R] = 0).
-struct RowTables { unsigned long long* BL; unsigned long long* BR; int* PL; int* SX; int* acc; /* [0] K [1] first L [2] first unswapped L [3] lowest partner */ };
-
-// __unguarded_partition of [f + 1, l) around E[f] (already the median) by `nw` waves of which this is number `w`
-// (COOP: the workgroup's eight with barriers in between; otherwise one wave alone).  Returns the cut.
+// acc: [0] K  [1] first L  [2] first L that stays  [3] seeds in the range
 template <bool COOP>
-__device__ __forceinline__ int partition_range(uint32_t* E, int f, int l, const RowTables& T, int w, int nw, int lane)
+__device__ __forceinline__ void team_sync()
 {
-    const int lo = f + 1, hi = l;
+    if (COOP) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+}
+
+// Passes 2 - 4 and the cut, given the row ballots of [lo, hi) in BL / BR (pass 1 differs between the two users).  EP: the
+// elements (global or LDS), LP: the place lists (u32 in global scratch / u16 in LDS), positions relative to `org`.
+template <bool COOP, typename EP, typename LP>
+__device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, unsigned long long* BL, unsigned long long* BR, int* PL, int* SX,
+                                              int* acc, LP Lpos, LP Rpos, int w, int nw, int lane, int tid, int nthreads)
+{
     const int R = (hi - lo + 63) >> 6;
-    const uint32_t pivot = E[f];
     const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
-    if ((COOP ? threadIdx.x : lane) == 0) { T.acc[0] = 0; T.acc[1] = 0x7fffffff; T.acc[2] = 0x7fffffff; T.acc[3] = 0x7fffffff; }
-    for (int r = w; r < R; r += nw) {
-        const int i = lo + r * 64 + lane;
-        const bool valid = i < hi;
-        const uint32_t v = valid ? E[i] : 0u;
-        const unsigned long long bl = __ballot(valid && !comp(v, pivot));
-        const unsigned long long br = __ballot(valid && !comp(pivot, v));
-        if (lane == 0) { T.BL[r] = bl; T.BR[r] = br; T.PL[r] = __popcll(bl); T.SX[r] = __popcll(br); }
-    }
-    if (COOP) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-    // exclusive prefix of the L counts (first wave of the team), inclusive suffix of the R counts (its second wave, or the same)
+    const unsigned long long lt = (1ull << lane) - 1ull;                                // lanes < this one
+    // (2) exclusive prefix of the L counts (first wave of the team), inclusive suffix of the R counts (its second wave)
     if (w == 0) {
         int carry = 0;
         for (int r0 = 0; r0 < R; r0 += 64) {
             const int r = r0 + lane;
-            const int c = r < R ? T.PL[r] : 0;
+            const int c = r < R ? PL[r] : 0;
             const int inc = wave_incl_scan_i(c, lane);
-            if (r < R) T.PL[r] = carry + inc - c;
+            if (r < R) PL[r] = carry + inc - c;
             carry += __shfl(inc, 63);
         }
     }
@@ -166,57 +172,139 @@ __device__ __forceinline__ int partition_range(uint32_t* E, int f, int l, const 
         int carry = 0;
         for (int r0 = 0; r0 < R; r0 += 64) {
             const int r = R - 1 - (r0 + lane);                 // from the last row backwards
-            const int c = r >= 0 ? T.SX[r] : 0;
+            const int c = r >= 0 ? SX[r] : 0;
             const int inc = wave_incl_scan_i(c, lane);
-            if (r >= 0) T.SX[r] = carry + inc;
+            if (r >= 0) SX[r] = carry + inc;
             carry += __shfl(inc, 63);
         }
-        if (lane == 0) T.SX[R] = 0;
+        if (lane == 0) SX[R] = 0;
     }
-    if (COOP) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+    team_sync<COOP>();
+    // (3) ranks; an L element of rank k is swapped iff at least k R elements lie to its right (L_k < R_k), an R element of rank
+    // k iff at least k L elements lie to its left; both publish their place under their rank
     for (int r = w; r < R; r += nw) {
         const int i = lo + r * 64 + lane;
-        const unsigned long long bl = T.BL[r], br = T.BR[r];
-        const bool isL = (bl >> lane) & 1ull;
-        const int k = T.PL[r] + __popcll(bl & le);                              // rank of this L element, from 1
-        const int after = T.SX[r + 1] + __popcll(br & ~le);                     // R elements to its right
-        const bool sw = isL && after >= k;                                      // L_k < R_k
-        int j = 0x7fffffff;
-        if (sw) {
-            int a = 0, b = R - 1;                                               // the last row r2 with SX[r2] >= k holds R_k
-            while (a < b) { const int m = (a + b + 1) >> 1; if (T.SX[m] >= k) a = m; else b = m - 1; }
-            j = lo + a * 64 + select_from_top(T.BR[a], k - T.SX[a + 1]);
-            const uint32_t mine = E[i], theirs = E[j];
-            E[i] = theirs;
-            E[j] = mine;
-        }
-        const unsigned long long bs = __ballot(sw);
+        const unsigned long long bl = BL[r], br = BR[r];
+        const bool isL = (bl >> lane) & 1ull, isR = (br >> lane) & 1ull;
+        const int kl = PL[r] + __popcll(bl & le), r_right = SX[r + 1] + __popcll(br & ~le);
+        const int kr = SX[r + 1] + __popcll(br >> lane), l_left = PL[r] + __popcll(bl & lt);
+        const bool swl = isL && r_right >= kl, swr = isR && l_left >= kr;
+        if (swl) Lpos[kl - 1] = i - org;
+        if (swr) Rpos[kr - 1] = i - org;
+        const unsigned long long bs = __ballot(swl);
         const unsigned long long un = bl & ~bs;                                 // L elements of the row that stay
-        int jm = j;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) jm = min(jm, __shfl_xor(jm, d));
         if (lane == 0) {
-            if (bs) { atomicAdd(&T.acc[0], __popcll(bs)); atomicMin(&T.acc[3], jm); }
-            if (bl) atomicMin(&T.acc[1], lo + r * 64 + __ffsll((long long)bl) - 1);
-            if (un) atomicMin(&T.acc[2], lo + r * 64 + __ffsll((long long)un) - 1);
+            if (bs) atomicAdd(&acc[0], __popcll(bs));
+            if (bl) atomicMin(&acc[1], lo + r * 64 + __ffsll((long long)bl) - 1);
+            if (un) atomicMin(&acc[2], lo + r * 64 + __ffsll((long long)un) - 1);
         }
     }
-    if (COOP) __syncthreads(); else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
-    const int K = T.acc[0];
-    const int cut = K == 0 ? T.acc[1] : min(T.acc[2], T.acc[3]);
-    if (COOP) __syncthreads(); else __builtin_amdgcn_wave_barrier();             // acc[] is reset by the next partition
+    team_sync<COOP>();
+    // (4) the swaps
+    const int K = acc[0];
+    for (int k0 = tid; k0 < K; k0 += nthreads * kU) {
+        int pi[kU], pj[kU];
+        uint32_t a[kU], b[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int k = k0 + u * nthreads;
+            pi[u] = k < K ? org + (int)Lpos[k] : -1;
+            pj[u] = k < K ? org + (int)Rpos[k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (pi[u] >= 0) { a[u] = E[pi[u]]; b[u] = E[pj[u]]; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) if (pi[u] >= 0) { E[pi[u]] = b[u]; E[pj[u]] = a[u]; }
+    }
+    const int cut = K == 0 ? acc[1] : min(acc[2], org + (int)Rpos[K - 1]);
+    team_sync<COOP>();                                                           // the tables are free again
     return cut;
 }
 
-// The introsort loop over E[0, n): phases 1 and 2 of the header.  small_list: global scratch, n / 16 + 64 entries.
-__device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned long long* small_list, uint32_t* lds, int rows_cap)
+// __unguarded_partition of [f + 1, l) around E[f] (already the median) in global memory by the whole workgroup.  Returns the
+// cut, or -1 when the range [f, l) holds no seed (nothing was moved then, and nothing needs to be).
+__device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, unsigned long long* BL, unsigned long long* BR, int* PL, int* SX,
+                                                int* acc, uint32_t* Lpos, uint32_t* Rpos, int w, int lane)
 {
-    // LDS carve-up: row tables for the cooperative partitions, then one small set per wave
+    const int lo = f + 1, hi = l;
+    const int R = (hi - lo + 63) >> 6;
+    const uint32_t pivot = E[f];
+    if (threadIdx.x == 0) { acc[0] = 0; acc[1] = 0x7fffffff; acc[2] = 0x7fffffff; acc[3] = (pivot & 0xfffffu) != 0u; }
+    __syncthreads();
+    // (1) eight rows in flight per wave
+    for (int r0 = w * kU; r0 < R; r0 += SW * kU) {
+        uint32_t v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int i = lo + (r0 + u) * 64 + lane; v[u] = i < hi ? E[i] : 0xffffffffu; }
+        int seeds = 0;
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int r = r0 + u;
+            if (r < R) {
+                const bool valid = lo + r * 64 + lane < hi;
+                const unsigned long long bl = __ballot(valid && !comp(v[u], pivot));
+                const unsigned long long br = __ballot(valid && !comp(pivot, v[u]));
+                seeds += __popcll(__ballot(valid && (v[u] & 0xfffffu) != 0u));
+                if (lane == 0) { BL[r] = bl; BR[r] = br; PL[r] = __popcll(bl); SX[r] = __popcll(br); }
+            }
+        }
+        if (lane == 0 && seeds) atomicAdd(&acc[3], seeds);
+    }
+    __syncthreads();
+    if (acc[3] == 0) { __syncthreads(); return -1; }
+    return partition_tail<true>(E, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW, lane, (int)threadIdx.x, ST);
+}
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
+// the same for a range [f, l) of a wave's LDS copy D (positions relative to the copy), one wave alone
+__device__ __forceinline__ int partition_lds(lds_u32* D, int f, int l, unsigned long long* BL, unsigned long long* BR, int* PL, int* SX,
+                                             int* acc, lds_u16* Lpos, lds_u16* Rpos, int lane)
+{
+    const int lo = f + 1, hi = l;
+    const int R = (hi - lo + 63) >> 6;
+    const uint32_t pivot = D[f];
+    if (lane == 0) { acc[0] = 0; acc[1] = 0x7fffffff; acc[2] = 0x7fffffff; }
+    int seeds = (pivot & 0xfffffu) != 0u;
+    for (int r = 0; r < R; ++r) {
+        const int i = lo + r * 64 + lane;
+        const bool valid = i < hi;
+        const uint32_t v = valid ? D[i] : 0u;
+        const unsigned long long bl = __ballot(valid && !comp(v, pivot));
+        const unsigned long long br = __ballot(valid && !comp(pivot, v));
+        seeds += __popcll(__ballot(valid && (v & 0xfffffu) != 0u));
+        if (lane == 0) { BL[r] = bl; BR[r] = br; PL[r] = __popcll(bl); SX[r] = __popcll(br); }
+    }
+    team_sync<false>();
+    if (seeds == 0) return -1;
+    return partition_tail<false>(D, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, 0, 1, lane, lane, 64);
+}
+
+__device__ __forceinline__ void median_to_first_lds(lds_u32* E, int f, int l)
+{
+    const int ia = f + 1, ib = f + (l - f) / 2, ic = l - 1;
+    const uint32_t a = E[ia], b = E[ib], c = E[ic];
+    int pick;
+    if (comp(a, b)) pick = comp(b, c) ? ib : (comp(a, c) ? ic : ia);
+    else pick = comp(a, c) ? ia : (comp(b, c) ? ic : ib);
+    const uint32_t r = E[f], p = E[pick];
+    E[f] = p;
+    E[pick] = r;
+}
+
+// The introsort loop over E[0, n): phases 1 and 2 of the header.  scratch: global, 3 n / 4 + 64 u64 entries (the list of small
+// ranges, then the two place lists of the global partitions).
+__device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned long long* scratch, uint32_t* lds, int rows_cap)
+{
+    // LDS carve-up: phase 1 = the row tables of the global partitions; phase 2 = one private block per working wave (aliased)
     unsigned long long* BL = reinterpret_cast<unsigned long long*>(lds);
     unsigned long long* BR = BL + rows_cap;
     int* PL = reinterpret_cast<int*>(BR + rows_cap);
     int* SX = PL + rows_cap;                              // rows_cap + 1 entries
-    int* wtab = SX + rows_cap + 64;                       // per wave: BL[34] BR[34] (as u64) PL[34] SX[36] acc[4] stack[64 x 2]
+    unsigned long long* small_list = scratch;
+    uint32_t* Lpos = reinterpret_cast<uint32_t*>(scratch + (n / 16 + 64));
+    uint32_t* Rpos = Lpos + (n / 2 + 8);
     __shared__ int acc[4];
     __shared__ int big_stack[3 * 72];
     __shared__ int n_big, n_small, next_small;
@@ -231,7 +319,6 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned l
         }
     }
     __syncthreads();
-    RowTables T{ BL, BR, PL, SX, acc };
     // ---- phase 1
     for (;;) {
         if (t == 0) {
@@ -253,7 +340,8 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned l
             --depth;
             if (t == 0) median_to_first(E, f, l);
             __syncthreads();
-            const int cut = partition_range<true>(E, f, l, T, w, SW, lane);
+            const int cut = partition_global(E, f, l, BL, BR, PL, SX, acc, Lpos, Rpos, w, lane);
+            if (cut < 0) { l = f; break; }                           // no seed in the range: nothing to order
             if (t == 0) {
                 const int rs = l - cut;
                 if (rs > kSmall) { big_stack[3 * n_big] = cut; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = depth; ++n_big; }
@@ -265,57 +353,66 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned l
         if (t == 0 && l - f > kSortThreshold) small_list[n_small++] = (unsigned long long)f | ((unsigned long long)l << 20) | ((unsigned long long)depth << 40);
         __syncthreads();
     }
-    // ---- phase 2: a wave per listed range, its subtree on a private stack
-    int* mine = wtab + w * kWaveWords;
-    RowTables W;
-    W.BL = reinterpret_cast<unsigned long long*>(mine);
-    W.BR = W.BL + 34;
-    W.PL = reinterpret_cast<int*>(W.BR + 34);
-    W.SX = W.PL + 34;
-    W.acc = W.SX + 36;
-    int* stack = W.acc + 4;                                   // 64 x (f, l | depth << 24 is too tight: two ints per entry)
-    const int total = n_small;
-    for (;;) {
-        int idx = 0;
-        if (lane == 0) idx = atomicAdd(&next_small, 1);
-        idx = __shfl(idx, 0);
-        if (idx >= total) break;
-        const unsigned long long it = small_list[idx];
-        int sp = 0;
-        int f = (int)(it & 0xfffffu), l = (int)((it >> 20) & 0xfffffu), depth = (int)(it >> 40);
+    // ---- phase 2: a wave per listed range, copied into its private LDS block, its subtree on a private stack
+    if (w < SW2) {
+        uint32_t* mine = lds + (size_t)w * kWaveWords;
+        lds_u32* D = (lds_u32*)(__attribute__((address_space(3))) void*)mine;
+        lds_u16* Lp = (lds_u16*)(D + kSmall);
+        lds_u16* Rp = Lp + kSmall / 2;
+        unsigned long long* wBL = reinterpret_cast<unsigned long long*>(mine + kSmall + kSmall / 2);
+        unsigned long long* wBR = wBL + 18;
+        int* wPL = reinterpret_cast<int*>(wBR + 18);
+        int* wSX = wPL + 18;
+        int* wacc = wSX + 20;
+        int* stack = wacc + 8;                                    // 64 x (f, l | depth << 24)
+        const int total = n_small;
         for (;;) {
-            while (l - f > kSortThreshold) {
-                if (depth == 0) {
-                    if (lane == 0) heap_sort_range(E, f, l);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                    break;
+            int idx = 0;
+            if (lane == 0) idx = atomicAdd(&next_small, 1);
+            idx = __shfl(idx, 0);
+            if (idx >= total) break;
+            const unsigned long long it = small_list[idx];
+            const int gf = (int)(it & 0xfffffu), gl = (int)((it >> 20) & 0xfffffu);
+            const int m = gl - gf;
+            int seeds = 0;
+            for (int x = lane; x < m; x += 64) { const uint32_t v = E[gf + x]; D[x] = v; seeds |= (v & 0xfffffu) != 0u; }
+            if (!__ballot(seeds)) continue;                           // no seed: leave it as it is
+            team_sync<false>();
+            int sp = 0;
+            int f = 0, l = m, depth = (int)(it >> 40);
+            for (;;) {
+                while (l - f > kSortThreshold) {
+                    if (depth == 0) {
+                        if (lane == 0) heap_sort_range(reinterpret_cast<uint32_t*>(mine), f, l);
+                        team_sync<false>();
+                        break;
+                    }
+                    --depth;
+                    if (lane == 0) median_to_first_lds(D, f, l);
+                    team_sync<false>();
+                    const int cut = partition_lds(D, f, l, wBL, wBR, wPL, wSX, wacc, Lp, Rp, lane);
+                    if (cut < 0) break;
+                    if (l - cut > kSortThreshold) {
+                        if (lane == 0) { stack[2 * sp] = cut; stack[2 * sp + 1] = l | (depth << 24); }
+                        ++sp;
+                    }
+                    l = cut;
                 }
-                --depth;
-                if (lane == 0) median_to_first(E, f, l);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                const int cut = partition_range<false>(E, f, l, W, 0, 1, lane);
-                if (l - cut > kSortThreshold) {
-                    if (lane == 0) { stack[2 * sp] = cut; stack[2 * sp + 1] = l | (depth << 24); }
-                    ++sp;
-                }
-                l = cut;
+                if (sp == 0) break;
+                --sp;
+                team_sync<false>();
+                f = stack[2 * sp];
+                l = stack[2 * sp + 1] & 0xffffff;
+                depth = stack[2 * sp + 1] >> 24;
             }
-            if (sp == 0) break;
-            --sp;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            f = stack[2 * sp];
-            l = stack[2 * sp + 1] & 0xffffff;
-            depth = stack[2 * sp + 1] >> 24;
+            team_sync<false>();
+            for (int x = lane; x < m; x += 64) E[gf + x] = D[x];
         }
     }
     __syncthreads();
 }
 
-
-// one stable 4-bit counting pass (same scheme as k_lsd_order.hip's radix_pass: every thread owns a contiguous run)
+// one stable 4-bit counting pass (same scheme as k_lsd_order.hip's radix_pass: every thread owns a contiguous run; [16][1024] counters)
 __device__ __forceinline__ void seed_radix_pass(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n, int shift,
                                                 uint32_t* cnt /*[SNB][ST]*/, int* tot, int* base)
 {
@@ -389,7 +486,7 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
     }
     __syncthreads();
     // ---- phases 1, 2
-    introsort_loop_wg(E, n, small_list, seed_lds, rows_cap);
+    introsort_loop_wg(E, n, small_list, seed_lds, rows_cap);          // (the scratch: this problem's slice of sort_b, Ps >= 3 n / 4 + 64 entries)
     // ---- phase 3: the seeds in array order ...
     int* rowc = reinterpret_cast<int*>(seed_lds);                  // [rows + 1]
     const int R = (n + 63) >> 6;
@@ -447,7 +544,8 @@ __global__ __launch_bounds__(ST) void k_std_sort_debug(uint32_t* __restrict__ E,
 static int seed_rows_cap(long long n) { return (int)(((n + 63) / 64 + 1 + 63) / 64 * 64); }
 static size_t seed_lds_bytes(int rows_cap)
 {
-    size_t words = (size_t)rows_cap * 6 + 128 + (size_t)SW * kWaveWords;
+    size_t words = (size_t)rows_cap * 6 + 128;
+    if (words < (size_t)SW2 * kWaveWords) words = (size_t)SW2 * kWaveWords;
     if (words < (size_t)SNB * ST) words = (size_t)SNB * ST;
     return words * sizeof(uint32_t);
 }

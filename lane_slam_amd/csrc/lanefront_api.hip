@@ -1023,7 +1023,7 @@ extern "C" int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32
         e[i] = ((uint32_t)keys[i] << 20) | (uint32_t)(i + 1);
     }
     int rc;
-    if ((rc = ensure(h, h->a_q, (size_t)n * 4)) || (rc = ensure(h, h->a_m, (size_t)n * 4)) || (rc = ensure(h, h->a_best, ((size_t)n / 16 + 64) * 8))) return rc;
+    if ((rc = ensure(h, h->a_q, (size_t)n * 4)) || (rc = ensure(h, h->a_m, (size_t)n * 4)) || (rc = ensure(h, h->a_best, (size_t)n * 5 + 2048))) return rc;     // the small-range list + the two place lists
     LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, e.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
     if (!launch_std_sort_debug(static_cast<uint32_t*>(h->a_q.p), static_cast<uint32_t*>(h->a_m.p), static_cast<unsigned long long*>(h->a_best.p), n, s)) {
         lf_set_error(h, LF_ERR_UNSUPPORTED, "lf_debug_std_sort: %d elements exceed the row tables", n); return LF_ERR_UNSUPPORTED;
