@@ -500,6 +500,23 @@ def golden_real_frames():
     print("real_frames.npz:", picks, [v.shape for v in out.values()])
 
 
+def golden_real_jpegs(count=28):
+    """`count` of the reference's 173 real Duckiebot camera frames (src/anti_instagram/annotation-tool/images/*.jpg: data files
+    of the reference) as their JPEG BYTE STREAMS, spread evenly over the five recording sessions (night, noon, closed room, ice
+    rink, coordination LEDs): input data for the GPU tests -- device JPEG decode -> the whole front end / the KeyLine path --
+    and for bench.py's real-content rows.  No expected outputs are stored: the pinned JPEG oracle and the oracle front end
+    compute them at test time."""
+    d = os.path.join(REF, "anti_instagram/annotation-tool/images")
+    names = sorted(n for n in os.listdir(d) if n.endswith(".jpg"))
+    picks = [names[(2 * k + 1) * len(names) // (2 * count)] for k in range(count)]
+    out = {"names": np.array(picks)}
+    for k, n in enumerate(picks):
+        with open(os.path.join(d, n), "rb") as f:
+            out["jpeg%02d" % k] = np.frombuffer(f.read(), np.uint8)
+    np.savez(os.path.join(OUT, "real_jpegs.npz"), **out)
+    print("real_jpegs.npz:", count, "streams,", sum(v.size for k, v in out.items() if k != "names"), "bytes:", picks)
+
+
 if __name__ == "__main__":
     install_stubs()
     golden_node_pipeline()
@@ -511,3 +528,4 @@ if __name__ == "__main__":
     install_stubs()
     golden_kmeans()
     golden_real_frames()
+    golden_real_jpegs()
