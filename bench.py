@@ -444,7 +444,7 @@ def main():
 
 def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D, cap):
     """Measurements that never replace `value` (VERDICT r1 #5).  Each is bounded to a few seconds."""
-    from lane_slam_amd import LineAssociator, LineDetectorHIP, synth
+    from lane_slam_amd import FrontEnd, LineAssociator, LineDetectorHIP, synth
     from lane_slam_amd.config import DEFAULT_DETECTOR_CONFIGURATION
     sec = {}
 
@@ -517,30 +517,49 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
     # ---- other content: the rate of region growing depends on what is in the frames.  (a) the three real Duckiebot
     # camera frames committed as test inputs (tests/golden/real_frames.npz), tiled to a batch, each copy shifted sideways;
     # (b) the synthetic frames with clutter (speckle + 40 random strokes in lane colours per frame: many short regions)
+    extra = {"fes": [], "ptrs": []}
+
     def content_rate(batch_host, label):
         d = torch.from_numpy(np.ascontiguousarray(batch_host)).to(dev)
         torch.cuda.synchronize()
+        state = {"D": D}
 
         def go(nb):
+            Dn = state["D"]
+            hs, ps = fes + extra["fes"], ptrs + extra["ptrs"]
             inflight, segsum = [], 0
             for k in range(nb):
-                slot = k % D
-                if len(inflight) == D:
-                    segsum += fes[inflight.pop(0)].wait()
-                fes[slot].submit_device(d.data_ptr(), B, ptrs[slot], cap, describe=True)
+                slot = k % Dn
+                if len(inflight) == Dn:
+                    segsum += hs[inflight.pop(0)].wait()
+                hs[slot].submit_device(d.data_ptr(), B, ps[slot], cap, describe=True)
                 inflight.append(slot)
             while inflight:
-                segsum += fes[inflight.pop(0)].wait()
+                segsum += hs[inflight.pop(0)].wait()
             return segsum
         go(D)
         torch.cuda.synchronize()
-        nb = 4 * D
+        # the in-flight depth follows the workload (lf_suggested_depth): busy content is bound by the chain of its longest
+        # problems, more batches in flight fill the machine; the extra handles are created once and kept for the other rows
+        want = max(D, fes[0].suggested_depth()) if args.depth == 0 else D
+        while len(fes) + len(extra["fes"]) < want:
+            extra["fes"].append(FrontEnd(fes[0].cfg, device=device_id, max_frames=B, max_lines_per_color=args.cap))
+            o_ = alloc_out(torch, dev, B, cap)
+            extra.setdefault("outs", []).append(o_)
+            extra["ptrs"].append({k: v.data_ptr() for k, v in o_.items()})
+        state["D"] = want
+        if want > D:
+            go(want)
+            torch.cuda.synchronize()
+        D_used = want
+        nb = 4 * D_used
         t0 = time.perf_counter()
         n_seg = go(nb)
         torch.cuda.synchronize()
         cdt = time.perf_counter() - t0
         return {"value": round(nb * B / cdt, 1), "unit": "frames/s", "segments_per_frame": round(n_seg / (nb * B), 1),
-                "what": "%s; detect->describe->project->sanity (no association), %d batches of %d frames, %d in flight" % (label, nb, B, D)}
+                "batches_in_flight": D_used,
+                "what": "%s; detect->describe->project->sanity (no association), %d batches of %d frames, %d in flight (lf_suggested_depth)" % (label, nb, B, D_used)}
     try:
         # 28 of the reference's camera frames, from their JPEG streams (tests/golden/real_jpegs.npz), decoded by the device decoder
         zj = np.load(os.path.join(ROOT, "tests", "golden", "real_jpegs.npz"))

@@ -496,6 +496,11 @@ int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, fl
 int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order);
 /* scaled LSD image size for this handle */
 int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
+/* How many batches (handles) a caller should keep in flight for the content this handle saw last: region growing is a chain
+ * of dependent steps per problem, and on busy content (camera frames with texture: a few problems of 10 - 20 k edge pixels set
+ * the batch's latency while most of the chip waits) only more batches in flight fill the machine.  6 while the last batch's
+ * problems fit the small LDS slice of k_lsd_grow (lane markings), 12 otherwise.  A hint: results never depend on it. */
+int lf_suggested_depth(const lf_handle* h);
 
 /* per-kernel timing with HIP events on the handle's stream */
 #define LF_N_STAGES 13

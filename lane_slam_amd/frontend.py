@@ -170,6 +170,11 @@ class FrontEnd(object):
         self._check(self.lib.lf_process_batch_async(self.h, ctypes.c_void_p(int(frames_host_ptr)), int(n_frames), 0,
                                                     ctypes.byref(s), int(bool(describe))))
 
+    def suggested_depth(self):
+        """Batches (handles) worth keeping in flight for the content this handle saw last (lf_suggested_depth): 6 on lane
+        frames, 12 on busy camera content.  A throughput hint only."""
+        return int(self.lib.lf_suggested_depth(self.h))
+
     def wait(self):
         """Block until the queued batch is complete; returns its segment count."""
         total = ctypes.c_int()

@@ -15,8 +15,16 @@ args = ap.parse_args()
 B = args.batch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = default_config("fullres")
-real = np.load(os.path.join(ROOT, "tests", "golden", "real_frames.npz"))
-rf = [real[k] for k in real.files if real[k].ndim == 3 and real[k].shape == (480, 640, 3)]
+def real_sample():
+    """the 28 camera frames of tests/golden/real_jpegs.npz, decoded by the device decoder"""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "real_jpegs.npz"))
+    streams = [bytes(z["jpeg%02d" % k]) for k in range(len(z["names"]))]
+    fe0 = FrontEnd(cfg, max_frames=len(streams), max_lines_per_color=64)
+    fr, st = fe0.decode_jpeg_batch(streams, n_threads=4)
+    fe0.close()
+    assert (st == 0).all()
+    return [fr[k] for k in range(len(streams))]
+rf = real_sample()
 def clutter(frames, seed):
     rng = np.random.default_rng(seed)
     out = frames.copy()

@@ -12,8 +12,10 @@ cfg = default_config(sys.argv[2] if len(sys.argv) > 2 else "fullres")      # "pa
 fe = FrontEnd(cfg, max_frames=n, max_lines_per_color=512)
 frames = synth.make_batch(n, 0)
 if os.environ.get("LF_STAMPS_REAL"):          # the three real camera frames of tests/golden, tiled as bench.py's secondary.real_frames does
-    real = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real_frames.npz"))
-    rf = [real[k] for k in real.files if real[k].ndim == 3 and real[k].shape == (480, 640, 3)]
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "real_jpegs.npz"))
+    streams = [bytes(z["jpeg%02d" % k]) for k in range(len(z["names"]))]
+    fr, st = fe.decode_jpeg_batch(streams, n_threads=4)
+    rf = [fr[k] for k in range(len(streams)) if st[k] == 0]
     frames = np.stack([np.roll(rf[i % len(rf)], 7 * (i // len(rf)), axis=1) for i in range(n)])
 fe.process_batch(frames)
 seg = fe.process_batch(frames)
