@@ -170,6 +170,23 @@ int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, in
                            lf_segments* out_dev, int describe);
 int lf_wait(lf_handle* h, int* n_segments);
 
+/* Which detector lf_process_batch / lf_process_batch_async run for stages a-2 .. a-4 of this handle's batches:
+ *   LF_DETECTOR_LSD      (default) the reference's: 3-channel Canny, colour masks, cv2 LSD (line_detector_lsd.py:38-72)
+ *   LF_DETECTOR_EDLINES  the package's second LineDetectorInterface implementation (lf_set_image_edlines is
+ *                        its one-frame form, same contract): EDLines (BinaryDescriptor::detect's detector,
+ *                        binary_descriptor_custom.cpp:415-513, one octave) on BGR2GRAY of the working image; a line belongs
+ *                        to every colour whose dilated mask is set under its truncated, clamped centre; then the SAME
+ *                        _findNormal / ordering, projection, line sanity and LBD stages as the LSD path, pipelined the same
+ *                        way (no host synchronisation before lf_wait).  A frame on which EDLines gives up (its anchor / edge /
+ *                        line arrays full: the reference prints "Line Detection not finished" and returns no lines) has no
+ *                        segments; lf_detector_failures tells how many frames of the last completed batch did.
+ * params: NULL = lf_edlines_default_params.  Not while a batch is in flight. */
+#define LF_DETECTOR_LSD 0
+#define LF_DETECTOR_EDLINES 1
+struct lf_edlines_params;
+int lf_set_detector(lf_handle* h, int detector, const struct lf_edlines_params* params_or_null);
+int lf_detector_failures(const lf_handle* h);
+
 /* ---- association: replaces BinaryDescriptorMatcher::match ------------------
  * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
  * each 256-bit query code in the map; idx = -1 and dist = -1 when the nearest

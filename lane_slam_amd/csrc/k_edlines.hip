@@ -1267,14 +1267,22 @@ __global__ __launch_bounds__(256) void k_kl_assemble(EdAll all, int n_octaves, c
     }
 }
 
-// plugin path: the octave-0 lines of frame 0 -> the per-colour slot lists the segment stage reads (lanefront_keylines.inc,
-// lf_set_image_edlines).  One wave; lines keep their order inside a colour.
+// The octave-0 lines of every frame -> the per-colour slot lists the segment stage reads (the EDLines detector behind the
+// LineDetectorInterface: lf_set_image_edlines, and behind lf_process_batch: lf_set_detector).  One wave per frame; lines keep
+// their order inside a colour; a frame on which the detector gave up has no lines and is counted in *failed.
 __global__ __launch_bounds__(64) void k_ed_slots(EdAll all, const uint32_t* __restrict__ maskbits, int Ww, int cap_lines,
-                                                float* __restrict__ slot_lines, int* __restrict__ counts)
+                                                float* __restrict__ slot_lines, int* __restrict__ counts, int* __restrict__ failed)
 {
     const EdOct& o = all.o[0];
-    const int lane = threadIdx.x;
-    const int n = o.counts[1] < 0 ? 0 : o.counts[2];
+    const int lane = threadIdx.x, f = blockIdx.x;
+    const int* fc = o.counts + 4 * (size_t)f;
+    const bool gave_up = fc[1] < 0;
+    const int n = gave_up ? 0 : fc[2];
+    if (gave_up && failed && lane == 0) atomicAdd(failed, 1);
+    const float* l_dir = o.l_dir + (size_t)f * o.max_lines;
+    const float* l_ep = o.l_ep + (size_t)f * o.max_lines * 4;
+    const uint32_t* mb = maskbits + (size_t)f * 3 * o.H * Ww;
+    float* sl = slot_lines + (size_t)f * 3 * cap_lines * 4;
     const double PI = 3.14159265358979323846;
     int cnt[3] = { 0, 0, 0 };
     for (int start = 0; start < n; start += 64) {
@@ -1282,8 +1290,8 @@ __global__ __launch_bounds__(64) void k_ed_slots(EdAll all, const uint32_t* __re
         float io[4] = { 0, 0, 0, 0 };
         int member = 0;
         if (l < n) {
-            const float direction = o.l_dir[l];
-            const float* ep = o.l_ep + 4 * (size_t)l;
+            const float direction = l_dir[l];
+            const float* ep = l_ep + 4 * (size_t)l;
             const float s1 = ep[0], s2 = ep[1], e1 = ep[2], e2 = ep[3];
             const float dx = e1 - s1, dy = e2 - s2;
             bool shouldChange = false;                                   // OctaveKeyLines :966-997
@@ -1298,22 +1306,22 @@ __global__ __launch_bounds__(64) void k_ed_slots(EdAll all, const uint32_t* __re
             ix = ix < 0 ? 0 : (ix > o.W - 1 ? o.W - 1 : ix);
             iy = iy < 0 ? 0 : (iy > o.H - 1 ? o.H - 1 : iy);
             for (int c = 0; c < 3; ++c)
-                if ((maskbits[((size_t)c * o.H + iy) * Ww + (ix >> 5)] >> (ix & 31)) & 1u) member |= 1 << c;
+                if ((mb[((size_t)c * o.H + iy) * Ww + (ix >> 5)] >> (ix & 31)) & 1u) member |= 1 << c;
         }
         for (int c = 0; c < 3; ++c) {
             const unsigned long long bal = __ballot((member >> c) & 1);
             const int pos = cnt[c] + __popcll(bal & ((1ull << lane) - 1ull));
             if (((member >> c) & 1) && pos < cap_lines)
-                for (int q = 0; q < 4; ++q) slot_lines[((size_t)c * cap_lines + pos) * 4 + q] = io[q];
+                for (int q = 0; q < 4; ++q) sl[((size_t)c * cap_lines + pos) * 4 + q] = io[q];
             cnt[c] += __popcll(bal);
         }
     }
-    if (lane < 3) counts[lane] = cnt[lane];         // more than cap_lines: the segment stage reports the overflow
+    if (lane < 3) counts[3 * f + lane] = cnt[lane];         // more than cap_lines: the segment stage reports the overflow
 }
 
-void launch_ed_slots(const EdAll& all, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, hipStream_t s)
+void launch_ed_slots(const EdAll& all, int n_frames, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, int* failed, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_ed_slots, dim3(1), dim3(64), 0, s, all, maskbits, Ww, cap_lines, slot_lines, counts);
+    hipLaunchKernelGGL(k_ed_slots, dim3(n_frames), dim3(64), 0, s, all, maskbits, Ww, cap_lines, slot_lines, counts, failed);
 }
 
 void launch_kl_count(const EdAll& all, int n_octaves, int n_frames, int* frame_count, int* status, hipStream_t s)

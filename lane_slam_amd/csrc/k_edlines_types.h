@@ -45,7 +45,7 @@ void launch_ed_resize(int H, int W, int DH, int DW, const int* tab, int n_frames
 void launch_pyrdown(int H, int W, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s);
 size_t ed_detect_lds_bytes(int W, int H, int scan, bool* marks_in_lds);
 int launch_ed_detect(const EdAll& all, const EdFitParams& fp, int n_octaves, int n_frames, size_t lds_bytes, hipStream_t s);
-void launch_ed_slots(const EdAll& all, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, hipStream_t s);
+void launch_ed_slots(const EdAll& all, int n_frames, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, int* failed, hipStream_t s);
 void launch_kl_count(const EdAll& all, int n_octaves, int n_frames, int* frame_count, int* status, hipStream_t s);
 void launch_kl_offsets(int n_frames, const int* frame_count, int capacity, int* frame_offset, int* totals, hipStream_t s);
 void launch_kl_assemble(const EdAll& all, int n_octaves, int n_frames, const int* frame_offset, int capacity, const KlOut& out, hipStream_t s);

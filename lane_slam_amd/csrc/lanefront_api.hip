@@ -118,6 +118,9 @@ struct lf_handle {
     bool pending = false;
     bool grow_mixed = false;     // the last batch had problems beyond the slice in numbers (> 1 %): one launch with both kinds of problem code
     int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
+    int detector = LF_DETECTOR_LSD;       // what lf_process_batch runs for a-2 .. a-4 (lf_set_detector)
+    lf_edlines_params ed_params;
+    int detector_failures = 0;            // frames of the last completed batch on which the EDLines detector gave up
     int tie_rule = LF_TIE_MIHASHER;   // lf_associate: the reference's rule unless lf_set_tie_rule says otherwise
     int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
     int env_mixed = -1;
@@ -432,7 +435,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) ||
         dalloc(h, &h->d_pend_rec, nprob * (size_t)lsd_grow_pend_cap(h->lsd) * 12 + 2) || dalloc(h, &h->d_pend_tag, nprob * (size_t)lsd_grow_pend_cap(h->lsd) + 1) || dalloc(h, &h->d_pend_count, nprob) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
-        dalloc(h, &h->d_overflow, 4) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
+        dalloc(h, &h->d_overflow, 8) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
@@ -607,6 +610,8 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     return LF_OK;
 }
 
+static int run_detect_edlines(lf_handle* h, const uint8_t* d_frames, int n);     // lanefront_keylines.inc
+
 static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
 {
     hipStream_t s = h->stream;
@@ -658,13 +663,15 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
         d_in = h->d_frames;
     }
     h->plugin_ready = false;
-    int rc = run_detect(h, d_in, n_frames, false);
+    int rc = h->detector == LF_DETECTOR_EDLINES ? run_detect_edlines(h, d_in, n_frames) : run_detect(h, d_in, n_frames, false);
     if (rc != LF_OK) return rc;
     rc = run_segments(h, n_frames, *out_dev, describe != 0);
     if (rc != LF_OK) return rc;
     // total + overflow flag travel to pinned host memory behind the kernels
     LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    if (h->detector == LF_DETECTOR_EDLINES) LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[5], h->d_overflow + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    else h->h_pinned[5] = 0;
     h->pending = true;
     h->pending_problems = n_frames * 3;
     h->pending_capacity = out_dev->capacity;
@@ -678,6 +685,7 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
     LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     if (!h->pending) { if (n_segments) *n_segments = 0; return LF_OK; }
     h->pending = false;
+    h->detector_failures = h->h_pinned[5];
     const int total = h->h_pinned[0];
     if (n_segments) *n_segments = total;
     // The next batch's region-growing slices (performance only: the results do not depend on them): 13 KB while nearly every

@@ -170,6 +170,17 @@ class FrontEnd(object):
         self._check(self.lib.lf_process_batch_async(self.h, ctypes.c_void_p(int(frames_host_ptr)), int(n_frames), 0,
                                                     ctypes.byref(s), int(bool(describe))))
 
+    def set_detector(self, detector, params=None):
+        """Which detector process_batch / submit_* run: "lsd" (the reference's, default) or "edlines" (EDLines on the gray
+        working image + the colour masks: include/lanefront.h, lf_set_detector).  params: edlines_params(...) or None."""
+        if detector not in _lib.DETECTORS:
+            raise ValueError("detector must be one of %r" % (sorted(_lib.DETECTORS),))
+        self._check(self.lib.lf_set_detector(self.h, _lib.DETECTORS[detector], ctypes.byref(params) if params is not None else None))
+
+    def detector_failures(self):
+        """Frames of the last completed batch on which the EDLines detector gave up (they have no segments)."""
+        return int(self.lib.lf_detector_failures(self.h))
+
     def suggested_depth(self):
         """Batches (handles) worth keeping in flight for the content this handle saw last (lf_suggested_depth): 6 on lane
         frames, 12 on busy camera content.  A throughput hint only."""

@@ -322,6 +322,51 @@ class Oracle(object):
         return out
 
 
+def _process_frame_edlines(self, bgr_in, params=None, describe=True):
+    """The oracle's pieces composed for the EDLines detector of the batched path (include/lanefront.h, lf_set_detector;
+    the contract of lf_set_image_edlines, frame by frame): EDLines (one octave) on BGR2GRAY of the working image, a line
+    to every colour whose dilated mask is set under its truncated, clamped centre, then the reference's _findNormal /
+    ordering, normalisation, ground projection, line sanity and BinaryDescriptor::compute's LBD -- same dict as
+    process_frame.  None when the detector gives up on the frame."""
+    work = self.preprocess(bgr_in)
+    gray = self.bgr2gray(work)
+    k = octave_keylines(gray, 1, params)
+    if k is None:
+        return None
+    bw = self.color_masks(self.bgr2hsv(work))
+    io = k["in_octave"]
+    cx = ((io[:, 0] + io[:, 2]) / np.float32(2)).astype(np.int64).clip(0, gray.shape[1] - 1)
+    cy = ((io[:, 1] + io[:, 3]) / np.float32(2)).astype(np.int64).clip(0, gray.shape[0] - 1)
+    lines, normals, color = [], [], []
+    for ci in range(3):
+        area = self.dilate(bw[ci])
+        sel = io[area[cy, cx] > 0]
+        if len(sel) == 0:
+            continue
+        ol, on, _ = self.find_normals(area, sel.copy())
+        lines.append(ol)
+        normals.append(on.astype(np.float32))
+        color.append(np.full(len(ol), ci, np.uint8))
+    n = sum(len(a) for a in lines)
+    r = {"n": n}
+    r["lines"] = np.concatenate(lines) if n else np.zeros((0, 4), np.float32)
+    r["normals"] = np.concatenate(normals) if n else np.zeros((0, 2), np.float32)
+    r["color"] = np.concatenate(color) if n else np.zeros(0, np.uint8)
+    r["pixels_normalized"] = self.normalize_lines(r["lines"]) if n else np.zeros((0, 4), np.float32)
+    r["ground"] = self.ground_project(r["pixels_normalized"]) if n else np.zeros((0, 4), np.float64)
+    r["keep"] = self.line_sanity(r["ground"], r["color"])[0] if n else np.zeros(0, np.uint8)
+    if describe and n:
+        dx, dy = self.sobel3(self.gaussian5(gray))
+        ext, ang, npx = self.keylines(r["lines"], gray.shape[0], gray.shape[1])
+        r["desc"], r["code"] = self.lbd(dx, dy, ext, ang, npx)
+    else:
+        r["desc"], r["code"] = np.zeros((0, 72), np.float32), np.zeros((0, 32), np.uint8)
+    return r
+
+
+Oracle.process_frame_edlines = _process_frame_edlines
+
+
 def _jpeg_lib():
     build()
     lib = ctypes.CDLL(_SO)

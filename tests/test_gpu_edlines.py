@@ -270,3 +270,69 @@ def test_keylines_edge_cases_blank_flat_and_mixed_batches():
     only_blank = fe.keylines_batch(np.stack([blank, flat]), n_octaves=2, gray=True)
     assert only_blank["n"] == 0 and list(only_blank["frame_offset"]) == [0, 0, 0]
     fe.close()
+
+
+def test_edlines_detector_in_the_batched_path():
+    """lf_set_detector(LF_DETECTOR_EDLINES): lf_process_batch / the pipelined lf_process_batch_async + lf_wait with the EDLines
+    detector in place of Canny + LSD -- 256 frames (lane frames, blank and flat ones in between, camera frames), every field
+    of the SegmentList against the oracle composition (Oracle.process_frame_edlines: the contract of the one-frame plugin,
+    test_edlines_plugin_matches_the_oracle_composition, frame by frame), descriptors included; several handles in flight; and
+    back to LSD on the same handle."""
+    import os
+    cfg = default_config("fullres")
+    o = O.Oracle(cfg)
+    B = 256
+    base = synth.make_batch(20, seed0=1200)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_jpegs.npz"))
+    cam = np.stack([O.jpeg_decode(bytes(z["jpeg%02d" % k])) for k in (0, 7, 13, 22)])
+    uniq = np.concatenate([base, cam, np.zeros((1, 480, 640, 3), np.uint8), np.full((1, 480, 640, 3), 140, np.uint8)])
+    pick = np.arange(B) % len(uniq)
+    frames = np.ascontiguousarray(uniq[pick])
+    want = [o.process_frame_edlines(f) for f in uniq]
+    assert all(w is not None for w in want) and want[-1]["n"] == 0 and want[-2]["n"] == 0 and sum(w["n"] for w in want) > 300
+    fes = [FrontEnd(cfg, max_frames=B, max_lines_per_color=1024) for _ in range(3)]
+    for fe in fes:
+        fe.set_detector("edlines")
+    seg = fes[0].process_batch(frames, describe=True)
+    assert fes[0].detector_failures() == 0
+    for f in range(B):
+        s, r = seg.frame(f), want[pick[f]]
+        assert s.n == r["n"], (f, s.n, r["n"])
+        for k in ("lines", "normals", "color", "pixels_normalized", "ground", "keep", "code"):
+            assert np.array_equal(getattr(s, k), r[k]), (f, k)
+        assert np.array_equal(s.desc, r["desc"])
+    # pipelined: three handles in flight, device outputs, the same totals and codes
+    import torch
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(frames).to(dev)
+    cap = B * 3 * 1024
+    outs = [{"frame_offset": torch.zeros(B + 1, dtype=torch.int32, device=dev), "lines": torch.zeros((cap, 4), dtype=torch.float32, device=dev),
+             "color": torch.zeros(cap, dtype=torch.uint8, device=dev), "keep": torch.zeros(cap, dtype=torch.uint8, device=dev),
+             "code": torch.zeros((cap, 32), dtype=torch.uint8, device=dev)} for _ in fes]
+    for rep in range(2):
+        for fe, out in zip(fes, outs):
+            fe.submit_device(d.data_ptr(), B, {k: v.data_ptr() for k, v in out.items()}, cap, describe=True)
+        for fe, out in zip(fes, outs):
+            n = fe.wait()
+            assert n == seg.n
+            assert np.array_equal(out["frame_offset"].cpu().numpy(), seg.frame_offset)
+            assert np.array_equal(out["lines"][:n].cpu().numpy(), seg.lines) and np.array_equal(out["code"][:n].cpu().numpy(), seg.code)
+            assert np.array_equal(out["keep"][:n].cpu().numpy(), seg.keep)
+    # other parameters; and the LSD detector again on the same handle
+    p = fes[1].edlines_params(gradient_threshold=25, anchor_threshold=4, scan_intervals=1, min_line_len=10, line_fit_err_threshold=1.4)
+    fes[1].set_detector("edlines", p)
+    s2 = fes[1].process_batch(frames[:24], describe=False)
+    op = O.edlines_params(gradient_threshold=25, anchor_threshold=4, scan_intervals=1, min_line_len=10, line_fit_err_threshold=1.4)
+    for f in range(24):
+        r = o.process_frame_edlines(frames[f], op, describe=False)
+        s = s2.frame(f)
+        assert s.n == r["n"] and np.array_equal(s.lines, r["lines"]) and np.array_equal(s.color, r["color"]), f
+    fes[2].set_detector("lsd")
+    s3 = fes[2].process_batch(frames[:6])
+    for f in range(6):
+        r = o.process_frame(frames[f], cap=3 * 1024)
+        assert s3.frame(f).n == r["n"] and np.array_equal(s3.frame(f).lines, r["lines"])
+    with pytest.raises(ValueError):
+        fes[0].set_detector("hough")
+    for fe in fes:
+        fe.close()
