@@ -621,8 +621,65 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
         sec["edlines_keylines"] = {"value": round(B / kdt, 1), "unit": "frames/s", "ms_per_batch": round(kdt * 1e3, 3), "keylines_per_frame": round(ktot.value / B, 1),
                                    "what": "lf_keylines_batch: EDLines over 3 octaves + multi-octave LBD (BinaryDescriptor::operator()), %d frames resident, ONE batch in "
                                            "flight (synchronous call)" % B}
+        # the same, pipelined: lf_keylines_batch_async on D handles in flight (one output block per handle)
+        kouts = [kout] + [{k: torch.zeros_like(v) for k, v in kout.items()} for _ in range(D - 1)]
+        kfos = [kfo] + [torch.zeros_like(kfo) for _ in range(D - 1)]
+        kptrs = [dict({k: v.data_ptr() for k, v in o_.items()}, frame_offset=f_.data_ptr()) for o_, f_ in zip(kouts, kfos)]
+
+        def kl_go(nb):
+            inflight, tot = [], 0
+            for k_ in range(nb):
+                slot = k_ % D
+                if len(inflight) == D:
+                    tot += fes[inflight.pop(0)].wait()
+                fes[slot].keylines_submit_device(d.data_ptr(), B, kptrs[slot], kcap, n_octaves=3)
+                inflight.append(slot)
+            while inflight:
+                tot += fes[inflight.pop(0)].wait()
+            return tot
+        kl_go(D)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ktot2 = kl_go(4 * D)
+        torch.cuda.synchronize()
+        kdt2 = time.perf_counter() - t0
+        sec["edlines_keylines_pipelined"] = {"value": round(4 * D * B / kdt2, 1), "unit": "frames/s", "keylines_per_frame": round(ktot2 / (4 * D * B), 1), "batches_in_flight": D,
+                                             "what": "lf_keylines_batch_async + lf_wait: EDLines over 3 octaves + multi-octave LBD, %d batches of %d frames, %d in flight" % (4 * D, B, D)}
     except Exception as e:
         sec["edlines_keylines"] = {"error": repr(e)}
+
+    # ---- EDLines as the detector of the batched end-to-end path (lf_set_detector): detect (EDLines + colour masks) -> normals ->
+    # project -> sanity -> LBD, D batches in flight; association left out like in the content rows
+    try:
+        for f_ in fes:
+            f_.set_detector("edlines")
+        d = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+
+        def ed_go(nb):
+            inflight, segsum = [], 0
+            for k_ in range(nb):
+                slot = k_ % D
+                if len(inflight) == D:
+                    segsum += fes[inflight.pop(0)].wait()
+                fes[slot].submit_device(d.data_ptr(), B, ptrs[slot], cap, describe=True)
+                inflight.append(slot)
+            while inflight:
+                segsum += fes[inflight.pop(0)].wait()
+            return segsum
+        ed_go(D)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nseg = ed_go(6 * D)
+        torch.cuda.synchronize()
+        edt = time.perf_counter() - t0
+        sec["edlines_pipeline"] = {"value": round(6 * D * B / edt, 1), "unit": "frames/s", "segments_per_frame": round(nseg / (6 * D * B), 1), "batches_in_flight": D,
+                                   "what": "lf_process_batch_async with LF_DETECTOR_EDLINES: EDLines (one octave) on the gray working image + colour masks -> normals -> "
+                                           "project -> sanity -> LBD, the step's synthetic frames, %d batches of %d frames, %d in flight (no association)" % (6 * D, B, D)}
+    except Exception as e:
+        sec["edlines_pipeline"] = {"error": repr(e)}
+    finally:
+        for f_ in fes:
+            f_.set_detector("lsd")
 
     # ---- JPEG ingest (8f-1): CompressedImage streams -> host Huffman decode -> GPU IDCT/colour -> the same path
     try:

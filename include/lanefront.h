@@ -392,6 +392,14 @@ void lf_edlines_default_params(lf_edlines_params* p);
 int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                       const lf_edlines_params* params_or_null, lf_keylines* out, int out_on_device, int describe,
                       int* n_keylines, int32_t* frame_status_or_null);
+/* The pipelined form (like lf_process_batch_async): images and every out_dev array in device memory, the whole batch is queued
+ * on the handle's stream and the call returns; lf_wait blocks and returns the KeyLine total in *n_segments (LF_ERR_CAPACITY
+ * when it exceeds out_dev->capacity: no array is complete then); lf_keylines_frame_status copies the per-frame status of the
+ * batch lf_wait completed.  One batch in flight per handle; several handles keep the chip busy while one frame's edge walk
+ * is a single wave's chain. */
+int lf_keylines_batch_async(lf_handle* h, const uint8_t* images_dev, int n_frames, int input_kind, int n_octaves,
+                            const lf_edlines_params* params_or_null, lf_keylines* out_dev, int describe);
+int lf_keylines_frame_status(lf_handle* h, int32_t* frame_status, int n_frames);
 /* Plugin path with the EDLines detector: lf_set_image_edlines, then lf_detect_lines exactly as after lf_set_image.
  * The reference has ONE LineDetectorInterface implementation working on colour masks (LineDetectorLSD,
  * line_detector_lsd.py:11-142); this is the package's second (SURVEY 8f-4 "alternative detector plugin") and its

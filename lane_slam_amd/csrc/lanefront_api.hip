@@ -116,6 +116,7 @@ struct lf_handle {
     int last_frames = 0;
     bool plugin_ready = false;
     bool pending = false;
+    bool pending_keylines = false;        // the batch in flight is lf_keylines_batch_async's: lf_wait reads the KeyLine state
     bool grow_mixed = false;     // the last batch had problems beyond the slice in numbers (> 1 %): one launch with both kinds of problem code
     int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
     int detector = LF_DETECTOR_LSD;       // what lf_process_batch runs for a-2 .. a-4 (lf_set_detector)
@@ -611,6 +612,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
 }
 
 static int run_detect_edlines(lf_handle* h, const uint8_t* d_frames, int n);     // lanefront_keylines.inc
+static void keylines_pending_result(lf_handle* h, int* total, int* overflow);
 
 static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
 {
@@ -673,6 +675,7 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
     if (h->detector == LF_DETECTOR_EDLINES) LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[5], h->d_overflow + 4, sizeof(int), hipMemcpyDeviceToHost, s));
     else h->h_pinned[5] = 0;
     h->pending = true;
+    h->pending_keylines = false;
     h->pending_problems = n_frames * 3;
     h->pending_capacity = out_dev->capacity;
     return LF_OK;
@@ -685,6 +688,14 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
     LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     if (!h->pending) { if (n_segments) *n_segments = 0; return LF_OK; }
     h->pending = false;
+    if (h->pending_keylines) {
+        h->pending_keylines = false;
+        int total_kl = 0, overflow = 0;
+        keylines_pending_result(h, &total_kl, &overflow);
+        if (n_segments) *n_segments = total_kl;
+        if (overflow) { lf_set_error(h, LF_ERR_CAPACITY, "%d KeyLines exceed the output capacity %d", total_kl, h->pending_capacity); return LF_ERR_CAPACITY; }
+        return LF_OK;
+    }
     h->detector_failures = h->h_pinned[5];
     const int total = h->h_pinned[0];
     if (n_segments) *n_segments = total;

@@ -310,6 +310,22 @@ class FrontEnd(object):
         out["frame_status"] = status
         return out
 
+    def keylines_submit_device(self, images_ptr, n_frames, out_ptrs, capacity, n_octaves=1, describe=True, params=None, gray=False):
+        """Queue lf_keylines_batch_async: images_ptr = device address of the frames ((n, in_rows, in_cols, 3) BGR, or with
+        gray=True (n, rows, cols) u8), out_ptrs = {KeyLine field or "frame_offset": device address}.  wait() returns the
+        KeyLine total; keylines_frame_status() the per-frame status afterwards."""
+        s = _lib.LfKeylines()
+        s.capacity = int(capacity)
+        for k, v in out_ptrs.items():
+            setattr(s, k, int(v))
+        self._check(self.lib.lf_keylines_batch_async(self.h, ctypes.c_void_p(int(images_ptr)), int(n_frames), 1 if gray else 0, int(n_octaves),
+                                                     ctypes.byref(params) if params is not None else None, ctypes.byref(s), int(bool(describe))))
+
+    def keylines_frame_status(self, n_frames):
+        st = np.zeros(int(n_frames), np.int32)
+        self._check(self.lib.lf_keylines_frame_status(self.h, _ptr(st), int(n_frames)))
+        return st
+
     def describe_keylines(self, gray, line_frame, in_octave, angle, num_pixels, octave):
         """BinaryDescriptor::compute on GIVEN KeyLines (ref: binary_descriptor_custom.cpp:524-687; pyramid of
         computeGaussianPyramid :350-371).  gray: (n_frames, rows, cols) u8.  Returns (desc [n, 72], code [n, 32])."""

@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library is loaded: torch brings its own HIP runtime, which has to initialise first)
 
 from lane_slam_amd import FrontEnd, LanefrontError, default_config, synth
 from oracle import oracle as O
@@ -302,7 +303,6 @@ def test_edlines_detector_in_the_batched_path():
             assert np.array_equal(getattr(s, k), r[k]), (f, k)
         assert np.array_equal(s.desc, r["desc"])
     # pipelined: three handles in flight, device outputs, the same totals and codes
-    import torch
     dev = torch.device("cuda", 0)
     d = torch.from_numpy(frames).to(dev)
     cap = B * 3 * 1024
@@ -334,5 +334,41 @@ def test_edlines_detector_in_the_batched_path():
         assert s3.frame(f).n == r["n"] and np.array_equal(s3.frame(f).lines, r["lines"])
     with pytest.raises(ValueError):
         fes[0].set_detector("hough")
+    for fe in fes:
+        fe.close()
+
+
+def test_keylines_batch_async_equals_the_synchronous_call():
+    """lf_keylines_batch_async + lf_wait on three handles in flight: the arrays the synchronous call returns, the KeyLine total
+    from lf_wait, the frame status afterwards; an output that is too small is an error at lf_wait."""
+    cfg = default_config("fullres")
+    B = 48
+    frames = synth.make_batch(B, seed0=1500)
+    frames[5] = 0
+    fes = [FrontEnd(cfg, max_frames=B, max_lines_per_color=256) for _ in range(3)]
+    want = fes[0].keylines_batch(frames, n_octaves=3, capacity=B * 3000)
+    dev = torch.device("cuda", 0)
+    d = torch.from_numpy(frames).to(dev)
+    cap = B * 3000
+    spec = {"frame_offset": (B + 1, torch.int32), "start_end": ((cap, 4), torch.float32), "in_octave": ((cap, 4), torch.float32), "angle": (cap, torch.float32),
+            "num_pixels": (cap, torch.int32), "octave": (cap, torch.int32), "class_id": (cap, torch.int32), "line_length": (cap, torch.float32),
+            "desc": ((cap, 72), torch.float32), "code": ((cap, 32), torch.uint8)}
+    outs = [{k: torch.zeros(shape, dtype=dt, device=dev) for k, (shape, dt) in spec.items()} for _ in fes]
+    for rep in range(2):
+        for fe, out in zip(fes, outs):
+            fe.keylines_submit_device(d.data_ptr(), B, {k: v.data_ptr() for k, v in out.items()}, cap, n_octaves=3)
+        for fe, out in zip(fes, outs):
+            n = fe.wait()
+            assert n == want["n"] and n > 400
+            assert np.array_equal(fe.keylines_frame_status(B), want["frame_status"])
+            for k in spec:
+                got = out[k].cpu().numpy()
+                assert np.array_equal(got if k == "frame_offset" else got[:n], want[k]), k
+    small = {k: v.data_ptr() for k, v in outs[0].items()}
+    fes[0].keylines_submit_device(d.data_ptr(), B, small, 10, n_octaves=3)
+    with pytest.raises(LanefrontError):
+        fes[0].wait()
+    fes[0].keylines_submit_device(d.data_ptr(), B, small, cap, n_octaves=3)             # and the handle is fine afterwards
+    assert fes[0].wait() == want["n"]
     for fe in fes:
         fe.close()
