@@ -116,6 +116,10 @@ struct lf_handle {
     int last_frames = 0;
     bool plugin_ready = false;
     bool pending = false;
+    // plugin path: what lf_detect_lines hands out is fetched ONCE per image, behind the kernels of lf_set_image, into pinned host
+    // memory (the first kPlugEager segments of the SegmentList + the three mask images): lf_detect_lines is then a host copy
+    uint8_t* plug_host = nullptr; size_t plug_host_bytes = 0; uint8_t* plug_in = nullptr; size_t plug_in_bytes = 0;
+    int plug_eager = 0;
     bool pending_keylines = false;        // the batch in flight is lf_keylines_batch_async's: lf_wait reads the KeyLine state
     bool grow_mixed = false;     // the last batch had problems beyond the slice in numbers (> 1 %): one launch with both kinds of problem code
     int grow_lds_level = 0;      // index into kGrowLdsKb: k_lsd_grow's LDS slice, moved by the share of problems that overflowed it in the last batch
@@ -484,10 +488,12 @@ extern "C" void lf_destroy(lf_handle* h)
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
+                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p, h->d_laddr, h->d_lmod, h->d_nlow };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     assoc_scratch_free(h->a_ws);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    if (h->plug_host) (void)hipHostFree(h->plug_host);
+    if (h->plug_in) (void)hipHostFree(h->plug_in);
     for (DevBuf* b : { &h->m_fo, &h->m_color, &h->m_pn, &h->m_nm, &h->m_gr, &h->m_keep, &h->m_counts, &h->m_boff, &h->m_body, &h->m_bad })
         if (b->p) (void)hipFree(b->p);
     if (h->jpeg) {
@@ -759,6 +765,47 @@ extern "C" int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frame
     return LF_OK;
 }
 
+constexpr int kPlugEager = 1024;     // segments fetched with the image (more than a frame has at the plugin's geometries)
+
+// the caller's image -> pinned staging (it may reuse its buffer at once, np.copy in line_detector_lsd.py:136) -> the device,
+// asynchronously: no synchronisation before the kernels
+static int plugin_stage_image(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes)
+{
+    const size_t need = (size_t)rows * cols * 3;
+    if (h->plug_in_bytes < need) {
+        if (h->plug_in) (void)hipHostFree(h->plug_in);
+        h->plug_in = nullptr; h->plug_in_bytes = 0;
+        LF_HIP_CHECK(h, hipHostMalloc((void**)&h->plug_in, need));
+        h->plug_in_bytes = need;
+    }
+    LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));          // the previous image's copy out of the staging buffer (normally long done)
+    for (int y = 0; y < rows; ++y) memcpy(h->plug_in + (size_t)y * cols * 3, bgr + (size_t)y * row_stride_bytes, (size_t)cols * 3);
+    LF_HIP_CHECK(h, hipMemcpyAsync(h->d_frames, h->plug_in, need, hipMemcpyHostToDevice, h->stream));
+    return LF_OK;
+}
+
+// queue the copies of everything lf_detect_lines returns behind the kernels; layout of plug_host:
+// [lines eager x 16][normals64 eager x 16][centers eager x 8][3 mask images]
+static int plugin_fetch_results(lf_handle* h)
+{
+    hipStream_t s = h->stream;
+    const int eager = kPlugEager < 3 * h->cap_lines ? kPlugEager : 3 * h->cap_lines;
+    const size_t need = (size_t)eager * 40 + 3 * h->P;
+    if (h->plug_host_bytes < need) {
+        if (h->plug_host) (void)hipHostFree(h->plug_host);
+        h->plug_host = nullptr; h->plug_host_bytes = 0;
+        LF_HIP_CHECK(h, hipHostMalloc((void**)&h->plug_host, need));
+        h->plug_host_bytes = need;
+    }
+    h->plug_eager = eager;
+    uint8_t* p = h->plug_host;
+    LF_HIP_CHECK(h, hipMemcpyAsync(p, h->d_out.lines, (size_t)eager * 16, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(p + (size_t)eager * 16, h->d_normals64, (size_t)eager * 16, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(p + (size_t)eager * 32, h->d_centers, (size_t)eager * 8, hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(p + (size_t)eager * 40, h->dbg_masks.p, 3 * h->P, hipMemcpyDeviceToHost, s));
+    return LF_OK;
+}
+
 extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
@@ -768,10 +815,9 @@ extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols
     LF_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     h->plugin_ready = false;
-    // the copy completes before return: the caller may reuse its buffer (np.copy in line_detector_lsd.py:136)
-    LF_HIP_CHECK(h, hipMemcpy2DAsync(h->d_frames, (size_t)cols * 3, bgr, (size_t)row_stride_bytes, (size_t)cols * 3, rows, hipMemcpyHostToDevice, s));
-    LF_HIP_CHECK(h, hipStreamSynchronize(s));
-    int rc = run_detect(h, h->d_frames, 1, true);
+    int rc = plugin_stage_image(h, bgr, rows, cols, row_stride_bytes);
+    if (rc != LF_OK) return rc;
+    rc = run_detect(h, h->d_frames, 1, true);
     if (rc != LF_OK) return rc;
     lf_segments dev = h->d_out;
     dev.desc = nullptr; dev.code = nullptr;
@@ -782,9 +828,10 @@ extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols
     if ((rc = ensure(h, h->dbg_masks, 3 * h->P)) != LF_OK) return rc;
     launch_edges_u8(h->canny, 3, h->d_maskbits, (uint8_t*)h->dbg_masks.p, s);
     h->h_counts.resize(3); h->h_seg_offset.resize(4);
+    if ((rc = plugin_fetch_results(h)) != LF_OK) return rc;
     LF_HIP_CHECK(h, hipMemcpyAsync(h->h_counts.data(), h->d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipMemcpyAsync(h->h_seg_offset.data(), h->d_seg_offset, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));          // the ONE synchronisation of an image: counts, segments and masks are on the host
     h->plugin_ready = true;
     return LF_OK;
 }
@@ -802,6 +849,19 @@ extern "C" int lf_detect_lines(lf_handle* h, int color, float* lines4, double* n
     if (n > h->cap_lines) { lf_set_error(h, LF_ERR_CAPACITY, "LSD found %d lines, max_lines_per_color is %d", n, h->cap_lines); return LF_ERR_CAPACITY; }
     if (n > cap) { lf_set_error(h, LF_ERR_CAPACITY, "%d lines exceed caller capacity %d", n, cap); return LF_ERR_CAPACITY; }
     const size_t off = (size_t)h->h_seg_offset[color];
+    if (h->plug_host && off + (size_t)n <= (size_t)h->plug_eager) {
+        // everything came with the image: host copies, no device work and no synchronisation
+        const uint8_t* p = h->plug_host;
+        const size_t e = (size_t)h->plug_eager;
+        if (n > 0) {
+            if (lines4) memcpy(lines4, p + off * 16, (size_t)n * 16);
+            if (normals2) memcpy(normals2, p + e * 16 + off * 16, (size_t)n * 16);
+            if (centers2) memcpy(centers2, p + e * 32 + off * 8, (size_t)n * 8);
+        }
+        if (area_or_null) memcpy(area_or_null, p + e * 40 + (size_t)color * h->P, h->P);
+        *n_out = n;
+        return LF_OK;
+    }
     if (n > 0) {
         if (lines4) LF_HIP_CHECK(h, hipMemcpyAsync(lines4, h->d_out.lines + off * 4, (size_t)n * 4 * sizeof(float), hipMemcpyDeviceToHost, s));
         if (normals2) LF_HIP_CHECK(h, hipMemcpyAsync(normals2, h->d_normals64 + off * 2, (size_t)n * 2 * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -58,6 +58,7 @@ class LineDetectorHIP(LineDetectorInterface):
         self._cap = int(max_lines_per_color)
         self._fe = None
         self._shape = None
+        self._bufs = None
         self.bgr = np.empty(0)
         _lib.load()          # fail at construction time if the HIP library is missing
 
@@ -92,14 +93,16 @@ class LineDetectorHIP(LineDetectorInterface):
             raise Exception("detectLines called before setImage")
         fe = self._fe
         cap = self._cap
-        lines = np.empty((cap, 4), np.float32)
-        normals = np.empty((cap, 2), np.float64)
-        centers = np.empty((cap, 2), np.float32)
+        # the receiving arrays are made once per detector (the library fills them from pinned memory it fetched with the
+        # image: no device work here); what is returned are copies of the used part, as the reference returns fresh arrays
+        if self._bufs is None or self._bufs[0].shape[0] != cap:
+            self._bufs = (np.empty((cap, 4), np.float32), np.empty((cap, 2), np.float64), np.empty((cap, 2), np.float32))
+            self._bufp = tuple(b.ctypes.data_as(ctypes.c_void_p) for b in self._bufs)
+        lines, normals, centers = self._bufs
         area = np.empty(self._shape, np.uint8)
         n = ctypes.c_int()
-        vp = ctypes.c_void_p
-        fe._check(fe.lib.lf_detect_lines(fe.h, _COLOR_CODE[color], lines.ctypes.data_as(vp), normals.ctypes.data_as(vp),
-                                         centers.ctypes.data_as(vp), area.ctypes.data_as(vp), cap, ctypes.byref(n)))
+        fe._check(fe.lib.lf_detect_lines(fe.h, _COLOR_CODE[color], self._bufp[0], self._bufp[1], self._bufp[2],
+                                         area.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(n)))
         k = n.value
         if k == 0:
             return Detections(lines=[], normals=[], area=area, centers=[])   # line_detector_lsd.py:68-71,87-88
