@@ -362,7 +362,7 @@ const char* lf_map_stage_name(int stage);
  *                     images [n][img_rows - top_cutoff][img_cols] u8 as they are
  * frame_status        optional host [n_frames]: 0 ok; 1..4: the detector gave up on an octave of that frame (anchor /
  *                     edge arrays full, :1533-1537, :2185-2196; more than 5 lines per edge or than the handle holds;
- *                     more than 4096 lines in the frame) -- such a frame has no KeyLines, as in the reference, where
+ *                     more than 32 767 lines in the frame: the reference counts lines in a `short`) -- such a frame has no KeyLines, as in the reference, where
  *                     detectImpl ignores OctaveKeyLines' return value (:465-468)
  * Synchronous.  LF_ERR_CAPACITY when the KeyLines do not fit out->capacity. */
 #define LF_MAX_OCTAVES 5

@@ -1109,7 +1109,8 @@ int launch_ed_detect(const EdAll& all, const EdFitParams& fp, int n_octaves, int
 // ------------------------------------------------------------------------------------------------ k_kl_assemble
 // OctaveKeyLines' second half (:726-1022) + detectImpl (:478-509).  One workgroup per frame; lines of all octaves
 // indexed 0 .. n-1 in octave order (= octaveLines).  LDS: per line octave / id-in-octave / class / length.
-constexpr int kKlMaxLines = 4096;           // lines of one frame over all octaves that the grouping can hold in LDS
+constexpr int kKlMaxLines = 4096;           // lines of one frame over all octaves that the grouping holds in LDS (more: global scratch)
+constexpr int kKlHardMax = 32767;           // the reference's own limit: its line counters are `short` (binary_descriptor_custom.cpp:1029-1064)
 
 __global__ __launch_bounds__(256) void k_kl_count(EdAll all, int n_octaves, int n_frames, int* __restrict__ frame_count, int* __restrict__ status)
 {
@@ -1121,20 +1122,31 @@ __global__ __launch_bounds__(256) void k_kl_count(EdAll all, int n_octaves, int 
         if (c[1] < 0) st = c[3] ? c[3] : 2;
         total += c[2];
     }
-    if (total > kKlMaxLines) st = 4;
+    if (total > kKlHardMax) st = 4;
     frame_count[f] = st ? 0 : total;          // a failing detector yields no KeyLines for its frame (:465-468, return value ignored)
     status[f] = st;
 }
 
-__global__ __launch_bounds__(256) void k_kl_assemble(EdAll all, int n_octaves, const int* __restrict__ frame_offset, int capacity, KlOut out)
+// BIG = false: frames of up to kKlMaxLines lines, the grouping tables in LDS (every frame seen so far outside the tests).
+// BIG = true: the frames beyond (up to the reference's own `short` limit), the same code with the tables in global scratch
+// (big: [frame][big_stride] x (f32 + 3 x u16)); either launch leaves the other kind of frame alone.
+template <bool BIG>
+__global__ __launch_bounds__(256) void k_kl_assemble(EdAll all, int n_octaves, const int* __restrict__ frame_offset, int capacity, KlOut out,
+                                                     uint8_t* __restrict__ big, int big_stride, int lds_lines)
 {
-    __shared__ float s_len[kKlMaxLines];
-    __shared__ uint16_t s_oct[kKlMaxLines], s_lid[kKlMaxLines], s_cls[kKlMaxLines];
+    __shared__ float l_len[BIG ? 1 : kKlMaxLines];
+    __shared__ uint16_t l_oct[BIG ? 1 : kKlMaxLines], l_lid[BIG ? 1 : kKlMaxLines], l_cls[BIG ? 1 : kKlMaxLines];
     __shared__ int s_ostart[LF_MAX_OCTAVES + 1];
     __shared__ int s_wave[4], s_next_class;
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int base = frame_offset[f], n = frame_offset[f + 1] - base;
     if (n <= 0 || base + n > capacity) return;
+    if ((n > lds_lines) != BIG || (BIG && n > big_stride)) return;
+    uint8_t* mine = BIG ? big + (size_t)f * big_stride * 10 : nullptr;
+    float* s_len = BIG ? reinterpret_cast<float*>(mine) : l_len;
+    uint16_t* s_oct = BIG ? reinterpret_cast<uint16_t*>(mine + (size_t)big_stride * 4) : l_oct;
+    uint16_t* s_lid = BIG ? s_oct + big_stride : l_lid;
+    uint16_t* s_cls = BIG ? s_lid + big_stride : l_cls;
     if (tid == 0) {
         int acc = 0;
         for (int oc = 0; oc < n_octaves; ++oc) { s_ostart[oc] = acc; acc += all.o[oc].counts[4 * (size_t)f + 2]; }
@@ -1329,9 +1341,16 @@ void launch_kl_count(const EdAll& all, int n_octaves, int n_frames, int* frame_c
     hipLaunchKernelGGL(k_kl_count, dim3((n_frames + 255) / 256), dim3(256), 0, s, all, n_octaves, n_frames, frame_count, status);
 }
 
-void launch_kl_assemble(const EdAll& all, int n_octaves, int n_frames, const int* frame_offset, int capacity, const KlOut& out, hipStream_t s)
+void launch_kl_assemble(const EdAll& all, int n_octaves, int n_frames, const int* frame_offset, int capacity, const KlOut& out, uint8_t* big, int big_stride,
+                        int lds_lines, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_kl_assemble, dim3(n_frames), dim3(256), 0, s, all, n_octaves, frame_offset, capacity, out);
+    lds_lines = lds_lines < 1 ? 1 : (lds_lines > kKlMaxLines ? kKlMaxLines : lds_lines);
+    hipLaunchKernelGGL(k_kl_assemble<false>, dim3(n_frames), dim3(256), 0, s, all, n_octaves, frame_offset, capacity, out, big, big_stride, lds_lines);
+    // frames with more than kKlMaxLines lines (none so far outside the tests): the same grouping with its tables in global scratch
+    int max_total = 0;
+    for (int oc = 0; oc < n_octaves; ++oc) max_total += all.o[oc].max_lines;
+    if (big && max_total > lds_lines)
+        hipLaunchKernelGGL(k_kl_assemble<true>, dim3(n_frames), dim3(256), 0, s, all, n_octaves, frame_offset, capacity, out, big, big_stride, lds_lines);
 }
 
 // exclusive scan of the per-frame counts -> frame_offset [n_frames + 1]; total and overflow flag into pinned[0..1]

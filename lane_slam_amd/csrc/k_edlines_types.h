@@ -48,6 +48,7 @@ int launch_ed_detect(const EdAll& all, const EdFitParams& fp, int n_octaves, int
 void launch_ed_slots(const EdAll& all, int n_frames, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, int* failed, hipStream_t s);
 void launch_kl_count(const EdAll& all, int n_octaves, int n_frames, int* frame_count, int* status, hipStream_t s);
 void launch_kl_offsets(int n_frames, const int* frame_count, int capacity, int* frame_offset, int* totals, hipStream_t s);
-void launch_kl_assemble(const EdAll& all, int n_octaves, int n_frames, const int* frame_offset, int capacity, const KlOut& out, hipStream_t s);
+void launch_kl_assemble(const EdAll& all, int n_octaves, int n_frames, const int* frame_offset, int capacity, const KlOut& out, uint8_t* big, int big_stride,
+                        int lds_lines, hipStream_t s);
 
 }  // namespace lf

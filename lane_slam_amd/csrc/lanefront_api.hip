@@ -129,6 +129,7 @@ struct lf_handle {
     int tie_rule = LF_TIE_MIHASHER;   // lf_associate: the reference's rule unless lf_set_tie_rule says otherwise
     int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
     int env_mixed = -1;
+    int env_kl_lds_lines = 0;    // LF_KL_LDS_LINES (test hook of the KeyLine grouping, lanefront_keylines.inc)
     int pending_problems = 0;
     int pending_capacity = 0;
     std::vector<int> h_counts, h_seg_offset;
@@ -535,6 +536,7 @@ extern "C" int lf_create(const lf_config* cfg, int device_id, int max_frames, in
     memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches));
     if (const char* ev = getenv("LF_GROW_LDS_LEVEL")) { const int v = atoi(ev); h->env_lds_level = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* ev = getenv("LF_GROW_MIXED")) h->env_mixed = atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = getenv("LF_KL_LDS_LINES")) { const int v = atoi(ev); h->env_kl_lds_lines = v < 1 ? 1 : (v > 4096 ? 4096 : v); }
     int rc = LF_OK;
     do {
         if (hipSetDevice(device_id) != hipSuccess) { lf_set_error(h, LF_ERR_HIP, "hipSetDevice(%d) failed", device_id); rc = LF_ERR_HIP; break; }

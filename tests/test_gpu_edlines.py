@@ -372,3 +372,29 @@ def test_keylines_batch_async_equals_the_synchronous_call():
     assert fes[0].wait() == want["n"]
     for fe in fes:
         fe.close()
+
+
+def test_frames_beyond_the_lds_grouping_tables():
+    """A frame with more KeyLines over all octaves than the grouping kernel's LDS tables hold (4096) takes the same grouping with
+    its tables in global scratch (round 3 gave such a frame status 4 and no KeyLines; the reference's own limit is a `short`).
+    LF_KL_LDS_LINES (read when the handle is created) lowers the switch-over so that ordinary frames cross it: every KeyLine
+    field, descriptor and code against the oracle, mixed with frames that stay in LDS."""
+    cfg = default_config("fullres")
+    frames = synth.make_batch(5, seed0=1700)
+    frames[2] = 0
+    rng = np.random.default_rng(12)
+    busy = frames[4]
+    for _ in range(160):
+        y, x = int(rng.integers(170, 470)), int(rng.integers(10, 600))
+        busy[y:y + int(rng.integers(2, 5)), x:x + int(rng.integers(10, 40))] = int(rng.integers(60, 255))
+    gray = _gray_frames(cfg, frames)
+    os.environ["LF_KL_LDS_LINES"] = "40"
+    try:
+        fe = FrontEnd(cfg, max_frames=5, max_lines_per_color=256)
+    finally:
+        del os.environ["LF_KL_LDS_LINES"]
+    k = fe.keylines_batch(frames, n_octaves=3, capacity=5 * 6000)
+    n = _check_keylines(k, gray, 3)
+    counts = np.diff(k["frame_offset"])
+    assert (counts > 40).any() and (counts <= 40).any() and n > 200, counts
+    fe.close()
