@@ -46,20 +46,46 @@
 
 namespace lf {
 
+// Diagnostic build only (-DLF_SEED_STAMPS): per-phase cycle counts of the first problems, printed from the kernel
+#ifdef LF_SEED_STAMPS
+#define SEED_T(v) const long long v = (long long)wall_clock64()
+#else
+#define SEED_T(v) do { } while (0)
+#endif
+
 constexpr int ST = 1024;             // threads: 16 waves
 constexpr int SW = ST / 64;
 constexpr int SW2 = 8;               // waves that work in phase 2 (each with a private LDS range)
 constexpr int kSmall = 1024;         // ranges up to this size are one wave's work, in LDS (16 rows)
+constexpr int kBlock = 8192;         // ranges up to this size are copied into LDS and partitioned there by the whole workgroup
 constexpr int kSortThreshold = 16;   // libstdc++ _S_threshold
 constexpr int kMaxLdsBytes = 150 * 1024;
 constexpr int SNB = 16;              // buckets of the final counting passes
 constexpr int kU = 8;                // rows / pairs in flight per wave / lane in the streaming passes
 // one wave's private LDS in phase 2, 32-bit words: the range, the two place lists (u16), row tables, accumulators, range stack
 constexpr int kWaveWords = kSmall + kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
+// phase 1b (a block of <= kBlock elements in LDS): [block][aliased: the workgroup's place lists (u16) | 8 waves' private lists, tables,
+// stacks][the workgroup's row tables][the block's list of small ranges]
+constexpr int kBlkWaveWords = kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
+constexpr int kBlkX = SW2 * kBlkWaveWords > kBlock / 2 ? SW2 * kBlkWaveWords : kBlock / 2;
+constexpr int kBlkRows = kBlock / 64 + 2;
+constexpr int kBlkWords = kBlock + kBlkX + (kBlkRows * 6 + 8) + 2 * (kBlock / 16);
 
 __device__ __forceinline__ uint32_t key_of(uint32_t v) { return v >> 20; }
 // compare_norm(a, b) = a.norm > b.norm
 __device__ __forceinline__ bool comp(uint32_t a, uint32_t b) { return key_of(a) > key_of(b); }
+
+// Everything the partition passes keep in LDS is addressed AS LDS (address space 3): through a generic pointer every table access
+// is a flat instruction -- the long way to LDS, and a wait for whatever global access is in flight (v2 of this kernel spent most
+// of its time there: 50 us per partition).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) int lds_i32;
+template <typename T> __device__ __forceinline__ T* as_lds(void* generic) { return (T*)(__attribute__((address_space(3))) void*)generic; }
+__device__ __forceinline__ void lds_add(lds_i32* p, int v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_min(lds_i32* p, int v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_or(lds_i32* p, int v) { (void)__hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 {
@@ -151,8 +177,8 @@ __device__ __forceinline__ void team_sync()
 // Passes 2 - 4 and the cut, given the row ballots of [lo, hi) in BL / BR (pass 1 differs between the two users).  EP: the
 // elements (global or LDS), LP: the place lists (u32 in global scratch / u16 in LDS), positions relative to `org`.
 template <bool COOP, typename EP, typename LP>
-__device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, unsigned long long* BL, unsigned long long* BR, int* PL, int* SX,
-                                              int* acc, LP Lpos, LP Rpos, int w, int nw, int lane, int tid, int nthreads)
+__device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, lds_u64* BL, lds_u64* BR, lds_i32* PL, lds_i32* SX,
+                                              lds_i32* acc, LP Lpos, LP Rpos, int w, int nw, int lane, int tid, int nthreads)
 {
     const int R = (hi - lo + 63) >> 6;
     const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
@@ -182,6 +208,7 @@ __device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, uns
     team_sync<COOP>();
     // (3) ranks; an L element of rank k is swapped iff at least k R elements lie to its right (L_k < R_k), an R element of rank
     // k iff at least k L elements lie to its left; both publish their place under their rank
+    int wK = 0, wFirstL = 0x7fffffff, wFirstStay = 0x7fffffff;
     for (int r = w; r < R; r += nw) {
         const int i = lo + r * 64 + lane;
         const unsigned long long bl = BL[r], br = BR[r];
@@ -193,11 +220,14 @@ __device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, uns
         if (swr) Rpos[kr - 1] = i - org;
         const unsigned long long bs = __ballot(swl);
         const unsigned long long un = bl & ~bs;                                 // L elements of the row that stay
-        if (lane == 0) {
-            if (bs) atomicAdd(&acc[0], __popcll(bs));
-            if (bl) atomicMin(&acc[1], lo + r * 64 + __ffsll((long long)bl) - 1);
-            if (un) atomicMin(&acc[2], lo + r * 64 + __ffsll((long long)un) - 1);
-        }
+        wK += __popcll(bs);
+        if (bl) wFirstL = min(wFirstL, lo + r * 64 + __ffsll((long long)bl) - 1);
+        if (un) wFirstStay = min(wFirstStay, lo + r * 64 + __ffsll((long long)un) - 1);
+    }
+    if (lane == 0) {
+        if (wK) lds_add(&acc[0], wK);
+        if (wFirstL != 0x7fffffff) lds_min(&acc[1], wFirstL);
+        if (wFirstStay != 0x7fffffff) lds_min(&acc[2], wFirstStay);
     }
     team_sync<COOP>();
     // (4) the swaps
@@ -223,8 +253,8 @@ __device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, uns
 
 // __unguarded_partition of [f + 1, l) around E[f] (already the median) in global memory by the whole workgroup.  Returns the
 // cut, or -1 when the range [f, l) holds no seed (nothing was moved then, and nothing needs to be).
-__device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, unsigned long long* BL, unsigned long long* BR, int* PL, int* SX,
-                                                int* acc, uint32_t* Lpos, uint32_t* Rpos, int w, int lane)
+__device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, lds_u64* BL, lds_u64* BR, lds_i32* PL, lds_i32* SX,
+                                                lds_i32* acc, uint32_t* Lpos, uint32_t* Rpos, int w, int lane)
 {
     const int lo = f + 1, hi = l;
     const int R = (hi - lo + 63) >> 6;
@@ -248,19 +278,16 @@ __device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, unsig
                 if (lane == 0) { BL[r] = bl; BR[r] = br; PL[r] = __popcll(bl); SX[r] = __popcll(br); }
             }
         }
-        if (lane == 0 && seeds) atomicAdd(&acc[3], seeds);
+        if (lane == 0 && seeds) lds_add(&acc[3], seeds);
     }
     __syncthreads();
     if (acc[3] == 0) { __syncthreads(); return -1; }
     return partition_tail<true>(E, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW, lane, (int)threadIdx.x, ST);
 }
 
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-typedef __attribute__((address_space(3))) uint16_t lds_u16;
-
 // the same for a range [f, l) of a wave's LDS copy D (positions relative to the copy), one wave alone
-__device__ __forceinline__ int partition_lds(lds_u32* D, int f, int l, unsigned long long* BL, unsigned long long* BR, int* PL, int* SX,
-                                             int* acc, lds_u16* Lpos, lds_u16* Rpos, int lane)
+__device__ __forceinline__ int partition_lds(lds_u32* D, int f, int l, lds_u64* BL, lds_u64* BR, lds_i32* PL, lds_i32* SX,
+                                             lds_i32* acc, lds_u16* Lpos, lds_u16* Rpos, int lane)
 {
     const int lo = f + 1, hi = l;
     const int R = (hi - lo + 63) >> 6;
@@ -295,31 +322,96 @@ __device__ __forceinline__ void median_to_first_lds(lds_u32* E, int f, int l)
 
 // The introsort loop over E[0, n): phases 1 and 2 of the header.  scratch: global, 3 n / 4 + 64 u64 entries (the list of small
 // ranges, then the two place lists of the global partitions).
+// __unguarded_partition of [f + 1, l) of an LDS block by the whole workgroup (pass 1 on LDS, then the shared tail)
+__device__ __forceinline__ int partition_lds_coop(lds_u32* D, int f, int l, lds_u64* BL, lds_u64* BR, lds_i32* PL, lds_i32* SX,
+                                                  lds_i32* acc, lds_u16* Lpos, lds_u16* Rpos, int w, int lane)
+{
+    const int lo = f + 1, hi = l;
+    const int R = (hi - lo + 63) >> 6;
+    const uint32_t pivot = D[f];
+    if (threadIdx.x == 0) { acc[0] = 0; acc[1] = 0x7fffffff; acc[2] = 0x7fffffff; acc[3] = (pivot & 0xfffffu) != 0u; }
+    __syncthreads();
+    int seeds = 0;
+    for (int r = w; r < R; r += SW) {
+        const int i = lo + r * 64 + lane;
+        const bool valid = i < hi;
+        const uint32_t v = valid ? D[i] : 0u;
+        const unsigned long long bl = __ballot(valid && !comp(v, pivot));
+        const unsigned long long br = __ballot(valid && !comp(pivot, v));
+        seeds += __popcll(__ballot(valid && (v & 0xfffffu) != 0u));
+        if (lane == 0) { BL[r] = bl; BR[r] = br; PL[r] = __popcll(bl); SX[r] = __popcll(br); }
+    }
+    if (lane == 0 && seeds) lds_add(&acc[3], seeds);
+    __syncthreads();
+    if (acc[3] == 0) { __syncthreads(); return -1; }
+    return partition_tail<true>(D, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW, lane, (int)threadIdx.x, ST);
+}
+
+// one wave works off the whole subtree of the range [f, l) of an LDS array alone (private tables, lists and stack)
+__device__ __forceinline__ void wave_subtree(lds_u32* D, uint32_t* D_generic, int f, int l, int depth, lds_u64* wBL, lds_u64* wBR,
+                                             lds_i32* wPL, lds_i32* wSX, lds_i32* wacc, lds_u16* Lp, lds_u16* Rp, lds_i32* stack, int lane)
+{
+    int sp = 0;
+    for (;;) {
+        while (l - f > kSortThreshold) {
+            if (depth == 0) {
+                if (lane == 0) heap_sort_range(D_generic, f, l);
+                team_sync<false>();
+                break;
+            }
+            --depth;
+            if (lane == 0) median_to_first_lds(D, f, l);
+            team_sync<false>();
+            const int cut = partition_lds(D, f, l, wBL, wBR, wPL, wSX, wacc, Lp, Rp, lane);
+            if (cut < 0) break;
+            if (l - cut > kSortThreshold) {
+                if (lane == 0) { stack[2 * sp] = cut; stack[2 * sp + 1] = l | (depth << 24); }
+                ++sp;
+            }
+            l = cut;
+        }
+        if (sp == 0) break;
+        --sp;
+        team_sync<false>();
+        f = stack[2 * sp];
+        l = stack[2 * sp + 1] & 0xffffff;
+        depth = stack[2 * sp + 1] >> 24;
+    }
+    team_sync<false>();
+}
+
+#ifdef LF_SEED_STAMPS
+__device__ int g_dbg_big[8], g_dbg_small[8];
+__device__ long long g_dbg_t[8][4];
+#endif
 __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned long long* scratch, uint32_t* lds, int rows_cap)
 {
     // LDS carve-up: phase 1 = the row tables of the global partitions; phase 2 = one private block per working wave (aliased)
-    unsigned long long* BL = reinterpret_cast<unsigned long long*>(lds);
-    unsigned long long* BR = BL + rows_cap;
-    int* PL = reinterpret_cast<int*>(BR + rows_cap);
-    int* SX = PL + rows_cap;                              // rows_cap + 1 entries
-    unsigned long long* small_list = scratch;
-    uint32_t* Lpos = reinterpret_cast<uint32_t*>(scratch + (n / 16 + 64));
+    lds_u64* BL = as_lds<lds_u64>(lds);
+    lds_u64* BR = BL + rows_cap;
+    lds_i32* PL = (lds_i32*)(BR + rows_cap);
+    lds_i32* SX = PL + rows_cap;                          // rows_cap + 1 entries
+    unsigned long long* small_list = scratch;                          // ranges of <= kSmall elements cut straight from a global partition
+    unsigned long long* block_list = scratch + (n / 16 + 64);          // ranges of kSmall < size <= kBlock: phase 1b
+    uint32_t* Lpos = reinterpret_cast<uint32_t*>(block_list + (n / kSmall + 64));
     uint32_t* Rpos = Lpos + (n / 2 + 8);
-    __shared__ int acc[4];
+    __shared__ int acc_[4];
+    lds_i32* acc = as_lds<lds_i32>(acc_);
     __shared__ int big_stack[3 * 72];
-    __shared__ int n_big, n_small, next_small;
+    __shared__ int n_big, n_small, n_block, next_small, n_blk_small;
     __shared__ int cur[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    auto pack = [](int f, int l, int depth) { return (unsigned long long)f | ((unsigned long long)l << 20) | ((unsigned long long)depth << 40); };
     if (t == 0) {
-        n_big = 0; n_small = 0; next_small = 0;
+        n_big = 0; n_small = 0; n_block = 0; next_small = 0;
         const int depth0 = 2 * (31 - __clz(n));
-        if (n > kSortThreshold) {
-            if (n > kSmall) { big_stack[0] = 0; big_stack[1] = n; big_stack[2] = depth0; n_big = 1; }
-            else { small_list[0] = (unsigned long long)0 | ((unsigned long long)n << 20) | ((unsigned long long)depth0 << 40); n_small = 1; }
-        }
+        if (n > kBlock) { big_stack[0] = 0; big_stack[1] = n; big_stack[2] = depth0; n_big = 1; }
+        else if (n > kSmall) block_list[n_block++] = pack(0, n, depth0);
+        else if (n > kSortThreshold) small_list[n_small++] = pack(0, n, depth0);
     }
     __syncthreads();
-    // ---- phase 1
+    SEED_T(ta);
+    // ---- phase 1: ranges of more than kBlock elements, in global memory
     for (;;) {
         if (t == 0) {
             if (n_big > 0) { --n_big; cur[0] = big_stack[3 * n_big]; cur[1] = big_stack[3 * n_big + 1]; cur[2] = big_stack[3 * n_big + 2]; cur[3] = 1; }
@@ -330,7 +422,7 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned l
         int f = cur[0], l = cur[1], depth = cur[2];
         __syncthreads();
         // the libstdc++ loop on this range: go on with the left part while it is big, park the right part
-        while (l - f > kSmall) {
+        while (l - f > kBlock) {
             if (depth == 0) {
                 if (t == 0) heap_sort_range(E, f, l);
                 __syncthreads();
@@ -341,31 +433,141 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned l
             if (t == 0) median_to_first(E, f, l);
             __syncthreads();
             const int cut = partition_global(E, f, l, BL, BR, PL, SX, acc, Lpos, Rpos, w, lane);
+#ifdef LF_SEED_STAMPS
+            if (t == 0) atomicAdd(&g_dbg_big[blockIdx.x % 8], 1);
+#endif
             if (cut < 0) { l = f; break; }                           // no seed in the range: nothing to order
             if (t == 0) {
                 const int rs = l - cut;
-                if (rs > kSmall) { big_stack[3 * n_big] = cut; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = depth; ++n_big; }
-                else if (rs > kSortThreshold) small_list[n_small++] = (unsigned long long)cut | ((unsigned long long)l << 20) | ((unsigned long long)depth << 40);
+                if (rs > kBlock) { big_stack[3 * n_big] = cut; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = depth; ++n_big; }
+                else if (rs > kSmall) block_list[n_block++] = pack(cut, l, depth);
+                else if (rs > kSortThreshold) small_list[n_small++] = pack(cut, l, depth);
             }
             l = cut;
             __syncthreads();
         }
-        if (t == 0 && l - f > kSortThreshold) small_list[n_small++] = (unsigned long long)f | ((unsigned long long)l << 20) | ((unsigned long long)depth << 40);
+        if (t == 0) {
+            if (l - f > kSmall) block_list[n_block++] = pack(f, l, depth);
+            else if (l - f > kSortThreshold) small_list[n_small++] = pack(f, l, depth);
+        }
         __syncthreads();
     }
-    // ---- phase 2: a wave per listed range, copied into its private LDS block, its subtree on a private stack
+    SEED_T(tb);
+    // ---- phase 1b: every listed block is copied into LDS, partitioned there by the whole workgroup down to kSmall, its small
+    // ranges are worked off in place by eight waves, and it is copied back
+    {
+        lds_u32* Dg = as_lds<lds_u32>(lds);
+        uint32_t* xreg = lds + kBlock;
+        lds_u16* cLp = as_lds<lds_u16>(xreg);
+        lds_u16* cRp = cLp + kBlock / 2;
+        lds_u64* bBL = as_lds<lds_u64>(lds + kBlock + kBlkX);
+        lds_u64* bBR = bBL + kBlkRows;
+        lds_i32* bPL = (lds_i32*)(bBR + kBlkRows);
+        lds_i32* bSX = bPL + kBlkRows;
+        lds_u32* blk_small = as_lds<lds_u32>(lds + kBlock + kBlkX + (kBlkRows * 6 + 8));          // pairs (f, l | depth << 24)
+        const int nb = n_block;
+        for (int bi = 0; bi < nb; ++bi) {
+            const unsigned long long it = block_list[bi];
+            const int gf = (int)(it & 0xfffffu), gl = (int)((it >> 20) & 0xfffffu);
+            const int m = gl - gf;
+            __syncthreads();
+            if (t == 0) { acc[3] = 0; n_big = 0; n_blk_small = 0; next_small = 0; }
+            __syncthreads();
+            {
+                int seeds = 0;
+                for (int x0 = t; x0 < m; x0 += ST * kU) {
+                    uint32_t v[kU];
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; v[u] = x < m ? E[gf + x] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; if (x < m) { Dg[x] = v[u]; seeds |= (v[u] & 0xfffffu) != 0u; } }
+                }
+                if (__ballot(seeds) && lane == 0) lds_or(&acc[3], 1);
+            }
+            __syncthreads();
+            if (acc[3] == 0) continue;                                  // no seed in the block
+            if (t == 0) { big_stack[0] = 0; big_stack[1] = m; big_stack[2] = (int)(it >> 40); n_big = 1; }
+            __syncthreads();
+            for (;;) {
+                if (t == 0) {
+                    if (n_big > 0) { --n_big; cur[0] = big_stack[3 * n_big]; cur[1] = big_stack[3 * n_big + 1]; cur[2] = big_stack[3 * n_big + 2]; cur[3] = 1; }
+                    else cur[3] = 0;
+                }
+                __syncthreads();
+                if (!cur[3]) break;
+                int f = cur[0], l = cur[1], depth = cur[2];
+                __syncthreads();
+                while (l - f > kSmall) {
+                    if (depth == 0) {
+                        if (t == 0) heap_sort_range(lds, f, l);
+                        __syncthreads();
+                        l = f;
+                        break;
+                    }
+                    --depth;
+                    if (t == 0) median_to_first_lds(Dg, f, l);
+                    __syncthreads();
+                    const int cut = partition_lds_coop(Dg, f, l, bBL, bBR, bPL, bSX, acc, cLp, cRp, w, lane);
+                    if (cut < 0) { l = f; break; }
+                    if (t == 0) {
+                        const int rs = l - cut;
+                        if (rs > kSmall) { big_stack[3 * n_big] = cut; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = depth; ++n_big; }
+                        else if (rs > kSortThreshold) { blk_small[2 * n_blk_small] = (uint32_t)cut; blk_small[2 * n_blk_small + 1] = (uint32_t)l | ((uint32_t)depth << 24); ++n_blk_small; }
+                    }
+                    l = cut;
+                    __syncthreads();
+                }
+                if (t == 0 && l - f > kSortThreshold) { blk_small[2 * n_blk_small] = (uint32_t)f; blk_small[2 * n_blk_small + 1] = (uint32_t)l | ((uint32_t)depth << 24); ++n_blk_small; }
+                __syncthreads();
+            }
+            // the block's small ranges: eight waves, in place (their private lists alias the workgroup's place lists, which are idle now)
+            if (w < SW2) {
+                uint32_t* mine = xreg + (size_t)w * kBlkWaveWords;
+                lds_u16* Lp = as_lds<lds_u16>(mine);
+                lds_u16* Rp = Lp + kSmall / 2;
+                lds_u64* wBL = as_lds<lds_u64>(mine + kSmall / 2);
+                lds_u64* wBR = wBL + 18;
+                lds_i32* wPL = (lds_i32*)(wBR + 18);
+                lds_i32* wSX = wPL + 18;
+                lds_i32* wacc = wSX + 20;
+                lds_i32* stack = wacc + 8;
+                const int total = n_blk_small;
+                for (;;) {
+                    int idx = 0;
+                    if (lane == 0) idx = atomicAdd(&next_small, 1);
+                    idx = __shfl(idx, 0);
+                    if (idx >= total) break;
+                    const uint32_t a = blk_small[2 * idx], b = blk_small[2 * idx + 1];
+                    wave_subtree(Dg, lds, (int)a, (int)(b & 0xffffffu), (int)(b >> 24), wBL, wBR, wPL, wSX, wacc, Lp, Rp, stack, lane);
+                }
+            }
+            __syncthreads();
+            for (int x0 = t; x0 < m; x0 += ST * kU) {
+#pragma unroll
+                for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; if (x < m) E[gf + x] = Dg[x]; }
+            }
+        }
+        __syncthreads();
+        if (t == 0) next_small = 0;
+        __syncthreads();
+    }
+    SEED_T(tc);
+    // ---- phase 2: a wave per range cut straight from a global partition, copied into its private LDS block
     if (w < SW2) {
         uint32_t* mine = lds + (size_t)w * kWaveWords;
-        lds_u32* D = (lds_u32*)(__attribute__((address_space(3))) void*)mine;
+        lds_u32* D = as_lds<lds_u32>(mine);
         lds_u16* Lp = (lds_u16*)(D + kSmall);
         lds_u16* Rp = Lp + kSmall / 2;
-        unsigned long long* wBL = reinterpret_cast<unsigned long long*>(mine + kSmall + kSmall / 2);
-        unsigned long long* wBR = wBL + 18;
-        int* wPL = reinterpret_cast<int*>(wBR + 18);
-        int* wSX = wPL + 18;
-        int* wacc = wSX + 20;
-        int* stack = wacc + 8;                                    // 64 x (f, l | depth << 24)
+        lds_u64* wBL = as_lds<lds_u64>(mine + kSmall + kSmall / 2);
+        lds_u64* wBR = wBL + 18;
+        lds_i32* wPL = (lds_i32*)(wBR + 18);
+        lds_i32* wSX = wPL + 18;
+        lds_i32* wacc = wSX + 20;
+        lds_i32* stack = wacc + 8;                                // 64 x (f, l | depth << 24)
         const int total = n_small;
+#ifdef LF_SEED_STAMPS
+        if (t == 0) g_dbg_small[blockIdx.x % 8] = total + 1000 * n_block;
+#endif
         for (;;) {
             int idx = 0;
             if (lane == 0) idx = atomicAdd(&next_small, 1);
@@ -378,38 +580,14 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, unsigned l
             for (int x = lane; x < m; x += 64) { const uint32_t v = E[gf + x]; D[x] = v; seeds |= (v & 0xfffffu) != 0u; }
             if (!__ballot(seeds)) continue;                           // no seed: leave it as it is
             team_sync<false>();
-            int sp = 0;
-            int f = 0, l = m, depth = (int)(it >> 40);
-            for (;;) {
-                while (l - f > kSortThreshold) {
-                    if (depth == 0) {
-                        if (lane == 0) heap_sort_range(reinterpret_cast<uint32_t*>(mine), f, l);
-                        team_sync<false>();
-                        break;
-                    }
-                    --depth;
-                    if (lane == 0) median_to_first_lds(D, f, l);
-                    team_sync<false>();
-                    const int cut = partition_lds(D, f, l, wBL, wBR, wPL, wSX, wacc, Lp, Rp, lane);
-                    if (cut < 0) break;
-                    if (l - cut > kSortThreshold) {
-                        if (lane == 0) { stack[2 * sp] = cut; stack[2 * sp + 1] = l | (depth << 24); }
-                        ++sp;
-                    }
-                    l = cut;
-                }
-                if (sp == 0) break;
-                --sp;
-                team_sync<false>();
-                f = stack[2 * sp];
-                l = stack[2 * sp + 1] & 0xffffff;
-                depth = stack[2 * sp + 1] >> 24;
-            }
-            team_sync<false>();
+            wave_subtree(D, mine, 0, m, (int)(it >> 40), wBL, wBR, wPL, wSX, wacc, Lp, Rp, stack, lane);
             for (int x = lane; x < m; x += 64) E[gf + x] = D[x];
         }
     }
     __syncthreads();
+#ifdef LF_SEED_STAMPS
+    { const long long td = (long long)wall_clock64(); if (t == 0) { g_dbg_t[blockIdx.x % 8][0] = tb - ta; g_dbg_t[blockIdx.x % 8][1] = tc - tb; g_dbg_t[blockIdx.x % 8][2] = td - tc; } }
+#endif
 }
 
 // one stable 4-bit counting pass (same scheme as k_lsd_order.hip's radix_pass: every thread owns a contiguous run; [16][1024] counters)
@@ -470,6 +648,7 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
     const int n = Wg * Hg;
     const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
     const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
+    SEED_T(t0);
     // ---- phase 0
     for (int i = t; i < n; i += ST) E[i] = 0u;
     __syncthreads();
@@ -485,15 +664,22 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
         E[y * Wg + x] = (uint32_t)(int)(l_mod[o + j] * bin_coef) << 20;
     }
     __syncthreads();
+    SEED_T(t1);
     // ---- phases 1, 2
     introsort_loop_wg(E, n, small_list, seed_lds, rows_cap);          // (the scratch: this problem's slice of sort_b, Ps >= 3 n / 4 + 64 entries)
+    SEED_T(t2);
     // ---- phase 3: the seeds in array order ...
     int* rowc = reinterpret_cast<int*>(seed_lds);                  // [rows + 1]
     const int R = (n + 63) >> 6;
-    for (int r = w; r < R; r += SW) {
-        const int i = r * 64 + lane;
-        const unsigned long long b = __ballot(i < n && (E[i] & 0xfffffu) != 0u);
-        if (lane == 0) rowc[r] = __popcll(b);
+    for (int r0 = w * kU; r0 < R; r0 += SW * kU) {
+        uint32_t v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int i = (r0 + u) * 64 + lane; v[u] = i < n ? E[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const unsigned long long b = __ballot((v[u] & 0xfffffu) != 0u);
+            if (lane == 0 && r0 + u < R) rowc[r0 + u] = __popcll(b);
+        }
     }
     __syncthreads();
     if (w == 0) {
@@ -507,12 +693,16 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
         }
     }
     __syncthreads();
-    for (int r = w; r < R; r += SW) {
-        const int i = r * 64 + lane;
-        const uint32_t v = i < n ? E[i] : 0u;
-        const bool seed = (v & 0xfffffu) != 0u;
-        const unsigned long long b = __ballot(seed);
-        if (seed) B[rowc[r] + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)((p.n_bins - 1) - (int)key_of(v)) << 20) | ((v & 0xfffffu) - 1u);
+    for (int r0 = w * kU; r0 < R; r0 += SW * kU) {
+        uint32_t v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) { const int i = (r0 + u) * 64 + lane; v[u] = i < n ? E[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const bool seed = (v[u] & 0xfffffu) != 0u;
+            const unsigned long long b = __ballot(seed);
+            if (seed) B[rowc[r0 + u] + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)((p.n_bins - 1) - (int)key_of(v[u])) << 20) | ((v[u] & 0xfffffu) - 1u);
+        }
     }
     __syncthreads();
     // ... and the final insertion sort: stable by bin, highest bin first (n_seeds == nd: every defined pixel is in the array once)
@@ -520,6 +710,9 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
     seed_radix_pass(B, A, nd, 20, cnt, tot, base);
     seed_radix_pass(A, B, nd, 24, cnt, tot, base);
     seed_radix_pass(B, A, nd, 28, cnt, tot, base);
+#ifdef LF_SEED_STAMPS
+    { const long long t3 = (long long)wall_clock64(); if (t == 0 && pc < 6) printf("[seed32] problem %d: n %d seeds %d low %d | phase0 %lld  loop %lld (%d big partitions, %d small ranges)  phase3 %lld  | global %lld  blocks %lld  small %lld (x10 ns)\n", pc, n, nd, nl, t1 - t0, t2 - t1, g_dbg_big[pc % 8], g_dbg_small[pc % 8], t3 - t2, g_dbg_t[pc % 8][0], g_dbg_t[pc % 8][1], g_dbg_t[pc % 8][2]); }
+#endif
 }
 
 // debug / test entry: std::sort(compare_norm) of n elements (key << 20 | index + 1) given in E; leaves E as the introsort loop
@@ -546,6 +739,7 @@ static size_t seed_lds_bytes(int rows_cap)
 {
     size_t words = (size_t)rows_cap * 6 + 128;
     if (words < (size_t)SW2 * kWaveWords) words = (size_t)SW2 * kWaveWords;
+    if (words < (size_t)kBlkWords) words = (size_t)kBlkWords;
     if (words < (size_t)SNB * ST) words = (size_t)SNB * ST;
     return words * sizeof(uint32_t);
 }

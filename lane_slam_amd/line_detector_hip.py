@@ -39,7 +39,10 @@ class LineDetectorInterface(object):
 
 
 class LineDetectorHIP(LineDetectorInterface):
-    def __init__(self, configuration, device=0, max_lines_per_color=2048):
+    def __init__(self, configuration, device=0, max_lines_per_color=2048, lsd_seed_order="opencv30"):
+        """configuration: the reference's 13 keys (line_detector_lsd.py:20-34), nothing else.  lsd_seed_order (keyword, not a
+        configuration key): "opencv30" or "opencv32" -- which OpenCV's LSD seed order inside a gradient bin (lf_config.lsd_seed_order;
+        ROS Kinetic's 3.3.1 is "opencv32")."""
         if not isinstance(configuration, dict):
             raise ValueError("Expecting a dict, obtained %r" % (configuration,))
         configuration = copy.deepcopy(configuration)
@@ -54,6 +57,7 @@ class LineDetectorHIP(LineDetectorInterface):
                 v = np.array(v)
             setattr(self, k, v)
         self._configuration = configuration
+        self._seed_order = lsd_seed_order
         self._device = device
         self._cap = int(max_lines_per_color)
         self._fe = None
@@ -72,6 +76,7 @@ class LineDetectorHIP(LineDetectorInterface):
             cfg["top_cutoff"] = 0
             cfg["detector"] = {k: (list(map(int, v)) if hasattr(v, "__len__") else v)
                                for k, v in self._configuration.items()}
+            cfg["lsd"]["seed_order"] = self._seed_order
             self._fe = FrontEnd(cfg, device=self._device, max_frames=1, max_lines_per_color=self._cap)
             self._shape = (rows, cols)
         return self._fe

@@ -143,4 +143,17 @@ def test_plugin_and_bad_values():
     hd["lsd"]["seed_order"] = "opencv32"
     with pytest.raises(LanefrontError):                      # 1536 x 576 LSD pixels: beyond the row tables, refused at lf_create
         FrontEnd(hd)
-    assert LineDetectorHIP is not None
+    # the plugin classes take it as a keyword beside the reference's 13 configuration keys
+    from lane_slam_amd import DEFAULT_DETECTOR_CONFIGURATION
+    cfg = default_config("parity")
+    cfg["lsd"]["seed_order"] = "opencv32"
+    o = Oracle(cfg)
+    det = LineDetectorHIP(dict(DEFAULT_DETECTOR_CONFIGURATION), lsd_seed_order="opencv32")
+    work = o.preprocess(frame)
+    det.setImage(work)
+    r = o.process_frame(frame, cap=3 * 512, describe=False)
+    got = [det.detectLines(c) for c in ("white", "yellow", "red")]
+    n = sum(len(d.lines) for d in got)
+    assert n == r["n"] and n > 0
+    cat = np.concatenate([np.asarray(d.lines, np.float32).reshape(-1, 4) for d in got])
+    assert np.array_equal(cat, r["lines"])
