@@ -748,6 +748,9 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
     mcodes = synth.random_codes(50000, 1234)
     am = LineAssociator(capacity=50048, color_gating=False, kept_only=False, device=device_id)
     am.seed(mcodes)
+    # the same map with the reference's tie rule (LF_TIE_MIHASHER: a second matrix pass that ranks the equally near entries)
+    am_mih = LineAssociator(capacity=50048, color_gating=False, kept_only=False, device=device_id, tie_rule="mihasher")
+    am_mih.seed(mcodes)
     for nq in (4096, 16384):
         q = synth.random_codes(nq, 99)
         planted = rng.choice(nq, nq // 20, replace=False)
@@ -771,17 +774,34 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
         tm = am.timing()
         am.set_profiling(False)
         ms_core = tm["assoc_mfma"][0] / max(tm["assoc_mfma"][1], 1)
+        di2 = torch.zeros(nq, dtype=torch.int32, device=dev)
+        for _ in range(3):
+            am_mih.associate_device(None, dq.data_ptr(), None, nq, di2.data_ptr(), dd.data_ptr())
+        am_mih.synchronize()
+        am_mih.timing()
+        am_mih.set_profiling(True)
+        for _ in range(20):
+            am_mih.associate_device(None, dq.data_ptr(), None, nq, di2.data_ptr(), dd.data_ptr())
+        am_mih.synchronize()
+        tm2 = am_mih.timing()
+        am_mih.set_profiling(False)
+        ms_mih = tm2["assoc_mfma"][0] / max(tm2["assoc_mfma"][1], 1)
         ops = 2.0 * nq * 50000 * 256
         stress.append({"N": nq, "M": 50000, "assoc_ms": round(ms_core, 4),
                        "Pop_per_s": round(ops / (ms_core * 1e-3) / 1e15, 3),
                        "frac_of_int8_mfma_peak": round(ops / (ms_core * 1e-3) / 1e15 / INT8_MFMA_PEAK_POPS, 3),
                        "frac_of_fp4_mfma_peak": round(ops / (ms_core * 1e-3) / 1e15 / (2 * INT8_MFMA_PEAK_POPS), 3),
-                       "matched_within_128": int((di >= 0).sum().item())})
+                       "matched_within_128": int((di >= 0).sum().item()),
+                       "assoc_ms_tie_rule_mihasher": round(ms_mih, 4), "tie_pass_ms": round(ms_mih - ms_core, 4),
+                       "indices_changed_by_the_tie_rule": int((di != di2).sum().item())})
     am.close()
+    am_mih.close()
     sec["assoc_stress_configs4"] = {"rows": stress, "peak_Pop_per_s": INT8_MFMA_PEAK_POPS,
                                     "what": "lf_map_associate on a 50 000-code map kept packed on the device; ops = 2*N*M*256 (SURVEY 8d); the ungated map runs on the FP4 matrix "
                                             "instruction (e2m1 +-1 operands, exact f32 accumulation), whose dense peak is 2 x the int8 peak: both fractions are given; "
-                                            "assoc_ms = the whole association (ONE launch: query expansion, MFMA loop, merge, report), HIP events on the map's stream, 20 calls"}
+                                            "assoc_ms = the whole association (ONE launch: query expansion, MFMA loop, merge, report), HIP events on the map's stream, 20 calls; "
+                                            "assoc_ms_tie_rule_mihasher = the same with lf_map_set_tie_rule(LF_TIE_MIHASHER): + the pass that ranks equally near entries "
+                                            "by the reference's discovery order (k_assoc_ties.hip)"}
     return sec
 
 
