@@ -400,6 +400,17 @@ int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int inp
 int lf_keylines_batch_async(lf_handle* h, const uint8_t* images_dev, int n_frames, int input_kind, int n_octaves,
                             const lf_edlines_params* params_or_null, lf_keylines* out_dev, int describe);
 int lf_keylines_frame_status(lf_handle* h, int32_t* frame_status, int n_frames);
+/* The library's OTHER detector: LSDDetectorC::detect (src/line_descriptor/src/LSDDetector_custom.cpp:49-72, 130-215) -- a gray
+ * pyramid by pyrDown (scale 2, no blur), cv::createLineSegmentDetector() with its DEFAULT parameters (REFINE_STD) on every level,
+ * one KeyLine per line (checkLineExtremes, start / end points scaled back to level 0, lineLength, numOfPixels = LineIterator's
+ * count, angle, size, response, pt; class_id counts through the octaves of a frame; no mask) -- and with describe != 0
+ * BinaryDescriptor::compute on those KeyLines (lf_describe_keylines).  Same lf_keylines block as lf_keylines_batch (salience is 0:
+ * not a KeyLine field); same input kinds.  Synchronous.  Every level runs the front end's LSD kernels on a GRAY image through a
+ * sub-handle of the level's geometry: dense problems, one wave per connected component -- a completeness path (detect -> compute
+ * for both detectors of the library), not a fast one.  LF_ERR_CAPACITY: more KeyLines than out->capacity, or a level with more
+ * lines than max_lines_per_color. */
+int lf_lsd_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+                          lf_keylines* out, int out_on_device, int describe, int* n_keylines);
 /* Plugin path with the EDLines detector: lf_set_image_edlines, then lf_detect_lines exactly as after lf_set_image.
  * The reference has ONE LineDetectorInterface implementation working on colour masks (LineDetectorLSD,
  * line_detector_lsd.py:11-142); this is the package's second (SURVEY 8f-4 "alternative detector plugin") and its

@@ -125,6 +125,9 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
                      const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
                      int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
                      uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s);
+void launch_lsd_grad_gray(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint8_t* gray, uint32_t* r_addr, float* r_deg,
+                          double* r_mod, double* r_cs, double* r_sn, int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy,
+                          uint32_t* list, int* list_count, uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s);
 // the seed order of OpenCV >= 3.2 (k_lsd_seed32.hip): rewrites order_a after launch_lsd_order; l_*: k_lsd_grad's "low" records
 bool lsd_seed32_supported(const LsdParams& p);
 void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const unsigned long long* maxgrad, const uint32_t* c_xy,

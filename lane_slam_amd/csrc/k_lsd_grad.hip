@@ -93,7 +93,8 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
                                                   int* __restrict__ n_rec, unsigned long long* __restrict__ maxgrad,
                                                   int max_nsx, int max_nsy, const uint32_t* __restrict__ list,
                                                   const int* __restrict__ list_count,
-                                                  uint32_t* __restrict__ l_addr, double* __restrict__ l_mod, int* __restrict__ n_low)
+                                                  uint32_t* __restrict__ l_addr, double* __restrict__ l_mod, int* __restrict__ n_low,
+                                                  const uint8_t* __restrict__ gray)
 {
     extern __shared__ double lds_d[];
     __shared__ double T[128];                     // ordered partial sums of k[j]*255 per 7-bit pattern
@@ -146,8 +147,11 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         const int nsx = sx_hi - sx_lo + 1, nsy = sy_hi - sy_lo + 1;
         const int nox = X1 - X0 + 1, noy = Y1 - Y0 + 1;   // scaled samples needed (incl. +1 neighbour)
         const int rw = nsx + 2 * h, rh = nsy + 2 * h;
-        const uint32_t* mk = mask_bits + (size_t)pc * p.Hc * p.Ww;
-        const uint32_t* eb = edge_bits + (size_t)f * p.Hc * p.Ww;
+        // gray != nullptr: LSD of a GRAY image (LSDDetectorC::detect runs cv's LSD on the levels of a gray pyramid,
+        // LSDDetector_custom.cpp:150-160): the raw tile is the image itself, [frame][Hc][W] u8, no bit planes
+        const uint8_t* gimg = gray ? gray + (size_t)f * p.Hc * p.W : nullptr;
+        const uint32_t* mk = gray ? nullptr : mask_bits + (size_t)pc * p.Hc * p.Ww;
+        const uint32_t* eb = gray ? nullptr : edge_bits + (size_t)f * p.Hc * p.Ww;
         if (threadIdx.x == 0) { n_def = 0; n_lo = 0; tile_max = 0ull; }
         // this tile's slice of the resize tables -> LDS (no dependent global loads in the passes below)
         if (threadIdx.x < nox) {
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         // raw rows as bit windows: bit t of rowbits[ty] = edge_color(reflect(sx_lo-h+t), reflect(sy_lo-h+ty))
         const int xs = sx_lo - h;
         const bool interior_x = xs >= 0 && xs + rw <= p.W && rw <= 64;
-        for (int ty = threadIdx.x; ty < rh; ty += LG_T) {
+        for (int ty = threadIdx.x; ty < (gray ? 0 : rh); ty += LG_T) {
             const int gy = reflect101(sy_lo - h + ty, p.Hc);
             const uint32_t* er = eb + (size_t)gy * p.Ww;
             const uint32_t* mr = mk + (size_t)gy * p.Ww;
@@ -192,7 +196,19 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         // row filter (table lookup; general path for wide kernels or windows > 64 bits)
         const bool small = rh * nsx < 4096 && nsx < 128;      // the magic division holds
         const uint32_t m_nsx = (1u << 19) / (uint32_t)nsx + 1u, m_nox = (1u << 19) / (uint32_t)nox + 1u;
-        if (use_table && rw <= 64) {
+        if (gray) {
+            // cv::RowFilter<uchar, double>: s = k[0] * S[0]; s += k[j] * S[j], the u8 samples converted to double
+            for (int idx = threadIdx.x; idx < rh * nsx; idx += LG_T) {
+                const int ry = idx / nsx, cx = idx - ry * nsx;
+                const uint8_t* row = gimg + (size_t)reflect101(sy_lo - h + ry, p.Hc) * p.W;
+                double s = 0.0;
+                for (int j = 0; j < p.ntaps; ++j) {
+                    const double term = p.k[j] * (double)row[reflect101(xs + cx + j, p.W)];
+                    if (j == 0) s = term; else s += term;
+                }
+                F[idx] = s;
+            }
+        } else if (use_table && rw <= 64) {
             const int msk = (1 << p.ntaps) - 1;
             for (int idx = threadIdx.x; idx < rh * nsx; idx += LG_T) {
                 const int ry = small ? div_small(idx, m_nsx) : idx / nsx, cx = idx - ry * nsx;
@@ -336,7 +352,41 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(LG_T), lds, s, p, rt, edge_bits, mask_bits, r_addr, r_deg, r_mod, r_cs,
-                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low);
+                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low, nullptr);
+}
+
+// every tile of colour 0 of every frame: the tile list of a gray image (nothing to classify)
+__global__ void k_lsd_list_all(int n_frames, int ntx, int nty, uint32_t* __restrict__ list, int* __restrict__ list_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = ntx * nty;
+    if (i >= n_frames * per) return;
+    const int f = i / per, t = i - f * per;
+    list[i] = ((uint32_t)(f * 3) << 16) | ((uint32_t)(t / ntx) << 8) | (uint32_t)(t % ntx);
+    if (i == 0) *list_count = n_frames * per;
+}
+
+// LSD front half on GRAY images [n_frames][Hc][W] (problem f * 3 holds frame f; problems f * 3 + 1, f * 3 + 2 stay empty)
+void launch_lsd_grad_gray(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint8_t* gray, uint32_t* r_addr, float* r_deg,
+                          double* r_mod, double* r_cs, double* r_sn, int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy,
+                          uint32_t* list, int* list_count, uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s)
+{
+    const int h = p.half;
+    const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
+    const size_t szHb = (size_t)max_nsy * (GT + 1), szSc = (size_t)(GT + 1) * (GT + 1);
+    size_t regA = szF > szHb ? szF : szHb;
+    const size_t min_a = (size_t)(l_addr ? 4 : 2) * GT * GT;
+    if (regA < min_a) regA = min_a;
+    const size_t regB = szBl > szSc ? szBl : szSc;
+    const size_t lds = sizeof(double) * (regA + regB);
+    const int ntx = (p.Ws + GT - 1) / GT, nty = (p.Hs + GT - 1) / GT;
+    (void)hipMemsetAsync(n_rec, 0, (size_t)n_frames * 3 * sizeof(int), s);
+    if (n_low) (void)hipMemsetAsync(n_low, 0, (size_t)n_frames * 3 * sizeof(int), s);
+    hipLaunchKernelGGL(k_lsd_list_all, dim3((n_frames * ntx * nty + 255) / 256), dim3(256), 0, s, n_frames, ntx, nty, list, list_count);
+    const int per_cu = (int)((150 * 1024) / (lds + 3072));
+    const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+    hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(LG_T), lds, s, p, rt, nullptr, nullptr, r_addr, r_deg, r_mod, r_cs,
+                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low, gray);
 }
 
 }  // namespace lf

@@ -135,6 +135,7 @@ struct lf_handle {
     std::vector<int> h_counts, h_seg_offset;
     JpegState* jpeg = nullptr;
     struct KlState* kl = nullptr;       // EDLines / KeyLines state (lanefront_keylines.inc), allocated on first use
+    struct LsdKlState* lsdkl = nullptr; // LSDDetectorC over octaves (lanefront_lsdkl.inc): sub-handles per pyramid level
     DevBuf m_fo, m_color, m_pn, m_nm, m_gr, m_keep, m_counts, m_boff, m_body, m_bad;   // SegmentList glue scratch
     // profiling
     bool profiling = false;
@@ -477,6 +478,8 @@ extern "C" const char* lf_stage_name(int stage) { return (stage >= 0 && stage < 
 
 struct KlState;
 static void kl_free(KlState* k);
+struct LsdKlState;
+static void lsdkl_free(LsdKlState* k);
 
 extern "C" void lf_destroy(lf_handle* h)
 {
@@ -505,6 +508,7 @@ extern "C" void lf_destroy(lf_handle* h)
         delete j;
     }
     kl_free(h->kl);
+    lsdkl_free(h->lsdkl);
     timing_resolve(h);
     for (EvPair& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1538,4 +1542,5 @@ extern "C" int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int 
 }
 
 #include "lanefront_keylines.inc"
+#include "lanefront_lsdkl.inc"
 #include "lanefront_jpeg_gpu.inc"

@@ -310,6 +310,36 @@ class FrontEnd(object):
         out["frame_status"] = status
         return out
 
+    def lsd_keylines_batch(self, images, n_octaves=1, describe=True, gray=False, capacity=None):
+        """LSDDetectorC::detect over n_octaves pyramid levels (ref: LSDDetector_custom.cpp:130-215) + BinaryDescriptor::compute:
+        the same dict as keylines_batch (no 'frame_status'; 'salience' is 0).  images as in keylines_batch."""
+        images = np.ascontiguousarray(images, np.uint8)
+        want = (self.rows, self.cols) if gray else (self.in_rows, self.in_cols, 3)
+        if images.ndim == len(want):
+            images = images[None]
+        if images.shape[1:] != want:
+            raise ValueError("images must be (n,%s), got %r" % (",".join(map(str, want)), images.shape))
+        n = images.shape[0]
+        cap = int(capacity) if capacity else n * 2048
+        out = {"frame_offset": np.zeros(n + 1, np.int32)}
+        s = _lib.LfKeylines()
+        s.capacity = cap
+        s.frame_offset = out["frame_offset"].ctypes.data
+        for k, dt, c in _lib.KEYLINE_FIELDS:
+            if k in ("desc", "code") and not describe:
+                continue
+            out[k] = np.zeros((cap, c) if c > 1 else cap, np.dtype(dt))
+            setattr(s, k, out[k].ctypes.data)
+        total = ctypes.c_int()
+        self._check(self.lib.lf_lsd_keylines_batch(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves), ctypes.byref(s), 0,
+                                                   int(bool(describe)), ctypes.byref(total)))
+        t = total.value
+        for k, _, _ in _lib.KEYLINE_FIELDS:
+            if k in out:
+                out[k] = out[k][:t]
+        out["n"] = t
+        return out
+
     def keylines_submit_device(self, images_ptr, n_frames, out_ptrs, capacity, n_octaves=1, describe=True, params=None, gray=False):
         """Queue lf_keylines_batch_async: images_ptr = device address of the frames ((n, in_rows, in_cols, 3) BGR, or with
         gray=True (n, rows, cols) u8), out_ptrs = {KeyLine field or "frame_offset": device address}.  wait() returns the

@@ -367,6 +367,51 @@ def _process_frame_edlines(self, bgr_in, params=None, describe=True):
 Oracle.process_frame_edlines = _process_frame_edlines
 
 
+def lsd_octave_keylines(gray, n_octaves=1, describe=True, seed_order="opencv30"):
+    """LSDDetectorC::detect (ref: src/line_descriptor/src/LSDDetector_custom.cpp:49-72, 130-215) + BinaryDescriptor::compute,
+    composed from the oracle's pieces: pyrDown pyramid (no blur), cv LSD with createLineSegmentDetector()'s defaults on every level,
+    KeyLine fill (:164-197), descriptors on compute's own pyramid.  Same dict keys as octave_keylines."""
+    from lane_slam_amd import default_config
+    gray = np.ascontiguousarray(gray, np.uint8)
+    out = {k: [] for k in ("start_end", "in_octave", "angle", "num_pixels", "line_length", "octave", "class_id", "response", "size", "pt")}
+    level = gray
+    cls = 0
+    for o in range(n_octaves):
+        rows, cols = level.shape
+        cfg = default_config("parity")
+        cfg["in_size"] = [rows, cols]; cfg["img_size"] = [rows, cols]; cfg["top_cutoff"] = 0
+        cfg["lsd"] = {"refine": 1, "scale": 0.8, "sigma_scale": 0.6, "quant": 2.0, "ang_th": 22.5, "log_eps": 0.0, "density_th": 0.7,
+                      "n_bins": 1024, "seed_order": seed_order}
+        oc = Oracle(cfg)
+        lines = np.asarray(oc.lsd(level, cap=20000), np.float32).reshape(-1, 4)
+        ext, _, npx = oc.keylines(lines, rows, cols)
+        n = ext.shape[0]
+        scale = np.float32(1 << o)
+        se = (ext * scale).astype(np.float32)
+        dx = (ext[:, 0] - ext[:, 2]).astype(np.float32).astype(np.float64)
+        dy = (ext[:, 1] - ext[:, 3]).astype(np.float32).astype(np.float64)
+        length = np.sqrt(dx * dx + dy * dy).astype(np.float32)
+        lib = ctypes.CDLL(_SO)
+        lib.lfo_atan2.restype = ctypes.c_double
+        lib.lfo_atan2.argtypes = [ctypes.c_double, ctypes.c_double]
+        ang = np.array([np.float32(lib.lfo_atan2(float(np.float32(se[i, 3] - se[i, 1])), float(np.float32(se[i, 2] - se[i, 0])))) for i in range(n)], np.float32)
+        out["start_end"].append(se); out["in_octave"].append(ext); out["angle"].append(ang); out["num_pixels"].append(npx)
+        out["line_length"].append(length); out["octave"].append(np.full(n, o, np.int32)); out["class_id"].append(np.arange(cls, cls + n, dtype=np.int32))
+        out["response"].append((length / np.float32(max(cols, rows))).astype(np.float32))
+        out["size"].append(((se[:, 2] - se[:, 0]) * (se[:, 3] - se[:, 1])).astype(np.float32))
+        out["pt"].append(np.stack([(se[:, 2] + se[:, 0]) / np.float32(2), (se[:, 3] + se[:, 1]) / np.float32(2)], axis=1).astype(np.float32))
+        cls += n
+        if o + 1 < n_octaves:
+            level = pyrdown_u8(level)
+    r = {k: (np.concatenate(v) if v else np.zeros(0)) for k, v in out.items()}
+    r["n"] = cls
+    if describe and cls:
+        r["desc"], r["code"] = describe_keylines(gray, r["in_octave"], r["angle"], r["num_pixels"], r["octave"])
+    else:
+        r["desc"], r["code"] = np.zeros((0, 72), np.float32), np.zeros((0, 32), np.uint8)
+    return r
+
+
 def _jpeg_lib():
     build()
     lib = ctypes.CDLL(_SO)

@@ -1,0 +1,67 @@
+"""LSDDetectorC::detect over octaves + BinaryDescriptor::compute on the device (ref:
+/root/reference/src/line_descriptor/src/LSDDetector_custom.cpp:49-72, 130-215): pyrDown pyramid, cv LSD with its default
+parameters (REFINE_STD) on every gray level, one KeyLine per line, descriptors from compute's own pyramid -- lf_lsd_keylines_batch
+against the oracle composition (oracle.lsd_octave_keylines), every field."""
+import os
+
+import numpy as np
+import pytest
+
+from lane_slam_amd import FrontEnd, LanefrontError, default_config, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("start_end", "in_octave", "angle", "num_pixels", "line_length", "octave", "class_id", "response", "size", "pt")
+
+
+def _check(k, gray, n_octaves, seed_order="opencv30"):
+    total = 0
+    for f in range(gray.shape[0]):
+        r = O.lsd_octave_keylines(gray[f], n_octaves, seed_order=seed_order)
+        a, b = int(k["frame_offset"][f]), int(k["frame_offset"][f + 1])
+        assert b - a == r["n"], (f, b - a, r["n"])
+        for name in FIELDS:
+            assert np.array_equal(k[name][a:b], r[name]), (f, name)
+        assert np.array_equal(k["code"][a:b], r["code"]), f
+        assert np.array_equal(k["desc"][a:b], r["desc"]) and np.abs(k["desc"][a:b] - r["desc"]).max(initial=0) <= 1e-4
+        total += r["n"]
+    assert k["n"] == total
+    return total
+
+
+@pytest.mark.parametrize("geometry,n_octaves", [("fullres", 3), ("parity", 2), ("fullres", 1)])
+def test_lsd_keylines_on_lane_frames(geometry, n_octaves):
+    cfg = default_config(geometry)
+    o = O.Oracle(cfg)
+    B = 5
+    frames = synth.make_batch(B, seed0=2100 + n_octaves)
+    frames[3] = 0                                                         # a blank frame in between: no KeyLines, offsets stay right
+    gray = np.stack([o.bgr2gray(o.preprocess(f)) for f in frames])
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=1024)
+    k = fe.lsd_keylines_batch(frames, n_octaves=n_octaves)
+    n = _check(k, gray, n_octaves)
+    assert n > (20 if geometry == "fullres" else 4) and k["frame_offset"][4] == k["frame_offset"][3]
+    k2 = fe.lsd_keylines_batch(gray, n_octaves=n_octaves, gray=True)     # the gray-image entry point gives the same
+    for name in ("frame_offset", "in_octave", "class_id", "code"):
+        assert np.array_equal(k[name], k2[name]), name
+    with pytest.raises(LanefrontError):
+        fe.lsd_keylines_batch(frames, n_octaves=n_octaves, capacity=3)
+    fe.close()
+
+
+def test_lsd_keylines_on_camera_frames_and_the_opencv32_seed_order(golden_dir):
+    """Gray camera images are dense LSD problems (60 k defined pixels in one connected component, grown by one wave; hundreds of
+    lines per level): two frames, two octaves, both seed orders."""
+    z = np.load(os.path.join(golden_dir, "real_jpegs.npz"))
+    frames = np.stack([O.jpeg_decode(bytes(z["jpeg%02d" % k])) for k in (7, 19)])
+    for seed_order in ("opencv30", "opencv32"):
+        cfg = default_config("fullres")
+        cfg["lsd"]["seed_order"] = seed_order
+        o = O.Oracle(cfg)
+        gray = np.stack([o.bgr2gray(o.preprocess(f)) for f in frames])
+        fe = FrontEnd(cfg, max_frames=2, max_lines_per_color=4096)
+        k = fe.lsd_keylines_batch(frames, n_octaves=2, capacity=2 * 4096)
+        n = _check(k, gray, 2, seed_order)
+        assert n > 300
+        fe.close()
