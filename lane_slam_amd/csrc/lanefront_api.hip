@@ -213,6 +213,8 @@ struct StageTimer {
 
 static int cv_round_host(double v) { return dm::round_half_even(v); }
 
+static thread_local bool g_lsd_only_create = false;      // set around the lf_create of an LSD-only sub-handle (lanefront_lsdkl.inc)
+
 static int build_params(lf_handle* h)
 {
     const lf_config& c = h->cfg;
@@ -223,7 +225,9 @@ static int build_params(lf_handle* h)
                      c.img_cols, c.top_cutoff);
         return LF_ERR_BAD_ARG;
     }
-    if (h->W % 32 != 0) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols must be a multiple of 32 (got %d)", h->W); return LF_ERR_UNSUPPORTED; }
+    // (the bit planes of the front end are whole 32-bit words per row; a sub-handle that only runs the LSD stages on gray pyramid
+    // levels -- lanefront_lsdkl.inc -- never touches them)
+    if (h->W % 32 != 0 && !g_lsd_only_create) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols must be a multiple of 32 (got %d)", h->W); return LF_ERR_UNSUPPORTED; }
     h->P = (size_t)h->Hc * h->W;
     h->Ww = (h->W + 31) / 32;
     // ---- pre
