@@ -221,6 +221,12 @@ int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* 
  * Exact XOR / popcount, one lane per query (k_knn.hip); on_device applies to every array. */
 int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, int k, int32_t* idx, float* dist,
                  int on_device);
+/* The `mask` argument of match / knnMatch / radiusMatch (binary_descriptor_matcher.cpp:231-235, 305-309, 477-481): a DMatch is made
+ * only for the queries whose mask byte is not 0, and carries its queryIdx.  lf_select_queries compacts those queries (in order)
+ * into selected32 [<= nq][32] with their row numbers in query_idx; run any of the three forms on selected32 -- result row i
+ * then belongs to query query_idx[i].  Blocking (returns the count). */
+int lf_select_queries(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* mask, uint8_t* selected32, int32_t* query_idx,
+                      int* n_selected, int on_device);
 int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, float max_distance,
                     int32_t* offsets, int32_t* idx, float* dist, int cap, int* total, int on_device);
 

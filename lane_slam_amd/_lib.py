@@ -26,7 +26,7 @@ EXPORTS = (
     "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_step_host", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
     "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu",
-    "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch",
+    "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
 )
 DETECTORS = {"lsd": 0, "edlines": 1}
 TIE_RULES = {"lowest": 0, "mihasher": 1}
@@ -166,6 +166,8 @@ def load():
     lib.lf_set_image_edlines.restype = ci
     lib.lf_keylines_batch_async.argtypes = [vp, vp, ci, ci, ci, ctypes.POINTER(LfEdlinesParams), ctypes.POINTER(LfKeylines), ci]
     lib.lf_keylines_batch_async.restype = ci
+    lib.lf_select_queries.argtypes = [vp, vp, ci, vp, vp, vp, ctypes.POINTER(ci), ci]
+    lib.lf_select_queries.restype = ci
     lib.lf_lsd_keylines_batch.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfKeylines), ci, ci, ctypes.POINTER(ci)]
     lib.lf_lsd_keylines_batch.restype = ci
     lib.lf_keylines_frame_status.argtypes = [vp, vp, ci]

@@ -162,6 +162,43 @@ __global__ __launch_bounds__(KQ) void k_radius_fill(const uint8_t* __restrict__ 
     }
 }
 
+// The matcher's per-query mask (binary_descriptor_matcher.cpp:231-235, 305-309, 477-481: a DMatch is made only for queries whose
+// mask byte is not 0, and carries its queryIdx): the unmasked queries, in order, with their original row numbers.  One workgroup;
+// stable compaction by ballot ranks and a running offset.
+__global__ __launch_bounds__(1024) void k_select_queries(const uint8_t* __restrict__ query, const uint8_t* __restrict__ mask, int nq,
+                                                         uint8_t* __restrict__ out, int32_t* __restrict__ qidx, int* __restrict__ n_out)
+{
+    __shared__ int s_wave[16], s_base;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int start = 0; start < nq; start += 1024) {
+        const int i = start + t;
+        const bool keep = i < nq && mask[i] != 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        if (keep) {
+            const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+            const uint4* src = reinterpret_cast<const uint4*>(query + (size_t)i * 32);
+            uint4* dst = reinterpret_cast<uint4*>(out + (size_t)pos * 32);
+            dst[0] = src[0]; dst[1] = src[1];
+            qidx[pos] = i;
+        }
+        __syncthreads();
+        if (t == 0) { int tot = 0; for (int w = 0; w < 16; ++w) tot += s_wave[w]; s_base += tot; }
+        __syncthreads();
+    }
+    if (t == 0) *n_out = s_base;
+}
+
+void launch_select_queries(const uint8_t* q, const uint8_t* mask, int nq, uint8_t* out, int32_t* qidx, int* n_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_select_queries, dim3(1), dim3(1024), 0, s, q, mask, nq, out, qidx, n_out);
+}
+
 void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int32_t* idx, float* dist, hipStream_t s)
 {
     hipLaunchKernelGGL(k_knn, dim3((nq + KQ - 1) / KQ), dim3(KQ), 0, s, q, nq, m, nm, k, max_distance, idx, dist);

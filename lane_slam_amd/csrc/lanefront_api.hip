@@ -974,6 +974,40 @@ extern "C" int lf_associate_float(lf_handle* h, const float* query72, int nq, co
 }
 
 // knnMatch / radiusMatch (binary_descriptor_matcher.cpp:258-335, 428-504): k_knn.hip
+extern "C" int lf_select_queries(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* mask, uint8_t* selected32, int32_t* query_idx,
+                                 int* n_selected, int on_device)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (nq < 0 || !n_selected || (nq > 0 && (!query32 || !mask || !selected32 || !query_idx))) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_select_queries: bad argument"); return LF_ERR_BAD_ARG; }
+    *n_selected = 0;
+    if (nq == 0) return LF_OK;
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = ensure(h, h->kn_total, 4 * sizeof(int))) != LF_OK) return rc;
+    const uint8_t *dq = query32, *dmask = mask;
+    uint8_t* dsel = selected32; int32_t* dqi = query_idx;
+    if (!on_device) {
+        if ((rc = ensure(h, h->a_q, (size_t)nq * 32)) || (rc = ensure(h, h->a_m, (size_t)nq * 33)) || (rc = ensure(h, h->a_idx, (size_t)nq * 4))) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, query32, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+        uint8_t* m8 = static_cast<uint8_t*>(h->a_m.p) + (size_t)nq * 32;
+        LF_HIP_CHECK(h, hipMemcpyAsync(m8, mask, (size_t)nq, hipMemcpyHostToDevice, s));
+        dq = static_cast<const uint8_t*>(h->a_q.p); dmask = m8; dsel = static_cast<uint8_t*>(h->a_m.p); dqi = static_cast<int32_t*>(h->a_idx.p);
+    }
+    launch_select_queries(dq, dmask, nq, dsel, dqi, static_cast<int*>(h->kn_total.p), s);
+    LF_HIP_CHECK(h, hipGetLastError());
+    int n = 0;
+    LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->kn_total.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    *n_selected = n;
+    if (!on_device && n > 0) {
+        LF_HIP_CHECK(h, hipMemcpyAsync(selected32, dsel, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipMemcpyAsync(query_idx, dqi, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+    }
+    return LF_OK;
+}
+
 extern "C" int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, int k, int32_t* idx, float* dist,
                             int on_device)
 {

@@ -215,6 +215,19 @@ class FrontEnd(object):
         self._check(self.lib.lf_associate(self.h, ctypes.c_void_p(int(q_ptr)), int(nq), ctypes.c_void_p(int(m_ptr)),
                                           int(nm), ctypes.c_void_p(int(idx_ptr)), ctypes.c_void_p(int(dist_ptr)), 1))
 
+    def select_queries(self, query_codes, mask):
+        """The matcher's per-query mask (ref: binary_descriptor_matcher.cpp:231-235): (codes of the queries whose mask byte is not
+        0, their row numbers = DMatch.queryIdx).  Feed the codes to associate / knn_match / radius_match."""
+        q = np.ascontiguousarray(query_codes, dtype=np.uint8).reshape(-1, 32)
+        m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+        if m.shape[0] != q.shape[0]:
+            raise ValueError("mask must have one byte per query")
+        sel = np.empty_like(q)
+        qi = np.empty(q.shape[0], np.int32)
+        n = ctypes.c_int()
+        self._check(self.lib.lf_select_queries(self.h, _ptr(q), q.shape[0], _ptr(m), _ptr(sel), _ptr(qi), ctypes.byref(n), 0))
+        return sel[:n.value].copy(), qi[:n.value].copy()
+
     def knn_match(self, query_codes, map_codes, k):
         """BinaryDescriptorMatcher::knnMatch (ref: binary_descriptor_matcher.cpp:258-335): (idx [nq, k] int32, dist [nq, k]
         float32), nearest first, within 128 bits; -1 where there are fewer than k."""

@@ -158,3 +158,28 @@ def test_live_map_with_the_references_rule(gating):
     for k in ("code", "color", "hits", "last_seen"):
         assert np.array_equal(g[k][:so["size"]], r[k][:so["size"]]), k
     a.close()
+
+
+def test_query_mask_of_the_matcher():
+    """match / knnMatch / radiusMatch with a mask (ref: binary_descriptor_matcher.cpp:231-235, 305-309, 477-481): DMatches only for
+    the queries whose mask byte is not 0, each with its queryIdx -- lf_select_queries + the unchanged calls."""
+    from oracle.oracle import Oracle
+    o = Oracle(default_config("parity"))
+    fe = FrontEnd(default_config("parity"))
+    rng = np.random.default_rng(8)
+    m = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (2500, 32), dtype=np.uint8)
+    mask = (rng.random(2500) < 0.4).astype(np.uint8) * rng.integers(1, 255, 2500).astype(np.uint8)
+    sel, qi = fe.select_queries(q, mask)
+    keep = np.nonzero(mask)[0]
+    assert np.array_equal(qi, keep) and np.array_equal(sel, q[keep])
+    gi, gd = fe.associate(sel, m)
+    wi, wd, _ = o.match_mih(q, m)
+    assert np.array_equal(gi, wi[keep]) and np.array_equal(gd, wd[keep])
+    ki, kd = fe.knn_match(sel, m, 3)
+    oi, od = o.knn_match(q, m, 3)
+    assert np.array_equal(ki, oi[keep]) and np.array_equal(kd, od[keep])
+    for mk in (np.zeros(2500, np.uint8), np.ones(2500, np.uint8)):
+        s2, q2 = fe.select_queries(q, mk)
+        assert len(q2) == int(mk.sum()) and np.array_equal(s2, q[mk != 0])
+    fe.close()
