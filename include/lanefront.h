@@ -204,7 +204,7 @@ int lf_detector_failures(const lf_handle* h);
 #define LF_TIE_MIHASHER 1
 int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
                  int32_t* idx, float* dist, int on_device);
-/* tie rule of this handle's lf_associate (LF_TIE_MIHASHER unless set) */
+/* tie rule of this handle's lf_associate, lf_knn_match and lf_radius_match (LF_TIE_MIHASHER unless set) */
 int lf_set_tie_rule(lf_handle* h, int tie_rule);
 /* float LBD (72-d, unit norm) Euclidean nearest neighbour on fp32 MFMA */
 int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
@@ -212,7 +212,8 @@ int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* 
 
 /* The list forms of the matcher (SURVEY a-10): BinaryDescriptorMatcher::knnMatch (binary_descriptor_matcher.cpp:258-335)
  * and radiusMatch (:428-504) = Mihasher with K = k / K = N: the nearest map codes within D = 128 bits, nearest first.
- * Among equally near codes: index order (the reference: its hash tables' discovery order; same deviation as lf_associate).
+ * Among equally near codes: the handle's tie rule (lf_set_tie_rule) -- LF_TIE_MIHASHER (default): the reference's discovery order,
+ * i.e. (distance, discovery key, index) as Mihasher::query records them (:716-722); LF_TIE_LOWEST: (distance, index).
  * lf_knn_match    idx / dist [nq][k], k <= 16; slots beyond the matches within 128 bits: idx -1, dist -1 (the reference
  *                 leaves them unset)
  * lf_radius_match all map codes within min(max_distance, 128) bits per query as a CSR list: offsets [nq + 1], idx / dist

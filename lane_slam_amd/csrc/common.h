@@ -226,9 +226,9 @@ void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks,
                        hipStream_t s);
 // knnMatch / radiusMatch forms (k_knn.hip)
 void launch_select_queries(const uint8_t* q, const uint8_t* mask, int nq, uint8_t* out, int32_t* qidx, int* n_out, hipStream_t s);
-void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int32_t* idx, float* dist, hipStream_t s);
+void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int mih, int32_t* idx, float* dist, hipStream_t s);
 void launch_radius(const uint8_t* q, int nq, const uint8_t* m, int nm, int max_distance, int32_t* hist, int32_t* count, int32_t* offsets,
-                   int* total, int cap, int32_t* idx, float* dist, hipStream_t s);
+                   int* total, int cap, int mih, int32_t* idx, float* dist, hipStream_t s);
 void launch_assoc_float(const float* q, int nq, const float* m, int nm, float* qn, float* mn,
                         unsigned long long* best, int32_t* idx, float* dist, hipStream_t s);
 // ---- JPEG ingest (k_jpeg.hip)

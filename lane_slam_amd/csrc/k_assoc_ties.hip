@@ -16,6 +16,7 @@
 // (rare) equal ones -- the ties -- leave the matrix pipeline: their discovery key is worked out from the query's raw code and
 // the map row's nibbles, both in LDS, and folded with a 64-bit atomic minimum (key << 32 | index), first in LDS, then once per query and map chunk in memory.
 #include "common.h"
+#include "mih_rank.h"
 
 namespace lf {
 
@@ -23,33 +24,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-// Position of every 8-bit string among the strings of its weight, in the order the reference's combination loop visits them
-// (:681-741 with curb = 8).  up[i] is one more than the place of the i-th one (up[i] == i: not placed yet); the ones from
-// `mv` down are placed / moved, the string is reported, then every one that touches the one above it (the top one: the
-// end of the byte) is taken off again and the first that does not is the next to move up a place.
-struct MihRank { uint8_t r[5][256]; };
-constexpr MihRank make_mih_rank()
-{
-    MihRank t{};
-    for (int s = 0; s <= 4; ++s) {
-        int up[6] = { 0, 1, 2, 3, 4, 5 };
-        up[s] = 9;
-        unsigned str = 0;
-        int order = 0, mv = s - 1;
-        for (;;) {
-            for (; mv >= 0; --mv) {
-                str ^= up[mv] == mv ? 1u << up[mv] : 3u << (up[mv] - 1);
-                ++up[mv];
-            }
-            t.r[s][str & 255u] = (uint8_t)order++;
-            int b = 0;
-            for (; b < s && up[b] == up[b + 1] - 1; ++b) { str ^= 1u << (up[b] - 1); up[b] = b; }
-            if (b == s) break;
-            mv = b;
-        }
-    }
-    return t;
-}
 __constant__ MihRank c_mih_rank = make_mih_rank();
 
 void mih_rank_host(uint8_t out[5][256])

@@ -10,8 +10,11 @@
 // ONE LANE PER QUERY, the query code in eight registers, map codes staged through LDS 256 at a time (every lane reads the
 // same address: a broadcast), XOR + popcount.  11 k queries x 66 k map codes = 1.2 ms; exact integer arithmetic.
 #include "common.h"
+#include "mih_rank.h"
 
 namespace lf {
+
+__constant__ MihRank c_knn_rank = make_mih_rank();
 
 constexpr int KQ = 256;          // queries per workgroup (one per lane)
 constexpr int KT = 256;          // map codes per LDS tile
@@ -23,6 +26,88 @@ __device__ __forceinline__ int knn_hamming(const uint32_t (&q)[8], const uint32_
 #pragma unroll
     for (int w = 0; w < 8; ++w) d += __popc(q[w] ^ t[w]);
     return d;
+}
+
+// The reference's order among equally near codes (LF_TIE_MIHASHER): (distance, discovery key, index) -- the key of a candidate
+// is worked out only when its distance lets it into the list.  64-bit columns: distance << 40 | key (16 bits) << 24 | index.
+__global__ __launch_bounds__(KQ) void k_knn_mih(const uint8_t* __restrict__ query, int nq, const uint8_t* __restrict__ map, int nm, int k,
+                                                int max_distance, int32_t* __restrict__ idx, float* __restrict__ dist)
+{
+    __shared__ uint32_t tile[KT * 8];
+    __shared__ unsigned long long best[KMAXK][KQ];
+    const int t = threadIdx.x, qi = blockIdx.x * KQ + t;
+    uint32_t q[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (qi < nq) {
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 32);
+        const uint4 a = p[0], b = p[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+    for (int j = 0; j < k; ++j) best[j][t] = ~0ull;
+    unsigned long long worst = ~0ull;
+    for (int base = 0; base < nm; base += KT) {
+        __syncthreads();
+        const int cnt = nm - base < KT ? nm - base : KT;
+        for (int i = t; i < cnt * 2; i += KQ) reinterpret_cast<uint4*>(tile)[i] = reinterpret_cast<const uint4*>(map + (size_t)base * 32)[i];
+        __syncthreads();
+        if (qi >= nq) continue;
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t* tj = tile + 8 * j;
+            const int d = knn_hamming(q, tj);
+            if (d > max_distance || (unsigned long long)d > (worst >> 40)) continue;
+            uint32_t x[8];
+#pragma unroll
+            for (int w = 0; w < 8; ++w) x[w] = q[w] ^ tj[w];
+            const unsigned long long key = ((unsigned long long)d << 40) | ((unsigned long long)(mih_key_from_xor(x, c_knn_rank) & 0xffffu) << 24) | (unsigned long long)(base + j);
+            if (key >= worst) continue;
+            int pos = k - 1;
+            while (pos > 0 && best[pos - 1][t] > key) { best[pos][t] = best[pos - 1][t]; --pos; }
+            best[pos][t] = key;
+            worst = best[k - 1][t];
+        }
+    }
+    if (qi >= nq) return;
+    for (int j = 0; j < k; ++j) {
+        const unsigned long long key = best[j][t];
+        const bool ok = key != ~0ull;
+        idx[(size_t)qi * k + j] = ok ? (int32_t)(key & 0xffffffull) : -1;
+        dist[(size_t)qi * k + j] = ok ? (float)(key >> 40) : -1.f;
+    }
+}
+
+// radiusMatch in the reference's order: after k_radius_fill (distance ascending, index ascending inside a distance) every run of
+// equal distance is put into (discovery key, index) order -- one lane per query, insertion sort of the run (runs are short: the
+// codes at ONE exact distance of one query)
+__global__ __launch_bounds__(KQ) void k_radius_order_mih(const uint8_t* __restrict__ query, int nq, const uint8_t* __restrict__ map,
+                                                         const int32_t* __restrict__ offsets, int cap, int32_t* __restrict__ idx, const float* __restrict__ dist)
+{
+    const int qi = blockIdx.x * KQ + threadIdx.x;
+    if (qi >= nq) return;
+    uint32_t q[8];
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(query + (size_t)qi * 32);
+        const uint4 a = p[0], b = p[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w; q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+    const int a0 = offsets[qi], a1 = min(offsets[qi + 1], cap);
+    auto key_of = [&](int j) {
+        const uint4* p = reinterpret_cast<const uint4*>(map + (size_t)j * 32);
+        const uint4 a = p[0], b = p[1];
+        const uint32_t x[8] = { q[0] ^ a.x, q[1] ^ a.y, q[2] ^ a.z, q[3] ^ a.w, q[4] ^ b.x, q[5] ^ b.y, q[6] ^ b.z, q[7] ^ b.w };
+        return ((unsigned long long)(mih_key_from_xor(x, c_knn_rank) & 0xffffu) << 32) | (unsigned int)j;
+    };
+    int r0 = a0;
+    while (r0 < a1) {
+        int r1 = r0 + 1;
+        while (r1 < a1 && dist[r1] == dist[r0]) ++r1;
+        for (int i = r0 + 1; i < r1; ++i) {                    // insertion sort by (key, index)
+            const int ji = idx[i];
+            const unsigned long long ki = key_of(ji);
+            int p = i;
+            while (p > r0 && key_of(idx[p - 1]) > ki) { idx[p] = idx[p - 1]; --p; }
+            idx[p] = ji;
+        }
+        r0 = r1;
+    }
 }
 
 // the k nearest within max_distance, (distance, index) ascending; missing slots: idx -1, dist -1
@@ -199,13 +284,14 @@ void launch_select_queries(const uint8_t* q, const uint8_t* mask, int nq, uint8_
     hipLaunchKernelGGL(k_select_queries, dim3(1), dim3(1024), 0, s, q, mask, nq, out, qidx, n_out);
 }
 
-void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int32_t* idx, float* dist, hipStream_t s)
+void launch_knn(const uint8_t* q, int nq, const uint8_t* m, int nm, int k, int max_distance, int mih, int32_t* idx, float* dist, hipStream_t s)
 {
+    if (mih) { hipLaunchKernelGGL(k_knn_mih, dim3((nq + KQ - 1) / KQ), dim3(KQ), 0, s, q, nq, m, nm, k, max_distance, idx, dist); return; }
     hipLaunchKernelGGL(k_knn, dim3((nq + KQ - 1) / KQ), dim3(KQ), 0, s, q, nq, m, nm, k, max_distance, idx, dist);
 }
 
 void launch_radius(const uint8_t* q, int nq, const uint8_t* m, int nm, int max_distance, int32_t* hist, int32_t* count, int32_t* offsets,
-                   int* total, int cap, int32_t* idx, float* dist, hipStream_t s)
+                   int* total, int cap, int mih, int32_t* idx, float* dist, hipStream_t s)
 {
     const int blocks = (nq + KQ - 1) / KQ;
     (void)hipMemsetAsync(hist, 0, (size_t)nq * 129 * sizeof(int32_t), s);
@@ -213,6 +299,7 @@ void launch_radius(const uint8_t* q, int nq, const uint8_t* m, int nm, int max_d
     hipLaunchKernelGGL(k_radius_scan, dim3((nq + 255) / 256), dim3(256), 0, s, nq, max_distance, hist, count);
     hipLaunchKernelGGL(k_radius_offsets, dim3(1), dim3(1024), 0, s, nq, count, offsets, total);
     hipLaunchKernelGGL(k_radius_fill, dim3(blocks), dim3(KQ), 0, s, q, nq, m, nm, max_distance, hist, offsets, cap, idx, dist);
+    if (mih && cap > 0) hipLaunchKernelGGL(k_radius_order_mih, dim3(blocks), dim3(KQ), 0, s, q, nq, m, offsets, cap, idx, dist);
 }
 
 }  // namespace lf

@@ -1031,7 +1031,7 @@ extern "C" int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const 
         if (nm > 0) LF_HIP_CHECK(h, hipMemcpyAsync(h->a_m.p, map32, (size_t)nm * 32, hipMemcpyHostToDevice, s));
         dq = (const uint8_t*)h->a_q.p; dm_ = (const uint8_t*)h->a_m.p; didx = (int32_t*)h->a_idx.p; ddist = (float*)h->a_dist.p;
     }
-    { StageTimer t(h, ST_ASSOC); launch_knn(dq, nq, dm_, nm, k, 128, didx, ddist, s); }
+    { StageTimer t(h, ST_ASSOC); launch_knn(dq, nq, dm_, nm, k, 128, h->tie_rule == LF_TIE_MIHASHER, didx, ddist, s); }
     LF_HIP_CHECK(h, hipGetLastError());
     if (!on_device) {
         LF_HIP_CHECK(h, hipMemcpyAsync(idx, didx, out * 4, hipMemcpyDeviceToHost, s));
@@ -1069,7 +1069,7 @@ extern "C" int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, con
     }
     {
         StageTimer t(h, ST_ASSOC);
-        launch_radius(dq, nq, dm_, nm, md, (int32_t*)h->kn_hist.p, (int32_t*)h->kn_count.p, doff, (int*)h->kn_total.p, cap, didx, ddist, s);
+        launch_radius(dq, nq, dm_, nm, md, (int32_t*)h->kn_hist.p, (int32_t*)h->kn_count.p, doff, (int*)h->kn_total.p, cap, h->tie_rule == LF_TIE_MIHASHER, didx, ddist, s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     int total = 0;

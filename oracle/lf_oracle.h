@@ -123,6 +123,9 @@ void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
 /* the same with the reference's tie rule (first discovered by Mihasher::query) and the number of equally near codes */
 void lfo_match_mih(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int32_t* idx, float* dist, int32_t* n_ties);
 long long lfo_mih_discovery_key(const uint8_t* query32, const uint8_t* train32);
+/* knnMatch / radiusMatch with the reference's order among equally near codes: (distance, discovery key, index) */
+void lfo_knn_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, float* dist);
+int lfo_radius_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, float max_distance, int32_t* offsets, int32_t* idx, float* dist);
 void lfo_knn_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt, int k, int32_t* idx, float* dist);
 int lfo_radius_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt, float max_distance, int32_t* offsets, int32_t* idx,
                      float* dist);

@@ -343,6 +343,57 @@ void lfo_knn_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, in
     }
 }
 
+/* The same two with the REFERENCE's order among equally near codes: Mihasher::query records, per distance, the codes in the
+ * order it discovers them (res[hammd * K + numres[hammd]], :716-722) and hands out the first K by distance, so the lists are
+ * ordered by (distance, discovery key, train index) -- lfo_mih_discovery_key above; every code within D = 128 bits is discovered
+ * before the search stops. */
+typedef struct { int d; long long key; int j; } MihCand;
+static int mih_cand_cmp(const void* a, const void* b)
+{
+    const MihCand* x = (const MihCand*)a; const MihCand* y = (const MihCand*)b;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    return x->j < y->j ? -1 : (x->j > y->j ? 1 : 0);
+}
+static int mih_candidates(const uint8_t* a, const uint8_t* t, int nt, int md, MihCand* c)
+{
+    int n = 0;
+    for (int j = 0; j < nt; ++j) {
+        int h = 0;
+        for (int b = 0; b < 32; ++b) h += __builtin_popcount((unsigned)(a[b] ^ t[(size_t)32 * j + b]));
+        if (h > md) continue;
+        c[n].d = h; c[n].key = lfo_mih_discovery_key(a, t + (size_t)32 * j); c[n].j = j; ++n;
+    }
+    qsort(c, (size_t)n, sizeof(MihCand), mih_cand_cmp);
+    return n;
+}
+void lfo_knn_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, int k, int32_t* idx, float* dist)
+{
+    MihCand* c = (MihCand*)malloc(sizeof(MihCand) * (size_t)(nt > 0 ? nt : 1));
+    for (int i = 0; i < nq; ++i) {
+        const int n = mih_candidates(q + (size_t)32 * i, t, nt, 128, c);
+        for (int g = 0; g < k; ++g) {
+            idx[(size_t)i * k + g] = g < n ? c[g].j : -1;
+            dist[(size_t)i * k + g] = g < n ? (float)c[g].d : -1.f;
+        }
+    }
+    free(c);
+}
+int lfo_radius_match_mih(const uint8_t* q, int nq, const uint8_t* t, int nt, float max_distance, int32_t* offsets, int32_t* idx, float* dist)
+{
+    const int md = max_distance >= 128.f ? 128 : (int)max_distance;
+    MihCand* c = (MihCand*)malloc(sizeof(MihCand) * (size_t)(nt > 0 ? nt : 1));
+    int total = 0;
+    for (int i = 0; i < nq; ++i) {
+        offsets[i] = total;
+        const int n = mih_candidates(q + (size_t)32 * i, t, nt, md, c);
+        for (int g = 0; g < n; ++g) { if (idx) idx[total] = c[g].j; if (dist) dist[total] = (float)c[g].d; ++total; }
+    }
+    offsets[nq] = total;
+    free(c);
+    return total;
+}
+
 int lfo_radius_match(const uint8_t* q, int nq, const uint8_t* t, int nt, float max_distance, int32_t* offsets, int32_t* idx, float* dist)
 {
     const int md = max_distance >= 128.f ? 128 : (int)max_distance;

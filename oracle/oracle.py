@@ -269,22 +269,23 @@ class Oracle(object):
         self.lib.lfo_match_mih(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist), _p(ties))
         return idx, dist, ties
 
-    def knn_match(self, q, t, k):
+    def knn_match(self, q, t, k, tie_rule="lowest"):
         q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
         t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
         idx = np.empty((q.shape[0], k), np.int32)
         dist = np.empty((q.shape[0], k), np.float32)
-        self.lib.lfo_knn_match(_p(q), q.shape[0], _p(t), t.shape[0], int(k), _p(idx), _p(dist))
+        getattr(self.lib, "lfo_knn_match_mih" if tie_rule == "mihasher" else "lfo_knn_match")(_p(q), q.shape[0], _p(t), t.shape[0], int(k), _p(idx), _p(dist))
         return idx, dist
 
-    def radius_match(self, q, t, max_distance):
+    def radius_match(self, q, t, max_distance, tie_rule="lowest"):
         q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
         t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
-        self.lib.lfo_radius_match.restype = ctypes.c_int
+        fn = getattr(self.lib, "lfo_radius_match_mih" if tie_rule == "mihasher" else "lfo_radius_match")
+        fn.restype = ctypes.c_int
         offsets = np.zeros(q.shape[0] + 1, np.int32)
-        total = self.lib.lfo_radius_match(_p(q), q.shape[0], _p(t), t.shape[0], ctypes.c_float(max_distance), _p(offsets), None, None)
+        total = fn(_p(q), q.shape[0], _p(t), t.shape[0], ctypes.c_float(max_distance), _p(offsets), None, None)
         idx, dist = np.empty(max(total, 1), np.int32), np.empty(max(total, 1), np.float32)
-        self.lib.lfo_radius_match(_p(q), q.shape[0], _p(t), t.shape[0], ctypes.c_float(max_distance), _p(offsets), _p(idx), _p(dist))
+        fn(_p(q), q.shape[0], _p(t), t.shape[0], ctypes.c_float(max_distance), _p(offsets), _p(idx), _p(dist))
         return offsets, idx[:total], dist[:total]
 
     def set_lsd_seed_order(self, mode):

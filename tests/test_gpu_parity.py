@@ -725,6 +725,18 @@ def test_knn_and_radius_match_follow_the_matcher_semantics():
             src[b >> 3] ^= np.uint8(1 << (b & 7))
         m[int(rng.integers(0, nm))] = src
     m[5] = m[900] = m[1700] = q[7]                         # exact duplicates: index order
+    # the reference's order among equally near codes (the default), then the index order
+    for k in (1, 3, 16):
+        gi, gd = fe.knn_match(q, m, k)
+        oi, od = o.knn_match(q, m, k, tie_rule="mihasher")
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od), k
+    wi, wd, _ = o.match_mih(q, m)
+    assert np.array_equal(gi[:, 0], wi) and np.array_equal(gd[:, 0], wd)       # k-NN's first column = match()
+    for r in (0.0, 17.5, 64.0, 128.0):
+        go, gi2, gd2 = fe.radius_match(q, m, r)
+        oo, oi2, od2 = o.radius_match(q, m, r, tie_rule="mihasher")
+        assert np.array_equal(go, oo) and np.array_equal(gi2, oi2) and np.array_equal(gd2, od2), r
+    fe.set_tie_rule("lowest")
     for k in (1, 3, 16):
         gi, gd = fe.knn_match(q, m, k)
         oi, od = o.knn_match(q, m, k)
