@@ -177,7 +177,7 @@ def test_query_mask_of_the_matcher():
     wi, wd, _ = o.match_mih(q, m)
     assert np.array_equal(gi, wi[keep]) and np.array_equal(gd, wd[keep])
     ki, kd = fe.knn_match(sel, m, 3)
-    oi, od = o.knn_match(q, m, 3)
+    oi, od = o.knn_match(q, m, 3, tie_rule="mihasher")
     assert np.array_equal(ki, oi[keep]) and np.array_equal(kd, od[keep])
     for mk in (np.zeros(2500, np.uint8), np.ones(2500, np.uint8)):
         s2, q2 = fe.select_queries(q, mk)
