@@ -424,22 +424,6 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 if (e >= 0) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
             }
         }
-        {
-            // the batch after this one, as far as its points are in the list already
-            nx_i = i + m;
-            nx_m = n - nx_i < 7 ? n - nx_i : 7;
-            nx_e = -1;
-            if (slot < nx_m) {
-                const uint32_t pk2 = reg_get(c, nx_i + slot);
-                const int x2 = (int)(pk2 & 0xffffu) + ddx, y2 = (int)(pk2 >> 16) + ddy;
-                const int rx2 = x2 - wx0, ry2 = y2 - wy0;
-                const bool inwin2 = rx2 >= 0 && rx2 < 9 && ry2 >= 0 && ry2 < 7;
-                if (!inwin2 && x2 >= 0 && x2 < W && y2 >= 0 && y2 < H) {
-                    nx_e = find_e(c, x2, y2);
-                    if (nx_e >= 0) { nx_dg = c.deg[nx_e]; nx_ck = c.cs[nx_e]; nx_sk = c.sn[nx_e]; }
-                }
-            }
-        }
         bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
         const double a = (double)dg * DEG2RAD;
         LFG_T1(c, 13)
@@ -466,6 +450,25 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         // offers; across spans the USED bits decide, re-read after every bulk accept.
         const float af = (float)a;
         const uint32_t key = ((uint32_t)yy << 16) | (uint32_t)xx;
+        {
+            // the batch after this one, as far as its points are in the list already -- issued only now, AFTER this batch's own
+            // values have been waited for and used (vmcnt counts in order: a wait for this batch's angle behind the new loads would
+            // wait for them too)
+            asm volatile("" :: "v"(dg), "v"(ck), "v"(sk), "v"(e));      // the compiler waits for this batch's values HERE, in front of the new loads
+            nx_i = i + m;
+            nx_m = n - nx_i < 7 ? n - nx_i : 7;
+            nx_e = -1;
+            if (slot < nx_m) {
+                const uint32_t pk2 = reg_get(c, nx_i + slot);
+                const int x2 = (int)(pk2 & 0xffffu) + ddx, y2 = (int)(pk2 >> 16) + ddy;
+                const int rx2 = x2 - wx0, ry2 = y2 - wy0;
+                const bool inwin2 = rx2 >= 0 && rx2 < 9 && ry2 >= 0 && ry2 < 7;
+                if (!inwin2 && x2 >= 0 && x2 < W && y2 >= 0 && y2 < H) {
+                    nx_e = find_e(c, x2, y2);
+                    if (nx_e >= 0) { nx_dg = c.deg[nx_e]; nx_ck = c.cs[nx_e]; nx_sk = c.sn[nx_e]; }
+                }
+            }
+        }
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
