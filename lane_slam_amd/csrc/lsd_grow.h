@@ -116,9 +116,6 @@ LFG_DEV int wave_max_i(int v)
     return max(a, b);
 }
 LFG_DEV void mem_fence() { __threadfence_block(); }
-// LDS only: orders this wave's LDS traffic (USED bits, region list head) without waiting for vector-memory loads in flight --
-// __threadfence_block waits for vmcnt(0) too, i.e. for the NEXT batch's prefetched candidates (region_grow)
-LFG_DEV void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_s_waitcnt(0xc07f); }
 #else
 LFG_DEV int wave_max_i(int v) { return v; }
 LFG_DEV int lane_id() { return 0; }
@@ -129,7 +126,6 @@ LFG_DEV int wave_sum_i(int v) { return v; }
 LFG_DEV double wave_max_d(double v) { return v; }
 LFG_DEV double wave_min_d(double v) { return v; }
 LFG_DEV void mem_fence() {}
-LFG_DEV void lds_fence() {}
 #endif
 
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
@@ -393,15 +389,6 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     const float EPSF = 0.0043633f;                        // 0.25 degree
     const bool bulk_ok = precf < 0.7f && precf > 4.f * EPSF;
     const float tn_cone = 0.5f * (precf - EPSF), tf_cone = precf + 0.5f * (precf - EPSF) + EPSF;
-    // Candidates of the NEXT batch are located and fetched while this batch is being decided (round 4): the list entries a batch
-    // starts from, their neighbours' entries and angles never change once written -- only the USED bits do, and those are read
-    // when the batch is processed -- so the trip to the compact arrays (a quarter of the longest chain's time) runs under the
-    // accept loop of the batch before.  nx_*: what was fetched for the batch starting at list index nx_i, for its first nx_m points.
-    int nx_i = -1, nx_m = 0, nx_e = -1;
-    float nx_dg = 0.f;
-    double nx_ck = 0.0, nx_sk = 0.0;
-    // the fences inside a batch must not wait for that fetch: LDS-only while nothing of the region lives in global memory
-    const bool lds_only = c.used_lds == 0x7fffffff;
     for (int i = 0; i < n;) {
         const int m = n - i < 7 ? n - i : 7;
         const bool lv = slot < m;
@@ -418,11 +405,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         LFG_T1(c, 12)
         LFG_CNT(c, 15, __ballot(inb && !inwin) != 0ull)
         if (!inwin) {
-            if (nx_i == i && slot < nx_m) { e = nx_e; dg = nx_dg; ck = nx_ck; sk = nx_sk; }      // fetched a batch ago
-            else {
-                e = inb ? find_e(c, xx, yy) : -1;
-                if (e >= 0) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
-            }
+            e = inb ? find_e(c, xx, yy) : -1;
+            if (e >= 0) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
         }
         bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
         const double a = (double)dg * DEG2RAD;
@@ -450,25 +434,6 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         // offers; across spans the USED bits decide, re-read after every bulk accept.
         const float af = (float)a;
         const uint32_t key = ((uint32_t)yy << 16) | (uint32_t)xx;
-        {
-            // the batch after this one, as far as its points are in the list already -- issued only now, AFTER this batch's own
-            // values have been waited for and used (vmcnt counts in order: a wait for this batch's angle behind the new loads would
-            // wait for them too)
-            asm volatile("" :: "v"(dg), "v"(ck), "v"(sk), "v"(e));      // the compiler waits for this batch's values HERE, in front of the new loads
-            nx_i = i + m;
-            nx_m = n - nx_i < 7 ? n - nx_i : 7;
-            nx_e = -1;
-            if (slot < nx_m) {
-                const uint32_t pk2 = reg_get(c, nx_i + slot);
-                const int x2 = (int)(pk2 & 0xffffu) + ddx, y2 = (int)(pk2 >> 16) + ddy;
-                const int rx2 = x2 - wx0, ry2 = y2 - wy0;
-                const bool inwin2 = rx2 >= 0 && rx2 < 9 && ry2 >= 0 && ry2 < 7;
-                if (!inwin2 && x2 >= 0 && x2 < W && y2 >= 0 && y2 < H) {
-                    nx_e = find_e(c, x2, y2);
-                    if (nx_e >= 0) { nx_dg = c.deg[nx_e]; nx_ck = c.cs[nx_e]; nx_sk = c.sn[nx_e]; }
-                }
-            }
-        }
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
@@ -528,7 +493,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             if (L >= 64) break;
             if (maskN != 0ull) {
                 // later offers of the pixels just accepted are no longer candidates
-                if (lds_only && n <= c.reg_lds) lds_fence(); else mem_fence();
+                mem_fence();
                 cand = cand && !used_get(c, e);
             }
             // the undecided lane: the reference's comparison under the angle of this moment
@@ -548,7 +513,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             }
             later = L >= 63 ? 0ull : (~0ull << (L + 1));
         }
-        if (added) { if (lds_only && n <= c.reg_lds) lds_fence(); else mem_fence(); }
+        if (added) mem_fence();
         LFG_T1(c, 14)
         LFG_CNT(c, 11, 1)
         i += m;
