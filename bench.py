@@ -223,6 +223,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, before any warm-up step: every handle runs one batch once (buffers grown on demand, kernel attributes, the handle's
+    # first look at the workload for its LDS-slice policy) -- with fewer warm-up steps than handles one of them would otherwise meet
+    # its first batch inside the timed region
+    for slot in range(D):
+        fes[slot].submit_device(frames_d[slot].data_ptr(), B, ptrs[slot], cap, describe=True)
+    for slot in range(D):
+        fes[slot].wait()
+    sync_all()
     run(args.warmup)
     sync_all()
     for f in fes:

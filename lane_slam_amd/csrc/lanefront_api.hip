@@ -1271,6 +1271,17 @@ extern "C" int lf_set_profiling(lf_handle* h, int enabled)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
     h->profiling = enabled != 0;
+    // the event pool is filled HERE, not inside the first profiled batches (an event pair per stage and batch: a 200-step run
+    // would otherwise create some thousand events while it is being timed)
+    if (h->profiling) {
+        (void)hipSetDevice(h->device);
+        while (h->ev_free.size() < 1024) {
+            EvPair n; n.st = 0;
+            if (hipEventCreate(&n.a) != hipSuccess) break;
+            if (hipEventCreate(&n.b) != hipSuccess) { (void)hipEventDestroy(n.a); break; }
+            h->ev_free.push_back(n);
+        }
+    }
     return LF_OK;
 }
 

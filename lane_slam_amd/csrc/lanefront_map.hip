@@ -152,6 +152,15 @@ extern "C" int lf_map_set_profiling(lf_map* m, int enabled)
 {
     if (!m) return LF_ERR_NOT_INITIALISED;
     m->profiling = enabled != 0;
+    if (m->profiling) {                       // fill the event pool now, not inside the first profiled steps
+        (void)hipSetDevice(m->device);
+        while (m->ev_free.size() < 512) {
+            lf_map::Ev n; n.st = 0;
+            if (hipEventCreate(&n.a) != hipSuccess) break;
+            if (hipEventCreate(&n.b) != hipSuccess) { (void)hipEventDestroy(n.a); break; }
+            m->ev_free.push_back(n);
+        }
+    }
     return LF_OK;
 }
 
