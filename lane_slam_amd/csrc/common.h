@@ -149,7 +149,7 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
                      uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
-                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, bool mixed, hipStream_t s);
+                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, bool mixed, int bitmap, hipStream_t s);   // bitmap: 0 = row-list form, 1 = bit-plane form, > 1 = bit-plane form with that many USED bits (tests)
 int lsd_grow_def_lds(const LsdParams& p, int lds_kb);   // defined pixels of a problem that fit k_lsd_grow's LDS slice of lds_kb KB
 constexpr int kGrowLdsKb[3] = { 13, 28, 40 };           // the slice sizes a handle moves between (k_lsd_grow.hip)
 int lsd_grow_pend_cap(const LsdParams& p);      // entries per problem of the pending-region list (k_lsd_eval)

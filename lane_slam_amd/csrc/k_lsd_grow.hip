@@ -57,7 +57,12 @@ __shared__ grow::EvalQueue g_evalq;
 // selected address (the long way to LDS, and a wait for every global load in flight).  BIG = true: the same code with the
 // bounds, for the problems that do not fit.  The kernel picks per workgroup (two launches, one per kind, run the two kinds one
 // after the other: 11 % fewer frames/s on the real camera frames, whose problems are of both kinds).
-template <bool BIG>
+//
+// BM = true (round 4, k_lsd_grow_bm: the handle's busy-content form): no row starts and x lists at all -- the defined pixels as a
+// bit plane of the scaled image plus a running count per 64-bit word (lsd_grow.h: a compact index is a rank), built here from the
+// compact list; Hs * Ws / 64 * 10 bytes whatever the number of defined pixels (20.5 KB at 512 x 256), so a problem is "big"
+// only when its USED bits do not fit (bm_used_cap entries), and those run the BIG code above in the same LDS.
+template <bool BIG, bool BM = false>
 __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
@@ -76,16 +81,48 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
+    // BM:        [bit plane (u64)] [word counts (u16)] [USED bits] [region lists]
+    const int bm_words = (int)(Ps >> 6) + 2;                 // + the word rank_before(H * W) reads, + one of padding
     int* rows = reinterpret_cast<int*>(lds);
-    uint32_t* usedc = lds + ((p.Hs + 2) & ~1);
+    uint32_t* usedc = BM ? lds + 2 * bm_words + ((bm_words + 1) >> 1) : lds + ((p.Hs + 2) & ~1);
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
     uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_LISTS * reg_lds);
+    unsigned long long* bits64 = reinterpret_cast<unsigned long long*>(lds);
+    uint16_t* pref = reinterpret_cast<uint16_t*>(lds + 2 * bm_words);
     const int n_def = norder[pc];
     const uint32_t* gxy = c_xy + (size_t)pc * Ps;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
-    for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
+    if (BM) {
+        __shared__ int wave_tot[GROW_WAVES];
+        for (int i = tid; i < 2 * bm_words; i += 64 * GROW_WAVES) lds[i] = 0u;
+        __syncthreads();
+        for (int i = tid; i < n_def; i += 64 * GROW_WAVES) {
+            const uint32_t xy = gxy[i];
+            const int pos = (int)(xy >> 16) * p.Ws + (int)(xy & 0xffffu);
+            atomicOr(lds + (pos >> 5), 1u << (pos & 31));
+        }
+        __syncthreads();
+        // running counts: every thread sums a run of consecutive words, the runs are scanned across the workgroup
+        const int per = (bm_words + 64 * GROW_WAVES - 1) / (64 * GROW_WAVES);
+        const int w0 = tid * per, w1 = w0 + per < bm_words ? w0 + per : bm_words;
+        int mine = 0;
+        for (int w = w0; w < w1; ++w) mine += __builtin_popcountll(bits64[w]);
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int base = incl - mine;
+        for (int k = 0; k < wave; ++k) base += wave_tot[k];
+        for (int w = w0; w < w1; ++w) { pref[w] = (uint16_t)base; base += __builtin_popcountll(bits64[w]); }
+    } else {
+        for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
+        for (int i = tid; i < n_def && i < def_lds; i += 64 * GROW_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
+    }
     for (int i = tid; i <= ((def_lds + 31) >> 5); i += 64 * GROW_WAVES) usedc[i] = 0u;
-    for (int i = tid; i < n_def && i < def_lds; i += 64 * GROW_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
     uint32_t* gu = gused + (size_t)pc * ((Ps + 31) / 32);
     if (n_def > def_lds)
         for (int i = tid; i < (n_def + 31) / 32; i += 64 * GROW_WAVES) gu[i] = 0u;
@@ -112,7 +149,8 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     c.pend_rec = pend_rec ? pend_rec + (size_t)pc * pend_cap * 12 : nullptr;
     c.pend_tag = pend_tag ? pend_tag + (size_t)pc * pend_cap : nullptr;
     c.pend_n = &pend_n; c.pend_cap = pend_cap;
-    c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = BIG ? def_lds : 0x7fffffff;
+    c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = BM ? -1 : BIG ? def_lds : 0x7fffffff;
+    c.bits64 = bits64; c.pref = pref;
     c.deg = c_deg + (size_t)pc * Ps;
     c.mod = c_mod + (size_t)pc * Ps;
     c.cs = c_cs + (size_t)pc * Ps;
@@ -219,10 +257,10 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
                                                  const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
                                                  int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
                                                  float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, const int* __restrict__ perm,
-                                                 double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
+                                                 double* pend_rec, int* pend_tag, int* pend_count, int pend_cap, int big_above)
 {
     const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;        // launch order: longest problems first (k_lsd_rank)
-    const bool big = norder[pc] > def_lds;
+    const bool big = norder[pc] > big_above;                         // = def_lds; behind k_lsd_grow_bm: what that kernel left
     if (MODE == 0 && big) return;
     if (MODE == 1 && !big) return;
     if (MODE != 0 && big)
@@ -231,6 +269,24 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     if (MODE != 1 && !big)
         lsd_grow_problem<false>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
                                 gused, tmp_lines, tmp_tags, lines, counts, reg_lds, def_lds, pc, pend_rec, pend_tag, pend_count, pend_cap);
+}
+
+// The bit-plane form: every problem whose USED bits fit (used_cap entries); the few that do not are left to k_lsd_grow<1>, launched
+// right behind with big_above = used_cap (one copy of the problem code per kernel: see MODE above).
+__global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow_bm(LsdParams p, const uint32_t* __restrict__ order,
+                                                 const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+                                                 const float* __restrict__ c_deg, const double* __restrict__ c_mod,
+                                                 const double* __restrict__ c_cs, const double* __restrict__ c_sn,
+                                                 const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
+                                                 const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
+                                                 int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int used_cap,
+                                                 const int* __restrict__ perm, double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
+{
+    const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+    if (norder[pc] > used_cap) return;
+    lsd_grow_problem<false, true>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
+                                  gused, tmp_lines, tmp_tags, lines, counts, reg_lds, used_cap, pc, pend_rec, pend_tag, pend_count, pend_cap);
 }
 
 // K_lsd_eval: rect_improve + final coordinates (grow::evaluate_pending) of every region on a problem's pending list, then
@@ -367,6 +423,27 @@ static void lsd_grow_slice(const LsdParams& p, int lds_kb, int& reg_lds, int& de
     lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
 }
 
+// The bit-plane form's LDS: 10 bytes per 64 pixels + USED bits for used_cap entries + the region-list heads.  Only for images whose
+// plane leaves room for problems to share a CU (<= 40 KB: 640x480 at both scales); false = use the row-list kernels.
+static bool lsd_grow_bitmap_slice(const LsdParams& p, int reg_lds, bool busy, int used_override, int& used_cap, size_t& lds)
+{
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t words = (Ps >> 6) + 2;
+    const size_t plane = words * 8 + ((words + 1) >> 1) * 4;
+    // USED bits for as many entries as keep SIX problems on a CU (160 KB / 6, less 2.25 KB: 1.7 KB of static words and ring + allocation granularity): that is
+    // the kernel's wave limit (LFG_WAVES per SIMD, four waves per problem); 11 k entries at 512 x 256.  On busy content (camera
+    // frames and clutter have problems of 20 - 40 k defined pixels, and one of those in the row-list code holds its batch up):
+    // FIVE problems per CU and 32 k entries (16 k: -20 % on those frames).  The counts are u16.
+    const size_t lists = (size_t)GROW_LISTS * reg_lds * 4;
+    const long long room = (long long)(160 * 1024 / (busy ? 5 : 6) - 2304) - (long long)plane - (long long)lists - 12;
+    used_cap = room > 512 ? (int)((room * 8) & ~31ll) : 4096;
+    if (used_cap > 32768) used_cap = 32768;                   // measured: 55 k entries (the most five problems per CU allow) is 3 - 5 % slower on camera frames
+    if (used_override > 0) used_cap = used_override & ~31;   // tests: a small capacity sends problems down the overflow path
+    if ((size_t)used_cap > Ps) used_cap = (int)((Ps + 31) & ~(size_t)31);
+    lds = plane + (size_t)((used_cap >> 5) + 1) * 4 + lists + 8;
+    return plane <= (size_t)28 * 1024 && Ps < ((size_t)1 << 21);
+}
+
 int lsd_grow_def_lds(const LsdParams& p, int lds_kb)
 {
     int reg_lds, def_lds;
@@ -384,15 +461,26 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,
                      const int* row_start, const uint16_t* c_label, const uint16_t* comp_list, const int* comp_count, int comp_cap,
                      uint32_t* reg, uint32_t* gused, float* tmp_lines, int* tmp_tags, float* lines, int* counts, const int* perm,
-                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, bool mixed, hipStream_t s)
+                     double* pend_rec, int* pend_tag, int* pend_count, int lds_kb, bool mixed, int bitmap, hipStream_t s)
 {
     int reg_lds, def_lds;
     size_t lds;
     lsd_grow_slice(p, lds_kb > 0 ? lds_kb : LFG_LDS_KB, reg_lds, def_lds, lds);
+    int big_above = def_lds;
 #define LF_GROW_LAUNCH(MODE)                                                                                                                   \
     hipLaunchKernelGGL(k_lsd_grow<MODE>, dim3(n_frames * 3), dim3(64 * GROW_WAVES), lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,        \
                        c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,               \
-                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p))
+                       tmp_tags, lines, counts, reg_lds, def_lds, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p), big_above)
+    size_t bm_lds = 0;
+    int bm_used = 0;
+    if (bitmap && !LFG_EVAL_KERNEL && lsd_grow_bitmap_slice(p, reg_lds, lds_kb > LFG_LDS_KB, bitmap > 1 ? bitmap : 0, bm_used, bm_lds)) {
+        hipLaunchKernelGGL(k_lsd_grow_bm, dim3(n_frames * 3), dim3(64 * GROW_WAVES), bm_lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
+                           c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
+                           tmp_tags, lines, counts, reg_lds, bm_used, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
+        big_above = bm_used;
+        LF_GROW_LAUNCH(1);
+        return;
+    }
     if (mixed) { LF_GROW_LAUNCH(2); }
     else { LF_GROW_LAUNCH(0); LF_GROW_LAUNCH(1); }
 #undef LF_GROW_LAUNCH

@@ -129,6 +129,7 @@ struct lf_handle {
     int tie_rule = LF_TIE_MIHASHER;   // lf_associate: the reference's rule unless lf_set_tie_rule says otherwise
     int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
     int env_mixed = -1;
+    int env_bitmap = 1;          // LF_GROW_BITMAP=0: the row-list form of k_lsd_grow (rounds 1 - 3) instead of the bit-plane form (A/B measurements); > 1: see launch_lsd_grow
     int env_kl_lds_lines = 0;    // LF_KL_LDS_LINES (test hook of the KeyLine grouping, lanefront_keylines.inc)
     int pending_problems = 0;
     int pending_capacity = 0;
@@ -544,6 +545,7 @@ extern "C" int lf_create(const lf_config* cfg, int device_id, int max_frames, in
     memset(h->ms, 0, sizeof(h->ms)); memset(h->launches, 0, sizeof(h->launches));
     if (const char* ev = getenv("LF_GROW_LDS_LEVEL")) { const int v = atoi(ev); h->env_lds_level = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* ev = getenv("LF_GROW_MIXED")) h->env_mixed = atoi(ev) != 0 ? 1 : 0;
+    if (const char* ev = getenv("LF_GROW_BITMAP")) { const int v = atoi(ev); h->env_bitmap = v < 0 ? 0 : v; }       // > 1: that many USED bits (tests)
     if (const char* ev = getenv("LF_KL_LDS_LINES")) { const int v = atoi(ev); h->env_kl_lds_lines = v < 1 ? 1 : (v > 4096 ? 4096 : v); }
     int rc = LF_OK;
     do {
@@ -620,7 +622,8 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
                         h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
                         h->d_slot_lines, h->d_counts, no_rank ? nullptr : h->d_perm, h->d_pend_rec, h->d_pend_tag, h->d_pend_count,
                         kGrowLdsKb[env_lds_level >= 0 ? env_lds_level : h->grow_lds_level],
-                        env_mixed >= 0 ? env_mixed != 0 : h->grow_mixed, s);
+                        env_mixed >= 0 ? env_mixed != 0 : h->grow_mixed,
+                        h->env_bitmap, s);
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
@@ -1187,7 +1190,8 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
-                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], true, s);
+                    h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], true,
+                    h->env_bitmap, s);
     LF_HIP_CHECK(h, hipGetLastError());
     int n = 0;
     LF_HIP_CHECK(h, hipMemcpyAsync(&n, h->d_counts, sizeof(int), hipMemcpyDeviceToHost, s));

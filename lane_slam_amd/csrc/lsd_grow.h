@@ -181,7 +181,9 @@ struct Ctx {
     const int* rows;          // LDS  [H+1]  first entry of each row; rows[H] = number of defined pixels
     const uint16_t* lxs;      // LDS  x coordinate of entries e < def_lds (sorted inside a row)
     const uint32_t* gxy;      // HBM  y<<16|x of every entry
-    int def_lds;
+    int def_lds;              // -1: BITMAP form -- no row lists; the defined pixels as a bit plane + a count per 64-bit word:
+    const unsigned long long* bits64;   // LDS  [H * W / 64 + 1] bit (y * W + x) set <=> the pixel's gradient is defined
+    const uint16_t* pref;               // LDS  [H * W / 64 + 1] defined pixels in front of the word = the compact index of its first one
     const float* deg;         // HBM  level-line angle, degrees (OpenCV fastAtan2 output)
     const double* mod;        // HBM  gradient magnitude
     const double* cs;         // HBM  cos((double)(float)angle_rad)
@@ -220,9 +222,24 @@ LFG_DEV void reg_set(const Ctx& c, int i, uint32_t v)
 }
 LFG_DEV int xs_get(const Ctx& c, int e) { return e < c.def_lds ? (int)c.lxs[e] : (int)(c.gxy[e] & 0xffffu); }
 
+// BITMAP form (round 4; k_lsd_grow.hip chooses it on busy content): a compact index is a RANK -- the number of defined pixels in
+// front of a raster position -- so every lookup is two LDS reads and a popcount instead of a binary search in a row list, whatever
+// the problem's size (problems beyond the LDS slice used to search their rows in global memory).
+LFG_DEV bool bm_mode(const Ctx& c) { return c.def_lds == -1; }
+LFG_DEV int rank_before(const Ctx& c, int pos)
+{
+    const int w = pos >> 6;
+    return (int)c.pref[w] + __builtin_popcountll(c.bits64[w] & ((1ull << (pos & 63)) - 1ull));
+}
+
 // entry of pixel (x, y), or -1 when its gradient is undefined: binary search in row y's sorted list
 LFG_DEV int find_e(const Ctx& c, int x, int y)
 {
+    if (bm_mode(c)) {
+        const int pos = y * c.W + x, b = pos & 63;
+        const unsigned long long w = c.bits64[pos >> 6];
+        return ((w >> b) & 1ull) ? (int)c.pref[pos >> 6] + __builtin_popcountll(w & ((1ull << b) - 1ull)) : -1;
+    }
     int lo = c.rows[y];
     const int end = c.rows[y + 1];
     int hi = end;
@@ -910,6 +927,7 @@ LFG_DEV void row_span(const RowGeom& g, int y, int W, int& xa, int& xb)
 // first entry of row y whose x is >= xa (binary search in the row's sorted x list)
 LFG_DEV int row_lower_bound(const Ctx& c, int y, int xa)
 {
+    if (bm_mode(c)) return rank_before(c, y * c.W + xa);
     int lo = c.rows[y], hi = c.rows[y + 1];
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs_get(c, mid) < xa) lo = mid + 1; else hi = mid; }
     return lo;
@@ -941,6 +959,19 @@ LFG_DEV double rect_nfa(const Ctx& c, const Rect& rec)
         if (xb < xa) continue;
         total_pts += xb - xa + 1;
         const int lo = row_lower_bound(c, y, xa);
+        if (bm_mode(c)) {
+            // the row's defined pixels in [xa, xb] are the entries lo .. hi - 1: no coordinates needed
+            const int hi = rank_before(c, y * c.W + xb + 1);
+            for (int k0 = lo; k0 < hi; k0 += 4) {
+                float dv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dv[u] = c.deg[k0 + u < hi ? k0 + u : hi - 1];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k0 + u < hi && angle_dist(dv[u], rec.theta) <= rec.prec) ++alg_pts;
+            }
+            continue;
+        }
         const int e1 = c.rows[y + 1];
         for (int k0 = lo; k0 < e1; k0 += 4) {
             int xv[4];
@@ -1056,6 +1087,40 @@ LFG_DEV void rect_nfa5(const Ctx& c, const Rect& base, int stage, bool* valid, d
         }
         if (ub < ua) continue;
         const int lo = row_lower_bound(c, y, ua);
+        if (bm_mode(c)) {
+            // walk the set bits of the row between ua and ub: the bit's place is the pixel's x, the running rank its entry
+            const int p0 = y * c.W + ua, p1 = y * c.W + ub;
+            int idx = lo;
+            for (int w = p0 >> 6; w <= (p1 >> 6); ++w) {
+                unsigned long long bw = c.bits64[w];
+                if (w == (p0 >> 6)) bw &= ~0ull << (p0 & 63);
+                if (w == (p1 >> 6) && (p1 & 63) != 63) bw &= (2ull << (p1 & 63)) - 1ull;
+                while (bw) {
+                    int xv[4], cnt = 0;
+                    float dv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        xv[u] = 0; dv[u] = 0.f;
+                        if (bw) {
+                            xv[u] = ((w << 6) | __builtin_ctzll(bw)) - y * c.W;
+                            bw &= bw - 1ull;
+                            dv[u] = c.deg[idx + u];
+                            cnt = u + 1;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (u >= cnt) break;
+                        const double nt = angle_dist(dv[u], theta);
+#pragma unroll
+                        for (int k = 0; k < 5; ++k)
+                            if (xv[u] >= xa[k] && xv[u] <= xb[k] && nt <= prec[k]) ++alg[k];
+                    }
+                    idx += cnt;
+                }
+            }
+            continue;
+        }
         const int e1 = c.rows[y + 1];
         for (int k0 = lo; k0 < e1; k0 += 4) {
             int xv[4];

@@ -766,11 +766,14 @@ def test_knn_and_radius_match_follow_the_matcher_semantics():
     fe.close()
 
 
+@pytest.mark.parametrize("form", ["bit plane", "row lists", "bit plane, 2048 USED bits", "bit plane, 8192 USED bits"])
 @pytest.mark.parametrize("level", ["0", "1", "2"])
-def test_region_growing_slice_size_does_not_change_results(level):
-    """k_lsd_grow's LDS slice (13 / 20 / 28 KB, normally chosen from the share of problems that overflowed it in the previous
-    batch) decides which problems take the all-in-LDS code and which the bounded one: a matter of speed only.  Every level,
-    forced, on frames whose problems straddle the slice sizes (lane frames, clutter, noise), against the oracle."""
+def test_region_growing_slice_size_does_not_change_results(level, form):
+    """k_lsd_grow's LDS slice (13 / 28 / 40 KB, normally chosen from the share of problems that overflowed it in the previous
+    batch) and its form -- the defined pixels as a bit plane with running counts (k_lsd_grow_bm, the default since round 4; problems
+    beyond its USED bits go to the bounded row-list code behind it) or as row lists (k_lsd_grow<MODE>) -- decide which code a
+    problem takes: a matter of speed only.  Every combination, forced, on frames whose problems straddle the sizes (lane frames,
+    clutter, noise), against the oracle."""
     from oracle.oracle import Oracle
     cfg = default_config("fullres")
     o = Oracle(cfg)
@@ -782,17 +785,19 @@ def test_region_growing_slice_size_does_not_change_results(level):
         busy[y:y + int(rng.integers(1, 4)), x:x + int(rng.integers(6, 60))] = ((235, 235, 235), (40, 220, 235), (40, 40, 220))[int(rng.integers(0, 3))]
     frames = np.concatenate([frames, busy[None]])
     os.environ["LF_GROW_LDS_LEVEL"] = level
+    os.environ["LF_GROW_BITMAP"] = "1" if form == "bit plane" else "0" if form == "row lists" else form.split()[-3]
     try:
         fe = FrontEnd(cfg, max_frames=4, max_lines_per_color=4096)
         seg = fe.process_batch(frames)
         seg2 = fe.process_batch(frames)                       # and again: nothing left over from the first batch
     finally:
         del os.environ["LF_GROW_LDS_LEVEL"]
+        del os.environ["LF_GROW_BITMAP"]
     for f in range(4):
         r = o.process_frame(frames[f], cap=3 * 4096)
         for sg in (seg, seg2):
             s = sg.frame(f)
-            assert s.n == r["n"], (level, f, s.n, r["n"])
+            assert s.n == r["n"], (level, form, f, s.n, r["n"])
             assert np.array_equal(s.lines, r["lines"]) and np.array_equal(s.color, r["color"]) and np.array_equal(s.keep, r["keep"])
     fe.close()
 

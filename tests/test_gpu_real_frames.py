@@ -61,6 +61,20 @@ def test_front_end_on_the_camera_streams(real, geometry):
         total += r["n"]
     print("\n%s: %d segments in %d camera frames (%.1f per frame)" % (geometry, total, B, total / B))
     assert total > (60 if geometry == "fullres" else 15) * B // 2
+    # k_lsd_grow's other forms (tests/test_gpu_parity.py::test_region_growing_slice_size_does_not_change_results): the row lists of
+    # rounds 1 - 3, and the bit plane with so few USED bits that the largest problems of these frames overflow it
+    import os
+    for form in ("0", "8192"):
+        os.environ["LF_GROW_BITMAP"] = form
+        try:
+            fe2 = FrontEnd(cfg, max_frames=B, max_lines_per_color=4096)
+        finally:
+            del os.environ["LF_GROW_BITMAP"]
+        for _ in range(2):                                                 # the second batch runs on the slice the first one chose
+            sg = fe2.process_batch(frames, describe=True)
+            assert sg.n == seg.n and np.array_equal(sg.lines, seg.lines) and np.array_equal(sg.code, seg.code)
+            assert np.array_equal(sg.frame_offset, seg.frame_offset)
+        fe2.close()
     fe.close()
 
 
