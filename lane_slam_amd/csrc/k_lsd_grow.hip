@@ -60,7 +60,7 @@ __shared__ grow::EvalQueue g_evalq;
 //
 // BM = true (round 4, k_lsd_grow_bm: the handle's busy-content form): no row starts and x lists at all -- the defined pixels as a
 // bit plane of the scaled image plus a running count per 64-bit word (lsd_grow.h: a compact index is a rank), built here from the
-// compact list; Hs * Ws / 64 * 10 bytes whatever the number of defined pixels (20.5 KB at 512 x 256), so a problem is "big"
+// compact list; Hs * Ws / 64 * 9 bytes whatever the number of defined pixels (18.5 KB at 512 x 256), so a problem is "big"
 // only when its USED bits do not fit (bm_used_cap entries), and those run the BIG code above in the same LDS.
 template <bool BIG, bool BM = false>
 __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint32_t* __restrict__ order,
@@ -73,7 +73,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
                                                  float* tmp_lines, int* tmp_tags, float* lines, int* counts, int reg_lds, int def_lds, int pc,
                                                  double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
 {
-    extern __shared__ uint32_t lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     int& next_comp = g_next_comp; int& line_count = g_line_count; int& waves_done = g_waves_done; int& pend_n = g_pend_n;
 #if LFG_EVAL_QUEUE
     grow::EvalQueue& evalq = g_evalq;
@@ -82,9 +82,9 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
     // BM:        [bit plane (u64)] [word counts (u16)] [USED bits] [region lists]
-    const int bm_words = (int)(Ps >> 6) + 2;                 // + the word rank_before(H * W) reads, + one of padding
+    const int bm_words = ((int)(Ps >> 6) + 2) & ~1;          // + the word rank_before(H * W) reads; whole pairs
     int* rows = reinterpret_cast<int*>(lds);
-    uint32_t* usedc = BM ? lds + 2 * bm_words + ((bm_words + 1) >> 1) : lds + ((p.Hs + 2) & ~1);
+    uint32_t* usedc = BM ? lds + 2 * bm_words + (((bm_words >> 1) + 1) >> 1) : lds + ((p.Hs + 2) & ~1);
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
     uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_LISTS * reg_lds);
     unsigned long long* bits64 = reinterpret_cast<unsigned long long*>(lds);
@@ -102,11 +102,12 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
             atomicOr(lds + (pos >> 5), 1u << (pos & 31));
         }
         __syncthreads();
-        // running counts: every thread sums a run of consecutive words, the runs are scanned across the workgroup
-        const int per = (bm_words + 64 * GROW_WAVES - 1) / (64 * GROW_WAVES);
-        const int w0 = tid * per, w1 = w0 + per < bm_words ? w0 + per : bm_words;
+        // running counts, one per pair of words: every thread sums a run of consecutive pairs, the runs are scanned across the workgroup
+        const int bm_pairs = bm_words >> 1;
+        const int per = (bm_pairs + 64 * GROW_WAVES - 1) / (64 * GROW_WAVES);
+        const int w0 = tid * per < bm_pairs ? tid * per : bm_pairs, w1 = w0 + per < bm_pairs ? w0 + per : bm_pairs;
         int mine = 0;
-        for (int w = w0; w < w1; ++w) mine += __builtin_popcountll(bits64[w]);
+        for (int w = w0; w < w1; ++w) mine += __builtin_popcountll(bits64[2 * w]) + __builtin_popcountll(bits64[2 * w + 1]);
         int incl = mine;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -117,7 +118,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
         __syncthreads();
         int base = incl - mine;
         for (int k = 0; k < wave; ++k) base += wave_tot[k];
-        for (int w = w0; w < w1; ++w) { pref[w] = (uint16_t)base; base += __builtin_popcountll(bits64[w]); }
+        for (int w = w0; w < w1; ++w) { pref[w] = (uint16_t)base; base += __builtin_popcountll(bits64[2 * w]) + __builtin_popcountll(bits64[2 * w + 1]); }
     } else {
         for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
         for (int i = tid; i < n_def && i < def_lds; i += 64 * GROW_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
@@ -423,21 +424,22 @@ static void lsd_grow_slice(const LsdParams& p, int lds_kb, int& reg_lds, int& de
     lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
 }
 
-// The bit-plane form's LDS: 10 bytes per 64 pixels + USED bits for used_cap entries + the region-list heads.  Only for images whose
+// The bit-plane form's LDS: 9 bytes per 64 pixels (a 64-bit word of the plane, a 16-bit count per pair of words) + USED bits for used_cap entries + the region-list heads.  Only for images whose
 // plane leaves room for problems to share a CU (<= 40 KB: 640x480 at both scales); false = use the row-list kernels.
 static bool lsd_grow_bitmap_slice(const LsdParams& p, int reg_lds, bool busy, int used_override, int& used_cap, size_t& lds)
 {
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    const size_t words = (Ps >> 6) + 2;
-    const size_t plane = words * 8 + ((words + 1) >> 1) * 4;
-    // USED bits for as many entries as keep SIX problems on a CU (160 KB / 6, less 2.25 KB: 1.7 KB of static words and ring + allocation granularity): that is
-    // the kernel's wave limit (LFG_WAVES per SIMD, four waves per problem); 11 k entries at 512 x 256.  On busy content (camera
-    // frames and clutter have problems of 20 - 40 k defined pixels, and one of those in the row-list code holds its batch up):
-    // FIVE problems per CU and 32 k entries (16 k: -20 % on those frames).  The counts are u16.
+    const size_t words = ((Ps >> 6) + 2) & ~(size_t)1;
+    const size_t plane = words * 8 + (((words >> 1) + 1) >> 1) * 4;
+    // USED bits for as many entries as keep SIX problems on a CU (160 KB / 6, less 2.25 KB: 1.7 KB of static words and ring +
+    // allocation granularity): that is the kernel's wave limit (LFG_WAVES per SIMD, four waves per problem).  27.7 k entries at
+    // 512 x 256: camera frames and the clutter frames have problems of 20 - 25 k defined pixels, and one of those in the row-list
+    // code holds its batch up (16 k entries: -20 % frames/s there).  The counts are u16.
+    (void)busy;
     const size_t lists = (size_t)GROW_LISTS * reg_lds * 4;
-    const long long room = (long long)(160 * 1024 / (busy ? 5 : 6) - 2304) - (long long)plane - (long long)lists - 12;
+    const long long room = (long long)(160 * 1024 / 6 - 2304) - (long long)plane - (long long)lists - 12;
     used_cap = room > 512 ? (int)((room * 8) & ~31ll) : 4096;
-    if (used_cap > 32768) used_cap = 32768;                   // measured: 55 k entries (the most five problems per CU allow) is 3 - 5 % slower on camera frames
+    if (used_cap > 32768) used_cap = 32768;
     if (used_override > 0) used_cap = used_override & ~31;   // tests: a small capacity sends problems down the overflow path
     if ((size_t)used_cap > Ps) used_cap = (int)((Ps + 31) & ~(size_t)31);
     lds = plane + (size_t)((used_cap >> 5) + 1) * 4 + lists + 8;

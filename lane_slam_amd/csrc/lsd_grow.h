@@ -183,7 +183,7 @@ struct Ctx {
     const uint32_t* gxy;      // HBM  y<<16|x of every entry
     int def_lds;              // -1: BITMAP form -- no row lists; the defined pixels as a bit plane + a count per 64-bit word:
     const unsigned long long* bits64;   // LDS  [H * W / 64 + 1] bit (y * W + x) set <=> the pixel's gradient is defined
-    const uint16_t* pref;               // LDS  [H * W / 64 + 1] defined pixels in front of the word = the compact index of its first one
+    const uint16_t* pref;               // LDS  [H * W / 128 + 1] defined pixels in front of a PAIR of words = the compact index of its first one
     const float* deg;         // HBM  level-line angle, degrees (OpenCV fastAtan2 output)
     const double* mod;        // HBM  gradient magnitude
     const double* cs;         // HBM  cos((double)(float)angle_rad)
@@ -225,11 +225,15 @@ LFG_DEV int xs_get(const Ctx& c, int e) { return e < c.def_lds ? (int)c.lxs[e] :
 // BITMAP form (round 4; k_lsd_grow.hip chooses it on busy content): a compact index is a RANK -- the number of defined pixels in
 // front of a raster position -- so every lookup is two LDS reads and a popcount instead of a binary search in a row list, whatever
 // the problem's size (problems beyond the LDS slice used to search their rows in global memory).
+struct alignas(16) BmPair { unsigned long long x, y; };      // two words of the plane, read together
 LFG_DEV bool bm_mode(const Ctx& c) { return c.def_lds == -1; }
 LFG_DEV int rank_before(const Ctx& c, int pos)
 {
+    // one 16-byte read for the pair of words, one 2-byte read for its count
     const int w = pos >> 6;
-    return (int)c.pref[w] + __builtin_popcountll(c.bits64[w] & ((1ull << (pos & 63)) - 1ull));
+    const BmPair v = reinterpret_cast<const BmPair*>(c.bits64)[w >> 1];
+    const unsigned long long cur = (w & 1) ? v.y : v.x;
+    return (int)c.pref[w >> 1] + ((w & 1) ? __builtin_popcountll(v.x) : 0) + __builtin_popcountll(cur & ((1ull << (pos & 63)) - 1ull));
 }
 
 // entry of pixel (x, y), or -1 when its gradient is undefined: binary search in row y's sorted list
@@ -237,8 +241,10 @@ LFG_DEV int find_e(const Ctx& c, int x, int y)
 {
     if (bm_mode(c)) {
         const int pos = y * c.W + x, b = pos & 63;
-        const unsigned long long w = c.bits64[pos >> 6];
-        return ((w >> b) & 1ull) ? (int)c.pref[pos >> 6] + __builtin_popcountll(w & ((1ull << b) - 1ull)) : -1;
+        const int wi = pos >> 6;
+        const BmPair v = reinterpret_cast<const BmPair*>(c.bits64)[wi >> 1];
+        const unsigned long long w = (wi & 1) ? v.y : v.x;
+        return ((w >> b) & 1ull) ? (int)c.pref[wi >> 1] + ((wi & 1) ? __builtin_popcountll(v.x) : 0) + __builtin_popcountll(w & ((1ull << b) - 1ull)) : -1;
     }
     int lo = c.rows[y];
     const int end = c.rows[y + 1];
@@ -479,14 +485,19 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             const unsigned long long maskN = __ballot(cand && is_near) & span;
             if (maskN != 0ull) {
                 // first offer wins inside the span: walk the near lanes in order, each new pixel strikes its later offers
-                unsigned long long maskA = maskN;
-                if (maskN & (maskN - 1ull)) {
+                // (every offer of an accepted pixel, inside the span or behind it, is struck from the candidates on the way:
+                // no trip to the USED bits between the spans of a batch)
+                unsigned long long maskA = maskN, struck = 0ull;
+                if ((maskN & (maskN - 1ull)) != 0ull || L < 64) {        // one pixel and nothing behind the span: nothing to strike
                     for (unsigned long long mm = maskN; mm != 0ull;) {
                         const int j = __builtin_ctzll(mm);
-                        const unsigned long long same = __ballot(key == (uint32_t)rl_i((int)key, j)) & mm & ~(1ull << j);
+                        const unsigned long long eq = __ballot(key == (uint32_t)rl_i((int)key, j));
+                        const unsigned long long same = eq & mm & ~(1ull << j);
+                        struck |= eq;
                         maskA &= ~same;
                         mm &= ~(same | (1ull << j));
                     }
+                    cand = cand && !((struck >> lane) & 1ull);
                 }
                 const bool acc = (maskA >> lane) & 1ull;
                 // region-list slot = n + number of accepted lanes below me
@@ -508,11 +519,6 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 LFG_CNT(c, 18, __popcll(maskA))
             }
             if (L >= 64) break;
-            if (maskN != 0ull) {
-                // later offers of the pixels just accepted are no longer candidates
-                mem_fence();
-                cand = cand && !used_get(c, e);
-            }
             // the undecided lane: the reference's comparison under the angle of this moment
             const bool hitL = (__ballot(cand && aligned_val(a, reg_angle, prec)) >> L) & 1ull;
             if (hitL) {
