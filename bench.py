@@ -561,7 +561,7 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
             go(want)
             torch.cuda.synchronize()
         D_used = want
-        nb = 4 * D_used
+        nb = 8 * D_used                                    # long enough for the fill and the drain of the pipeline (one batch's latency each) to be a few per cent
         t0 = time.perf_counter()
         n_seg = go(nb)
         torch.cuda.synchronize()

@@ -14,8 +14,12 @@ constexpr float kNotDef = -1024.0f; // LSD NOTDEF marker (angle plane, degrees)
 #ifndef LF_LABEL_ITEMS
 #define LF_LABEL_ITEMS 8192
 #endif
-constexpr int kLabelItems = LF_LABEL_ITEMS;   // problems up to this many defined pixels are split into connected components (LsdParams::label_items;
-                                    // 32768 for LSD images of more than 400 k pixels, i.e. 1080p frames)
+constexpr int kLabelItems = LF_LABEL_ITEMS;   // problems up to AT LEAST this many defined pixels are split into connected components (LsdParams::label_items:
+                                    // a third of the LSD image, see lanefront_api.hip)
+#ifndef LF_LABEL_LDS
+#define LF_LABEL_LDS 6144
+#endif
+constexpr int kLabelLds = LF_LABEL_LDS;       // ... in LDS up to this many (LsdParams::label_lds), in the region scratch beyond
 constexpr int kCompCap = 1024;      // component list entries per problem (more eligible components: one component)
 
 enum Stage {
@@ -52,8 +56,9 @@ struct LsdParams {
     double log_nt, log_eps, density_th, scale;
     int min_reg_size, n_bins, refine;
     int cap_lines;
-    int label_items;    // k_lsd_label's capacity: problems with more defined pixels are grown as one component
-    int label_items_max; // ... the largest value a handle moves it to (sizes the region scratch)
+    int label_items;    // k_lsd_label's capacity: problems with more defined pixels are grown as one component (labels are u16; sizes the region scratch)
+    int label_items_max; // = label_items (rounds 2 - 3: a handle moved label_items up to this)
+    int label_lds;      // problems of up to this many defined pixels are labelled in LDS, the others in the region scratch (k_lsd_label)
 };
 
 struct SegParams {
@@ -143,7 +148,7 @@ void launch_lsd_dense_debug(const LsdParams& p, int n_frames, const int* norder,
                             const double* c_mod, float* ang, double* mod, hipStream_t s);
 void launch_lsd_rank(int n_prob, const int* norder, int* perm, hipStream_t s);
 void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
-                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, hipStream_t s);
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, uint32_t* scratch, bool big_expected, hipStream_t s);
 size_t lsd_grow_reg_stride(const LsdParams& p);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,

@@ -2,6 +2,7 @@
 // See lsd_grow.h for the algorithm, the reference citation and the lane-cooperation scheme.
 #include "common.h"
 #include "lsd_grow.h"
+#include "lsd_bitplane.h"
 
 namespace lf {
 
@@ -82,7 +83,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     const size_t Ps = (size_t)p.Hs * p.Ws;
     // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
     // BM:        [bit plane (u64)] [word counts (u16)] [USED bits] [region lists]
-    const int bm_words = ((int)(Ps >> 6) + 2) & ~1;          // + the word rank_before(H * W) reads; whole pairs
+    const int bm_words = bitplane_words(Ps);                 // + the word rank_before(H * W) reads; whole pairs (lsd_bitplane.h)
     int* rows = reinterpret_cast<int*>(lds);
     uint32_t* usedc = BM ? lds + 2 * bm_words + (((bm_words >> 1) + 1) >> 1) : lds + ((p.Hs + 2) & ~1);
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
@@ -94,31 +95,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
     if (BM) {
         __shared__ int wave_tot[GROW_WAVES];
-        for (int i = tid; i < 2 * bm_words; i += 64 * GROW_WAVES) lds[i] = 0u;
-        __syncthreads();
-        for (int i = tid; i < n_def; i += 64 * GROW_WAVES) {
-            const uint32_t xy = gxy[i];
-            const int pos = (int)(xy >> 16) * p.Ws + (int)(xy & 0xffffu);
-            atomicOr(lds + (pos >> 5), 1u << (pos & 31));
-        }
-        __syncthreads();
-        // running counts, one per pair of words: every thread sums a run of consecutive pairs, the runs are scanned across the workgroup
-        const int bm_pairs = bm_words >> 1;
-        const int per = (bm_pairs + 64 * GROW_WAVES - 1) / (64 * GROW_WAVES);
-        const int w0 = tid * per < bm_pairs ? tid * per : bm_pairs, w1 = w0 + per < bm_pairs ? w0 + per : bm_pairs;
-        int mine = 0;
-        for (int w = w0; w < w1; ++w) mine += __builtin_popcountll(bits64[2 * w]) + __builtin_popcountll(bits64[2 * w + 1]);
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += v;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        int base = incl - mine;
-        for (int k = 0; k < wave; ++k) base += wave_tot[k];
-        for (int w = w0; w < w1; ++w) { pref[w] = (uint16_t)base; base += __builtin_popcountll(bits64[2 * w]) + __builtin_popcountll(bits64[2 * w + 1]); }
+        bitplane_build<64 * GROW_WAVES>(lds, gxy, n_def, p.Ws, Ps, wave_tot);
     } else {
         for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
         for (int i = tid; i < n_def && i < def_lds; i += 64 * GROW_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);

@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include "common.h"
+#include <type_traits>
+#include "lsd_bitplane.h"
 
 namespace lf {
 using std::max;
@@ -302,27 +304,66 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
 // (the parent array lives in LDS and is addressed as such: a volatile access through a generic pointer is a flat load)
 typedef __attribute__((address_space(3))) uint32_t uf_lds_u32;
 typedef volatile uf_lds_u32 uf_lds_vu32;
-__device__ __forceinline__ uint32_t uf_min(uf_lds_vu32* q, uint32_t v) { return __hip_atomic_fetch_min((uf_lds_u32*)q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ uint32_t uf_find(uf_lds_vu32* P, uint32_t x)
+// The union-find's storage.  UfLds: the LDS tables (problems of up to label_lds entries).  UfGlb (round 4): the same tables in the
+// problem's region scratch in global memory, for the problems beyond that -- every access an agent-scope atomic (served by the L2:
+// the vector L1 is not coherent with the atomics that re-parent nodes).  Slower per access, but such a workgroup asks for no
+// dynamic LDS at all: with k_lsd_grow's workgroups of other batches filling every CU's LDS in 25 KB pieces, a labelling workgroup
+// that needed 147 KB (24 k entries) only started once a whole CU had drained -- 18 ms in the queue against 0.6 ms of work
+// (tools/pipe_overlap.py on camera frames), which capped the whole pipeline.
+struct UfLds {                       // component sizes: u32 words
+    uf_lds_vu32* P;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return P[i]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { P[i] = v; }
+    __device__ __forceinline__ void add(uint32_t i, uint32_t v) const { (void)__hip_atomic_fetch_add((uf_lds_u32*)&P[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+};
+typedef __attribute__((address_space(3))) uint16_t uf_lds_u16;
+struct UfLds16 {                     // parents: u16 (an LDS problem has at most label_lds <= 65535 entries); min by compare-and-swap on the word
+    volatile uf_lds_u16* P;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return P[i]; }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { P[i] = (uint16_t)v; }
+    __device__ __forceinline__ uint32_t min(uint32_t i, uint32_t v) const
+    {
+        uf_lds_u32* w = (uf_lds_u32*)P + (i >> 1);
+        const uint32_t sh = (i & 1u) * 16u;
+        uint32_t cur = *(volatile uf_lds_u32*)w;
+        for (;;) {
+            const uint32_t old = (cur >> sh) & 0xffffu;
+            if (v >= old) return old;
+            uint32_t expect = cur;
+            if (__hip_atomic_compare_exchange_strong(w, &expect, (cur & ~(0xffffu << sh)) | (v << sh), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return old;
+            cur = expect;
+        }
+    }
+};
+struct UfGlb {
+    uint32_t* P;
+    __device__ __forceinline__ uint32_t get(uint32_t i) const { return __hip_atomic_load(P + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void set(uint32_t i, uint32_t v) const { __hip_atomic_store(P + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ uint32_t min(uint32_t i, uint32_t v) const { return __hip_atomic_fetch_min(P + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void add(uint32_t i, uint32_t v) const { (void)__hip_atomic_fetch_add(P + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+};
+template <class UF>
+__device__ __forceinline__ uint32_t uf_find(const UF& P, uint32_t x)
 {
-    uint32_t p = P[x];
+    uint32_t p = P.get(x);
     while (p != x) {
-        const uint32_t g = P[p];
-        if (g != p) (void)uf_min(&P[x], g);                            // path halving
+        const uint32_t g = P.get(p);
+        if (g != p) (void)P.min(x, g);                                 // path halving
         x = p;
         p = g;
     }
     return x;
 }
 
-__device__ __forceinline__ void uf_unite(uf_lds_vu32* P, uint32_t a, uint32_t b)
+template <class UF>
+__device__ __forceinline__ void uf_unite(const UF& P, uint32_t a, uint32_t b)
 {
     for (;;) {
         a = uf_find(P, a);
         b = uf_find(P, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }            // a > b: hang a below b
-        const uint32_t old = uf_min(&P[a], b);
+        const uint32_t old = P.min(a, b);
         if (old == a) return;                                          // a was still a root: done
         a = old;                                                       // somebody re-parented a meanwhile: go on from there
     }
@@ -334,34 +375,85 @@ constexpr int LT = 512;
 #endif
 constexpr int kCompTop = LF_COMP_TOP;       // components that get a pass over the seed list of their own; the rest share one
 
+// GLB = false: the problems of up to label_lds entries, tables in LDS (4 bytes per entry: u16 parent + u16 x, later u16 size).  GLB = true: the larger ones (up to
+// label_items), tables in the problem's region scratch, x coordinates from the compact list.  Each launch leaves the other's
+// problems alone.
+template <bool GLB>
 __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                   const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
-                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int* __restrict__ comp_key, int comp_cap)
+                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int* __restrict__ comp_key, int comp_cap,
+                                                  uint32_t* __restrict__ scratch, size_t scratch_stride, int glb_follows)
 {
     extern __shared__ uint32_t dyn_lds[];
-    // 48 KB: three workgroups per CU, i.e. all 768 problems of a 256-frame batch are resident at once
-    const int LI = p.label_items;
-    uint32_t* parent = dyn_lds;                               // [label_items]
-    uint16_t* xs = reinterpret_cast<uint16_t*>(dyn_lds + LI);                 // [label_items], the union phase's x lists ...
-    uint32_t* csize2 = dyn_lds + LI;                          // ... then the component sizes, two u16 counters per word
+    const int LS = p.label_lds;
     __shared__ uint16_t roots[kCompCap];
     __shared__ int n_roots, rest_total;
     const int pc = blockIdx.x, t = threadIdx.x;
     const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps;
     const int n = norder[pc];
+    if (GLB ? n <= LS : (n > LS && glb_follows)) return;        // the other launch's
     uint16_t* lab = c_label + o;
     uint16_t* list = comp_list + (size_t)pc * kCompCap;
     if (n == 0) { if (t == 0) { comp_count[pc] = 0; comp_key[pc] = 0; } return; }
-    if (n > LI) {
-        // too large for the LDS tables (1080p problems): one component = the whole problem, as before
+    if (n > p.label_items || (!GLB && n > LS)) {
+        // beyond the 16-bit labels / the scratch -- or a large problem when the host did not expect one (launch_lsd_label): one
+        // component = the whole problem, a valid labelling (k_lsd_grow then grows it with one wave)
         for (int e = t; e < n; e += LT) lab[e] = 0;
         if (t == 0) { list[0] = 0; comp_count[pc] = 1; comp_key[pc] = n; }
         return;
     }
+    // parent [n]; the component sizes, two u16 counters per word [(n + 1) / 2] (LDS: where the x lists were)
+    const uint16_t* xs_lds = reinterpret_cast<const uint16_t*>(dyn_lds + LS / 2);
+    uint32_t* gtab = scratch + (size_t)pc * scratch_stride;
+    typename std::conditional<GLB, UfGlb, UfLds16>::type parent;
+    typename std::conditional<GLB, UfGlb, UfLds>::type csize2;
+    if constexpr (GLB) { parent.P = gtab; csize2.P = gtab + ((n + 1) & ~1); }
+    else { parent.P = (volatile uf_lds_u16*)dyn_lds; csize2.P = (uf_lds_vu32*)(dyn_lds + LS / 2); }
+    auto xs = [&](int k) -> int { if constexpr (GLB) return (int)(c_xy[o + k] & 0xffffu); else return (int)xs_lds[k]; };
     const int* rs = row_start + (size_t)pc * (p.Hs + 1);
-    for (int e = t; e < n; e += LT) xs[e] = (uint16_t)(c_xy[o + e] & 0xffffu);
     if (t == 0) { n_roots = 0; rest_total = 0; }
-    __syncthreads();
+    if constexpr (GLB) {
+        // The large problems find their neighbours in the bit plane (lsd_bitplane.h: 9 bytes of LDS per 64 pixels whatever the
+        // problem's size), and work run by run: a pixel whose left neighbour is defined belongs to that pixel's run, and the
+        // run already touches everything above that the pixel's up-left and up neighbours belong to -- so only the first pixel
+        // of a run looks at all three pixels above, the others only at a run that BEGINS up-right of them.
+        __shared__ int wave_tot[LT / 64];
+        bitplane_build<LT>(dyn_lds, c_xy + o, n, p.Ws, Ps, wave_tot);
+        __syncthreads();
+        const unsigned long long* bits64 = reinterpret_cast<const unsigned long long*>(dyn_lds);
+        const uint16_t* pref = reinterpret_cast<const uint16_t*>(dyn_lds + 2 * bitplane_words(Ps));
+        auto bit = [&](int pos) -> bool { return (bits64[pos >> 6] >> (pos & 63)) & 1ull; };
+        auto rank = [&](int pos) -> uint32_t {
+            const int w = pos >> 6;
+            const unsigned long long lo = bits64[w & ~1], cur = bits64[w];
+            return (uint32_t)pref[w >> 1] + ((w & 1) ? (uint32_t)__builtin_popcountll(lo) : 0u) + (uint32_t)__builtin_popcountll(cur & ((1ull << (pos & 63)) - 1ull));
+        };
+        for (int e = t; e < n; e += LT) {
+            const uint32_t xy = c_xy[o + e];
+            const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16), pos = y * p.Ws + x;
+            // the defined pixels directly to the left, inside the row: the run's first entry is that many entries back
+            int back = 0;
+            while (back < x && bit(pos - back - 1)) ++back;
+            parent.set((uint32_t)e, (uint32_t)(e - back));
+        }
+        __syncthreads();
+        for (int e = t; e < n; e += LT) {
+            const uint32_t xy = c_xy[o + e];
+            const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
+            if (y == 0) continue;
+            const int up = (y - 1) * p.Ws + x;
+            const bool head = x == 0 || !bit(up + p.Ws - 1);
+            const bool uL = x > 0 && bit(up - 1), uC = bit(up), uR = x + 1 < p.Ws && bit(up + 1);
+            if (head) {
+                if (uL) uf_unite(parent, (uint32_t)e, rank(up - 1));
+                else if (uC) uf_unite(parent, (uint32_t)e, rank(up));
+                if (uR && !uC) uf_unite(parent, (uint32_t)e, rank(up + 1));
+            } else if (uR && !uC) uf_unite(parent, (uint32_t)e, rank(up + 1));
+        }
+        __syncthreads();
+    } else {
+        for (int e = t; e < n; e += LT) reinterpret_cast<uint16_t*>(dyn_lds + LS / 2)[e] = (uint16_t)(c_xy[o + e] & 0xffffu);
+        __syncthreads();
     // horizontal runs first, without atomics: every entry starts as a child of the first entry of its run of
     // consecutive x (a forest of depth one whose roots are the smallest indices), so the union phase below only has
     // to stitch runs of adjacent rows together
@@ -369,8 +461,9 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
         const int y = (int)(c_xy[o + e] >> 16);
         const int first = rs[y];
         int h = e;
-        while (h > first && (int)xs[h - 1] + 1 == (int)xs[h]) --h;
-        parent[e] = (uint32_t)h;
+        int xh = xs(h);
+        while (h > first) { const int xp = xs(h - 1); if (xp + 1 != xh) break; --h; xh = xp; }
+        parent.set((uint32_t)e, (uint32_t)h);
     }
     __syncthreads();
     for (int e = t; e < n; e += LT) {
@@ -380,20 +473,21 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
             int lo = rs[y - 1];
             const int end = rs[y];
             int hi = end;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)xs[mid] < x - 1) lo = mid + 1; else hi = mid; }
-            for (int k = lo; k < end && k < lo + 3 && (int)xs[k] <= x + 1; ++k) uf_unite((uf_lds_vu32*)parent, (uint32_t)e, (uint32_t)k);
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (xs(mid) < x - 1) lo = mid + 1; else hi = mid; }
+            for (int k = lo; k < end && k < lo + 3 && xs(k) <= x + 1; ++k) uf_unite(parent, (uint32_t)e, (uint32_t)k);
         }
     }
     __syncthreads();
-    for (int i = t; i < (n + 1) / 2; i += LT) csize2[i] = 0u;     // the x lists are no longer needed
+    }
+    for (int i = t; i < (n + 1) / 2; i += LT) csize2.set((uint32_t)i, 0u);     // (LDS: the x lists are no longer needed)
     __syncthreads();
     for (int e = t; e < n; e += LT) {
-        const uint32_t r = uf_find((uf_lds_vu32*)parent, (uint32_t)e);
+        const uint32_t r = uf_find(parent, (uint32_t)e);
         lab[e] = (uint16_t)r;
-        atomicAdd(&csize2[r >> 1], 1u << (16 * (r & 1u)));        // counts stay below 2^16 (n <= 8192): no carry between the halves
+        csize2.add(r >> 1, 1u << (16 * (r & 1u)));              // counts stay below 2^16 (n < 65536): no carry between the halves
     }
     __syncthreads();
-    auto csize = [&](uint32_t r) -> uint32_t { return (csize2[r >> 1] >> (16 * (r & 1u))) & 0xffffu; };
+    auto csize = [&](uint32_t r) -> uint32_t { return (csize2.get(r >> 1) >> (16 * (r & 1u))) & 0xffffu; };
     const uint32_t minsz = p.min_reg_size > 1 ? (uint32_t)p.min_reg_size : 1u;
     for (int e = t; e < n; e += LT)
         if (csize((uint32_t)e) >= minsz) {                       // only roots have a count
@@ -416,7 +510,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
             rank += (sj > si || (sj == si && rj < ri)) ? 1 : 0;
         }
         list[rank] = (uint16_t)ri;
-        parent[ri] = (uint32_t)rank;                             // (the union-find is done with: a root's slot now holds its rank)
+        parent.set(ri, (uint32_t)rank);                          // (the union-find is done with: a root's slot now holds its rank)
         if (rank == 0) comp_key[pc] = (int)si;                   // launch-order key (k_lsd_rank): the largest component = the longest wave
         if (rank >= kCompTop) atomicAdd(&rest_total, (int)si);
     }
@@ -433,7 +527,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
     const uint16_t rest_root = list[kCompTop];
     for (int e = t; e < n; e += LT) {
         const uint32_t r = lab[e];
-        if (csize(r) >= minsz && parent[r] >= (uint32_t)kCompTop) lab[e] = rest_root;
+        if (csize(r) >= minsz && parent.get(r) >= (uint32_t)kCompTop) lab[e] = rest_root;
     }
     if (t == 0) {
         const int rest = rest_total;
@@ -473,15 +567,18 @@ void launch_lsd_rank(int n_prob, const int* norder, int* perm, hipStream_t s)
     hipLaunchKernelGGL(k_lsd_rank, dim3(1), dim3(1024), 0, s, n_prob, norder, perm);
 }
 
+// big_expected: whether to launch the global-table kernel behind the LDS one (the host's guess from the last batch's largest problem:
+// lane-marking frames have none and save the launch; a large problem that turns up unexpected is labelled as one component)
 void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
-                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, hipStream_t s)
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, uint32_t* scratch, bool big_expected, hipStream_t s)
 {
-    const size_t lds = (size_t)p.label_items * (4 + 2);
-    if (lds > 48 * 1024)      // per device: set before every launch that needs it (see launch_lsd_order)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)p.label_lds * (2 + 2);
     // LF_DIAG_COMP_CAP: a smaller component list, so that tests reach the "more components than the list holds" fallback
     static const int comp_cap = getenv("LF_DIAG_COMP_CAP") ? max(1, min(kCompCap, atoi(getenv("LF_DIAG_COMP_CAP")))) : kCompCap;
-    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap);
+    const size_t stride = lsd_grow_reg_stride(p);               // the region scratch is free until k_lsd_grow runs
+    hipLaunchKernelGGL(k_lsd_label<false>, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, stride, big_expected ? 1 : 0);
+    if (big_expected)
+        hipLaunchKernelGGL(k_lsd_label<true>, dim3(n_frames * 3), dim3(LT), bitplane_lds_words((size_t)p.Hs * p.Ws) * 4, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, stride, 1);
 }
 
 // Debug only: dense angle / magnitude planes rebuilt from the compact arrays (NOTDEF / 0 elsewhere).

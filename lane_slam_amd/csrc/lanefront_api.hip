@@ -129,6 +129,7 @@ struct lf_handle {
     int tie_rule = LF_TIE_MIHASHER;   // lf_associate: the reference's rule unless lf_set_tie_rule says otherwise
     int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
     int env_mixed = -1;
+    bool label_big = true;       // the last batch had a problem beyond k_lsd_label's LDS tables (launch_lsd_label; a guess: results never depend on it)
     int env_bitmap = 1;          // LF_GROW_BITMAP=0: the row-list form of k_lsd_grow (rounds 1 - 3) instead of the bit-plane form (A/B measurements); > 1: see launch_lsd_grow
     int env_kl_lds_lines = 0;    // LF_KL_LDS_LINES (test hook of the KeyLine grouping, lanefront_keylines.inc)
     int pending_problems = 0;
@@ -304,14 +305,15 @@ static int build_params(lf_handle* h)
     L.n_bins = c.lsd_n_bins; L.refine = c.lsd_refine; L.cap_lines = h->cap_lines;
     if (c.lsd_seed_order != LF_LSD_SEED_OPENCV30 && c.lsd_seed_order != LF_LSD_SEED_OPENCV32) { lf_set_error(h, LF_ERR_BAD_ARG, "lsd_seed_order %d: LF_LSD_SEED_OPENCV30 or LF_LSD_SEED_OPENCV32", c.lsd_seed_order); return LF_ERR_BAD_ARG; }
     if (c.lsd_seed_order == LF_LSD_SEED_OPENCV32 && !lsd_seed32_supported(L)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_seed_order OPENCV32: the %dx%d LSD image exceeds the row tables of the sort emulation (k_lsd_seed32.hip)", L.Ws, L.Hs); return LF_ERR_UNSUPPORTED; }
-    // component labelling capacity: 8192 entries (48 KB of LDS, three problems per CU) for 640x480-class images,
-    // 24576 (144 KB, one problem per CU) for 1080p-class ones, whose problems hold 10-20 k defined pixels
-    // ... and in between a handle follows its workload: real camera frames have problems of 9 - 16 k defined pixels, which
-    // without labelling are grown by ONE wave (70 M cycles) -- lf_wait moves label_items to what the last batch's largest problem
-    // needed (in steps of 4096 up to label_items_max; results do not depend on it, only how many waves share a problem)
-    L.label_items = h->Ps > 400000 ? 24576 : kLabelItems;
-    L.label_items_max = 24576;
-    while (L.label_items_max > kLabelItems && (size_t)(L.label_items_max - 4096) >= h->Ps) L.label_items_max -= 4096;      // no problem has more pixels than the image
+    // component labelling (k_lsd_label): problems of up to label_lds = 6144 defined pixels in LDS (24 KB per workgroup: what one
+    // workgroup of k_lsd_grow gives back when it leaves a CU), the larger ones in the problem's region scratch, up to label_items
+    // -- a third of the scaled image (every growing wave has a region list of that size in the scratch) and below 2^16 (the
+    // labels are u16).  Rounds 2 - 3 had every problem's tables in LDS, 48 KB per workgroup growing with the workload to 144 KB.
+    L.label_lds = kLabelLds;
+    L.label_items = (int)(h->Ps / 3 / 1024) * 1024;
+    if (L.label_items > 64512) L.label_items = 64512;
+    if (L.label_items < kLabelItems) L.label_items = kLabelItems;
+    L.label_items_max = L.label_items;
     // ---- segments
     SegParams& S = h->seg;
     memset(&S, 0, sizeof(S));
@@ -608,7 +610,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     }
     {
         StageTimer t(h, ST_LSD_ORDER);
-        launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
+        launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, h->label_big, s);
         static const bool no_rank = getenv("LF_DIAG_NO_RANK") != nullptr;
         if (!no_rank) launch_lsd_rank(n * 3, h->d_comp_key, h->d_perm, s);
     }
@@ -725,11 +727,7 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
         const int over_small = h->h_pinned[2], over_medium = h->h_pinned[3], np = h->pending_problems;
         h->grow_lds_level = over_medium * 4 > np ? 2 : (over_small * 20 > np ? 1 : 0);
         h->grow_mixed = (h->grow_lds_level == 0 ? over_small : over_medium) * 100 > np;
-        if (h->Ps <= 400000 && !getenv("LF_LABEL_ITEMS_FIXED")) {
-            int li = kLabelItems;
-            while (li < h->h_pinned[4] && li < h->lsd.label_items_max) li += 4096;
-            h->lsd.label_items = li;
-        }
+        h->label_big = h->h_pinned[4] > h->lsd.label_lds;       // whether the next batch gets k_lsd_label's global-table launch
     }
     if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
     if (total > h->pending_capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, h->pending_capacity); return LF_ERR_CAPACITY; }
@@ -1187,7 +1185,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
         launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, s);
-    launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, s);
+    launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, true, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
                     h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], true,
