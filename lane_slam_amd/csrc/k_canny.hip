@@ -334,6 +334,77 @@ __global__ __launch_bounds__(1024) void k_hysteresis(CannyParams p, uint32_t* __
     for (int i = threadIdx.x; i < nw; i += blockDim.x) gs[i] = S[i];
 }
 
+// K_hysteresis_cols (round 4): the same fixpoint, reached in far fewer sweeps on real images.  k_hysteresis moves a strong mark one
+// row per sweep (and any distance inside a 32-pixel word), so a weak chain running down the image costs as many sweeps as it has
+// rows: 19 x the time of the lane frames on camera frames (1.19 ms per batch, a third of everything that is not region growing
+// there).  Here a thread owns R consecutive rows of one word column, holds them in registers and sweeps them down and then up
+// inside one iteration, each row seeing the rows already updated: a mark crosses the thread's R rows in one iteration.  The words
+// of the neighbouring columns and of the rows above and below the strip are read from LDS as they are at that moment -- other
+// threads may or may not have written theirs yet: every value ever stored is a sound one (a weak pixel 8-connected to a strong
+// one), marks are only ever added, and the loop ends after an iteration in which nobody stored anything, i.e. in which every
+// thread saw the final state -- the unique fixpoint, whatever the interleaving.  One barrier per iteration.
+template <int R>
+__global__ __launch_bounds__(1024) void k_hysteresis_cols(CannyParams p, uint32_t* __restrict__ strong, const uint32_t* __restrict__ weak)
+{
+    extern __shared__ uint32_t lds[];
+    const int nw = p.Hc * p.Ww, Ww = p.Ww, Hc = p.Hc;
+    uint32_t* S = lds;
+    const int f = blockIdx.x;
+    uint32_t* gs = strong + (size_t)f * nw;
+    const uint32_t* gw = weak + (size_t)f * nw;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) S[i] = gs[i];
+    const int t = threadIdx.x;
+    const int x = t % Ww, y0 = (t / Ww) * R;
+    const bool mine = y0 < Hc;
+    uint32_t w[R], cur[R];
+    bool any_weak = false;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        w[r] = (mine && y0 + r < Hc) ? gw[(y0 + r) * Ww + x] : 0u;
+        any_weak = any_weak || w[r] != 0u;
+    }
+    __syncthreads();
+    auto spread = [](uint32_t c) { return c | (c << 1) | (c >> 1); };
+    for (int iter = 0; iter < 65536; ++iter) {
+        int changed = 0;
+        if (any_weak) {
+            // rows y0 - 1 .. y0 + R of this column and of the two beside it
+            uint32_t side[R + 2], above, below;
+#pragma unroll
+            for (int r = -1; r <= R; ++r) {
+                const int yy = y0 + r;
+                const bool in = yy >= 0 && yy < Hc;
+                const uint32_t* row = S + yy * Ww;
+                const uint32_t c = in ? row[x] : 0u;
+                const uint32_t l = in && x > 0 ? row[x - 1] : 0u;
+                const uint32_t rr = in && x + 1 < Ww ? row[x + 1] : 0u;
+                side[r + 1] = (l >> 31) | (rr << 31);
+                if (r == -1) above = c; else if (r == R) below = c; else cur[r] = c;
+            }
+            uint32_t old[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) old[r] = cur[r];
+            auto step = [&](int r) {
+                if (w[r] == 0u) return;
+                const uint32_t up = r == 0 ? above : cur[r - 1], dn = r == R - 1 ? below : cur[r + 1];
+                uint32_t sgot = (spread(up) | spread(cur[r]) | spread(dn) | side[r] | side[r + 1] | side[r + 2]) & w[r];
+                sgot = fill_up(w[r], sgot);
+                sgot = __brev(fill_up(__brev(w[r]), __brev(sgot)));
+                cur[r] |= sgot;
+            };
+#pragma unroll
+            for (int r = 0; r < R; ++r) step(r);
+#pragma unroll
+            for (int r = R - 2; r >= 0; --r) step(r);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (cur[r] != old[r]) { S[(y0 + r) * Ww + x] = cur[r]; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) gs[i] = S[i];
+}
+
 // Working images whose two bit planes do not fit one workgroup's LDS (e.g. 1920x720: 2 x 173 KB): one workgroup
 // per frame sweeps the frame in horizontal STRIPS.  A strip (its weak rows, its strong rows and one strong halo row
 // above and below, which stay fixed) is brought into LDS, iterated to its local fixpoint exactly as k_hysteresis
@@ -419,7 +490,12 @@ int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, cons
 {
     const int nw = p.Hc * p.Ww;
     const size_t lds = (size_t)nw * 2 * sizeof(uint32_t);
-    if (lds <= 64 * 1024 && nw <= 8 * 1024) {
+    static const bool jacobi = getenv("LF_HYST_JACOBI") != nullptr;         // A/B: the sweep-per-row kernel of rounds 1 - 3
+    if (!jacobi && (size_t)nw * 4 <= 64 * 1024 && p.Ww * ((p.Hc + 7) / 8) <= 1024) {
+        hipLaunchKernelGGL(k_hysteresis_cols<8>, dim3(n_frames), dim3(1024), (size_t)nw * 4, s, p, strong, weak);
+    } else if (!jacobi && (size_t)nw * 4 <= 64 * 1024 && p.Ww * ((p.Hc + 15) / 16) <= 1024) {
+        hipLaunchKernelGGL(k_hysteresis_cols<16>, dim3(n_frames), dim3(1024), (size_t)nw * 4, s, p, strong, weak);
+    } else if (lds <= 64 * 1024 && nw <= 8 * 1024) {
         hipLaunchKernelGGL(k_hysteresis, dim3(n_frames), dim3(1024), lds, s, p, strong, weak);
     } else {
         // strips of at most 8192 words (8 per thread) and 60 KB of LDS for the three row sets
