@@ -30,7 +30,7 @@ using std::max;
 using std::min;
 
 constexpr int OT = 512;          // threads
-constexpr int NB = 16;           // buckets per pass (4-bit digits; [16][512] u32 = 32 KB LDS)
+constexpr int NB = 16;           // buckets per pass of k_lsd_order (4-bit digits; [16][512] u32 = 32 KB LDS)
 constexpr int LDS_ITEMS = 8192;  // problems up to this many defined pixels are ordered entirely in LDS (2 x 32 KB, dynamic)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
@@ -43,10 +43,11 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
-template <typename T>
+template <typename T, int NB = 16>
 __device__ __forceinline__ void radix_pass(const T* __restrict__ src, T* __restrict__ dst, int n, int shift,
                            uint32_t* cnt /*[NB][OT]*/, int* tot /*[NB]*/, int* base /*[NB]*/)
 {
+    static_assert(NB % (OT / 64) == 0, "every wave scans NB / waves bucket rows");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int seg = (n + OT - 1) / OT;
     const int i0 = min(n, t * seg), i1 = min(n, i0 + seg);
@@ -269,12 +270,178 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
     radix_pass(B, A, n, 28, cnt, tot, base);                 // sorted list ends in order_a
 }
 
+// K_lsd_order_bm (round 4): the same outputs without a sort for the raster order.  The defined pixels of a problem are the set
+// bits of a bit plane of its scaled image; a pixel's compact index e -- its place among them in raster order -- is the number of
+// set bits in front of it (lsd_bitplane.h).  So: (A) build the plane and its running counts in LDS from the unordered records
+// (one LDS atomic per record); (B) every record goes straight to its place rank(address) in the compact arrays, row_start[y] =
+// rank(y * Ws), and the seed item (bin key << 20 | e) to a list in raster order; (C) one stable counting pass over the 10-bit bin
+// key: every wave owns a contiguous piece of that list and walks it 64 items at a time, an item's place among the items of its
+// bin = the wave's running count of the bin + the same-bin lanes below it (ten ballots); the walk is done twice, first to count
+// per (wave, bin), then -- the counts turned into start positions -- to place.
+// LDS: 9 bytes per 64 pixels for (A) and (B), 16 KB of (wave, bin) counters for (C) in the same space: 18.5 KB at 512 x 256
+// whatever the number of defined pixels, against the 64 KB of k_lsd_order (whose problems beyond 8192 records sorted in HBM,
+// eight passes): a workgroup finds room beside k_lsd_grow's (25 KB each), and the largest problem of a camera frame (24 k
+// records) no longer takes 0.8 ms.  Problems it cannot take (more than 65 535 records: u16 counters) sort in HBM as before, with
+// 8-bucket passes whose counter matrix fits the same LDS.
+constexpr int OB_BINS = 1024;
+__global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t* __restrict__ r_addr,
+                                                     const float* __restrict__ r_deg, const double* __restrict__ r_mod,
+                                                     const double* __restrict__ r_cs, const double* __restrict__ r_sn,
+                                                     const int* __restrict__ n_rec,
+                                                     const unsigned long long* __restrict__ maxgrad,
+                                                     unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
+                                                     uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b,
+                                                     int* __restrict__ norder, uint32_t* __restrict__ c_xy,
+                                                     float* __restrict__ c_deg, double* __restrict__ c_mod,
+                                                     double* __restrict__ c_cs, double* __restrict__ c_sn,
+                                                     int* __restrict__ row_start, int force_hbm)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    __shared__ int tot[8];
+    __shared__ int base[8];
+    __shared__ int wave_tot[OT / 64];
+    __shared__ uint32_t bin_base[OB_BINS];
+    const int pc = blockIdx.x;
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t o = (size_t)pc * Ps;
+    const int n = n_rec[pc];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t* A = order_a + o;
+    uint32_t* B = order_b + o;
+    int* RS = row_start + (size_t)pc * (p.Hs + 1);
+    if (t == 0) norder[pc] = n;
+    if (n == 0) {
+        for (int y = t; y <= p.Hs; y += OT) RS[y] = 0;
+        return;
+    }
+    const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
+    const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
+    if (n > 65535 || force_hbm) {
+        // ---- the items in HBM, 3-bit digits ([8][512] u32 = 16 KB of counters): raster order by address, then the seeds by bin
+        unsigned long long* X = sort_a + o;
+        unsigned long long* Y = sort_b + o;
+        for (int i = t; i < n; i += OT) X[i] = ((unsigned long long)r_addr[o + i] << 32) | (unsigned int)i;
+        __syncthreads();
+        for (int k = 0; k < 8; ++k) {                       // 24 address bits
+            radix_pass<unsigned long long, 8>(k & 1 ? Y : X, k & 1 ? X : Y, n, 32 + 3 * k, dyn_lds, tot, base);
+        }
+        for (int e = t; e < n; e += OT) {                   // sorted by address in X
+            const unsigned long long it = X[e];
+            const uint32_t addr = (uint32_t)(it >> 32), ri = (uint32_t)it;
+            const int y = (int)(addr / (uint32_t)p.Ws), x = (int)(addr - (uint32_t)y * (uint32_t)p.Ws);
+            const double m = r_mod[o + ri];
+            c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
+            c_deg[o + e] = r_deg[o + ri];
+            c_mod[o + e] = m;
+            c_cs[o + e] = r_cs[o + ri];
+            c_sn[o + e] = r_sn[o + ri];
+            const int bin = (int)(m * bin_coef);
+            A[e] = ((uint32_t)((p.n_bins - 1) - bin) << 20) | (uint32_t)e;
+            const int yp = e == 0 ? -1 : (int)((uint32_t)(X[e - 1] >> 32) / (uint32_t)p.Ws);
+            for (int yy = yp + 1; yy <= y; ++yy) RS[yy] = e;
+            if (e == n - 1)
+                for (int yy = y + 1; yy <= p.Hs; ++yy) RS[yy] = n;
+        }
+        __syncthreads();
+        radix_pass<uint32_t, 8>(A, B, n, 20, dyn_lds, tot, base);
+        radix_pass<uint32_t, 8>(B, A, n, 23, dyn_lds, tot, base);
+        radix_pass<uint32_t, 8>(A, B, n, 26, dyn_lds, tot, base);
+        radix_pass<uint32_t, 8>(B, A, n, 29, dyn_lds, tot, base);             // 12 key bits; the sorted list ends in order_a
+        return;
+    }
+    // (A) the plane
+    bitplane_build<OT, false>(dyn_lds, r_addr + o, n, p.Ws, Ps, wave_tot);
+    __syncthreads();
+    // (B) records to their places; seed items in raster order into B
+    for (int i = t; i < n; i += OT) {
+        const uint32_t addr = r_addr[o + i];
+        const uint32_t e = bitplane_rank(dyn_lds, Ps, (int)addr);
+        const int y = (int)(addr / (uint32_t)p.Ws), x = (int)(addr - (uint32_t)y * (uint32_t)p.Ws);
+        const double m = r_mod[o + i];
+        c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
+        c_deg[o + e] = r_deg[o + i];
+        c_mod[o + e] = m;
+        c_cs[o + e] = r_cs[o + i];
+        c_sn[o + e] = r_sn[o + i];
+        B[e] = ((uint32_t)((p.n_bins - 1) - (int)(m * bin_coef)) << 20) | e;
+    }
+    for (int y = t; y <= p.Hs; y += OT) RS[y] = (int)bitplane_rank(dyn_lds, Ps, y * p.Ws);
+    __syncthreads();                                         // B complete (and visible: same workgroup, barrier), the plane free
+    // (C) stable counting pass over the bin key
+    uint16_t* wcnt = reinterpret_cast<uint16_t*>(dyn_lds);   // [OT / 64][OB_BINS]
+    for (int i = t; i < (OT / 64) * OB_BINS / 2; i += OT) dyn_lds[i] = 0u;
+    __syncthreads();
+    const int C = ((n + OT / 64 - 1) / (OT / 64) + 63) & ~63;       // whole 64-item steps per wave
+    const int start = w * C, end = min(n, start + C);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint16_t* mine = wcnt + w * OB_BINS;
+    auto walk = [&](bool place) {
+        for (int i0 = start; i0 < end; i0 += 64) {
+            const int i = i0 + lane;
+            const bool valid = i < end;
+            const uint32_t it = valid ? B[i] : 0u;
+            const uint32_t d = it >> 20;
+            unsigned long long mask = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 10; ++b) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                mask &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            if (valid) {
+                const uint32_t run = mine[d];
+                if (place) A[run + (uint32_t)__popcll(mask & lt)] = it;
+                if ((mask >> lane) >> 1 == 0ull) mine[d] = (uint16_t)(run + (uint32_t)__popcll(mask));       // last lane of the group
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    walk(false);
+    __syncthreads();
+    // counts -> start positions: bins ascending, waves ascending inside a bin
+    for (int d = t; d < OB_BINS; d += OT) {
+        uint32_t s_ = 0;
+        for (int k = 0; k < OT / 64; ++k) s_ += wcnt[k * OB_BINS + d];
+        bin_base[d] = s_;
+    }
+    __syncthreads();
+    if (w == 0) {
+        uint32_t carry = 0;
+        for (int d0 = 0; d0 < OB_BINS; d0 += 64) {
+            const uint32_t v = bin_base[d0 + lane];
+            const uint32_t inc = (uint32_t)wave_incl_scan((int)v, lane);
+            bin_base[d0 + lane] = carry + inc - v;
+            carry += (uint32_t)__shfl((int)inc, 63);
+        }
+    }
+    __syncthreads();
+    for (int d = t; d < OB_BINS; d += OT) {
+        uint32_t run = bin_base[d];
+        for (int k = 0; k < OT / 64; ++k) { const uint32_t c_ = wcnt[k * OB_BINS + d]; wcnt[k * OB_BINS + d] = (uint16_t)run; run += c_; }
+    }
+    __syncthreads();
+    walk(true);
+}
+
 void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, const float* r_deg, const double* r_mod,
                       const double* r_cs, const double* r_sn, const int* n_rec, const unsigned long long* maxgrad,
                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b,
                       int* norder, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs, double* c_sn,
                       int* row_start, hipStream_t s)
 {
+    // the bit-plane form wherever the plane fits its LDS budget and the bins its counters (LF_ORDER_SORT=1: the sorting kernel of
+    // rounds 1 - 3, for A/B; LF_ORDER_HBM=1: every problem down the bit-plane kernel's HBM branch, for the tests)
+    static const bool old_form = getenv("LF_ORDER_SORT") != nullptr;
+    static const int force_hbm = getenv("LF_ORDER_HBM") ? 1 : 0;
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    size_t blds = bitplane_lds_words(Ps) * 4;
+    if (blds < (size_t)(OT / 64) * OB_BINS * 2) blds = (size_t)(OT / 64) * OB_BINS * 2;
+    if (blds < (size_t)8 * OT * 4) blds = (size_t)8 * OT * 4;
+    if (!old_form && p.n_bins <= OB_BINS && blds <= 40 * 1024 && Ps < ((size_t)1 << 20)) {
+        hipLaunchKernelGGL(k_lsd_order_bm, dim3(n_frames * 3), dim3(OT), blds, s, p, r_addr, r_deg, r_mod, r_cs, r_sn, n_rec, maxgrad,
+                           sort_a, sort_b, order_a, order_b, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, force_hbm);
+        return;
+    }
     const size_t lds = ((size_t)2 * LDS_ITEMS + 2 * (size_t)(p.Hs + 2) + 2 * (OT / 64) * 32) * sizeof(uint32_t);
     // more than 64 KB of dynamic LDS needs the opt-in; the attribute is PER DEVICE, so it is set before every such launch
     // (a refusal surfaces through hipGetLastError() in the caller's LF_HIP_CHECK after the launch)

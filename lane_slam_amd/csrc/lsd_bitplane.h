@@ -16,7 +16,8 @@ __host__ __device__ inline size_t bitplane_lds_words(size_t Ps) { const size_t w
 
 // Build both from the compact coordinate list (y << 16 | x), by all NT threads of the workgroup; wave_tot: NT / 64 ints of LDS.
 // Ends with the tables complete for the calling thread's own writes only: the caller synchronises.
-template <int NT>
+// XY = true: the list holds y << 16 | x (the compact coordinate list); false: raster addresses y * Ws + x (k_lsd_grad's records)
+template <int NT, bool XY = true>
 __device__ __forceinline__ void bitplane_build(uint32_t* lds, const uint32_t* __restrict__ gxy, int n_def, int Ws, size_t Ps, int* wave_tot)
 {
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -27,7 +28,7 @@ __device__ __forceinline__ void bitplane_build(uint32_t* lds, const uint32_t* __
     __syncthreads();
     for (int i = tid; i < n_def; i += NT) {
         const uint32_t xy = gxy[i];
-        const int pos = (int)(xy >> 16) * Ws + (int)(xy & 0xffffu);
+        const int pos = XY ? (int)(xy >> 16) * Ws + (int)(xy & 0xffffu) : (int)xy;
         atomicOr(lds + (pos >> 5), 1u << (pos & 31));
     }
     __syncthreads();
@@ -48,6 +49,16 @@ __device__ __forceinline__ void bitplane_build(uint32_t* lds, const uint32_t* __
     int base = incl - mine;
     for (int k = 0; k < wave; ++k) base += wave_tot[k];
     for (int w = w0; w < w1; ++w) { pref[w] = (uint16_t)base; base += __builtin_popcountll(bits64[2 * w]) + __builtin_popcountll(bits64[2 * w + 1]); }
+}
+
+// the rank of raster position pos: the number of defined pixels in front of it
+__device__ __forceinline__ uint32_t bitplane_rank(const uint32_t* lds, size_t Ps, int pos)
+{
+    const unsigned long long* bits64 = reinterpret_cast<const unsigned long long*>(lds);
+    const uint16_t* pref = reinterpret_cast<const uint16_t*>(lds + 2 * bitplane_words(Ps));
+    const int w = pos >> 6;
+    const unsigned long long lo = bits64[w & ~1], cur = bits64[w];
+    return (uint32_t)pref[w >> 1] + ((w & 1) ? (uint32_t)__builtin_popcountll(lo) : 0u) + (uint32_t)__builtin_popcountll(cur & ((1ull << (pos & 63)) - 1ull));
 }
 
 }  // namespace lf

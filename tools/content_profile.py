@@ -11,6 +11,7 @@ from lane_slam_amd import FrontEnd, default_config, synth, _lib
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--only", default="", help="one of synthetic / clutter / real (for a run under rocprofv3 --kernel-trace --stats)")
 args = ap.parse_args()
 B = args.batch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -46,6 +47,8 @@ def clutter(frames, seed):
 
 workloads = {"synthetic": synth.make_batch(B, 0), "clutter": clutter(synth.make_batch(B, 0), 4321), "real": np.stack([np.roll(rf[i % len(rf)], 7 * (i // len(rf)), axis=1) for i in range(B)])}
 for name, frames in workloads.items():
+    if args.only and name != args.only:
+        continue
     fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=512)
     fe.set_profiling(True)
     seg = None
