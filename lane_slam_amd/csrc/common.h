@@ -129,7 +129,7 @@ void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, u
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
                      const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
                      int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
-                     uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s);
+                     uint32_t* l_addr, double* l_mod, int* n_low, bool counters_zeroed, hipStream_t s);
 void launch_lsd_grad_gray(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint8_t* gray, uint32_t* r_addr, float* r_deg,
                           double* r_mod, double* r_cs, double* r_sn, int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy,
                           uint32_t* list, int* list_count, uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s);

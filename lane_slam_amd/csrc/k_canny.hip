@@ -343,8 +343,11 @@ __global__ __launch_bounds__(1024) void k_hysteresis(CannyParams p, uint32_t* __
 // threads may or may not have written theirs yet: every value ever stored is a sound one (a weak pixel 8-connected to a strong
 // one), marks are only ever added, and the loop ends after an iteration in which nobody stored anything, i.e. in which every
 // thread saw the final state -- the unique fixpoint, whatever the interleaving.  One barrier per iteration.
-template <int R>
-__global__ __launch_bounds__(1024) void k_hysteresis_cols(CannyParams p, uint32_t* __restrict__ strong, const uint32_t* __restrict__ weak)
+// R = 32 rows per thread and 256 threads where that covers the image (640 x 320: 200 threads): a workgroup of four waves and 25 KB
+// of LDS is what one workgroup of k_lsd_grow leaves behind on a CU -- with 1024 threads (R = 8) the kernel waited 7 - 17 ms for
+// a CU with sixteen free wave slots while other batches' region growing held 24 of 32 everywhere (tools/pipe_overlap.py).
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void k_hysteresis_cols(CannyParams p, uint32_t* __restrict__ strong, const uint32_t* __restrict__ weak)
 {
     extern __shared__ uint32_t lds[];
     const int nw = p.Hc * p.Ww, Ww = p.Ww, Hc = p.Hc;
@@ -491,10 +494,13 @@ int launch_hysteresis(const CannyParams& p, int n_frames, uint32_t* strong, cons
     const int nw = p.Hc * p.Ww;
     const size_t lds = (size_t)nw * 2 * sizeof(uint32_t);
     static const bool jacobi = getenv("LF_HYST_JACOBI") != nullptr;         // A/B: the sweep-per-row kernel of rounds 1 - 3
-    if (!jacobi && (size_t)nw * 4 <= 64 * 1024 && p.Ww * ((p.Hc + 7) / 8) <= 1024) {
-        hipLaunchKernelGGL(k_hysteresis_cols<8>, dim3(n_frames), dim3(1024), (size_t)nw * 4, s, p, strong, weak);
-    } else if (!jacobi && (size_t)nw * 4 <= 64 * 1024 && p.Ww * ((p.Hc + 15) / 16) <= 1024) {
-        hipLaunchKernelGGL(k_hysteresis_cols<16>, dim3(n_frames), dim3(1024), (size_t)nw * 4, s, p, strong, weak);
+    const bool fits = !jacobi && (size_t)nw * 4 <= 64 * 1024;
+    if (fits && p.Ww * ((p.Hc + 31) / 32) <= 256) {
+        hipLaunchKernelGGL((k_hysteresis_cols<32, 256>), dim3(n_frames), dim3(256), (size_t)nw * 4, s, p, strong, weak);
+    } else if (fits && p.Ww * ((p.Hc + 15) / 16) <= 512) {
+        hipLaunchKernelGGL((k_hysteresis_cols<16, 512>), dim3(n_frames), dim3(512), (size_t)nw * 4, s, p, strong, weak);
+    } else if (fits && p.Ww * ((p.Hc + 15) / 16) <= 1024) {
+        hipLaunchKernelGGL((k_hysteresis_cols<16, 1024>), dim3(n_frames), dim3(1024), (size_t)nw * 4, s, p, strong, weak);
     } else if (lds <= 64 * 1024 && nw <= 8 * 1024) {
         hipLaunchKernelGGL(k_hysteresis, dim3(n_frames), dim3(1024), lds, s, p, strong, weak);
     } else {

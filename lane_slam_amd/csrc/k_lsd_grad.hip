@@ -334,7 +334,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
                      const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
                      int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
-                     uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s)
+                     uint32_t* l_addr, double* l_mod, int* n_low, bool counters_zeroed, hipStream_t s)
 {
     const int h = p.half;
     const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
@@ -345,9 +345,11 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
     const size_t regB = szBl > szSc ? szBl : szSc;
     const size_t lds = sizeof(double) * (regA + regB);
     dim3 grid((p.Hs + GT - 1) / GT, n_frames * 3);
-    (void)hipMemsetAsync(list_count, 0, sizeof(int), s);
-    (void)hipMemsetAsync(n_rec, 0, (size_t)n_frames * 3 * sizeof(int), s);
-    if (n_low) (void)hipMemsetAsync(n_low, 0, (size_t)n_frames * 3 * sizeof(int), s);
+    if (!counters_zeroed) {                                  // (the batch path zeroes all of a batch's counters with one memset)
+        (void)hipMemsetAsync(list_count, 0, sizeof(int), s);
+        (void)hipMemsetAsync(n_rec, 0, (size_t)n_frames * 3 * sizeof(int), s);
+        if (n_low) (void)hipMemsetAsync(n_low, 0, (size_t)n_frames * 3 * sizeof(int), s);
+    }
     hipLaunchKernelGGL(k_lsd_classify, grid, dim3(256), 0, s, p, rt, edge_bits, mask_bits, list, list_count);
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));

@@ -456,7 +456,16 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
         hipLaunchKernelGGL(k_lsd_grow_bm, dim3(n_frames * 3), dim3(64 * GROW_WAVES), bm_lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
                            c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
                            tmp_tags, lines, counts, reg_lds, bm_used, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
+        // what it left (none, on every frame measured): the bounded row-list code, in a slice no larger than the bit-plane kernel's
+        // LDS -- these workgroups must find room as easily (a 40 KB request waited 1 - 4 ms behind other batches' workgroups)
         big_above = bm_used;
+        for (int kb = (int)(bm_lds >> 10); kb >= 8; --kb) {
+            const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4, regs = (size_t)GROW_LISTS * reg_lds * 4;
+            const long long left = (long long)kb * 1024 - (long long)fixed - (long long)regs - 8;
+            def_lds = left > 0 ? (int)(left * 8 / 17) & ~31 : 0;
+            lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
+            if (lds <= bm_lds) break;
+        }
         LF_GROW_LAUNCH(1);
         return;
     }

@@ -712,26 +712,27 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
 // longest first: when the chip is
 // full of another batch's growing waves, the workgroups of this launch start as slots free up, and the long problems
 // should not be the last to start).  rank by counting: n_prob <= 768.
-__global__ __launch_bounds__(1024) void k_lsd_rank(int n_prob, const int* __restrict__ norder, int* __restrict__ perm)
+__global__ __launch_bounds__(256) void k_lsd_rank(int n_prob, const int* __restrict__ norder, int* __restrict__ perm)
 {
+    // one workgroup of four waves (1024 threads waited for a CU with sixteen free wave slots: see k_hysteresis_cols)
     __shared__ int nd[1024];
-    for (int base = 0; base < n_prob; base += 1024) {       // (n_prob <= 1024 in every configuration; kept general)
-        const int i = base + threadIdx.x;
-        if (i < n_prob) nd[threadIdx.x] = norder[i];
-        __syncthreads();
-        if (i < n_prob && n_prob <= 1024) {
-            const int mine = nd[threadIdx.x];
-            int rank = 0;
-            for (int j = 0; j < n_prob; ++j) rank += (nd[j] > mine || (nd[j] == mine && j < i)) ? 1 : 0;
-            perm[rank] = i;
-        } else if (i < n_prob) perm[i] = i;
-        __syncthreads();
+    if (n_prob > 1024) {                                     // (never: 3 x 256 frames; kept general)
+        for (int i = threadIdx.x; i < n_prob; i += 256) perm[i] = i;
+        return;
+    }
+    for (int i = threadIdx.x; i < n_prob; i += 256) nd[i] = norder[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_prob; i += 256) {
+        const int mine = nd[i];
+        int rank = 0;
+        for (int j = 0; j < n_prob; ++j) rank += (nd[j] > mine || (nd[j] == mine && j < i)) ? 1 : 0;
+        perm[rank] = i;
     }
 }
 
 void launch_lsd_rank(int n_prob, const int* norder, int* perm, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lsd_rank, dim3(1), dim3(1024), 0, s, n_prob, norder, perm);
+    hipLaunchKernelGGL(k_lsd_rank, dim3(1), dim3(256), 0, s, n_prob, norder, perm);
 }
 
 // big_expected: whether to launch the global-table kernel behind the LDS one (the host's guess from the last batch's largest problem:

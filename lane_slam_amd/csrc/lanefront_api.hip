@@ -72,6 +72,8 @@ struct lf_handle {
     float* d_rdeg = nullptr;
     double *d_rmod = nullptr, *d_rcs = nullptr, *d_rsn = nullptr;
     int* d_nrec = nullptr;
+    uint8_t* d_zero = nullptr; size_t zero_bytes = 0;   // d_maxgrad | d_nrec | d_nlow | d_tile_count | d_overflow: the counters a batch starts from zero, ONE memset (each memset is a dispatch of its own and waited 0.3 ms in a busy pipeline)
+    bool overflow_zeroed = false;
     // lsd_seed_order = OPENCV32 only: pixels with a non-zero but undefined gradient (k_lsd_grad -> k_lsd_seed32)
     uint32_t* d_laddr = nullptr; double* d_lmod = nullptr; int* d_nlow = nullptr;
     unsigned long long *d_sort_a = nullptr, *d_sort_b = nullptr;
@@ -440,22 +442,33 @@ static int alloc_buffers(lf_handle* h)
     if (dalloc(h, &h->d_frames, h->frames_bytes) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_gray, B * P) || 
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) || dalloc(h, &h->d_maskbits, nprob * h->Hc * h->Ww) ||
         dalloc(h, &h->d_raddr, nprob * Ps) || dalloc(h, &h->d_rdeg, nprob * Ps) || dalloc(h, &h->d_rmod, nprob * Ps) ||
-        dalloc(h, &h->d_rcs, nprob * Ps) || dalloc(h, &h->d_rsn, nprob * Ps) || dalloc(h, &h->d_nrec, nprob) ||
+        dalloc(h, &h->d_rcs, nprob * Ps) || dalloc(h, &h->d_rsn, nprob * Ps) ||
         dalloc(h, &h->d_sort_a, nprob * Ps) || dalloc(h, &h->d_sort_b, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
-        dalloc(h, &h->d_tile_count, 1) || dalloc(h, &h->d_maxgrad, nprob) || dalloc(h, &h->d_order_a, nprob * Ps) ||
+        dalloc(h, &h->d_order_a, nprob * Ps) ||
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
         dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(h->lsd)) ||
         dalloc(h, &h->d_clabel, nprob * Ps) || dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) || dalloc(h, &h->d_perm, nprob) || dalloc(h, &h->d_comp_key, nprob) ||
         dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) ||
         dalloc(h, &h->d_pend_rec, nprob * (size_t)lsd_grow_pend_cap(h->lsd) * 12 + 2) || dalloc(h, &h->d_pend_tag, nprob * (size_t)lsd_grow_pend_cap(h->lsd) + 1) || dalloc(h, &h->d_pend_count, nprob) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
-        dalloc(h, &h->d_overflow, 8) || dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
+        dalloc(h, &h->d_slot_lines, cap * 4) || dalloc(h, &h->d_seg_frame, cap) ||
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32 &&
-        (dalloc(h, &h->d_laddr, nprob * Ps) || dalloc(h, &h->d_lmod, nprob * Ps) || dalloc(h, &h->d_nlow, nprob)))
+        (dalloc(h, &h->d_laddr, nprob * Ps) || dalloc(h, &h->d_lmod, nprob * Ps)))
         return LF_ERR_HIP;
+    {
+        h->zero_bytes = nprob * 8 + nprob * 4 + nprob * 4 + 16 + 32;
+        if (dalloc(h, &h->d_zero, h->zero_bytes)) return LF_ERR_HIP;
+        h->d_maxgrad = reinterpret_cast<unsigned long long*>(h->d_zero);
+        h->d_nrec = reinterpret_cast<int*>(h->d_zero + nprob * 8);
+        int* nlow = h->d_nrec + nprob;
+        if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32) h->d_nlow = nlow;
+        h->d_tile_count = nlow + nprob;
+        h->d_overflow = h->d_tile_count + 4;
+        LF_HIP_CHECK(h, hipMemset(h->d_zero, 0, h->zero_bytes));
+    }
     h->out_capacity = (int)cap;
     lf_segments& o = h->d_out;
     memset(&o, 0, sizeof(o));
@@ -494,12 +507,12 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_gray, h->dbg_masks.p, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
-                     h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_maxgrad, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list, h->d_tile_count,
-                     h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_overflow, h->d_slot_lines,
+                     h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_zero, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list,
+                     h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_slot_lines,
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p, h->d_laddr, h->d_lmod, h->d_nlow };
+                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p, h->d_laddr, h->d_lmod };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     assoc_scratch_free(h->a_ws);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
@@ -597,9 +610,10 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     }
     {
         StageTimer t(h, ST_LSD_GRAD);
-        LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, (size_t)n * 3 * sizeof(unsigned long long), s));
+        LF_HIP_CHECK(h, hipMemsetAsync(h->d_zero, 0, h->zero_bytes, s));           // every counter of the batch (see d_zero)
+        h->overflow_zeroed = true;
         launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec,
-                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, s);
+                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, true, s);
     }
     {
         StageTimer t(h, ST_LSD_ORDER);
@@ -640,7 +654,8 @@ static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
     hipStream_t s = h->stream;
     {
         StageTimer t(h, ST_SEGMENTS);
-        LF_HIP_CHECK(h, hipMemsetAsync(h->d_overflow, 0, 4 * sizeof(int), s));
+        if (!h->overflow_zeroed) LF_HIP_CHECK(h, hipMemsetAsync(h->d_overflow, 0, 4 * sizeof(int), s));
+        h->overflow_zeroed = false;
         launch_seg_offsets(n, h->cap_lines, h->d_counts, h->d_seg_offset, dev_out.frame_offset ? dev_out.frame_offset : h->d_frame_offset,
                            h->d_overflow, h->d_norder, lsd_grow_def_lds(h->lsd, kGrowLdsKb[0]), lsd_grow_def_lds(h->lsd, kGrowLdsKb[1]), s);
         launch_segments(h->seg, n, h->d_slot_lines, h->d_counts, h->d_seg_offset, h->d_maskbits, h->Ww, dev_out, h->d_seg_frame,
@@ -1180,7 +1195,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     LF_HIP_CHECK(h, hipMemcpyAsync(h->d_maskbits, ones.data(), nw * 12, hipMemcpyHostToDevice, s));
     LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, 3 * sizeof(unsigned long long), s));
     launch_lsd_grad(h->lsd, h->rt, 1, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad,
-                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, s);
+                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, false, s);
     launch_lsd_order(h->lsd, 1, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder,
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
