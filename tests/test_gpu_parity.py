@@ -823,3 +823,43 @@ def test_region_growing_slice_follows_the_workload():
             s, r = seg.frame(f), want[id(batch)][f]
             assert s.n == r["n"] and np.array_equal(s.lines, r["lines"]) and np.array_equal(s.keep, r["keep"])
     fe.close()
+
+
+@pytest.mark.parametrize("env", ["LF_ORDER_HBM", "LF_ORDER_SORT", "LF_HYST_JACOBI"])
+def test_other_forms_of_the_round4_kernels(env):
+    """Round 4 replaced three kernels of the batch path by forms that need a workgroup no larger than k_lsd_grow's (ordering by rank
+    in a bit plane, hysteresis by column sweeps); the forms they replaced stay in the library behind process-wide switches --
+    LF_ORDER_SORT (the sorting k_lsd_order), LF_HYST_JACOBI (one row per sweep) -- and k_lsd_order_bm has an HBM branch for problems
+    of more than 65 535 records that no frame reaches (LF_ORDER_HBM sends every problem down it).  Each, in a process of its own,
+    against the oracle: lane frames, a busy frame, 160x120 and 640x480."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import numpy as np
+        from lane_slam_amd import FrontEnd, default_config, synth
+        from oracle.oracle import Oracle
+        rng = np.random.default_rng(8)
+        for geometry in ("fullres", "parity"):
+            cfg = default_config(geometry)
+            o = Oracle(cfg)
+            frames = synth.make_batch(3, seed0=321)
+            busy = frames[0].copy()
+            for _ in range(260):
+                y, x = int(rng.integers(170, 470)), int(rng.integers(10, 620))
+                busy[y:y + int(rng.integers(1, 4)), x:x + int(rng.integers(6, 60))] = ((235, 235, 235), (40, 220, 235), (40, 40, 220))[int(rng.integers(0, 3))]
+            frames = np.concatenate([frames, busy[None]])
+            fe = FrontEnd(cfg, max_frames=4, max_lines_per_color=4096)
+            for _ in range(2):
+                seg = fe.process_batch(frames, describe=True)
+                for f in range(4):
+                    r = o.process_frame(frames[f], cap=3 * 4096)
+                    s = seg.frame(f)
+                    assert s.n == r["n"], (geometry, f, s.n, r["n"])
+                    assert np.array_equal(s.lines, r["lines"]) and np.array_equal(s.color, r["color"]) and np.array_equal(s.code, r["code"])
+            fe.close()
+        print("same")
+    ''')
+    envd = dict(os.environ)
+    envd[env] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=envd, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("same"), out.stdout[-2000:] + out.stderr[-4000:]
