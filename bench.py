@@ -311,7 +311,7 @@ def main():
             if name in counted:
                 # what bounds a streaming kernel that sits below the HBM roofline: its vector issue utilisation (rocprofv3 SQ passes,
                 # tools/profile_round.sh), quoted only while the kernel source is the one the counters were measured on
-                kpath = os.path.join(ROOT, "profiles", "r03_kernel_counters.json")
+                kpath = os.path.join(ROOT, "profiles", "kernel_counters.json")
                 if os.path.exists(kpath):
                     kj = json.load(open(kpath)).get("kernels", {}).get(counted[name][0])
                     if kj and kj.get("source_digest") == source_digest(counted[name][1]):
@@ -320,13 +320,13 @@ def main():
                 # latency / issue bound: no bandwidth or matrix roofline.  What bounds it, as counters: wave-slot
                 # occupancy, vector issue utilisation and where its wave-cycles go (rocprofv3 SQ passes measured offline by
                 # tools/profile_round.sh; quoted only while the kernel source is the one they were measured on)
-                gpath = os.path.join(ROOT, "profiles", "r03_grow_counters.json")
+                gpath = os.path.join(ROOT, "profiles", "grow_counters.json")
                 if os.path.exists(gpath):
                     gj = json.load(open(gpath))
                     if gj.get("source_digest") == source_digest("lane_slam_amd/csrc/lsd_grow.h", "lane_slam_amd/csrc/k_lsd_grow.hip"):
                         e["counters"] = {k_: v for k_, v in gj.items() if k_ in ("one_batch_in_flight", "six_batches_in_flight", "source")}
                     else:
-                        e["counters"] = "profiles/r03_grow_counters.json was measured on another lsd_grow.h / k_lsd_grow.hip: not quoted"
+                        e["counters"] = "profiles/grow_counters.json was measured on another lsd_grow.h / k_lsd_grow.hip: not quoted"
             kernels.append(e)
         streaming = [k for k in kernels if "GBps" in k]
         # dominant streaming kernel = the one that has to move the most bytes
@@ -336,21 +336,21 @@ def main():
             # PMC traffic is measured offline (separate rocprofv3 --pmc passes, tools/profile_round.sh) and is only quoted
             # while the kernel it was measured on is the kernel that runs: the file records the digest of its source
             traffic, traffic_note = None, None
-            tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if tj["workload"] == {"batch": B, "geometry": args.geometry}:
                     if tj.get("source_digest", {}).get("k_pre") == source_digest("lane_slam_amd/csrc/k_pre.hip"):
                         traffic = tj["traffic_bytes_per_launch"].get(dom["stage"])
                     else:
-                        traffic_note = "profiles/r03_traffic.json was measured on another k_pre.hip: not quoted"
+                        traffic_note = "profiles/traffic.json was measured on another k_pre.hip: not quoted"
             roofline = {"bound": "hbm", "kernel": dom["stage"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(dom["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_launch_ms": dom["avg_ms"], "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
                         "measured": "HIP events on the launch stream, %d single-batch steps run right after the "
                                     "timed region (per-kernel times inside the overlapped region are in "
                                     "kernels_timed_region)" % solo_steps,
-                        "traffic_source": "profiles/r03_traffic.json (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes)" if traffic else traffic_note,
+                        "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes, corrected as MI355X_MICROARCH.md prescribes)" if traffic else traffic_note,
                         "note": "dominant STREAMING kernel (most algorithmic bytes, SURVEY 8d).  The longest kernel by time, lsd_grow "
                                 "(sequential-semantics LSD region growing), is latency / issue bound and "
                                 "has no bandwidth or MFMA roofline (SURVEY 8d: report time); its time is in `kernels`"}

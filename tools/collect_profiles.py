@@ -43,7 +43,7 @@ for sub, name in (("pq", "_pmc_grow_sq.csv"), ("pq2", "_pmc_grow_sq2.csv"), ("pq
     f = glob.glob(os.path.join(T, sub + "/**/*counter_collection.csv"), recursive=True)
     if f:
         slim(f[0], os.path.join(P, prefix + name))
-with open(os.path.join(P, "r03_traffic.json"), "w") as g:
+with open(os.path.join(P, "traffic.json"), "w") as g:
     subprocess.check_call([sys.executable, "tools/pmc_traffic.py", os.path.join(P, prefix + "_pmc_write_size.csv"),
                            os.path.join(P, prefix + "_pmc_fetch_size.csv"), prefix], stdout=g)
 subprocess.check_call([sys.executable, "tools/pmc_grow.py", prefix])

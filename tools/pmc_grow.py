@@ -3,7 +3,7 @@
 latency bound a number").
 
 usage: tools/pmc_grow.py <prefix>        e.g. r03_b  ->  reads profiles/<prefix>_pmc_grow_sq*.csv (+ _d6 variants),
-                                                         writes profiles/r03_grow_counters.json
+                                                         writes profiles/grow_counters.json
 
 Counter units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count QUAD-cycles summed over all waves;
 SQ_BUSY_CYCLES counts cycles per shader engine (32 on the MI355X); SQ_INSTS_* count wave instructions.  WAIT_ANY +
@@ -64,7 +64,7 @@ for tag, suffix in (("one_batch_in_flight", ""), ("six_batches_in_flight", "_d6"
         path = os.path.join(P, "%s_pmc_grow_%s%s.csv" % (prefix, part, suffix))
         # the instance that does the work on the synthetic frames: <0> (problems that fit the LDS slice; <1>, launched behind it,
         # finds nothing to do there); earlier sets: one kernel, or two templated on a bool
-        for name in ("k_lsd_grow<0>", "k_lsd_grow", "k_lsd_grow<false>"):
+        for name in ("k_lsd_grow_bm", "k_lsd_grow<0>", "k_lsd_grow", "k_lsd_grow<false>"):
             got = per_kernel(path, name)
             if got:
                 c.update(got)
@@ -72,7 +72,7 @@ for tag, suffix in (("one_batch_in_flight", ""), ("six_batches_in_flight", "_d6"
     d = derive(c)
     if d:
         res[tag] = d
-json.dump(res, open(os.path.join(P, "r03_grow_counters.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(P, "grow_counters.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 
 # The streaming kernels below the 40 % HBM line: what bounds them, from the same passes.  valu_issue_utilisation
@@ -80,7 +80,7 @@ print(json.dumps(res, indent=1))
 # HBM fraction can only rise by executing fewer instructions per byte.
 STREAMING = {"k_pre": ["lane_slam_amd/csrc/k_pre.hip"], "k_canny_nms": ["lane_slam_amd/csrc/k_canny.hip"],
              "k_lbd_grad": ["lane_slam_amd/csrc/k_lbd.hip"], "k_lsd_grad": ["lane_slam_amd/csrc/k_lsd_grad.hip"],
-             "k_lbd": ["lane_slam_amd/csrc/k_lbd.hip"], "k_hysteresis": ["lane_slam_amd/csrc/k_canny.hip"]}
+             "k_lbd": ["lane_slam_amd/csrc/k_lbd.hip"], "k_hysteresis_cols<32, 256>": ["lane_slam_amd/csrc/k_canny.hip"], "k_lsd_order_bm": ["lane_slam_amd/csrc/k_lsd_order.hip"]}
 out = {"source": res["source"], "kernels": {}}
 for kname, files in STREAMING.items():
     c = {}
@@ -91,5 +91,5 @@ for kname, files in STREAMING.items():
         d.pop("wave_slot_occupancy", None)          # that figure is priced at k_lsd_grow's register budget
         d["source_digest"] = digest(*files)
         out["kernels"][kname] = d
-json.dump(out, open(os.path.join(P, "r03_kernel_counters.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(P, "kernel_counters.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

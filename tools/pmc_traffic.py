@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Derive per-launch HBM traffic from two rocprofv3 PMC passes (WRITE_SIZE, FETCH_SIZE; separate runs).
 
-usage: tools/pmc_traffic.py <pmc_write.csv> <pmc_fetch.csv> <tag> > profiles/r03_traffic.json
+usage: tools/pmc_traffic.py <pmc_write.csv> <pmc_fetch.csv> <tag> > profiles/traffic.json
 
 Counters are in KB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (the counter
 reports half the bytes of wide coalesced reads).  Output keys: kernel short names plus the stage
