@@ -148,7 +148,7 @@ void launch_lsd_dense_debug(const LsdParams& p, int n_frames, const int* norder,
                             const double* c_mod, float* ang, double* mod, hipStream_t s);
 void launch_lsd_rank(int n_prob, const int* norder, int* perm, hipStream_t s);
 void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
-                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, uint32_t* scratch, bool big_expected, hipStream_t s);
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, uint32_t* scratch, hipStream_t s);
 size_t lsd_grow_reg_stride(const LsdParams& p);
 void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, const int* norder, const uint32_t* c_xy,
                      const float* c_deg, const double* c_mod, const double* c_cs, const double* c_sn,

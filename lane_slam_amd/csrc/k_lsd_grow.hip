@@ -63,7 +63,11 @@ __shared__ grow::EvalQueue g_evalq;
 // bit plane of the scaled image plus a running count per 64-bit word (lsd_grow.h: a compact index is a rank), built here from the
 // compact list; Hs * Ws / 64 * 9 bytes whatever the number of defined pixels (18.5 KB at 512 x 256), so a problem is "big"
 // only when its USED bits do not fit (bm_used_cap entries), and those run the BIG code above in the same LDS.
-template <bool BIG, bool BM = false>
+// ZL = true (k_lsd_grow_zl, behind the bit-plane kernel): the bounded code with NOTHING in LDS -- row starts, x coordinates, USED
+// bits and region lists all read from global memory.  Slow, and meant to be: it serves the problems beyond the bit-plane kernel's
+// USED bits, which no frame measured has, and a launch of it asks for no dynamic LDS, so its (empty) workgroups pass through a busy
+// chip in microseconds where the row-list slice made them queue for 1.4 ms per batch.
+template <bool BIG, bool BM = false, bool ZL = false>
 __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint32_t* __restrict__ order,
                                                  const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                  const float* __restrict__ c_deg, const double* __restrict__ c_mod,
@@ -84,7 +88,8 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     // LDS carve: [row starts] [USED bits] [region lists, one per wave] [x lists (u16)]
     // BM:        [bit plane (u64)] [word counts (u16)] [USED bits] [region lists]
     const int bm_words = bitplane_words(Ps);                 // + the word rank_before(H * W) reads; whole pairs (lsd_bitplane.h)
-    int* rows = reinterpret_cast<int*>(lds);
+    if (ZL) { reg_lds = 0; def_lds = 0; }
+    const int* rows = ZL ? row_start + (size_t)pc * (p.Hs + 1) : reinterpret_cast<const int*>(lds);
     uint32_t* usedc = BM ? lds + 2 * bm_words + (((bm_words >> 1) + 1) >> 1) : lds + ((p.Hs + 2) & ~1);
     uint32_t* lreg = usedc + ((def_lds + 31) >> 5) + 1;
     uint16_t* lxs = reinterpret_cast<uint16_t*>(lreg + GROW_LISTS * reg_lds);
@@ -96,11 +101,12 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     if (BM) {
         __shared__ int wave_tot[GROW_WAVES];
         bitplane_build<64 * GROW_WAVES>(lds, gxy, n_def, p.Ws, Ps, wave_tot);
-    } else {
-        for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) rows[i] = grs[i];
+    } else if (!ZL) {
+        for (int i = tid; i <= p.Hs; i += 64 * GROW_WAVES) lds[i] = (uint32_t)grs[i];
         for (int i = tid; i < n_def && i < def_lds; i += 64 * GROW_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
     }
-    for (int i = tid; i <= ((def_lds + 31) >> 5); i += 64 * GROW_WAVES) usedc[i] = 0u;
+    if (!ZL)
+        for (int i = tid; i <= ((def_lds + 31) >> 5); i += 64 * GROW_WAVES) usedc[i] = 0u;
     uint32_t* gu = gused + (size_t)pc * ((Ps + 31) / 32);
     if (n_def > def_lds)
         for (int i = tid; i < (n_def + 31) / 32; i += 64 * GROW_WAVES) gu[i] = 0u;
@@ -265,6 +271,22 @@ __global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu
     if (norder[pc] > used_cap) return;
     lsd_grow_problem<false, true>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
                                   gused, tmp_lines, tmp_tags, lines, counts, reg_lds, used_cap, pc, pend_rec, pend_tag, pend_count, pend_cap);
+}
+
+__global__ __launch_bounds__(64 * GROW_WAVES) __attribute__((amdgpu_waves_per_eu(LFG_WAVES))) void k_lsd_grow_zl(LsdParams p, const uint32_t* __restrict__ order,
+                                                 const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+                                                 const float* __restrict__ c_deg, const double* __restrict__ c_mod,
+                                                 const double* __restrict__ c_cs, const double* __restrict__ c_sn,
+                                                 const int* __restrict__ row_start, const uint16_t* __restrict__ c_label,
+                                                 const uint16_t* __restrict__ comp_list, const int* __restrict__ comp_count,
+                                                 int comp_cap, uint32_t* reg, size_t reg_stride, uint32_t* gused,
+                                                 float* tmp_lines, int* tmp_tags, float* lines, int* counts, int big_above,
+                                                 const int* __restrict__ perm, double* pend_rec, int* pend_tag, int* pend_count, int pend_cap)
+{
+    const int pc = perm ? perm[blockIdx.x] : (int)blockIdx.x;
+    if (norder[pc] <= big_above) return;
+    lsd_grow_problem<true, false, true>(p, order, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, reg_stride,
+                                        gused, tmp_lines, tmp_tags, lines, counts, 0, 0, pc, pend_rec, pend_tag, pend_count, pend_cap);
 }
 
 // K_lsd_eval: rect_improve + final coordinates (grow::evaluate_pending) of every region on a problem's pending list, then
@@ -456,17 +478,11 @@ void launch_lsd_grow(const LsdParams& p, int n_frames, const uint32_t* order, co
         hipLaunchKernelGGL(k_lsd_grow_bm, dim3(n_frames * 3), dim3(64 * GROW_WAVES), bm_lds, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
                            c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
                            tmp_tags, lines, counts, reg_lds, bm_used, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
-        // what it left (none, on every frame measured): the bounded row-list code, in a slice no larger than the bit-plane kernel's
-        // LDS -- these workgroups must find room as easily (a 40 KB request waited 1 - 4 ms behind other batches' workgroups)
-        big_above = bm_used;
-        for (int kb = (int)(bm_lds >> 10); kb >= 8; --kb) {
-            const size_t fixed = (size_t)((p.Hs + 2) & ~1) * 4, regs = (size_t)GROW_LISTS * reg_lds * 4;
-            const long long left = (long long)kb * 1024 - (long long)fixed - (long long)regs - 8;
-            def_lds = left > 0 ? (int)(left * 8 / 17) & ~31 : 0;
-            lds = fixed + (size_t)(((def_lds + 31) >> 5) + 1) * 4 + regs + (size_t)def_lds * 2 + 8;
-            if (lds <= bm_lds) break;
-        }
-        LF_GROW_LAUNCH(1);
+        // what it left (none, on every frame measured): the bounded code with its tables in global memory (k_lsd_grow_zl)
+        hipLaunchKernelGGL(k_lsd_grow_zl, dim3(n_frames * 3), dim3(64 * GROW_WAVES), 0, s, p, order, norder, c_xy, c_deg, c_mod, c_cs,
+                           c_sn, row_start, c_label, comp_list, comp_count, comp_cap, reg, lsd_grow_reg_stride(p), gused, tmp_lines,
+                           tmp_tags, lines, counts, bm_used, perm, pend_rec, pend_tag, pend_count, lsd_grow_pend_cap(p));
+        (void)big_above;
         return;
     }
     if (mixed) { LF_GROW_LAUNCH(2); }

@@ -542,29 +542,27 @@ constexpr int LT = 512;
 #endif
 constexpr int kCompTop = LF_COMP_TOP;       // components that get a pass over the seed list of their own; the rest share one
 
-// GLB = false: the problems of up to label_lds entries, tables in LDS (4 bytes per entry: u16 parent + u16 x, later u16 size).  GLB = true: the larger ones (up to
-// label_items), tables in the problem's region scratch, x coordinates from the compact list.  Each launch leaves the other's
-// problems alone.
+// GLB = false: the problems of up to label_lds entries, tables in LDS (4 bytes per entry: u16 parent + u16 x, later u16 size).
+// GLB = true: the larger ones (up to label_items), tables in the problem's region scratch, neighbours through the bit plane.
 template <bool GLB>
-__global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+__device__ __forceinline__ void lsd_label_problem(const LsdParams& p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
                                                   const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
                                                   uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int* __restrict__ comp_key, int comp_cap,
-                                                  uint32_t* __restrict__ scratch, size_t scratch_stride, int glb_follows)
+                                                  uint32_t* __restrict__ scratch, size_t scratch_stride)
 {
-    extern __shared__ uint32_t dyn_lds[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     const int LS = p.label_lds;
     __shared__ uint16_t roots[kCompCap];
     __shared__ int n_roots, rest_total;
     const int pc = blockIdx.x, t = threadIdx.x;
     const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps;
     const int n = norder[pc];
-    if (GLB ? n <= LS : (n > LS && glb_follows)) return;        // the other launch's
     uint16_t* lab = c_label + o;
     uint16_t* list = comp_list + (size_t)pc * kCompCap;
     if (n == 0) { if (t == 0) { comp_count[pc] = 0; comp_key[pc] = 0; } return; }
-    if (n > p.label_items || (!GLB && n > LS)) {
-        // beyond the 16-bit labels / the scratch -- or a large problem when the host did not expect one (launch_lsd_label): one
-        // component = the whole problem, a valid labelling (k_lsd_grow then grows it with one wave)
+    if (n > p.label_items) {
+        // beyond the 16-bit labels / the scratch: one component = the whole problem, a valid labelling (k_lsd_grow then grows it
+        // with one wave)
         for (int e = t; e < n; e += LT) lab[e] = 0;
         if (t == 0) { list[0] = 0; comp_count[pc] = 1; comp_key[pc] = n; }
         return;
@@ -735,18 +733,38 @@ void launch_lsd_rank(int n_prob, const int* norder, int* perm, hipStream_t s)
     hipLaunchKernelGGL(k_lsd_rank, dim3(1), dim3(256), 0, s, n_prob, norder, perm);
 }
 
-// big_expected: whether to launch the global-table kernel behind the LDS one (the host's guess from the last batch's largest problem:
-// lane-marking frames have none and save the launch; a large problem that turns up unexpected is labelled as one component)
-void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
-                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, uint32_t* scratch, bool big_expected, hipStream_t s)
+// one launch, the form chosen per problem (both fit 24 KB of dynamic LDS; two launches cost a busy pipeline ~2 ms of a batch's latency)
+__global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __restrict__ norder, const uint32_t* __restrict__ c_xy,
+                                                  const int* __restrict__ row_start, uint16_t* __restrict__ c_label,
+                                                  uint16_t* __restrict__ comp_list, int* __restrict__ comp_count, int* __restrict__ comp_key, int comp_cap,
+                                                  uint32_t* __restrict__ scratch, size_t scratch_stride, int plane_fits)
 {
-    const size_t lds = (size_t)p.label_lds * (2 + 2);
+    const int n = norder[blockIdx.x];
+    if (n <= p.label_lds)
+        lsd_label_problem<false>(p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, scratch_stride);
+    else if (plane_fits)
+        lsd_label_problem<true>(p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, scratch_stride);
+    else {
+        // (images whose bit plane exceeds the launch's LDS: 1080p) one component = the whole problem
+        const size_t o = (size_t)blockIdx.x * p.Hs * p.Ws;
+        for (int e = threadIdx.x; e < n; e += LT) c_label[o + e] = 0;
+        if (threadIdx.x == 0) { comp_list[(size_t)blockIdx.x * kCompCap] = 0; comp_count[blockIdx.x] = 1; comp_key[blockIdx.x] = n; }
+    }
+}
+
+void launch_lsd_label(const LsdParams& p, int n_frames, const int* norder, const uint32_t* c_xy, const int* row_start,
+                      uint16_t* c_label, uint16_t* comp_list, int* comp_count, int* comp_key, uint32_t* scratch, hipStream_t s)
+{
+    size_t lds = (size_t)p.label_lds * (2 + 2);
+    const size_t plane = bitplane_lds_words((size_t)p.Hs * p.Ws) * 4;
+    const int plane_fits = plane <= 150 * 1024 ? 1 : 0;       // (1080p: 124 KB, one workgroup per CU -- as the 144 KB tables of round 3 were)
+    if (plane_fits && plane > lds) lds = plane;
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_label), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     // LF_DIAG_COMP_CAP: a smaller component list, so that tests reach the "more components than the list holds" fallback
     static const int comp_cap = getenv("LF_DIAG_COMP_CAP") ? max(1, min(kCompCap, atoi(getenv("LF_DIAG_COMP_CAP")))) : kCompCap;
     const size_t stride = lsd_grow_reg_stride(p);               // the region scratch is free until k_lsd_grow runs
-    hipLaunchKernelGGL(k_lsd_label<false>, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, stride, big_expected ? 1 : 0);
-    if (big_expected)
-        hipLaunchKernelGGL(k_lsd_label<true>, dim3(n_frames * 3), dim3(LT), bitplane_lds_words((size_t)p.Hs * p.Ws) * 4, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, stride, 1);
+    hipLaunchKernelGGL(k_lsd_label, dim3(n_frames * 3), dim3(LT), lds, s, p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, stride, plane_fits);
 }
 
 // Debug only: dense angle / magnitude planes rebuilt from the compact arrays (NOTDEF / 0 elsewhere).

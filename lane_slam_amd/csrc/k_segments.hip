@@ -16,7 +16,8 @@ namespace lf {
 
 // overflow[0]: some problem has more lines than cap_lines.  overflow[1], [2]: problems whose defined pixels exceed the region
 // growing kernel's LDS slice at its small / medium size (the host sizes the next batch's slices from them, k_lsd_grow.hip);
-// overflow[3]: the largest problem's defined pixels (the host sizes the component labelling from it)
+// overflow[3]: the largest problem's defined pixels; overflow[7]: the batch's segment total (so that ONE copy of the eight words
+// takes everything lf_wait needs to the host)
 __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict__ counts, int* __restrict__ seg_offset,
                               int* __restrict__ frame_offset, int* __restrict__ overflow, const int* __restrict__ norder, int cap_small, int cap_medium)
 {
@@ -51,14 +52,15 @@ __global__ void k_seg_offsets(int n_frames, int cap_lines, const int* __restrict
         if (t == blockDim.x - 1) carry = off + inc;
         __syncthreads();
     }
-    if (t == 0) { seg_offset[n] = carry; frame_offset[n_frames] = carry; }
+    if (t == 0) { seg_offset[n] = carry; frame_offset[n_frames] = carry; overflow[7] = carry; }
     if (ovf) atomicOr(overflow, 1);
 }
 
 void launch_seg_offsets(int n_frames, int cap_lines, const int* counts, int* seg_offset, int* frame_offset,
                         int* overflow, const int* norder, int cap_small, int cap_medium, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(1024), 0, s, n_frames, cap_lines, counts, seg_offset,
+    // four waves: a 1024-thread workgroup waits for a CU with sixteen free wave slots in a busy pipeline
+    hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(256), 0, s, n_frames, cap_lines, counts, seg_offset,
                        frame_offset, overflow, norder, cap_small, cap_medium);
 }
 

@@ -131,7 +131,6 @@ struct lf_handle {
     int tie_rule = LF_TIE_MIHASHER;   // lf_associate: the reference's rule unless lf_set_tie_rule says otherwise
     int env_lds_level = -1;      // LF_GROW_LDS_LEVEL / LF_GROW_MIXED: test and tuning overrides, read when the handle is created, clamped
     int env_mixed = -1;
-    bool label_big = true;       // the last batch had a problem beyond k_lsd_label's LDS tables (launch_lsd_label; a guess: results never depend on it)
     int env_bitmap = 1;          // LF_GROW_BITMAP=0: the row-list form of k_lsd_grow (rounds 1 - 3) instead of the bit-plane form (A/B measurements); > 1: see launch_lsd_grow
     int env_kl_lds_lines = 0;    // LF_KL_LDS_LINES (test hook of the KeyLine grouping, lanefront_keylines.inc)
     int pending_problems = 0;
@@ -624,7 +623,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     }
     {
         StageTimer t(h, ST_LSD_ORDER);
-        launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, h->label_big, s);
+        launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, s);
         static const bool no_rank = getenv("LF_DIAG_NO_RANK") != nullptr;
         if (!no_rank) launch_lsd_rank(n * 3, h->d_comp_key, h->d_perm, s);
     }
@@ -706,10 +705,8 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
     rc = run_segments(h, n_frames, *out_dev, describe != 0);
     if (rc != LF_OK) return rc;
     // total + overflow flag travel to pinned host memory behind the kernels
-    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[0], h->d_seg_offset + n_frames * 3, sizeof(int), hipMemcpyDeviceToHost, s));
-    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    if (h->detector == LF_DETECTOR_EDLINES) LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[5], h->d_overflow + 4, sizeof(int), hipMemcpyDeviceToHost, s));
-    else h->h_pinned[5] = 0;
+    // one copy: overflow[0..3] -> h_pinned[1..4], the detector's failure count -> [5], the segment total (overflow[7]) -> [8]
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 8 * sizeof(int), hipMemcpyDeviceToHost, s));
     h->pending = true;
     h->pending_keylines = false;
     h->pending_problems = n_frames * 3;
@@ -732,8 +729,8 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
         if (overflow) { lf_set_error(h, LF_ERR_CAPACITY, "%d KeyLines exceed the output capacity %d", total_kl, h->pending_capacity); return LF_ERR_CAPACITY; }
         return LF_OK;
     }
-    h->detector_failures = h->h_pinned[5];
-    const int total = h->h_pinned[0];
+    h->detector_failures = h->detector == LF_DETECTOR_EDLINES ? h->h_pinned[5] : 0;
+    const int total = h->h_pinned[8];
     if (n_segments) *n_segments = total;
     // The next batch's region-growing slices (performance only: the results do not depend on them): 13 KB while nearly every
     // problem fits it (the synthetic lane frames), 28 KB when more than 5 % overflow it (real camera frames have two to three
@@ -742,7 +739,6 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
         const int over_small = h->h_pinned[2], over_medium = h->h_pinned[3], np = h->pending_problems;
         h->grow_lds_level = over_medium * 4 > np ? 2 : (over_small * 20 > np ? 1 : 0);
         h->grow_mixed = (h->grow_lds_level == 0 ? over_small : over_medium) * 100 > np;
-        h->label_big = h->h_pinned[4] > h->lsd.label_lds;       // whether the next batch gets k_lsd_label's global-table launch
     }
     if (h->h_pinned[1]) { lf_set_error(h, LF_ERR_CAPACITY, "an LSD run produced more than max_lines_per_color=%d lines", h->cap_lines); return LF_ERR_CAPACITY; }
     if (total > h->pending_capacity) { lf_set_error(h, LF_ERR_CAPACITY, "%d segments exceed the output capacity %d", total, h->pending_capacity); return LF_ERR_CAPACITY; }
@@ -1200,7 +1196,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
         launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, s);
-    launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, true, s);
+    launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
                     h->d_slot_lines, h->d_counts, nullptr, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, kGrowLdsKb[h->grow_lds_level], true,
