@@ -541,7 +541,7 @@ int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order);
 int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
 /* How many batches (handles) a caller should keep in flight for the content this handle saw last: region growing is a chain
  * of dependent steps per problem, and on busy content (camera frames with texture: a few problems of 10 - 20 k edge pixels set
- * the batch's latency while most of the chip waits) only more batches in flight fill the machine.  6 while the last batch's
+ * the batch's latency while most of the chip waits) only more batches in flight fill the machine.  8 (6 until the kernels of round 4: six and eight measured 144 - 146 k and 147 - 148 k frames/s) while the last batch's
  * problems fit the small LDS slice of k_lsd_grow (lane markings), 18 otherwise (measured on camera frames, round 4: 6 / 12 / 18 in
  * flight = 50 k / 56 k / 62 k frames/s; give the HIP runtime more hardware queues than that: GPU_MAX_HW_QUEUES, INTEGRATION.md
  * section 4).  A hint: results never depend on it. */

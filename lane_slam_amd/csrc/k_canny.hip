@@ -371,37 +371,44 @@ __global__ __launch_bounds__(NT) void k_hysteresis_cols(CannyParams p, uint32_t*
     for (int iter = 0; iter < 65536; ++iter) {
         int changed = 0;
         if (any_weak) {
-            // rows y0 - 1 .. y0 + R of this column and of the two beside it
-            uint32_t side[R + 2], above, below;
+            // rows y0 - 1 .. y0 + R of this column; of the two columns beside it only the bit that touches this one matters (bit 31
+            // of the left word, bit 0 of the right one): one bit per row, kept as two masks (bit r + 1 = row y0 + r)
+            uint32_t above = 0u, below = 0u;
+            unsigned long long sideL = 0ull, sideR = 0ull;
+            int at = (y0 - 1) * Ww + x;                        // walks down the column; opaque to the optimiser, which would otherwise
+            int yv = y0, xv = x;                               // keep 102 loop-invariant addresses and as many lane masks in registers
+            asm volatile("" : "+v"(at), "+v"(yv), "+v"(xv));   // across the iterations (256 VGPRs, 190 spilled SGPRs)
 #pragma unroll
-            for (int r = -1; r <= R; ++r) {
-                const int yy = y0 + r;
+            for (int r = -1; r <= R; ++r, at += Ww) {
+                const int yy = yv + r;
                 const bool in = yy >= 0 && yy < Hc;
-                const uint32_t* row = S + yy * Ww;
-                const uint32_t c = in ? row[x] : 0u;
-                const uint32_t l = in && x > 0 ? row[x - 1] : 0u;
-                const uint32_t rr = in && x + 1 < Ww ? row[x + 1] : 0u;
-                side[r + 1] = (l >> 31) | (rr << 31);
-                if (r == -1) above = c; else if (r == R) below = c; else cur[r] = c;
+                const uint32_t* row = S + (in ? at - xv : 0);
+                const uint32_t c = in ? row[xv] : 0u;
+                const uint32_t l = in && xv > 0 ? row[xv - 1] : 0u;
+                const uint32_t rr = in && xv + 1 < Ww ? row[xv + 1] : 0u;
+                sideL |= (unsigned long long)(l >> 31) << (r + 1);
+                sideR |= (unsigned long long)(rr & 1u) << (r + 1);
+                if (r == -1) above = c; else if (r == R) below = c; else { cur[r] = c; asm volatile("" : "+v"(w[r])); }   // (nor anything derived from w[r])
+                if ((r & 7) == 6) asm volatile("" ::: "memory");      // eight rows' reads in flight at a time, not all 34 (registers: see above)
             }
-            uint32_t old[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) old[r] = cur[r];
+            uint32_t dirty = 0u;                               // rows of the strip that changed (R <= 32)
             auto step = [&](int r) {
                 if (w[r] == 0u) return;
                 const uint32_t up = r == 0 ? above : cur[r - 1], dn = r == R - 1 ? below : cur[r + 1];
-                uint32_t sgot = (spread(up) | spread(cur[r]) | spread(dn) | side[r] | side[r + 1] | side[r + 2]) & w[r];
+                const uint32_t side = (((sideL >> r) & 7ull) ? 1u : 0u) | (((sideR >> r) & 7ull) ? 0x80000000u : 0u);   // rows r - 1, r, r + 1
+                uint32_t sgot = (spread(up) | spread(cur[r]) | spread(dn) | side) & w[r];
                 sgot = fill_up(w[r], sgot);
                 sgot = __brev(fill_up(__brev(w[r]), __brev(sgot)));
-                cur[r] |= sgot;
+                if (sgot & ~cur[r]) { cur[r] |= sgot; dirty |= 1u << r; }
             };
 #pragma unroll
-            for (int r = 0; r < R; ++r) step(r);
+            for (int r = 0; r < R; ++r) { step(r); asm volatile("" : "+v"(w[r])); }      // (the up sweep recomputes what it needs from w[r])
 #pragma unroll
             for (int r = R - 2; r >= 0; --r) step(r);
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                if (cur[r] != old[r]) { S[(y0 + r) * Ww + x] = cur[r]; changed = 1; }
+                if ((dirty >> r) & 1u) S[at - (R + 1 - r) * Ww] = cur[r];
+            changed = dirty != 0u;
         }
         if (!__syncthreads_or(changed)) break;
     }

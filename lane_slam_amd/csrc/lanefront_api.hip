@@ -1149,7 +1149,7 @@ extern "C" int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_
 extern "C" int lf_suggested_depth(const lf_handle* h)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
-    return h->grow_lds_level == 0 && !h->grow_mixed ? 6 : 18;
+    return h->grow_lds_level == 0 && !h->grow_mixed ? 8 : 18;
 }
 
 extern "C" int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order)
