@@ -24,6 +24,7 @@
 // checked against the oracle without a GPU (tests/hostsim); that build is a test harness,
 // not a product path.
 #pragma once
+#include <type_traits>
 #include "detmath.h"
 
 #ifndef LF_HOST_SIM
@@ -220,6 +221,22 @@ LFG_DEV void reg_set(const Ctx& c, int i, uint32_t v)
 {
     if (lane_id() == 0) { if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v; }
 }
+#ifndef LF_HOST_SIM
+// LO = true: the caller knows the index is below reg_lds (region_grow decides per batch, wave-uniformly): a plain LDS access.  The
+// generic forms above select between an LDS and a global address and compile to FLAT accesses -- the long way to LDS, and every
+// wait behind one waits on both memory counters: the store of an accepted pixel made the ordered float sums behind it wait for
+// the store to complete (s_waitcnt vmcnt(0) lgkmcnt(0) in the loop).
+template <bool LO> LFG_DEV uint32_t reg_get_t(const Ctx& c, int i)
+{
+    if (LO) return ((__attribute__((address_space(3))) uint32_t*)c.lreg)[i];
+    return reg_get(c, i);
+}
+template <bool LO> LFG_DEV void reg_put_t(const Ctx& c, int i, uint32_t v)       // the calling lane's slot
+{
+    if (LO) ((__attribute__((address_space(3))) uint32_t*)c.lreg)[i] = v;
+    else if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v;
+}
+#endif
 LFG_DEV int xs_get(const Ctx& c, int e) { return e < c.def_lds ? (int)c.lxs[e] : (int)(c.gxy[e] & 0xffffu); }
 
 // BITMAP form (round 4; k_lsd_grow.hip chooses it on busy content): a compact index is a RANK -- the number of defined pixels in
@@ -265,28 +282,31 @@ LFG_DEV int find_e(const Ctx& c, int x, int y)
 // lists, whose HBM tail is real, measured slower: the per-lane branch costs more than the flat access).
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 LFG_DEV lds_u32* as_lds(uint32_t* p) { return (lds_u32*)p; }
+// (`e < 0x7fffffff` does not fold -- e might be INT_MAX for all the compiler knows -- and left a branch and the global half of
+// every USED operation in the all-in-LDS kernels; the equality does)
+LFG_DEV bool used_in_lds(const Ctx& c, int e) { return c.used_lds == 0x7fffffff || e < c.used_lds; }
 LFG_DEV bool used_get(const Ctx& c, int e)
 {
     uint32_t w;
-    if (e < c.used_lds) w = as_lds(c.usedc)[e >> 5]; else w = c.gused[e >> 5];
+    if (used_in_lds(c, e)) w = as_lds(c.usedc)[e >> 5]; else w = c.gused[e >> 5];
     return (w >> (e & 31)) & 1u;
 }
 // atomics without return value: no read-modify-write round trip on the sequential path
 LFG_DEV void used_or(const Ctx& c, int e)                // the calling lane's entry
 {
-    if (e < c.used_lds) __hip_atomic_fetch_or(as_lds(c.usedc) + (e >> 5), 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (used_in_lds(c, e)) __hip_atomic_fetch_or(as_lds(c.usedc) + (e >> 5), 1u << (e & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicOr(&c.gused[e >> 5], 1u << (e & 31));
 }
 LFG_DEV void used_set(const Ctx& c, int e) { if (lane_id() == 0) used_or(c, e); }
 LFG_DEV void used_and(const Ctx& c, int e)               // the calling lane's entry
 {
-    if (e < c.used_lds) __hip_atomic_fetch_and(as_lds(c.usedc) + (e >> 5), ~(1u << (e & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (used_in_lds(c, e)) __hip_atomic_fetch_and(as_lds(c.usedc) + (e >> 5), ~(1u << (e & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else atomicAnd(&c.gused[e >> 5], ~(1u << (e & 31)));
 }
 LFG_DEV void used_clr(const Ctx& c, int e)
 {
     if (lane_id() == 0) {
-        if (e < c.used_lds) __hip_atomic_fetch_and(as_lds(c.usedc) + (e >> 5), ~(1u << (e & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (used_in_lds(c, e)) __hip_atomic_fetch_and(as_lds(c.usedc) + (e >> 5), ~(1u << (e & 31)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else atomicAnd(&c.gused[e >> 5], ~(1u << (e & 31)));
     }
 }
@@ -413,9 +433,12 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     const bool bulk_ok = precf < 0.7f && precf > 4.f * EPSF;
     const float tn_cone = 0.5f * (precf - EPSF), tf_cone = precf + 0.5f * (precf - EPSF) + EPSF;
     for (int i = 0; i < n;) {
+      // one batch; LO: every list index it touches (i .. n + 63) is in the LDS part of the list -- nearly always (see reg_get_t)
+      auto batch = [&](auto lo_tag) {
+        constexpr bool LO = decltype(lo_tag)::value;
         const int m = n - i < 7 ? n - i : 7;
         const bool lv = slot < m;
-        const uint32_t pkl = lv ? reg_get(c, i + slot) : 0u;
+        const uint32_t pkl = lv ? reg_get_t<LO>(c, i + slot) : 0u;
         const int pxl = (int)(pkl & 0xffffu), pyl = (int)(pkl >> 16);
         const int xx = pxl + ddx, yy = pyl + ddy;
         const bool inb = lv && xx >= 0 && xx < W && yy >= 0 && yy < H;
@@ -498,8 +521,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 // region-list slot = n + number of accepted lanes below me
                 const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(maskA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)maskA, 0u));
                 if (acc) {
-                    const int pos = n + below;
-                    if (pos < c.reg_lds) c.lreg[pos] = key; else c.greg[pos] = key;
+                    reg_put_t<LO>(c, n + below, key);
                     used_or(c, e);
                 }
                 n += __popcll(maskA);
@@ -526,7 +548,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 const int eL = rl_i(e, L);
                 const int ay = rl_i(yy, L), ax = rl_i(xx, L);
                 used_set(c, eL);
-                reg_set(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
+                if (lane == 0) reg_put_t<LO>(c, n, ((uint32_t)ay << 16) | (uint32_t)ax);
                 ++n;
                 sumdx = (float)((double)sumdx + rl_d(ck, L));
                 sumdy = (float)((double)sumdy + rl_d(sk, L));
@@ -541,6 +563,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         LFG_T1(c, 14)
         LFG_CNT(c, 11, 1)
         i += m;
+      };
+      if (n + 64 <= c.reg_lds) batch(std::true_type{}); else batch(std::false_type{});
     }
 #else
     for (int i = 0; i < n; ++i) {
