@@ -591,9 +591,19 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
 }
 
 // ------------------------------------------------------------------ region2rect
-LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double prec, double p, Rect& rec)
+// LO (device build): the whole region list is in its LDS part (reg_size <= reg_lds, nearly always): plain LDS reads (reg_get_t).
+// The ordered f64 sums take their terms from lane registers in list order; the products that go into them do not depend on the
+// order and are formed by all lanes at once (same operands, same operations, no contraction: the same bits) -- the sequential part
+// of a point is three additions.
+template <bool LO>
+LFG_DEV void region2rect_t(const Ctx& c, int reg_size, double reg_angle, double prec, double p, Rect& rec)
 {
     const int lane = lane_id();
+#ifndef LF_HOST_SIM
+    auto list_at = [&](int i) { return reg_get_t<LO>(c, i); };
+#else
+    auto list_at = [&](int i) { return reg_get(c, i); };
+#endif
     double x = 0, y = 0, sum = 0;
     // points and weights of the first 64 region points stay in lane registers for the second pass
     // (most regions are shorter than that: one row search + one trip to the magnitudes instead of two)
@@ -602,16 +612,15 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
     for (int base = 0; base < reg_size; base += LFG_NL) {
         const int i = base + lane;
         const bool v = i < reg_size;
-        const uint32_t pk = v ? reg_get(c, i) : 0u;
+        const uint32_t pk = v ? list_at(i) : 0u;
         const double w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
         if (base == 0) { pk0 = pk; w0 = w; }
+        const double xw = (double)(int)(pk & 0xffffu) * w, yw = (double)(int)(pk >> 16) * w;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
-            const uint32_t q = (uint32_t)rl_i((int)pk, j);
-            const double weight = rl_d(w, j);
-            x += (double)(int)(q & 0xffffu) * weight;
-            y += (double)(int)(q >> 16) * weight;
-            sum += weight;
+            x += rl_d(xw, j);
+            y += rl_d(yw, j);
+            sum += rl_d(w, j);
         }
     }
     x /= sum;
@@ -624,18 +633,17 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
         uint32_t pk = pk0;
         double w = w0;
         if (base != 0) {
-            pk = v ? reg_get(c, i) : 0u;
+            pk = v ? list_at(i) : 0u;
             w = v ? c.mod[find_e(c, (int)(pk & 0xffffu), (int)(pk >> 16))] : 0.0;
         }
+        const double ddx = (double)(int)(pk & 0xffffu) - x;
+        const double ddy = (double)(int)(pk >> 16) - y;
+        const double tyy = ddy * ddy * w, txx = ddx * ddx * w, txy = ddx * ddy * w;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
-            const uint32_t q = (uint32_t)rl_i((int)pk, j);
-            const double weight = rl_d(w, j);
-            const double ddx = (double)(int)(q & 0xffffu) - x;
-            const double ddy = (double)(int)(q >> 16) - y;
-            Ixx += ddy * ddy * weight;
-            Iyy += ddx * ddx * weight;
-            Ixy -= ddx * ddy * weight;
+            Ixx += rl_d(tyy, j);
+            Iyy += rl_d(txx, j);
+            Ixy -= rl_d(txy, j);
         }
     }
     const double lambda = 0.5 * (Ixx + Iyy - dm::dsqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
@@ -648,7 +656,7 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
     // extents: max/min are order independent -> lane-parallel
     double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
     for (int i = lane; i < reg_size; i += LFG_NL) {
-        const uint32_t pk = reg_get(c, i);
+        const uint32_t pk = list_at(i);
         const double regdx = (double)(int)(pk & 0xffffu) - x;
         const double regdy = (double)(int)(pk >> 16) - y;
         const double l = regdx * dx + regdy * dy;
@@ -666,6 +674,14 @@ LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double pr
     rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy;
     rec.prec = prec; rec.p = p;
     if (rec.width < 1.0) rec.width = 1.0;
+}
+LFG_DEV void region2rect(const Ctx& c, int reg_size, double reg_angle, double prec, double p, Rect& rec)
+{
+#ifndef LF_HOST_SIM
+    if (reg_size <= c.reg_lds) region2rect_t<true>(c, reg_size, reg_angle, prec, p, rec);
+    else
+#endif
+        region2rect_t<false>(c, reg_size, reg_angle, prec, p, rec);
 }
 
 // ------------------------------------------------------------------ refine
