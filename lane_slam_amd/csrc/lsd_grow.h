@@ -50,6 +50,9 @@ constexpr double NOTDEF_D = -1024.0;
 
 // ------------------------------------------------------------------ wave primitives
 #ifndef LF_HOST_SIM
+// the lanes for which p holds, as the condition mask the compiler already has (HIP's __ballot(int) goes through a 0 / 1 register and
+// a compare: three instructions and a vector -> scalar dependency per ballot, eight ballots per accept span)
+LFG_DEV unsigned long long lfg_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 LFG_DEV int lane_id() { return (int)(threadIdx.x & 63u); }
 LFG_DEV int rl_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 LFG_DEV float rl_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
@@ -416,7 +419,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     if (c.min_reg_size > 1) {
         const int ax = k9 - 4, ay = slot - 3;
         const bool adj = lane < 63 && ax >= -1 && ax <= 1 && ay >= -1 && ay <= 1 && (ax != 0 || ay != 0);
-        if (__ballot(adj && w_e >= 0 && !used_get(c, w_e)) == 0ull) {
+        if (lfg_ballot(adj && w_e >= 0 && !used_get(c, w_e)) == 0ull) {
             reg_size = 1;
             reg_angle = NOTDEF_D;
             LFG_CNT(c, 20, 1)
@@ -430,7 +433,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     LFG_T1(c, 16)
     const float precf = (float)prec;
     const float EPSF = 0.0043633f;                        // 0.25 degree
-    const bool bulk_ok = precf < 0.7f && precf > 4.f * EPSF;
+    const bool bulk_ok = __builtin_amdgcn_readfirstlane((int)(precf < 0.7f && precf > 4.f * EPSF)) != 0;     // (uniform, said explicitly: see the accept loop)
     const float tn_cone = 0.5f * (precf - EPSF), tf_cone = precf + 0.5f * (precf - EPSF) + EPSF;
     for (int i = 0; i < n;) {
       // one batch; LO: every list index it touches (i .. n + 63) is in the LDS part of the list -- nearly always (see reg_get_t)
@@ -449,12 +452,15 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         float dg = __shfl(w_deg, widx);
         double ck = __shfl(w_cs, widx), sk = __shfl(w_sn, widx);
         LFG_T1(c, 12)
-        LFG_CNT(c, 15, __ballot(inb && !inwin) != 0ull)
+        LFG_CNT(c, 15, lfg_ballot(inb && !inwin) != 0ull)
         if (!inwin) {
             e = inb ? find_e(c, xx, yy) : -1;
             if (e >= 0) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
         }
-        bool cand = e >= 0 && !used_get(c, e);            // defined and free at batch start
+        // the candidates -- defined and free at batch start -- as a LANE MASK (wave-uniform integers from here on: a per-lane bool
+        // that survives a branch comes back through a 0 / 1 register and a compare every time it is balloted, three instructions
+        // and a vector -> scalar dependency, eight times per span)
+        unsigned long long candm = lfg_ballot(e >= 0 && !used_get(c, e));
         const double a = (double)dg * DEG2RAD;
         LFG_T1(c, 13)
         // The reference tests the candidates one by one, in lane order, each against the running region angle,
@@ -483,36 +489,37 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         unsigned long long later = ~0ull;                 // lanes at or after the cursor
         bool added = false;
         for (;;) {
-            const unsigned long long cb = __ballot(cand) & later;
+            const unsigned long long cb = candm & later;
             if (cb == 0ull) break;                        // nobody left to test
             float ad = af - (float)reg_angle;
             ad = ad < 0.f ? -ad : ad;
             if (ad > 3.14159265f) ad = 6.28318531f - ad;
-            bool is_near = false, is_mid = true;          // everything undecided = the reference's loop, lane by lane
+            unsigned long long nearM = 0ull, midM = ~0ull;    // everything undecided = the reference's loop, lane by lane
             if (bulk_ok) {
                 // division free: ad <= prec - EPS - (pi/2) m / smax  <=>  (ad - prec + EPS) smax + (pi/2) m <= 0
-                const float hm = 1.5707964f * (float)__popcll(__ballot(cand && ad <= precf) & later);
+                const float hm = 1.5707964f * (float)__popcll(lfg_ballot(ad <= precf) & cb);
                 const float sx_ = sumdx < 0.f ? -sumdx : sumdx, sy_ = sumdy < 0.f ? -sumdy : sumdy;
                 const float smax = sx_ > sy_ ? sx_ : sy_;
-                if ((precf - EPSF - tn_cone) * smax > hm) {            // the magnitude pair has the wider near band
-                    is_near = (ad - precf + EPSF) * smax + hm <= 0.f;
-                    is_mid = !is_near && !((ad - precf - EPSF) * smax - hm > 0.f);
+                // (the sums are the same in every lane; said explicitly, or the branch and every mask behind it count as divergent)
+                if (__builtin_amdgcn_readfirstlane((int)((precf - EPSF - tn_cone) * smax > hm))) {            // the magnitude pair has the wider near band
+                    nearM = lfg_ballot((ad - precf + EPSF) * smax + hm <= 0.f);
+                    midM = ~nearM & ~lfg_ballot((ad - precf - EPSF) * smax - hm > 0.f);
                 } else {
-                    is_near = ad <= tn_cone;
-                    is_mid = !is_near && ad <= tf_cone;
+                    nearM = lfg_ballot(ad <= tn_cone);
+                    midM = ~nearM & lfg_ballot(ad <= tf_cone);
                 }
             }
-            const unsigned long long maskM = __ballot(cand && is_mid) & later;
+            const unsigned long long maskM = midM & cb;
             const int L = maskM ? __builtin_ctzll(maskM) : 64;
-            const unsigned long long span = later & (L >= 64 ? ~0ull : ((1ull << L) - 1ull));
-            const unsigned long long maskN = __ballot(cand && is_near) & span;
+            const unsigned long long span = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+            const unsigned long long maskN = nearM & cb & span;
             if (maskN != 0ull) {
                 // first offer wins inside the span: walk the near lanes in order, each new pixel strikes its later offers
                 unsigned long long maskA = maskN;
                 if (maskN & (maskN - 1ull)) {
                     for (unsigned long long mm = maskN; mm != 0ull;) {
                         const int j = __builtin_ctzll(mm);
-                        const unsigned long long same = __ballot(key == (uint32_t)rl_i((int)key, j)) & mm & ~(1ull << j);
+                        const unsigned long long same = lfg_ballot(key == (uint32_t)rl_i((int)key, j)) & mm & ~(1ull << j);
                         maskA &= ~same;
                         mm &= ~(same | (1ull << j));
                     }
@@ -540,10 +547,10 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 // later offers of the pixels just accepted are no longer candidates (measured: striking them by key in the loop
                 // above instead of this trip to the USED bits made the kernel 1.5 % slower)
                 mem_fence();
-                cand = cand && !used_get(c, e);
+                candm &= ~lfg_ballot(e >= 0 && used_get(c, e));
             }
             // the undecided lane: the reference's comparison under the angle of this moment
-            const bool hitL = (__ballot(cand && aligned_val(a, reg_angle, prec)) >> L) & 1ull;
+            const bool hitL = ((lfg_ballot(aligned_val(a, reg_angle, prec)) & candm) >> L) & 1ull;
             if (hitL) {
                 const int eL = rl_i(e, L);
                 const int ay = rl_i(yy, L), ax = rl_i(xx, L);
@@ -553,7 +560,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 sumdx = (float)((double)sumdx + rl_d(ck, L));
                 sumdy = (float)((double)sumdy + rl_d(sk, L));
                 reg_angle = (double)dm::fast_atan2_deg(sumdy, sumdx) * DEG2RAD;
-                if (e == eL) cand = false;                // the same pixel seen from a later point is now USED
+                candm &= ~lfg_ballot(e == eL);            // the same pixel seen from a later point is now USED
                 added = true;
                 LFG_CNT(c, 19, 1)
             }
@@ -721,7 +728,7 @@ LFG_DEV void reduce_radius_step(const Ctx& c, int& reg_size, double xc, double y
         const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
         const bool out = v && dist_sq(xc, yc, (double)px, (double)py) > radSq;
         if (out) used_and(c, find_e(c, px, py));
-        m += __popcll(__ballot(v && !out));
+        m += __popcll(lfg_ballot(v && !out));
     }
     if (m == n) return;
     int hb = 0, fb = n;                 // front places scanned so far: [0, hb); back places scanned so far: [fb, n)
@@ -733,7 +740,7 @@ LFG_DEV void reduce_radius_step(const Ctx& c, int& reg_size, double xc, double y
             const bool v = i < m;
             const uint32_t pk = v ? reg_get(c, i) : 0u;
             const bool out = v && dist_sq(xc, yc, (double)(int)(pk & 0xffffu), (double)(int)(pk >> 16)) > radSq;
-            const unsigned long long mk = __ballot(out);
+            const unsigned long long mk = lfg_ballot(out);
             hq = wave_compact(i, mk);
             nh = __popcll(mk);
             hb += LFG_NL;
@@ -745,7 +752,7 @@ LFG_DEV void reduce_radius_step(const Ctx& c, int& reg_size, double xc, double y
             const bool v = i >= m;
             const uint32_t pk = v ? reg_get(c, i) : 0u;
             const bool keep = v && !(dist_sq(xc, yc, (double)(int)(pk & 0xffffu), (double)(int)(pk >> 16)) > radSq);
-            const unsigned long long mk = __ballot(keep);
+            const unsigned long long mk = lfg_ballot(keep);
             fq = wave_compact((int)pk, mk);
             nf = __popcll(mk);
             fb -= LFG_NL;
@@ -1390,12 +1397,12 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         const int my_e = (int)(seed_items & 0xfffffu);
         const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;               // beside the label, not behind it: one round trip per chunk less
         if (sv && c.label) sv = (int)c.label[my_e] == c.root;          // seeds of other components are not ours
-        if (__ballot(sv) == 0ull) continue;
+        if (lfg_ballot(sv) == 0ull) continue;
         LFG_T1(c, 8)
         unsigned long long pending = ~0ull;
       for (;;) {
         mem_fence();
-        const unsigned long long fr = __ballot(sv && !used_get(c, my_e)) & pending;
+        const unsigned long long fr = lfg_ballot(sv && !used_get(c, my_e)) & pending;
         if (fr == 0ull) break;
         const int sl = __builtin_ctzll(fr);
         pending = sl >= 63 ? 0ull : (~0ull << (sl + 1));
