@@ -261,10 +261,14 @@ LFG_DEV int find_e(const Ctx& c, int x, int y)
 {
     if (bm_mode(c)) {
         const int pos = y * c.W + x, b = pos & 63;
+        // both reads at once and no branch: the count is read whether the pixel turns out to be defined or not (a test of the bit
+        // in front of it put a second LDS round trip on the growing wave's chain)
         const int wi = pos >> 6;
         const BmPair v = reinterpret_cast<const BmPair*>(c.bits64)[wi >> 1];
+        const int pf = (int)c.pref[wi >> 1];
         const unsigned long long w = (wi & 1) ? v.y : v.x;
-        return ((w >> b) & 1ull) ? (int)c.pref[wi >> 1] + ((wi & 1) ? __builtin_popcountll(v.x) : 0) + __builtin_popcountll(w & ((1ull << b) - 1ull)) : -1;
+        const int e = pf + ((wi & 1) ? __builtin_popcountll(v.x) : 0) + __builtin_popcountll(w & ((1ull << b) - 1ull));
+        return ((w >> b) & 1ull) ? e : -1;
     }
     int lo = c.rows[y];
     const int end = c.rows[y + 1];
@@ -460,7 +464,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         // the candidates -- defined and free at batch start -- as a LANE MASK (wave-uniform integers from here on: a per-lane bool
         // that survives a branch comes back through a 0 / 1 register and a compare every time it is balloted, three instructions
         // and a vector -> scalar dependency, eight times per span)
-        unsigned long long candm = lfg_ballot(e >= 0 && !used_get(c, e));
+        unsigned long long candm = lfg_ballot((e >= 0) & !used_get(c, e < 0 ? 0 : e));      // (no branch around the LDS read)
         const double a = (double)dg * DEG2RAD;
         LFG_T1(c, 13)
         // The reference tests the candidates one by one, in lane order, each against the running region angle,
@@ -547,7 +551,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 // later offers of the pixels just accepted are no longer candidates (measured: striking them by key in the loop
                 // above instead of this trip to the USED bits made the kernel 1.5 % slower)
                 mem_fence();
-                candm &= ~lfg_ballot(e >= 0 && used_get(c, e));
+                candm &= ~lfg_ballot((e >= 0) & used_get(c, e < 0 ? 0 : e));
             }
             // the undecided lane: the reference's comparison under the angle of this moment
             const bool hitL = ((lfg_ballot(aligned_val(a, reg_angle, prec)) & candm) >> L) & 1ull;
