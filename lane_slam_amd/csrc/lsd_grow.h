@@ -1401,12 +1401,13 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         const int my_e = (int)(seed_items & 0xfffffu);
         const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;               // beside the label, not behind it: one round trip per chunk less
         if (sv && c.label) sv = (int)c.label[my_e] == c.root;          // seeds of other components are not ours
-        if (lfg_ballot(sv) == 0ull) continue;
+        const unsigned long long svm = lfg_ballot(sv);                 // our seeds of this chunk, as a lane mask (see the accept loop)
+        if (svm == 0ull) continue;
         LFG_T1(c, 8)
         unsigned long long pending = ~0ull;
       for (;;) {
         mem_fence();
-        const unsigned long long fr = lfg_ballot(sv && !used_get(c, my_e)) & pending;
+        const unsigned long long fr = svm & ~lfg_ballot(used_get(c, my_e)) & pending;      // (lanes without a seed read entry 0: masked)
         if (fr == 0ull) break;
         const int sl = __builtin_ctzll(fr);
         pending = sl >= 63 ? 0ull : (~0ull << (sl + 1));
