@@ -423,7 +423,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     if (c.min_reg_size > 1) {
         const int ax = k9 - 4, ay = slot - 3;
         const bool adj = lane < 63 && ax >= -1 && ax <= 1 && ay >= -1 && ay <= 1 && (ax != 0 || ay != 0);
-        if (lfg_ballot(adj && w_e >= 0 && !used_get(c, w_e)) == 0ull) {
+        if (lfg_ballot(adj && w_e >= 0 && !used_get(c, w_e)) == 0ull) {                    // (measured: without the branch around the LDS read, + 2 %)
             reg_size = 1;
             reg_angle = NOTDEF_D;
             LFG_CNT(c, 20, 1)
@@ -554,6 +554,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 candm &= ~lfg_ballot((e >= 0) & used_get(c, e < 0 ? 0 : e));
             }
             // the undecided lane: the reference's comparison under the angle of this moment
+            // (measured: the same comparison on lane L's angle as a wave-uniform value -- readlane, scalar branches -- made the
+            // kernel 15 % slower)
             const bool hitL = ((lfg_ballot(aligned_val(a, reg_angle, prec)) & candm) >> L) & 1ull;
             if (hitL) {
                 const int eL = rl_i(e, L);
