@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <functional>
 #include "common.h"
+#include "lsd_bitplane.h"
 #include "jpeg_entropy.h"
 
 using namespace lf;
@@ -311,6 +312,12 @@ static int build_params(lf_handle* h)
     // -- a third of the scaled image (every growing wave has a region list of that size in the scratch) and below 2^16 (the
     // labels are u16).  Rounds 2 - 3 had every problem's tables in LDS, 48 KB per workgroup growing with the workload to 144 KB.
     L.label_lds = kLabelLds;
+    {
+        // images whose bit plane is larger than that anyway (1080p: 124 KB, one workgroup per CU): the LDS form for every problem
+        // that fits the same request
+        const size_t plane = bitplane_lds_words(h->Ps) * 4;
+        if (plane <= 150 * 1024 && plane / 4 > (size_t)L.label_lds) L.label_lds = (int)((plane / 4 < 65534 ? plane / 4 : 65534) & ~(size_t)1);
+    }
     L.label_items = (int)(h->Ps / 3 / 1024) * 1024;
     if (L.label_items > 64512) L.label_items = 64512;
     if (L.label_items < kLabelItems) L.label_items = kLabelItems;
