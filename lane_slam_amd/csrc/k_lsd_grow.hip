@@ -13,8 +13,12 @@ namespace lf {
 // (same-call A/B: 141.8 k -> 145.0 k frames/s; kernel alone 2.84 -> 2.89 ms; 72 / 64 VGPRs: 146 k / 145 k on a box where
 // 80 gave 146.6 k).  History: 128 natural -> 96 at three waves per problem was +2.2 %; capping the kernel at 12 waves per
 // CU instead of 16 cost 12 %.  13 KB of LDS per problem stays above the wave limit.
+// Round 4, after the bit plane (25 KB of LDS per problem: six problems per CU by LDS) and the work on the growing wave's
+// instruction stream: FIVE waves per SIMD = 96 VGPRs (38 spilled values instead of 129) = five problems per CU measures better than six
+// (same-call A/B, two pairs: lane frames 151.9 / 152.0 k -> 153.3 / 154.4 k frames/s, clutter 38.0 / 38.4 k -> 39.8 / 40.0 k, camera
+// frames equal; four waves = 128 VGPRs, no spills: 149.3 k / 36.5 k / 77 k) -- and leaves 35 KB of LDS per CU to the other kernels.
 #ifndef LFG_WAVES
-#define LFG_WAVES 6
+#define LFG_WAVES 5
 #endif
 #ifndef LFG_LDS_KB
 #define LFG_LDS_KB 13

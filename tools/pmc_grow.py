@@ -12,7 +12,7 @@ import csv, hashlib, json, os, sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_SE, N_SIMD, SLOTS_AT_80_VGPR = 32, 1024, 6144          # shader engines, SIMDs, wave slots at k_lsd_grow's 80 VGPRs (6 per SIMD)
+N_SE, N_SIMD, SLOTS_AT_80_VGPR = 32, 1024, 5120          # shader engines, SIMDs, wave slots at k_lsd_grow's 96 VGPRs (5 per SIMD since round 4; 80 / 6 before)
 
 
 def digest(*rel):
