@@ -434,8 +434,10 @@ static bool lsd_grow_bitmap_slice(const LsdParams& p, int reg_lds, bool busy, in
     const size_t Ps = (size_t)p.Hs * p.Ws;
     const size_t words = ((Ps >> 6) + 2) & ~(size_t)1;
     const size_t plane = words * 8 + (((words >> 1) + 1) >> 1) * 4;
-    // USED bits for as many entries as keep SIX problems on a CU (160 KB / 6, less 2.25 KB: 1.7 KB of static words and ring +
-    // allocation granularity): that is the kernel's wave limit (LFG_WAVES per SIMD, four waves per problem).  27.7 k entries at
+    // USED bits for as many entries as would keep SIX problems on a CU (160 KB / 6, less 2.25 KB: 1.7 KB of static words and ring +
+    // allocation granularity) -- the kernel runs five per CU since it went to 96 VGPRs (LFG_WAVES), and the sixth share is what
+    // other kernels' workgroups find free on every CU (all 32 k entries the u16 counts allow, 0.6 KB more: measured equal to
+    // slightly worse; 512 list entries per wave in LDS instead of 256: equal).  27.7 k entries at
     // 512 x 256: camera frames and the clutter frames have problems of 20 - 25 k defined pixels, and one of those in the row-list
     // code holds its batch up (16 k entries: -20 % frames/s there).  The counts are u16.
     (void)busy;
