@@ -141,8 +141,8 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     c.bits64 = bits64; c.pref = pref;
     c.deg = c_deg + (size_t)pc * Ps;
     c.mod = c_mod + (size_t)pc * Ps;
-    c.cs = c_cs + (size_t)pc * Ps;
-    c.sn = c_sn + (size_t)pc * Ps;
+    c.cs = c_cs + (size_t)pc * Ps * 2;                       // interleaved (cos, sin) pairs: lsd_grow.h cs_sn()
+    c.sn = c_sn + (size_t)pc * Ps * 2;
     c.usedc = usedc; c.gused = gu; c.used_lds = BIG ? def_lds : 0x7fffffff;
     // every wave has its own region list: reg_lds entries in LDS, the rest in its slice of the problem's scratch.
     // Problems too large for k_lsd_label's LDS (> label_items defined pixels) come as ONE component: wave 0 takes it

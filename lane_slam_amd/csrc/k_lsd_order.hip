@@ -4,7 +4,8 @@
 // Input: the problem's unordered RECORD list from k_lsd_grad (address, angle, magnitude, cos, sin of
 // every pixel whose gradient is defined; tiles append in arbitrary order).
 // Output, all in COMPACT index space e = raster rank among the problem's defined pixels:
-//   c_xy / c_deg / c_mod / c_cs / c_sn[e]   the record fields gathered in raster order
+//   c_xy / c_deg / c_mod / c_cs / c_sn[e]   the record fields gathered in raster order (c_cs, c_sn: ONE array of (cos, sin) pairs --
+//                                           c_sn = c_cs + 1, both indexed 2 e: k_lsd_grow fetches a candidate's pair with one load)
 //   row_start[y]                            first entry of every scaled-image row
 //   order[i]                                seeds, (n_bins-1-bin) << 20 | e, sorted: OpenCV lsd.cpp
 //       ll_angle (restated, see oracle/lf_oracle_lsd.c lfo_lsd_ll_angle) visits pixels by descending
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
             c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
             c_deg[o + e] = r_deg[o + ri];
             c_mod[o + e] = m;
-            c_cs[o + e] = r_cs[o + ri];
-            c_sn[o + e] = r_sn[o + ri];
+            c_cs[2 * (o + e)] = r_cs[o + ri];
+            c_sn[2 * (o + e)] = r_sn[o + ri];
             const uint32_t key = (uint32_t)((p.n_bins - 1) - (int)(m * bin_coef));
             LA[e] = (key << 20) | e;
         }
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
         c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
         c_deg[o + e] = r_deg[o + ri];
         c_mod[o + e] = m;
-        c_cs[o + e] = r_cs[o + ri];
-        c_sn[o + e] = r_sn[o + ri];
+        c_cs[2 * (o + e)] = r_cs[o + ri];
+        c_sn[2 * (o + e)] = r_sn[o + ri];
         const int bin = (int)(m * bin_coef);
         B[e] = ((uint32_t)((p.n_bins - 1) - bin) << 20) | (uint32_t)e;     // seeds carry the compact index
         // rows (y_prev, y] start at e; the first entry also covers rows 0..y
@@ -333,8 +334,8 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
             c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
             c_deg[o + e] = r_deg[o + ri];
             c_mod[o + e] = m;
-            c_cs[o + e] = r_cs[o + ri];
-            c_sn[o + e] = r_sn[o + ri];
+            c_cs[2 * (o + e)] = r_cs[o + ri];
+            c_sn[2 * (o + e)] = r_sn[o + ri];
             const int bin = (int)(m * bin_coef);
             A[e] = ((uint32_t)((p.n_bins - 1) - bin) << 20) | (uint32_t)e;
             const int yp = e == 0 ? -1 : (int)((uint32_t)(X[e - 1] >> 32) / (uint32_t)p.Ws);
@@ -361,8 +362,8 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
         c_xy[o + e] = ((uint32_t)y << 16) | (uint32_t)x;
         c_deg[o + e] = r_deg[o + i];
         c_mod[o + e] = m;
-        c_cs[o + e] = r_cs[o + i];
-        c_sn[o + e] = r_sn[o + i];
+        c_cs[2 * (o + e)] = r_cs[o + i];
+        c_sn[2 * (o + e)] = r_sn[o + i];
         B[e] = ((uint32_t)((p.n_bins - 1) - (int)(m * bin_coef)) << 20) | e;
     }
     for (int y = t; y <= p.Hs; y += OT) RS[y] = (int)bitplane_rank(dyn_lds, Ps, y * p.Ws);

@@ -452,7 +452,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_sort_a, nprob * Ps) || dalloc(h, &h->d_sort_b, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
         dalloc(h, &h->d_order_a, nprob * Ps) ||
         dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
-        dalloc(h, &h->d_ccs, nprob * Ps) || dalloc(h, &h->d_csn, nprob * Ps) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(h->lsd)) ||
+        dalloc(h, &h->d_ccs, nprob * Ps * 2) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(h->lsd)) ||
         dalloc(h, &h->d_clabel, nprob * Ps) || dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) || dalloc(h, &h->d_perm, nprob) || dalloc(h, &h->d_comp_key, nprob) ||
         dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) ||
         dalloc(h, &h->d_pend_rec, nprob * (size_t)lsd_grow_pend_cap(h->lsd) * 12 + 2) || dalloc(h, &h->d_pend_tag, nprob * (size_t)lsd_grow_pend_cap(h->lsd) + 1) || dalloc(h, &h->d_pend_count, nprob) || dalloc(h, &h->d_norder, nprob) ||
@@ -461,6 +461,7 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
+    h->d_csn = h->d_ccs + 1;          // (cos, sin) pairs in one array: k_lsd_order.hip
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32 &&
         (dalloc(h, &h->d_laddr, nprob * Ps) || dalloc(h, &h->d_lmod, nprob * Ps)))
         return LF_ERR_HIP;
@@ -513,7 +514,7 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_gray, h->dbg_masks.p, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
-                     h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_zero, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_gused, h->d_row_start, h->d_tile_list,
+                     h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_zero, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_gused, h->d_row_start, h->d_tile_list,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_slot_lines,
                      h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,

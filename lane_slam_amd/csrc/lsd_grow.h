@@ -190,8 +190,8 @@ struct Ctx {
     const uint16_t* pref;               // LDS  [H * W / 128 + 1] defined pixels in front of a PAIR of words = the compact index of its first one
     const float* deg;         // HBM  level-line angle, degrees (OpenCV fastAtan2 output)
     const double* mod;        // HBM  gradient magnitude
-    const double* cs;         // HBM  cos((double)(float)angle_rad)
-    const double* sn;
+    const double* cs;         // HBM  cos((double)(float)angle_rad) -- device build: INTERLEAVED with sn, entry e at cs[2 e], cs[2 e + 1]
+    const double* sn;         //      (one 16-byte load per candidate and one cache line instead of two; cs_sn() below)
     uint32_t* usedc;          // LDS  USED bit per entry e < used_lds
     uint32_t* gused;          // HBM  USED bits of the remaining entries
     int used_lds;
@@ -240,6 +240,16 @@ template <bool LO> LFG_DEV void reg_put_t(const Ctx& c, int i, uint32_t v)      
     else if (i < c.reg_lds) c.lreg[i] = v; else c.greg[i] = v;
 }
 #endif
+// cosine and sine of entry e's level-line angle
+LFG_DEV void cs_sn(const Ctx& c, int e, double& ck, double& sk)
+{
+#ifndef LF_HOST_SIM
+    const double2 v = *reinterpret_cast<const double2*>(c.cs + 2 * (size_t)e);
+    ck = v.x; sk = v.y;
+#else
+    ck = c.cs[e]; sk = c.sn[e];
+#endif
+}
 LFG_DEV int xs_get(const Ctx& c, int e) { return e < c.def_lds ? (int)c.lxs[e] : (int)(c.gxy[e] & 0xffffu); }
 
 // BITMAP form (round 4; k_lsd_grow.hip chooses it on busy content): a compact index is a RANK -- the number of defined pixels in
@@ -431,7 +441,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         }
     }
     reg_angle = angle_of(c.deg[seed_e]);
-    if (w_e >= 0) { w_deg = c.deg[w_e]; w_cs = c.cs[w_e]; w_sn = c.sn[w_e]; }
+    if (w_e >= 0) { w_deg = c.deg[w_e]; cs_sn(c, w_e, w_cs, w_sn); }
     const SinCos sc0 = sincos_eval(reg_angle);
     float sumdx = (float)sc0.c, sumdy = (float)sc0.s;
     LFG_T1(c, 16)
@@ -459,7 +469,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         LFG_CNT(c, 15, lfg_ballot(inb && !inwin) != 0ull)
         if (!inwin) {
             e = inb ? find_e(c, xx, yy) : -1;
-            if (e >= 0) { dg = c.deg[e]; ck = c.cs[e]; sk = c.sn[e]; }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
+            if (e >= 0) { dg = c.deg[e]; cs_sn(c, e, ck, sk); }      // fetched whether USED or not: the USED test below is an LDS round trip that need not sit in front of the trip to the compact arrays
         }
         // the candidates -- defined and free at batch start -- as a LANE MASK (wave-uniform integers from here on: a per-lane bool
         // that survives a branch comes back through a 0 / 1 register and a compare every time it is balloted, three instructions
