@@ -250,6 +250,8 @@ LFG_DEV void cs_sn(const Ctx& c, int e, double& ck, double& sk)
     ck = c.cs[e]; sk = c.sn[e];
 #endif
 }
+// (the angle in the same record as well -- 32 bytes per entry: cos, sin, angle, padding -- measured slower: kernel alone 1.90 -> 1.99
+// ms, camera frames - 1.7 %; neighbouring entries of a row then share a cache line half as often)
 LFG_DEV int xs_get(const Ctx& c, int e) { return e < c.def_lds ? (int)c.lxs[e] : (int)(c.gxy[e] & 0xffffu); }
 
 // BITMAP form (round 4; k_lsd_grow.hip chooses it on busy content): a compact index is a RANK -- the number of defined pixels in
