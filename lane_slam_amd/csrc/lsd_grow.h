@@ -391,7 +391,7 @@ LFG_DEV bool double_equal(double a, double b)
 
 // ------------------------------------------------------------------ region_grow
 // seed_e: compact entry of the seed pixel (sx, sy)
-LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size, double& reg_angle, double prec)
+LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size, double& reg_angle, double prec, float pre_deg = -4096.f)
 {
     const int W = c.W, H = c.H;
     const int lane = lane_id();
@@ -442,9 +442,20 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             return;
         }
     }
-    reg_angle = angle_of(c.deg[seed_e]);
-    if (w_e >= 0) { w_deg = c.deg[w_e]; cs_sn(c, w_e, w_cs, w_sn); }
-    const SinCos sc0 = sincos_eval(reg_angle);
+    // The seed's own angle comes with the seed list when detect() has it (pre_deg: fetched per chunk, beside the seeds' coordinates):
+    // its sine and cosine are then worked out INLINE while the window's angles are on their way -- through the out-of-line routine the
+    // call would first wait for every load in flight, and with the angle from the compact array there was a round trip in front of it
+    const bool pre = __builtin_amdgcn_readfirstlane((int)(pre_deg != -4096.f)) != 0;
+    SinCos sc0;
+    if (pre) {
+        reg_angle = angle_of(pre_deg);
+        if (w_e >= 0) { w_deg = c.deg[w_e]; cs_sn(c, w_e, w_cs, w_sn); }
+        dm::dsincos(reg_angle, sc0.s, sc0.c);
+    } else {
+        reg_angle = angle_of(c.deg[seed_e]);
+        if (w_e >= 0) { w_deg = c.deg[w_e]; cs_sn(c, w_e, w_cs, w_sn); }
+        sc0 = sincos_eval(reg_angle);
+    }
     float sumdx = (float)sc0.c, sumdy = (float)sc0.s;
     LFG_T1(c, 16)
     const float precf = (float)prec;
@@ -1414,6 +1425,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         const uint32_t seed_items = sv ? order[base + lane_id()] : 0u;
         const int my_e = (int)(seed_items & 0xfffffu);
         const uint32_t seed_xy = sv ? c.gxy[my_e] : 0u;               // beside the label, not behind it: one round trip per chunk less
+        const float seed_dg = sv ? c.deg[my_e] : 0.f;                  // ... and the seed's angle (region_grow: pre_deg)
         if (sv && c.label) sv = (int)c.label[my_e] == c.root;          // seeds of other components are not ours
         const unsigned long long svm = lfg_ballot(sv);                 // our seeds of this chunk, as a lane mask (see the accept loop)
         if (svm == 0ull) continue;
@@ -1427,6 +1439,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         pending = sl >= 63 ? 0ull : (~0ull << (sl + 1));
         const int se = rl_i(my_e, sl);
         const uint32_t sxy = (uint32_t)rl_i((int)seed_xy, sl);
+        const float sdg = rl_f(seed_dg, sl);
         const int tag = base + sl;
         LFG_T1(c, 0)
 #else
@@ -1449,7 +1462,11 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         bool rejected = false;
         for (;;) {
             if (phase < 2) {
+#ifndef LF_HOST_SIM
+                region_grow(c, gx, gy, ge, reg_size, reg_angle, grow_prec, phase == 0 ? sdg : -4096.f);
+#else
                 region_grow(c, gx, gy, ge, reg_size, reg_angle, grow_prec);
+#endif
                 if (phase == 0) { LFG_T1(c, 1) LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size) } else { LFG_T1(c, 22) }
                 if (reg_size < (phase == 0 ? c.min_reg_size : 2)) { rejected = true; break; }
             }
