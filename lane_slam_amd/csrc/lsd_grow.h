@@ -432,10 +432,13 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     // already used.  Their region is the seed alone whatever the angles are, and (for min_reg_size > 1) it is thrown
     // away -- so it is recognised here from the row lists and the USED bits in LDS, before anything is fetched from
     // the compact arrays and before the seed's sine / cosine are worked out.
-    if (c.min_reg_size > 1) {
+    // (the same mask is the candidate mask of the region's FIRST batch: the seed's eight neighbours, in the window's own lanes)
+    unsigned long long firstm;
+    {
         const int ax = k9 - 4, ay = slot - 3;
         const bool adj = lane < 63 && ax >= -1 && ax <= 1 && ay >= -1 && ay <= 1 && (ax != 0 || ay != 0);
-        if (lfg_ballot(adj && w_e >= 0 && !used_get(c, w_e)) == 0ull) {                    // (measured: without the branch around the LDS read, + 2 %)
+        firstm = lfg_ballot(adj && w_e >= 0 && !used_get(c, w_e));                          // (measured: without the branch around the LDS read, + 2 %)
+        if (c.min_reg_size > 1 && firstm == 0ull) {
             reg_size = 1;
             reg_angle = NOTDEF_D;
             LFG_CNT(c, 20, 1)
@@ -464,20 +467,33 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     const float tn_cone = 0.5f * (precf - EPSF), tf_cone = precf + 0.5f * (precf - EPSF) + EPSF;
     for (int i = 0; i < n;) {
       // one batch; LO: every list index it touches (i .. n + 63) is in the LDS part of the list -- nearly always (see reg_get_t)
-      auto batch = [&](auto lo_tag) {
+      auto batch = [&](auto lo_tag, auto first_tag) {
         constexpr bool LO = decltype(lo_tag)::value;
-        const int m = n - i < 7 ? n - i : 7;
+        // FIRST: the region's first batch -- one frontier point, the seed, whose eight neighbours ARE window lanes (lane = 9 * row +
+        // column: ascending lane order is their raster order, the reference's visiting order) and whose candidate mask the
+        // isolated-seed test has just worked out: no list read, no shuffles, no second look at the USED bits
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int m, e, xx, yy;
+        float dg;
+        double ck, sk;
+        unsigned long long candm;
+        if constexpr (FIRST) {
+            m = 1; e = w_e; dg = w_deg; ck = w_cs; sk = w_sn;
+            xx = wx0 + k9; yy = wy0 + slot;
+            candm = firstm;
+        } else {
+        m = n - i < 7 ? n - i : 7;
         const bool lv = slot < m;
         const uint32_t pkl = lv ? reg_get_t<LO>(c, i + slot) : 0u;
         const int pxl = (int)(pkl & 0xffffu), pyl = (int)(pkl >> 16);
-        const int xx = pxl + ddx, yy = pyl + ddy;
+        xx = pxl + ddx; yy = pyl + ddy;
         const bool inb = lv && xx >= 0 && xx < W && yy >= 0 && yy < H;
         const int rx = xx - wx0, ry = yy - wy0;
         const bool inwin = lv && rx >= 0 && rx < 9 && ry >= 0 && ry < 7;
         const int widx = inwin ? ry * 9 + rx : 0;
-        int e = __shfl(w_e, widx);
-        float dg = __shfl(w_deg, widx);
-        double ck = __shfl(w_cs, widx), sk = __shfl(w_sn, widx);
+        e = __shfl(w_e, widx);
+        dg = __shfl(w_deg, widx);
+        ck = __shfl(w_cs, widx); sk = __shfl(w_sn, widx);
         LFG_T1(c, 12)
         LFG_CNT(c, 15, lfg_ballot(inb && !inwin) != 0ull)
         if (!inwin) {
@@ -487,7 +503,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         // the candidates -- defined and free at batch start -- as a LANE MASK (wave-uniform integers from here on: a per-lane bool
         // that survives a branch comes back through a 0 / 1 register and a compare every time it is balloted, three instructions
         // and a vector -> scalar dependency, eight times per span)
-        unsigned long long candm = lfg_ballot((e >= 0) & !used_get(c, e < 0 ? 0 : e));      // (no branch around the LDS read)
+        candm = lfg_ballot((e >= 0) & !used_get(c, e < 0 ? 0 : e));      // (no branch around the LDS read)
+        }
         const double a = (double)dg * DEG2RAD;
         LFG_T1(c, 13)
         // The reference tests the candidates one by one, in lane order, each against the running region angle,
@@ -600,7 +617,9 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
         LFG_CNT(c, 11, 1)
         i += m;
       };
-      if (n + 64 <= c.reg_lds) batch(std::true_type{}); else batch(std::false_type{});
+      if (i == 0 && 65 <= c.reg_lds) batch(std::true_type{}, std::true_type{});
+      else if (n + 64 <= c.reg_lds) batch(std::true_type{}, std::false_type{});
+      else batch(std::false_type{}, std::false_type{});
     }
 #else
     for (int i = 0; i < n; ++i) {
