@@ -396,7 +396,14 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     const int W = c.W, H = c.H;
     const int lane = lane_id();
     int n = 1;
+#ifndef LF_HOST_SIM
+    if (lane == 0) {                                          // (entry 0 is in the LDS part whenever there is one: a plain LDS store, see reg_get_t)
+        if (c.reg_lds > 0) reg_put_t<true>(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
+        else c.greg[0] = ((uint32_t)sy << 16) | (uint32_t)sx;
+    }
+#else
     reg_set(c, 0, ((uint32_t)sy << 16) | (uint32_t)sx);
+#endif
     used_set(c, seed_e);
 #ifdef LF_HOST_SIM
     reg_angle = angle_of(c.deg[seed_e]);
