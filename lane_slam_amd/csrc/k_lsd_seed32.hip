@@ -53,11 +53,26 @@ namespace lf {
 #define SEED_T(v) do { } while (0)
 #endif
 
-constexpr int ST = 1024;             // threads: 16 waves
+// Workgroup shape (round 4, end): 256 threads, four waves in phase 2, LDS blocks of 4096 elements.  The first form ran 1024 threads
+// with 64 KB of LDS per problem: sixteen waves on one CU and that much LDS only come free together when a CU drains, and the
+// kernel queued behind other batches' region growing -- smaller is faster even ALONE (the
+// partitions are chains of dependent round trips, not throughput), same-call sweep, frames/s with lsd.seed_order = opencv32 at
+// 640x480 / 160x120:   1024 thr, 8 waves, 8192: 65.8 k / 198 k      512, 8, 8192: 77.4 k / 238 k      256, 4, 4096: 74 k / 257 k
+//                       256, 4, 2048: 72 k / 259 k      128, 2, 2048: 56 k / 271 k.   Every shape passes tests/test_gpu_seed_order.py.
+#ifndef LF_SEED_THREADS
+#define LF_SEED_THREADS 256
+#endif
+#ifndef LF_SEED_WAVES2
+#define LF_SEED_WAVES2 4
+#endif
+#ifndef LF_SEED_BLOCK
+#define LF_SEED_BLOCK 4096
+#endif
+constexpr int ST = LF_SEED_THREADS;  // threads
 constexpr int SW = ST / 64;
-constexpr int SW2 = 8;               // waves that work in phase 2 (each with a private LDS range)
+constexpr int SW2 = LF_SEED_WAVES2;  // waves that work in phase 2 (each with a private LDS range)
 constexpr int kSmall = 1024;         // ranges up to this size are one wave's work, in LDS (16 rows)
-constexpr int kBlock = 8192;         // ranges up to this size are copied into LDS and partitioned there by the whole workgroup
+constexpr int kBlock = LF_SEED_BLOCK; // ranges up to this size are copied into LDS and partitioned there by the whole workgroup
 constexpr int kSortThreshold = 16;   // libstdc++ _S_threshold
 constexpr int kMaxLdsBytes = 150 * 1024;
 constexpr int SNB = 16;              // buckets of the final counting passes
