@@ -708,7 +708,13 @@ __device__ __forceinline__ void ed_solve(const EdFit& f, double& e0, double& e1)
     e1 = coef * ((double)A[0] * (double)f.ATV[1] - (double)A[2] * (double)f.ATV[0]);
 }
 
-constexpr int ED_THREADS = 512, ED_WAVES = ED_THREADS / 64;
+// 256 threads: one walking wave and three fitting ones (512 until the end of round 4: eight waves of one frame on one CU; four let
+// twice as many frames share the device -- three octaves 0.714 -> 0.640 ms, pipelined KeyLines 204 k -> 242 k frames/s, the EDLines
+// detector in the batch path 362 k -> 417 k; 128 / 192 / 1024 threads: 236 k / 240 k / 150 k)
+#ifndef LF_ED_THREADS
+#define LF_ED_THREADS 256
+#endif
+constexpr int ED_THREADS = LF_ED_THREADS, ED_WAVES = ED_THREADS / 64;
 
 // the line records the fitting waves produce, in the order they finish them: per frame [max_lines] of each field
 struct EdTemp {
