@@ -84,16 +84,18 @@ __global__ void k_map_pack_block(int n, int n_frames, const int* __restrict__ fr
     row[74] = row[75] = row[76] = row[77] = row[78] = row[79] = 0;
 }
 
-// ---- update, step 1 of 3: classification.  1024 rows per workgroup, any number of workgroups (an 8-rank step is
-// 8 x 16 Ki rows): every row becomes "refresh entry t", "append, rank r among this workgroup's appends" or nothing;
+// ---- update, step 1 of 3: classification.  kMapWg = 256 rows per workgroup (1024 until the end of round 4: a sixteen-wave
+// workgroup waits for a CU with sixteen free wave slots, and next to other batches' region growing there is none -- map_update
+// 0.016 ms alone, 0.39 ms in the pipeline), any number of workgroups (an 8-rank step is 8 x 16 Ki rows): every row becomes "refresh entry t", "append, rank r among this workgroup's appends" or nothing;
 // refresh winners are elected (atomicMax) and hits counted here, the appends of each workgroup are counted for the
 // scan in k_map_plan.  A block with a bad header, or one that carries the OVERFLOW marker (its rank had more
 // segments than a block holds and sent only the header, lf_map_pack_block), makes EVERY workgroup skip the whole
 // update: all replicas see the same blocks, so all of them skip the same step.
-__global__ __launch_bounds__(1024) void k_map_classify(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int block_rows,
+constexpr int kMapWg = 256;
+__global__ __launch_bounds__(kMapWg) void k_map_classify(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int block_rows,
                                                        int force_append, int* __restrict__ act, int* __restrict__ wg_count)
 {
-    __shared__ int wave_count[16];
+    __shared__ int wave_count[kMapWg / 64];
     __shared__ int bad_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int G = block_rows - 1;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(1024) void k_map_classify(MapDev m, const uint8_t* 
     const int size0 = m.state[0];
     if (tid == 0) bad_sh = 0;
     __syncthreads();
-    for (int b = tid; b < n_blocks; b += 1024) {
+    for (int b = tid; b < n_blocks; b += kMapWg) {
         const uint32_t* hd = reinterpret_cast<const uint32_t*>(blocks + (size_t)b * block_rows * kRow);
         int f = 0;
         if (hd[0] != kMagic || hd[1] > (uint32_t)G) f |= 2;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(1024) void k_map_classify(MapDev m, const uint8_t* 
     }
     __syncthreads();
     const int bad = bad_sh;
-    const int s = blockIdx.x * 1024 + tid;
+    const int s = blockIdx.x * kMapWg + tid;
     bool is_app = false, is_ref = false;
     int target = -1;
     if (!bad && s < total) {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(1024) void k_map_classify(MapDev m, const uint8_t* 
     const unsigned long long rbal = __ballot(is_ref);
     __syncthreads();
     int off = 0, all = 0;
-    for (int w = 0; w < 16; ++w) { const int c = wave_count[w]; if (w < wave) off += c; all += c; }
+    for (int w = 0; w < kMapWg / 64; ++w) { const int c = wave_count[w]; if (w < wave) off += c; all += c; }
     if (s < total) act[s] = is_ref ? (target | kRefFlag) : (is_app ? off + before : -1);
     if (is_ref) {
         atomicMax(&m.winner[target], s);
@@ -149,15 +151,15 @@ __global__ __launch_bounds__(1024) void k_map_classify(MapDev m, const uint8_t* 
 
 // ---- step 2 of 3: one workgroup scans the workgroups' append counts (wg_count -> exclusive bases, in place) and
 // advances the map's state
-__global__ __launch_bounds__(1024) void k_map_plan(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int n_wg,
+__global__ __launch_bounds__(kMapWg) void k_map_plan(MapDev m, const uint8_t* __restrict__ blocks, int n_blocks, int n_wg,
                                                    int* __restrict__ wg_count)
 {
-    __shared__ int wave_sum[16];
+    __shared__ int wave_sum[kMapWg / 64];
     __shared__ int carry_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry_sh = 0;
     __syncthreads();
-    for (int start = 0; start < n_wg; start += 1024) {
+    for (int start = 0; start < n_wg; start += kMapWg) {
         const int i = start + tid;
         const int v = i < n_wg ? wg_count[i] : 0;
         int incl = v;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_map_plan(MapDev m, const uint8_t* __re
         for (int w = 0; w < wave; ++w) off += wave_sum[w];
         if (i < n_wg) wg_count[i] = off + incl - v;
         __syncthreads();
-        if (tid == 1023) carry_sh = off + incl;
+        if (tid == kMapWg - 1) carry_sh = off + incl;
         __syncthreads();
     }
     if (tid == 0) {
@@ -212,7 +214,7 @@ __global__ void k_map_apply(MapDev m, const uint8_t* __restrict__ blocks, int n_
     if ((size_t)s >= total) return;
     int a = act[s];
     if (a == -1) return;
-    if (!(a & kRefFlag)) a += wg_base[s >> 10];
+    if (!(a & kRefFlag)) a += wg_base[s / kMapWg];
     const int n_app = m.state[3], head0 = m.state[5], size0 = m.state[6], step = m.state[7];
     const int cap = m.capacity;
     int pos;
@@ -344,11 +346,11 @@ void launch_map_update(const MapDevice& md, const uint8_t* blocks, int n_blocks,
     m.winner = md.winner; m.mx = md.mx; m.mcx = md.mcx; m.state = md.state; m.totals = md.totals;
     // act: [rows] actions, then [n_wg] append counts / bases of the classification workgroups
     const size_t rows = (size_t)n_blocks * (block_rows - 1);
-    const int n_wg = (int)((rows + 1023) / 1024);
+    const int n_wg = (int)((rows + kMapWg - 1) / kMapWg);
     int* wg_count = act + rows;
     if (n_wg)
-        hipLaunchKernelGGL(k_map_classify, dim3(n_wg), dim3(1024), 0, s, m, blocks, n_blocks, block_rows, force_append, act, wg_count);
-    hipLaunchKernelGGL(k_map_plan, dim3(1), dim3(1024), 0, s, m, blocks, n_blocks, n_wg, wg_count);
+        hipLaunchKernelGGL(k_map_classify, dim3(n_wg), dim3(kMapWg), 0, s, m, blocks, n_blocks, block_rows, force_append, act, wg_count);
+    hipLaunchKernelGGL(k_map_plan, dim3(1), dim3(kMapWg), 0, s, m, blocks, n_blocks, n_wg, wg_count);
     const size_t threads = rows * 32;
     if (threads)
         hipLaunchKernelGGL(k_map_apply, dim3((threads + 255) / 256), dim3(256), 0, s, m, blocks, n_blocks, block_rows, act, wg_count);

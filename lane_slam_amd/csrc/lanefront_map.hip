@@ -291,7 +291,7 @@ static int update_blocks(lf_map* m, const uint8_t* blocks, int n_blocks, int blo
     int rc;
     const size_t rows = (size_t)n_blocks * (size_t)(block_rows - 1);
     if (rows >= (1u << 30)) { map_error(m, "lf_map_update: too many rows"); return LF_ERR_CAPACITY; }
-    if ((rc = grow(m, m->act, (rows + rows / 1024 + 2) * sizeof(int))) != LF_OK) return rc;      // actions + per-workgroup append counts
+    if ((rc = grow(m, m->act, (rows + rows / 256 + 2) * sizeof(int))) != LF_OK) return rc;      // actions + per-workgroup append counts (k_map.hip: kMapWg = 256 rows each)
     {
         MapTimer t(m, 3);
         launch_map_update(m->d, blocks, n_blocks, block_rows, force_append, static_cast<int*>(m->act.p), m->stream);
