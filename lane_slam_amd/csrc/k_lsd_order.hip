@@ -30,15 +30,20 @@ namespace lf {
 using std::max;
 using std::min;
 
-// four waves per workgroup for the ordering and the labelling too (512 threads until the end of round 4): camera frames 84.4 k -> 85.7 -
-// 87.1 k frames/s, clutter 44.8 k -> 45.5 k, lane frames equal (same-call A/B)
+// four waves per workgroup for the bit-plane ordering (OBT) and the labelling (LT) (512 threads until the end of round 4): camera frames
+// 84.4 k -> 85.7 - 87.1 k frames/s, clutter 44.8 k -> 45.5 k, lane frames equal (same-call A/B).  The sorting kernel of rounds 1 - 3 (OT),
+// which the 1080p geometries still use, keeps 512: with 256 it was 35 % slower on their larger problems.
 #ifndef LF_ORDER_THREADS
-#define LF_ORDER_THREADS 256
+#define LF_ORDER_THREADS 512
+#endif
+#ifndef LF_ORDER_BM_THREADS
+#define LF_ORDER_BM_THREADS 256
 #endif
 #ifndef LF_LABEL_THREADS
 #define LF_LABEL_THREADS 256
 #endif
-constexpr int OT = LF_ORDER_THREADS;          // threads
+constexpr int OT = LF_ORDER_THREADS;          // threads of k_lsd_order
+constexpr int OBT = LF_ORDER_BM_THREADS;      // threads of k_lsd_order_bm
 constexpr int NB = 16;           // buckets per pass of k_lsd_order (4-bit digits; [16][512] u32 = 32 KB LDS)
 constexpr int LDS_ITEMS = 8192;  // problems up to this many defined pixels are ordered entirely in LDS (2 x 32 KB, dynamic)
 
@@ -52,25 +57,25 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
-template <typename T, int NB = 16>
+template <typename T, int NB = 16, int NT = OT>
 __device__ __forceinline__ void radix_pass(const T* __restrict__ src, T* __restrict__ dst, int n, int shift,
-                           uint32_t* cnt /*[NB][OT]*/, int* tot /*[NB]*/, int* base /*[NB]*/)
+                           uint32_t* cnt /*[NB][NT]*/, int* tot /*[NB]*/, int* base /*[NB]*/)
 {
-    static_assert(NB % (OT / 64) == 0, "every wave scans NB / waves bucket rows");
+    static_assert(NB % (NT / 64) == 0, "every wave scans NB / waves bucket rows");
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int seg = (n + OT - 1) / OT;
+    const int seg = (n + NT - 1) / NT;
     const int i0 = min(n, t * seg), i1 = min(n, i0 + seg);
-    for (int b = 0; b < NB; ++b) cnt[b * OT + t] = 0;
-    for (int i = i0; i < i1; ++i) cnt[(int)((src[i] >> shift) & (NB - 1)) * OT + t]++;
+    for (int b = 0; b < NB; ++b) cnt[b * NT + t] = 0;
+    for (int i = i0; i < i1; ++i) cnt[(int)((src[i] >> shift) & (NB - 1)) * NT + t]++;
     __syncthreads();
     // wave `wave` scans bucket rows wave*2, wave*2+1 (8 waves x 2 = 16 rows)
-    for (int bb = 0; bb < NB / (OT / 64); ++bb) {
-        const int b = wave * (NB / (OT / 64)) + bb;
+    for (int bb = 0; bb < NB / (NT / 64); ++bb) {
+        const int b = wave * (NB / (NT / 64)) + bb;
         int carry = 0;
-        for (int c = 0; c < OT / 64; ++c) {
-            int v = (int)cnt[b * OT + c * 64 + lane];
+        for (int c = 0; c < NT / 64; ++c) {
+            int v = (int)cnt[b * NT + c * 64 + lane];
             int inc = wave_incl_scan(v, lane);
-            cnt[b * OT + c * 64 + lane] = (uint32_t)(carry + inc - v);
+            cnt[b * NT + c * 64 + lane] = (uint32_t)(carry + inc - v);
             carry += __shfl(inc, 63);
         }
         if (lane == 0) tot[b] = carry;
@@ -85,7 +90,7 @@ __device__ __forceinline__ void radix_pass(const T* __restrict__ src, T* __restr
     for (int i = i0; i < i1; ++i) {
         const T it = src[i];
         int b = (int)((it >> shift) & (NB - 1));
-        uint32_t pos = (uint32_t)base[b] + cnt[b * OT + t]++;
+        uint32_t pos = (uint32_t)base[b] + cnt[b * NT + t]++;
         dst[pos] = it;
     }
     __syncthreads();
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
 // records) no longer takes 0.8 ms.  Problems it cannot take (more than 65 535 records: u16 counters) sort in HBM as before, with
 // 8-bucket passes whose counter matrix fits the same LDS.
 constexpr int OB_BINS = 1024;
-__global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t* __restrict__ r_addr,
+__global__ __launch_bounds__(OBT) void k_lsd_order_bm(LsdParams p, const uint32_t* __restrict__ r_addr,
                                                      const float* __restrict__ r_deg, const double* __restrict__ r_mod,
                                                      const double* __restrict__ r_cs, const double* __restrict__ r_sn,
                                                      const int* __restrict__ n_rec,
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ int tot[8];
     __shared__ int base[8];
-    __shared__ int wave_tot[OT / 64];
+    __shared__ int wave_tot[OBT / 64];
     __shared__ uint32_t bin_base[OB_BINS];
     const int pc = blockIdx.x;
     const size_t Ps = (size_t)p.Hs * p.Ws;
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
     int* RS = row_start + (size_t)pc * (p.Hs + 1);
     if (t == 0) norder[pc] = n;
     if (n == 0) {
-        for (int y = t; y <= p.Hs; y += OT) RS[y] = 0;
+        for (int y = t; y <= p.Hs; y += OBT) RS[y] = 0;
         return;
     }
     const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
@@ -329,12 +334,12 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
         // ---- the items in HBM, 3-bit digits ([8][512] u32 = 16 KB of counters): raster order by address, then the seeds by bin
         unsigned long long* X = sort_a + o;
         unsigned long long* Y = sort_b + o;
-        for (int i = t; i < n; i += OT) X[i] = ((unsigned long long)r_addr[o + i] << 32) | (unsigned int)i;
+        for (int i = t; i < n; i += OBT) X[i] = ((unsigned long long)r_addr[o + i] << 32) | (unsigned int)i;
         __syncthreads();
         for (int k = 0; k < 8; ++k) {                       // 24 address bits
-            radix_pass<unsigned long long, 8>(k & 1 ? Y : X, k & 1 ? X : Y, n, 32 + 3 * k, dyn_lds, tot, base);
+            radix_pass<unsigned long long, 8, OBT>(k & 1 ? Y : X, k & 1 ? X : Y, n, 32 + 3 * k, dyn_lds, tot, base);
         }
-        for (int e = t; e < n; e += OT) {                   // sorted by address in X
+        for (int e = t; e < n; e += OBT) {                   // sorted by address in X
             const unsigned long long it = X[e];
             const uint32_t addr = (uint32_t)(it >> 32), ri = (uint32_t)it;
             const int y = (int)(addr / (uint32_t)p.Ws), x = (int)(addr - (uint32_t)y * (uint32_t)p.Ws);
@@ -352,17 +357,17 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
                 for (int yy = y + 1; yy <= p.Hs; ++yy) RS[yy] = n;
         }
         __syncthreads();
-        radix_pass<uint32_t, 8>(A, B, n, 20, dyn_lds, tot, base);
-        radix_pass<uint32_t, 8>(B, A, n, 23, dyn_lds, tot, base);
-        radix_pass<uint32_t, 8>(A, B, n, 26, dyn_lds, tot, base);
-        radix_pass<uint32_t, 8>(B, A, n, 29, dyn_lds, tot, base);             // 12 key bits; the sorted list ends in order_a
+        radix_pass<uint32_t, 8, OBT>(A, B, n, 20, dyn_lds, tot, base);
+        radix_pass<uint32_t, 8, OBT>(B, A, n, 23, dyn_lds, tot, base);
+        radix_pass<uint32_t, 8, OBT>(A, B, n, 26, dyn_lds, tot, base);
+        radix_pass<uint32_t, 8, OBT>(B, A, n, 29, dyn_lds, tot, base);             // 12 key bits; the sorted list ends in order_a
         return;
     }
     // (A) the plane
-    bitplane_build<OT, false>(dyn_lds, r_addr + o, n, p.Ws, Ps, wave_tot);
+    bitplane_build<OBT, false>(dyn_lds, r_addr + o, n, p.Ws, Ps, wave_tot);
     __syncthreads();
     // (B) records to their places; seed items in raster order into B
-    for (int i = t; i < n; i += OT) {
+    for (int i = t; i < n; i += OBT) {
         const uint32_t addr = r_addr[o + i];
         const uint32_t e = bitplane_rank(dyn_lds, Ps, (int)addr);
         const int y = (int)(addr / (uint32_t)p.Ws), x = (int)(addr - (uint32_t)y * (uint32_t)p.Ws);
@@ -374,13 +379,13 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
         c_sn[2 * (o + e)] = r_sn[o + i];
         B[e] = ((uint32_t)((p.n_bins - 1) - (int)(m * bin_coef)) << 20) | e;
     }
-    for (int y = t; y <= p.Hs; y += OT) RS[y] = (int)bitplane_rank(dyn_lds, Ps, y * p.Ws);
+    for (int y = t; y <= p.Hs; y += OBT) RS[y] = (int)bitplane_rank(dyn_lds, Ps, y * p.Ws);
     __syncthreads();                                         // B complete (and visible: same workgroup, barrier), the plane free
     // (C) stable counting pass over the bin key
-    uint16_t* wcnt = reinterpret_cast<uint16_t*>(dyn_lds);   // [OT / 64][OB_BINS]
-    for (int i = t; i < (OT / 64) * OB_BINS / 2; i += OT) dyn_lds[i] = 0u;
+    uint16_t* wcnt = reinterpret_cast<uint16_t*>(dyn_lds);   // [OBT / 64][OB_BINS]
+    for (int i = t; i < (OBT / 64) * OB_BINS / 2; i += OBT) dyn_lds[i] = 0u;
     __syncthreads();
-    const int C = ((n + OT / 64 - 1) / (OT / 64) + 63) & ~63;       // whole 64-item steps per wave
+    const int C = ((n + OBT / 64 - 1) / (OBT / 64) + 63) & ~63;       // whole 64-item steps per wave
     const int start = w * C, end = min(n, start + C);
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint16_t* mine = wcnt + w * OB_BINS;
@@ -408,9 +413,9 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
     walk(false);
     __syncthreads();
     // counts -> start positions: bins ascending, waves ascending inside a bin
-    for (int d = t; d < OB_BINS; d += OT) {
+    for (int d = t; d < OB_BINS; d += OBT) {
         uint32_t s_ = 0;
-        for (int k = 0; k < OT / 64; ++k) s_ += wcnt[k * OB_BINS + d];
+        for (int k = 0; k < OBT / 64; ++k) s_ += wcnt[k * OB_BINS + d];
         bin_base[d] = s_;
     }
     __syncthreads();
@@ -424,9 +429,9 @@ __global__ __launch_bounds__(OT) void k_lsd_order_bm(LsdParams p, const uint32_t
         }
     }
     __syncthreads();
-    for (int d = t; d < OB_BINS; d += OT) {
+    for (int d = t; d < OB_BINS; d += OBT) {
         uint32_t run = bin_base[d];
-        for (int k = 0; k < OT / 64; ++k) { const uint32_t c_ = wcnt[k * OB_BINS + d]; wcnt[k * OB_BINS + d] = (uint16_t)run; run += c_; }
+        for (int k = 0; k < OBT / 64; ++k) { const uint32_t c_ = wcnt[k * OB_BINS + d]; wcnt[k * OB_BINS + d] = (uint16_t)run; run += c_; }
     }
     __syncthreads();
     walk(true);
@@ -444,10 +449,10 @@ void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, 
     static const int force_hbm = getenv("LF_ORDER_HBM") ? 1 : 0;
     const size_t Ps = (size_t)p.Hs * p.Ws;
     size_t blds = bitplane_lds_words(Ps) * 4;
-    if (blds < (size_t)(OT / 64) * OB_BINS * 2) blds = (size_t)(OT / 64) * OB_BINS * 2;
-    if (blds < (size_t)8 * OT * 4) blds = (size_t)8 * OT * 4;
+    if (blds < (size_t)(OBT / 64) * OB_BINS * 2) blds = (size_t)(OBT / 64) * OB_BINS * 2;
+    if (blds < (size_t)8 * OBT * 4) blds = (size_t)8 * OBT * 4;
     if (!old_form && p.n_bins <= OB_BINS && blds <= 40 * 1024 && Ps < ((size_t)1 << 20)) {
-        hipLaunchKernelGGL(k_lsd_order_bm, dim3(n_frames * 3), dim3(OT), blds, s, p, r_addr, r_deg, r_mod, r_cs, r_sn, n_rec, maxgrad,
+        hipLaunchKernelGGL(k_lsd_order_bm, dim3(n_frames * 3), dim3(OBT), blds, s, p, r_addr, r_deg, r_mod, r_cs, r_sn, n_rec, maxgrad,
                            sort_a, sort_b, order_a, order_b, norder, c_xy, c_deg, c_mod, c_cs, c_sn, row_start, force_hbm);
         return;
     }
