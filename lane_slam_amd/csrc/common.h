@@ -136,9 +136,10 @@ void launch_lsd_grad_gray(const LsdParams& p, const ResizeTables& rt, int n_fram
 // the seed order of OpenCV >= 3.2 (k_lsd_seed32.hip): rewrites order_a after launch_lsd_order; l_*: k_lsd_grad's "low" records
 bool lsd_seed32_supported(const LsdParams& p);
 void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const unsigned long long* maxgrad, const uint32_t* c_xy,
-                       const double* c_mod, const uint32_t* l_addr, const double* l_mod, const int* n_low,
-                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b, hipStream_t s);
-bool launch_std_sort_debug(uint32_t* E, uint32_t* tmp, unsigned long long* small_list, int n, hipStream_t s);
+                       const double* c_mod, const uint32_t* l_addr, double* l_mod, const int* n_low,
+                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b, int big, hipStream_t s);
+size_t std_sort_debug_words(int n);
+void launch_std_sort_debug(const uint32_t* E, uint32_t* work, int n, int* count, hipStream_t s);
 void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, const float* r_deg, const double* r_mod,
                       const double* r_cs, const double* r_sn, const int* n_rec, const unsigned long long* maxgrad,
                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b,

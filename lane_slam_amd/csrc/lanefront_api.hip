@@ -627,7 +627,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         launch_lsd_order(h->lsd, n, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
         // OpenCV >= 3.2: the seeds in the order std::sort leaves them in (the compact arrays and row starts stay as they are)
         if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
-            launch_lsd_seed32(h->lsd, n, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, s);
+            launch_lsd_seed32(h->lsd, n, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
     }
     {
         StageTimer t(h, ST_LSD_ORDER);
@@ -1172,15 +1172,23 @@ extern "C" int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32
         e[i] = ((uint32_t)keys[i] << 20) | (uint32_t)(i + 1);
     }
     int rc;
-    if ((rc = ensure(h, h->a_q, (size_t)n * 4)) || (rc = ensure(h, h->a_m, (size_t)n * 4)) || (rc = ensure(h, h->a_best, (size_t)n * 5 + 2048))) return rc;     // the small-range list + the two place lists
+    const size_t words = std_sort_debug_words(n);
+    if ((rc = ensure(h, h->a_q, (size_t)n * 4)) || (rc = ensure(h, h->a_m, words * 4)) || (rc = ensure(h, h->a_best, 64))) return rc;
     LF_HIP_CHECK(h, hipMemcpyAsync(h->a_q.p, e.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-    if (!launch_std_sort_debug(static_cast<uint32_t*>(h->a_q.p), static_cast<uint32_t*>(h->a_m.p), static_cast<unsigned long long*>(h->a_best.p), n, s)) {
-        lf_set_error(h, LF_ERR_UNSUPPORTED, "lf_debug_std_sort: %d elements exceed the row tables", n); return LF_ERR_UNSUPPORTED;
-    }
+    launch_std_sort_debug(static_cast<const uint32_t*>(h->a_q.p), static_cast<uint32_t*>(h->a_m.p), n, static_cast<int*>(h->a_best.p), s);
     LF_HIP_CHECK(h, hipGetLastError());
-    LF_HIP_CHECK(h, hipMemcpyAsync(e.data(), h->a_q.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    int cnt = 0;
+    LF_HIP_CHECK(h, hipMemcpyAsync(&cnt, h->a_best.p, sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipStreamSynchronize(s));
-    for (int i = 0; i < n; ++i) order[i] = (int32_t)(e[i] & 0xfffffu) - 1;
+    // the sorted non-zero keys sit in the `out` area of the work buffer (k_lsd_seed32.hip: seed_work): 4 * cap words in
+    const size_t cap = words / 12;
+    if (cnt > 0) LF_HIP_CHECK(h, hipMemcpy(e.data(), static_cast<uint32_t*>(h->a_m.p) + 4 * cap, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < cnt; ++i) order[i] = (int32_t)(e[i] & 0xfffffu);
+    // the elements with key 0 (the detector's flat pixels) are anonymous: listed behind, by index
+    {
+        int k = cnt;
+        for (int i = 0; i < n; ++i) if (keys[i] == 0) order[k++] = i;
+    }
     return LF_OK;
 }
 
@@ -1203,7 +1211,7 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     launch_lsd_order(h->lsd, 1, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder,
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
-        launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, s);
+        launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
