@@ -58,6 +58,8 @@ namespace lf {
 #define SEED_T(v) const long long v = (long long)wall_clock64()
 #else
 #define SEED_T(v) do { } while (0)
+#define FST(k) do { } while (0)
+#define FST0 do { } while (0)
 #endif
 
 // Workgroup shape (round 4, end): 256 threads, four waves in phase 2, LDS blocks of 4096 elements.  The first form ran 1024 threads
@@ -378,6 +380,162 @@ __device__ __forceinline__ int partition_lds_coop(lds_u32* D, int f, int l, lds_
     return partition_tail<true>(D, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW, lane, (int)threadIdx.x, ST);
 }
 
+#ifdef LF_SEED_STAMPS
+__device__ int g_dbg_big[8], g_dbg_small[8], g_dbg_chain[8][4];
+__device__ long long g_dbg_b[8][6];
+__device__ long long g_dbg_w[8][8];
+__device__ long long g_dbg_f[8][12];
+#define FST(k) do { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) g_dbg_f[blockIdx.x % 8][k] += n_ - fs_; fs_ = n_; } while (0)
+#define FST0 long long fs_ = (long long)wall_clock64()
+__device__ long long g_dbg_t[8][4];
+#endif
+
+// A range of at most 64 elements and its whole subtree in ONE wave's registers (round 5): lane = element, every lane carries the
+// bounds [f, l) of the range of the loop it currently belongs to, and all ranges inside the window are partitioned AT THE SAME TIME,
+// level by level: the median of three by lane shuffles, the L / R ballots masked with the lane's own range, ranks = popcounts, the
+// swapped elements change places through 128 words of private LDS under their ranks (range start + rank: the ranges are
+// disjoint), the cut from the ballots.  No row tables, no place lists, no stack: ~110 vector instructions per LEVEL whatever the
+// number of ranges -- the ~65 % of all partitions that work on 17 .. 64 elements cost ~1.2 k cycles each as single LDS partitions.
+__device__ __forceinline__ void wave_window(lds_u32* D, uint32_t* D_generic, int w0, int n, int depth, lds_u32* xch, int lane)
+{
+    const bool in = lane < n;
+    uint32_t v = in ? D[w0 + lane] : 0u;
+    int f = 0, l = n, d = depth;
+    bool done = false;
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
+    const unsigned long long lt = (1ull << lane) - 1ull;                                // lanes < this one
+    for (;;) {
+        const unsigned long long segm = (l >= 64 ? ~0ull : ((1ull << l) - 1ull)) & ~((1ull << f) - 1ull);
+        const unsigned long long sb = __ballot(in && (v & 0xfffffu) != 0u);
+        const bool active = in && !done && (l - f) > kSortThreshold && (sb & segm) != 0ull;
+        if (__ballot(active) == 0ull) break;
+        if (__ballot(active && d == 0) != 0ull) {                          // depth limit used up: libstdc++ heap sorts the range
+            if (in) D[w0 + lane] = v;
+            team_sync<false>();
+            if (active && d == 0 && lane == f) heap_sort_range(D_generic, w0 + f, w0 + l);
+            team_sync<false>();
+            if (in) v = D[w0 + lane];
+            if (active && d == 0) done = true;
+            continue;
+        }
+        // __move_median_to_first(f, f + 1, mid, l - 1)
+        const int ia = f + 1, ib = f + ((l - f) >> 1), ic = l - 1;
+        const uint32_t va = __shfl(v, ia), vb = __shfl(v, ib), vc = __shfl(v, ic), vf = __shfl(v, f);
+        int pick;
+        if (comp(va, vb)) pick = comp(vb, vc) ? ib : (comp(va, vc) ? ic : ia);
+        else pick = comp(va, vc) ? ia : (comp(vb, vc) ? ic : ib);
+        const uint32_t pv = pick == ia ? va : (pick == ib ? vb : vc);
+        if (active) { if (lane == f) v = pv; else if (lane == pick) v = vf; }
+        // __unguarded_partition of [f + 1, l) around pv
+        const bool part = active && lane > f;
+        const uint32_t kp = key_of(pv), kv = key_of(v);
+        const bool isL = part && kv <= kp, isR = part && kv >= kp;
+        const unsigned long long bl = __ballot(isL) & segm, br = __ballot(isR) & segm;
+        const int kl = __popcll(bl & le), r_right = __popcll(br & ~le);
+        const int kr = __popcll(br >> lane), l_left = __popcll(bl & lt);
+        const bool swl = isL && r_right >= kl, swr = isR && l_left >= kr;
+        if (swl) xch[f + kl] = v;
+        if (swr) xch[64 + f + kr] = v;
+        team_sync<false>();
+        if (swl) v = xch[64 + f + kl];
+        if (swr) v = xch[f + kr];
+        team_sync<false>();
+        const unsigned long long bs = __ballot(swl) & segm, bsr = __ballot(swr) & segm;
+        const int K = __popcll(bs);
+        const unsigned long long un = bl & ~bs;
+        const int firstL = bl ? __ffsll((long long)bl) - 1 : 64, firstStay = un ? __ffsll((long long)un) - 1 : 64;
+        const int RK = bsr ? __ffsll((long long)bsr) - 1 : 64;
+        const int cut = K == 0 ? firstL : min(firstStay, RK);
+        if (active) { if (lane < cut) l = cut; else f = cut; --d; }
+    }
+    if (in) D[w0 + lane] = v;
+    team_sync<false>();
+}
+
+// __move_median_to_first + __unguarded_partition of the range [f, l) (65 .. 1024 elements: up to 16 rows of 64) of an LDS array by ONE
+// wave, without tables in LDS (round 5): every lane reads the three candidates itself (same addresses: a broadcast), the L / R
+// ballots of row r stay in the registers of LANE r, their prefix / suffix counts are lane scans, a row's ballots and counts come
+// back as v_readlane with the (uniform) row number, the cut is followed in scalar registers while the rows go by (first L, first L
+// that stays, leftmost swapped R), four rows' loads are in flight at a time.  What is left in LDS: the two place lists of the
+// swapped elements (u16, under their ranks) and the pairwise swaps.  Returns the cut, -1 when the range holds no seed.
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long x, int r)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, r), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), r);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int wave_partition(lds_u32* D, int f, int l, lds_u16* Lpos, lds_u16* Rpos, int lane)
+{
+    const int lo = f + 1, hi = l;
+    const int R = (hi - lo + 63) >> 6;
+    const int ia = f + 1, ib = f + ((l - f) >> 1), ic = l - 1;
+    const uint32_t ea = D[ia], eb = D[ib], ec = D[ic], ef = D[f];
+    int pick;
+    if (comp(ea, eb)) pick = comp(eb, ec) ? ib : (comp(ea, ec) ? ic : ia);
+    else pick = comp(ea, ec) ? ia : (comp(eb, ec) ? ic : ib);
+    const uint32_t pivot = pick == ia ? ea : (pick == ib ? eb : ec);
+    if (lane == 0) { D[pick] = ef; D[f] = pivot; }
+    team_sync<false>();
+    const uint32_t kp = key_of(pivot);
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);      // lanes <= this one
+    const unsigned long long lt = (1ull << lane) - 1ull;                                // lanes < this one
+    // (1) the ballots of every row; lane r keeps row r's
+    unsigned long long myBL = 0ull, myBR = 0ull;
+    unsigned long long seeds = (pivot & 0xfffffu) != 0u ? 1ull : 0ull;
+    for (int r0 = 0; r0 < R; r0 += 4) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = lo + (r0 + u) * 64 + lane; v[u] = i < hi ? D[i] : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + u;
+            const bool valid = lo + r * 64 + lane < hi;
+            const unsigned long long bl = __ballot(valid && key_of(v[u]) <= kp);
+            const unsigned long long br = __ballot(valid && key_of(v[u]) >= kp);
+            seeds |= __ballot(valid && (v[u] & 0xfffffu) != 0u);
+            if (lane == r) { myBL = bl; myBR = br; }
+        }
+    }
+    if (seeds == 0ull) return -1;
+    // (2) L elements in the rows in front of row r, R elements in the rows behind it
+    const int cl = __popcll(myBL), cr = __popcll(myBR);
+    const int myPL = wave_incl_scan_i(cl, lane) - cl;
+    const int incr = wave_incl_scan_i(cr, lane);
+    const int mySX = __shfl(incr, 63) - incr;
+    // (3) ranks; the swapped elements publish their places under their ranks; the cut's ingredients in passing
+    int K = 0, firstL = 0x7fffffff, firstStay = 0x7fffffff, RK = 0x7fffffff;
+    for (int r = 0; r < R; ++r) {
+        const unsigned long long bl = readlane64(myBL, r), br = readlane64(myBR, r);
+        const int pl = __builtin_amdgcn_readlane(myPL, r), sx = __builtin_amdgcn_readlane(mySX, r);
+        const int i = lo + r * 64 + lane;
+        const bool isL = (bl >> lane) & 1ull, isR = (br >> lane) & 1ull;
+        const int kl = pl + __popcll(bl & le), r_right = sx + __popcll(br & ~le);
+        const int kr = sx + __popcll(br >> lane), l_left = pl + __popcll(bl & lt);
+        const bool swl = isL && r_right >= kl, swr = isR && l_left >= kr;
+        if (swl) Lpos[kl - 1] = (uint16_t)i;
+        if (swr) Rpos[kr - 1] = (uint16_t)i;
+        const unsigned long long bs = __ballot(swl), bsr = __ballot(swr);
+        const unsigned long long un = bl & ~bs;
+        K += __popcll(bs);
+        if (firstL == 0x7fffffff && bl) firstL = lo + r * 64 + __ffsll((long long)bl) - 1;
+        if (firstStay == 0x7fffffff && un) firstStay = lo + r * 64 + __ffsll((long long)un) - 1;
+        if (RK == 0x7fffffff && bsr) RK = lo + r * 64 + __ffsll((long long)bsr) - 1;
+    }
+    team_sync<false>();
+    // (4) the swaps, pair by pair
+    for (int k0 = lane; k0 < K; k0 += 64 * 4) {
+        int pi[4], pj[4];
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int k = k0 + u * 64; pi[u] = k < K ? (int)Lpos[k] : -1; pj[u] = k < K ? (int)Rpos[k] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (pi[u] >= 0) { a[u] = D[pi[u]]; b[u] = D[pj[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (pi[u] >= 0) { D[pi[u]] = b[u]; D[pj[u]] = a[u]; }
+    }
+    team_sync<false>();
+    return K == 0 ? firstL : min(firstStay, RK);
+}
+
 // one wave works off the whole subtree of the range [f, l) of an LDS array alone (private tables, lists and stack)
 __device__ __forceinline__ void wave_subtree(lds_u32* D, uint32_t* D_generic, int f, int l, int depth, lds_u64* wBL, lds_u64* wBR,
                                              lds_i32* wPL, lds_i32* wSX, lds_i32* wacc, lds_u16* Lp, lds_u16* Rp, lds_i32* stack, int lane)
@@ -385,15 +543,24 @@ __device__ __forceinline__ void wave_subtree(lds_u32* D, uint32_t* D_generic, in
     int sp = 0;
     for (;;) {
         while (l - f > kSortThreshold) {
+#ifdef LF_SEED_STAMPS
+            if (l - f <= 64) { const long long c0 = clock64(); wave_window(D, D_generic, f, l - f, depth, (lds_u32*)Lp, lane); if (lane == 0 && (threadIdx.x >> 6) == 0) { g_dbg_w[blockIdx.x % 8][0] += 1; g_dbg_w[blockIdx.x % 8][1] += clock64() - c0; } break; }
+#else
+            if (l - f <= 64) { wave_window(D, D_generic, f, l - f, depth, (lds_u32*)Lp, lane); break; }
+#endif
             if (depth == 0) {
                 if (lane == 0) heap_sort_range(D_generic, f, l);
                 team_sync<false>();
                 break;
             }
             --depth;
-            if (lane == 0) median_to_first_lds(D, f, l);
-            team_sync<false>();
-            const int cut = partition_lds(D, f, l, wBL, wBR, wPL, wSX, wacc, Lp, Rp, lane);
+#ifdef LF_SEED_STAMPS
+            const long long c0 = clock64();
+#endif
+            const int cut = wave_partition(D, f, l, Lp, Rp, lane);
+#ifdef LF_SEED_STAMPS
+            if (lane == 0 && (threadIdx.x >> 6) == 0) { g_dbg_w[blockIdx.x % 8][2] += 1; g_dbg_w[blockIdx.x % 8][3] += clock64() - c0; g_dbg_w[blockIdx.x % 8][4] += (l - f + 62) >> 6; }
+#endif
             if (cut < 0) break;
             if (l - cut > kSortThreshold) {
                 if (lane == 0) { stack[2 * sp] = cut; stack[2 * sp + 1] = l | (depth << 24); }
@@ -411,10 +578,6 @@ __device__ __forceinline__ void wave_subtree(lds_u32* D, uint32_t* D_generic, in
     team_sync<false>();
 }
 
-#ifdef LF_SEED_STAMPS
-__device__ int g_dbg_big[8], g_dbg_small[8], g_dbg_chain[8][4];
-__device__ long long g_dbg_t[8][4];
-#endif
 
 // a dense range the chain left: elements E[off, off + len), depth allowance left
 struct SeedRange { int off, len, depth; };
@@ -521,6 +684,7 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
             const int gf = (int)(it & 0xffffffu), gl = (int)((it >> 24) & 0xffffffu);
             const int m = gl - gf;
             __syncthreads();
+            SEED_T(b0);
             if (t == 0) { acc[3] = 0; n_big = 0; n_blk_small = 0; next_small = 0; }
             __syncthreads();
             {
@@ -536,6 +700,7 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
             }
             __syncthreads();
             if (acc[3] == 0) continue;                                  // no seed in the block
+            SEED_T(b1);
             if (t == 0) { big_stack[0] = 0; big_stack[1] = m; big_stack[2] = (int)(it >> 48); n_big = 1; }
             __syncthreads();
             for (;;) {
@@ -571,6 +736,10 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
                 __syncthreads();
             }
             // the block's small ranges: the waves, in place (their private lists alias the workgroup's place lists, which are idle now)
+            SEED_T(b2);
+#ifdef LF_SEED_STAMPS
+            long long my_w = 0;
+#endif
             if (w < SW2) {
                 uint32_t* mine = xreg + (size_t)w * kBlkWaveWords;
                 lds_u16* Lp = as_lds<lds_u16>(mine);
@@ -590,8 +759,16 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
                     const uint32_t a = blk_small[2 * idx], b = blk_small[2 * idx + 1];
                     wave_subtree(Dg, lds, (int)a, (int)(b & 0xffffffu), (int)(b >> 24), wBL, wBR, wPL, wSX, wacc, Lp, Rp, stack, lane);
                 }
+#ifdef LF_SEED_STAMPS
+                my_w = (long long)wall_clock64() - b2;
+#endif
             }
             __syncthreads();
+            SEED_T(b3);
+#ifdef LF_SEED_STAMPS
+            if (t == 0) { long long* g = g_dbg_b[blockIdx.x % 8]; g[0] += b1 - b0; g[1] += b2 - b1; g[2] += b3 - b2; g[4] += n_blk_small; }
+            if (lane == 0) atomicMin((unsigned long long*)&g_dbg_b[blockIdx.x % 8][5], (unsigned long long)my_w);
+#endif
             for (int x0 = t; x0 < m; x0 += ST * kU) {
 #pragma unroll
                 for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; if (x < m) E[gf + x] = Dg[x]; }
@@ -645,13 +822,13 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
 // `cap` u32 words (cap >= the array length n and >= 1024):
 struct SeedWork {
     uint32_t* E;              // the dense array the chain writes out
-    uint32_t* V[2];           // the list's values (bin << 20 | seed + 1), double buffered
-    uint32_t* P[2];           // the list's positions when it does not fit LDS (double buffered); P[0] also stages a split's new list for the LDS form
+    uint32_t* V0; uint32_t* V1;   // the list's values (bin << 20 | seed + 1), double buffered (scalar members, selected with ?: -- an array indexed
+    uint32_t* P0; uint32_t* P1;   // by the buffer number put the struct into scratch memory and made every access a flat one); the list's positions
     uint32_t* PP;             // split: the positions of the entries above the pivot; the dense phase's global row tables; the final passes' second buffer
     uint32_t* T;              // split: the entry at the k-th L place (or none)
     uint32_t* RT;             // row tables of a list that does not fit LDS (6 words per 64 entries)
-    unsigned long long* dscratch;   // the dense phase's range lists and place lists: aliases V[1] | P[0]
-    uint32_t* out;            // the seeds in their final order (aliases P[1])
+    unsigned long long* dscratch;   // the dense phase's range lists and place lists: aliases V1 | P0
+    uint32_t* out;            // the seeds in their final order (aliases P1)
 };
 
 // the chain's state: LDS, written by single threads between barriers
@@ -700,9 +877,439 @@ __device__ __forceinline__ void chain_materialize(uint32_t* E, int off, int f, i
     __syncthreads();
 }
 
-// PL: the positions in LDS (single buffer Pl, new places through registers), else in W.P[cur] (double buffered)
+// ---- the chain on a BIT PLANE (ranges whose plane fits LDS; round 5, second form) -------------------------------------------------
+// Nothing in a fold or a split needs the list in ORDER -- only "how many entries lie in front of position q" (a rank) and "where
+// is the k-th position without an entry" (a select) -- so for a range of up to a few hundred thousand positions the list stays an
+// unordered array of (position, value) in global memory and a step works on the bit plane of the entries' positions in LDS
+// (lsd_bitplane.h's layout: 64-bit words + a 16-bit running count per pair of words; rebuilt per step: the range halves with
+// every fold): a fold rewrites nothing but the POSITIONS of the entries it moves (values never move, nothing is merged or
+// sorted), a split reads two planes (the entries above the pivot / not below it).  rank = 3 LDS reads, select = a binary search
+// over the running counts of zeros + a bisection inside the word.
+struct Plane { lds_u64* bits; lds_u16* pref; lds_u16* stab; int pairs; };
+// words of LDS one plane over `len` positions takes: the bits, a count per pair of words, a select entry per 128 clear bits
+__host__ __device__ inline int plane_words_for(int len) { const int words = ((len >> 6) + 2) & ~1, pairs = words >> 1; return 2 * words + ((pairs + 1) >> 1) + ((pairs + 3) >> 1); }
+__device__ __forceinline__ Plane plane_at(lds_u32* base, int len)
+{
+    Plane pl;
+    const int words = ((len >> 6) + 2) & ~1;
+    pl.bits = (lds_u64*)base;
+    pl.pairs = words >> 1;
+    pl.pref = (lds_u16*)(base + 2 * words);
+    pl.stab = (lds_u16*)(base + 2 * words + ((pl.pairs + 1) >> 1));
+    return pl;
+}
+// set bits in front of bit q
+__device__ __forceinline__ int plane_rank(const Plane& pl, int q)
+{
+    const int w = q >> 6;
+    const unsigned long long lo = pl.bits[w & ~1], cur = pl.bits[w];
+    return (int)pl.pref[w >> 1] + ((w & 1) ? __popcll(lo) : 0) + __popcll(cur & ((1ull << (q & 63)) - 1ull));
+}
+// the kk-th set bit of wd (1-based): the largest p with fewer than kk set bits below bit p
+__device__ __forceinline__ int word_select(unsigned long long wd, int kk)
+{
+    int p = 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        if (__popcll(wd & ((1ull << (p + s)) - 1ull)) < kk) p += s;
+    }
+    return p;
+}
+// N selects at a time, step by step together (a lone wave waits ~100+ cycles for every LDS read: N chains side by side cost
+// little more than one): out[u] = index of the k[u]-th (1-based) CLEAR bit; the caller makes sure the plane holds that many.
+// stab[j] = the pair of words that holds clear bit number 128 j + 1, so the pair of the k-th is at most a few steps further.
+template <int N>
+__device__ __forceinline__ void plane_select0_n(const Plane& pl, const int (&k)[N], int (&out)[N])
+{
+    int x[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) x[u] = (int)pl.stab[(k[u] - 1) >> 7];
+    for (;;) {                                                   // on to the last pair with fewer than k clear bits in front of it
+        int nx[N];
+        bool any = false;
+#pragma unroll
+        for (int u = 0; u < N; ++u) { const int c = x[u] + 1; nx[u] = c < pl.pairs ? 128 * c - (int)pl.pref[c] : 0x7fffffff; }
+#pragma unroll
+        for (int u = 0; u < N; ++u) if (nx[u] < k[u]) { ++x[u]; any = true; }
+        if (!any) break;
+    }
+    unsigned long long w0[N], w1[N];
+    int p0[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) { w0[u] = pl.bits[2 * x[u]]; w1[u] = pl.bits[2 * x[u] + 1]; p0[u] = (int)pl.pref[x[u]]; }
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        int kk = k[u] - (128 * x[u] - p0[u]);
+        unsigned long long wd = ~w0[u];
+        int base = 128 * x[u];
+        const int z0 = __popcll(wd);
+        if (kk > z0) { kk -= z0; wd = ~w1[u]; base += 64; }
+        out[u] = base + word_select(wd, kk);
+    }
+}
+__device__ __forceinline__ int plane_select0(const Plane& pl, int k)
+{
+    const int kk[1] = { k };
+    int out[1];
+    plane_select0_n<1>(pl, kk, out);
+    return out[0];
+}
+
+// running counts of a plane whose bits are set (all threads; ends synchronised); returns the number of set bits
+__device__ __forceinline__ int plane_counts(const Plane& pl, lds_i32* wave_tot)
+{
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (pl.pairs + ST - 1) / ST;
+    const int w0 = tid * per < pl.pairs ? tid * per : pl.pairs, w1 = w0 + per < pl.pairs ? w0 + per : pl.pairs;
+    int mine = 0;
+    for (int q = w0; q < w1; ++q) mine += __popcll(pl.bits[2 * q]) + __popcll(pl.bits[2 * q + 1]);
+    const int incl = wave_incl_scan_i(mine, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int basev = incl - mine, total = 0;
+    for (int k = 0; k < SW; ++k) { const int v = wave_tot[k]; if (k < wave) basev += v; total += v; }
+    for (int q = w0; q < w1; ++q) {
+        const int c = __popcll(pl.bits[2 * q]) + __popcll(pl.bits[2 * q + 1]);
+        pl.pref[q] = (uint16_t)basev;
+        // the select table: this pair holds the clear bits number zb0 + 1 .. zb1
+        const int zb0 = 128 * q - basev, zb1 = zb0 + 128 - c;
+        for (int j = (zb0 + 127) >> 7; 128 * j < zb1; ++j) pl.stab[j] = (uint16_t)q;
+        basev += c;
+    }
+    __syncthreads();
+    return total;
+}
+__device__ __forceinline__ void plane_set(lds_u32* base, int q) { (void)__hip_atomic_fetch_or(base + (q >> 5), 1u << (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+
+// one step (fold or split) of the chain on the planes.  The list: slots [a, b) of (cur ? W.P1 : W.P0) / (cur ? W.V1 : W.V0), any order, value 0 = dead slot.
+// pr / regs_ok: while the list has at most kEPT x ST slots every thread keeps the positions of ITS slots (a + t + u ST) in registers
+// from one fold to the next (0xffffffff = dead slot; global memory is written through for the steps that read it): a run of folds --
+// the usual top of the chain -- then reads nothing from global memory at all, it is plane arithmetic in LDS.
+constexpr uint32_t kDeadSlot = 0xffffffffu;
+#ifndef LF_SEED_SEL
+#define LF_SEED_SEL 4
+#endif
+constexpr int kSel = LF_SEED_SEL;           // selects / list slots a thread works on side by side (registers: the kernel must keep three waves per SIMD)
+__device__ __forceinline__ void chain_step_plane(const SeedWork& W, __attribute__((address_space(3))) ChainState* cs, lds_u32* lds,
+                                                 uint32_t (&pr)[kEPT], bool& regs_ok)
+{
+    const int t = threadIdx.x, lane = t & 63;
+    const int f = cs->f, l = cs->l, a = cs->a, b = cs->b, depth = cs->depth, cur = cs->cur, seeds = cs->seeds;
+    const int len = l - f;
+    uint32_t* V = (cur ? W.V1 : W.V0);
+    uint32_t* P = (cur ? W.P1 : W.P0);
+    uint32_t* V2 = (cur ? W.V0 : W.V1);
+    uint32_t* P2 = (cur ? W.P0 : W.P1);
+    lds_i32* wtot = (lds_i32*)&cs->wtot[0];
+    const bool persist = b - a <= kEPT * ST;
+    auto load_tile = [&](int base) {
+        uint32_t vv[kEPT];
+#pragma unroll
+        for (int u = 0; u < kEPT; ++u) { const int i = base + t + u * ST, ic = i < b ? i : b - 1; vv[u] = V[ic]; pr[u] = P[ic]; }     // (clamped, not predicated: the loads go out together)
+#pragma unroll
+        for (int u = 0; u < kEPT; ++u) if (vv[u] == 0u || base + t + u * ST >= b) pr[u] = kDeadSlot;
+    };
+    // ---- pass A: the plane of the entries' positions over [f, l) (bit = position - f), and the entries at f, f + 1, mid, l - 1
+    FST0;
+    const Plane pl = plane_at(lds, len);
+    for (int i = t; i < 4 * pl.pairs; i += ST) lds[i] = 0u;
+    if (t < 4) { cs->md_idx[t] = -1; cs->md_val[t] = 0u; }
+    __syncthreads();
+    const int q0 = f, q1 = f + 1, q2 = f + len / 2, q3 = l - 1;
+    for (int base = a; base < b; base += kEPT * ST) {
+        if (!(persist && regs_ok)) load_tile(base);
+#pragma unroll
+        for (int u = 0; u < kEPT; ++u) {
+            const uint32_t pos = pr[u];
+            if (pos != kDeadSlot) {
+                plane_set(lds, (int)pos - f);
+                if ((int)pos == q0 || (int)pos == q1 || (int)pos == q2 || (int)pos == q3) {
+                    const int i = base + t + u * ST;
+                    const int which = (int)pos == q0 ? 0 : ((int)pos == q1 ? 1 : ((int)pos == q2 ? 2 : 3));
+                    cs->md_idx[which] = i; cs->md_val[which] = V[i];
+                }
+            }
+        }
+    }
+    if (persist) regs_ok = true;
+    __syncthreads();
+    FST(0);
+    const int total = plane_counts(pl, wtot);
+    FST(1);
+    const uint32_t vf = cs->md_val[0], va = cs->md_val[1], vb = cs->md_val[2], vc = cs->md_val[3];
+    const int xf = cs->md_idx[0];
+    int pk;                                                            // 1: f + 1, 2: mid, 3: l - 1  (three different places: len > 16)
+    if (comp(va, vb)) pk = comp(vb, vc) ? 2 : (comp(va, vc) ? 3 : 1);
+    else pk = comp(va, vc) ? 1 : (comp(vb, vc) ? 3 : 2);
+    const uint32_t pv = cs->md_val[pk];
+    const int xp = cs->md_idx[pk];
+    const int pick = pk == 1 ? q1 : (pk == 2 ? q2 : q3);
+    __syncthreads();
+    // the median goes to f, what was at f to the median's place
+    if (t == 0) {
+        if (xp >= 0) { V[xp] = vf; if (xf >= 0) V[xf] = 0u; }           // (vf == 0: the slot dies)
+        else if (xf >= 0) P[xf] = (uint32_t)pick;
+    }
+    const int lo = f + 1, hi = l, plen = hi - lo;
+    if (key_of(pv) == 0u) {
+        // ================================================ FOLD
+        if (xf >= 0) {                                                    // the entry at f (bit 0) went to `pick`: its bit moves, the counts are made again (rare)
+            if (persist) {
+#pragma unroll
+                for (int u = 0; u < kEPT; ++u) if (a + t + u * ST == xf) pr[u] = (uint32_t)pick;
+            }
+            if (t == 0) {
+                (void)__hip_atomic_fetch_and(lds, ~1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                plane_set(lds, pick - f);
+            }
+            __syncthreads();
+            (void)plane_counts(pl, wtot);
+        }
+        __syncthreads();
+        // bit 0 (the pivot's place) is clear: the entries of [lo, q) are rank(q - f), the k-th zero of [lo, hi) is the plane's (k + 1)-th
+        FST(2);
+        const int mm = total;
+        const int Zt = plen - mm;
+        // K = the largest k with 2 k - (entries inside the last k positions) <= Zt: one wave, 64 candidates per round
+        if (t < 64) {
+            int klo = 0, khi = plen + 1;                                  // feasible(klo), not feasible(khi)
+            while (khi - klo > 1) {
+                const int step = (khi - klo + 63) / 64;
+                const int k = klo + (lane + 1) * step;
+                bool feas = false;
+                if (k < khi) feas = 2 * k - (mm - plane_rank(pl, len - k)) <= Zt;
+                const unsigned long long bf = __ballot(feas);
+                const int cnt = bf == ~0ull ? 64 : __ffsll((long long)~bf) - 1;   // candidates 1 .. cnt are feasible
+                const int nlo = klo + cnt * step;
+                khi = min(khi, nlo + step);
+                klo = nlo;
+            }
+            if (lane == 0) cs->K = klo;
+        }
+        __syncthreads();
+        FST(3);
+        const int K = cs->K;
+        if (t == ST - 1) {
+            int cut;
+            if (K == 0) cut = f + plane_select0(pl, 2);
+            else { cut = hi - K; if (Zt >= K + 1) cut = min(cut, f + plane_select0(pl, K + 2)); }
+            cs->cut = cut;
+        }
+        // the entries of the last K positions move to the first K zeros: the one at hi - k to the k-th (eight selects at a time)
+        for (int base = a; base < b; base += kEPT * ST) {
+            if (!persist) load_tile(base);
+#pragma unroll
+            for (int g = 0; g < kEPT; g += kSel) {
+                int kk[kSel], sel[kSel];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < kSel; ++u) {
+                    const uint32_t pos = pr[g + u];
+                    const bool mv = pos != kDeadSlot && (int)pos >= hi - K;
+                    kk[u] = mv ? hi - (int)pos + 1 : 1;
+                    any |= mv;
+                }
+                if (__ballot(any) == 0ull) continue;
+                plane_select0_n<kSel>(pl, kk, sel);
+#pragma unroll
+                for (int u = 0; u < kSel; ++u) {
+                    const uint32_t pos = pr[g + u];
+                    if (pos != kDeadSlot && (int)pos >= hi - K) {
+                        const uint32_t np = (uint32_t)(f + sel[u]);
+                        pr[g + u] = np;
+                        P[base + t + (g + u) * ST] = np;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        FST(4);
+        if (t == 0) { cs->l = cs->cut; cs->depth = depth - 1; }
+        __syncthreads();
+        FST(5);
+#ifdef LF_SEED_STAMPS
+        if (t == 0) atomicAdd(&g_dbg_chain[blockIdx.x % 8][0], 1);
+#endif
+        return;
+    }
+    __syncthreads();
+    // ================================================ SPLIT
+    // Every pass walks the list in tiles of kST x ST slots whose loads go out together (one trip to L2 per tile and pass; a slot at a
+    // time was a trip each: 75 us per split).
+    const uint32_t kp = key_of(pv);
+    const int pw = plane_words_for(plen);
+    lds_u32* ldsG = lds + ((pw + 1) & ~1);
+    const Plane pa = plane_at(lds, plen), pg = plane_at(ldsG, plen);       // entries above the pivot / not below it
+    constexpr int kST = 8;
+#pragma unroll
+    for (int u = 0; u < kEPT; ++u) pr[u] = kDeadSlot;                     // (the register copy of the positions ends here: a split writes a new list)
+    regs_ok = false;
+    uint32_t vv[kST], pp[kST];
+    auto load_vals = [&](int base) {                                       // (after the median's move: a dead slot has value 0)
+#pragma unroll
+        for (int u = 0; u < kST; ++u) { const int i = base + t + u * ST, ic = i < b ? i : b - 1; vv[u] = V[ic]; pp[u] = P[ic]; }
+#pragma unroll
+        for (int u = 0; u < kST; ++u) if (base + t + u * ST >= b) vv[u] = 0u;
+    };
+    for (int i = t; i < 4 * pa.pairs; i += ST) { lds[i] = 0u; ldsG[i] = 0u; }
+    if (t == 0) { cs->K = 0; cs->minR = 0x7fffffff; cs->lseeds = (pv & 0xfffffu) != 0u; cs->nright = 0; }
+    __syncthreads();
+    for (int base = a; base < b; base += kST * ST) {
+        load_vals(base);
+#pragma unroll
+        for (int u = 0; u < kST; ++u) {
+            if (vv[u] && key_of(vv[u]) >= kp) {
+                plane_set(ldsG, (int)pp[u] - lo);
+                if (key_of(vv[u]) > kp) plane_set(lds, (int)pp[u] - lo);
+            }
+        }
+    }
+    __syncthreads();
+    FST(6);
+    const int nA = plane_counts(pa, wtot);
+    const int nG = plane_counts(pg, wtot);
+    const int nonA = plen - nA;
+    FST(7);
+    // K = the R entries (rank k from the right) with L_k in front of them; R_K = the leftmost of them;  TV <- none
+    for (int k = t; k <= nG + 1; k += ST) W.T[k] = 0u;
+    {
+        int wk = 0, mymin = 0x7fffffff;                                   // (one reduction per wave at the end: a shuffle costs a lone wave ~150 cycles)
+        for (int base = a; base < b; base += kST * ST) {
+            load_vals(base);
+#pragma unroll
+            for (int g = 0; g < kST; g += kSel) {
+                int gr[kSel], kk[kSel], sel[kSel];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < kSel; ++u) {
+                    const bool isG = vv[g + u] != 0u && key_of(vv[g + u]) >= kp;
+                    gr[u] = isG ? nG - plane_rank(pg, (int)pp[g + u] - lo) : 0x7fffffff;
+                    kk[u] = gr[u] <= nonA ? gr[u] : 1;
+                    any |= isG;
+                }
+                if (__ballot(any) == 0ull) continue;
+                plane_select0_n<kSel>(pa, kk, sel);
+#pragma unroll
+                for (int u = 0; u < kSel; ++u) {
+                    const int pos = (int)pp[g + u];
+                    const bool ok = gr[u] <= nonA && lo + sel[u] < pos;
+                    wk += __popcll(__ballot(ok));
+                    if (ok) mymin = min(mymin, pos);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) mymin = min(mymin, __shfl_xor(mymin, d));
+        if (lane == 0 && wk) { lds_add((lds_i32*)&cs->K, wk); lds_min((lds_i32*)&cs->minR, mymin); }
+    }
+    __syncthreads();
+    FST(8);
+    const int K = cs->K;
+    // TV[k] <- the VALUE of the entry at L_k, for the entries with key <= kp among the first K L places (0: that place holds a zero)
+    for (int base = a; base < b; base += kST * ST) {
+        load_vals(base);
+#pragma unroll
+        for (int u = 0; u < kST; ++u) {
+            if (vv[u] && key_of(vv[u]) <= kp) {
+                const int q = (int)pp[u] - lo;
+                const int lrank = q - plane_rank(pa, q) + 1;
+                if (lrank <= K) W.T[lrank] = vv[u];
+            }
+        }
+    }
+    if (t == ST - 1) {
+        const int l1 = K + 1 <= nonA ? lo + plane_select0(pa, K + 1) : 0x7fffffff;
+        cs->cut = K == 0 ? l1 : min(l1, cs->minR);
+    }
+    __syncthreads();
+    FST(9);
+    const int cut = cs->cut;
+    const int off = cs->e_used;
+    // output: the left part [f, cut) dense into E, the right part's list (any order) into the other buffers
+    //   a swapped R entry (rank k <= K) goes to L_k; its place takes the element that was at L_k (TV[k]; a zero: the slot goes)
+    //   a swapped L entry is written by the R entry it changes places with
+    //   the others stay: left of the cut into E, right of it into the new list
+    int wseeds = 0;
+    for (int base = a; base < b; base += kST * ST) {
+        load_vals(base);
+        int gr[kST];
+        uint32_t tv[kST];
+        uint32_t lmask = 0u, emask = 0u;                                   // bit u: slot u is a swapped L element / goes into the new list
+#pragma unroll
+        for (int u = 0; u < kST; ++u) {
+            const uint32_t v = vv[u];
+            const int q = (int)pp[u] - lo;
+            gr[u] = 0x7fffffff;
+            if (v) {
+                if (key_of(v) >= kp) gr[u] = nG - plane_rank(pg, q);
+                if (key_of(v) <= kp && q - plane_rank(pa, q) + 1 <= K) lmask |= 1u << u;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kST; ++u) tv[u] = gr[u] <= K ? W.T[gr[u]] : 0u;    // (the tile's gathers together)
+#pragma unroll
+        for (int g = 0; g < kST; g += kSel) {
+            int kk[kSel], sel[kSel];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < kSel; ++u) { kk[u] = gr[g + u] <= K ? gr[g + u] : 1; any |= gr[g + u] <= K; }
+            if (__ballot(any) == 0ull) continue;
+            plane_select0_n<kSel>(pa, kk, sel);
+#pragma unroll
+            for (int u = 0; u < kSel; ++u) if (gr[g + u] <= K) W.E[off + lo + sel[u] - f] = vv[g + u];
+        }
+        int wemit = 0;
+#pragma unroll
+        for (int u = 0; u < kST; ++u) {
+            const uint32_t v = vv[u];
+            const int pos = (int)pp[u];
+            bool emit = false, left = false;
+            if (v) {
+                if (gr[u] <= K) { left = true; emit = tv[u] != 0u; }
+                else if ((lmask >> u) & 1u) { }
+                else if (pos < cut) { W.E[off + pos - f] = v; left = true; }
+                else { emit = true; tv[u] = v; }
+            }
+            wseeds += __popcll(__ballot(left && (v & 0xfffffu) != 0u));
+            wemit += __popcll(__ballot(emit));
+            if (emit) emask |= 1u << u;
+        }
+        if (wemit) {                                                        // one reservation per wave and tile
+            int base_ = 0;
+            if (lane == 0) base_ = __hip_atomic_fetch_add((lds_i32*)&cs->nright, wemit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            base_ = a + __shfl(base_, 0);
+#pragma unroll
+            for (int u = 0; u < kST; ++u) {
+                const bool emit = (emask >> u) & 1u;
+                const unsigned long long be = __ballot(emit);
+                if (emit) { const int dst = base_ + __popcll(be & ((1ull << lane) - 1ull)); P2[dst] = pp[u]; V2[dst] = tv[u]; }
+                base_ += __popcll(be);
+            }
+        }
+    }
+    regs_ok = false;                                                      // a new list, in the other buffers
+    if (lane == 0 && wseeds) lds_add((lds_i32*)&cs->lseeds, wseeds);
+    if (t == 0) W.E[off] = pv;
+    __syncthreads();
+    FST(10);
+    if (t == 0) {
+        const int k = cs->n_ranges;
+        cs->ranges[k].off = off; cs->ranges[k].len = cut - f; cs->ranges[k].depth = depth - 1;
+        cs->n_ranges = k + 1;
+        cs->e_used = off + (cut - f);
+        cs->seeds = seeds - cs->lseeds;
+        cs->f = cut; cs->depth = depth - 1; cs->b = a + cs->nright; cs->cur = cur ^ 1;
+    }
+    __syncthreads();
+#ifdef LF_SEED_STAMPS
+    if (t == 0) atomicAdd(&g_dbg_chain[blockIdx.x % 8][1], 1);
+#endif
+}
+
+// PL: the positions in LDS (single buffer Pl, new places through registers), else in (cur ? W.P1 : W.P0) (double buffered)
 template <bool PL>
-__device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds_u32* tab, ChainState* cs_generic, int n, int m0, int nseeds)
+__device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds_u32* tab, ChainState* cs_generic, int n, int m0, int nseeds, lds_u32* plane_lds, int plane_lds_words)
 {
     typedef __attribute__((address_space(3))) ChainState lds_cs;
     lds_cs* cs = (lds_cs*)(__attribute__((address_space(3))) void*)cs_generic;
@@ -710,14 +1317,16 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
     if (t == 0) {
         cs->f = 0; cs->l = n; cs->depth = 2 * (31 - __clz(n)); cs->a = 0; cs->b = m0; cs->seeds = nseeds; cs->cur = 0; cs->e_used = 0; cs->n_ranges = 0;
     }
+    uint32_t pr[kEPT];                                                    // the plane form's register copy of this thread's list slots
+    bool regs_ok = false;
     __syncthreads();
     for (;;) {
         const int f = cs->f, l = cs->l, a = cs->a, b = cs->b, depth = cs->depth, cur = cs->cur, seeds = cs->seeds;
         const int len = l - f, m = b - a;
-        uint32_t* V = W.V[cur];
-        uint32_t* V2 = W.V[cur ^ 1];
-        uint32_t* Pg = W.P[cur];
-        uint32_t* Pg2 = W.P[cur ^ 1];
+        uint32_t* V = (cur ? W.V1 : W.V0);
+        uint32_t* V2 = (cur ? W.V0 : W.V1);
+        uint32_t* Pg = (cur ? W.P1 : W.P0);
+        uint32_t* Pg2 = (cur ? W.P0 : W.P1);
         __syncthreads();                                                  // everybody has read the state
         if (seeds == 0) break;
         if (len <= kChainDense || (len - m) * 4 <= len || depth == 0 || cs->n_ranges >= kMaxRanges - 1) {
@@ -727,7 +1336,17 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
             __syncthreads();
             break;
         }
-        // ---- the median of three: the values at f, f + 1, mid, l - 1
+        if (!PL && 2 * ((plane_words_for(len) + 1) & ~1) <= plane_lds_words && m <= 65535) {   // the range's planes fit LDS: the unordered form
+#ifdef LF_SEED_STAMPS
+            const long long c0 = (long long)wall_clock64(); const int nr0 = cs->n_ranges;
+#endif
+            chain_step_plane(W, cs, plane_lds, pr, regs_ok);
+#ifdef LF_SEED_STAMPS
+            if (t == 0) { const int sp = cs->n_ranges != nr0; g_dbg_chain[blockIdx.x % 8][2 + sp] += (int)((long long)wall_clock64() - c0); }
+#endif
+            continue;
+        }
+        // ---- (longer ranges: the list in position order, ranks by binary search) the median of three: the values at f, f + 1, mid, l - 1
         if (t < 4) {
             const int q = t == 0 ? f : (t == 1 ? f + 1 : (t == 2 ? f + len / 2 : l - 1));
             const int i = PL ? list_lower_bound(Pl, a, b, q) : list_lower_bound(Pg, a, b, q);
@@ -963,7 +1582,7 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
             __syncthreads();
             if (w == 0) { const int tot = PL ? wave_scan_rows(lCA, R, lane) : wave_scan_rows(gCA, R, lane); if (lane == 0) cs->nright = tot; }
             __syncthreads();
-            uint32_t* Pn = PL ? W.P[0] : Pg2;                                // the new list's positions (staged in global memory for the LDS form)
+            uint32_t* Pn = PL ? W.P0 : Pg2;                                // the new list's positions (staged in global memory for the LDS form)
             for (int r = w; r < R; r += SW) {
                 const int i = a1 + r * 64 + lane;
                 const unsigned long long be = TBA(r);
@@ -979,7 +1598,7 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
             __syncthreads();
             const int nright = cs->nright;
             if (PL) {
-                for (int i = a1 + t; i < a1 + nright; i += ST) Pl[i] = W.P[0][i];
+                for (int i = a1 + t; i < a1 + nright; i += ST) Pl[i] = W.P0[i];
             }
             if (t == 0) {
                 const int k = cs->n_ranges;
@@ -1038,22 +1657,15 @@ __device__ __forceinline__ void seed_radix_pass(const uint32_t* __restrict__ src
     __syncthreads();
 }
 
-// The whole sort of one problem, given its explicit list (m entries; positions in W.P[0] -- copied into LDS when they fit --,
-// values in W.V[0]) over an array of n elements with n_seeds seeds: chain, dense phases, and the final insertion sort as stable
+// The whole sort of one problem, given its explicit list (m entries; positions in W.P0 -- copied into LDS when they fit --,
+// values in W.V0) over an array of n elements with n_seeds seeds: chain, dense phases, and the final insertion sort as stable
 // counting passes.  Leaves the seeds in W.out as (n_bins - 1 - bin) << 20 | payload - 1, in their final order.
-__device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int n_seeds, int n_bins, uint32_t* lds, int rows_cap, int* tot, int* base)
+__device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int n_seeds, int n_bins, uint32_t* lds, int lds_words, int rows_cap, int* tot, int* base)
 {
     __shared__ ChainState cstate;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     SEED_T(t0);
-    if (m <= kListLds) {
-        lds_u32* Pl = as_lds<lds_u32>(lds);
-        for (int i = t; i < m; i += ST) Pl[i] = W.P[0][i];
-        __syncthreads();
-        sparse_chain<true>(W, Pl, Pl + kListLds, &cstate, n, m, n_seeds);
-    } else {
-        sparse_chain<false>(W, nullptr, nullptr, &cstate, n, m, n_seeds);
-    }
+    sparse_chain<false>(W, nullptr, nullptr, &cstate, n, m, n_seeds, as_lds<lds_u32>(lds), lds_words);
     SEED_T(t1);
     const int M = cstate.e_used;
     introsort_loop_wg(W.E, M, cstate.ranges, cstate.n_ranges, W.dscratch, lds, rows_cap, W.PP);
@@ -1086,7 +1698,7 @@ __device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int
     seed_radix_pass(A, B, n_seeds, 24, cnt, tot, base);
     seed_radix_pass(B, A, n_seeds, 28, cnt, tot, base);
 #ifdef LF_SEED_STAMPS
-    { const long long t3 = (long long)wall_clock64(); if (t == 0 && blockIdx.x < 6) printf("[seed32] problem %d: n %d list %d seeds %d | chain %lld (%d folds, %d splits -> %d dense in %d ranges)  loop %lld (%d big partitions, %d small ranges; global %lld  blocks %lld  small %lld)  final %lld (x10 ns)\n", (int)blockIdx.x, n, m, n_seeds, t1 - t0, g_dbg_chain[blockIdx.x % 8][0], g_dbg_chain[blockIdx.x % 8][1], M, cstate.n_ranges, t2 - t1, g_dbg_big[blockIdx.x % 8], g_dbg_small[blockIdx.x % 8], g_dbg_t[blockIdx.x % 8][0], g_dbg_t[blockIdx.x % 8][1], g_dbg_t[blockIdx.x % 8][2], t3 - t2); }
+    { const long long t3 = (long long)wall_clock64(); if (t == 0 && blockIdx.x < 6) printf("[seed32] problem %d: n %d list %d seeds %d | chain %lld (%d folds %d, %d splits %d -> %d dense in %d ranges)  loop %lld (%d big partitions, %d small ranges; global %lld  blocks %lld [copy-in %lld coop %lld waves %lld (%lld ranges)]  small %lld)  final %lld (x10 ns) | fold: passA %lld counts %lld median %lld K %lld passB %lld state %lld | split: build %lld counts %lld K %lld TV %lld out %lld | wave 0: %lld windows %lld cycles, %lld partitions (%lld rows) %lld cycles\n", (int)blockIdx.x, n, m, n_seeds, t1 - t0, g_dbg_chain[blockIdx.x % 8][0], g_dbg_chain[blockIdx.x % 8][2], g_dbg_chain[blockIdx.x % 8][1], g_dbg_chain[blockIdx.x % 8][3], M, cstate.n_ranges, t2 - t1, g_dbg_big[blockIdx.x % 8], g_dbg_small[blockIdx.x % 8], g_dbg_t[blockIdx.x % 8][0], g_dbg_t[blockIdx.x % 8][1], g_dbg_b[blockIdx.x % 8][0], g_dbg_b[blockIdx.x % 8][1], g_dbg_b[blockIdx.x % 8][2], g_dbg_b[blockIdx.x % 8][4], g_dbg_t[blockIdx.x % 8][2], t3 - t2, g_dbg_f[blockIdx.x % 8][0], g_dbg_f[blockIdx.x % 8][1], g_dbg_f[blockIdx.x % 8][2], g_dbg_f[blockIdx.x % 8][3], g_dbg_f[blockIdx.x % 8][4], g_dbg_f[blockIdx.x % 8][5], g_dbg_f[blockIdx.x % 8][6], g_dbg_f[blockIdx.x % 8][7], g_dbg_f[blockIdx.x % 8][8], g_dbg_f[blockIdx.x % 8][9], g_dbg_f[blockIdx.x % 8][10], g_dbg_w[blockIdx.x % 8][0], g_dbg_w[blockIdx.x % 8][1], g_dbg_w[blockIdx.x % 8][2], g_dbg_w[blockIdx.x % 8][4], g_dbg_w[blockIdx.x % 8][3]); }
 #endif
 }
 
@@ -1113,9 +1725,9 @@ __device__ __forceinline__ void plane_scan(uint32_t* lds, int words, int* wave_t
 __device__ __forceinline__ SeedWork seed_work(uint32_t* sa, uint32_t* sb, uint32_t* oa, uint32_t* ob, uint32_t* tt, size_t cap)
 {
     SeedWork W;
-    W.E = sa; W.V[0] = sa + cap;
-    W.V[1] = sb; W.P[0] = sb + cap;
-    W.P[1] = oa; W.PP = ob;
+    W.E = sa; W.V0 = sa + cap;
+    W.V1 = sb; W.P0 = sb + cap;
+    W.P1 = oa; W.PP = ob;
     W.T = tt; W.RT = tt + ((cap + 1) & ~(size_t)1);                   // (8-byte aligned: the row tables hold 64-bit ballots)
     W.dscratch = reinterpret_cast<unsigned long long*>(sb);
     W.out = oa;
@@ -1123,18 +1735,18 @@ __device__ __forceinline__ SeedWork seed_work(uint32_t* sa, uint32_t* sb, uint32
 }
 
 // plane_ok: the gradient image's bit plane fits the kernel's LDS
-__global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __restrict__ n_rec, const unsigned long long* __restrict__ maxgrad,
+__global__ __launch_bounds__(ST, 3) void k_lsd_seed32(LsdParams p, const int* __restrict__ n_rec, const unsigned long long* __restrict__ maxgrad,
                                                    const uint32_t* __restrict__ c_xy, const double* __restrict__ c_mod,
                                                    const uint32_t* __restrict__ l_addr, double* l_mod, const int* __restrict__ n_low,
                                                    unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
-                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b, int rows_cap, int plane_ok)
+                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b, int rows_cap, int plane_ok, int lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
     __shared__ int tot[SNB];
     __shared__ int base[SNB];
     __shared__ int wave_tot[SW];
     __shared__ int n_list;
-    const int pc = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int pc = blockIdx.x, t = threadIdx.x, lane = t & 63;
     const size_t Ps = (size_t)p.Hs * p.Ws;
     const size_t o = (size_t)pc * Ps;
     const int nd = n_rec[pc];
@@ -1172,8 +1784,8 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
             const uint32_t xy = c_xy[o + e];
             const int pos = (int)(xy >> 16) * Wg + (int)(xy & 0xffffu);
             const uint32_t idx = bitplane_rank(seed_lds, (size_t)n, pos);
-            W.P[0][idx] = (uint32_t)pos;
-            W.V[0][idx] = ((uint32_t)(int)(c_mod[o + e] * bin_coef) << 20) | (uint32_t)(e + 1);
+            W.P0[idx] = (uint32_t)pos;
+            W.V0[idx] = ((uint32_t)(int)(c_mod[o + e] * bin_coef) << 20) | (uint32_t)(e + 1);
         }
         for (int j = t; j < nl; j += ST) {
             const uint32_t a = l_addr[o + j];
@@ -1182,8 +1794,8 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
                 const int y = (int)(a / (uint32_t)p.Ws), x = (int)(a - (uint32_t)y * (uint32_t)p.Ws);
                 const int pos = y * Wg + x;
                 const uint32_t idx = bitplane_rank(seed_lds, (size_t)n, pos);
-                W.P[0][idx] = (uint32_t)pos;
-                W.V[0][idx] = (uint32_t)bin << 20;
+                W.P0[idx] = (uint32_t)pos;
+                W.V0[idx] = (uint32_t)bin << 20;
                 ++mine;
             }
         }
@@ -1193,8 +1805,8 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
     } else {
         // no plane: the low records (position << 10 | bin) sorted by position with counting passes in global memory, then merged
         // with the defined pixels by rank (binary searches)
-        uint32_t* LA = W.V[1];
-        uint32_t* LB = W.P[1];
+        uint32_t* LA = W.V1;
+        uint32_t* LB = W.P1;
         if (t == 0) n_list = 0;
         __syncthreads();
         // compaction of the records with a non-zero bin (order irrelevant: they are sorted next)
@@ -1230,28 +1842,28 @@ __global__ __launch_bounds__(ST) void k_lsd_seed32(LsdParams p, const int* __res
             const int pos = (int)(xy >> 16) * Wg + (int)(xy & 0xffffu);
             int x = 0, y = nlz;
             while (x < y) { const int mid = (x + y) >> 1; if ((int)(src[mid] >> 10) < pos) x = mid + 1; else y = mid; }
-            W.P[0][e + x] = (uint32_t)pos;
-            W.V[0][e + x] = ((uint32_t)(int)(c_mod[o + e] * bin_coef) << 20) | (uint32_t)(e + 1);
+            W.P0[e + x] = (uint32_t)pos;
+            W.V0[e + x] = ((uint32_t)(int)(c_mod[o + e] * bin_coef) << 20) | (uint32_t)(e + 1);
         }
         for (int j = t; j < nlz; j += ST) {
             const uint32_t it = src[j];
             const int pos = (int)(it >> 10);
             int x = 0, y = nd;
             while (x < y) { const int mid = (x + y) >> 1; const uint32_t xy = c_xy[o + mid]; if ((int)(xy >> 16) * Wg + (int)(xy & 0xffffu) < pos) x = mid + 1; else y = mid; }
-            W.P[0][j + x] = (uint32_t)pos;
-            W.V[0][j + x] = (it & 1023u) << 20;
+            W.P0[j + x] = (uint32_t)pos;
+            W.V0[j + x] = (it & 1023u) << 20;
         }
         __syncthreads();
     }
     const int m = nd + n_list;
     __syncthreads();
-    seed32_sort(W, n, m, nd, p.n_bins, seed_lds, rows_cap, tot, base);
+    seed32_sort(W, n, m, nd, p.n_bins, seed_lds, lds_words, rows_cap, tot, base);
 }
 
 // debug / test entry: std::sort(compare_norm) of n keys: E[i] = key << 20 | i + 1.  Elements with key 0 are the detector's flat
 // pixels: anonymous.  Leaves the elements with a non-zero key in out[0 .. count) in the order std::sort leaves them, as
 // (1023 - key) << 20 | i, and the count in *count.  work: 12 * cap words, cap = max(n, 1024) rounded up to 64.
-__global__ __launch_bounds__(ST) void k_std_sort_debug(const uint32_t* __restrict__ E, uint32_t* __restrict__ work, int n, int cap, int rows_cap, int* __restrict__ count)
+__global__ __launch_bounds__(ST, 3) void k_std_sort_debug(const uint32_t* __restrict__ E, uint32_t* __restrict__ work, int n, int cap, int rows_cap, int* __restrict__ count, int lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
     __shared__ int tot[SNB];
@@ -1276,23 +1888,28 @@ __global__ __launch_bounds__(ST) void k_std_sort_debug(const uint32_t* __restric
         const uint32_t v = i < n ? E[i] : 0u;
         const bool on = key_of(v) != 0u;
         const unsigned long long bb = __ballot(on);
-        if (on) { const int idx = rowc[r] + __popcll(bb & ((1ull << lane) - 1ull)); W.P[0][idx] = (uint32_t)i; W.V[0][idx] = v; }
+        if (on) { const int idx = rowc[r] + __popcll(bb & ((1ull << lane) - 1ull)); W.P0[idx] = (uint32_t)i; W.V0[idx] = v; }
     }
     __syncthreads();
     const int m = m_sh;
     if (t == 0) *count = m;
     if (m == 0) return;
-    seed32_sort(W, n, m, m, 1024, seed_lds, rows_cap, tot, base);
+    seed32_sort(W, n, m, m, 1024, seed_lds, lds_words, rows_cap, tot, base);
 }
 
-static size_t seed_lds_bytes(int rows_cap, size_t plane_words)
+// LDS of the kernels: what the dense phases need; plus, when they fit kPlaneLdsBytes, the two planes of a split over the whole array
+// (then the whole chain runs on planes; longer arrays start in the ordered form and change over once their range is short enough)
+constexpr size_t kPlaneLdsBytes = 56 * 1024;
+static size_t seed_lds_bytes(int rows_cap, long long n)
 {
     size_t words = (size_t)rows_cap * 6 + 128;
     if (words < (size_t)SW2 * kWaveWords) words = (size_t)SW2 * kWaveWords;
     if (words < (size_t)kBlkWords) words = (size_t)kBlkWords;
     if (words < (size_t)SNB * ST) words = (size_t)SNB * ST;
-    if (words < (size_t)kListLds + (size_t)(kListLds / 64) * 6 + 16) words = (size_t)kListLds + (size_t)(kListLds / 64) * 6 + 16;
-    if (words < plane_words) words = plane_words;
+    if (n < (1ll << 30)) {
+        const size_t two = 2 * (((size_t)plane_words_for((int)n) + 1) & ~(size_t)1);
+        if (two * 4 <= kPlaneLdsBytes && words < two) words = two;
+    }
     return words * sizeof(uint32_t);
 }
 
@@ -1317,13 +1934,13 @@ void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const
         const long long full = ((n + 63) / 64 + 1 + 63) / 64 * 64;
         if ((size_t)full * 24 + 512 <= (size_t)kMaxLdsBytes) rows_cap = (int)full;
     }
-    const size_t plane = bitplane_lds_words((size_t)n);
-    const int plane_ok = plane * 4 <= 24 * 1024;
-    const size_t lds = seed_lds_bytes(rows_cap, plane_ok ? plane : 0);
+    size_t lds = seed_lds_bytes(rows_cap, n);
+    { static const char* pad = getenv("LF_SEED_LDS_PAD"); if (pad) lds += (size_t)atoi(pad) * 1024; }      // experiment: how much the pipeline minds the kernel's LDS
+    const int plane_ok = bitplane_lds_words((size_t)n) * 4 <= lds;      // the list's initial order by ranks in a plane of the gradient image
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_lsd_seed32, dim3(n_frames * 3), dim3(ST), lds, s, p, n_rec, maxgrad, c_xy, c_mod, l_addr, l_mod, n_low,
-                       sort_a, sort_b, order_a, order_b, rows_cap, plane_ok);
+                       sort_a, sort_b, order_a, order_b, rows_cap, plane_ok, (int)(lds / 4));
 }
 
 // words of device scratch k_std_sort_debug needs for n elements
@@ -1333,10 +1950,10 @@ void launch_std_sort_debug(const uint32_t* E, uint32_t* work, int n, int* count,
 {
     const size_t cap = ((size_t)(n < 1024 ? 1024 : n) + 63) / 64 * 64;
     const int rows_cap = kRowsLds;
-    const size_t lds = seed_lds_bytes(rows_cap, 0);
+    const size_t lds = seed_lds_bytes(rows_cap, n);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_std_sort_debug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_std_sort_debug, dim3(1), dim3(ST), lds, s, E, work, n, (int)cap, rows_cap, count);
+    hipLaunchKernelGGL(k_std_sort_debug, dim3(1), dim3(ST), lds, s, E, work, n, (int)cap, rows_cap, count, (int)(lds / 4));
 }
 
 }  // namespace lf
