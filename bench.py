@@ -101,8 +101,12 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend; gloo (host staging) only to dry-run the N>1 path on a shared GPU")
     ap.add_argument("--depth", type=int, default=0, help="independent batches in flight (handles/streams); 0: 8 (6 until round 4)")
-    ap.add_argument("--seed-order", default="opencv30", choices=["opencv30", "opencv32"],
-                    help="LSD seed order inside a gradient bin (lf_config.lsd_seed_order): opencv32 = std::sort's, as on ROS Kinetic's 3.3.1")
+    ap.add_argument("--seed-order", default="opencv32", choices=["opencv30", "opencv32"],
+                    help="LSD seed order inside a gradient bin (lf_config.lsd_seed_order): opencv32 = std::sort's, as on ROS Kinetic's 3.3.1 "
+                         "(what the reference computes: the default); opencv30 = raster order, an A/B option")
+    ap.add_argument("--tie-rule", default="mihasher", choices=["mihasher", "lowest"],
+                    help="which of several equally near map entries the live map returns: mihasher = the one "
+                         "BinaryDescriptorMatcher::match finds first (the default), lowest = the lowest index (one pass, an A/B option)")
     ap.add_argument("--lsd-refine", type=int, default=2, help="diagnostic only: 0/1 skip refine / NFA stages (invalid as a headline run)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline (0 = auto, -1 = skip)")
     ap.add_argument("--secondary", default="auto", choices=["auto", "all", "none"],
@@ -180,7 +184,7 @@ def main():
     # (append-only like show_map.py:28-42, oldest entries overwritten).
     M = args.map + MAP_ROLL
     amap = LineAssociator(capacity=M, color_gating=False, max_distance=128, policy="append", kept_only=True,
-                          when_full="ring", device=local_rank)
+                          when_full="ring", device=local_rank, tie_rule=args.tie_rule)
     amap.seed(synth.random_codes(M, 1234))
     G = 16 * 1024                                    # segments per rank block; a batch with more raises (never truncates)
     sharded = ShardedAssociator(amap, block_segments=G, device=dev, backend=args.backend, force_collective=force)
@@ -364,7 +368,7 @@ def main():
                                    % ("BASELINE configs[4] frame size (optional stress mode): " if hd else "BASELINE configs[1]: ",
                                       B, in_cols, in_rows, uniq, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M, D),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0], "live_map": map_state,
-                       "lsd_seed_order": args.seed_order,
+                       "lsd_seed_order": args.seed_order, "tie_rule": args.tie_rule,
                        "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, one all-gather of segment blocks per step, replicated map" % world},
             "roofline": roofline,
@@ -432,6 +436,10 @@ def main():
         do_secondary = args.secondary == "all" or (args.secondary == "auto" and world == 1 and not force and args.geometry == "fullres")
         if do_secondary:
             result["secondary"] = secondary(args, torch, dev, local_rank, fes, ptrs, a_idx, a_dist, host, B, D, cap)
+            if args.seed_order == "opencv32" and args.tie_rule == "mihasher":
+                # the other configuration (OpenCV 3.0 / 3.1 seed order, lowest-index ties: NOT what the reference's stack computes),
+                # side by side: the same bench as a child process after this one's buffers are gone (below)
+                result["secondary"]["ab_opencv30_lowest"] = "pending"
     # The JSON line is the LAST thing on stdout: libraries that log through C stdio (RCCL prints its version banner
     # under NCCL_DEBUG=VERSION, buffered until exit when stdout is a pipe) are flushed on every rank first.
     import ctypes
@@ -445,6 +453,21 @@ def main():
     if multi:
         dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
+    if rank == 0 and isinstance(result.get("secondary"), dict) and result["secondary"].get("ab_opencv30_lowest") == "pending":
+        import subprocess
+        try:
+            torch.cuda.empty_cache()
+            out = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(max(20, args.steps)), "--warmup", str(args.warmup),
+                                  "--seed-order", "opencv30", "--tie-rule", "lowest", "--secondary", "none", "--cpu-frames", "-1",
+                                  "--batch", str(args.batch), "--map", str(args.map)], capture_output=True, text=True, timeout=600)
+            ab = json.loads(out.stdout.strip().splitlines()[-1])
+            result["secondary"]["ab_opencv30_lowest"] = {
+                "value": ab["value"], "unit": "frames/s", "ms_per_step": ab["ms_per_step"], "steps": ab["steps"],
+                "note": "lsd_seed_order = opencv30 (raster order inside a bin: OpenCV 3.0 / 3.1) and tie_rule = lowest (lowest map index): the "
+                        "A/B options, NOT the reference's behaviour (ROS Kinetic's OpenCV 3.3.1 orders seeds with std::sort; "
+                        "BinaryDescriptorMatcher::match returns the first-discovered candidate); same bench, child process, same GPU"}
+        except Exception as e:                                           # a measurement beside the headline: never fatal
+            result["secondary"]["ab_opencv30_lowest"] = {"error": str(e)[:200]}
     if rank == 0:
         print(json.dumps(result))
         sys.stdout.flush()

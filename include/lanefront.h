@@ -81,8 +81,10 @@ typedef struct lf_config {
      *   LF_LSD_SEED_OPENCV30  3.0 / 3.1: per-bin lists, raster order inside a gradient bin (one counting sort).
      *   LF_LSD_SEED_OPENCV32  3.2 ... 3.4.5 -- ROS Kinetic's 3.3.1, the stack the reference names (README.md:54): every pixel of
      *                         the gradient image sorted with std::sort(compare_norm); inside a bin the order is what libstdc++'s
-     *                         introsort leaves, reproduced on the device move for move (k_lsd_seed32.hip).  Working images up
-     *                         to 2^18 LSD pixels (640x480 and below); larger ones: LF_ERR_UNSUPPORTED at lf_create. */
+     *                         introsort leaves, reproduced on the device move for move (k_lsd_seed32.hip; any working image up
+     *                         to 2^21 LSD pixels since round 5).  THIS IS WHAT THE REFERENCE'S STACK COMPUTES: a caller that wants the
+     *                         reference's segments sets it (the Python mirror's default_config() and plugin classes do); the
+     *                         value 0 of a zeroed struct is the older order, kept as an A/B option. */
     int32_t lsd_seed_order;
     int32_t reserved0;             /* 0 */
 } lf_config;
@@ -197,8 +199,8 @@ int lf_detector_failures(const lf_handle* h);
  *   LF_TIE_MIHASHER  the reference's: the candidate Mihasher::query meets first (binary_descriptor_matcher.cpp:635-753) --
  *                    by search radius, then substring, then the position of the differing bits in its enumeration
  *                    (:681-741), then train index.  Costs a second matrix pass that ranks only the ties (k_assoc_ties.hip).
- *                    THE DEFAULT of lf_associate: it is what BinaryDescriptorMatcher::match returns.
- *   LF_TIE_LOWEST    the lowest map index; one pass.  The default of the live map (lf_map_*, this package's own contract).
+ *                    THE DEFAULT of lf_associate and of the live map (lf_map_*): it is what BinaryDescriptorMatcher::match returns.
+ *   LF_TIE_LOWEST    the lowest map index; one pass (an A/B option; the default of the live map until round 4).
  */
 #define LF_TIE_LOWEST 0
 #define LF_TIE_MIHASHER 1
@@ -316,7 +318,7 @@ int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_
  * on_device applies to all four arrays; with host arrays the call returns when idx / dist are in place. */
 int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, const uint8_t* color, int n,
                      int32_t* idx, float* dist, int on_device);
-/* tie rule of the map's associations (lf_map_associate, lf_map_step*): LF_TIE_LOWEST unless set; with LF_TIE_MIHASHER and
+/* tie rule of the map's associations (lf_map_associate, lf_map_step*): LF_TIE_MIHASHER unless set; with LF_TIE_MIHASHER and
  * colour gating the reference's discovery order applies among the entries the query may match */
 int lf_map_set_tie_rule(lf_map* m, int tie_rule);
 /* Device arrays of `segs` (frame_offset, code, color, keep, ground; capacity ignored) + idx / dist -> one block in
@@ -535,7 +537,9 @@ int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps);
 int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out);
 /* the sort emulation behind lsd_seed_order = LF_LSD_SEED_OPENCV32 alone: order[i] = index of the element that
  * std::sort(begin, end, [](a, b) { return a.key > b.key; }) of libstdc++ leaves at place i, for n keys in [0, 1023] in their
- * initial order (host pointers; n < 2^20) */
+ * initial order (host pointers; n < 2^20).  Elements with key 0 are the detector's flat pixels -- never seeds, anonymous on the
+ * device (the sparse form keeps only the non-zero keys): the elements with a non-zero key come first, in std::sort's order, the
+ * zero-key ones follow by index (std::sort leaves them behind the others too, in an order nothing observes) */
 int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order);
 /* scaled LSD image size for this handle */
 int lf_lsd_size(const lf_handle* h, int* rows, int* cols);

@@ -80,7 +80,10 @@ def default_config(geometry="parity", in_size=(480, 640)):
         "ai_shift": [0.0, 0.0, 0.0],
         "detector": copy.deepcopy(DEFAULT_DETECTOR_CONFIGURATION),
         "lsd": {"refine": 2, "scale": 0.8, "sigma_scale": 0.6, "quant": 2.0, "ang_th": 22.5,
-                "log_eps": 0.0, "density_th": 0.7, "n_bins": 1024},
+                "log_eps": 0.0, "density_th": 0.7, "n_bins": 1024,
+                # the seed order inside a gradient bin: "opencv32" = std::sort's (OpenCV 3.2 .. 3.4.5: the reference's ROS Kinetic
+                # ships 3.3.1), "opencv30" = raster order (3.0 / 3.1; about 0.3 ms less per 256-frame batch)
+                "seed_order": "opencv32"},
         "H": list(DEFAULT_HOMOGRAPHY), "K": list(DEFAULT_K), "D": list(DEFAULT_D),
         "R": list(DEFAULT_R), "P": list(DEFAULT_P),
         "cam_size": [480, 640],
@@ -143,7 +146,7 @@ def fill_struct(s, cfg):
     s.cam_h, s.cam_w = cfg["cam_size"]
     for k, v in cfg["sanity"].items():
         setattr(s, k, float(v))
-    order = lsd.get("seed_order", "opencv30")
+    order = lsd.get("seed_order", "opencv32")
     if order not in LSD_SEED_ORDERS:
         raise ValueError("lsd.seed_order must be one of %r" % (sorted(LSD_SEED_ORDERS),))
     s.lsd_seed_order = LSD_SEED_ORDERS[order]

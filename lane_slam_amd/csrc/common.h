@@ -198,14 +198,20 @@ __host__ __device__ inline uint32_t assoc_fp4_expand(uint32_t byte)
 }
 // per-caller scratch of the associator (k_assoc.hip): one key per query and map chunk + arrival counters; sized by
 // launch_assoc_core itself
-struct AssocScratch { unsigned int* part = nullptr; int* done = nullptr; size_t cap_part = 0, cap_blocks = 0; };
+struct AssocScratch {
+    unsigned int* part = nullptr; int* done = nullptr; size_t cap_part = 0, cap_blocks = 0;
+    // the last launch_assoc_core's split of the map (the tie pass reads part[] with it) and the tie pass's query lists
+    int qblocks = 0, splits = 0, m_chunk = 0;
+    int* tie_list = nullptr; size_t cap_list = 0;
+    unsigned long long* tie_res = nullptr;        // set by the caller before launch_assoc_core when launch_assoc_ties follows: the merge step then writes the tie pass's query lists
+};
 void assoc_scratch_free(AssocScratch& w);
 void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int fp4, int8_t* x, int8_t* cx, hipStream_t s);
 hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const int8_t* mcx, int nm,
                              const int* nm_dev, int gating, int max_distance, AssocScratch& w, int32_t* idx, float* dist, hipStream_t s);
 // the reference's tie rule as a second pass over the packed map (k_assoc_ties.hip); after launch_assoc_core on the same stream
 hipError_t launch_assoc_ties(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const uint8_t* mcode, const uint8_t* mcolor,
-                             int nm, const int* nm_dev, int gating, unsigned long long* res, int32_t* idx, const float* dist, hipStream_t s);
+                             int nm, const int* nm_dev, int gating, AssocScratch& w, unsigned long long* res, int32_t* idx, const float* dist, hipStream_t s);
 hipError_t launch_assoc(const uint8_t* q, int nq, const uint8_t* m, int nm, int8_t* mx, int8_t* mcx, AssocScratch& w, int32_t* idx,
                         float* dist, hipStream_t s);
 void launch_assoc_nomatch(int nq, int32_t* idx, float* dist, hipStream_t s);

@@ -96,7 +96,8 @@ __device__ __forceinline__ int q_expand(uint32_t nibble)
 
 template <int QW>
 __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int mine_q, int nq, int max_distance, unsigned int* __restrict__ part,
-                                                        int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+                                                        int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                                        int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     // The chunk's 256 keys go to this workgroup's row of part[] -- NOT atomicMin on a shared word per query: device-scope
     // atomics are executed at the memory side, 131 072 of them (16 k queries x 8 chunks) are slow however short the
@@ -114,6 +115,7 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
     LF_STAMP(5);
     if (!s_last) return;
     const int qq = blockIdx.x * AQW + threadIdx.x;
+    int best_ham = -1;                                                     // this query's reported distance (-1: none)
     if (qq < nq) {
         // eight rows in flight per thread: the merge is the serial tail of the launch (the last workgroup of the query block
         // runs it alone), a dependent load per chunk would cost a memory round trip each
@@ -132,7 +134,32 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
         for (; c < nc; ++c) v = min(v, __hip_atomic_load(col + (size_t)c * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         const int ham = (int)(v >> 22);
         if (v == 0x7fffffffu || ham > max_distance) { idx[qq] = -1; dist[qq] = -1.f; }
-        else { idx[qq] = (int)(v & 0x1fffffu); dist[qq] = (float)ham; }
+        else { idx[qq] = (int)(v & 0x1fffffu); dist[qq] = (float)ham; best_ham = ham; }
+    }
+    if (tie_pieces) {
+        // For the tie pass (k_assoc_ties.hip), in the same breath: per map chunk, the queries of this block whose best distance in the
+        // chunk IS their best distance overall -- a candidate as near as the optimum can sit nowhere else.  Wave w of the block
+        // writes them as piece (chunk, 4 blockIdx.x + w): up to 64 query numbers and a count (no atomics, no kernel of its own).
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const int n_pieces = gridDim.x * 4, piece = blockIdx.x * 4 + wv;
+        if (qq < nq) tie_res[qq] = ~0ull;
+        const unsigned int* col = part + (size_t)blockIdx.x * AQW + threadIdx.x;
+        const size_t stride = (size_t)gridDim.x * AQW;
+        const unsigned int nc = gridDim.y;
+        for (unsigned int c0 = 0; c0 < nc; c0 += 8) {
+            unsigned int t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = (c0 + k < nc && qq < nq) ? __hip_atomic_load(col + (size_t)(c0 + k) * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffffu;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned int c = c0 + k;
+                if (c >= nc) break;
+                const bool on = best_ham >= 0 && t[k] != 0x7fffffffu && (int)(t[k] >> 22) == best_ham;
+                const unsigned long long bo = __ballot(on);
+                if (lane == 0) tie_counts[(size_t)c * n_pieces + piece] = __popcll(bo);
+                if (on) tie_pieces[((size_t)c * n_pieces + piece) * 64 + __popcll(bo & ((1ull << lane) - 1ull))] = qq;
+            }
+        }
     }
     if (threadIdx.x == 0) __hip_atomic_store(done + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -150,7 +177,8 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
                                            const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                            int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
                                            int max_distance, unsigned int* __restrict__ part, int* __restrict__ done,
-                                           int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, int8_t* ctile, uint2* xtab)
+                                           int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, int8_t* ctile, uint2* xtab,
+                                           int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     // nm_bound sized the grid on the host; when the exact size is only known on the device (the live map's size
     // after an update still in flight) it is read here.  Rows in [size, bound) are all-zero operands and are dropped
@@ -274,7 +302,7 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
         }
     }
     LF_STAMP(4);
-    assoc_publish_and_merge<AQW>(mine, mine_q, nq, max_distance, part, done, idx, dist);
+    assoc_publish_and_merge<AQW>(mine, mine_q, nq, max_distance, part, done, idx, dist, tie_pieces, tie_counts, tie_res);
 }
 
 // The ungated kernel on the FP4 matrix instruction (k_assoc_loop.inc, LF_ASSOC_LOOP_FP4; gen_assoc_loop.py gen_fp4 has the
@@ -286,7 +314,8 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
                                                int max_distance, unsigned int* __restrict__ part, int* __restrict__ done,
                                                int32_t* __restrict__ idx, float* __restrict__ dist, int8_t* tile, int8_t* ctile,
-                                               uint32_t* xtab, uint32_t* ttab)
+                                               uint32_t* xtab, uint32_t* ttab,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     LF_STAMP(0); LF_STAMP(1);
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
@@ -404,41 +433,44 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
         }
     }
     LF_STAMP(4);
-    assoc_publish_and_merge<QW>(mine, mine_q, nq, max_distance, part, done, idx, dist);
+    assoc_publish_and_merge<QW>(mine, mine_q, nq, max_distance, part, done, idx, dist, tie_pieces, tie_counts, tie_res);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_fp4(const uint8_t* __restrict__ q, int nq, const int8_t* __restrict__ mx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
-                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[6 * AM * 128];     // six 8 KB tile buffers (gen_fp4 nbuf); the four key dumps reuse 32 KB of them
     __shared__ uint32_t xtab[256];
     __shared__ uint32_t ttab[1024];
-    assoc_body_fp4<false>(q, nullptr, nq, mx, nullptr, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab, ttab);
+    assoc_body_fp4<false>(q, nullptr, nq, mx, nullptr, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab, ttab, tie_pieces, tie_counts, tie_res);
 }
 
 // colour gated: one more matrix step per row block (gen_fp4 gated = True), the map's colour rows stream beside the tiles
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_fp4_gated(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
-                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[6 * AM * 128];
     __shared__ __attribute__((aligned(1024))) int8_t ctile[6 * AM * 32];
     __shared__ uint32_t xtab[256];
     __shared__ uint32_t ttab[1024];
-    assoc_body_fp4<true>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab, ttab);
+    assoc_body_fp4<true>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab, ttab, tie_pieces, tie_counts, tie_res);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
-                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];     // triple buffered map tile
     __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];     // the tiles' ninth-step operands
     __shared__ uint2 xtab[256];
-    assoc_body<true>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab);
+    assoc_body<true>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab, tie_pieces, tie_counts, tie_res);
 }
 
 // the same without colour gating: 8 MFMA steps per block (the block counter is the chain's start value), no ninth-step
@@ -446,11 +478,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_plain(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
-                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist)
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
 {
     __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 256];
     __shared__ uint2 xtab[256];
-    assoc_body<false>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab);
+    assoc_body<false>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab, tie_pieces, tie_counts, tie_res);
 }
 
 __global__ void k_fill_u32(unsigned int* p, size_t n, unsigned int v)
@@ -497,7 +530,8 @@ void assoc_scratch_free(AssocScratch& w)
 {
     if (w.part) (void)hipFree(w.part);
     if (w.done) (void)hipFree(w.done);
-    w.part = nullptr; w.done = nullptr; w.cap_part = 0; w.cap_blocks = 0;
+    if (w.tie_list) (void)hipFree(w.tie_list);
+    w.part = nullptr; w.done = nullptr; w.cap_part = 0; w.cap_blocks = 0; w.tie_list = nullptr; w.cap_list = 0;
 }
 
 void launch_assoc_pack_map(const uint8_t* codes, const uint8_t* colors, int n, int n_pad, int fp4, int8_t* x, int8_t* cx, hipStream_t s)
@@ -527,13 +561,30 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     splits = (nm_pad + m_chunk - 1) / m_chunk;
     hipError_t e = assoc_scratch_reserve(w, (size_t)qblocks, (size_t)splits, s);
     if (e != hipSuccess) return e;
+    w.qblocks = qblocks; w.splits = splits; w.m_chunk = m_chunk;
+    // the tie pass's lists are written by this launch's merge step when the caller asked for them (w.tie_res: the result words)
+    int *tie_pieces = nullptr, *tie_counts = nullptr;
+    if (w.tie_res) {
+        const size_t n_pieces = (size_t)qblocks * 4;
+        const size_t need = (size_t)splits * n_pieces * 64 + (size_t)splits * n_pieces;
+        if (need > w.cap_list) {
+            if (w.tie_list) (void)hipFree(w.tie_list);
+            w.tie_list = nullptr; w.cap_list = 0;
+            e = hipMalloc(&w.tie_list, (need + need / 2) * sizeof(int));
+            if (e != hipSuccess) return e;
+            w.cap_list = need + need / 2;
+        }
+        tie_pieces = w.tie_list;
+        tie_counts = w.tie_list + (size_t)splits * n_pieces * 64;
+    }
+    unsigned long long* tie_res = w.tie_res;
     // ungated: the FP4 kernel (its map operands are e2m1 rows: MapDevice::fp4 / launch_assoc_pack_map(fp4 = 1));
     // LF_ASSOC_INT8=1 keeps the int8 kernel for A/B runs -- the caller's operands must then be int8 rows
     static const bool force_i8 = getenv("LF_ASSOC_INT8") != nullptr;
-    if (gating && !force_i8) hipLaunchKernelGGL(k_assoc_fp4_gated, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
-    else if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
-    else if (!force_i8) hipLaunchKernelGGL(k_assoc_fp4, dim3(qblocks, splits), dim3(256), 0, s, q, nq, mx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
-    else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist);
+    if (gating && !force_i8) hipLaunchKernelGGL(k_assoc_fp4_gated, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
+    else if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
+    else if (!force_i8) hipLaunchKernelGGL(k_assoc_fp4, dim3(qblocks, splits), dim3(256), 0, s, q, nq, mx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
+    else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
 #ifdef LF_ASSOC_STAMPS
     {
         static int calls = 0;

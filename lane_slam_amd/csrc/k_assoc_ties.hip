@@ -15,6 +15,13 @@
 // accumulator value with its row's known optimum (one v_cmp per register, masks OR-ed on the scalar side), and only the
 // (rare) equal ones -- the ties -- leave the matrix pipeline: their discovery key is worked out from the query's raw code and
 // the map row's nibbles, both in LDS, and folded with a 64-bit atomic minimum (key << 32 | index), first in LDS, then once per query and map chunk in memory.
+//
+// Round 5: ONLY WHERE A TIE CAN BE.  The distance pass leaves, per query and map chunk, the chunk's best (distance, column) in
+// part[] (k_assoc.hip: assoc_publish_and_merge).  A candidate as near as the query's optimum can only sit in a chunk whose best
+// distance IS the optimum -- one chunk for most queries, two or three when the tie is real -- so the distance pass's merge step lists,
+// per chunk, the queries that have to look there (their row of part[] against their optimum), and the matrix pass here runs on those
+// (chunk, 256 listed queries) pieces alone: about 1 / (number of chunks) of the N x M products instead of all of them.  A chunk is
+// cut into `subs` pieces of whole tile groups so that the few pieces still fill the chip.
 #include "common.h"
 #include "mih_rank.h"
 
@@ -45,50 +52,50 @@ __device__ __forceinline__ uint32_t fp4_collapse(uint32_t w)
     return (t | (t >> 12)) & 0xffu;
 }
 
-// The lanes whose bit is set in `hits` hold, in accumulator register r, a candidate as near as its row's optimum: work out
-// its discovery key -- the smallest (weight, substring) over the 32 byte substrings, then ONE table lookup for the place of that
-// substring's difference in the enumeration -- from the query's raw code (LDS copy) and the map row's nibbles in the LDS tile,
-// and fold it into the query's running minimum.  Rare; kept out of line so the matrix loop stays small.
-template <bool GATED>
-__device__ __noinline__ void ties_fold(uint32_t hits, int col, int col_in_tile, int row_base, const uint8_t* tile, const uint32_t* qraw,
-                                       const uint8_t* __restrict__ qcolor, const uint8_t* __restrict__ mcolor, int q_first, int nq,
-                                       unsigned long long* s_res)
+// One candidate as near as its query's optimum: its discovery key -- the smallest (weight, substring) over the 32 byte substrings,
+// then ONE table lookup for the place of that substring's difference in the enumeration -- from the two raw codes, folded into the
+// query's result word with a 64-bit atomic minimum (key << 32 | index).  Round 5: the matrix loop only STAGES the candidates (a
+// pair of numbers each, in LDS); their keys are worked out at the next flush, one candidate per thread -- inside the matrix loop a
+// candidate cost ~500 instructions on one or two lanes of a wave, and since the pass only visits chunks that hold candidates
+// that was most of its time.
+__device__ __noinline__ void tie_eval(const uint8_t* __restrict__ q, const uint8_t* __restrict__ mcode, const uint8_t* __restrict__ qcolor,
+                                         const uint8_t* __restrict__ mcolor, bool gated, int qg, int col, unsigned long long* __restrict__ res)
 {
-    while (hits) {
-        const int r = __ffs(hits) - 1;
-        hits &= hits - 1;
-        const int ql = row_base + (r & 3) + 8 * (r >> 2);
-        const int qg = q_first + ql;
-        if (qg >= nq) continue;
-        if (GATED) {
-            const int qc = qcolor[qg], mc = mcolor[col];
-            if (qc < 3 && mc < 3 && qc != mc) continue;
-        }
-        uint32_t best = 0xffffffffu, bx = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {                            // 16-byte chunk c of the row's 128 bytes = code bytes 4 c .. 4 c + 3
-            const uint4 w = *reinterpret_cast<const uint4*>(tile + c * 1024 + col_in_tile * 16);
-            const uint32_t mb = fp4_collapse(w.x) | (fp4_collapse(w.y) << 8) | (fp4_collapse(w.z) << 16) | (fp4_collapse(w.w) << 24);
-            const uint32_t x = mb ^ qraw[ql * 8 + c];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const uint32_t xb = (x >> (8 * t)) & 255u;
-                const uint32_t hk = (uint32_t)__popc(xb) * 32u + (uint32_t)(4 * c + t);        // (weight, substring)
-                if (hk < best) { best = hk; bx = xb; }
-            }
-        }
-        const uint32_t h = best >> 5;
-        if (h > 4) continue;                                     // cannot happen within 128 bits; the reference would never meet it
-        const uint32_t key = (best << 8) | c_mih_rank.r[h][bx];
-        atomicMin(&s_res[ql], ((unsigned long long)key << 32) | (uint32_t)col);
+    if (gated) {
+        const int qc = qcolor[qg], mc = mcolor[col];
+        if (qc < 3 && mc < 3 && qc != mc) return;
     }
+    const uint4 a0 = *reinterpret_cast<const uint4*>(q + (size_t)qg * 32), a1 = *reinterpret_cast<const uint4*>(q + (size_t)qg * 32 + 16);
+    const uint4 b0 = *reinterpret_cast<const uint4*>(mcode + (size_t)col * 32), b1 = *reinterpret_cast<const uint4*>(mcode + (size_t)col * 32 + 16);
+    const uint32_t x[8] = { a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w, a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w };
+    uint32_t best = 0xffffffffu, bx = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint32_t xb = (x[c] >> (8 * t)) & 255u;
+            const uint32_t hk = (uint32_t)__popc(xb) * 32u + (uint32_t)(4 * c + t);        // (weight, substring)
+            if (hk < best) { best = hk; bx = xb; }
+        }
+    }
+    const uint32_t h = best >> 5;
+    if (h > 4) return;                                       // cannot happen within 128 bits; the reference would never meet it
+    const uint32_t key = (best << 8) | c_mih_rank.r[h][bx];
+    atomicMin(res + qg, ((unsigned long long)key << 32) | (uint32_t)col);
 }
 
+constexpr int THCAP = 256;        // candidates a workgroup stages in LDS between two flushes (one per thread of a flush)
+
+// Persistent workgroups over the WORK ITEMS of the pass: item = (map chunk c of the distance pass, slab of 256 of the queries
+// listed for c, piece of c's columns).  The lists come from the distance pass's merge step (k_assoc.hip: pieces of up to 64 query
+// numbers per (chunk, wave of a query block) and their counts); every workgroup adds the counts up for itself (a few thousand
+// words) -- no list kernel, no prefix kernel, no early-exit workgroups.
 template <bool GATED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_ties(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
-                                                    const int8_t* __restrict__ mx, const uint8_t* __restrict__ mcolor,
+                                                    const int8_t* __restrict__ mx, const uint8_t* __restrict__ mcode, const uint8_t* __restrict__ mcolor,
                                                     int nm_bound, const int* __restrict__ nm_dev,
-                                                    int nm_pad, int m_chunk, const float* __restrict__ dist,
+                                                    int nm_pad, int m_chunk, int splits, int subs, int sub_len, const int* __restrict__ pieces,
+                                                    const int* __restrict__ counts, int n_pieces, const float* __restrict__ dist,
                                                     unsigned long long* __restrict__ res)
 {
     // two buffers of TGROUP map tiles, filled by LDS-DMA (global_load_lds: 64 lanes x 16 bytes = 1 KB of a tile per instruction
@@ -97,121 +104,167 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ __attribute__((aligned(1024))) uint8_t tiles_a[TGROUP * 8192];
     __shared__ __attribute__((aligned(1024))) uint8_t tiles_b[TGROUP * 8192];
     __shared__ __attribute__((aligned(16))) uint32_t qraw[TQW * 8];
-    __shared__ unsigned long long s_res[TQW];
     __shared__ uint32_t xtab[256];
+    __shared__ int s_qid[TQW];
+    __shared__ int2 s_hits[THCAP];
+    __shared__ int s_nh;
+    __shared__ int s_items[129];          // items in front of chunk c (splits <= 128)
+    __shared__ int s_wsum[4];
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int q0 = blockIdx.x * TQW + wave * 64;
     const int r32 = lane & 31, half = lane >> 5;
-    const int m_begin = blockIdx.y * m_chunk;
-    const int m_end = min(nm_pad, m_begin + m_chunk);
-    const int n_tiles = __builtin_amdgcn_readfirstlane((m_end - m_begin) / 64);
-    if (n_tiles <= 0 || m_begin >= nm) return;
-    const uint8_t* src = reinterpret_cast<const uint8_t*>(mx) + (size_t)(m_begin / 64) * 8192;
-    const int n_groups = (n_tiles + TGROUP - 1) / TGROUP;
-    auto fetch = [&](int g, uint8_t* dst) {
-#pragma unroll
-        for (int k = 0; k < TGROUP * 2; ++k) {
-            const int off = k * 4096 + wave * 1024;
-            if (g * TGROUP + (off >> 13) < n_tiles)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * (TGROUP * 8192) + off + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
-        }
-    };
-    fetch(0, tiles_a);
+    int* s_pfx = reinterpret_cast<int*>(tiles_b);          // the current chunk's running piece counts: n_pieces + 1 words, gone before tiles_b is filled
     xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
-    s_res[threadIdx.x] = ~0ull;
-    {
-        // the workgroup's 256 raw query codes (8 KB): thread t copies query t
-        const int qi = blockIdx.x * TQW + threadIdx.x;
-        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-        if (qi < nq) { c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32); c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16); }
-        *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8]) = c0;
-        *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8 + 4]) = c1;
+    if (threadIdx.x == 0) s_nh = 0;
+    // ---- the items: chunk c has ceil(listed(c) / 256) slabs x subs pieces
+    for (int c = wave; c < splits; c += 4) {               // one wave per chunk adds its counts up
+        int tot = 0;
+        for (int p = lane; p < n_pieces; p += 64) tot += counts[(size_t)c * n_pieces + p];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+        if (lane == 0) s_items[c + 1] = ((tot + TQW - 1) / TQW) * subs;
     }
     __syncthreads();
-    // query operands: step s, k-half `half` = code dword 2 s + half, eight e2m1 nibbles per code byte (k_assoc.hip)
-    v8i A[2][4];
-    // Every chain STARTS at 0.5 - (the dot product a tie has = 256 - 2 * the row's minimum distance), so a tie ends at exactly
-    // +0.5, every other candidate at k + 0.5 with k a non-zero integer (all exact in f32), and rows without a match near -3e38.
-    // Read as unsigned integers, +0.5 (0x3f000000) is then the SMALLEST value an accumulator can hold -- positive floats order
-    // like their bit patterns, negative ones lie above them all -- so "is there a tie among these registers" is an unsigned
-    // minimum (v_min3_u32: two registers per instruction) and one compare, instead of a compare and a scalar OR per register.
-    v16f start[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-        const uint32_t* c = &qraw[(wave * 64 + 32 * b + r32) * 8];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const uint32_t w = c[2 * s + half];
-            A[b][s] = v8i{ (int)xtab[w & 0xffu], (int)xtab[(w >> 8) & 0xffu], (int)xtab[(w >> 16) & 0xffu], (int)xtab[w >> 24], 0, 0, 0, 0 };
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = q0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float d = qr < nq ? dist[qr] : -1.f;
-            start[b][r] = d >= 0.f ? 0.5f - (256.f - 2.f * d) : -3.0e38f;
-        }
-    }
-    // accumulator sets: (tile tl of the group, column block cb, row block b) -> 16 dot products per lane; the two row blocks of a
-    // column block share its fragments and run as two interleaved chains
-    auto dots2 = [&](const uint8_t* tiles, int tl, int cb, v16f& acc0, v16f& acc1) {
-        const uint8_t* fb = tiles + tl * 8192 + half * 1024 + (cb * 32 + r32) * 16;
-        acc0 = start[0]; acc1 = start[1];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const v4i f = *reinterpret_cast<const v4i*>(fb + s * 2048);
-            const v8i B = v8i{ f.x, f.y, f.z, f.w, 0, 0, 0, 0 };
-            acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0][s], B, acc0, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-            acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[1][s], B, acc1, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        }
-    };
+    if (threadIdx.x == 0) { s_items[0] = 0; for (int c = 0; c < splits; ++c) s_items[c + 1] += s_items[c]; }
+    __syncthreads();
+    const int n_items = s_items[splits];
     constexpr uint32_t kTie = 0x3f000000u;          // +0.5
-    auto umin16 = [](const v16f& a, uint32_t m) {
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) m = min(m, min(__float_as_uint(a[r]), __float_as_uint(a[r + 1])));
-        return m;
-    };
-    auto group = [&](int g, const uint8_t* tiles, uint8_t* next) {
-        if (g + 1 < n_groups) fetch(g + 1, next);
-        // the matrix loop proper: no branch inside -- which column blocks saw a tie anywhere in the wave is kept as a scalar bit mask
-        uint32_t sets = 0;
-#pragma unroll
-        for (int pair = 0; pair < TSETS / 2; ++pair) {
-            v16f acc0, acc1;
-            dots2(tiles, pair >> 1, pair & 1, acc0, acc1);
-            const uint32_t m = umin16(acc1, umin16(acc0, 0xffffffffu));
-            sets |= (__builtin_amdgcn_ballot_w64(m == kTie) != 0 ? 3u : 0u) << (2 * pair);
-        }
-        if (g * TGROUP + TGROUP > n_tiles) sets &= (1u << (4 * (n_tiles - g * TGROUP))) - 1u;      // a group's tiles past the chunk's end
-        if (sets) {
-            // candidates as near as their row's optimum (rare): recompute the set, find the registers, fold the keys
-#pragma unroll
-            for (int set = 0; set < TSETS; ++set) {
-                if (!(sets & (1u << set))) continue;
-                const int tl = set >> 2, cb = (set >> 1) & 1, b = set & 1;
-                v16f acc0, acc1;
-                dots2(tiles, tl, cb, acc0, acc1);
-                const v16f acc = b ? acc1 : acc0;
-                uint32_t hits = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) hits |= (__float_as_uint(acc[r]) == kTie ? 1u : 0u) << r;
-                const int col = m_begin + (g * TGROUP + tl) * 64 + cb * 32 + r32;
-                if (col >= nm) hits = 0;
-                if (__builtin_amdgcn_ballot_w64(hits != 0))
-                    ties_fold<GATED>(hits, col, cb * 32 + r32, wave * 64 + 32 * b + 4 * half, tiles + tl * 8192, qraw, qcolor, mcolor,
-                                     blockIdx.x * TQW, nq, s_res);
-            }
-        }
+    // the staged candidates' discovery keys, one candidate per thread
+    auto flush = [&]() {
+        const int n = min(s_nh, THCAP);
+        if ((int)threadIdx.x < n) { const int2 hpair = s_hits[threadIdx.x]; tie_eval(q, mcode, qcolor, mcolor, GATED, hpair.x, hpair.y, res); }
+        __syncthreads();
+        if (threadIdx.x == 0) s_nh = 0;
         __syncthreads();
     };
-    for (int g = 0; g < n_groups; g += 2) {
-        group(g, tiles_a, tiles_b);
-        if (g + 1 < n_groups) group(g + 1, tiles_b, tiles_a);
+    for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+        int chunk = 0;
+        while (s_items[chunk + 1] <= item) ++chunk;
+        const int rel = item - s_items[chunk];
+        const int slab = rel / subs, piece = rel - slab * subs;
+        const int m_begin = chunk * m_chunk + piece * sub_len;
+        const int m_end = min(min(nm_pad, (chunk + 1) * m_chunk), m_begin + sub_len);
+        const int n_tiles = __builtin_amdgcn_readfirstlane((m_end - m_begin) / 64);
+        if (n_tiles <= 0 || m_begin >= nm) continue;
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(mx) + (size_t)(m_begin / 64) * 8192;
+        const int n_groups = (n_tiles + TGROUP - 1) / TGROUP;
+        auto fetch = [&](int g, uint8_t* dst) {
+#pragma unroll
+            for (int k = 0; k < TGROUP * 2; ++k) {
+                const int off = k * 4096 + wave * 1024;
+                if (g * TGROUP + (off >> 13) < n_tiles)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)g * (TGROUP * 8192) + off + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(dst + off), 16, 0, 0);
+            }
+        };
+        fetch(0, tiles_a);
+        // the chunk's running piece counts (workgroup scan), then the slab's queries: listed query number li sits in the last piece
+        // whose running count is <= li
+        {
+            const int* cnt = counts + (size_t)chunk * n_pieces;
+            int carry = 0;
+            for (int p0 = 0; p0 < n_pieces; p0 += 256) {
+                const int p = p0 + threadIdx.x;
+                const int v = p < n_pieces ? cnt[p] : 0;
+                int inc = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int n = __shfl_up(inc, d); if (lane >= d) inc += n; }
+                if (lane == 63) s_wsum[wave] = inc;
+                __syncthreads();
+                int base = carry;
+                for (int k = 0; k < wave; ++k) base += s_wsum[k];
+                if (p < n_pieces) s_pfx[p] = base + inc - v;
+                carry += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) s_pfx[n_pieces] = carry;
+            __syncthreads();
+            const int n_listed = s_pfx[n_pieces];
+            const int li = slab * TQW + threadIdx.x;
+            int qi = -1;
+            if (li < n_listed) {
+                int x = 0, y = n_pieces;
+                while (y - x > 1) { const int mid = (x + y) >> 1; if (s_pfx[mid] <= li) x = mid; else y = mid; }
+                qi = pieces[((size_t)chunk * n_pieces + x) * 64 + (li - s_pfx[x])];
+            }
+            s_qid[threadIdx.x] = qi;
+            uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+            if (qi >= 0) { c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32); c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16); }
+            *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8]) = c0;
+            *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8 + 4]) = c1;
+        }
+        __syncthreads();
+        // query operands: step s, k-half `half` = code dword 2 s + half, eight e2m1 nibbles per code byte (k_assoc.hip)
+        v8i A[2][4];
+        // Every chain STARTS at 0.5 - (the dot product a tie has = 256 - 2 * the row's minimum distance), so a tie ends at exactly
+        // +0.5 (0x3f000000), every other candidate at k + 0.5 with k a non-zero integer (all exact in f32), rows without a match near -3e38.
+        v16f start[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const uint32_t* c = &qraw[(wave * 64 + 32 * b + r32) * 8];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const uint32_t w = c[2 * s + half];
+                A[b][s] = v8i{ (int)xtab[w & 0xffu], (int)xtab[(w >> 8) & 0xffu], (int)xtab[(w >> 16) & 0xffu], (int)xtab[w >> 24], 0, 0, 0, 0 };
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qr = s_qid[wave * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half];
+                const float d = qr >= 0 ? dist[qr] : -1.f;
+                start[b][r] = d >= 0.f ? 0.5f - (256.f - 2.f * d) : -3.0e38f;
+            }
+        }
+        // accumulator sets: (tile tl of the group, column block cb, row block b) -> 16 dot products per lane; the two row blocks of a
+        // column block share its fragments and run as two interleaved chains
+        auto dots2 = [&](const uint8_t* tiles, int tl, int cb, v16f& acc0, v16f& acc1) {
+            const uint8_t* fb = tiles + tl * 8192 + half * 1024 + (cb * 32 + r32) * 16;
+            acc0 = start[0]; acc1 = start[1];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v4i f = *reinterpret_cast<const v4i*>(fb + s * 2048);
+                const v8i B = v8i{ f.x, f.y, f.z, f.w, 0, 0, 0, 0 };
+                acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0][s], B, acc0, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[1][s], B, acc1, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            }
+        };
+        auto group = [&](int g, const uint8_t* tiles, uint8_t* next) {
+            if (g + 1 < n_groups) fetch(g + 1, next);
+            const int tiles_here = min(TGROUP, n_tiles - g * TGROUP);
+#pragma unroll
+            for (int pair = 0; pair < TSETS / 2; ++pair) {
+                const int tl = pair >> 1, cb = pair & 1;
+                if (tl >= tiles_here) break;                                    // a group's tiles past the piece's end
+                v16f acc0, acc1;
+                dots2(tiles, tl, cb, acc0, acc1);
+                const int col = m_begin + (g * TGROUP + tl) * 64 + cb * 32 + r32;
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    uint32_t hits = 0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hits |= (__float_as_uint(b ? acc1[r] : acc0[r]) == kTie ? 1u : 0u) << r;
+                    if (col >= nm) hits = 0;
+                    if (__builtin_amdgcn_ballot_w64(hits != 0)) {
+                        while (hits) {
+                            const int r = __ffs(hits) - 1;
+                            hits &= hits - 1;
+                            const int qg = s_qid[wave * 64 + 32 * b + 4 * half + (r & 3) + 8 * (r >> 2)];
+                            if (qg < 0) continue;
+                            const int pos = atomicAdd(&s_nh, 1);
+                            if (pos < THCAP) s_hits[pos] = make_int2(qg, col);
+                            else tie_eval(q, mcode, qcolor, mcolor, GATED, qg, col, res);      // (the stage is full: on the spot)
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_nh > THCAP / 2) flush();                                      // (uniform: read after the barrier)
+        };
+        for (int g = 0; g < n_groups; g += 2) {
+            group(g, tiles_a, tiles_b);
+            if (g + 1 < n_groups) group(g + 1, tiles_b, tiles_a);
+        }
+        flush();
     }
-    const unsigned long long mine = s_res[threadIdx.x];
-    const int qg = blockIdx.x * TQW + threadIdx.x;
-    if (mine != ~0ull && qg < nq) atomicMin(res + qg, mine);
 }
 
 __global__ void k_assoc_ties_finish(int nq, const unsigned long long* __restrict__ res, int32_t* __restrict__ idx)
@@ -226,23 +279,29 @@ __global__ void k_assoc_ties_finish(int nq, const unsigned long long* __restrict
 // reference's search finds first.  mx: the map's packed e2m1 rows (the raw bits are read back from them); mcolor: the map's raw
 // colours (gating only; mcode is not read).  res: nq u64.
 hipError_t launch_assoc_ties(const uint8_t* q, const uint8_t* qcolor, int nq, const int8_t* mx, const uint8_t* mcode, const uint8_t* mcolor,
-                             int nm, const int* nm_dev, int gating, unsigned long long* res, int32_t* idx, const float* dist, hipStream_t s)
+                             int nm, const int* nm_dev, int gating, AssocScratch& w, unsigned long long* res, int32_t* idx, const float* dist, hipStream_t s)
 {
     if (nq <= 0 || nm <= 0) return hipSuccess;
     const int nm_pad = (int)assoc_rows_padded_m(nm);
-    const int tiles = nm_pad / 64;
     const int qblocks = (nq + TQW - 1) / TQW;
-    // two workgroups fit a CU (32 KB of tiles each): about two rounds of the chip, chunks of whole tile groups
-    int splits = 1024 / qblocks;
-    if (splits < 1) splits = 1;
-    if (splits > (tiles + TGROUP - 1) / TGROUP) splits = (tiles + TGROUP - 1) / TGROUP;
-    int m_chunk = (tiles + splits - 1) / splits;
-    m_chunk = (m_chunk + TGROUP - 1) / TGROUP * TGROUP * 64;
-    splits = (nm_pad + m_chunk - 1) / m_chunk;
-    hipError_t e = hipMemsetAsync(res, 0xff, (size_t)nq * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
-    if (gating) hipLaunchKernelGGL(k_assoc_ties<true>, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcolor, nm, nm_dev, nm_pad, m_chunk, dist, res);
-    else hipLaunchKernelGGL(k_assoc_ties<false>, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcolor, nm, nm_dev, nm_pad, m_chunk, dist, res);
+    const int splits = w.splits, m_chunk = w.m_chunk;                      // the distance pass's split of the map: its lists are laid out by it
+    // the distance pass must have been launched with w.tie_res = res: its merge step wrote the lists and reset the result words
+    if (splits < 1 || splits > 128 || w.qblocks != qblocks || w.tie_res != res || !w.tie_list) return hipErrorInvalidValue;
+    if ((size_t)qblocks * 4 + 1 > (size_t)TGROUP * 8192 / 4) return hipErrorInvalidValue;      // (the running piece counts of a chunk sit in one tile buffer: 2^19 queries per call)
+    const int n_pieces = qblocks * 4;
+    const int* pieces = w.tie_list;
+    const int* counts = w.tie_list + (size_t)splits * n_pieces * 64;
+    // every listed (chunk, slab) is cut into pieces of whole tile groups: about 1.5 nq / 256 slabs in all, 512 workgroup slots
+    const int tiles_chunk = m_chunk / 64;
+    int subs = (768 + qblocks + qblocks / 2 - 1) / (qblocks + qblocks / 2);
+    if (subs > (tiles_chunk + TGROUP - 1) / TGROUP) subs = (tiles_chunk + TGROUP - 1) / TGROUP;
+    if (subs < 1) subs = 1;
+    int sub_len = (tiles_chunk + subs - 1) / subs;
+    sub_len = (sub_len + TGROUP - 1) / TGROUP * TGROUP * 64;
+    subs = (m_chunk + sub_len - 1) / sub_len;
+    const int grid = 512;
+    if (gating) hipLaunchKernelGGL(k_assoc_ties<true>, dim3(grid), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, splits, subs, sub_len, pieces, counts, n_pieces, dist, res);
+    else hipLaunchKernelGGL(k_assoc_ties<false>, dim3(grid), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, splits, subs, sub_len, pieces, counts, n_pieces, dist, res);
     hipLaunchKernelGGL(k_assoc_ties_finish, dim3((nq + 255) / 256), dim3(256), 0, s, nq, res, idx);
     return hipGetLastError();
 }

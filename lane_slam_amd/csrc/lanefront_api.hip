@@ -940,9 +940,10 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
     }
     {
         StageTimer t(h, ST_ASSOC);
+        h->a_ws.tie_res = h->tie_rule == LF_TIE_MIHASHER ? static_cast<unsigned long long*>(h->a_best.p) : nullptr;      // (the distance pass then lists the queries of the tie pass)
         LF_HIP_CHECK(h, launch_assoc(dq, nq, dmp, nm, (int8_t*)h->a_mx.p, (int8_t*)h->a_mcx.p, h->a_ws, didx, ddist, s));
         if (h->tie_rule == LF_TIE_MIHASHER)
-            LF_HIP_CHECK(h, launch_assoc_ties(dq, nullptr, nq, (const int8_t*)h->a_mx.p, dmp, nullptr, nm, nullptr, 0,
+            LF_HIP_CHECK(h, launch_assoc_ties(dq, nullptr, nq, (const int8_t*)h->a_mx.p, dmp, nullptr, nm, nullptr, 0, h->a_ws,
                                               static_cast<unsigned long long*>(h->a_best.p), didx, ddist, s));
     }
     LF_HIP_CHECK(h, hipGetLastError());

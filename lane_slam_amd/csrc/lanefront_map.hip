@@ -265,6 +265,9 @@ extern "C" int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** o
     m->d.capacity = cfg->capacity; m->d.policy = cfg->policy; m->d.kept_only = cfg->kept_only;
     m->d.merge_distance = cfg->merge_distance; m->d.when_full = cfg->when_full;
     m->d.fp4 = getenv("LF_ASSOC_INT8") ? 0 : 1;          // e2m1 operands for the FP4 matrix instruction (int8 rows only for A/B runs)
+    // the reference's tie rule is the default (round 5); the int8 A/B kernels have no tie pass: the lowest index there, said once
+    m->tie_rule = m->d.fp4 ? LF_TIE_MIHASHER : LF_TIE_LOWEST;
+    if (!m->d.fp4) { static bool told = false; if (!told) { told = true; fprintf(stderr, "lanefront: LF_ASSOC_INT8 is set: the live map falls back to LF_TIE_LOWEST (the int8 A/B kernels have no tie pass)\n"); } }
     *out = m;
     return LF_OK;
 }
@@ -395,11 +398,12 @@ extern "C" int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, 
         {
             // one launch: query operands are expanded in registers, results are written by the last workgroup to arrive
             MapTimer t(m, 1);
+            m->ws.tie_res = m->tie_rule == LF_TIE_MIHASHER ? static_cast<unsigned long long*>(m->tie_res.p) : nullptr;
             MAP_HIP(m, launch_assoc_core(dq, m->cfg.color_gating ? dc : nullptr, n, m->d.mx, m->d.mcx, size, m->d.state, m->cfg.color_gating,
                                          m->cfg.max_distance, m->ws, didx, ddist, s));
             if (m->tie_rule == LF_TIE_MIHASHER)       // second pass: among the equally near entries, the one the reference's search meets first
                 MAP_HIP(m, launch_assoc_ties(dq, m->cfg.color_gating ? dc : nullptr, n, m->d.mx, m->d.code, m->d.color, size, m->d.state,
-                                             m->cfg.color_gating, static_cast<unsigned long long*>(m->tie_res.p), didx, ddist, s));
+                                             m->cfg.color_gating, m->ws, static_cast<unsigned long long*>(m->tie_res.p), didx, ddist, s));
         }
     }
     MAP_HIP(m, hipGetLastError());

@@ -21,7 +21,7 @@ _WHEN_FULL = {"ring": 0, "error": 1}
 
 class LineAssociator(object):
     def __init__(self, capacity=65536, color_gating=False, max_distance=128, policy="append", kept_only=True,
-                 merge_distance=0, when_full="ring", device=0, tie_rule="lowest"):
+                 merge_distance=0, when_full="ring", device=0, tie_rule="mihasher"):
         self.lib = _lib.load()
         if tie_rule not in _lib.TIE_RULES:
             raise ValueError("tie_rule must be one of %r" % (sorted(_lib.TIE_RULES),))
@@ -38,8 +38,7 @@ class LineAssociator(object):
             self.m = None
             from .frontend import LanefrontError
             raise LanefrontError(rc, msg)
-        if tie_rule != "lowest":
-            self._check(self.lib.lf_map_set_tie_rule(self.m, _lib.TIE_RULES[tie_rule]))
+        self._check(self.lib.lf_map_set_tie_rule(self.m, _lib.TIE_RULES[tie_rule]))
 
     def close(self):
         if getattr(self, "m", None):

@@ -39,7 +39,7 @@ class LineDetectorInterface(object):
 
 
 class LineDetectorHIP(LineDetectorInterface):
-    def __init__(self, configuration, device=0, max_lines_per_color=2048, lsd_seed_order="opencv30"):
+    def __init__(self, configuration, device=0, max_lines_per_color=2048, lsd_seed_order="opencv32"):
         """configuration: the reference's 13 keys (line_detector_lsd.py:20-34), nothing else.  lsd_seed_order (keyword, not a
         configuration key): "opencv30" or "opencv32" -- which OpenCV's LSD seed order inside a gradient bin (lf_config.lsd_seed_order;
         ROS Kinetic's 3.3.1 is "opencv32")."""

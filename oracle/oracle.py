@@ -91,7 +91,7 @@ def _struct_from_dict(cfg):
     s.cam_h, s.cam_w = cfg["cam_size"]
     for k, v in cfg["sanity"].items():
         setattr(s, k, float(v))
-    s.lsd_seed_order = {"opencv30": 0, "opencv32": 1}[lsd.get("seed_order", "opencv30")]
+    s.lsd_seed_order = {"opencv30": 0, "opencv32": 1}[lsd.get("seed_order", "opencv32")]
     return s
 
 
@@ -476,7 +476,7 @@ class OracleMap(object):
     lane_slam_amd.LineAssociator."""
 
     def __init__(self, capacity=65536, color_gating=False, max_distance=128, policy="append", kept_only=True,
-                 merge_distance=0, when_full="ring", tie_rule="lowest"):
+                 merge_distance=0, when_full="ring", tie_rule="mihasher"):
         build()
         self.lib = ctypes.CDLL(_SO)
         self.lib.lfo_map_create.restype = ctypes.c_void_p

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 FIELDS = ("start_end", "in_octave", "angle", "num_pixels", "line_length", "octave", "class_id", "response", "size", "pt")
 
 
-def _check(k, gray, n_octaves, seed_order="opencv30"):
+def _check(k, gray, n_octaves, seed_order="opencv32"):
     total = 0
     for f in range(gray.shape[0]):
         r = O.lsd_octave_keylines(gray[f], n_octaves, seed_order=seed_order)

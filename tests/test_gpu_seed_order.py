@@ -104,6 +104,7 @@ def test_segments_under_the_opencv32_seed_order(geometry, n):
     cfg = default_config(geometry)
     cfg["lsd"]["seed_order"] = "opencv32"
     cfg30 = default_config(geometry)
+    cfg30["lsd"]["seed_order"] = "opencv30"                  # the A/B option (the default is opencv32 since round 5)
     frames = synth.make_batch(n, seed0=700)
     rng = np.random.default_rng(77)
     busy = frames[0].copy()

@@ -9,7 +9,27 @@ import subprocess
 import numpy as np
 import pytest
 
-from lane_slam_amd import default_config, synth
+from lane_slam_amd import default_config as _default_config, synth
+
+
+def default_config(*a, **k):
+    """The harness hands the growing code its seeds in raster order inside a bin (the OpenCV 3.0 order: the growing logic under test
+    does not depend on which order it is given) -- so the oracle it is compared with runs that order too."""
+    cfg = _default_config(*a, **k)
+    cfg["lsd"]["seed_order"] = "opencv30"
+    return cfg
+
+
+@pytest.fixture(scope="module")
+def oracle_parity():
+    from oracle.oracle import Oracle
+    return Oracle(default_config("parity"))
+
+
+@pytest.fixture(scope="module")
+def oracle_fullres():
+    from oracle.oracle import Oracle
+    return Oracle(default_config("fullres"))
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -29,8 +29,13 @@ def test_ungated_association_is_the_matcher():
     q = _codes(rng, 80)
     q[:20] = [_flip(codes[i], rng.choice(256, size=i, replace=False)) for i in range(20)]
     i1, d1 = m.associate(q)
-    i2, d2 = o.match(q, codes)
+    i2, d2, _ = o.match_mih(q, codes)                        # the map's default tie rule is the matcher's (Mihasher::query's first-found)
     assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    low = OracleMap(capacity=512, tie_rule="lowest")
+    low.seed(codes)
+    i3, d3 = low.associate(q)
+    i4, d4 = o.match(q, codes)
+    assert np.array_equal(i3, i4) and np.array_equal(d3, d4)
     assert m.state()["size"] == 300 and m.state()["head"] == 300
 
 

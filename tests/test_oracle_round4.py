@@ -24,7 +24,7 @@ def test_map_tie_rule_switch_equals_the_matcher_restatement():
     wi, wd, ties = o.match_mih(q, m)
     li, ld = o.match(q, m)
     a = O.OracleMap(capacity=2048, kept_only=False, tie_rule="mihasher")
-    b = O.OracleMap(capacity=2048, kept_only=False)
+    b = O.OracleMap(capacity=2048, kept_only=False, tie_rule="lowest")
     a.seed(m); b.seed(m)
     gi, gd = a.associate(q)
     assert np.array_equal(gi, wi) and np.array_equal(gd, wd)

@@ -126,6 +126,7 @@ def test_census_of_the_two_deviations_on_bench_like_input():
     changed, total, seg_changed, seg_total = 0, 0, 0, 0
     for geometry, n in (("parity", 30), ("fullres", 6)):
         c2 = default_config(geometry)
+        c2["lsd"]["seed_order"] = "opencv30"          # the switch below turns the std::sort order on and off
         o2 = Oracle(c2)
         for f in synth.make_batch(n, seed0=700):
             o2.set_lsd_seed_order(0)
