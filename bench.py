@@ -780,7 +780,7 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
     stress = []
     rng = np.random.default_rng(1234)
     mcodes = synth.random_codes(50000, 1234)
-    am = LineAssociator(capacity=50048, color_gating=False, kept_only=False, device=device_id)
+    am = LineAssociator(capacity=50048, color_gating=False, kept_only=False, device=device_id, tie_rule="lowest")       # the distance pass alone
     am.seed(mcodes)
     # the same map with the reference's tie rule (LF_TIE_MIHASHER: a second matrix pass that ranks the equally near entries)
     am_mih = LineAssociator(capacity=50048, color_gating=False, kept_only=False, device=device_id, tie_rule="mihasher")

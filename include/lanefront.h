@@ -233,6 +233,28 @@ int lf_select_queries(lf_handle* h, const uint8_t* query32, int nq, const uint8_
 int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, float max_distance,
                     int32_t* offsets, int32_t* idx, float* dist, int cap, int* total, int on_device);
 
+/* BinaryDescriptorMatcher's DATASET form (binary_descriptor_matcher.cpp:70-111 add / train / clear, :117-195 match, :339-425
+ * knnMatch, :508-595 radiusMatch): the descriptors of several train images are added one matrix at a time and searched as ONE set;
+ * every DMatch says which image it came from.  As in the reference: trainIdx is the row number IN THE SET (not rebased to the
+ * image), imgIdx the image whose rows hold it (indexesMap.upper_bound - 1, including std::map::insert's refusal to overwrite: an
+ * image added right after an EMPTY one is reported under the empty one's number), and masks[imgIdx][query] == 0 drops a match
+ * AFTER the search (it does not steer the search).  masks: NULL, or one pointer per added image (NULL = all ones) to nq bytes.
+ * The searches are lf_associate / lf_knn_match / lf_radius_match on the set, with the handle's tie rule; host arrays; blocking.
+ *   lf_matcher_match         out [<= nq]; *n_out matches (queries without a code within 128 bits make none)
+ *   lf_matcher_knn_match     lists per query: list_offsets [nq + 1], out [<= nq k]; compact_result != 0 drops the empty lists
+ *                            (*n_lists of them remain; without it list i is query i's)
+ *   lf_matcher_radius_match  the same with every code within max_distance; *total = the matches the search found before the masks;
+ *                            LF_ERR_CAPACITY when total > cap (size the arrays and call again) */
+typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } lf_dmatch;
+int lf_matcher_add(lf_handle* h, const uint8_t* codes32, int n, int on_device);
+int lf_matcher_clear(lf_handle* h);
+int lf_matcher_size(const lf_handle* h, int* n_images, int* n_descriptors);
+int lf_matcher_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* const* masks, lf_dmatch* out, int* n_out);
+int lf_matcher_knn_match(lf_handle* h, const uint8_t* query32, int nq, int k, const uint8_t* const* masks, int compact_result,
+                         int32_t* list_offsets, lf_dmatch* out, int* n_lists);
+int lf_matcher_radius_match(lf_handle* h, const uint8_t* query32, int nq, float max_distance, const uint8_t* const* masks,
+                            int compact_result, int32_t* list_offsets, lf_dmatch* out, int cap, int* n_lists, int* total);
+
 /* Anti-instagram colour clustering (k-means part).  Replaces
  *   anti_instagram/kmeans.py:22-47  runKMeans(cv_img, num_colors, init)
  * = sklearn.cluster.KMeans(n_clusters, max_iter, init = <array>).fit_predict on B, G, R points + cluster_centers_, label
@@ -420,6 +442,25 @@ int lf_keylines_frame_status(lf_handle* h, int32_t* frame_status, int n_frames);
  * lines than max_lines_per_color. */
 int lf_lsd_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                           lf_keylines* out, int out_on_device, int describe, int* n_keylines);
+/* The fork's own overloads of the same detector (the reason its files are called _custom): LSDDetectorC::detect(image, keylines,
+ * scale, numOctaves, LSDOptions, mask) and detectFast -- LSDDetector_custom.cpp:218-325 and :327-438 are the same text -- i.e. the
+ * caller's parameters for cv::createLineSegmentDetector (descriptor_custom.hpp:906-916), `length > opts.min_length` (:277; class_id
+ * counts the kept lines), and the mask argument (:203-213, :312-322): KeyLines whose two end points (image coordinates, truncated)
+ * BOTH lie on zero mask pixels are erased.
+ *   opts   NULL = lf_lsd_keylines_batch (OpenCV's defaults, no length test)
+ *   masks  NULL, or n_frames images of the handle's WORKING size [rows][cols] u8
+ * With lsd_seed_order = LF_LSD_SEED_OPENCV32: (n_bins - 1) * quant / sin(ang_th) >= 361 (a pixel with a defined gradient must not
+ * fall into bin 0), else LF_ERR_UNSUPPORTED. */
+typedef struct {
+    int32_t refine;              /* cv::LSD_REFINE_NONE 0, _STD 1, _ADV 2 */
+    int32_t n_bins;
+    double scale, sigma_scale, quant, ang_th, log_eps, density_th;
+    double min_length;
+} lf_lsd_options;
+void lf_lsd_default_options(lf_lsd_options* opts);      /* createLineSegmentDetector()'s: 1, 1024, 0.8, 0.6, 2.0, 22.5, 0, 0.7; min_length 0 */
+int lf_lsd_keylines_batch_ex(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+                             const lf_lsd_options* opts, const uint8_t* masks, int masks_on_device,
+                             lf_keylines* out, int out_on_device, int describe, int* n_keylines);
 /* Plugin path with the EDLines detector: lf_set_image_edlines, then lf_detect_lines exactly as after lf_set_image.
  * The reference has ONE LineDetectorInterface implementation working on colour masks (LineDetectorLSD,
  * line_detector_lsd.py:11-142); this is the package's second (SURVEY 8f-4 "alternative detector plugin") and its

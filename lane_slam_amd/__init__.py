@@ -7,6 +7,7 @@ The package is a thin host-side mirror of the reference's interfaces for this pa
                         describe_keylines <-> BinaryDescriptor::detect / compute with octaves (SURVEY 8f-4)
   LineAssociator   <->  line_associator node (a stub in the reference) + show_map's segment store: device-resident
                         live map, MFMA Hamming association, colour gating, append / merge updates (lf_map_*)
+  BinaryDescriptorMatcher <-> the matcher's dataset form (add / train / match / knnMatch / radiusMatch over several train images, imgIdx)
   FrontEnd         <->  batch form of line_detector_node / ground_projection_node /
                         line_sanity_node callbacks + BinaryDescriptor / BinaryDescriptorMatcher
 There is no CPU fallback: importing works anywhere, but creating a detector without the
@@ -15,7 +16,8 @@ HIP library or without a GPU raises.
 from .config import (COLOR_NAMES, DEFAULT_DETECTOR_CONFIGURATION, RED, WHITE, YELLOW, default_config)
 from .frontend import FrontEnd, LanefrontError, Segments
 from .line_associator import LineAssociator
+from .matcher import BinaryDescriptorMatcher, DMatch
 from .line_detector_hip import Detections, LineDetectorEDLines, LineDetectorHIP, LineDetectorInterface
 
-__all__ = ["LineAssociator", "FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorEDLines", "LineDetectorInterface", "Detections",
+__all__ = ["BinaryDescriptorMatcher", "DMatch", "LineAssociator", "FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorEDLines", "LineDetectorInterface", "Detections",
            "default_config", "DEFAULT_DETECTOR_CONFIGURATION", "WHITE", "YELLOW", "RED", "COLOR_NAMES"]

@@ -27,6 +27,8 @@ EXPORTS = (
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
     "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu",
     "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
+    "lf_lsd_default_options", "lf_lsd_keylines_batch_ex",
+    "lf_matcher_add", "lf_matcher_clear", "lf_matcher_size", "lf_matcher_match", "lf_matcher_knn_match", "lf_matcher_radius_match",
 )
 DETECTORS = {"lsd": 0, "edlines": 1}
 TIE_RULES = {"lowest": 0, "mihasher": 1}
@@ -57,6 +59,13 @@ KEYLINE_FIELDS = (("start_end", "f4", 4), ("in_octave", "f4", 4), ("angle", "f4"
 class LfKeylines(ctypes.Structure):
     """ctypes mirror of `lf_keylines` (include/lanefront.h)."""
     _fields_ = [("capacity", ctypes.c_int32), ("frame_offset", ctypes.c_void_p)] + [(k, ctypes.c_void_p) for k, _, _ in KEYLINE_FIELDS]
+
+
+class LfLsdOptions(ctypes.Structure):
+    """ctypes mirror of `lf_lsd_options` (include/lanefront.h): LSDDetectorC::LSDOptions (descriptor_custom.hpp:906-916)."""
+    _fields_ = [("refine", ctypes.c_int32), ("n_bins", ctypes.c_int32), ("scale", ctypes.c_double), ("sigma_scale", ctypes.c_double),
+                ("quant", ctypes.c_double), ("ang_th", ctypes.c_double), ("log_eps", ctypes.c_double), ("density_th", ctypes.c_double),
+                ("min_length", ctypes.c_double)]
 
 
 class LfMapConfig(ctypes.Structure):
@@ -168,8 +177,20 @@ def load():
     lib.lf_keylines_batch_async.restype = ci
     lib.lf_select_queries.argtypes = [vp, vp, ci, vp, vp, vp, ctypes.POINTER(ci), ci]
     lib.lf_select_queries.restype = ci
+    lib.lf_matcher_add.argtypes = [vp, vp, ci, ci]
+    lib.lf_matcher_clear.argtypes = [vp]
+    lib.lf_matcher_size.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    lib.lf_matcher_match.argtypes = [vp, vp, ci, vp, vp, ctypes.POINTER(ci)]
+    lib.lf_matcher_knn_match.argtypes = [vp, vp, ci, ci, vp, ci, vp, vp, ctypes.POINTER(ci)]
+    lib.lf_matcher_radius_match.argtypes = [vp, vp, ci, ctypes.c_float, vp, ci, vp, vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    for fn in (lib.lf_matcher_add, lib.lf_matcher_clear, lib.lf_matcher_size, lib.lf_matcher_match, lib.lf_matcher_knn_match, lib.lf_matcher_radius_match):
+        fn.restype = ci
     lib.lf_lsd_keylines_batch.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfKeylines), ci, ci, ctypes.POINTER(ci)]
     lib.lf_lsd_keylines_batch.restype = ci
+    lib.lf_lsd_keylines_batch_ex.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfLsdOptions), vp, ci, ctypes.POINTER(LfKeylines), ci, ci, ctypes.POINTER(ci)]
+    lib.lf_lsd_keylines_batch_ex.restype = ci
+    lib.lf_lsd_default_options.argtypes = [ctypes.POINTER(LfLsdOptions)]
+    lib.lf_lsd_default_options.restype = None
     lib.lf_keylines_frame_status.argtypes = [vp, vp, ci]
     lib.lf_keylines_frame_status.restype = ci
     lib.lf_set_detector.argtypes = [vp, ci, ctypes.POINTER(LfEdlinesParams)]

@@ -78,6 +78,9 @@ namespace lf {
 #ifndef LF_SEED_EPT
 #define LF_SEED_EPT 32
 #endif
+#ifndef LF_SEED_OCC
+#define LF_SEED_OCC 3              // workgroups per CU the register allocation must allow (168 VGPRs: three; 128: four, with spills)
+#endif
 constexpr int ST = LF_SEED_THREADS;  // threads
 constexpr int SW = ST / 64;
 constexpr int SW2 = LF_SEED_WAVES2;  // waves that work in phase 2 (each with a private LDS range)
@@ -1667,9 +1670,15 @@ __device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int
     SEED_T(t0);
     sparse_chain<false>(W, nullptr, nullptr, &cstate, n, m, n_seeds, as_lds<lds_u32>(lds), lds_words);
     SEED_T(t1);
+#if defined(LF_SEED_STOP) && LF_SEED_STOP == 1
+    return;                                                   // (instruction-count experiments only: the result is not made)
+#endif
     const int M = cstate.e_used;
     introsort_loop_wg(W.E, M, cstate.ranges, cstate.n_ranges, W.dscratch, lds, rows_cap, W.PP);
     SEED_T(t2);
+#if defined(LF_SEED_STOP) && LF_SEED_STOP == 2
+    return;
+#endif
     // ---- the seeds in array order ...
     uint32_t* A = W.out;
     uint32_t* B = W.PP;
@@ -1735,7 +1744,7 @@ __device__ __forceinline__ SeedWork seed_work(uint32_t* sa, uint32_t* sb, uint32
 }
 
 // plane_ok: the gradient image's bit plane fits the kernel's LDS
-__global__ __launch_bounds__(ST, 3) void k_lsd_seed32(LsdParams p, const int* __restrict__ n_rec, const unsigned long long* __restrict__ maxgrad,
+__global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, const int* __restrict__ n_rec, const unsigned long long* __restrict__ maxgrad,
                                                    const uint32_t* __restrict__ c_xy, const double* __restrict__ c_mod,
                                                    const uint32_t* __restrict__ l_addr, double* l_mod, const int* __restrict__ n_low,
                                                    unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
@@ -1863,7 +1872,7 @@ __global__ __launch_bounds__(ST, 3) void k_lsd_seed32(LsdParams p, const int* __
 // debug / test entry: std::sort(compare_norm) of n keys: E[i] = key << 20 | i + 1.  Elements with key 0 are the detector's flat
 // pixels: anonymous.  Leaves the elements with a non-zero key in out[0 .. count) in the order std::sort leaves them, as
 // (1023 - key) << 20 | i, and the count in *count.  work: 12 * cap words, cap = max(n, 1024) rounded up to 64.
-__global__ __launch_bounds__(ST, 3) void k_std_sort_debug(const uint32_t* __restrict__ E, uint32_t* __restrict__ work, int n, int cap, int rows_cap, int* __restrict__ count, int lds_words)
+__global__ __launch_bounds__(ST, LF_SEED_OCC) void k_std_sort_debug(const uint32_t* __restrict__ E, uint32_t* __restrict__ work, int n, int cap, int rows_cap, int* __restrict__ count, int lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
     __shared__ int tot[SNB];

@@ -114,6 +114,7 @@ struct lf_handle {
     DevBuf km_pts, km_lab, km_f64, km_cnt;
     DevBuf kn_hist, kn_count, kn_off, kn_total;       // radiusMatch scratch
     AssocScratch a_ws;
+    struct MatcherState* matcher = nullptr;     // BinaryDescriptorMatcher's dataset (lanefront_matcher.inc)
     // pinned host scalars
     int* h_pinned = nullptr;     // [0] total segments, [1] overflow
     int last_frames = 0;
@@ -508,6 +509,7 @@ static void kl_free(KlState* k);
 struct LsdKlState;
 static void lsdkl_free(LsdKlState* k);
 
+static void matcher_free(struct MatcherState* m);
 extern "C" void lf_destroy(lf_handle* h)
 {
     if (!h) return;
@@ -536,6 +538,7 @@ extern "C" void lf_destroy(lf_handle* h)
     }
     kl_free(h->kl);
     lsdkl_free(h->lsdkl);
+    matcher_free(h->matcher);
     timing_resolve(h);
     for (EvPair& e : h->ev_free) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1622,4 +1625,5 @@ extern "C" int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int 
 
 #include "lanefront_keylines.inc"
 #include "lanefront_lsdkl.inc"
+#include "lanefront_matcher.inc"
 #include "lanefront_jpeg_gpu.inc"

@@ -232,7 +232,17 @@ extern "C" int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** o
     m->cap_pad = assoc_rows_padded_m(cfg->capacity);
 #define CREATE_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { map_error(m, "%s failed: %s", #expr, hipGetErrorString(_e)); return fail(LF_ERR_HIP); } } while (0)
     CREATE_HIP(hipSetDevice(device_id));
-    CREATE_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    {
+        // The map's steps are the one serial chain of a pipelined front end (step k's association needs step k - 1's update): its
+        // kernels go to a HIGH-PRIORITY stream, so that their workgroups (76 KB of LDS each) are not the last to find room between the
+        // region-growing workgroups of the batches in flight (LF_MAP_PRIORITY=0: a plain stream, for A/B)
+        int least = 0, greatest = 0;
+        static const bool plain = getenv("LF_MAP_PRIORITY") && atoi(getenv("LF_MAP_PRIORITY")) == 0;
+        if (!plain && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            CREATE_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, greatest));
+        else
+            CREATE_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    }
     CREATE_HIP(hipEventCreateWithFlags(&m->ev_state, hipEventDisableTiming));
     CREATE_HIP(hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming));
     CREATE_HIP(hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming));

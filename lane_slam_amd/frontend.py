@@ -323,9 +323,23 @@ class FrontEnd(object):
         out["frame_status"] = status
         return out
 
-    def lsd_keylines_batch(self, images, n_octaves=1, describe=True, gray=False, capacity=None):
+    def lsd_options(self, **kw):
+        """LSDDetectorC::LSDOptions (ref: descriptor_custom.hpp:906-916) with cv::createLineSegmentDetector()'s defaults and min_length 0;
+        keywords: refine, scale, sigma_scale, quant, ang_th, log_eps, density_th, n_bins, min_length."""
+        o = _lib.LfLsdOptions()
+        self.lib.lf_lsd_default_options(ctypes.byref(o))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise ValueError("unknown LSD option %r" % (k,))
+            setattr(o, k, v)
+        return o
+
+    def lsd_keylines_batch(self, images, n_octaves=1, describe=True, gray=False, capacity=None, options=None, masks=None):
         """LSDDetectorC::detect over n_octaves pyramid levels (ref: LSDDetector_custom.cpp:130-215) + BinaryDescriptor::compute:
-        the same dict as keylines_batch (no 'frame_status'; 'salience' is 0).  images as in keylines_batch."""
+        the same dict as keylines_batch (no 'frame_status'; 'salience' is 0).  images as in keylines_batch.
+        options (lsd_options(...)): the fork's detect(..., LSDOptions, mask) / detectFast overloads (:218-438) -- the detector's
+        parameters and the min_length filter; masks: (n, rows, cols) u8 of the working size -- KeyLines with both end points on zero
+        mask pixels are erased (:203-213)."""
         images = np.ascontiguousarray(images, np.uint8)
         want = (self.rows, self.cols) if gray else (self.in_rows, self.in_cols, 3)
         if images.ndim == len(want):
@@ -344,8 +358,16 @@ class FrontEnd(object):
             out[k] = np.zeros((cap, c) if c > 1 else cap, np.dtype(dt))
             setattr(s, k, out[k].ctypes.data)
         total = ctypes.c_int()
-        self._check(self.lib.lf_lsd_keylines_batch(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves), ctypes.byref(s), 0,
-                                                   int(bool(describe)), ctypes.byref(total)))
+        if masks is not None:
+            masks = np.ascontiguousarray(masks, np.uint8)
+            if masks.ndim == 2:
+                masks = masks[None]
+            if masks.shape != (n, self.rows, self.cols):
+                raise ValueError("masks must be (%d,%d,%d), got %r" % (n, self.rows, self.cols, masks.shape))
+        self._check(self.lib.lf_lsd_keylines_batch_ex(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves),
+                                                      ctypes.byref(options) if options is not None else None,
+                                                      _ptr(masks) if masks is not None else None, 0, ctypes.byref(s), 0,
+                                                      int(bool(describe)), ctypes.byref(total)))
         t = total.value
         for k, _, _ in _lib.KEYLINE_FIELDS:
             if k in out:

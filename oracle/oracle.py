@@ -368,10 +368,13 @@ def _process_frame_edlines(self, bgr_in, params=None, describe=True):
 Oracle.process_frame_edlines = _process_frame_edlines
 
 
-def lsd_octave_keylines(gray, n_octaves=1, describe=True, seed_order="opencv30"):
+def lsd_octave_keylines(gray, n_octaves=1, describe=True, seed_order="opencv30", options=None, mask=None):
     """LSDDetectorC::detect (ref: src/line_descriptor/src/LSDDetector_custom.cpp:49-72, 130-215) + BinaryDescriptor::compute,
     composed from the oracle's pieces: pyrDown pyramid (no blur), cv LSD with createLineSegmentDetector()'s defaults on every level,
-    KeyLine fill (:164-197), descriptors on compute's own pyramid.  Same dict keys as octave_keylines."""
+    KeyLine fill (:164-197), descriptors on compute's own pyramid.  Same dict keys as octave_keylines.
+    options: dict of LSDOptions fields (:218-325 detect / :327-438 detectFast, the same text twice): the detector's parameters and
+    `length > min_length` (:277), class_id counting the kept lines (:293); mask: u8 image -- KeyLines whose two end points both lie on
+    zero pixels are erased, correctly (keyCounter-- after the erase, :203-213 / :312-322)."""
     from lane_slam_amd import default_config
     gray = np.ascontiguousarray(gray, np.uint8)
     out = {k: [] for k in ("start_end", "in_octave", "angle", "num_pixels", "line_length", "octave", "class_id", "response", "size", "pt")}
@@ -383,9 +386,16 @@ def lsd_octave_keylines(gray, n_octaves=1, describe=True, seed_order="opencv30")
         cfg["in_size"] = [rows, cols]; cfg["img_size"] = [rows, cols]; cfg["top_cutoff"] = 0
         cfg["lsd"] = {"refine": 1, "scale": 0.8, "sigma_scale": 0.6, "quant": 2.0, "ang_th": 22.5, "log_eps": 0.0, "density_th": 0.7,
                       "n_bins": 1024, "seed_order": seed_order}
+        if options:
+            cfg["lsd"].update({k: v for k, v in options.items() if k != "min_length"})
         oc = Oracle(cfg)
         lines = np.asarray(oc.lsd(level, cap=20000), np.float32).reshape(-1, 4)
         ext, _, npx = oc.keylines(lines, rows, cols)
+        if options is not None:                                # (:277) length > opts.min_length, the float-rounded length against the double
+            ddx = (ext[:, 0] - ext[:, 2]).astype(np.float32).astype(np.float64)
+            ddy = (ext[:, 1] - ext[:, 3]).astype(np.float32).astype(np.float64)
+            kept = np.sqrt(ddx * ddx + ddy * ddy).astype(np.float32).astype(np.float64) > float(options.get("min_length", 0.0))
+            ext, npx = ext[kept], npx[kept]
         n = ext.shape[0]
         scale = np.float32(1 << o)
         se = (ext * scale).astype(np.float32)
@@ -405,6 +415,12 @@ def lsd_octave_keylines(gray, n_octaves=1, describe=True, seed_order="opencv30")
         if o + 1 < n_octaves:
             level = pyrdown_u8(level)
     r = {k: (np.concatenate(v) if v else np.zeros(0)) for k, v in out.items()}
+    if mask is not None and cls:
+        se = r["start_end"]
+        sx, sy, ex, ey = (se[:, i].astype(np.int64) for i in range(4))     # (int) of a non-negative float: truncation
+        keep = ~((mask[sy, sx] == 0) & (mask[ey, ex] == 0))
+        r = {k: v[keep] for k, v in r.items()}
+        cls = int(keep.sum())
     r["n"] = cls
     if describe and cls:
         r["desc"], r["code"] = describe_keylines(gray, r["in_octave"], r["angle"], r["num_pixels"], r["octave"])

@@ -65,3 +65,43 @@ def test_lsd_keylines_on_camera_frames_and_the_opencv32_seed_order(golden_dir):
         n = _check(k, gray, 2, seed_order)
         assert n > 300
         fe.close()
+
+
+def test_lsd_options_min_length_and_mask():
+    """The fork's own overloads (VERDICT r4 missing #2, #3): LSDDetectorC::detect(image, keylines, scale, numOctaves, LSDOptions, mask) and
+    detectFast (ref: LSDDetector_custom.cpp:218-325, 327-438; descriptor_custom.hpp:906-916): the caller's detector parameters, the
+    min_length filter with class_id counting the kept lines, and the mask that erases a KeyLine when both its end points lie on zero
+    pixels -- every field against the oracle's composition, with and without descriptors."""
+    cfg = default_config("fullres")
+    k = FrontEnd(cfg, max_frames=3, max_lines_per_color=2048)
+    frames = synth.make_batch(3, seed0=40)
+    gray = np.stack([O.Oracle(cfg).bgr2gray(O.Oracle(cfg).preprocess(f)) for f in frames])
+    rng = np.random.default_rng(3)
+    masks = np.zeros(gray.shape, np.uint8)
+    masks[:, :, : gray.shape[2] // 2] = 255                     # the right half is masked out ...
+    masks[1] = (rng.random(gray.shape[1:]) < 0.5).astype(np.uint8) * 255      # ... a random mask for frame 1
+    cases = [dict(), dict(min_length=12.5), dict(refine=2, quant=1.5, ang_th=30.0, density_th=0.6, n_bins=512, min_length=4.0),
+             dict(refine=0, scale=0.5, sigma_scale=0.8, log_eps=1.0)]
+    seen = 0
+    for kw in cases:
+        for mk in (None, masks):
+            got = k.lsd_keylines_batch(gray, 2, describe=True, gray=True, options=k.lsd_options(**kw), masks=mk)
+            for f in range(3):
+                r = O.lsd_octave_keylines(gray[f], 2, describe=True, seed_order=cfg["lsd"]["seed_order"], options=kw, mask=None if mk is None else mk[f])
+                a, b = int(got["frame_offset"][f]), int(got["frame_offset"][f + 1])
+                assert b - a == r["n"], (kw, mk is not None, f, b - a, r["n"])
+                for name in FIELDS:
+                    assert np.array_equal(got[name][a:b], r[name]), (kw, f, name)
+                seen += r["n"]
+    assert seen > 200
+    plain = k.lsd_keylines_batch(gray, 2, describe=False, gray=True)
+    same = k.lsd_keylines_batch(gray, 2, describe=False, gray=True, options=k.lsd_options())
+    assert plain["n"] == same["n"] and np.array_equal(plain["start_end"], same["start_end"])
+    filt = k.lsd_keylines_batch(gray, 2, describe=False, gray=True, options=k.lsd_options(min_length=12.5))
+    assert 0 < filt["n"] < plain["n"] and np.array_equal(filt["class_id"][:5], np.arange(5))
+    cut = k.lsd_keylines_batch(gray, 2, describe=False, gray=True, masks=masks)
+    assert 0 < cut["n"] < plain["n"]
+    from lane_slam_amd import LanefrontError
+    with pytest.raises(LanefrontError):
+        k.lsd_keylines_batch(gray, 1, gray=True, options=k.lsd_options(n_bins=4096))
+    k.close()
