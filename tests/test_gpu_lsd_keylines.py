@@ -81,7 +81,7 @@ def test_lsd_options_min_length_and_mask():
     masks[:, :, : gray.shape[2] // 2] = 255                     # the right half is masked out ...
     masks[1] = (rng.random(gray.shape[1:]) < 0.5).astype(np.uint8) * 255      # ... a random mask for frame 1
     cases = [dict(), dict(min_length=12.5), dict(refine=2, quant=1.5, ang_th=30.0, density_th=0.6, n_bins=512, min_length=4.0),
-             dict(refine=0, scale=0.5, sigma_scale=0.8, log_eps=1.0)]
+             dict(refine=0, scale=0.7, sigma_scale=0.7, log_eps=1.0)]
     seen = 0
     for kw in cases:
         for mk in (None, masks):
