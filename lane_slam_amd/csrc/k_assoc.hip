@@ -154,7 +154,9 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
             for (int k = 0; k < 8; ++k) {
                 const unsigned int c = c0 + k;
                 if (c >= nc) break;
-                const bool on = best_ham >= 0 && t[k] != 0x7fffffffu && (int)(t[k] >> 22) == best_ham;
+                // (a query whose optimum is distance 0 needs no second look: every candidate at distance 0 equals the query, all their
+                // discovery keys are (weight 0, substring 0, place 0), and the train index decides -- the lowest, which this pass reports)
+                const bool on = best_ham > 0 && t[k] != 0x7fffffffu && (int)(t[k] >> 22) == best_ham;
                 const unsigned long long bo = __ballot(on);
                 if (lane == 0) tie_counts[(size_t)c * n_pieces + piece] = __popcll(bo);
                 if (on) tie_pieces[((size_t)c * n_pieces + piece) * 64 + __popcll(bo & ((1ull << lane) - 1ull))] = qq;
