@@ -22,6 +22,7 @@
 // per chunk, the queries that have to look there (their row of part[] against their optimum), and the matrix pass here runs on those
 // (chunk, 256 listed queries) pieces alone: about 1 / (number of chunks) of the N x M products instead of all of them.  A chunk is
 // cut into `subs` pieces of whole tile groups so that the few pieces still fill the chip.
+#include <cstdlib>
 #include "common.h"
 #include "mih_rank.h"
 
@@ -39,9 +40,11 @@ void mih_rank_host(uint8_t out[5][256])
     for (int s = 0; s < 5; ++s) for (int i = 0; i < 256; ++i) out[s][i] = t.r[s][i];
 }
 
-constexpr int TQW = 256;          // queries per workgroup: 4 waves x 2 row blocks x 32
-constexpr int TGROUP = 4;         // 64-row map tiles (8 KB of e2m1 rows each) per LDS buffer: a group's matrix work (~1.5 us) covers the next group's fetch
-constexpr int TSETS = TGROUP * 4; // accumulator sets per group: tile x column block x row block
+// Two shapes of the pass (round 5).  SMALL: one 32-query row block per wave, one 8 KB map tile per LDS buffer -- 24 KB of LDS and 128
+// registers, a workgroup that finds room on a chip full of region-growing workgroups (25 KB, 96 registers each) as soon as ONE of
+// them retires; it is what a pipelined front end's map steps use (same bench, same call: 119 k -> 124 k frames/s against the big
+// shape, although alone it is a third slower).  BIG: two row blocks per wave sharing every map fragment, two tiles per buffer (45 KB,
+// 230 registers): the faster one alone, used for large query sets.
 
 // eight e2m1 nibbles (0x2 = bit 0, 0xA = bit 1) -> the code byte they were expanded from (assoc_fp4_expand's inverse)
 __device__ __forceinline__ uint32_t fp4_collapse(uint32_t w)
@@ -85,13 +88,15 @@ __device__ __noinline__ void tie_eval(const uint8_t* __restrict__ q, const uint8
 }
 
 constexpr int THCAP = 256;        // candidates a workgroup stages in LDS between two flushes (one per thread of a flush)
+#define TQW (128 * TRB)
+#define TSETS (TGROUP * 4)        // accumulator sets per group: tile x column block x row block
 
 // Persistent workgroups over the WORK ITEMS of the pass: item = (map chunk c of the distance pass, slab of 256 of the queries
 // listed for c, piece of c's columns).  The lists come from the distance pass's merge step (k_assoc.hip: pieces of up to 64 query
 // numbers per (chunk, wave of a query block) and their counts); every workgroup adds the counts up for itself (a few thousand
 // words) -- no list kernel, no prefix kernel, no early-exit workgroups.
-template <bool GATED>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_ties(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
+template <bool GATED, int TRB, int TGROUP, int kTieUnroll>
+__device__ __forceinline__ void assoc_ties_body(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                     const int8_t* __restrict__ mx, const uint8_t* __restrict__ mcode, const uint8_t* __restrict__ mcolor,
                                                     int nm_bound, const int* __restrict__ nm_dev,
                                                     int nm_pad, int m_chunk, int splits, int subs, int sub_len, const int* __restrict__ pieces,
@@ -182,26 +187,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int n_listed = s_pfx[n_pieces];
             const int li = slab * TQW + threadIdx.x;
             int qi = -1;
-            if (li < n_listed) {
+            if (li < n_listed && (int)threadIdx.x < TQW) {
                 int x = 0, y = n_pieces;
                 while (y - x > 1) { const int mid = (x + y) >> 1; if (s_pfx[mid] <= li) x = mid; else y = mid; }
                 qi = pieces[((size_t)chunk * n_pieces + x) * 64 + (li - s_pfx[x])];
             }
-            s_qid[threadIdx.x] = qi;
-            uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-            if (qi >= 0) { c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32); c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16); }
-            *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8]) = c0;
-            *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8 + 4]) = c1;
+            if ((int)threadIdx.x < TQW) {
+                s_qid[threadIdx.x] = qi;
+                uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+                if (qi >= 0) { c0 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32); c1 = *reinterpret_cast<const uint4*>(q + (size_t)qi * 32 + 16); }
+                *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8]) = c0;
+                *reinterpret_cast<uint4*>(&qraw[threadIdx.x * 8 + 4]) = c1;
+            }
         }
         __syncthreads();
         // query operands: step s, k-half `half` = code dword 2 s + half, eight e2m1 nibbles per code byte (k_assoc.hip)
-        v8i A[2][4];
+        v8i A[TRB][4];
         // Every chain STARTS at 0.5 - (the dot product a tie has = 256 - 2 * the row's minimum distance), so a tie ends at exactly
         // +0.5 (0x3f000000), every other candidate at k + 0.5 with k a non-zero integer (all exact in f32), rows without a match near -3e38.
-        v16f start[2];
+        v16f start[TRB];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const uint32_t* c = &qraw[(wave * 64 + 32 * b + r32) * 8];
+        for (int b = 0; b < TRB; ++b) {
+            const uint32_t* c = &qraw[(wave * (32 * TRB) + 32 * b + r32) * 8];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const uint32_t w = c[2 * s + half];
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int qr = s_qid[wave * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half];
+                const int qr = s_qid[wave * (32 * TRB) + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half];
                 const float d = qr >= 0 ? dist[qr] : -1.f;
                 start[b][r] = d >= 0.f ? 0.5f - (256.f - 2.f * d) : -3.0e38f;
             }
@@ -218,19 +225,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // column block share its fragments and run as two interleaved chains
         auto dots2 = [&](const uint8_t* tiles, int tl, int cb, v16f& acc0, v16f& acc1) {
             const uint8_t* fb = tiles + tl * 8192 + half * 1024 + (cb * 32 + r32) * 16;
-            acc0 = start[0]; acc1 = start[1];
+            acc0 = start[0]; acc1 = start[TRB - 1];
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const v4i f = *reinterpret_cast<const v4i*>(fb + s * 2048);
                 const v8i B = v8i{ f.x, f.y, f.z, f.w, 0, 0, 0, 0 };
                 acc0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[0][s], B, acc0, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-                acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[1][s], B, acc1, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+                if (TRB == 2) acc1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[TRB - 1][s], B, acc1, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
             }
         };
         auto group = [&](int g, const uint8_t* tiles, uint8_t* next) {
             if (g + 1 < n_groups) fetch(g + 1, next);
             const int tiles_here = min(TGROUP, n_tiles - g * TGROUP);
-#pragma unroll
+#pragma unroll kTieUnroll
             for (int pair = 0; pair < TSETS / 2; ++pair) {
                 const int tl = pair >> 1, cb = pair & 1;
                 if (tl >= tiles_here) break;                                    // a group's tiles past the piece's end
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 dots2(tiles, tl, cb, acc0, acc1);
                 const int col = m_begin + (g * TGROUP + tl) * 64 + cb * 32 + r32;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < TRB; ++b) {
                     uint32_t hits = 0;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hits |= (__float_as_uint(b ? acc1[r] : acc0[r]) == kTie ? 1u : 0u) << r;
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         while (hits) {
                             const int r = __ffs(hits) - 1;
                             hits &= hits - 1;
-                            const int qg = s_qid[wave * 64 + 32 * b + 4 * half + (r & 3) + 8 * (r >> 2)];
+                            const int qg = s_qid[wave * (32 * TRB) + 32 * b + 4 * half + (r & 3) + 8 * (r >> 2)];
                             if (qg < 0) continue;
                             const int pos = atomicAdd(&s_nh, 1);
                             if (pos < THCAP) s_hits[pos] = make_int2(qg, col);
@@ -267,6 +274,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+#undef TQW
+#undef TSETS
+#define LF_TIE_ARGS const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq, const int8_t* __restrict__ mx, const uint8_t* __restrict__ mcode, \
+    const uint8_t* __restrict__ mcolor, int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int splits, int subs, int sub_len, \
+    const int* __restrict__ pieces, const int* __restrict__ counts, int n_pieces, const float* __restrict__ dist, unsigned long long* __restrict__ res
+#define LF_TIE_PASS q, qcolor, nq, mx, mcode, mcolor, nm_bound, nm_dev, nm_pad, m_chunk, splits, subs, sub_len, pieces, counts, n_pieces, dist, res
+template <bool GATED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_assoc_ties_small(LF_TIE_ARGS) { assoc_ties_body<GATED, 1, 1, 1>(LF_TIE_PASS); }
+template <bool GATED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_assoc_ties_big(LF_TIE_ARGS) { assoc_ties_body<GATED, 2, 2, 2>(LF_TIE_PASS); }
+#undef LF_TIE_ARGS
+#undef LF_TIE_PASS
+
 __global__ void k_assoc_ties_finish(int nq, const unsigned long long* __restrict__ res, int32_t* __restrict__ idx)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -283,25 +303,34 @@ hipError_t launch_assoc_ties(const uint8_t* q, const uint8_t* qcolor, int nq, co
 {
     if (nq <= 0 || nm <= 0) return hipSuccess;
     const int nm_pad = (int)assoc_rows_padded_m(nm);
-    const int qblocks = (nq + TQW - 1) / TQW;
+    const int qblocks = (nq + 255) / 256;                                   // the distance pass's query blocks (256 queries each)
     const int splits = w.splits, m_chunk = w.m_chunk;                      // the distance pass's split of the map: its lists are laid out by it
     // the distance pass must have been launched with w.tie_res = res: its merge step wrote the lists and reset the result words
     if (splits < 1 || splits > 128 || w.qblocks != qblocks || w.tie_res != res || !w.tie_list) return hipErrorInvalidValue;
-    if ((size_t)qblocks * 4 + 1 > (size_t)TGROUP * 8192 / 4) return hipErrorInvalidValue;      // (the running piece counts of a chunk sit in one tile buffer: 2^19 queries per call)
+    // the shape: SMALL up to 12 288 queries (a front end's batch: the pass must find room between other kernels), BIG beyond
+    // (LF_TIE_SHAPE=small|big overrides, for A/B runs)
+    static const char* forced = getenv("LF_TIE_SHAPE");
+    const bool small = forced ? forced[0] == 's' : nq <= 12288;
+    const int trb = small ? 1 : 2, tgroup = small ? 1 : 2;
+    if ((size_t)qblocks * 4 + 1 > (size_t)tgroup * 8192 / 4) return hipErrorInvalidValue;      // (the running piece counts of a chunk sit in one tile buffer)
     const int n_pieces = qblocks * 4;
     const int* pieces = w.tie_list;
     const int* counts = w.tie_list + (size_t)splits * n_pieces * 64;
-    // every listed (chunk, slab) is cut into pieces of whole tile groups: about 1.5 nq / 256 slabs in all, 512 workgroup slots
+    // every listed (chunk, slab) is cut into pieces of whole tile groups: about 1.5 slabs per 128 / 256 queries in all, 512 workgroup slots
+    const int tqw = 128 * trb;
     const int tiles_chunk = m_chunk / 64;
-    int subs = (768 + qblocks + qblocks / 2 - 1) / (qblocks + qblocks / 2);
-    if (subs > (tiles_chunk + TGROUP - 1) / TGROUP) subs = (tiles_chunk + TGROUP - 1) / TGROUP;
+    const int slabs = (nq + tqw - 1) / tqw;
+    int subs = (768 + slabs + slabs / 2 - 1) / (slabs + slabs / 2);
+    if (subs > (tiles_chunk + tgroup - 1) / tgroup) subs = (tiles_chunk + tgroup - 1) / tgroup;
     if (subs < 1) subs = 1;
     int sub_len = (tiles_chunk + subs - 1) / subs;
-    sub_len = (sub_len + TGROUP - 1) / TGROUP * TGROUP * 64;
+    sub_len = (sub_len + tgroup - 1) / tgroup * tgroup * 64;
     subs = (m_chunk + sub_len - 1) / sub_len;
-    const int grid = 512;
-    if (gating) hipLaunchKernelGGL(k_assoc_ties<true>, dim3(grid), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, splits, subs, sub_len, pieces, counts, n_pieces, dist, res);
-    else hipLaunchKernelGGL(k_assoc_ties<false>, dim3(grid), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, splits, subs, sub_len, pieces, counts, n_pieces, dist, res);
+    static const int grid = getenv("LF_TIE_GRID") ? atoi(getenv("LF_TIE_GRID")) : 512;
+#define LF_TIE_LAUNCH(K) hipLaunchKernelGGL(K, dim3(grid), dim3(256), 0, s, q, qcolor, nq, mx, mcode, mcolor, nm, nm_dev, nm_pad, m_chunk, splits, subs, sub_len, pieces, counts, n_pieces, dist, res)
+    if (small) { if (gating) LF_TIE_LAUNCH(k_assoc_ties_small<true>); else LF_TIE_LAUNCH(k_assoc_ties_small<false>); }
+    else { if (gating) LF_TIE_LAUNCH(k_assoc_ties_big<true>); else LF_TIE_LAUNCH(k_assoc_ties_big<false>); }
+#undef LF_TIE_LAUNCH
     hipLaunchKernelGGL(k_assoc_ties_finish, dim3((nq + 255) / 256), dim3(256), 0, s, nq, res, idx);
     return hipGetLastError();
 }

@@ -1670,15 +1670,9 @@ __device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int
     SEED_T(t0);
     sparse_chain<false>(W, nullptr, nullptr, &cstate, n, m, n_seeds, as_lds<lds_u32>(lds), lds_words);
     SEED_T(t1);
-#if defined(LF_SEED_STOP) && LF_SEED_STOP == 1
-    return;                                                   // (instruction-count experiments only: the result is not made)
-#endif
     const int M = cstate.e_used;
     introsort_loop_wg(W.E, M, cstate.ranges, cstate.n_ranges, W.dscratch, lds, rows_cap, W.PP);
     SEED_T(t2);
-#if defined(LF_SEED_STOP) && LF_SEED_STOP == 2
-    return;
-#endif
     // ---- the seeds in array order ...
     uint32_t* A = W.out;
     uint32_t* B = W.PP;
@@ -1944,7 +1938,6 @@ void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const
         if ((size_t)full * 24 + 512 <= (size_t)kMaxLdsBytes) rows_cap = (int)full;
     }
     size_t lds = seed_lds_bytes(rows_cap, n);
-    { static const char* pad = getenv("LF_SEED_LDS_PAD"); if (pad) lds += (size_t)atoi(pad) * 1024; }      // experiment: how much the pipeline minds the kernel's LDS
     const int plane_ok = bitplane_lds_words((size_t)n) * 4 <= lds;      // the list's initial order by ranks in a plane of the gradient image
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
