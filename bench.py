@@ -154,7 +154,15 @@ def main():
     cfg = default_config("fullres", in_size=(in_rows, in_cols)) if hd else default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
     cfg["lsd"]["seed_order"] = args.seed_order
-    # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers)
+    # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers: about 120 bytes per LSD pixel and
+    # problem, 10 GB at 640x480 x 256 frames, 40 GB at 1080p x 128 -- DESIGN.md section 3); with --depth 0 no more of them than fit
+    # 85 % of the device's free memory (1080p with the low-gradient records of lsd.seed_order = opencv32: five)
+    if args.depth == 0:
+        rows_w, cols_w = cfg["img_size"][0] - cfg["top_cutoff"], cfg["img_size"][1]
+        ps = int(np.ceil(rows_w * 0.8)) * int(np.ceil(cols_w * 0.8))
+        handle_bytes = (108 + (12 if args.seed_order == "opencv32" else 0)) * ps * 3 * B + 16 * rows_w * cols_w * B + in_rows * in_cols * 3 * B
+        free_b, _total_b = torch.cuda.mem_get_info(local_rank)
+        D = max(2, min(D, int(0.85 * free_b // handle_bytes)))
     fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D)]
     fe = fes[0]
     P = fe.rows * fe.cols

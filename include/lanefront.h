@@ -31,6 +31,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the library is built with -fvisibility=hidden: exactly the entry points declared here are exported */
+#define LF_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -120,19 +123,19 @@ typedef struct lf_segments {
 } lf_segments;
 
 /* ---- lifetime ------------------------------------------------------------ */
-int lf_abi_version(void);
+LF_API int lf_abi_version(void);
 
 /* max_frames: largest batch lf_process_batch will be given (1 for the plugin path).
  * max_lines_per_color: capacity of one LSD run (one frame, one colour). */
-int lf_create(const lf_config* cfg, int device_id, int max_frames, int max_lines_per_color,
+LF_API int lf_create(const lf_config* cfg, int device_id, int max_frames, int max_lines_per_color,
               lf_handle** out);
-void lf_destroy(lf_handle* h);
-const char* lf_last_error(const lf_handle* h);
+LF_API void lf_destroy(lf_handle* h);
+LF_API const char* lf_last_error(const lf_handle* h);
 /* wait for all work queued on the handle's HIP stream */
-int lf_synchronize(lf_handle* h);
+LF_API int lf_synchronize(lf_handle* h);
 /* the handle's HIP stream (a hipStream_t) for callers that order their own device work against the handle's with
  * events instead of host synchronisation (e.g. torch.cuda.ExternalStream); the stream stays owned by the handle */
-int lf_get_stream(lf_handle* h, void** hip_stream);
+LF_API int lf_get_stream(lf_handle* h, void** hip_stream);
 
 /* ---- plugin path: replaces LineDetectorLSD (line_detector_lsd.py:11-142) ---
  * lf_set_image  <-> LineDetectorLSD.setImage(bgr)      (:135-139)
@@ -143,8 +146,8 @@ int lf_get_stream(lf_handle* h, void** hip_stream);
  * (line_detector_node.py:180); it must be rows x cols == the handle's working
  * size (img_rows - top_cutoff, img_cols).  Host pointers.
  */
-int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes);
-int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, float* centers2,
+LF_API int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes);
+LF_API int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, float* centers2,
                     uint8_t* area_or_null, int cap, int* n_out);
 
 /* ---- batch path: processImage_ + ground_projection + line_sanity + describe -
@@ -160,7 +163,7 @@ int lf_detect_lines(lf_handle* h, int color, float* lines4, double* normals2, fl
  * With device outputs the call is asynchronous except for the final count
  * read-back; with host outputs it returns when the data is in place.
  */
-int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+LF_API int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
                      lf_segments* out, int out_on_device, int describe, int* n_segments);
 
 /* Pipelined form: lf_process_batch_async queues the whole batch on the handle's HIP stream and
@@ -168,9 +171,9 @@ int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, int fram
  * segment count.  Several handles used in turn keep as many independent batches in flight, which
  * lets one batch's latency-bound LSD region growing overlap the next batch's streaming
  * kernels.  One batch in flight per handle. */
-int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
+LF_API int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
                            lf_segments* out_dev, int describe);
-int lf_wait(lf_handle* h, int* n_segments);
+LF_API int lf_wait(lf_handle* h, int* n_segments);
 
 /* Which detector lf_process_batch / lf_process_batch_async run for stages a-2 .. a-4 of this handle's batches:
  *   LF_DETECTOR_LSD      (default) the reference's: 3-channel Canny, colour masks, cv2 LSD (line_detector_lsd.py:38-72)
@@ -186,8 +189,8 @@ int lf_wait(lf_handle* h, int* n_segments);
 #define LF_DETECTOR_LSD 0
 #define LF_DETECTOR_EDLINES 1
 struct lf_edlines_params;
-int lf_set_detector(lf_handle* h, int detector, const struct lf_edlines_params* params_or_null);
-int lf_detector_failures(const lf_handle* h);
+LF_API int lf_set_detector(lf_handle* h, int detector, const struct lf_edlines_params* params_or_null);
+LF_API int lf_detector_failures(const lf_handle* h);
 
 /* ---- association: replaces BinaryDescriptorMatcher::match ------------------
  * (binary_descriptor_matcher.cpp:197-254): exact Hamming nearest neighbour of
@@ -204,12 +207,12 @@ int lf_detector_failures(const lf_handle* h);
  */
 #define LF_TIE_LOWEST 0
 #define LF_TIE_MIHASHER 1
-int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
+LF_API int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm,
                  int32_t* idx, float* dist, int on_device);
 /* tie rule of this handle's lf_associate, lf_knn_match and lf_radius_match (LF_TIE_MIHASHER unless set) */
-int lf_set_tie_rule(lf_handle* h, int tie_rule);
+LF_API int lf_set_tie_rule(lf_handle* h, int tie_rule);
 /* float LBD (72-d, unit norm) Euclidean nearest neighbour on fp32 MFMA */
-int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
+LF_API int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* map72, int nm,
                        int32_t* idx, float* dist, int on_device);
 
 /* The list forms of the matcher (SURVEY a-10): BinaryDescriptorMatcher::knnMatch (binary_descriptor_matcher.cpp:258-335)
@@ -222,15 +225,15 @@ int lf_associate_float(lf_handle* h, const float* query72, int nq, const float* 
  *                 [cap] (distance ascending, then index); *total = number of matches; LF_ERR_CAPACITY when total > cap
  *                 (offsets and *total are complete then: size the arrays and call again)
  * Exact XOR / popcount, one lane per query (k_knn.hip); on_device applies to every array. */
-int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, int k, int32_t* idx, float* dist,
+LF_API int lf_knn_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, int k, int32_t* idx, float* dist,
                  int on_device);
 /* The `mask` argument of match / knnMatch / radiusMatch (binary_descriptor_matcher.cpp:231-235, 305-309, 477-481): a DMatch is made
  * only for the queries whose mask byte is not 0, and carries its queryIdx.  lf_select_queries compacts those queries (in order)
  * into selected32 [<= nq][32] with their row numbers in query_idx; run any of the three forms on selected32 -- result row i
  * then belongs to query query_idx[i].  Blocking (returns the count). */
-int lf_select_queries(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* mask, uint8_t* selected32, int32_t* query_idx,
+LF_API int lf_select_queries(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* mask, uint8_t* selected32, int32_t* query_idx,
                       int* n_selected, int on_device);
-int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, float max_distance,
+LF_API int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* map32, int nm, float max_distance,
                     int32_t* offsets, int32_t* idx, float* dist, int cap, int* total, int on_device);
 
 /* BinaryDescriptorMatcher's DATASET form (binary_descriptor_matcher.cpp:70-111 add / train / clear, :117-195 match, :339-425
@@ -246,13 +249,13 @@ int lf_radius_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t*
  *   lf_matcher_radius_match  the same with every code within max_distance; *total = the matches the search found before the masks;
  *                            LF_ERR_CAPACITY when total > cap (size the arrays and call again) */
 typedef struct { int32_t queryIdx, trainIdx, imgIdx; float distance; } lf_dmatch;
-int lf_matcher_add(lf_handle* h, const uint8_t* codes32, int n, int on_device);
-int lf_matcher_clear(lf_handle* h);
-int lf_matcher_size(const lf_handle* h, int* n_images, int* n_descriptors);
-int lf_matcher_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* const* masks, lf_dmatch* out, int* n_out);
-int lf_matcher_knn_match(lf_handle* h, const uint8_t* query32, int nq, int k, const uint8_t* const* masks, int compact_result,
+LF_API int lf_matcher_add(lf_handle* h, const uint8_t* codes32, int n, int on_device);
+LF_API int lf_matcher_clear(lf_handle* h);
+LF_API int lf_matcher_size(const lf_handle* h, int* n_images, int* n_descriptors);
+LF_API int lf_matcher_match(lf_handle* h, const uint8_t* query32, int nq, const uint8_t* const* masks, lf_dmatch* out, int* n_out);
+LF_API int lf_matcher_knn_match(lf_handle* h, const uint8_t* query32, int nq, int k, const uint8_t* const* masks, int compact_result,
                          int32_t* list_offsets, lf_dmatch* out, int* n_lists);
-int lf_matcher_radius_match(lf_handle* h, const uint8_t* query32, int nq, float max_distance, const uint8_t* const* masks,
+LF_API int lf_matcher_radius_match(lf_handle* h, const uint8_t* query32, int nq, float max_distance, const uint8_t* const* masks,
                             int compact_result, int32_t* list_offsets, lf_dmatch* out, int cap, int* n_lists, int* total);
 
 /* Anti-instagram colour clustering (k-means part).  Replaces
@@ -263,7 +266,7 @@ int lf_matcher_radius_match(lf_handle* h, const uint8_t* query32, int nq, float 
  * index).  init_centers [k][3] f64, k <= 16; max_iter 25 and tol 1e-4 are the reference's (scikit-learn's default tol).
  * centers_out [k][3] f64, counts_out [k], *inertia_out (score = -inertia), *n_iter_out.  Blocking.  LF_ERR_BAD_ARG when a
  * cluster stays empty (fewer distinct samples than clusters); LF_ERR_UNSUPPORTED for n > 2^24 points. */
-int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int k, const double* init_centers, int max_iter,
+LF_API int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_device, int k, const double* init_centers, int max_iter,
               double tol, double* centers_out, long long* counts_out, double* inertia_out, int* n_iter_out);
 
 /* ---- live map + associator (SURVEY a-11, 8f-3) ------------------------------------------------
@@ -324,53 +327,53 @@ typedef struct lf_map_config {
     int32_t when_full;         /* LF_MAP_RING | LF_MAP_FULL_ERROR */
 } lf_map_config;
 
-int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** out);
-void lf_map_destroy(lf_map* m);
-const char* lf_map_last_error(const lf_map* m);      /* m == NULL: the last lf_map_create failure */
-int lf_map_get_stream(lf_map* m, void** hip_stream);
-int lf_map_synchronize(lf_map* m);
+LF_API int lf_map_create(int device_id, const lf_map_config* cfg, lf_map** out);
+LF_API void lf_map_destroy(lf_map* m);
+LF_API const char* lf_map_last_error(const lf_map* m);      /* m == NULL: the last lf_map_create failure */
+LF_API int lf_map_get_stream(lf_map* m, void** hip_stream);
+LF_API int lf_map_synchronize(lf_map* m);
 /* append n entries as they are (color NULL: 255 = matches every colour; ground NULL: zeros); hits 1, last_seen -1 */
-int lf_map_seed(lf_map* m, const uint8_t* code32, const uint8_t* color, const double* ground4, int n, int on_device);
+LF_API int lf_map_seed(lf_map* m, const uint8_t* code32, const uint8_t* color, const double* ground4, int n, int on_device);
 /* entries in use, ring head, lifetime counters; waits for the map's stream; reports a failing update (once, the
  * outputs are still filled in) */
-int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_t* total_refreshed);
+LF_API int lf_map_size(lf_map* m, int* size, int* head, int64_t* total_appended, int64_t* total_refreshed);
 /* Nearest map entry of n queries (a-10 semantics + the map's gating / max_distance).  color may be NULL when
  * gating is off.  h: the handle whose stream produced the query arrays (the map's stream waits for it, and the
  * handle's next batch waits until the map has read them), or NULL when the caller has ordered that itself.
  * on_device applies to all four arrays; with host arrays the call returns when idx / dist are in place. */
-int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, const uint8_t* color, int n,
+LF_API int lf_map_associate(lf_map* m, lf_handle* h, const uint8_t* code32, const uint8_t* color, int n,
                      int32_t* idx, float* dist, int on_device);
 /* tie rule of the map's associations (lf_map_associate, lf_map_step*): LF_TIE_MIHASHER unless set; with LF_TIE_MIHASHER and
  * colour gating the reference's discovery order applies among the entries the query may match */
-int lf_map_set_tie_rule(lf_map* m, int tie_rule);
+LF_API int lf_map_set_tie_rule(lf_map* m, int tie_rule);
 /* Device arrays of `segs` (frame_offset, code, color, keep, ground; capacity ignored) + idx / dist -> one block in
  * device memory.  block_rows < n + 1: LF_ERR_CAPACITY -- never truncated: the block is then ONLY a header with the
  * overflow marker, which a rank of a multi-GPU step still all-gathers so that every replica skips that step's update
  * together (lf_map_update) and reports LF_ERR_CAPACITY instead of waiting for a collective that never comes.
  * frame_pose: host [n_frames][3] = x, y, theta per frame, or NULL. */
-int lf_map_pack_block(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const int32_t* idx,
+LF_API int lf_map_pack_block(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const int32_t* idx,
                       const float* dist, const double* frame_pose, int step, uint8_t* block, int block_rows);
 /* apply n_blocks consecutive blocks of block_rows rows each (device memory), in order.  If any of them has a bad
  * header or the overflow marker, NONE is applied (reported as described above). */
-int lf_map_update(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows);
+LF_API int lf_map_update(lf_map* m, const uint8_t* blocks, int n_blocks, int block_rows);
 /* single-GPU convenience: lf_map_associate + lf_map_pack_block + lf_map_update; idx / dist device arrays [n] */
-int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const double* frame_pose,
+LF_API int lf_map_step(lf_map* m, lf_handle* h, const lf_segments* segs, int n, int n_frames, const double* frame_pose,
                 int step, int32_t* idx, float* dist);
 /* lf_map_step with HOST arrays in `segs` (frame_offset, code, color, keep, ground as lf_process_batch returns them with
  * out_on_device = 0) and host idx / dist: upload, associate, update, download; returns when idx / dist are in place */
-int lf_map_step_host(lf_map* m, const lf_segments* segs, int n, int n_frames, const double* frame_pose, int step,
+LF_API int lf_map_step_host(lf_map* m, const lf_segments* segs, int n, int n_frames, const double* frame_pose, int step,
                      int32_t* idx, float* dist);
 /* copy entries [first, first + n) to host arrays (NULL arrays are skipped); waits for the map's stream */
-int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,
+LF_API int lf_map_fetch(lf_map* m, int first, int n, uint8_t* code32, uint8_t* color, double* ground4, int32_t* hits,
                  int32_t* last_seen);
 
 /* per-stage timing with HIP events on the map's stream: 0 query packing (always 0 calls since the association became one
  * launch that expands the queries itself), 1 association (MFMA), 2 block packing,
  * 3 map update.  lf_map_get_timing returns what accumulated since the previous call and resets it. */
 #define LF_MAP_N_STAGES 4
-int lf_map_set_profiling(lf_map* m, int enabled);
-int lf_map_get_timing(lf_map* m, double* ms_per_stage, int32_t* launches_per_stage, int n);
-const char* lf_map_stage_name(int stage);
+LF_API int lf_map_set_profiling(lf_map* m, int enabled);
+LF_API int lf_map_get_timing(lf_map* m, double* ms_per_stage, int32_t* launches_per_stage, int n);
+LF_API const char* lf_map_stage_name(int stage);
 
 /* ---- EDLines detector + multi-octave KeyLines / LBD --------------------------------
  * The reference's second detector: BinaryDescriptor::operator() with useProvidedKeyLines = false
@@ -419,18 +422,26 @@ typedef struct lf_keylines {
     float* desc;
     uint8_t* code;
 } lf_keylines;
-void lf_edlines_default_params(lf_edlines_params* p);
-int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+LF_API void lf_edlines_default_params(lf_edlines_params* p);
+LF_API int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                       const lf_edlines_params* params_or_null, lf_keylines* out, int out_on_device, int describe,
                       int* n_keylines, int32_t* frame_status_or_null);
+/* The `mask` argument of BinaryDescriptor::detect (binary_descriptor_custom.cpp:415-437, 509-519): masks = n_frames images of the
+ * handle's WORKING size [rows][cols] u8; a KeyLine whose two end points (image coordinates, truncated) both lie on zero pixels is
+ * erased -- BY THE REFERENCE'S LOOP AS WRITTEN, which does not step back after an erase: the KeyLine that slides into the erased
+ * place is never tested, so of a run of consecutive KeyLines that fail the test the 1st, 3rd, 5th ... go and the 2nd, 4th ... stay.
+ * (LSDDetectorC::detect has the step back: lf_lsd_keylines_batch_ex.)  out->capacity must hold the KeyLines BEFORE the mask. */
+LF_API int lf_keylines_batch_masked(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+                             const lf_edlines_params* params_or_null, const uint8_t* masks, int masks_on_device, lf_keylines* out,
+                             int out_on_device, int describe, int* n_keylines, int32_t* frame_status);
 /* The pipelined form (like lf_process_batch_async): images and every out_dev array in device memory, the whole batch is queued
  * on the handle's stream and the call returns; lf_wait blocks and returns the KeyLine total in *n_segments (LF_ERR_CAPACITY
  * when it exceeds out_dev->capacity: no array is complete then); lf_keylines_frame_status copies the per-frame status of the
  * batch lf_wait completed.  One batch in flight per handle; several handles keep the chip busy while one frame's edge walk
  * is a single wave's chain. */
-int lf_keylines_batch_async(lf_handle* h, const uint8_t* images_dev, int n_frames, int input_kind, int n_octaves,
+LF_API int lf_keylines_batch_async(lf_handle* h, const uint8_t* images_dev, int n_frames, int input_kind, int n_octaves,
                             const lf_edlines_params* params_or_null, lf_keylines* out_dev, int describe);
-int lf_keylines_frame_status(lf_handle* h, int32_t* frame_status, int n_frames);
+LF_API int lf_keylines_frame_status(lf_handle* h, int32_t* frame_status, int n_frames);
 /* The library's OTHER detector: LSDDetectorC::detect (src/line_descriptor/src/LSDDetector_custom.cpp:49-72, 130-215) -- a gray
  * pyramid by pyrDown (scale 2, no blur), cv::createLineSegmentDetector() with its DEFAULT parameters (REFINE_STD) on every level,
  * one KeyLine per line (checkLineExtremes, start / end points scaled back to level 0, lineLength, numOfPixels = LineIterator's
@@ -440,7 +451,7 @@ int lf_keylines_frame_status(lf_handle* h, int32_t* frame_status, int n_frames);
  * sub-handle of the level's geometry: dense problems, one wave per connected component -- a completeness path (detect -> compute
  * for both detectors of the library), not a fast one.  LF_ERR_CAPACITY: more KeyLines than out->capacity, or a level with more
  * lines than max_lines_per_color. */
-int lf_lsd_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+LF_API int lf_lsd_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                           lf_keylines* out, int out_on_device, int describe, int* n_keylines);
 /* The fork's own overloads of the same detector (the reason its files are called _custom): LSDDetectorC::detect(image, keylines,
  * scale, numOctaves, LSDOptions, mask) and detectFast -- LSDDetector_custom.cpp:218-325 and :327-438 are the same text -- i.e. the
@@ -457,8 +468,8 @@ typedef struct {
     double scale, sigma_scale, quant, ang_th, log_eps, density_th;
     double min_length;
 } lf_lsd_options;
-void lf_lsd_default_options(lf_lsd_options* opts);      /* createLineSegmentDetector()'s: 1, 1024, 0.8, 0.6, 2.0, 22.5, 0, 0.7; min_length 0 */
-int lf_lsd_keylines_batch_ex(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
+LF_API void lf_lsd_default_options(lf_lsd_options* opts);      /* createLineSegmentDetector()'s: 1, 1024, 0.8, 0.6, 2.0, 22.5, 0, 0.7; min_length 0 */
+LF_API int lf_lsd_keylines_batch_ex(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                              const lf_lsd_options* opts, const uint8_t* masks, int masks_on_device,
                              lf_keylines* out, int out_on_device, int describe, int* n_keylines);
 /* Plugin path with the EDLines detector: lf_set_image_edlines, then lf_detect_lines exactly as after lf_set_image.
@@ -469,14 +480,14 @@ int lf_lsd_keylines_batch_ex(lf_handle* h, const uint8_t* images, int n_frames, 
  * (line_detector_lsd.py:38-58) is set under the truncated, clamped centre of the line; normals, centres and the
  * endpoint ordering come from the same code as for LSD lines (_findNormal / _correctPixelOrdering, :74-125).
  * LF_ERR_CAPACITY when the detector gives up on the image (the reference prints "Line Detection not finished"). */
-int lf_set_image_edlines(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes,
+LF_API int lf_set_image_edlines(lf_handle* h, const uint8_t* bgr, int rows, int cols, int row_stride_bytes,
                          const lf_edlines_params* params_or_null);
 /* BinaryDescriptor::compute on GIVEN KeyLines (:524-687, useDetectionData = false): gradients from
  * computeGaussianPyramid (:350-371: GaussianBlur 5x5 sigma 1, then pyrDown by 2 per octave) + Sobel (:374-398).
  * gray: [n_frames][rows][cols] u8 working images; per line: its frame, in_octave endpoints (4), angle, num_pixels,
  * octave (< LF_MAX_OCTAVES).  desc [n][72] / code [n][32], either may be NULL.  All arrays host (on_device = 0) or
  * device.  The multi-octave LSD KeyLines of LSDDetector_custom.cpp:130-215 (scale 2) are what lives on this pyramid. */
-int lf_describe_keylines(lf_handle* h, const uint8_t* gray, int n_frames, const int32_t* line_frame, const float* in_octave4,
+LF_API int lf_describe_keylines(lf_handle* h, const uint8_t* gray, int n_frames, const int32_t* line_frame, const float* in_octave4,
                          const float* angle, const int32_t* num_pixels, const int32_t* octave, int n, float* desc72,
                          uint8_t* code32, int on_device);
 /* intermediate results of the last lf_keylines_batch for tests (synchronises): `what` = 0 blurred octave image (u8)
@@ -485,7 +496,7 @@ int lf_describe_keylines(lf_handle* h, const uint8_t* gray, int n_frames, const 
  * edges, lines, status) 7 line endpoints (f32 x4, [frames][max_lines]) 8 lineEquation[2] (f64) 9 direction (f32)
  * 10 pixels per line (i32) 11 salience (f32) 12 the octave's input image (u8); dims: octave rows, cols, cap, max_edges,
  * max_lines */
-int lf_keylines_debug_fetch(lf_handle* h, int octave, int what, void* dst, size_t bytes, int32_t* dims5_or_null);
+LF_API int lf_keylines_debug_fetch(lf_handle* h, int octave, int what, void* dst, size_t bytes, int32_t* dims5_or_null);
 
 /* ---- host ingest: replaces duckietown_utils.jpg.image_cv_from_jpg ---------------
  * = cv2.imdecode(np.fromstring(data, np.uint8), cv2.IMREAD_COLOR)
@@ -507,7 +518,7 @@ int lf_keylines_debug_fetch(lf_handle* h, int octave, int what, void* dst, size_
  *                         (line_detector_node.py:155-158).  Without frame_status the call returns
  *                         LF_ERR_DECODE if any frame failed.
  */
-int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
+LF_API int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
                          int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
                          int* frame_status);
 /* The same with the ENTROPY DECODER ON THE DEVICE as well (k_jhuff.hip): the host only parses the headers; unstuffing,
@@ -515,14 +526,14 @@ int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const size_t*
  * the handle's stream.  Same streams accepted, same output bits, same per-frame status as lf_jpeg_decode_batch.  n_threads:
  * host threads for header parsing and for copying the entropy-coded bytes into pinned memory (<= 0: up to 16).  The call
  * returns when the batch is decoded (the per-frame status comes from the device). */
-int lf_jpeg_decode_batch_gpu(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
+LF_API int lf_jpeg_decode_batch_gpu(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
                              int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
                              int* frame_status);
 /* size and layout of one stream without decoding it (hmax x vmax = luma sampling factors) */
-int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax);
+LF_API int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax);
 /* the handle's own device staging buffer for input frames ([max_frames][in_rows][in_cols][3] u8): decode
  * into it, then hand the same pointer to lf_process_batch with frames_on_device = 1 */
-int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* bytes);
+LF_API int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* bytes);
 
 /* ---- SegmentList glue ---------------------------------------------------------------
  * The reference hands segments from node to node as duckietown_msgs/SegmentList and builds / walks them one
@@ -545,9 +556,9 @@ int lf_frames_buffer(lf_handle* h, uint8_t** device_ptr, size_t* bytes);
 #define LF_MSG_DETECTOR 0
 #define LF_MSG_GROUND 1
 #define LF_MSG_FILTERED 2
-int lf_serialize_segments(lf_handle* h, const lf_segments* segs, int segs_on_device, int n_frames, int stage,
+LF_API int lf_serialize_segments(lf_handle* h, const lf_segments* segs, int segs_on_device, int n_frames, int stage,
                           uint8_t* out, size_t out_capacity, int out_on_device, int64_t* frame_byte_offset);
-int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int bodies_on_device, const int64_t* frame_byte_offset,
+LF_API int lf_deserialize_segments(lf_handle* h, const uint8_t* bodies, int bodies_on_device, const int64_t* frame_byte_offset,
                             int n_frames, lf_segments* out, int out_on_device, int* n_segments);
 
 /* ---- introspection for tests and the benchmark ---------------------------- */
@@ -565,40 +576,40 @@ typedef enum lf_buffer_id {
     LF_BUF_LSD_SCRATCH = 10  /* u32 [frames][3][Hs*Ws]   region-list scratch (diagnostic builds park counters here) */
 } lf_buffer_id;
 /* copy an intermediate buffer of the last batch to host memory (synchronises) */
-int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes);
+LF_API int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes);
 /* evaluate one deterministic-math routine on the device (host arrays in/out):
  * which = 0 exp 1 log 2 sin 3 cos 4 atan 5 asin 6 log10 7 sinh_small 8 atan2(a,b) 9 pow(a,b)
  *         10 sqrt 11 a/b 12 fastAtan2(float a, float b) 13 sqrtf 14 float a/b */
-int lf_debug_detmath(lf_handle* h, int which, const double* a, const double* b_or_null, double* y, int n);
+LF_API int lf_debug_detmath(lf_handle* h, int which, const double* a, const double* b_or_null, double* y, int n);
 /* counter calibration: stream `bytes` of a scratch buffer `reps` times with `width` (4 / 8 / 12 / 16) bytes per lane
  * per access (write != 0: stores, 4 or 16); run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` (tools/fetch_probe.py) */
-int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps);
+LF_API int lf_debug_probe(lf_handle* h, int width, int write, size_t bytes, int reps);
 /* LSD stages alone on a binary image of the handle's working size (non-zero = edge pixel, colour
  * mask forced to all ones); host pointers; lines before normal-based endpoint ordering */
-int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out);
+LF_API int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, int cols, float* lines4, int cap, int* n_out);
 /* the sort emulation behind lsd_seed_order = LF_LSD_SEED_OPENCV32 alone: order[i] = index of the element that
  * std::sort(begin, end, [](a, b) { return a.key > b.key; }) of libstdc++ leaves at place i, for n keys in [0, 1023] in their
  * initial order (host pointers; n < 2^20).  Elements with key 0 are the detector's flat pixels -- never seeds, anonymous on the
  * device (the sparse form keeps only the non-zero keys): the elements with a non-zero key come first, in std::sort's order, the
  * zero-key ones follow by index (std::sort leaves them behind the others too, in an order nothing observes) */
-int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order);
+LF_API int lf_debug_std_sort(lf_handle* h, const int32_t* keys, int n, int32_t* order);
 /* scaled LSD image size for this handle */
-int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
+LF_API int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
 /* How many batches (handles) a caller should keep in flight for the content this handle saw last: region growing is a chain
  * of dependent steps per problem, and on busy content (camera frames with texture: a few problems of 10 - 20 k edge pixels set
  * the batch's latency while most of the chip waits) only more batches in flight fill the machine.  8 (6 until the kernels of round 4: six and eight measured 144 - 146 k and 147 - 148 k frames/s) while the last batch's
  * problems fit the small LDS slice of k_lsd_grow (lane markings), 18 otherwise (measured on camera frames, round 4: 6 / 12 / 18 in
  * flight = 50 k / 56 k / 62 k frames/s; give the HIP runtime more hardware queues than that: GPU_MAX_HW_QUEUES, INTEGRATION.md
  * section 4).  A hint: results never depend on it. */
-int lf_suggested_depth(const lf_handle* h);
+LF_API int lf_suggested_depth(const lf_handle* h);
 
 /* per-kernel timing with HIP events on the handle's stream */
 #define LF_N_STAGES 13
-int lf_set_profiling(lf_handle* h, int enabled);
+LF_API int lf_set_profiling(lf_handle* h, int enabled);
 /* ms accumulated per stage since the last reset, and launches counted */
-int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n);
-int lf_reset_timing(lf_handle* h);
-const char* lf_stage_name(int stage);
+LF_API int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n);
+LF_API int lf_reset_timing(lf_handle* h);
+LF_API const char* lf_stage_name(int stage);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ EXPORTS = (
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
     "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu",
     "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
-    "lf_lsd_default_options", "lf_lsd_keylines_batch_ex",
+    "lf_lsd_default_options", "lf_lsd_keylines_batch_ex", "lf_keylines_batch_masked",
     "lf_matcher_add", "lf_matcher_clear", "lf_matcher_size", "lf_matcher_match", "lf_matcher_knn_match", "lf_matcher_radius_match",
 )
 DETECTORS = {"lsd": 0, "edlines": 1}
@@ -167,6 +167,9 @@ def load():
     lib.lf_keylines_batch.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfEdlinesParams), ctypes.POINTER(LfKeylines), ci, ci,
                                       ctypes.POINTER(ci), vp]
     lib.lf_keylines_batch.restype = ci
+    lib.lf_keylines_batch_masked.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfEdlinesParams), vp, ci, ctypes.POINTER(LfKeylines), ci, ci,
+                                             ctypes.POINTER(ci), vp]
+    lib.lf_keylines_batch_masked.restype = ci
     lib.lf_describe_keylines.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, ci]
     lib.lf_describe_keylines.restype = ci
     lib.lf_keylines_debug_fetch.argtypes = [vp, ci, ci, vp, ctypes.c_size_t, vp]

@@ -1376,4 +1376,88 @@ void launch_kl_offsets(int n_frames, const int* frame_count, int capacity, int* 
     hipLaunchKernelGGL(k_kl_offsets, dim3(1), dim3(64), 0, s, n_frames, frame_count, capacity, frame_offset, totals);
 }
 
+// ---- the `mask` argument of BinaryDescriptor::detect (ref: binary_descriptor_custom.cpp:509-519), with its loop as written:
+//     for (keyCounter = 0; keyCounter < keylines.size(); keyCounter++)
+//         if (mask(start) == 0 && mask(end) == 0) keylines.erase(keylines.begin() + keyCounter);
+// -- no step back after the erase, so the KeyLine that slides into the erased place is never tested: in a run of consecutive
+// KeyLines that fail the test the 1st, 3rd, 5th ... are erased and the 2nd, 4th ... survive.  With lastgood(j) = the last KeyLine
+// in front of j that passes, erased(j) = fails(j) and (j - lastgood(j) - 1) even: a prefix maximum.  (LSDDetectorC::detect has the
+// step back, LSDDetector_custom.cpp:203-213: every failing KeyLine goes; lanefront_lsdkl.inc.)
+// k_kl_mask_flags: one workgroup per frame over the assembled (unmasked) KeyLines: erased[] and the frame's kept count.
+__global__ __launch_bounds__(256) void k_kl_mask_flags(const int* __restrict__ fo, const float* __restrict__ start_end, const uint8_t* __restrict__ masks,
+                                                      int rows, int cols, int capacity, uint8_t* __restrict__ erased, int* __restrict__ kept_count)
+{
+    __shared__ int s_w[4], s_k[4];
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int base = fo[f], n = fo[f + 1] - base;
+    if (n <= 0 || base + n > capacity) { if (t == 0) kept_count[f] = 0; return; }
+    const uint8_t* mk = masks + (size_t)f * rows * cols;
+    int carry = -1, kept = 0;                                              // last passing KeyLine so far (index in the frame)
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + t;
+        bool fails = false;
+        if (j < n) {
+            const float* e = start_end + 4 * (size_t)(base + j);
+            fails = mk[(size_t)(int)e[1] * cols + (int)e[0]] == 0 && mk[(size_t)(int)e[3] * cols + (int)e[2]] == 0;
+        }
+        int lg = (j < n && !fails) ? j : -1;                                // inclusive prefix maximum over the chunk
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(lg, d); if (lane >= d) lg = max(lg, o); }
+        if (lane == 63) s_w[wave] = lg;
+        __syncthreads();
+        int before = carry;
+        for (int k = 0; k < wave; ++k) before = max(before, s_w[k]);
+        lg = max(lg, before);
+        const bool er = fails && (((j - lg - 1) & 1) == 0);
+        if (j < n) erased[base + j] = er ? 1 : 0;
+        const unsigned long long bk = __ballot(j < n && !er);
+        if (lane == 0) s_k[wave] = __popcll(bk);
+        carry = max(max(max(carry, s_w[0]), max(s_w[1], s_w[2])), s_w[3]);
+        __syncthreads();
+        kept += s_k[0] + s_k[1] + s_k[2] + s_k[3];
+        __syncthreads();
+    }
+    if (t == 0) kept_count[f] = kept;
+}
+
+// k_kl_mask_move: the kept KeyLines of every frame, in order, from the assembled arrays to the final ones at the new offsets
+__global__ __launch_bounds__(256) void k_kl_mask_move(const int* __restrict__ fo_src, const int* __restrict__ fo_dst, int capacity, const uint8_t* __restrict__ erased,
+                                                     KlOut src, KlOut dst)
+{
+    __shared__ int s_k[4];
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int base = fo_src[f], n = fo_src[f + 1] - base, out0 = fo_dst[f];
+    if (n <= 0 || base + n > capacity || fo_dst[f + 1] > capacity) return;
+    int done = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + t;
+        const bool keep = j < n && !erased[base + j];
+        const unsigned long long bk = __ballot(keep);
+        if (lane == 0) s_k[wave] = __popcll(bk);
+        __syncthreads();
+        int r = done + __popcll(bk & ((1ull << lane) - 1ull));
+        for (int k = 0; k < wave; ++k) r += s_k[k];
+        if (keep) {
+            const size_t a = (size_t)base + j, b = (size_t)out0 + r;
+#define MV4(fld) if (src.fld && dst.fld) { dst.fld[4 * b] = src.fld[4 * a]; dst.fld[4 * b + 1] = src.fld[4 * a + 1]; dst.fld[4 * b + 2] = src.fld[4 * a + 2]; dst.fld[4 * b + 3] = src.fld[4 * a + 3]; }
+#define MV1(fld) if (src.fld && dst.fld) dst.fld[b] = src.fld[a];
+            MV4(start_end) MV4(in_octave) MV1(angle) MV1(num_pixels) MV1(line_length) MV1(octave) MV1(class_id) MV1(response) MV1(size) MV1(salience) MV1(frame)
+            if (src.pt && dst.pt) { dst.pt[2 * b] = src.pt[2 * a]; dst.pt[2 * b + 1] = src.pt[2 * a + 1]; }
+#undef MV4
+#undef MV1
+        }
+        done += s_k[0] + s_k[1] + s_k[2] + s_k[3];
+        __syncthreads();
+    }
+}
+
+void launch_kl_mask(int n_frames, const int* fo_src, int* fo_dst, int* totals, int capacity, const uint8_t* masks, int rows, int cols, uint8_t* erased,
+                    int* kept_count, const KlOut& src, const KlOut& dst, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_kl_mask_flags, dim3(n_frames), dim3(256), 0, s, fo_src, src.start_end, masks, rows, cols, capacity, erased, kept_count);
+    launch_kl_offsets(n_frames, kept_count, capacity, fo_dst, totals, s);
+    hipLaunchKernelGGL(k_kl_mask_move, dim3(n_frames), dim3(256), 0, s, fo_src, fo_dst, capacity, erased, src, dst);
+}
+
+
 }  // namespace lf

@@ -38,6 +38,8 @@ struct KlOut {
 };
 
 
+void launch_kl_mask(int n_frames, const int* fo_src, int* fo_dst, int* totals, int capacity, const uint8_t* masks, int rows, int cols, uint8_t* erased,
+                    int* kept_count, const KlOut& src, const KlOut& dst, hipStream_t s);
 void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* taps5, int grad_threshold, uint8_t* blur,
                     uint32_t* dxy, uint16_t* g, hipStream_t s);
 void ed_resize_tables(int H, int W, int DH, int DW, double scale, int* tab);        // 4 ints per destination column, then 4 per destination row

@@ -445,7 +445,7 @@ static bool lsd_grow_bitmap_slice(const LsdParams& p, int reg_lds, bool busy, in
     const long long room = (long long)(160 * 1024 / 6 - 2304) - (long long)plane - (long long)lists - 12;
     used_cap = room > 512 ? (int)((room * 8) & ~31ll) : 4096;
     if (used_cap > 32768) used_cap = 32768;
-    if (used_override > 0) used_cap = used_override & ~31;   // tests: a small capacity sends problems down the overflow path
+    if (used_override > 0) used_cap = (used_override > 32768 ? 32768 : used_override) & ~31;   // tests: a small capacity sends problems down the overflow path (clamped: the plane's running counts are u16)
     if ((size_t)used_cap > Ps) used_cap = (int)((Ps + 31) & ~(size_t)31);
     lds = plane + (size_t)((used_cap >> 5) + 1) * 4 + lists + 8;
     return plane <= (size_t)28 * 1024 && Ps < ((size_t)1 << 21);

@@ -601,6 +601,7 @@ extern "C" int lf_synchronize(lf_handle* h)
 static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_working_image)
 {
     hipStream_t s = h->stream;
+    h->overflow_zeroed = false;          // (set at the successful END only: an error exit must not leave run_segments believing the overflow words are zero)
     PreParams pp = h->pre;
     if (from_working_image) {
         // plugin path: the caller already resized, cropped and colour-corrected (line_detector_node.py:163-180)
@@ -621,7 +622,6 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     {
         StageTimer t(h, ST_LSD_GRAD);
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_zero, 0, h->zero_bytes, s));           // every counter of the batch (see d_zero)
-        h->overflow_zeroed = true;
         launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec,
                         h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, true, s);
     }
@@ -653,6 +653,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
     }
     LF_HIP_CHECK(h, hipGetLastError());
     h->last_frames = n;
+    h->overflow_zeroed = true;           // the batch's one memset (above) covered the overflow words
     return LF_OK;
 }
 
@@ -928,10 +929,10 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
     const size_t nm_pad = assoc_rows_padded_m(nm);
     int rc;
     if ((rc = ensure(h, h->a_mx, nm_pad * 256)) || (rc = ensure(h, h->a_mcx, nm_pad * 32))) return rc;
-    if (h->tie_rule == LF_TIE_MIHASHER) {
-        if (getenv("LF_ASSOC_INT8")) { lf_set_error(h, LF_ERR_UNSUPPORTED, "LF_ASSOC_INT8 (the int8 A/B kernels) supports LF_TIE_LOWEST only"); return LF_ERR_UNSUPPORTED; }
-        if ((rc = ensure(h, h->a_best, (size_t)nq * 8)) != LF_OK) return rc;
-    }
+    // the int8 A/B kernels (LF_ASSOC_INT8) have no tie pass: the lowest index there, said once
+    const bool ties = h->tie_rule == LF_TIE_MIHASHER && !getenv("LF_ASSOC_INT8");
+    if (h->tie_rule == LF_TIE_MIHASHER && !ties) { static bool told = false; if (!told) { told = true; fprintf(stderr, "lanefront: LF_ASSOC_INT8 is set: lf_associate falls back to LF_TIE_LOWEST (the int8 A/B kernels have no tie pass)\n"); } }
+    if (ties && (rc = ensure(h, h->a_best, (size_t)nq * 8)) != LF_OK) return rc;
     const uint8_t *dq = query32, *dmp = map32;
     int32_t* didx = idx; float* ddist = dist;
     if (!on_device) {
@@ -943,9 +944,9 @@ extern "C" int lf_associate(lf_handle* h, const uint8_t* query32, int nq, const 
     }
     {
         StageTimer t(h, ST_ASSOC);
-        h->a_ws.tie_res = h->tie_rule == LF_TIE_MIHASHER ? static_cast<unsigned long long*>(h->a_best.p) : nullptr;      // (the distance pass then lists the queries of the tie pass)
+        h->a_ws.tie_res = ties ? static_cast<unsigned long long*>(h->a_best.p) : nullptr;      // (the distance pass then lists the queries of the tie pass)
         LF_HIP_CHECK(h, launch_assoc(dq, nq, dmp, nm, (int8_t*)h->a_mx.p, (int8_t*)h->a_mcx.p, h->a_ws, didx, ddist, s));
-        if (h->tie_rule == LF_TIE_MIHASHER)
+        if (ties)
             LF_HIP_CHECK(h, launch_assoc_ties(dq, nullptr, nq, (const int8_t*)h->a_mx.p, dmp, nullptr, nm, nullptr, 0, h->a_ws,
                                               static_cast<unsigned long long*>(h->a_best.p), didx, ddist, s));
     }

@@ -182,8 +182,8 @@ class FrontEnd(object):
         return int(self.lib.lf_detector_failures(self.h))
 
     def suggested_depth(self):
-        """Batches (handles) worth keeping in flight for the content this handle saw last (lf_suggested_depth): 6 on lane
-        frames, 12 on busy camera content.  A throughput hint only."""
+        """Batches (handles) worth keeping in flight for the content this handle saw last (lf_suggested_depth): 8 on lane
+        frames, 18 on busy camera content.  A throughput hint only."""
         return int(self.lib.lf_suggested_depth(self.h))
 
     def wait(self):
@@ -288,11 +288,13 @@ class FrontEnd(object):
             setattr(p, k, v)
         return p
 
-    def keylines_batch(self, images, n_octaves=1, describe=True, params=None, gray=False, capacity=None):
+    def keylines_batch(self, images, n_octaves=1, describe=True, params=None, gray=False, capacity=None, masks=None):
         """BinaryDescriptor::operator() with drawn KeyLines (ref: binary_descriptor_custom.cpp:263-301): EDLines over
         n_octaves octaves + LBD on the detector's gradients.  images: raw camera frames (n, in_rows, in_cols, 3) BGR, or
         with gray=True working-size gray images (n, rows, cols) u8.  Returns a dict of per-KeyLine numpy arrays (KeyLine
-        fields, include/lanefront.h) + 'n', 'frame_offset' and 'frame_status'."""
+        fields, include/lanefront.h) + 'n', 'frame_offset' and 'frame_status'.
+        masks: (n, rows, cols) u8 of the working size = detect's mask argument (:509-519): a KeyLine with both end points on zero
+        pixels is erased, by the reference's loop as written (no step back after an erase: see include/lanefront.h)."""
         images = np.ascontiguousarray(images, np.uint8)
         want = (self.rows, self.cols) if gray else (self.in_rows, self.in_cols, 3)
         if images.ndim == len(want):
@@ -312,9 +314,19 @@ class FrontEnd(object):
             setattr(s, k, out[k].ctypes.data)
         total = ctypes.c_int()
         status = np.zeros(n, np.int32)
-        self._check(self.lib.lf_keylines_batch(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves),
-                                               ctypes.byref(params) if params is not None else None, ctypes.byref(s), 0,
-                                               int(bool(describe)), ctypes.byref(total), _ptr(status)))
+        if masks is not None:
+            masks = np.ascontiguousarray(masks, np.uint8)
+            if masks.ndim == 2:
+                masks = masks[None]
+            if masks.shape != (n, self.rows, self.cols):
+                raise ValueError("masks must be (%d,%d,%d), got %r" % (n, self.rows, self.cols, masks.shape))
+            self._check(self.lib.lf_keylines_batch_masked(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves),
+                                                          ctypes.byref(params) if params is not None else None, _ptr(masks), 0, ctypes.byref(s), 0,
+                                                          int(bool(describe)), ctypes.byref(total), _ptr(status)))
+        else:
+            self._check(self.lib.lf_keylines_batch(self.h, _ptr(images), n, 1 if gray else 0, 0, int(n_octaves),
+                                                   ctypes.byref(params) if params is not None else None, ctypes.byref(s), 0,
+                                                   int(bool(describe)), ctypes.byref(total), _ptr(status)))
         t = total.value
         for k, _, _ in _lib.KEYLINE_FIELDS:
             if k in out:

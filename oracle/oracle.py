@@ -694,6 +694,22 @@ def edlines(blurred, params=None):
     return out
 
 
+def erase_by_mask_as_written(start_end, mask):
+    """BinaryDescriptor::detectImpl's mask loop AS WRITTEN (ref: binary_descriptor_custom.cpp:509-519):
+        for (keyCounter = 0; keyCounter < keylines.size(); keyCounter++)
+            if (mask(start) == 0 && mask(end) == 0) keylines.erase(keylines.begin() + keyCounter);
+    -- no step back after the erase, so the element that slides into the erased place is skipped.  Returns the indices (into
+    start_end) of the KeyLines that remain."""
+    idx = list(range(len(start_end)))
+    k = 0
+    while k < len(idx):
+        sx, sy, ex, ey = (int(v) for v in start_end[idx[k]])
+        if mask[sy, sx] == 0 and mask[ey, ex] == 0:
+            del idx[k]
+        k += 1
+    return np.asarray(idx, np.int64)
+
+
 def octave_keylines(gray, n_octaves=1, params=None, ksize=5, cap=20000):
     """BinaryDescriptor::operator() (detect with EDLines over n_octaves + LBD on the detector's gradients): dict of
     per-KeyLine arrays in detectImpl's order, plus 'octave_size' [(rows, cols)] and 'octave_lines'."""

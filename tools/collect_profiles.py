@@ -47,4 +47,27 @@ with open(os.path.join(P, "traffic.json"), "w") as g:
     subprocess.check_call([sys.executable, "tools/pmc_traffic.py", os.path.join(P, prefix + "_pmc_write_size.csv"),
                            os.path.join(P, prefix + "_pmc_fetch_size.csv"), prefix], stdout=g)
 subprocess.check_call([sys.executable, "tools/pmc_grow.py", prefix])
+# round 5: the A/B configurations, the 1080p geometry, the seed-order kernel's phase stamps, instruction counts per kernel
+for f in glob.glob(os.path.join(T, "bench_ab_*.json")) + glob.glob(os.path.join(T, "bench_hd.json")):
+    shutil.copy(f, os.path.join(P, prefix + "_" + os.path.basename(f)))
+if os.path.exists(os.path.join(T, "seed_stamps.txt")):
+    with open(os.path.join(T, "seed_stamps.txt")) as f, open(os.path.join(P, prefix + "_seed32_stamps.txt"), "w") as g:
+        g.writelines(l for l in f if l.startswith("[seed32]"))
+f = glob.glob(os.path.join(T, "pi/**/*counter_collection.csv"), recursive=True)
+if f:
+    tot, cnt = {}, {}
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"].split("(")[0].split("::")[-1]
+        tot.setdefault(k, {}).setdefault(r["Counter_Name"], 0.0)
+        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "SQ_INSTS_VALU":
+            cnt[k] = cnt.get(k, 0) + 1
+    with open(os.path.join(P, prefix + "_instructions_per_kernel.txt"), "w") as g:
+        g.write("wave instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES; bench.py --depth 1, 256-frame batch)\n")
+        for k, v in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_INSTS_VALU", 0)):
+            n = max(cnt.get(k, 1), 1)
+            if v.get("SQ_INSTS_VALU", 0) / n < 1e4:
+                continue
+            g.write("%-32s VALU %8.2f M  SALU %8.2f M  LDS %7.2f M  wave quad-cycles %9.1f M\n" % (k[:32], v.get("SQ_INSTS_VALU", 0) / n / 1e6, v.get("SQ_INSTS_SALU", 0) / n / 1e6,
+                                                                                                 v.get("SQ_INSTS_LDS", 0) / n / 1e6, v.get("SQ_WAVE_CYCLES", 0) / n / 1e6))
 print("collected", prefix)

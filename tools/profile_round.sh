@@ -6,7 +6,14 @@ python -m pytest tests -m gpu -x -q > $R/gpurun_out/$T/pytest.log 2>&1; echo "py
 python bench.py > $R/gpurun_out/$T/bench_n1.json 2> $R/gpurun_out/$T/bench_n1.err
 # the driver's form of the same run (20 timed steps: the six-deep pipeline's fill and drain weigh more)
 python bench.py --gpus 1 --steps 20 --warmup 5 --secondary none > $R/gpurun_out/$T/bench_driver_form.json 2>/dev/null
-python tools/assoc_rate.py > $R/gpurun_out/$T/assoc_rate.txt 2>&1
+python tools/assoc_rate.py --tie-rule lowest > $R/gpurun_out/$T/assoc_rate.txt 2>&1
+python tools/assoc_rate.py --tie-rule mihasher >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
+LF_TIE_SHAPE=big python tools/assoc_rate.py --tie-rule mihasher --pairs 4096x50000,16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
+LF_TIE_SHAPE=small python tools/assoc_rate.py --tie-rule mihasher --pairs 4096x50000,16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
+# round 5: the A/B options beside the defaults (opencv32 + mihasher), same call
+for ab in "opencv32 lowest" "opencv30 mihasher" "opencv30 lowest"; do set -- $ab; python bench.py --steps 100 --secondary none --cpu-frames -1 --seed-order $1 --tie-rule $2 > $R/gpurun_out/$T/bench_ab_$1_$2.json 2>/dev/null; done
+python bench.py --geometry hd --steps 30 --secondary none --cpu-frames -1 > $R/gpurun_out/$T/bench_hd.json 2>/dev/null
+if [ -f lane_slam_amd/liblanefront_sstamps.so ]; then LANEFRONT_LIBRARY=$R/lane_slam_amd/liblanefront_sstamps.so python tools/_seedstamps.py > $R/gpurun_out/$T/seed_stamps.txt 2>&1; fi
 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
 LF_ASSOC_INT8=1 python tools/assoc_rate.py --pairs 16384x50000,65536x262144 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
 LF_ASSOC_INT8=1 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
@@ -17,6 +24,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/d1 -- p
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$T/pw -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$T/pf -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
 # wave-slot occupancy and vector issue utilisation of the LSD region growing kernel: one batch in flight
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --output-format csv -d $R/gpurun_out/$T/pi -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU --output-format csv -d $R/gpurun_out/$T/pq -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/$T/pq2 -- python3 $R/bench.py --steps 2 --warmup 1 $B --depth 1 > /dev/null 2>&1
 # the same with six batches in flight (the configuration the headline is measured in)
