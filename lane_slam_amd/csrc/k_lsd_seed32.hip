@@ -81,11 +81,32 @@ namespace lf {
 #ifndef LF_SEED_OCC
 #define LF_SEED_OCC 3              // workgroups per CU the register allocation must allow (168 VGPRs: three; 128: four, with spills)
 #endif
-constexpr int ST = LF_SEED_THREADS;  // threads
+constexpr int ST = LF_SEED_THREADS;  // threads of the list + chain kernel
 constexpr int SW = ST / 64;
-constexpr int SW2 = LF_SEED_WAVES2;  // waves that work in phase 2 (each with a private LDS range)
-constexpr int kSmall = 1024;         // ranges up to this size are one wave's work, in LDS (16 rows)
-constexpr int kBlock = LF_SEED_BLOCK; // ranges up to this size are copied into LDS and partitioned there by the whole workgroup
+// the dense kernel in two forms (A/B): 1 = the block engine (all ranges of a block level by level, 512 threads), 0 = the wave form
+// (workgroup partitions down to 1024 elements, then single waves; 256 threads)
+#ifndef LF_SEED_ENGINE
+#define LF_SEED_ENGINE 0
+#endif
+#ifndef LF_SEED_DENSE_THREADS
+#define LF_SEED_DENSE_THREADS (LF_SEED_ENGINE ? 512 : 256)
+#endif
+#ifndef LF_SEED_DENSE_OCC
+#define LF_SEED_DENSE_OCC (LF_SEED_ENGINE ? 2 : 4)      // waves per SIMD the register allocation must allow
+#endif
+constexpr int DT = LF_SEED_DENSE_THREADS;   // threads of the dense kernel (the block engine: one element per thread and row group)
+constexpr int kBlock = LF_SEED_BLOCK; // ranges up to this size are worked off in an LDS block
+constexpr int SW2 = LF_SEED_WAVES2;  // waves that work in phase 2 of the wave form (each with a private LDS range)
+constexpr int kSmall = 1024;         // wave form: ranges up to this size are one wave's work, in LDS (16 rows)
+// wave form: one wave's private LDS in phase 2, 32-bit words: the range, the two place lists (u16), row tables, accumulators, range stack
+constexpr int kWaveWords = kSmall + kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
+// wave form, phase 1b (a block of <= kBlock elements in LDS): [block][aliased: the workgroup's place lists (u16) | the waves' private lists, tables,
+// stacks][the workgroup's row tables][the block's list of small ranges]
+constexpr int kBlkWaveWords = kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
+constexpr int kBlkX = SW2 * kBlkWaveWords > kBlock / 2 ? SW2 * kBlkWaveWords : kBlock / 2;
+constexpr int kBlkRows = kBlock / 64 + 2;
+constexpr int kBlkWords = kBlock + kBlkX + (kBlkRows * 6 + 8) + 2 * (kBlock / 16);
+
 constexpr int kSortThreshold = 16;   // libstdc++ _S_threshold
 constexpr int kMaxLdsBytes = 150 * 1024;
 constexpr int SNB = 16;              // buckets of the final counting passes
@@ -95,14 +116,6 @@ constexpr int kListLds = kEPT * ST;  // the explicit list's positions stay in LD
 constexpr int kChainDense = 1024;    // a sparse range this short is written out densely
 constexpr int kMaxRanges = 48;       // dense ranges the chain can leave (one per split + the last: the depth allowance is 2 lg n <= 42)
 constexpr int kRowsLds = 512;        // row tables in LDS for dense ranges of up to 64 x this many elements (longer ones: tables in global memory)
-// one wave's private LDS in phase 2, 32-bit words: the range, the two place lists (u16), row tables, accumulators, range stack
-constexpr int kWaveWords = kSmall + kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
-// phase 1b (a block of <= kBlock elements in LDS): [block][aliased: the workgroup's place lists (u16) | 8 waves' private lists, tables,
-// stacks][the workgroup's row tables][the block's list of small ranges]
-constexpr int kBlkWaveWords = kSmall / 2 + 2 * 18 * 2 + 18 + 20 + 8 + 128;
-constexpr int kBlkX = SW2 * kBlkWaveWords > kBlock / 2 ? SW2 * kBlkWaveWords : kBlock / 2;
-constexpr int kBlkRows = kBlock / 64 + 2;
-constexpr int kBlkWords = kBlock + kBlkX + (kBlkRows * 6 + 8) + 2 * (kBlock / 16);
 
 __device__ __forceinline__ uint32_t key_of(uint32_t v) { return v >> 20; }
 // compare_norm(a, b) = a.norm > b.norm
@@ -123,14 +136,33 @@ __device__ __forceinline__ void lds_or(lds_i32* p, int v) { (void)__hip_atomic_f
 __device__ __forceinline__ void tab_add(lds_i32* p, int v) { lds_add(p, v); }
 __device__ __forceinline__ void tab_min(lds_i32* p, int v) { lds_min(p, v); }
 
-__device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
+// Wave scans and reductions as DPP (row shifts inside the rows of 16 lanes, then row broadcasts): ~50 cycles instead of six trips through
+// the LDS crossbar (__shfl_up compiles to ds_bpermute_b32: ~100 cycles apiece in a lone wave, and the partitions are chains of them)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_incl_scan_i(int v, int /*lane*/)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int n = __shfl_up(v, d);
-        if (lane >= d) v += n;
-    }
+    v += dpp_or_zero<0x111, 0xf>(v);          // row_shr:1 (lanes without a source add 0)
+    v += dpp_or_zero<0x112, 0xf>(v);          // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);          // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);          // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);          // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v);          // row_bcast:31 into rows 2 and 3
     return v;
+}
+__device__ __forceinline__ int wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
+__device__ __forceinline__ int wave_sum_i(int v) { return wave_last(wave_incl_scan_i(v, 0)); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or_max(int v) { return __builtin_amdgcn_update_dpp(0x7fffffff, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_min_i(int v)
+{
+    v = min(v, dpp_or_max<0x111, 0xf>(v));
+    v = min(v, dpp_or_max<0x112, 0xf>(v));
+    v = min(v, dpp_or_max<0x114, 0xf>(v));
+    v = min(v, dpp_or_max<0x118, 0xf>(v));
+    v = min(v, dpp_or_max<0x142, 0xa>(v));
+    v = min(v, dpp_or_max<0x143, 0xc>(v));
+    return wave_last(v);
 }
 
 // __move_median_to_first(result = f, a = f + 1, b = mid, c = l - 1)
@@ -228,7 +260,7 @@ __device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, T64
             const int c = r < R ? PL[r] : 0;
             const int inc = wave_incl_scan_i(c, lane);
             if (r < R) PL[r] = carry + inc - c;
-            carry += __shfl(inc, 63);
+            carry += wave_last(inc);
         }
     }
     if (w == (COOP ? 1 : 0)) {
@@ -238,7 +270,7 @@ __device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, T64
             const int c = r >= 0 ? SX[r] : 0;
             const int inc = wave_incl_scan_i(c, lane);
             if (r >= 0) SX[r] = carry + inc;
-            carry += __shfl(inc, 63);
+            carry += wave_last(inc);
         }
         if (lane == 0) SX[R] = 0;
     }
@@ -290,7 +322,7 @@ __device__ __forceinline__ int partition_tail(EP E, int org, int lo, int hi, T64
 
 // __unguarded_partition of [f + 1, l) around E[f] (already the median) in global memory by the whole workgroup.  Returns the
 // cut, or -1 when the range [f, l) holds no seed (nothing was moved then, and nothing needs to be).
-template <typename T64, typename T32>
+template <int NT, typename T64, typename T32>
 __device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, T64 BL, T64 BR, T32 PL, T32 SX,
                                                 lds_i32* acc, uint32_t* Lpos, uint32_t* Rpos, int w, int lane)
 {
@@ -300,7 +332,7 @@ __device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, T64 B
     if (threadIdx.x == 0) { acc[0] = 0; acc[1] = 0x7fffffff; acc[2] = 0x7fffffff; acc[3] = (pivot & 0xfffffu) != 0u; }
     __syncthreads();
     // (1) eight rows in flight per wave
-    for (int r0 = w * kU; r0 < R; r0 += SW * kU) {
+    for (int r0 = w * kU; r0 < R; r0 += (NT / 64) * kU) {
         uint32_t v[kU];
 #pragma unroll
         for (int u = 0; u < kU; ++u) { const int i = lo + (r0 + u) * 64 + lane; v[u] = i < hi ? E[i] : 0xffffffffu; }
@@ -320,9 +352,23 @@ __device__ __forceinline__ int partition_global(uint32_t* E, int f, int l, T64 B
     }
     __syncthreads();
     if (acc[3] == 0) { __syncthreads(); return -1; }
-    return partition_tail<true>(E, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW, lane, (int)threadIdx.x, ST);
+    return partition_tail<true>(E, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, NT / 64, lane, (int)threadIdx.x, NT);
 }
 
+#ifdef LF_SEED_STAMPS
+__device__ int g_dbg_big[8], g_dbg_small[8], g_dbg_chain[8][4];
+__device__ long long g_dbg_b[8][6];
+__device__ long long g_dbg_w[8][8];
+__device__ long long g_dbg_f[8][12];
+#define FST(k) do { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) g_dbg_f[blockIdx.x % 8][k] += n_ - fs_; fs_ = n_; } while (0)
+#define FST0 long long fs_ = (long long)wall_clock64()
+__device__ long long g_dbg_t[8][4];
+#endif
+
+// a dense range the chain left: elements E[off, off + len), depth allowance left
+struct SeedRange { int off, len, depth; };
+
+// ---- the wave form of the dense phase (rounds 4 - 5) ------------------------------------------------------------------------------
 // the same for a range [f, l) of a wave's LDS copy D (positions relative to the copy), one wave alone
 __device__ __forceinline__ int partition_lds(lds_u32* D, int f, int l, lds_u64* BL, lds_u64* BR, lds_i32* PL, lds_i32* SX,
                                              lds_i32* acc, lds_u16* Lpos, lds_u16* Rpos, int lane)
@@ -368,7 +414,7 @@ __device__ __forceinline__ int partition_lds_coop(lds_u32* D, int f, int l, lds_
     if (threadIdx.x == 0) { acc[0] = 0; acc[1] = 0x7fffffff; acc[2] = 0x7fffffff; acc[3] = (pivot & 0xfffffu) != 0u; }
     __syncthreads();
     int seeds = 0;
-    for (int r = w; r < R; r += SW) {
+    for (int r = w; r < R; r += SW2) {
         const int i = lo + r * 64 + lane;
         const bool valid = i < hi;
         const uint32_t v = valid ? D[i] : 0u;
@@ -380,18 +426,9 @@ __device__ __forceinline__ int partition_lds_coop(lds_u32* D, int f, int l, lds_
     if (lane == 0 && seeds) lds_add(&acc[3], seeds);
     __syncthreads();
     if (acc[3] == 0) { __syncthreads(); return -1; }
-    return partition_tail<true>(D, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW, lane, (int)threadIdx.x, ST);
+    return partition_tail<true>(D, 0, lo, hi, BL, BR, PL, SX, acc, Lpos, Rpos, w, SW2, lane, (int)threadIdx.x, 64 * SW2);
 }
 
-#ifdef LF_SEED_STAMPS
-__device__ int g_dbg_big[8], g_dbg_small[8], g_dbg_chain[8][4];
-__device__ long long g_dbg_b[8][6];
-__device__ long long g_dbg_w[8][8];
-__device__ long long g_dbg_f[8][12];
-#define FST(k) do { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) g_dbg_f[blockIdx.x % 8][k] += n_ - fs_; fs_ = n_; } while (0)
-#define FST0 long long fs_ = (long long)wall_clock64()
-__device__ long long g_dbg_t[8][4];
-#endif
 
 // A range of at most 64 elements and its whole subtree in ONE wave's registers (round 5): lane = element, every lane carries the
 // bounds [f, l) of the range of the loop it currently belongs to, and all ranges inside the window are partitioned AT THE SAME TIME,
@@ -503,7 +540,7 @@ __device__ __forceinline__ int wave_partition(lds_u32* D, int f, int l, lds_u16*
     const int cl = __popcll(myBL), cr = __popcll(myBR);
     const int myPL = wave_incl_scan_i(cl, lane) - cl;
     const int incr = wave_incl_scan_i(cr, lane);
-    const int mySX = __shfl(incr, 63) - incr;
+    const int mySX = wave_last(incr) - incr;
     // (3) ranks; the swapped elements publish their places under their ranks; the cut's ingredients in passing
     int K = 0, firstL = 0x7fffffff, firstStay = 0x7fffffff, RK = 0x7fffffff;
     for (int r = 0; r < R; ++r) {
@@ -582,13 +619,12 @@ __device__ __forceinline__ void wave_subtree(lds_u32* D, uint32_t* D_generic, in
 }
 
 
-// a dense range the chain left: elements E[off, off + len), depth allowance left
-struct SeedRange { int off, len, depth; };
 
 // The introsort loop over the listed ranges of E (n = their total extent): the phases 1, 1b, 2 of the dense form.  scratch: global,
 // 3 n / 4 + 192 u64 entries (the list of small ranges, the list of blocks, then the two place lists of the global partitions);
 // gtab: global row tables (6 words per 64 elements of the longest range + 16) for ranges beyond rows_cap rows.
-__device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const SeedRange* ranges, int n_ranges, unsigned long long* scratch,
+template <int NT>
+__device__ __forceinline__ void introsort_loop_waves(uint32_t* E, int n, const SeedRange* ranges, int n_ranges, unsigned long long* scratch,
                                                   uint32_t* lds, int rows_cap, uint32_t* gtab)
 {
     // LDS carve-up: phase 1 = the row tables of the global partitions; phase 2 = one private block per working wave (aliased)
@@ -640,14 +676,14 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
             if (t == 0) median_to_first(E, f, l);
             __syncthreads();
             int cut;
-            if (((l - f - 1 + 63) >> 6) <= rows_cap - 1) cut = partition_global(E, f, l, BL, BR, PL, SX, acc, Lpos, Rpos, w, lane);
+            if (((l - f - 1 + 63) >> 6) <= rows_cap - 1) cut = partition_global<NT>(E, f, l, BL, BR, PL, SX, acc, Lpos, Rpos, w, lane);
             else {
                 const int rc = ((l - f) >> 6) + 2;
                 unsigned long long* gBL = reinterpret_cast<unsigned long long*>(gtab);
                 unsigned long long* gBR = gBL + rc;
                 int* gPL = reinterpret_cast<int*>(gBR + rc);
                 int* gSX = gPL + rc;
-                cut = partition_global(E, f, l, gBL, gBR, gPL, gSX, acc, Lpos, Rpos, w, lane);
+                cut = partition_global<NT>(E, f, l, gBL, gBR, gPL, gSX, acc, Lpos, Rpos, w, lane);
             }
 #ifdef LF_SEED_STAMPS
             if (t == 0) atomicAdd(&g_dbg_big[blockIdx.x % 8], 1);
@@ -692,12 +728,12 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
             __syncthreads();
             {
                 int seeds = 0;
-                for (int x0 = t; x0 < m; x0 += ST * kU) {
+                for (int x0 = t; x0 < m; x0 += NT * kU) {
                     uint32_t v[kU];
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; v[u] = x < m ? E[gf + x] : 0u; }
+                    for (int u = 0; u < kU; ++u) { const int x = x0 + u * NT; v[u] = x < m ? E[gf + x] : 0u; }
 #pragma unroll
-                    for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; if (x < m) { Dg[x] = v[u]; seeds |= (v[u] & 0xfffffu) != 0u; } }
+                    for (int u = 0; u < kU; ++u) { const int x = x0 + u * NT; if (x < m) { Dg[x] = v[u]; seeds |= (v[u] & 0xfffffu) != 0u; } }
                 }
                 if (__ballot(seeds) && lane == 0) lds_or(&acc[3], 1);
             }
@@ -757,7 +793,7 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
                 for (;;) {
                     int idx = 0;
                     if (lane == 0) idx = atomicAdd(&next_small, 1);
-                    idx = __shfl(idx, 0);
+                    idx = __builtin_amdgcn_readfirstlane(idx);
                     if (idx >= total) break;
                     const uint32_t a = blk_small[2 * idx], b = blk_small[2 * idx + 1];
                     wave_subtree(Dg, lds, (int)a, (int)(b & 0xffffffu), (int)(b >> 24), wBL, wBR, wPL, wSX, wacc, Lp, Rp, stack, lane);
@@ -772,9 +808,9 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
             if (t == 0) { long long* g = g_dbg_b[blockIdx.x % 8]; g[0] += b1 - b0; g[1] += b2 - b1; g[2] += b3 - b2; g[4] += n_blk_small; }
             if (lane == 0) atomicMin((unsigned long long*)&g_dbg_b[blockIdx.x % 8][5], (unsigned long long)my_w);
 #endif
-            for (int x0 = t; x0 < m; x0 += ST * kU) {
+            for (int x0 = t; x0 < m; x0 += NT * kU) {
 #pragma unroll
-                for (int u = 0; u < kU; ++u) { const int x = x0 + u * ST; if (x < m) E[gf + x] = Dg[x]; }
+                for (int u = 0; u < kU; ++u) { const int x = x0 + u * NT; if (x < m) E[gf + x] = Dg[x]; }
             }
         }
         __syncthreads();
@@ -801,7 +837,7 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
         for (;;) {
             int idx = 0;
             if (lane == 0) idx = atomicAdd(&next_small, 1);
-            idx = __shfl(idx, 0);
+            idx = __builtin_amdgcn_readfirstlane(idx);
             if (idx >= total) break;
             const unsigned long long it = small_list[idx];
             const int gf = (int)(it & 0xffffffu), gl = (int)((it >> 24) & 0xffffffu);
@@ -817,6 +853,413 @@ __device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const Seed
     __syncthreads();
 #ifdef LF_SEED_STAMPS
     { const long long td = (long long)wall_clock64(); if (t == 0) { g_dbg_t[blockIdx.x % 8][0] = tb - ta; g_dbg_t[blockIdx.x % 8][1] = tc - tb; g_dbg_t[blockIdx.x % 8][2] = td - tc; } }
+#endif
+}
+
+
+// ============================================================================================================================
+// The block engine (round 5, second form of the dense phase).  Ranges of up to kBlock elements are gathered into an LDS block --
+// several at a time -- and ALL the ranges of the loop inside the block are partitioned AT THE SAME TIME, level by level, by the whole
+// workgroup: element x of the block is thread ((x >> 6) % waves, x & 63)'s, which carries the bounds [f, l) and the depth allowance
+// of the range x currently belongs to in one register (the loop's ranges are disjoint: no table of ranges exists).  One level:
+//   (a) the leader (x == f) of every live range reads the three candidates and swaps the median to the front (__move_median_to_first);
+//   (b) every element compares itself with its range's pivot D[f]; the L / R ballots of its row become two bit planes, kept as 32-bit
+//       words beside their running popcount: the number of L (R) elements in front of any position is ONE 8-byte read, a mask and a
+//       count;
+//   (d) ranks from the planes: L elements in front of x minus those in front of f + 1, R elements from x to l; an L element of rank k
+//       is swapped iff k R elements lie to its right, an R element of rank k iff k L elements lie to its left (the header's rule); both
+//       publish their place under their rank in ONE u16 list (L under f + k, R under l - k: 2 K < l - f), and the first candidate of
+//       every (row, range) lowers the range's cut (min of the first L that stays and the leftmost swapped R);
+//   (e) the swapped elements fetch their partner's value, (f) store it, read the cut and shrink their bounds to [f, cut) or [cut, l).
+// Five barriers per level whatever the number of ranges, ~log2(n / 16) + a few levels; rows without a live range are skipped.  A range
+// whose depth allowance is used up is heap sorted by its leader lane (libstdc++'s fallback; adversarial inputs only).
+// It replaces the workgroup partitions in an LDS block, the single-wave partitions and the 64-element register windows (which cost
+// 5.3 k and 3.6 k cycles apiece as chains of dependent LDS round trips in a lone wave: 160 us of a 4 k-element problem's 200).
+#ifdef LF_SEED_STAMPS
+#define ENG_T0 long long et_ = (long long)wall_clock64(); if (threadIdx.x == 0) g_dbg_w[blockIdx.x % 8][0] += 1
+#define ENG_T(k) do { const long long n_ = (long long)wall_clock64(); if (threadIdx.x == 0) g_dbg_w[blockIdx.x % 8][k] += n_ - et_; et_ = n_; } while (0)
+#else
+#define ENG_T0 do { } while (0)
+#define ENG_T(k) do { } while (0)
+#endif
+constexpr int kEngRows = kBlock / 64;
+constexpr int kEngWordsP = 2 * kEngRows;                 // 32-bit words of a plane
+constexpr int kEngCut = kBlock / 16;                     // one cut slot per 16 positions: ranges are longer than 16 and disjoint
+constexpr int kEngBatch = 64;                            // ranges per block at most
+constexpr int kEngWords = kBlock + kBlock / 2 + 4 * (kEngWordsP + 2) + 2 * kEngCut + 8 + (kEngBatch + 2) + 2 * kEngBatch;
+static_assert(kBlock <= 8192 && kBlock % 512 == 0, "13-bit positions, whole rows per wave");
+typedef uint32_t eng_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) eng_u32x2 lds_u32x2;
+
+__device__ __forceinline__ uint32_t eng_pack(int f, int l, int d) { return (uint32_t)f | ((uint32_t)(l - 1) << 13) | ((uint32_t)d << 26); }
+// elements of a plane in front of position q, given the plane's entry (bits, count in front of the word) for q >> 5
+__device__ __forceinline__ int eng_rank(eng_u32x2 e, int q) { return (int)e.y + __popc(e.x & ((1u << (q & 31)) - 1u)); }
+
+template <int NT>
+__device__ __forceinline__ void dense_blocks(uint32_t* E, const unsigned long long* list, int n_items, uint32_t* lds)
+{
+    constexpr int NW = NT / 64, RPT = kEngRows / NW, G = RPT < 4 ? RPT : 4;
+    static_assert(kEngRows % NW == 0 && RPT % G == 0 && RPT <= 32, "rows per thread");
+    lds_u32* D = as_lds<lds_u32>(lds);
+    lds_u16* PP = (lds_u16*)(D + kBlock);
+    lds_u32x2* LT = (lds_u32x2*)(D + kBlock + kBlock / 2);
+    lds_u32x2* RT = LT + (kEngWordsP + 2);
+    lds_i32* cutT = (lds_i32*)(RT + (kEngWordsP + 2));
+    lds_i32* flags = cutT + 2 * kEngCut;                  // [0], [1] per level: 1 = a live range, 2 = one without depth allowance; [2] seeds; [3] ranges; [4] elements
+    lds_i32* boff = flags + 8;                            // [ranges + 1] block offsets
+    lds_i32* bsrc = boff + (kEngBatch + 2);               // where a range lies in E
+    lds_i32* bdep = bsrc + kEngBatch;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    for (int i = t; i < kEngWordsP + 2; i += NT) { const eng_u32x2 z = { 0u, 0u }; LT[i] = z; RT[i] = z; }
+    int next = 0;
+    while (next < n_items) {
+        __syncthreads();
+        // ---- the next block: as many listed ranges as fit (wave 0)
+        if (w == 0) {
+            const int i = next + lane;
+            const unsigned long long it = i < n_items ? list[i] : 0ull;
+            const int rf = (int)(it & 0xffffffu), rl = (int)((it >> 24) & 0xffffffu);
+            const int sz = i < n_items ? rl - rf : 0;
+            const int inc = wave_incl_scan_i(sz, lane);
+            const bool fits = i < n_items && inc <= kBlock;
+            const int cnt = __popcll(__ballot(fits));             // sizes are positive: the fitting ones are a prefix
+            if (fits) { boff[lane] = inc - sz; bsrc[lane] = rf; bdep[lane] = (int)(it >> 48); }
+            if (lane == cnt - 1) { boff[cnt] = inc; flags[4] = inc; }
+            if (lane == 0) { flags[3] = cnt; flags[2] = 0; flags[0] = 0; flags[1] = 0; }
+        }
+        for (int i = t; i < kEngCut; i += NT) cutT[i] = 0x7fffffff;
+        __syncthreads();
+        const int cnt = flags[3], total = flags[4];
+        next += cnt;
+        // ---- copy in; every element's range
+        uint32_t st[RPT], tmp[RPT];
+        int gidx[RPT];
+        {
+            int seeds = 0, fl = 0;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int x = ((j * NW + w) << 6) | lane;
+                int k = 0;
+                if (cnt > 1) {
+                    int a = 0, b = cnt;                                   // the last range with boff <= x
+                    while (b - a > 1) { const int mid = (a + b) >> 1; if (boff[mid] <= x) a = mid; else b = mid; }
+                    k = a;
+                }
+                const bool in = x < total;
+                const int f = boff[k], l = boff[k + 1], d = bdep[k];
+                gidx[j] = in ? bsrc[k] + (x - f) : -1;
+                st[j] = in ? eng_pack(f, l, d) : 0u;
+                if (in) fl |= d == 0 ? 3 : 1;
+            }
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) tmp[j] = gidx[j] >= 0 ? E[gidx[j]] : 0u;
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                const int x = ((j * NW + w) << 6) | lane;
+                if (gidx[j] >= 0) { D[x] = tmp[j]; seeds |= (tmp[j] & 0xfffffu) != 0u; }
+            }
+            const unsigned long long sb = __ballot(seeds != 0);
+            fl = (__ballot(fl & 1) ? 1 : 0) | (__ballot(fl & 2) ? 2 : 0);
+            if (lane == 0) { if (sb) lds_or(&flags[2], 1); if (fl) lds_or(&flags[0], fl); }
+        }
+        __syncthreads();
+        if (flags[2] == 0) continue;                                      // no seed in the block: nothing to order
+        // ---- the levels
+        for (int lvl = 0;; ++lvl) {
+            ENG_T0;
+            const int p = lvl & 1;
+            lds_i32* cut_cur = cutT + p * kEngCut;
+            lds_i32* cut_nxt = cutT + (p ^ 1) * kEngCut;
+            const int fl = flags[p];
+            if (!(fl & 1)) break;
+            for (int i = t; i < kEngCut; i += NT) cut_nxt[i] = 0x7fffffff;
+            if (t == 0) flags[p ^ 1] = 0;
+            if (fl & 2) {                                                 // depth limit used up somewhere: libstdc++ heap sorts that range
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const uint32_t s = st[j];
+                    const int x = ((j * NW + w) << 6) | lane;
+                    const int f = (int)(s & 0x1fffu), l = (int)((s >> 13) & 0x1fffu) + 1;
+                    if (l - f > kSortThreshold && (s >> 26) == 0u && x == f) heap_sort_range(lds, f, l);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < RPT; ++j) {
+                    const uint32_t s = st[j];
+                    const int f = (int)(s & 0x1fffu), l = (int)((s >> 13) & 0x1fffu) + 1;
+                    if (l - f > kSortThreshold && (s >> 26) == 0u) st[j] = 0u;
+                }
+            }
+            // (a) the leaders: the median of three to the front
+#pragma unroll
+            for (int g = 0; g < RPT; g += G) {
+                bool lead[G];
+                int f[G], l[G];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint32_t s = st[g + u];
+                    const int x = (((g + u) * NW + w) << 6) | lane;
+                    f[u] = (int)(s & 0x1fffu); l[u] = (int)((s >> 13) & 0x1fffu) + 1;
+                    lead[u] = l[u] - f[u] > kSortThreshold && x == f[u];
+                    any |= lead[u];
+                }
+                if (__ballot(any) == 0ull) continue;
+                uint32_t ea[G], eb[G], ec[G], ef[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int x = (((g + u) * NW + w) << 6) | lane;
+                    ea[u] = D[lead[u] ? f[u] + 1 : x]; eb[u] = D[lead[u] ? f[u] + ((l[u] - f[u]) >> 1) : x]; ec[u] = D[lead[u] ? l[u] - 1 : x]; ef[u] = D[x];
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int ia = f[u] + 1, ib = f[u] + ((l[u] - f[u]) >> 1), ic = l[u] - 1;
+                    int pick;
+                    if (comp(ea[u], eb[u])) pick = comp(eb[u], ec[u]) ? ib : (comp(ea[u], ec[u]) ? ic : ia);
+                    else pick = comp(ea[u], ec[u]) ? ia : (comp(eb[u], ec[u]) ? ic : ib);
+                    const uint32_t pv = pick == ia ? ea[u] : (pick == ib ? eb[u] : ec[u]);
+                    if (lead[u]) { D[f[u]] = pv; D[pick] = ef[u]; }
+                }
+            }
+            __syncthreads();
+            ENG_T(1);
+            // (b) L / R planes
+            uint32_t lmask = 0u, rmask = 0u;
+#pragma unroll
+            for (int g = 0; g < RPT; g += G) {
+                bool act[G];
+                int f[G];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint32_t s = st[g + u];
+                    f[u] = (int)(s & 0x1fffu);
+                    act[u] = (int)((s >> 13) & 0x1fffu) + 1 - f[u] > kSortThreshold;
+                    any |= act[u];
+                }
+                if (__ballot(any) == 0ull) continue;
+                uint32_t v[G], pv[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int x = (((g + u) * NW + w) << 6) | lane;
+                    v[u] = D[x]; pv[u] = D[act[u] ? f[u] : x];
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int row = (g + u) * NW + w;
+                    const int x = (row << 6) | lane;
+                    const bool part = act[u] && x > f[u];
+                    const uint32_t kp = key_of(pv[u]), kv = key_of(v[u]);
+                    const bool isL = part && kv <= kp, isR = part && kv >= kp;
+                    const unsigned long long bl = __ballot(isL), br = __ballot(isR);
+                    if (isL) lmask |= 1u << (g + u);
+                    if (isR) rmask |= 1u << (g + u);
+                    if (lane == 0) { LT[2 * row].x = (uint32_t)bl; LT[2 * row + 1].x = (uint32_t)(bl >> 32); RT[2 * row].x = (uint32_t)br; RT[2 * row + 1].x = (uint32_t)(br >> 32); }
+                }
+            }
+            __syncthreads();
+            ENG_T(2);
+            // (d) running counts of the planes (every wave writes the same table), ranks, places, cuts
+            {
+                int cL = 0, cR = 0;
+#pragma unroll
+                for (int r0 = 0; r0 < kEngWordsP; r0 += 64) {
+                    const int a = __popc(LT[r0 + lane].x), b = __popc(RT[r0 + lane].x);
+                    const int ia = wave_incl_scan_i(a, lane), ib = wave_incl_scan_i(b, lane);
+                    LT[r0 + lane].y = (uint32_t)(cL + ia - a); RT[r0 + lane].y = (uint32_t)(cR + ib - b);
+                    cL += wave_last(ia); cR += wave_last(ib);
+                }
+                if (lane == 0) { LT[kEngWordsP].y = (uint32_t)cL; RT[kEngWordsP].y = (uint32_t)cR; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            uint32_t swm = 0u;
+#pragma unroll
+            for (int g = 0; g < RPT; g += G) {
+                bool act[G];
+                int f[G], l[G];
+                bool any = false;
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const uint32_t s = st[g + u];
+                    f[u] = (int)(s & 0x1fffu); l[u] = (int)((s >> 13) & 0x1fffu) + 1;
+                    act[u] = l[u] - f[u] > kSortThreshold;
+                    any |= act[u];
+                }
+                if (__ballot(any) == 0ull) continue;
+                eng_u32x2 lx[G], rx[G], lf[G], rl[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int x = (((g + u) * NW + w) << 6) | lane;
+                    lx[u] = LT[x >> 5]; rx[u] = RT[x >> 5];
+                    lf[u] = LT[act[u] ? (f[u] + 1) >> 5 : x >> 5]; rl[u] = RT[act[u] ? l[u] >> 5 : x >> 5];
+                }
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const int x = (((g + u) * NW + w) << 6) | lane;
+                    const bool isL = (lmask >> (g + u)) & 1u, isR = (rmask >> (g + u)) & 1u;
+                    const int l_left = eng_rank(lx[u], x) - eng_rank(lf[u], f[u] + 1), kl = l_left + 1;
+                    const int kr = eng_rank(rl[u], l[u]) - eng_rank(rx[u], x), r_right = kr - (isR ? 1 : 0);
+                    const bool swl = isL && r_right >= kl, swr = isR && l_left >= kr;
+                    if (swl) PP[f[u] + kl] = (uint16_t)x;
+                    if (swr) PP[l[u] - kr] = (uint16_t)x;
+                    tmp[g + u] = swl ? (uint32_t)(l[u] - kl) : (swr ? (uint32_t)(f[u] + kr) : 0u);
+                    if (swl || swr) swm |= 1u << (g + u);
+                    // the first candidate of this range in this row lowers the cut
+                    const bool cand = (isL && !swl) || swr;
+                    const unsigned long long cm = __ballot(cand);
+                    const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
+                    const int at_start = __builtin_amdgcn_ds_bpermute(4 * max(f[u] - (x & ~63), 0), before);
+                    if (cand && before == at_start) lds_min(&cut_cur[f[u] >> 4], x);
+                }
+            }
+            __syncthreads();
+            ENG_T(3);
+            // (e) the partner's value
+#pragma unroll
+            for (int g = 0; g < RPT; g += G) {
+                if (__ballot(((swm >> g) & ((1u << G) - 1u)) != 0u) == 0ull) continue;
+                int y[G];
+#pragma unroll
+                for (int u = 0; u < G; ++u) y[u] = (int)PP[((swm >> (g + u)) & 1u) ? tmp[g + u] : 0u];
+#pragma unroll
+                for (int u = 0; u < G; ++u) { const uint32_t vy = D[y[u]]; if ((swm >> (g + u)) & 1u) tmp[g + u] = vy; }
+            }
+            __syncthreads();
+            // (f) the swap, the cut, the bounds of the next level
+            {
+                int more = 0;
+#pragma unroll
+                for (int g = 0; g < RPT; g += G) {
+                    bool act[G];
+                    int f[G], l[G], cut[G];
+                    bool any = false;
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const uint32_t s = st[g + u];
+                        f[u] = (int)(s & 0x1fffu); l[u] = (int)((s >> 13) & 0x1fffu) + 1;
+                        act[u] = l[u] - f[u] > kSortThreshold;
+                        any |= act[u];
+                    }
+                    if (__ballot(any) == 0ull) continue;
+#pragma unroll
+                    for (int u = 0; u < G; ++u) cut[u] = cut_cur[act[u] ? f[u] >> 4 : 0];
+#pragma unroll
+                    for (int u = 0; u < G; ++u) {
+                        const int x = (((g + u) * NW + w) << 6) | lane;
+                        if ((swm >> (g + u)) & 1u) D[x] = tmp[g + u];
+                        if (act[u]) {
+                            const int d = (int)(st[g + u] >> 26) - 1;
+                            const int nf = x < cut[u] ? f[u] : cut[u], nl = x < cut[u] ? cut[u] : l[u];
+                            st[g + u] = eng_pack(nf, nl, d);
+                            if (nl - nf > kSortThreshold) more |= d == 0 ? 3 : 1;
+                        }
+                    }
+                }
+                more = (__ballot(more & 1) ? 1 : 0) | (__ballot(more & 2) ? 2 : 0);
+                if (lane == 0 && more) lds_or(&flags[p ^ 1], more);
+            }
+            __syncthreads();
+            ENG_T(4);
+        }
+        // ---- copy out
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) {
+            const int x = ((j * NW + w) << 6) | lane;
+            if (gidx[j] >= 0) tmp[j] = D[x];
+        }
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) if (gidx[j] >= 0) E[gidx[j]] = tmp[j];
+    }
+    __syncthreads();
+}
+
+
+// The introsort loop over the listed ranges of E (n = their total extent).  scratch: global, 3 n / 4 + 192 u64 entries (the list of
+// ranges of <= kBlock elements, then the two place lists of the global partitions); gtab: global row tables (6 words per 64 elements
+// of the longest range + 16) for ranges beyond rows_cap rows.
+template <int NT>
+__device__ __forceinline__ void introsort_loop_wg(uint32_t* E, int n, const SeedRange* ranges, int n_ranges, unsigned long long* scratch,
+                                                  uint32_t* lds, int rows_cap, uint32_t* gtab)
+{
+    // LDS: phase 1 = the row tables of the global partitions; phase 2 = the block engine's (aliased)
+    lds_u64* BL = as_lds<lds_u64>(lds);
+    lds_u64* BR = BL + rows_cap;
+    lds_i32* PL = (lds_i32*)(BR + rows_cap);
+    lds_i32* SX = PL + rows_cap;                          // rows_cap + 1 entries
+    unsigned long long* work_list = scratch;                           // ranges of 17 .. kBlock elements: phase 2
+    uint32_t* Lpos = reinterpret_cast<uint32_t*>(scratch + (n / 16 + 64) + (n / 1024 + 64));
+    uint32_t* Rpos = Lpos + (n / 2 + 8);
+    __shared__ int acc_[4];
+    lds_i32* acc = as_lds<lds_i32>(acc_);
+    __shared__ int big_stack[3 * (72 + kMaxRanges)];
+    __shared__ int n_big, n_work;
+    __shared__ int cur[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    auto pack = [](int f, int l, int depth) { return (unsigned long long)f | ((unsigned long long)l << 24) | ((unsigned long long)depth << 48); };
+    if (t == 0) {
+        n_big = 0; n_work = 0;
+        for (int i = 0; i < n_ranges; ++i) {
+            const int f = ranges[i].off, l = f + ranges[i].len, d = ranges[i].depth, sz = ranges[i].len;
+            if (sz > kBlock) { big_stack[3 * n_big] = f; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = d; ++n_big; }
+            else if (sz > kSortThreshold) work_list[n_work++] = pack(f, l, d);
+        }
+    }
+    __syncthreads();
+    SEED_T(ta);
+    // ---- phase 1: ranges of more than kBlock elements, in global memory
+    for (;;) {
+        if (t == 0) {
+            if (n_big > 0) { --n_big; cur[0] = big_stack[3 * n_big]; cur[1] = big_stack[3 * n_big + 1]; cur[2] = big_stack[3 * n_big + 2]; cur[3] = 1; }
+            else cur[3] = 0;
+        }
+        __syncthreads();
+        if (!cur[3]) break;
+        int f = cur[0], l = cur[1], depth = cur[2];
+        __syncthreads();
+        // the libstdc++ loop on this range: go on with the left part while it is big, park the right part
+        while (l - f > kBlock) {
+            if (depth == 0) {
+                if (t == 0) heap_sort_range(E, f, l);
+                __syncthreads();
+                l = f;
+                break;
+            }
+            --depth;
+            if (t == 0) median_to_first(E, f, l);
+            __syncthreads();
+            int cut;
+            if (((l - f - 1 + 63) >> 6) <= rows_cap - 1) cut = partition_global<NT>(E, f, l, BL, BR, PL, SX, acc, Lpos, Rpos, w, lane);
+            else {
+                const int rc = ((l - f) >> 6) + 2;
+                unsigned long long* gBL = reinterpret_cast<unsigned long long*>(gtab);
+                unsigned long long* gBR = gBL + rc;
+                int* gPL = reinterpret_cast<int*>(gBR + rc);
+                int* gSX = gPL + rc;
+                cut = partition_global<NT>(E, f, l, gBL, gBR, gPL, gSX, acc, Lpos, Rpos, w, lane);
+            }
+#ifdef LF_SEED_STAMPS
+            if (t == 0) atomicAdd(&g_dbg_big[blockIdx.x % 8], 1);
+#endif
+            if (cut < 0) { l = f; break; }                           // no seed in the range: nothing to order
+            if (t == 0) {
+                const int rs = l - cut;
+                if (rs > kBlock) { big_stack[3 * n_big] = cut; big_stack[3 * n_big + 1] = l; big_stack[3 * n_big + 2] = depth; ++n_big; }
+                else if (rs > kSortThreshold) work_list[n_work++] = pack(cut, l, depth);
+            }
+            l = cut;
+            __syncthreads();
+        }
+        if (t == 0 && l - f > kSortThreshold) work_list[n_work++] = pack(f, l, depth);
+        __syncthreads();
+    }
+    SEED_T(tb);
+    // ---- phase 2: everything else, block by block in LDS
+    const int nw = n_work;
+    __syncthreads();
+    dense_blocks<NT>(E, work_list, nw, lds);
+#ifdef LF_SEED_STAMPS
+    { const long long tc = (long long)wall_clock64(); if (t == 0) { g_dbg_t[blockIdx.x % 8][0] = tb - ta; g_dbg_t[blockIdx.x % 8][1] = tc - tb; g_dbg_small[blockIdx.x % 8] = nw; } }
 #endif
 }
 
@@ -864,7 +1307,7 @@ __device__ __forceinline__ int wave_scan_rows(CT cnt, int R, int lane)
         const int c = r < R ? (int)cnt[r] : 0;
         const int inc = wave_incl_scan_i(c, lane);
         if (r < R) cnt[r] = carry + inc - c;
-        carry += __shfl(inc, 63);
+        carry += wave_last(inc);
     }
     return carry;
 }
@@ -1202,8 +1645,7 @@ __device__ __forceinline__ void chain_step_plane(const SeedWork& W, __attribute_
                 }
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) mymin = min(mymin, __shfl_xor(mymin, d));
+        mymin = wave_min_i(mymin);
         if (lane == 0 && wk) { lds_add((lds_i32*)&cs->K, wk); lds_min((lds_i32*)&cs->minR, mymin); }
     }
     __syncthreads();
@@ -1281,7 +1723,7 @@ __device__ __forceinline__ void chain_step_plane(const SeedWork& W, __attribute_
         if (wemit) {                                                        // one reservation per wave and tile
             int base_ = 0;
             if (lane == 0) base_ = __hip_atomic_fetch_add((lds_i32*)&cs->nright, wemit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            base_ = a + __shfl(base_, 0);
+            base_ = a + __builtin_amdgcn_readfirstlane(base_);
 #pragma unroll
             for (int u = 0; u < kST; ++u) {
                 const bool emit = (emask >> u) & 1u;
@@ -1530,7 +1972,7 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
                     }
                     const unsigned long long bo = __ballot(ok);
                     wk += __popcll(bo);
-                    if (bo) wmin = min(wmin, __shfl(pos, __ffsll((long long)bo) - 1));
+                    if (bo) wmin = min(wmin, __builtin_amdgcn_readlane(pos, __ffsll((long long)bo) - 1));
                 }
                 if (lane == 0) {
                     if (wk) lds_add((lds_i32*)&cs->K, wk);
@@ -1625,23 +2067,24 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
 }
 
 // one stable 4-bit counting pass (same scheme as k_lsd_order.hip's radix_pass: every thread owns a contiguous run; [16][ST] counters)
+template <int NT>
 __device__ __forceinline__ void seed_radix_pass(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int n, int shift,
-                                                uint32_t* cnt /*[SNB][ST]*/, int* tot, int* base)
+                                                uint32_t* cnt /*[SNB][NT]*/, int* tot, int* base)
 {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int seg = (n + ST - 1) / ST;
+    const int seg = (n + NT - 1) / NT;
     const int i0 = min(n, t * seg), i1 = min(n, i0 + seg);
-    for (int b = 0; b < SNB; ++b) cnt[b * ST + t] = 0;
-    for (int i = i0; i < i1; ++i) cnt[(int)((src[i] >> shift) & (SNB - 1)) * ST + t]++;
+    for (int b = 0; b < SNB; ++b) cnt[b * NT + t] = 0;
+    for (int i = i0; i < i1; ++i) cnt[(int)((src[i] >> shift) & (SNB - 1)) * NT + t]++;
     __syncthreads();
-    for (int bb = 0; bb < SNB / SW; ++bb) {
-        const int b = wave * (SNB / SW) + bb;
+    for (int bb = 0; bb < SNB / (NT / 64); ++bb) {
+        const int b = wave * (SNB / (NT / 64)) + bb;
         int carry = 0;
-        for (int c = 0; c < ST / 64; ++c) {
-            const int v = (int)cnt[b * ST + c * 64 + lane];
+        for (int c = 0; c < NT / 64; ++c) {
+            const int v = (int)cnt[b * NT + c * 64 + lane];
             const int inc = wave_incl_scan_i(v, lane);
-            cnt[b * ST + c * 64 + lane] = (uint32_t)(carry + inc - v);
-            carry += __shfl(inc, 63);
+            cnt[b * NT + c * 64 + lane] = (uint32_t)(carry + inc - v);
+            carry += wave_last(inc);
         }
         if (lane == 0) tot[b] = carry;
     }
@@ -1655,30 +2098,59 @@ __device__ __forceinline__ void seed_radix_pass(const uint32_t* __restrict__ src
     for (int i = i0; i < i1; ++i) {
         const uint32_t it = src[i];
         const int b = (int)((it >> shift) & (SNB - 1));
-        dst[(uint32_t)base[b] + cnt[b * ST + t]++] = it;
+        dst[(uint32_t)base[b] + cnt[b * NT + t]++] = it;
     }
     __syncthreads();
 }
 
-// The whole sort of one problem, given its explicit list (m entries; positions in W.P0 -- copied into LDS when they fit --,
-// values in W.V0) over an array of n elements with n_seeds seeds: chain, dense phases, and the final insertion sort as stable
-// counting passes.  Leaves the seeds in W.out as (n_bins - 1 - bin) << 20 | payload - 1, in their final order.
-__device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int n_seeds, int n_bins, uint32_t* lds, int lds_words, int rows_cap, int* tot, int* base)
+// The sort of one problem is two kernels (round 5, second half): k_lsd_seed32 builds the explicit list and runs the CHAIN on it -- bit
+// planes of the whole gradient image in LDS, 256 threads --, k_lsd_seed32_dense the introsort loop on the dense ranges the chain left and
+// the final insertion sort -- the block engine, 512 threads, half the LDS.  Between them: the dense array E in global memory and the
+// chain's result (elements used, ranges) in the first words of the problem's RT area.
+
+// kernel 1: the chain on the explicit list (m entries; positions in W.P0, values in W.V0) over an array of n elements with n_seeds seeds
+__device__ __forceinline__ void seed32_chain(const SeedWork& W, int n, int m, int n_seeds, uint32_t* lds, int lds_words)
 {
     __shared__ ChainState cstate;
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x;
     SEED_T(t0);
     sparse_chain<false>(W, nullptr, nullptr, &cstate, n, m, n_seeds, as_lds<lds_u32>(lds), lds_words);
+    int* state = reinterpret_cast<int*>(W.RT);
+    if (t == 0) { state[0] = cstate.e_used; state[1] = cstate.n_ranges; }
+    for (int i = t; i < cstate.n_ranges; i += ST) { state[2 + 3 * i] = cstate.ranges[i].off; state[3 + 3 * i] = cstate.ranges[i].len; state[4 + 3 * i] = cstate.ranges[i].depth; }
+#ifdef LF_SEED_STAMPS
+    { const long long t1 = (long long)wall_clock64(); if (t == 0 && blockIdx.x < 6) printf("[seed32] problem %d: n %d list %d seeds %d | chain %lld (%d folds %d, %d splits %d -> %d dense in %d ranges) (x10 ns) | fold: passA %lld counts %lld median %lld K %lld passB %lld state %lld | split: build %lld counts %lld K %lld TV %lld out %lld\n", (int)blockIdx.x, n, m, n_seeds, t1 - t0, g_dbg_chain[blockIdx.x % 8][0], g_dbg_chain[blockIdx.x % 8][2], g_dbg_chain[blockIdx.x % 8][1], g_dbg_chain[blockIdx.x % 8][3], cstate.e_used, cstate.n_ranges, g_dbg_f[blockIdx.x % 8][0], g_dbg_f[blockIdx.x % 8][1], g_dbg_f[blockIdx.x % 8][2], g_dbg_f[blockIdx.x % 8][3], g_dbg_f[blockIdx.x % 8][4], g_dbg_f[blockIdx.x % 8][5], g_dbg_f[blockIdx.x % 8][6], g_dbg_f[blockIdx.x % 8][7], g_dbg_f[blockIdx.x % 8][8], g_dbg_f[blockIdx.x % 8][9], g_dbg_f[blockIdx.x % 8][10]); }
+#endif
+}
+
+// kernel 2: the dense phases and the final insertion sort as stable counting passes.  Leaves the seeds in W.out as
+// (n_bins - 1 - bin) << 20 | payload - 1, in their final order.
+template <int NT>
+__device__ __forceinline__ void seed32_dense(const SeedWork& W, int n_seeds, int n_bins, uint32_t* lds, int rows_cap, int* tot, int* base)
+{
+    __shared__ SeedRange ranges[kMaxRanges];
+    __shared__ int hdr[2];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int* state = reinterpret_cast<const int*>(W.RT);
+    if (t < 2) hdr[t] = state[t];
+    __syncthreads();
+    const int M = hdr[0], n_ranges = hdr[1];
+    for (int i = t; i < n_ranges; i += NT) { ranges[i].off = state[2 + 3 * i]; ranges[i].len = state[3 + 3 * i]; ranges[i].depth = state[4 + 3 * i]; }
+    __syncthreads();
     SEED_T(t1);
-    const int M = cstate.e_used;
-    introsort_loop_wg(W.E, M, cstate.ranges, cstate.n_ranges, W.dscratch, lds, rows_cap, W.PP);
+#if LF_SEED_ENGINE
+    introsort_loop_wg<NT>(W.E, M, ranges, n_ranges, W.dscratch, lds, rows_cap, W.PP);
+#else
+    static_assert(NT == 64 * SW2, "the wave form's workgroup");
+    introsort_loop_waves<NT>(W.E, M, ranges, n_ranges, W.dscratch, lds, rows_cap, W.PP);
+#endif
     SEED_T(t2);
     // ---- the seeds in array order ...
     uint32_t* A = W.out;
     uint32_t* B = W.PP;
     int* rowc = reinterpret_cast<int*>(W.T);                         // [rows + 1] (global: M / 64 rows)
     const int R = (M + 63) >> 6;
-    for (int r = w; r < R; r += SW) {
+    for (int r = w; r < R; r += NT / 64) {
         const int i = r * 64 + lane;
         const uint32_t v = i < M ? W.E[i] : 0u;
         const unsigned long long bb = __ballot((v & 0xfffffu) != 0u);
@@ -1687,7 +2159,7 @@ __device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int
     __syncthreads();
     if (w == 0) (void)wave_scan_rows(rowc, R, lane);
     __syncthreads();
-    for (int r = w; r < R; r += SW) {
+    for (int r = w; r < R; r += NT / 64) {
         const int i = r * 64 + lane;
         const uint32_t v = i < M ? W.E[i] : 0u;
         const bool seed = (v & 0xfffffu) != 0u;
@@ -1697,11 +2169,11 @@ __device__ __forceinline__ void seed32_sort(const SeedWork& W, int n, int m, int
     __syncthreads();
     // ... and the final insertion sort: stable by bin, highest bin first (every seed is in E once)
     uint32_t* cnt = lds;
-    seed_radix_pass(B, A, n_seeds, 20, cnt, tot, base);
-    seed_radix_pass(A, B, n_seeds, 24, cnt, tot, base);
-    seed_radix_pass(B, A, n_seeds, 28, cnt, tot, base);
+    seed_radix_pass<NT>(B, A, n_seeds, 20, cnt, tot, base);
+    seed_radix_pass<NT>(A, B, n_seeds, 24, cnt, tot, base);
+    seed_radix_pass<NT>(B, A, n_seeds, 28, cnt, tot, base);
 #ifdef LF_SEED_STAMPS
-    { const long long t3 = (long long)wall_clock64(); if (t == 0 && blockIdx.x < 6) printf("[seed32] problem %d: n %d list %d seeds %d | chain %lld (%d folds %d, %d splits %d -> %d dense in %d ranges)  loop %lld (%d big partitions, %d small ranges; global %lld  blocks %lld [copy-in %lld coop %lld waves %lld (%lld ranges)]  small %lld)  final %lld (x10 ns) | fold: passA %lld counts %lld median %lld K %lld passB %lld state %lld | split: build %lld counts %lld K %lld TV %lld out %lld | wave 0: %lld windows %lld cycles, %lld partitions (%lld rows) %lld cycles\n", (int)blockIdx.x, n, m, n_seeds, t1 - t0, g_dbg_chain[blockIdx.x % 8][0], g_dbg_chain[blockIdx.x % 8][2], g_dbg_chain[blockIdx.x % 8][1], g_dbg_chain[blockIdx.x % 8][3], M, cstate.n_ranges, t2 - t1, g_dbg_big[blockIdx.x % 8], g_dbg_small[blockIdx.x % 8], g_dbg_t[blockIdx.x % 8][0], g_dbg_t[blockIdx.x % 8][1], g_dbg_b[blockIdx.x % 8][0], g_dbg_b[blockIdx.x % 8][1], g_dbg_b[blockIdx.x % 8][2], g_dbg_b[blockIdx.x % 8][4], g_dbg_t[blockIdx.x % 8][2], t3 - t2, g_dbg_f[blockIdx.x % 8][0], g_dbg_f[blockIdx.x % 8][1], g_dbg_f[blockIdx.x % 8][2], g_dbg_f[blockIdx.x % 8][3], g_dbg_f[blockIdx.x % 8][4], g_dbg_f[blockIdx.x % 8][5], g_dbg_f[blockIdx.x % 8][6], g_dbg_f[blockIdx.x % 8][7], g_dbg_f[blockIdx.x % 8][8], g_dbg_f[blockIdx.x % 8][9], g_dbg_f[blockIdx.x % 8][10], g_dbg_w[blockIdx.x % 8][0], g_dbg_w[blockIdx.x % 8][1], g_dbg_w[blockIdx.x % 8][2], g_dbg_w[blockIdx.x % 8][4], g_dbg_w[blockIdx.x % 8][3]); }
+    { const long long t3 = (long long)wall_clock64(); if (t == 0 && blockIdx.x < 6) printf("[seed32 dense] problem %d: %d elements in %d ranges, seeds %d | loop %lld (%d big partitions, %d listed ranges; global %lld  blocks %lld)  final %lld (x10 ns) | %lld levels: a %lld b %lld d %lld e+f %lld\n", (int)blockIdx.x, M, n_ranges, n_seeds, t2 - t1, g_dbg_big[blockIdx.x % 8], g_dbg_small[blockIdx.x % 8], g_dbg_t[blockIdx.x % 8][0], g_dbg_t[blockIdx.x % 8][1], t3 - t2, g_dbg_w[blockIdx.x % 8][0], g_dbg_w[blockIdx.x % 8][1], g_dbg_w[blockIdx.x % 8][2], g_dbg_w[blockIdx.x % 8][3], g_dbg_w[blockIdx.x % 8][4]); }
 #endif
 }
 
@@ -1742,7 +2214,7 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
                                                    const uint32_t* __restrict__ c_xy, const double* __restrict__ c_mod,
                                                    const uint32_t* __restrict__ l_addr, double* l_mod, const int* __restrict__ n_low,
                                                    unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
-                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b, int rows_cap, int plane_ok, int lds_words)
+                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b, int plane_ok, int lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
     __shared__ int tot[SNB];
@@ -1802,7 +2274,7 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
                 ++mine;
             }
         }
-        for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+        mine = wave_sum_i(mine);
         if (lane == 0 && mine) atomicAdd(&n_list, mine);
         __syncthreads();
     } else {
@@ -1827,7 +2299,7 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
             const unsigned long long bo = __ballot(on);
             int wbase = 0;
             if (lane == 0 && bo) wbase = atomicAdd(&n_list, __popcll(bo));
-            wbase = __shfl(wbase, 0);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
             if (on) LA[wbase + __popcll(bo & ((1ull << lane) - 1ull))] = item;
         }
         __syncthreads();
@@ -1836,7 +2308,7 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
         uint32_t* src = LA;
         uint32_t* dst = LB;
         for (int shift = 10; shift < 32; shift += 4) {
-            seed_radix_pass(src, dst, nlz, shift, seed_lds, tot, base);
+            seed_radix_pass<ST>(src, dst, nlz, shift, seed_lds, tot, base);
             uint32_t* x = src; src = dst; dst = x;
         }
         // src: sorted by position.  Ranks: a defined pixel e goes to e + (low records in front of it), a low record j to j + (defined in front)
@@ -1860,17 +2332,33 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
     }
     const int m = nd + n_list;
     __syncthreads();
-    seed32_sort(W, n, m, nd, p.n_bins, seed_lds, lds_words, rows_cap, tot, base);
+    seed32_chain(W, n, m, nd, seed_lds, lds_words);
+}
+
+// kernel 2 of a problem: see seed32_dense
+__global__ __launch_bounds__(DT, LF_SEED_DENSE_OCC) void k_lsd_seed32_dense(LsdParams p, const int* __restrict__ n_rec, double* l_mod,
+                                                            unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
+                                                            uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b, int rows_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
+    __shared__ int tot[SNB];
+    __shared__ int base[SNB];
+    const int pc = blockIdx.x;
+    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t o = (size_t)pc * Ps;
+    const int nd = n_rec[pc];
+    if (nd == 0) return;
+    const SeedWork W = seed_work(reinterpret_cast<uint32_t*>(sort_a + o), reinterpret_cast<uint32_t*>(sort_b + o), order_a + o, order_b + o,
+                                 reinterpret_cast<uint32_t*>(l_mod + o), Ps);
+    seed32_dense<DT>(W, nd, p.n_bins, seed_lds, rows_cap, tot, base);
 }
 
 // debug / test entry: std::sort(compare_norm) of n keys: E[i] = key << 20 | i + 1.  Elements with key 0 are the detector's flat
 // pixels: anonymous.  Leaves the elements with a non-zero key in out[0 .. count) in the order std::sort leaves them, as
 // (1023 - key) << 20 | i, and the count in *count.  work: 12 * cap words, cap = max(n, 1024) rounded up to 64.
-__global__ __launch_bounds__(ST, LF_SEED_OCC) void k_std_sort_debug(const uint32_t* __restrict__ E, uint32_t* __restrict__ work, int n, int cap, int rows_cap, int* __restrict__ count, int lds_words)
+__global__ __launch_bounds__(ST, LF_SEED_OCC) void k_std_sort_debug(const uint32_t* __restrict__ E, uint32_t* __restrict__ work, int n, int cap, int* __restrict__ count, int lds_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
-    __shared__ int tot[SNB];
-    __shared__ int base[SNB];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const SeedWork W = seed_work(work, work + 2 * (size_t)cap, work + 4 * (size_t)cap, work + 5 * (size_t)cap, work + 6 * (size_t)cap, (size_t)cap);
     // the list: compaction of the non-zero keys (already in position order)
@@ -1897,22 +2385,47 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_std_sort_debug(const uint32
     const int m = m_sh;
     if (t == 0) *count = m;
     if (m == 0) return;
-    seed32_sort(W, n, m, m, 1024, seed_lds, lds_words, rows_cap, tot, base);
+    seed32_chain(W, n, m, m, seed_lds, lds_words);
 }
 
-// LDS of the kernels: what the dense phases need; plus, when they fit kPlaneLdsBytes, the two planes of a split over the whole array
-// (then the whole chain runs on planes; longer arrays start in the ordered form and change over once their range is short enough)
-constexpr size_t kPlaneLdsBytes = 56 * 1024;
-static size_t seed_lds_bytes(int rows_cap, long long n)
+__global__ __launch_bounds__(DT, LF_SEED_DENSE_OCC) void k_std_sort_debug_dense(uint32_t* __restrict__ work, int cap, int rows_cap, const int* __restrict__ count)
 {
-    size_t words = (size_t)rows_cap * 6 + 128;
-    if (words < (size_t)SW2 * kWaveWords) words = (size_t)SW2 * kWaveWords;
-    if (words < (size_t)kBlkWords) words = (size_t)kBlkWords;
-    if (words < (size_t)SNB * ST) words = (size_t)SNB * ST;
+    extern __shared__ __attribute__((aligned(16))) uint32_t seed_lds[];
+    __shared__ int tot[SNB];
+    __shared__ int base[SNB];
+    const int m = *count;
+    if (m == 0) return;
+    const SeedWork W = seed_work(work, work + 2 * (size_t)cap, work + 4 * (size_t)cap, work + 5 * (size_t)cap, work + 6 * (size_t)cap, (size_t)cap);
+    seed32_dense<DT>(W, m, 1024, seed_lds, rows_cap, tot, base);
+}
+
+// LDS of the chain kernel: the two planes of a split over the whole array when they fit kPlaneLdsBytes (then the whole chain runs on
+// planes; longer arrays start in the ordered form and change over once their range is short enough); at least the counters of the
+// counting passes that order a list without a plane
+constexpr size_t kPlaneLdsBytes = 56 * 1024;
+static size_t seed_lds_bytes(long long n)
+{
+    size_t words = (size_t)SNB * ST;
+    bool planes = false;
     if (n < (1ll << 30)) {
         const size_t two = 2 * (((size_t)plane_words_for((int)n) + 1) & ~(size_t)1);
-        if (two * 4 <= kPlaneLdsBytes && words < two) words = two;
+        planes = two * 4 <= kPlaneLdsBytes;
+        if (planes && words < two) words = two;
     }
+    if (!planes && words < 8192) words = 8192;                            // room for the planes of a range once it is short enough
+    return words * sizeof(uint32_t);
+}
+// ... of the dense kernel: the block engine, the row tables of the global partitions, the counters of the final passes
+static size_t seed_dense_lds_bytes(int rows_cap)
+{
+    size_t words = (size_t)rows_cap * 6 + 128;
+#if LF_SEED_ENGINE
+    if (words < (size_t)kEngWords) words = (size_t)kEngWords;
+#else
+    if (words < (size_t)SW2 * kWaveWords) words = (size_t)SW2 * kWaveWords;
+    if (words < (size_t)kBlkWords) words = (size_t)kBlkWords;
+#endif
+    if (words < (size_t)SNB * DT) words = (size_t)SNB * DT;
     return words * sizeof(uint32_t);
 }
 
@@ -1937,12 +2450,15 @@ void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const
         const long long full = ((n + 63) / 64 + 1 + 63) / 64 * 64;
         if ((size_t)full * 24 + 512 <= (size_t)kMaxLdsBytes) rows_cap = (int)full;
     }
-    size_t lds = seed_lds_bytes(rows_cap, n);
+    const size_t lds = seed_lds_bytes(n), lds2 = seed_dense_lds_bytes(rows_cap);
     const int plane_ok = bitplane_lds_words((size_t)n) * 4 <= lds;      // the list's initial order by ranks in a plane of the gradient image
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds2 > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(k_lsd_seed32, dim3(n_frames * 3), dim3(ST), lds, s, p, n_rec, maxgrad, c_xy, c_mod, l_addr, l_mod, n_low,
-                       sort_a, sort_b, order_a, order_b, rows_cap, plane_ok, (int)(lds / 4));
+                       sort_a, sort_b, order_a, order_b, plane_ok, (int)(lds / 4));
+    hipLaunchKernelGGL(k_lsd_seed32_dense, dim3(n_frames * 3), dim3(DT), lds2, s, p, n_rec, l_mod, sort_a, sort_b, order_a, order_b, rows_cap);
 }
 
 // words of device scratch k_std_sort_debug needs for n elements
@@ -1952,10 +2468,13 @@ void launch_std_sort_debug(const uint32_t* E, uint32_t* work, int n, int* count,
 {
     const size_t cap = ((size_t)(n < 1024 ? 1024 : n) + 63) / 64 * 64;
     const int rows_cap = kRowsLds;
-    const size_t lds = seed_lds_bytes(rows_cap, n);
+    const size_t lds = seed_lds_bytes(n), lds2 = seed_dense_lds_bytes(rows_cap);
     if (lds > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_std_sort_debug), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_std_sort_debug, dim3(1), dim3(ST), lds, s, E, work, n, (int)cap, rows_cap, count, (int)(lds / 4));
+    if (lds2 > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_std_sort_debug_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(k_std_sort_debug, dim3(1), dim3(ST), lds, s, E, work, n, (int)cap, count, (int)(lds / 4));
+    hipLaunchKernelGGL(k_std_sort_debug_dense, dim3(1), dim3(DT), lds2, s, work, (int)cap, rows_cap, static_cast<const int*>(count));
 }
 
 }  // namespace lf

@@ -161,12 +161,17 @@ extern "C" void lf_set_error(lf_handle* h, int code, const char* fmt, ...)
 
 static char g_create_err[512] = "no error";
 
+// LF_ALLOC_TRACE=1: one line per device allocation of a handle on stderr (what the footprint figures in DESIGN.md §3 are made of)
+static bool alloc_trace() { static const bool on = [] { const char* e = getenv("LF_ALLOC_TRACE"); return e && *e && *e != '0'; }(); return on; }
 template <typename T>
-static int dalloc(lf_handle* h, T** p, size_t count)
+static int dalloc_(lf_handle* h, T** p, size_t count, const char* what)
 {
-    LF_HIP_CHECK(h, hipMalloc((void**)p, count ? count * sizeof(T) : sizeof(T)));
+    const size_t bytes = count ? count * sizeof(T) : sizeof(T);
+    LF_HIP_CHECK(h, hipMalloc((void**)p, bytes));
+    if (alloc_trace()) fprintf(stderr, "lanefront alloc %-28s %12zu B\n", what, bytes);
     return LF_OK;
 }
+#define dalloc(h, p, count) dalloc_(h, p, count, #p)
 
 static int ensure(lf_handle* h, DevBuf& b, size_t bytes)
 {
