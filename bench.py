@@ -154,16 +154,15 @@ def main():
     cfg = default_config("fullres", in_size=(in_rows, in_cols)) if hd else default_config(args.geometry)
     cfg["lsd"]["refine"] = args.lsd_refine
     cfg["lsd"]["seed_order"] = args.seed_order
-    # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers: about 120 bytes per LSD pixel and
-    # problem, 10 GB at 640x480 x 256 frames, 40 GB at 1080p x 128 -- DESIGN.md section 3); with --depth 0 no more of them than fit
-    # 85 % of the device's free memory (1080p with the low-gradient records of lsd.seed_order = opencv32: five)
+    # D handles = D independent batches in flight (each handle owns a HIP stream and its buffers: the per-problem lists of the LSD stages
+    # start at an eighth of the LSD image and grow with the content -- 2.4 GB at 640x480 x 256 frames on lane frames);
+    # with --depth 0 no more of them than fit 85 % of the device's free memory, measured on the first handle
+    free0, _total_b = torch.cuda.mem_get_info(local_rank)
+    fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap)]
+    handle_bytes = max(1, free0 - torch.cuda.mem_get_info(local_rank)[0])
     if args.depth == 0:
-        rows_w, cols_w = cfg["img_size"][0] - cfg["top_cutoff"], cfg["img_size"][1]
-        ps = int(np.ceil(rows_w * 0.8)) * int(np.ceil(cols_w * 0.8))
-        handle_bytes = (108 + (12 if args.seed_order == "opencv32" else 0)) * ps * 3 * B + 16 * rows_w * cols_w * B + in_rows * in_cols * 3 * B
-        free_b, _total_b = torch.cuda.mem_get_info(local_rank)
-        D = max(2, min(D, int(0.85 * free_b // handle_bytes)))
-    fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D)]
+        D = max(2, min(D, 1 + int((0.85 * free0 - handle_bytes) // handle_bytes)))
+    fes += [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D - 1)]
     fe = fes[0]
     P = fe.rows * fe.cols
 
@@ -377,6 +376,7 @@ def main():
                                       B, in_cols, in_rows, uniq, args.geometry, fe.cols, fe.rows, fe.lsd_cols, fe.lsd_rows, M, D),
                        "frames_per_gpu_per_step": B, "segments_per_step_rank0": seg_total[0], "live_map": map_state,
                        "lsd_seed_order": args.seed_order, "tie_rule": args.tie_rule,
+                       "handle_gb": round(handle_bytes / 1e9, 2), "lsd_list_entries": fe.lsd_list_capacity()[0], "lsd_lists_grown": sum(f.lsd_list_capacity()[1] for f in fes),
                        "host_ms_per_step": host_profile, "batches_in_flight": D, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                        "parallelism": "frame-sharded x%d, one all-gather of segment blocks per step, replicated map" % world},
             "roofline": roofline,

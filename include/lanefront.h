@@ -603,6 +603,14 @@ LF_API int lf_lsd_size(const lf_handle* h, int* rows, int* cols);
  * section 4).  A hint: results never depend on it. */
 LF_API int lf_suggested_depth(const lf_handle* h);
 
+/* The per-problem lists of the LSD stages (records of defined pixels, compact arrays, seed lists, sort scratch: ~100 bytes per entry
+ * and (frame, colour)).  A handle for more than 16 frames starts with an eighth of the LSD image per problem -- a lane frame's colour has
+ * 3 - 6 % of its pixels defined, a camera frame's 10 - 20 % -- and when a batch holds a problem with more, lf_wait reallocates the lists
+ * with room to spare and runs that batch again (results never depend on the capacity; only that one batch takes twice as long).
+ * *entries = the current capacity per problem, *grown = how many times it was raised.  LF_LSD_RECORDS=<entries> | full in the
+ * environment sets the starting capacity of handles created afterwards (full = the whole LSD image: never a second run). */
+LF_API int lf_lsd_list_capacity(const lf_handle* h, int* entries, int* grown);
+
 /* per-kernel timing with HIP events on the handle's stream */
 #define LF_N_STAGES 13
 LF_API int lf_set_profiling(lf_handle* h, int enabled);

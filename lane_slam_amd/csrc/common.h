@@ -59,6 +59,8 @@ struct LsdParams {
     int label_items;    // k_lsd_label's capacity: problems with more defined pixels are grown as one component (labels are u16; sizes the region scratch)
     int label_items_max; // = label_items (rounds 2 - 3: a handle moved label_items up to this)
     int label_lds;      // problems of up to this many defined pixels are labelled in LDS, the others in the region scratch (k_lsd_label)
+    int rec_cap;        // entries per problem of every per-problem list (records, compact arrays, seed lists, sort scratch): the stride of those
+                        // arrays.  Hs * Ws holds any problem; a batch handle starts lower and grows when a batch needs more (lanefront_api.hip)
 };
 
 struct SegParams {
@@ -129,19 +131,19 @@ void launch_edges_u8(const CannyParams& p, int n_frames, const uint32_t* bits, u
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
                      const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
                      int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
-                     uint32_t* l_addr, double* l_mod, int* n_low, bool counters_zeroed, hipStream_t s);
+                     uint32_t* l_addr, double* l_mod, int* n_low, int* rec_need, bool counters_zeroed, hipStream_t s);
 void launch_lsd_grad_gray(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint8_t* gray, uint32_t* r_addr, float* r_deg,
                           double* r_mod, double* r_cs, double* r_sn, int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy,
                           uint32_t* list, int* list_count, uint32_t* l_addr, double* l_mod, int* n_low, hipStream_t s);
 // the seed order of OpenCV >= 3.2 (k_lsd_seed32.hip): rewrites order_a after launch_lsd_order; l_*: k_lsd_grad's "low" records
 bool lsd_seed32_supported(const LsdParams& p);
-void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const unsigned long long* maxgrad, const uint32_t* c_xy,
+void launch_lsd_seed32(const LsdParams& p, int n_frames, int* n_rec, int* norder, int* rec_need, const unsigned long long* maxgrad, const uint32_t* c_xy,
                        const double* c_mod, const uint32_t* l_addr, double* l_mod, const int* n_low,
                        unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b, int big, hipStream_t s);
 size_t std_sort_debug_words(int n);
 void launch_std_sort_debug(const uint32_t* E, uint32_t* work, int n, int* count, hipStream_t s);
 void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, const float* r_deg, const double* r_mod,
-                      const double* r_cs, const double* r_sn, const int* n_rec, const unsigned long long* maxgrad,
+                      const double* r_cs, const double* r_sn, int* n_rec, const unsigned long long* maxgrad,
                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b,
                       int* norder, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs, double* c_sn,
                       int* row_start, hipStream_t s);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
                                                   int max_nsx, int max_nsy, const uint32_t* __restrict__ list,
                                                   const int* __restrict__ list_count,
                                                   uint32_t* __restrict__ l_addr, double* __restrict__ l_mod, int* __restrict__ n_low,
-                                                  const uint8_t* __restrict__ gray)
+                                                  const uint8_t* __restrict__ gray, int* __restrict__ rec_need)
 {
     extern __shared__ double lds_d[];
     __shared__ double T[128];                     // ordered partial sums of k[j]*255 per 7-bit pattern
@@ -132,7 +132,6 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
     double* dln = lds_d + (size_t)GT * GT;               // their gradient magnitudes
     double* lln = lds_d + (size_t)2 * GT * GT;           // "low" pixels: magnitude, address
     uint32_t* lla = reinterpret_cast<uint32_t*>(lds_d + (size_t)3 * GT * GT);
-    const size_t Ps = (size_t)p.Hs * p.Ws;
     const double DEG_TO_RADS = 3.14159265358979323846 / 180;
 
     for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
@@ -307,8 +306,15 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         __syncthreads();
         // one record per defined pixel; cos/sin of the float-rounded angle (what region growing
         // accumulates) evaluated on full waves.  Record order is arbitrary (k_lsd_order sorts by address).
-        const size_t rb = (size_t)pc * Ps + rec_base;
-        for (int e = threadIdx.x; e < nd; e += LG_T) {
+        // (a problem with more records than the handle's lists hold: nothing is written, the need is reported, the host grows the
+        // lists and runs the batch again -- lanefront_api.hip: lsd_records_retry)
+        const bool rec_fit = rec_base + nd <= p.rec_cap, low_fit = low_base + n_lo <= p.rec_cap;
+        if (threadIdx.x == 0 && rec_need) {
+            if (!rec_fit) atomicMax(rec_need, rec_base + nd);
+            if (l_addr && !low_fit) atomicMax(rec_need, low_base + n_lo);
+        }
+        const size_t rb = (size_t)pc * p.rec_cap + rec_base;
+        for (int e = threadIdx.x; e < nd && rec_fit; e += LG_T) {
             const uint2 it = dl[e];
             const double* q = Sc + it.y;                          // the pixel's 2x2 neighbourhood again: the same gx, gy as above
             const double DA = q[GT + 2] - q[0];
@@ -325,8 +331,8 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
             r_sn[rb + e] = s_;
         }
         if (l_addr) {
-            const size_t lb = (size_t)pc * Ps + low_base;
-            for (int e = threadIdx.x; e < n_lo; e += LG_T) { l_addr[lb + e] = lla[e]; l_mod[lb + e] = lln[e]; }
+            const size_t lb = (size_t)pc * p.rec_cap + low_base;
+            for (int e = threadIdx.x; e < n_lo && low_fit; e += LG_T) { l_addr[lb + e] = lla[e]; l_mod[lb + e] = lln[e]; }
         }
     }
 }
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
 void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, const uint32_t* edge_bits,
                      const uint32_t* mask_bits, uint32_t* r_addr, float* r_deg, double* r_mod, double* r_cs, double* r_sn,
                      int* n_rec, unsigned long long* maxgrad, int max_nsx, int max_nsy, uint32_t* list, int* list_count,
-                     uint32_t* l_addr, double* l_mod, int* n_low, bool counters_zeroed, hipStream_t s)
+                     uint32_t* l_addr, double* l_mod, int* n_low, int* rec_need, bool counters_zeroed, hipStream_t s)
 {
     const int h = p.half;
     const size_t szF = (size_t)(max_nsy + 2 * h) * max_nsx, szBl = (size_t)max_nsy * max_nsx;
@@ -354,7 +360,7 @@ void launch_lsd_grad(const LsdParams& p, const ResizeTables& rt, int n_frames, c
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(LG_T), lds, s, p, rt, edge_bits, mask_bits, r_addr, r_deg, r_mod, r_cs,
-                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low, nullptr);
+                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low, nullptr, rec_need);
 }
 
 // every tile of colour 0 of every frame: the tile list of a gray image (nothing to classify)
@@ -388,7 +394,7 @@ void launch_lsd_grad_gray(const LsdParams& p, const ResizeTables& rt, int n_fram
     const int per_cu = (int)((150 * 1024) / (lds + 3072));
     const int blocks = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
     hipLaunchKernelGGL(k_lsd_grad, dim3(blocks), dim3(LG_T), lds, s, p, rt, nullptr, nullptr, r_addr, r_deg, r_mod, r_cs,
-                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low, gray);
+                       r_sn, n_rec, maxgrad, max_nsx, max_nsy, list, list_count, l_addr, l_mod, n_low, gray, nullptr);
 }
 
 }  // namespace lf

@@ -100,7 +100,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     unsigned long long* bits64 = reinterpret_cast<unsigned long long*>(lds);
     uint16_t* pref = reinterpret_cast<uint16_t*>(lds + 2 * bm_words);
     const int n_def = norder[pc];
-    const uint32_t* gxy = c_xy + (size_t)pc * Ps;
+    const uint32_t* gxy = c_xy + (size_t)pc * p.rec_cap;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
     if (BM) {
         __shared__ int wave_tot[GROW_WAVES];
@@ -139,10 +139,10 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     c.pend_n = &pend_n; c.pend_cap = pend_cap;
     c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = BM ? -1 : BIG ? def_lds : 0x7fffffff;
     c.bits64 = bits64; c.pref = pref;
-    c.deg = c_deg + (size_t)pc * Ps;
-    c.mod = c_mod + (size_t)pc * Ps;
-    c.cs = c_cs + (size_t)pc * Ps * 2;                       // interleaved (cos, sin) pairs: lsd_grow.h cs_sn()
-    c.sn = c_sn + (size_t)pc * Ps * 2;
+    c.deg = c_deg + (size_t)pc * p.rec_cap;
+    c.mod = c_mod + (size_t)pc * p.rec_cap;
+    c.cs = c_cs + (size_t)pc * p.rec_cap * 2;                       // interleaved (cos, sin) pairs: lsd_grow.h cs_sn()
+    c.sn = c_sn + (size_t)pc * p.rec_cap * 2;
     c.usedc = usedc; c.gused = gu; c.used_lds = BIG ? def_lds : 0x7fffffff;
     // every wave has its own region list: reg_lds entries in LDS, the rest in its slice of the problem's scratch.
     // Problems too large for k_lsd_label's LDS (> label_items defined pixels) come as ONE component: wave 0 takes it
@@ -153,7 +153,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;
     c.min_reg_size = p.min_reg_size; c.refine = p.refine;
-    c.label = c_label + (size_t)pc * Ps;
+    c.label = c_label + (size_t)pc * p.rec_cap;
     c.tags = tt; c.line_count = &line_count;
 #ifdef LFG_STAMPS
     for (int k = 0; k < 24; ++k) c.stamps[k] = 0;
@@ -168,7 +168,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
         k = __builtin_amdgcn_readfirstlane(k);
         if (k >= n_comp) break;
         c.root = (int)clist[k];
-        (void)grow::detect(c, order + (size_t)pc * Ps, n_def, tl, p.cap_lines);
+        (void)grow::detect(c, order + (size_t)pc * p.rec_cap, n_def, tl, p.cap_lines);
     }
     // no more components for this wave: help with the deferred evaluations until every growing wave is done and the ring is
     // empty -- or until there has been nothing to take for a while (an idle wave gives its slot back; whatever is pushed
@@ -317,11 +317,10 @@ __global__ __launch_bounds__(64 * LFG_EVAL_WAVES) void k_lsd_eval(LsdParams p, c
         if (tid == 0) counts[pc] = p.cap_lines + 1;
         return;
     }
-    const size_t Ps = (size_t)p.Hs * p.Ws;
     int* rows = reinterpret_cast<int*>(lds);
     uint16_t* lxs = reinterpret_cast<uint16_t*>(lds + ((p.Hs + 2) & ~1));
     const int n_def = norder[pc];
-    const uint32_t* gxy = c_xy + (size_t)pc * Ps;
+    const uint32_t* gxy = c_xy + (size_t)pc * p.rec_cap;
     const int* grs = row_start + (size_t)pc * (p.Hs + 1);
     for (int i = tid; i <= p.Hs; i += 64 * LFG_EVAL_WAVES) rows[i] = grs[i];
     for (int i = tid; i < n_def && i < def_lds; i += 64 * LFG_EVAL_WAVES) lxs[i] = (uint16_t)(gxy[i] & 0xffffu);
@@ -331,7 +330,7 @@ __global__ __launch_bounds__(64 * LFG_EVAL_WAVES) void k_lsd_eval(LsdParams p, c
     c.W = p.Ws; c.H = p.Hs;
     c.q = nullptr;
     c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
-    c.deg = c_deg + (size_t)pc * Ps;
+    c.deg = c_deg + (size_t)pc * p.rec_cap;
     c.mod = nullptr; c.cs = nullptr; c.sn = nullptr; c.usedc = nullptr; c.gused = nullptr; c.used_lds = 0;
     c.lreg = nullptr; c.greg = nullptr; c.reg_lds = 0;
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
@@ -399,8 +398,10 @@ size_t lsd_grow_reg_stride(const LsdParams& p)
     // region scratch per problem: the whole scaled image for a single-component problem (one wave), or one
     // slice per wave -- components come from k_lsd_label only for problems of <= label_items defined pixels
     const size_t Ps = (size_t)p.Hs * p.Ws;
+    // (a region holds defined pixels: no more than the problem's lists, rec_cap)
     const size_t need = (size_t)GROW_LISTS * (p.label_items_max > p.label_items ? p.label_items_max : p.label_items);
-    return Ps > need ? Ps : need;
+    const size_t all = (size_t)p.rec_cap < Ps ? (size_t)p.rec_cap : Ps;
+    return all > need ? all : need;
 }
 
 // LDS per problem: row starts + (per defined pixel: 2 B of x + 1 USED bit) + one region-list head per wave.

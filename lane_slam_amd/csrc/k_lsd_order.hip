@@ -153,7 +153,7 @@ __device__ __forceinline__ void stable_pass5(const uint32_t* src, Dst* dst, int 
 __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* __restrict__ r_addr,
                                                   const float* __restrict__ r_deg, const double* __restrict__ r_mod,
                                                   const double* __restrict__ r_cs, const double* __restrict__ r_sn,
-                                                  const int* __restrict__ n_rec,
+                                                  int* __restrict__ n_rec,
                                                   const unsigned long long* __restrict__ maxgrad,
                                                   unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
                                                   uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b,
@@ -172,8 +172,12 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
     __shared__ int base[NB];
     const int pc = blockIdx.x;
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    const size_t o = (size_t)pc * Ps;
-    const int n = n_rec[pc];
+    const size_t o = (size_t)pc * p.rec_cap;
+    // (more records than the handle's lists hold: k_lsd_grad wrote none and reported the need -- an empty problem until the host has
+    // grown the lists and runs the batch again; later kernels read the count from n_rec too)
+    const int n_raw = n_rec[pc];
+    const int n = n_raw > p.rec_cap ? 0 : n_raw;
+    if (n_raw > p.rec_cap && threadIdx.x == 0) n_rec[pc] = 0;
     const int t = threadIdx.x;
     unsigned long long* X = sort_a + o;
     unsigned long long* Y = sort_b + o;
@@ -301,7 +305,7 @@ constexpr int OB_BINS = 1024;
 __global__ __launch_bounds__(OBT) void k_lsd_order_bm(LsdParams p, const uint32_t* __restrict__ r_addr,
                                                      const float* __restrict__ r_deg, const double* __restrict__ r_mod,
                                                      const double* __restrict__ r_cs, const double* __restrict__ r_sn,
-                                                     const int* __restrict__ n_rec,
+                                                     int* __restrict__ n_rec,
                                                      const unsigned long long* __restrict__ maxgrad,
                                                      unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
                                                      uint32_t* __restrict__ order_a, uint32_t* __restrict__ order_b,
@@ -317,8 +321,12 @@ __global__ __launch_bounds__(OBT) void k_lsd_order_bm(LsdParams p, const uint32_
     __shared__ uint32_t bin_base[OB_BINS];
     const int pc = blockIdx.x;
     const size_t Ps = (size_t)p.Hs * p.Ws;
-    const size_t o = (size_t)pc * Ps;
-    const int n = n_rec[pc];
+    const size_t o = (size_t)pc * p.rec_cap;
+    // (more records than the handle's lists hold: k_lsd_grad wrote none and reported the need -- an empty problem until the host has
+    // grown the lists and runs the batch again; later kernels read the count from n_rec too)
+    const int n_raw = n_rec[pc];
+    const int n = n_raw > p.rec_cap ? 0 : n_raw;
+    if (n_raw > p.rec_cap && threadIdx.x == 0) n_rec[pc] = 0;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     uint32_t* A = order_a + o;
     uint32_t* B = order_b + o;
@@ -438,7 +446,7 @@ __global__ __launch_bounds__(OBT) void k_lsd_order_bm(LsdParams p, const uint32_
 }
 
 void launch_lsd_order(const LsdParams& p, int n_frames, const uint32_t* r_addr, const float* r_deg, const double* r_mod,
-                      const double* r_cs, const double* r_sn, const int* n_rec, const unsigned long long* maxgrad,
+                      const double* r_cs, const double* r_sn, int* n_rec, const unsigned long long* maxgrad,
                       unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b,
                       int* norder, uint32_t* c_xy, float* c_deg, double* c_mod, double* c_cs, double* c_sn,
                       int* row_start, hipStream_t s)
@@ -569,7 +577,7 @@ __device__ __forceinline__ void lsd_label_problem(const LsdParams& p, const int*
     __shared__ uint16_t roots[kCompCap];
     __shared__ int n_roots, rest_total;
     const int pc = blockIdx.x, t = threadIdx.x;
-    const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps;
+    const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * p.rec_cap;
     const int n = norder[pc];
     uint16_t* lab = c_label + o;
     uint16_t* list = comp_list + (size_t)pc * kCompCap;
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(LT) void k_lsd_label(LsdParams p, const int* __rest
         lsd_label_problem<true>(p, norder, c_xy, row_start, c_label, comp_list, comp_count, comp_key, comp_cap, scratch, scratch_stride);
     else {
         // (images whose bit plane exceeds the launch's LDS: 1080p) one component = the whole problem
-        const size_t o = (size_t)blockIdx.x * p.Hs * p.Ws;
+        const size_t o = (size_t)blockIdx.x * p.rec_cap;
         for (int e = threadIdx.x; e < n; e += LT) c_label[o + e] = 0;
         if (threadIdx.x == 0) { comp_list[(size_t)blockIdx.x * kCompCap] = 0; comp_count[blockIdx.x] = 1; comp_key[blockIdx.x] = n; }
     }
@@ -787,15 +795,15 @@ __global__ void k_lsd_dense_debug(LsdParams p, const int* __restrict__ norder, c
                                   float* __restrict__ ang, double* __restrict__ mod)
 {
     const int pc = blockIdx.x;
-    const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps;
+    const size_t Ps = (size_t)p.Hs * p.Ws, o = (size_t)pc * Ps, oc = (size_t)pc * p.rec_cap;     // (dense planes | compact arrays)
     for (size_t i = threadIdx.x; i < Ps; i += blockDim.x) { ang[o + i] = kNotDef; mod[o + i] = 0.0; }
     __syncthreads();
     const int n = norder[pc];
     for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        const uint32_t xy = c_xy[o + e];
+        const uint32_t xy = c_xy[oc + e];
         const size_t a = (size_t)(xy >> 16) * p.Ws + (xy & 0xffffu);
-        ang[o + a] = c_deg[o + e];
-        mod[o + a] = c_mod[o + e];
+        ang[o + a] = c_deg[oc + e];
+        mod[o + a] = c_mod[oc + e];
     }
 }
 

@@ -886,7 +886,7 @@ constexpr int kEngRows = kBlock / 64;
 constexpr int kEngWordsP = 2 * kEngRows;                 // 32-bit words of a plane
 constexpr int kEngCut = kBlock / 16;                     // one cut slot per 16 positions: ranges are longer than 16 and disjoint
 constexpr int kEngBatch = 64;                            // ranges per block at most
-constexpr int kEngWords = kBlock + kBlock / 2 + 4 * (kEngWordsP + 2) + 2 * kEngCut + 8 + (kEngBatch + 2) + 2 * kEngBatch;
+[[maybe_unused]] constexpr int kEngWords = kBlock + kBlock / 2 + 4 * (kEngWordsP + 2) + 2 * kEngCut + 8 + (kEngBatch + 2) + 2 * kEngBatch;
 static_assert(kBlock <= 8192 && kBlock % 512 == 0, "13-bit positions, whole rows per wave");
 typedef uint32_t eng_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) eng_u32x2 lds_u32x2;
@@ -1275,6 +1275,7 @@ struct SeedWork {
     uint32_t* RT;             // row tables of a list that does not fit LDS (6 words per 64 entries)
     unsigned long long* dscratch;   // the dense phase's range lists and place lists: aliases V1 | P0
     uint32_t* out;            // the seeds in their final order (aliases P1)
+    int cap;                  // entries each of these areas holds (LsdParams::rec_cap)
 };
 
 // the chain's state: LDS, written by single threads between barriers
@@ -1760,7 +1761,7 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
     lds_cs* cs = (lds_cs*)(__attribute__((address_space(3))) void*)cs_generic;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (t == 0) {
-        cs->f = 0; cs->l = n; cs->depth = 2 * (31 - __clz(n)); cs->a = 0; cs->b = m0; cs->seeds = nseeds; cs->cur = 0; cs->e_used = 0; cs->n_ranges = 0;
+        cs->f = 0; cs->l = n; cs->depth = 2 * (31 - __clz(n)); cs->a = 0; cs->b = m0; cs->seeds = nseeds; cs->cur = 0; cs->e_used = 0; cs->n_ranges = 0; cs->stop = 0;
     }
     uint32_t pr[kEPT];                                                    // the plane form's register copy of this thread's list slots
     bool regs_ok = false;
@@ -1776,6 +1777,11 @@ __device__ __forceinline__ void sparse_chain(const SeedWork& W, lds_u32* Pl, lds
         if (seeds == 0) break;
         if (len <= kChainDense || (len - m) * 4 <= len || depth == 0 || cs->n_ranges >= kMaxRanges - 1) {
             const int off = cs->e_used;
+            if (off + len > W.cap) {                                      // the dense array would not hold it (the split parts are explicit entries: they always fit)
+                if (t == 0) cs->stop = off + len;
+                __syncthreads();
+                break;
+            }
             if (PL) chain_materialize(W.E, off, f, l, Pl, V, a, b); else chain_materialize(W.E, off, f, l, Pg, V, a, b);
             if (t == 0) { const int k = cs->n_ranges; cs->ranges[k].off = off; cs->ranges[k].len = len; cs->ranges[k].depth = depth; cs->n_ranges = k + 1; cs->e_used = off + len; }
             __syncthreads();
@@ -2109,18 +2115,20 @@ __device__ __forceinline__ void seed_radix_pass(const uint32_t* __restrict__ src
 // chain's result (elements used, ranges) in the first words of the problem's RT area.
 
 // kernel 1: the chain on the explicit list (m entries; positions in W.P0, values in W.V0) over an array of n elements with n_seeds seeds
-__device__ __forceinline__ void seed32_chain(const SeedWork& W, int n, int m, int n_seeds, uint32_t* lds, int lds_words)
+__device__ __forceinline__ int seed32_chain(const SeedWork& W, int n, int m, int n_seeds, uint32_t* lds, int lds_words)
 {
     __shared__ ChainState cstate;
     const int t = threadIdx.x;
     SEED_T(t0);
     sparse_chain<false>(W, nullptr, nullptr, &cstate, n, m, n_seeds, as_lds<lds_u32>(lds), lds_words);
     int* state = reinterpret_cast<int*>(W.RT);
+    if (cstate.stop) return cstate.stop;                                  // the dense array needs this many entries
     if (t == 0) { state[0] = cstate.e_used; state[1] = cstate.n_ranges; }
     for (int i = t; i < cstate.n_ranges; i += ST) { state[2 + 3 * i] = cstate.ranges[i].off; state[3 + 3 * i] = cstate.ranges[i].len; state[4 + 3 * i] = cstate.ranges[i].depth; }
 #ifdef LF_SEED_STAMPS
     { const long long t1 = (long long)wall_clock64(); if (t == 0 && blockIdx.x < 6) printf("[seed32] problem %d: n %d list %d seeds %d | chain %lld (%d folds %d, %d splits %d -> %d dense in %d ranges) (x10 ns) | fold: passA %lld counts %lld median %lld K %lld passB %lld state %lld | split: build %lld counts %lld K %lld TV %lld out %lld\n", (int)blockIdx.x, n, m, n_seeds, t1 - t0, g_dbg_chain[blockIdx.x % 8][0], g_dbg_chain[blockIdx.x % 8][2], g_dbg_chain[blockIdx.x % 8][1], g_dbg_chain[blockIdx.x % 8][3], cstate.e_used, cstate.n_ranges, g_dbg_f[blockIdx.x % 8][0], g_dbg_f[blockIdx.x % 8][1], g_dbg_f[blockIdx.x % 8][2], g_dbg_f[blockIdx.x % 8][3], g_dbg_f[blockIdx.x % 8][4], g_dbg_f[blockIdx.x % 8][5], g_dbg_f[blockIdx.x % 8][6], g_dbg_f[blockIdx.x % 8][7], g_dbg_f[blockIdx.x % 8][8], g_dbg_f[blockIdx.x % 8][9], g_dbg_f[blockIdx.x % 8][10]); }
 #endif
+    return 0;
 }
 
 // kernel 2: the dense phases and the final insertion sort as stable counting passes.  Leaves the seeds in W.out as
@@ -2206,11 +2214,13 @@ __device__ __forceinline__ SeedWork seed_work(uint32_t* sa, uint32_t* sb, uint32
     W.T = tt; W.RT = tt + ((cap + 1) & ~(size_t)1);                   // (8-byte aligned: the row tables hold 64-bit ballots)
     W.dscratch = reinterpret_cast<unsigned long long*>(sb);
     W.out = oa;
+    W.cap = (int)cap;
     return W;
 }
 
 // plane_ok: the gradient image's bit plane fits the kernel's LDS
-__global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, const int* __restrict__ n_rec, const unsigned long long* __restrict__ maxgrad,
+__global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, int* __restrict__ n_rec, int* __restrict__ norder, int* __restrict__ rec_need,
+                                                   const unsigned long long* __restrict__ maxgrad,
                                                    const uint32_t* __restrict__ c_xy, const double* __restrict__ c_mod,
                                                    const uint32_t* __restrict__ l_addr, double* l_mod, const int* __restrict__ n_low,
                                                    unsigned long long* __restrict__ sort_a, unsigned long long* __restrict__ sort_b,
@@ -2222,7 +2232,7 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
     __shared__ int wave_tot[SW];
     __shared__ int n_list;
     const int pc = blockIdx.x, t = threadIdx.x, lane = t & 63;
-    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t Ps = (size_t)p.rec_cap;                                  // entries per problem of every list
     const size_t o = (size_t)pc * Ps;
     const int nd = n_rec[pc];
     if (nd == 0) return;
@@ -2233,6 +2243,13 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
     const double max_grad = __longlong_as_double((long long)maxgrad[pc]);
     const double bin_coef = (max_grad > 0) ? (double)(p.n_bins - 1) / max_grad : 0;
     const int nl = n_low[pc];
+    // The problem's lists hold rec_cap entries: the explicit list (at most nd + nl) must fit, and so must the low records (k_lsd_grad wrote
+    // none of them otherwise).  A problem that does not fit is dropped from this batch (no seeds: k_lsd_grow leaves it alone) and its need
+    // reported; the host grows the lists and runs the batch again (lanefront_api.hip: lsd_records_retry).
+    if (nl > p.rec_cap || nd + nl > p.rec_cap) {
+        if (t == 0) { atomicMax(rec_need, nd + nl); n_rec[pc] = 0; norder[pc] = 0; }
+        return;
+    }
     // ---- the explicit list in position order: defined pixels (already in raster order) + the undefined ones with a non-zero bin
     if (plane_ok && nd + nl <= 65535) {
         const int words = bitplane_words((size_t)n);
@@ -2332,7 +2349,8 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_lsd_seed32(LsdParams p, con
     }
     const int m = nd + n_list;
     __syncthreads();
-    seed32_chain(W, n, m, nd, seed_lds, lds_words);
+    const int need = seed32_chain(W, n, m, nd, seed_lds, lds_words);
+    if (need && t == 0) { atomicMax(rec_need, need); n_rec[pc] = 0; norder[pc] = 0; }
 }
 
 // kernel 2 of a problem: see seed32_dense
@@ -2344,7 +2362,7 @@ __global__ __launch_bounds__(DT, LF_SEED_DENSE_OCC) void k_lsd_seed32_dense(LsdP
     __shared__ int tot[SNB];
     __shared__ int base[SNB];
     const int pc = blockIdx.x;
-    const size_t Ps = (size_t)p.Hs * p.Ws;
+    const size_t Ps = (size_t)p.rec_cap;
     const size_t o = (size_t)pc * Ps;
     const int nd = n_rec[pc];
     if (nd == 0) return;
@@ -2385,7 +2403,7 @@ __global__ __launch_bounds__(ST, LF_SEED_OCC) void k_std_sort_debug(const uint32
     const int m = m_sh;
     if (t == 0) *count = m;
     if (m == 0) return;
-    seed32_chain(W, n, m, m, seed_lds, lds_words);
+    if (seed32_chain(W, n, m, m, seed_lds, lds_words) && t == 0) *count = 0;      // (cannot happen: cap >= n)
 }
 
 __global__ __launch_bounds__(DT, LF_SEED_DENSE_OCC) void k_std_sort_debug_dense(uint32_t* __restrict__ work, int cap, int rows_cap, const int* __restrict__ count)
@@ -2440,7 +2458,7 @@ bool lsd_seed32_supported(const LsdParams& p)
 
 // big != 0: dense problems are expected (LSD of a gray image: most pixels have a gradient) -- the row tables of the dense phase
 // cover the whole image in LDS when they fit
-void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const unsigned long long* maxgrad, const uint32_t* c_xy,
+void launch_lsd_seed32(const LsdParams& p, int n_frames, int* n_rec, int* norder, int* rec_need, const unsigned long long* maxgrad, const uint32_t* c_xy,
                        const double* c_mod, const uint32_t* l_addr, double* l_mod, const int* n_low,
                        unsigned long long* sort_a, unsigned long long* sort_b, uint32_t* order_a, uint32_t* order_b, int big, hipStream_t s)
 {
@@ -2456,7 +2474,7 @@ void launch_lsd_seed32(const LsdParams& p, int n_frames, const int* n_rec, const
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (lds2 > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(k_lsd_seed32, dim3(n_frames * 3), dim3(ST), lds, s, p, n_rec, maxgrad, c_xy, c_mod, l_addr, l_mod, n_low,
+    hipLaunchKernelGGL(k_lsd_seed32, dim3(n_frames * 3), dim3(ST), lds, s, p, n_rec, norder, rec_need, maxgrad, c_xy, c_mod, l_addr, l_mod, n_low,
                        sort_a, sort_b, order_a, order_b, plane_ok, (int)(lds / 4));
     hipLaunchKernelGGL(k_lsd_seed32_dense, dim3(n_frames * 3), dim3(DT), lds2, s, p, n_rec, l_mod, sort_a, sort_b, order_a, order_b, rows_cap);
 }

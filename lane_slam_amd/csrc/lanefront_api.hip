@@ -53,6 +53,7 @@ struct lf_handle {
     // geometry
     int Hc = 0, W = 0, Hs = 0, Ws = 0, Ww = 0;
     size_t P = 0, Ps = 0;
+    int label_items_full = 0;    // LsdParams::label_items of a handle whose lists hold whole images (alloc_lsd_lists lowers it with rec_cap)
     PreParams pre;
     CannyParams canny;
     LsdParams lsd;
@@ -116,7 +117,9 @@ struct lf_handle {
     AssocScratch a_ws;
     struct MatcherState* matcher = nullptr;     // BinaryDescriptorMatcher's dataset (lanefront_matcher.inc)
     // pinned host scalars
-    int* h_pinned = nullptr;     // [0] total segments, [1] overflow
+    int* h_pinned = nullptr;     // [0] total segments, [1] overflow ... [6] entries the per-problem lists would have needed (d_overflow[5])
+    const uint8_t* pend_in = nullptr; int pend_n = 0; lf_segments pend_out; bool pend_describe = false;   // the batch in flight (lsd_records_retry)
+    int lists_grown = 0;         // times the per-problem lists were reallocated
     int last_frames = 0;
     bool plugin_ready = false;
     bool pending = false;
@@ -328,6 +331,8 @@ static int build_params(lf_handle* h)
     if (L.label_items > 64512) L.label_items = 64512;
     if (L.label_items < kLabelItems) L.label_items = kLabelItems;
     L.label_items_max = L.label_items;
+    h->label_items_full = L.label_items;
+    L.rec_cap = (int)h->Ps;                               // (alloc_buffers chooses the batch handles' starting capacity)
     // ---- segments
     SegParams& S = h->seg;
     memset(&S, 0, sizeof(S));
@@ -442,6 +447,39 @@ static int upload_tables(lf_handle* h)
     return LF_OK;
 }
 
+// the arrays whose stride is LsdParams::rec_cap: records, sort scratch, seed lists, compact arrays, labels, the region scratch, low records
+static void free_lsd_lists(lf_handle* h)
+{
+    void* ptrs[] = { h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_cxy, h->d_cdeg,
+                     h->d_cmod, h->d_ccs, h->d_reg, h->d_clabel, h->d_laddr, h->d_lmod };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->d_raddr = nullptr; h->d_rdeg = nullptr; h->d_rmod = nullptr; h->d_rcs = nullptr; h->d_rsn = nullptr; h->d_sort_a = nullptr; h->d_sort_b = nullptr;
+    h->d_order_a = nullptr; h->d_order_b = nullptr; h->d_cxy = nullptr; h->d_cdeg = nullptr; h->d_cmod = nullptr; h->d_ccs = nullptr; h->d_csn = nullptr;
+    h->d_reg = nullptr; h->d_clabel = nullptr; h->d_laddr = nullptr; h->d_lmod = nullptr;
+}
+
+static int alloc_lsd_lists(lf_handle* h, int rec_cap)
+{
+    const size_t nprob = (size_t)h->max_frames * 3, S = (size_t)rec_cap;
+    LsdParams& L = h->lsd;
+    L.rec_cap = rec_cap;
+    // (components are only kept apart for problems of up to label_items defined pixels; no problem has more than rec_cap)
+    // (... but not below kLabelItems: the labelling kernel's LDS form and the growing waves' scratch slices are laid out for that)
+    const int li = rec_cap > kLabelItems ? rec_cap : kLabelItems;
+    L.label_items = h->label_items_full < li ? h->label_items_full : li;
+    L.label_items_max = L.label_items;
+    if (dalloc(h, &h->d_raddr, nprob * S) || dalloc(h, &h->d_rdeg, nprob * S) || dalloc(h, &h->d_rmod, nprob * S) ||
+        dalloc(h, &h->d_rcs, nprob * S) || dalloc(h, &h->d_rsn, nprob * S) || dalloc(h, &h->d_sort_a, nprob * S) || dalloc(h, &h->d_sort_b, nprob * S) ||
+        dalloc(h, &h->d_order_a, nprob * S) || dalloc(h, &h->d_order_b, nprob * S) || dalloc(h, &h->d_cxy, nprob * S) || dalloc(h, &h->d_cdeg, nprob * S) ||
+        dalloc(h, &h->d_cmod, nprob * S) || dalloc(h, &h->d_ccs, nprob * S * 2) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(L)) ||
+        dalloc(h, &h->d_clabel, nprob * S))
+        return LF_ERR_HIP;
+    h->d_csn = h->d_ccs + 1;          // (cos, sin) pairs in one array: k_lsd_order.hip
+    if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32 && (dalloc(h, &h->d_laddr, nprob * S) || dalloc(h, &h->d_lmod, nprob * S)))
+        return LF_ERR_HIP;
+    return LF_OK;
+}
+
 static int alloc_buffers(lf_handle* h)
 {
     const size_t B = (size_t)h->max_frames, P = h->P, Ps = h->Ps;
@@ -453,13 +491,9 @@ static int alloc_buffers(lf_handle* h)
     h->frames_bytes = B * in_px * 3 > P * 3 ? B * in_px * 3 : P * 3;
     if (dalloc(h, &h->d_frames, h->frames_bytes) || dalloc(h, &h->d_bgr, B * P) || dalloc(h, &h->d_gray, B * P) || 
         dalloc(h, &h->d_edges_u8, B * P) || dalloc(h, &h->d_strong, B * h->Hc * h->Ww) || dalloc(h, &h->d_weak, B * h->Hc * h->Ww) || dalloc(h, &h->d_maskbits, nprob * h->Hc * h->Ww) ||
-        dalloc(h, &h->d_raddr, nprob * Ps) || dalloc(h, &h->d_rdeg, nprob * Ps) || dalloc(h, &h->d_rmod, nprob * Ps) ||
-        dalloc(h, &h->d_rcs, nprob * Ps) || dalloc(h, &h->d_rsn, nprob * Ps) ||
-        dalloc(h, &h->d_sort_a, nprob * Ps) || dalloc(h, &h->d_sort_b, nprob * Ps) || dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
-        dalloc(h, &h->d_order_a, nprob * Ps) ||
-        dalloc(h, &h->d_order_b, nprob * Ps) || dalloc(h, &h->d_cxy, nprob * Ps) || dalloc(h, &h->d_cdeg, nprob * Ps) || dalloc(h, &h->d_cmod, nprob * Ps) ||
-        dalloc(h, &h->d_ccs, nprob * Ps * 2) || dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) || dalloc(h, &h->d_reg, nprob * lsd_grow_reg_stride(h->lsd)) ||
-        dalloc(h, &h->d_clabel, nprob * Ps) || dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) || dalloc(h, &h->d_perm, nprob) || dalloc(h, &h->d_comp_key, nprob) ||
+        dalloc(h, &h->d_tile_list, nprob * (size_t)(((h->Ws + 31) / 32) * ((h->Hs + 31) / 32))) ||
+        dalloc(h, &h->d_gused, nprob * ((Ps + 31) / 32)) || dalloc(h, &h->d_row_start, nprob * (size_t)(h->Hs + 1)) ||
+        dalloc(h, &h->d_comp_list, nprob * (size_t)kCompCap) || dalloc(h, &h->d_comp_count, nprob) || dalloc(h, &h->d_perm, nprob) || dalloc(h, &h->d_comp_key, nprob) ||
         dalloc(h, &h->d_tmp_lines, cap * 4) || dalloc(h, &h->d_tmp_tags, cap) ||
         dalloc(h, &h->d_pend_rec, nprob * (size_t)lsd_grow_pend_cap(h->lsd) * 12 + 2) || dalloc(h, &h->d_pend_tag, nprob * (size_t)lsd_grow_pend_cap(h->lsd) + 1) || dalloc(h, &h->d_pend_count, nprob) || dalloc(h, &h->d_norder, nprob) ||
         dalloc(h, &h->d_counts, nprob) || dalloc(h, &h->d_seg_offset, nprob + 1) || dalloc(h, &h->d_frame_offset, B + 1) ||
@@ -467,10 +501,20 @@ static int alloc_buffers(lf_handle* h)
         dalloc(h, &h->d_dxy, B * P) || dalloc(h, &h->d_normals64, cap * 2) ||
         dalloc(h, &h->d_centers, cap * 2))
         return LF_ERR_HIP;
-    h->d_csn = h->d_ccs + 1;          // (cos, sin) pairs in one array: k_lsd_order.hip
-    if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32 &&
-        (dalloc(h, &h->d_laddr, nprob * Ps) || dalloc(h, &h->d_lmod, nprob * Ps)))
-        return LF_ERR_HIP;
+    // The per-problem lists.  A batch handle starts with an eighth of the LSD image per problem (a lane frame's colour has 3 - 6 % of its
+    // pixels defined, a camera frame's 10 - 20 %) and grows when a batch needs more (lsd_records_retry); handles of a few frames and the
+    // LSD-only sub-handles (gray images: every pixel can be defined) hold whole images.  LF_LSD_RECORDS=<entries> | full overrides.
+    {
+        size_t cap = Ps;
+        if (h->max_frames > 16 && !g_lsd_only_create) cap = (Ps / 8 + 4095) / 4096 * 4096;
+        const char* e = g_lsd_only_create ? nullptr : getenv("LF_LSD_RECORDS");
+        if (e && *e) { if (!strcmp(e, "full")) cap = Ps; else if (atol(e) > 0) cap = (size_t)atol(e); }
+        else if (cap < 8192) cap = 8192;
+        if (cap < 1024) cap = 1024;
+        if (cap > Ps) cap = Ps;
+        const int rc = alloc_lsd_lists(h, (int)cap);
+        if (rc != LF_OK) return rc;
+    }
     {
         h->zero_bytes = nprob * 8 + nprob * 4 + nprob * 4 + 16 + 32;
         if (dalloc(h, &h->d_zero, h->zero_bytes)) return LF_ERR_HIP;
@@ -521,13 +565,14 @@ extern "C" void lf_destroy(lf_handle* h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     void* ptrs[] = { h->d_frames, h->d_bgr, h->d_gray, h->dbg_masks.p, h->d_edges_u8, h->d_strong, h->d_weak, h->d_maskbits, h->d_sdiv, h->d_hdiv,
-                     h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_zero, h->d_sort_a, h->d_sort_b, h->dbg_ang.p, h->dbg_mod.p, h->d_order_a, h->d_order_b, h->d_reg, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_gused, h->d_row_start, h->d_tile_list,
+                     h->d_zero, h->dbg_ang.p, h->dbg_mod.p, h->d_gused, h->d_row_start, h->d_tile_list,
                      h->d_norder, h->d_counts, h->d_seg_offset, h->d_frame_offset, h->d_slot_lines,
-                     h->d_seg_frame, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
+                     h->d_seg_frame, h->d_comp_list, h->d_comp_count, h->d_perm, h->d_comp_key, h->d_tmp_lines, h->d_tmp_tags, h->d_pend_rec, h->d_pend_tag, h->d_pend_count, h->d_dxy, h->dbg_dx.p, h->dbg_dy.p, h->d_gauss_g, h->d_gauss_l, h->d_xofs, h->d_y0, h->d_y1,
                      h->d_xa, h->d_yb, h->d_out.lines, h->d_out.normals, h->d_out.color, h->d_out.pixels_normalized,
                      h->d_out.ground, h->d_out.keep, h->d_out.desc, h->d_out.code, h->d_normals64, h->d_centers,
-                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p, h->d_laddr, h->d_lmod };
+                     h->km_pts.p, h->km_lab.p, h->km_f64.p, h->km_cnt.p, h->kn_hist.p, h->kn_count.p, h->kn_off.p, h->kn_total.p, h->a_q.p, h->a_m.p, h->a_mx.p, h->a_mcx.p, h->a_best.p, h->a_idx.p, h->a_dist.p, h->a_qn.p, h->a_mn.p, h->dbg_bgr.p };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    free_lsd_lists(h);
     assoc_scratch_free(h->a_ws);
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     if (h->plug_host) (void)hipHostFree(h->plug_host);
@@ -628,14 +673,14 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
         StageTimer t(h, ST_LSD_GRAD);
         LF_HIP_CHECK(h, hipMemsetAsync(h->d_zero, 0, h->zero_bytes, s));           // every counter of the batch (see d_zero)
         launch_lsd_grad(h->lsd, h->rt, n, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec,
-                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, true, s);
+                        h->d_maxgrad, h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, h->d_overflow + 5, true, s);
     }
     {
         StageTimer t(h, ST_LSD_ORDER);
         launch_lsd_order(h->lsd, n, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
         // OpenCV >= 3.2: the seeds in the order std::sort leaves them in (the compact arrays and row starts stay as they are)
         if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
-            launch_lsd_seed32(h->lsd, n, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
+            launch_lsd_seed32(h->lsd, n, h->d_nrec, h->d_norder, h->d_overflow + 5, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
     }
     {
         StageTimer t(h, ST_LSD_ORDER);
@@ -728,7 +773,21 @@ extern "C" int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n
     h->pending_keylines = false;
     h->pending_problems = n_frames * 3;
     h->pending_capacity = out_dev->capacity;
+    h->pend_in = d_in; h->pend_n = n_frames; h->pend_out = *out_dev; h->pend_describe = describe != 0;
     return LF_OK;
+}
+
+// The per-problem lists of the LSD stages hold LsdParams::rec_cap entries.  When a batch had a problem with more (d_overflow[5], read
+// by the caller: the largest need), that problem was dropped on the device; here the lists are reallocated with room to spare and the
+// caller runs the batch again.  The stream must be idle.  Results never depend on the capacity -- only whether a batch runs twice.
+static int lsd_grow_lists(lf_handle* h, int need)
+{
+    size_t cap = ((size_t)need + (size_t)need / 4 + 4095) / 4096 * 4096;
+    if (cap > h->Ps) cap = h->Ps;
+    if (alloc_trace()) fprintf(stderr, "lanefront: a problem needs %d list entries, the handle holds %d: growing to %zu\n", need, h->lsd.rec_cap, cap);
+    free_lsd_lists(h);
+    ++h->lists_grown;
+    return alloc_lsd_lists(h, (int)cap);
 }
 
 extern "C" int lf_wait(lf_handle* h, int* n_segments)
@@ -745,6 +804,16 @@ extern "C" int lf_wait(lf_handle* h, int* n_segments)
         if (n_segments) *n_segments = total_kl;
         if (overflow) { lf_set_error(h, LF_ERR_CAPACITY, "%d KeyLines exceed the output capacity %d", total_kl, h->pending_capacity); return LF_ERR_CAPACITY; }
         return LF_OK;
+    }
+    for (int attempt = 0; h->detector != LF_DETECTOR_EDLINES && h->h_pinned[6] > h->lsd.rec_cap; ++attempt) {
+        // a problem did not fit the per-problem lists: grow them and run the batch again (its inputs are still where they were)
+        if (attempt == 4) { lf_set_error(h, LF_ERR_CAPACITY, "the LSD lists keep overflowing (%d entries needed)", h->h_pinned[6]); return LF_ERR_CAPACITY; }
+        int rc = lsd_grow_lists(h, h->h_pinned[6]);
+        if (rc == LF_OK) rc = run_detect(h, h->pend_in, h->pend_n, false);
+        if (rc == LF_OK) rc = run_segments(h, h->pend_n, h->pend_out, h->pend_describe);
+        if (rc != LF_OK) return rc;
+        LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[1], h->d_overflow, 8 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));
     }
     h->detector_failures = h->detector == LF_DETECTOR_EDLINES ? h->h_pinned[5] : 0;
     const int total = h->h_pinned[8];
@@ -856,6 +925,7 @@ extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols
     h->plugin_ready = false;
     int rc = plugin_stage_image(h, bgr, rows, cols, row_stride_bytes);
     if (rc != LF_OK) return rc;
+    for (int attempt = 0;; ++attempt) {
     rc = run_detect(h, h->d_frames, 1, true);
     if (rc != LF_OK) return rc;
     lf_segments dev = h->d_out;
@@ -870,7 +940,13 @@ extern "C" int lf_set_image(lf_handle* h, const uint8_t* bgr, int rows, int cols
     if ((rc = plugin_fetch_results(h)) != LF_OK) return rc;
     LF_HIP_CHECK(h, hipMemcpyAsync(h->h_counts.data(), h->d_counts, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipMemcpyAsync(h->h_seg_offset.data(), h->d_seg_offset, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    LF_HIP_CHECK(h, hipMemcpyAsync(&h->h_pinned[6], h->d_overflow + 5, sizeof(int), hipMemcpyDeviceToHost, s));
     LF_HIP_CHECK(h, hipStreamSynchronize(s));          // the ONE synchronisation of an image: counts, segments and masks are on the host
+    // (a handle made for batches holds short per-problem lists: grow them and detect again when this image needs more)
+    if (h->h_pinned[6] <= h->lsd.rec_cap) break;
+    if (attempt == 4) { lf_set_error(h, LF_ERR_CAPACITY, "the LSD lists keep overflowing (%d entries needed)", h->h_pinned[6]); return LF_ERR_CAPACITY; }
+    if ((rc = lsd_grow_lists(h, h->h_pinned[6])) != LF_OK) return rc;
+    }
     h->plugin_ready = true;
     return LF_OK;
 }
@@ -1164,6 +1240,14 @@ extern "C" int lf_kmeans(lf_handle* h, const uint8_t* bgr_points, int n, int on_
     return LF_OK;
 }
 
+extern "C" int lf_lsd_list_capacity(const lf_handle* h, int* entries, int* grown)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (entries) *entries = h->lsd.rec_cap;
+    if (grown) *grown = h->lists_grown;
+    return LF_OK;
+}
+
 extern "C" int lf_suggested_depth(const lf_handle* h)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;
@@ -1208,6 +1292,11 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     if (!img || !lines4 || !n_out || rows != h->Hc || cols != h->W) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_debug_lsd_binary: bad argument (image must be %dx%d)", h->Hc, h->W); return LF_ERR_BAD_ARG; }
     LF_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
+    if ((size_t)h->lsd.rec_cap < h->Ps) {                 // (a debug entry: any binary image must fit -- whole-image lists from here on)
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+        const int rc = lsd_grow_lists(h, (int)h->Ps);
+        if (rc != LF_OK) return rc;
+    }
     const size_t nw = (size_t)h->Hc * h->Ww;
     std::vector<uint32_t> bits(nw, 0u), ones(nw * 3, 0xffffffffu);
     for (int y = 0; y < rows; ++y)
@@ -1217,11 +1306,11 @@ extern "C" int lf_debug_lsd_binary(lf_handle* h, const uint8_t* img, int rows, i
     LF_HIP_CHECK(h, hipMemcpyAsync(h->d_maskbits, ones.data(), nw * 12, hipMemcpyHostToDevice, s));
     LF_HIP_CHECK(h, hipMemsetAsync(h->d_maxgrad, 0, 3 * sizeof(unsigned long long), s));
     launch_lsd_grad(h->lsd, h->rt, 1, h->d_strong, h->d_maskbits, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad,
-                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, false, s);
+                    h->max_nsx, h->max_nsy, h->d_tile_list, h->d_tile_count, h->d_laddr, h->d_lmod, h->d_nlow, h->d_overflow + 5, false, s);
     launch_lsd_order(h->lsd, 1, h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_nrec, h->d_maxgrad, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_norder,
                      h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start, s);
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32)
-        launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
+        launch_lsd_seed32(h->lsd, 1, h->d_nrec, h->d_norder, h->d_overflow + 5, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
     launch_lsd_label(h->lsd, 1, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, s);
     launch_lsd_grow(h->lsd, 1, h->d_order_a, h->d_norder, h->d_cxy, h->d_cdeg, h->d_cmod, h->d_ccs, h->d_csn, h->d_row_start,
                     h->d_clabel, h->d_comp_list, h->d_comp_count, kCompCap, h->d_reg, h->d_gused, h->d_tmp_lines, h->d_tmp_tags,
@@ -1283,7 +1372,14 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
         else { src = h->dbg_mod.p; avail = n * 3 * h->Ps * sizeof(double); }
         break;
     }
-    case LF_BUF_LSD_ORDER: src = h->d_order_a; avail = n * 3 * h->Ps * sizeof(uint32_t); break;
+    case LF_BUF_LSD_ORDER: {
+        // [frames][3][Hs * Ws] for the caller; the handle's lists have rec_cap entries per problem
+        const size_t row = h->Ps * sizeof(uint32_t), have = (size_t)h->lsd.rec_cap * sizeof(uint32_t);
+        if (bytes > n * 3 * row) { lf_set_error(h, LF_ERR_CAPACITY, "buffer %d holds %zu bytes, %zu requested", buffer_id, n * 3 * row, bytes); return LF_ERR_CAPACITY; }
+        LF_HIP_CHECK(h, hipMemcpy2DAsync(dst, row, h->d_order_a, have, have, bytes / row, hipMemcpyDeviceToHost, s));
+        LF_HIP_CHECK(h, hipStreamSynchronize(s));
+        return LF_OK;
+    }
     case LF_BUF_LSD_NORDER: src = h->d_norder; avail = n * 3 * sizeof(int); break;
     case LF_BUF_LBD_DX:
     case LF_BUF_LBD_DY: {

@@ -186,6 +186,13 @@ class FrontEnd(object):
         frames, 18 on busy camera content.  A throughput hint only."""
         return int(self.lib.lf_suggested_depth(self.h))
 
+    def lsd_list_capacity(self):
+        """(entries per problem the LSD stages' lists hold, times they were grown): lf_lsd_list_capacity.  A batch with a problem
+        that needs more is run a second time by wait() after the lists were reallocated; results never depend on it."""
+        e, g = ctypes.c_int(0), ctypes.c_int(0)
+        self._check(self.lib.lf_lsd_list_capacity(self.h, ctypes.byref(e), ctypes.byref(g)))
+        return int(e.value), int(g.value)
+
     def wait(self):
         """Block until the queued batch is complete; returns its segment count."""
         total = ctypes.c_int()

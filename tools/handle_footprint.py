@@ -1,3 +1,4 @@
+# Device memory a handle holds, allocation by allocation (LF_ALLOC_TRACE=1): python tools/handle_footprint.py 2> alloc.txt
 import os, sys
 os.environ["LF_ALLOC_TRACE"]="1"
 import torch
