@@ -48,6 +48,7 @@
 // The heap sort of a range that used up the depth limit (never seen on image data; tested with adversarial keys through
 // lf_debug_std_sort) is libstdc++'s __heap_select + __sort_heap replayed by one lane.
 #include <cstdlib>
+#include <cstring>
 #include "common.h"
 #include "lsd_bitplane.h"
 
@@ -2474,8 +2475,11 @@ void launch_lsd_seed32(const LsdParams& p, int n_frames, int* n_rec, int* norder
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (lds2 > 48 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsd_seed32_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    static const char* diag_skip = getenv("LF_DIAG_SKIP");     // diagnostic only (what-if timing, results are wrong): "seedchain", "seeddense"
+    if (!(diag_skip && strstr(diag_skip, "seedchain")))
     hipLaunchKernelGGL(k_lsd_seed32, dim3(n_frames * 3), dim3(ST), lds, s, p, n_rec, norder, rec_need, maxgrad, c_xy, c_mod, l_addr, l_mod, n_low,
                        sort_a, sort_b, order_a, order_b, plane_ok, (int)(lds / 4));
+    if (!(diag_skip && (strstr(diag_skip, "seeddense") || strstr(diag_skip, "seedchain"))))
     hipLaunchKernelGGL(k_lsd_seed32_dense, dim3(n_frames * 3), dim3(DT), lds2, s, p, n_rec, l_mod, sort_a, sort_b, order_a, order_b, rows_cap);
 }
 
