@@ -86,6 +86,12 @@ __global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables 
 #define LF_LSD_GRAD_THREADS 256
 #endif
 constexpr int LG_T = LF_LSD_GRAD_THREADS;      // threads per tile
+#ifndef LF_GRAD_WAVES
+#define LF_GRAD_WAVES 0
+#endif
+#if LF_GRAD_WAVES
+__attribute__((amdgpu_waves_per_eu(LF_GRAD_WAVES, LF_GRAD_WAVES)))
+#endif
 __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt, const uint32_t* __restrict__ edge_bits,
                                                   const uint32_t* __restrict__ mask_bits, uint32_t* __restrict__ r_addr,
                                                   float* __restrict__ r_deg, double* __restrict__ r_mod,

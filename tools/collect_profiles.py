@@ -52,7 +52,11 @@ for f in glob.glob(os.path.join(T, "bench_ab_*.json")) + glob.glob(os.path.join(
     shutil.copy(f, os.path.join(P, prefix + "_" + os.path.basename(f)))
 if os.path.exists(os.path.join(T, "seed_stamps.txt")):
     with open(os.path.join(T, "seed_stamps.txt")) as f, open(os.path.join(P, prefix + "_seed32_stamps.txt"), "w") as g:
-        g.writelines(l for l in f if l.startswith("[seed32]"))
+        g.writelines(l for l in f if l.startswith("[seed32"))
+for name, dst in (("whatif.txt", "_whatif.txt"), ("handle_footprint.txt", "_handle_footprint.txt")):
+    if os.path.exists(os.path.join(T, name)):
+        with open(os.path.join(T, name)) as f, open(os.path.join(P, prefix + dst), "w") as g:
+            g.writelines(l for l in f if "amdgpu.ids" not in l)
 f = glob.glob(os.path.join(T, "pi/**/*counter_collection.csv"), recursive=True)
 if f:
     tot, cnt = {}, {}

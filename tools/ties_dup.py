@@ -1,3 +1,5 @@
+"""The tie pass on maps that hold copies of the queries (exact: the bench steady state; one bit away: 28 equally near copies each) and on
+random codes: lowest-index rule against the Mihasher rule, per-call time of lf_map_associate (HIP events on the map stream)."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.getcwd())
