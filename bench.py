@@ -118,7 +118,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from lane_slam_amd import FrontEnd, LineAssociator, default_config, synth
+    from lane_slam_amd import FrontEnd, LineAssociator, default_config, synth, _lib
     from lane_slam_amd.distributed import ShardedAssociator
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,6 +306,20 @@ def main():
                 e["algorithmic_bytes"] = sb[name] * B
                 e["GBps"] = round(sb[name] * B / (avg * 1e-3) / 1e9, 1)
                 e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
+            if name == "lsd_blur_resample_grad" and avg > 0:
+                # the bytes of the design that was built -- bit planes in (the Canny edge plane and the three colour masks of
+                # every frame: P / 8 bytes each), sparse records out (32 bytes per pixel with a defined gradient, 12 per pixel with a
+                # non-zero gradient below the threshold when lsd_seed_order = opencv32: counted on the last batch) -- not SURVEY 8d's dense
+                # planes, which this stage never writes.  It is bound by its double-precision blur and resampling, not by these bytes.
+                try:
+                    nd = int(fes[0].fetch(_lib.LF_BUF_LSD_NORDER, B).sum())
+                    nl = int(fes[0].fetch(_lib.LF_BUF_LSD_NLOW, B).sum())
+                    e["algorithmic_bytes"] = B * 4 * (P // 8) + 32 * nd + 12 * nl
+                    e["GBps"] = round(e["algorithmic_bytes"] / (avg * 1e-3) / 1e9, 1)
+                    e["frac_of_hbm_peak"] = round(e["GBps"] / HBM_PEAK_GBS, 4)
+                    e["bytes_note"] = "bit planes in (4 P / 8 per frame) + %d records x 32 B + %d low-gradient records x 12 B of one batch; k_lsd_classify + k_lsd_grad" % (nd, nl)
+                except Exception as ex:
+                    e["bytes_note"] = "record counts unavailable: %r" % (ex,)
             if name == "assoc_mfma" and avg > 0 and seg_total[0] > 0:
                 # 2 * N * M * 256 ops per call (one launch: query expansion, matrix loop, merge, report; the
                 # map's operands stay packed across calls), priced against the dense peak OF THE INSTRUCTION IT RUNS ON
@@ -339,7 +353,7 @@ def main():
                     else:
                         e["counters"] = "profiles/grow_counters.json was measured on another lsd_grow.h / k_lsd_grow.hip: not quoted"
             kernels.append(e)
-        streaming = [k for k in kernels if "GBps" in k]
+        streaming = [k for k in kernels if "GBps" in k and k["stage"] in sb]
         # dominant streaming kernel = the one that has to move the most bytes
         dom = max(streaming, key=lambda k: k["algorithmic_bytes"]) if streaming else None
         roofline = None

@@ -573,7 +573,8 @@ typedef enum lf_buffer_id {
     LF_BUF_LBD_DX = 7,       /* i16 [frames][Hc][W]                                        */
     LF_BUF_LBD_DY = 8,       /* i16 [frames][Hc][W]                                        */
     LF_BUF_LSD_COUNTS = 9,   /* i32 [frames][3]          lines per run                    */
-    LF_BUF_LSD_SCRATCH = 10  /* u32 [frames][3][Hs*Ws]   region-list scratch (diagnostic builds park counters here) */
+    LF_BUF_LSD_SCRATCH = 10, /* u32 [frames][3][Hs*Ws]   region-list scratch (diagnostic builds park counters here) */
+    LF_BUF_LSD_NLOW = 11     /* i32 [frames][3]   pixels with a non-zero gradient below the threshold (the low records of lsd_seed_order = OPENCV32; 0 otherwise) */
 } lf_buffer_id;
 /* copy an intermediate buffer of the last batch to host memory (synchronises) */
 LF_API int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t bytes);

@@ -14,7 +14,7 @@ LF_N_STAGES = 13
 LF_MAP_N_STAGES = 4
 LF_MSG_DETECTOR, LF_MSG_GROUND, LF_MSG_FILTERED = 0, 1, 2
 (LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,
- LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS, LF_BUF_LSD_SCRATCH) = range(11)
+ LF_BUF_LSD_NORDER, LF_BUF_LBD_DX, LF_BUF_LBD_DY, LF_BUF_LSD_COUNTS, LF_BUF_LSD_SCRATCH, LF_BUF_LSD_NLOW) = range(12)
 
 # every symbol include/lanefront.h declares
 EXPORTS = (

@@ -1393,6 +1393,9 @@ extern "C" int lf_debug_fetch(lf_handle* h, int buffer_id, void* dst, size_t byt
         break;
     }
     case LF_BUF_LSD_COUNTS: src = h->d_counts; avail = n * 3 * sizeof(int); break;
+    case LF_BUF_LSD_NLOW:
+        if (!h->d_nlow) { memset(dst, 0, bytes < n * 3 * sizeof(int) ? bytes : n * 3 * sizeof(int)); return LF_OK; }
+        src = h->d_nlow; avail = n * 3 * sizeof(int); break;
     case LF_BUF_LSD_SCRATCH: src = h->d_reg; avail = n * 3 * lsd_grow_reg_stride(h->lsd) * sizeof(uint32_t); break;
     default: lf_set_error(h, LF_ERR_BAD_ARG, "unknown buffer id %d", buffer_id); return LF_ERR_BAD_ARG;
     }
