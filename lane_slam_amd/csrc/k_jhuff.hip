@@ -31,7 +31,10 @@
 namespace lf {
 
 constexpr int JH_T = 256;          // k_jh_unstuff
-constexpr int JH_TD = 1024;        // k_jh_decode: one thread per subsequence of a typical camera frame (~300)
+#ifndef LF_JH_THREADS
+#define LF_JH_THREADS 1024
+#endif
+constexpr int JH_TD = LF_JH_THREADS;        // k_jh_decode: one thread per subsequence of a typical camera frame (~300)
 constexpr int JH_LDS_CLEAN = 96 * 1024;     // scans up to this many clean bytes are decoded out of LDS
 #ifndef LF_JH_SB
 #define LF_JH_SB 48
