@@ -301,6 +301,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         for (uint32_t u = sub_first[g]; u < sub_first[g + 1]; ++u) u_seg[u] = (uint32_t)g;
     __syncthreads();
     int dummy_err = 0;
+    const long long jt0 = getenv_debug ? (long long)wall_clock64() : 0;     // (LF_JH_DEBUG: where a frame's time goes, x10 ns)
     // ---- pass 0: assumed entry states
     for (int u = t; u < n_sub; u += JH_T) {
         const int g = (int)u_seg[u];
@@ -314,6 +315,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
     }
     __syncthreads();
+    const long long jt1 = getenv_debug ? (long long)wall_clock64() : 0;
     // ---- until every subsequence starts from what its predecessor hands over
     for (int pass = 0; pass < n_sub + 1; ++pass) {
         for (int u = t; u < n_sub; u += JH_T) {
@@ -346,6 +348,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         __syncthreads();
         if (!any) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d redone %d passes %d\n", f, n_sub, s_redo, pass + 1); break; }
     }
+    const long long jt2 = getenv_debug ? (long long)wall_clock64() : 0;
     // ---- blocks completed before every subsequence (exclusive prefix over the frame's subsequences)
     if (t == 0) s_carry = 0;
     __syncthreads();
@@ -364,6 +367,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         if (t == JH_T - 1) s_carry = off + inc;
         __syncthreads();
     }
+    const long long jt3 = getenv_debug ? (long long)wall_clock64() : 0;
     // ---- the decode that counts: coefficients out, a sequential decoder's checks
     int16_t* coef = coef_all + (size_t)F.coef_base * 64;
     int err = 0;
@@ -391,6 +395,8 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
     if (err) atomicOr(&s_err, err);
     __threadfence_block();
     __syncthreads();
+    const long long jt4 = getenv_debug ? (long long)wall_clock64() : 0;
+    if (getenv_debug && t == 0) printf("frame %d: pass 0 %lld, passes %lld, prefix %lld, final decode %lld (x10 ns)\n", f, jt1 - jt0, jt2 - jt1, jt3 - jt2, jt4 - jt3);
     if (t == 0) {
         I->n_sub = n_sub;
         I->err = s_err;
