@@ -170,7 +170,9 @@ LF_API int lf_process_batch(lf_handle* h, const uint8_t* frames, int n_frames, i
  * returns at once (device outputs only); lf_wait blocks until it is done and returns the
  * segment count.  Several handles used in turn keep as many independent batches in flight, which
  * lets one batch's latency-bound LSD region growing overlap the next batch's streaming
- * kernels.  One batch in flight per handle. */
+ * kernels.  One batch in flight per handle.  Device frames and the out_dev arrays must stay valid and unchanged until lf_wait
+ * returns: when a batch needs longer per-problem lists than the handle holds, lf_wait grows them and runs the batch a second
+ * time from the same inputs into the same outputs (lf_lsd_list_capacity). */
 LF_API int lf_process_batch_async(lf_handle* h, const uint8_t* frames, int n_frames, int frames_on_device,
                            lf_segments* out_dev, int describe);
 LF_API int lf_wait(lf_handle* h, int* n_segments);
