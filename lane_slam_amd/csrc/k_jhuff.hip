@@ -167,13 +167,17 @@ __device__ __forceinline__ int jh_code(const jpeg::HuffDev& h, uint32_t w, int& 
 {
     const uint32_t e = h.fast[w >> 23];
     if (e) { sym = (int)(e & 255u); return (int)(e >> 8); }
+    // codes of 10 .. 16 bits: the SHORTEST length whose prefix is a code.  All seven limits are fetched at once (the loop with an early
+    // exit was a chain of up to seven dependent LDS trips, and with 64 lanes on different symbols some lane of a wave takes this path
+    // at nearly every step)
     const int code16 = (int)(w >> 16);
-    for (int len = 10; len <= 16; ++len) {
-        const int c = code16 >> (16 - len);
-        if (c <= h.maxcode[len]) { sym = (int)h.vals[(c + h.delta[len]) & 255]; return len; }
-    }
+    int len = 0;
+#pragma unroll
+    for (int l = 16; l >= 10; --l)
+        if ((code16 >> (16 - l)) <= h.maxcode[l]) len = l;
     sym = 0;
-    return 0;
+    if (len) sym = (int)h.vals[((code16 >> (16 - len)) + h.delta[len]) & 255];
+    return len;
 }
 
 struct JhState { uint32_t bit; int blk, k; };     // next symbol starts at `bit`; block `blk` of the MCU; coefficient k (0: DC code next)
