@@ -42,6 +42,14 @@
 // insertion sort is a stable counting sort by bin of the seeds in E' order.  tools/probe/seed_sparse_proto.cpp is the same chain
 // written for the host and checked against the real std::sort (3 000 random arrays + the bins of lane / clutter / camera frames).
 //
+// TWO KERNELS per batch since the second half of round 5 (one workgroup per problem in each): k_lsd_seed32 builds the list and runs the chain
+// -- the planes need 42 KB of LDS at 511 x 255 and the batched selects 168 registers --, k_lsd_seed32_dense works off the dense ranges and
+// runs the final passes with 28 KB and 94 registers; the dense array and the chain's result (elements used, ranges) wait in global memory
+// in between.  As one kernel every problem held the larger footprint of both phases for the whole 0.45 ms, and in a pipeline whose SIMDs are
+// full of region-growing waves a stage costs its registers and LDS times its duration (123 k -> 129 k frames/s).
+// The dense phase exists in two forms: the wave form (default) and the level-synchronous block engine (-DLF_SEED_ENGINE=1: faster alone,
+// slower in the pipeline; tools/seed_engine_ab.sh).
+//
 // One workgroup per problem (frame, colour).  Elements are u32: bin << 20 | payload (compact index + 1 of a pixel with a
 // defined gradient, 0 for the others: only seeds need to be told apart).  A RANGE WITHOUT A SEED IS NEVER PARTITIONED: the loop
 // only permutes a range within itself, so what it does to a range that holds no seed cannot be seen in the result.
