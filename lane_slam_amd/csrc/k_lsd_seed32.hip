@@ -98,7 +98,7 @@ constexpr int SW = ST / 64;
 #define LF_SEED_ENGINE 0
 #endif
 #ifndef LF_SEED_DENSE_THREADS
-#define LF_SEED_DENSE_THREADS (LF_SEED_ENGINE ? 512 : 256)
+#define LF_SEED_DENSE_THREADS (LF_SEED_ENGINE ? 512 : 256)      // (wave form with two waves per problem: - 1.5 % in the pipeline; with one: does not run)
 #endif
 #ifndef LF_SEED_DENSE_OCC
 #define LF_SEED_DENSE_OCC (LF_SEED_ENGINE ? 2 : 4)      // waves per SIMD the register allocation must allow
