@@ -13,7 +13,7 @@ LF_TIE_SHAPE=small python tools/assoc_rate.py --tie-rule mihasher --pairs 4096x5
 # round 5: the A/B options beside the defaults (opencv32 + mihasher), same call
 for ab in "opencv32 lowest" "opencv30 mihasher" "opencv30 lowest"; do set -- $ab; python bench.py --steps 100 --secondary none --cpu-frames -1 --seed-order $1 --tie-rule $2 > $R/gpurun_out/$T/bench_ab_$1_$2.json 2>/dev/null; done
 python bench.py --geometry hd --steps 30 --secondary none --cpu-frames -1 > $R/gpurun_out/$T/bench_hd.json 2>/dev/null
-if [ -f lane_slam_amd/liblanefront_sstamps.so ]; then LANEFRONT_LIBRARY=$R/lane_slam_amd/liblanefront_sstamps.so python tools/_seedstamps.py > $R/gpurun_out/$T/seed_stamps.txt 2>&1; fi
+if [ -f lane_slam_amd/liblanefront_sstamps.so ]; then LANEFRONT_LIBRARY=$R/lane_slam_amd/liblanefront_sstamps.so python tools/seed_stamps.py > $R/gpurun_out/$T/seed_stamps.txt 2>&1; fi
 LF_ALLOC_TRACE=1 python tools/handle_footprint.py 2> $R/gpurun_out/$T/handle_footprint.txt
 bash tools/whatif_round.sh > $R/gpurun_out/$T/whatif.txt 2>&1
 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1

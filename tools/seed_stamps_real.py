@@ -1,3 +1,4 @@
+"""The same as tools/seed_stamps.py on two of the real camera frames (tests/golden/real_jpegs.npz)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
