@@ -194,30 +194,31 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
     int done = 0;
     uint32_t bit = st.bit;
     int blk = st.blk, k = st.k;
-    // The stream goes through a 64-bit buffer in registers, the next dword always on its way: a symbol's only dependent
-    // trip to LDS is its code-table lookup (a fresh three-dword look per symbol was two trips in a row, ~500 cycles per symbol).
-    // buf: the next `cnt` bits of the stream, left-aligned; nd: the dword that `nextw` holds (clamped to the interval's
-    // last dword + 1: reads never go past what the interval owns plus one dword, as before).
+    // The stream goes through two dwords in registers (wcur, wnxt: big-endian order restored) and a bit offset sh into wcur, the dword
+    // after them always on its way (pre: raw, its bytes are swapped when it moves up -- swapping at the load made every refill wait
+    // for it): a symbol's only dependent trip to LDS is its code-table lookup, and the look at the next 32 bits is one funnel shift
+    // (round 5; a 64-bit left-aligned buffer before: two quarter-rate 64-bit shifts per symbol).  nd: the dword `pre` holds (clamped
+    // to the interval's last dword + 1: reads never go past what the interval owns plus one dword, as before).
     const uint32_t* p = reinterpret_cast<const uint32_t*>(clean);
     const uint32_t dmax = (end_bit >> 5) + 1u;
     uint32_t nd = bit >> 5;
-    auto fetch = [&](uint32_t d) { const uint32_t dc_ = d < dmax ? d : dmax; return __builtin_bswap32(p[PAD ? dc_ + (dc_ >> 5) : dc_]); };
-    uint64_t buf = ((uint64_t)fetch(nd) << 32) | (uint64_t)fetch(nd + 1);
-    buf <<= (bit & 31u);
-    int cnt = 64 - (int)(bit & 31u);
+    auto fetch = [&](uint32_t d) { const uint32_t dc_ = d < dmax ? d : dmax; return p[PAD ? dc_ + (dc_ >> 5) : dc_]; };
+    uint32_t wcur = __builtin_bswap32(fetch(nd)), wnxt = __builtin_bswap32(fetch(nd + 1));
+    uint32_t sh = bit & 31u;
     nd += 2;
-    uint32_t nextw = fetch(nd);
-    // the tables of the current block: DC and AC table of its component
+    uint32_t pre = fetch(nd);
+    // the tables of the current block: DC and AC table of its component (their addresses change with the block, not with the symbol)
     int comp = blk < sel.luma ? 0 : blk - sel.luma + 1;
-    int tdc = (int)((sel.tsel >> (4 * comp)) & 15u), tac = (int)((sel.tsel >> (4 * comp + 12)) & 15u);
+    const jpeg::HuffDev* hdc = &tabs.t[(sel.tsel >> (4 * comp)) & 15u];
+    const jpeg::HuffDev* hac = &tabs.t[(sel.tsel >> (4 * comp + 12)) & 15u];
     while (bit < limit) {
         if (WRITE && cur >= end_block) break;
         // one symbol = one Huffman code + its magnitude bits (at most 16 + 15 bits: one 32-bit look).  DC and AC share the
         // path: DC is "run 0, size = the symbol" (T.81 F.2.2.1), AC "run = high nibble, size = low nibble" with EOB / ZRL
         const bool dc = k == 0;
-        const uint32_t w = (uint32_t)(buf >> 32);
+        const uint32_t w = sh ? __builtin_amdgcn_alignbit(wcur, wnxt, 32u - sh) : wcur;      // the next 32 bits
         int sym;
-        const int len = jh_code(tabs.t[dc ? tdc : tac], w, sym);
+        const int len = jh_code(*(dc ? hdc : hac), w, sym);
         const int run = dc ? 0 : sym >> 4, sz = dc ? sym : sym & 15;
         const int kn = k + run;
         const bool bad = len == 0 || (dc && sym > 11) || (!dc && sz != 0 && kn > 63);
@@ -234,13 +235,13 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
             k = (!dc && sz == 0) ? (run == 15 ? k + 16 : 64) : kn + 1;           // ZRL / EOB / a coefficient
         }
         bit += (uint32_t)n;
-        buf <<= n;
-        cnt -= n;
-        if (cnt <= 32) {
-            buf |= (uint64_t)nextw << (32 - cnt);
-            cnt += 32;
+        sh += (uint32_t)n;                              // n <= 16 + 15: at most one dword moves up
+        if (sh >= 32u) {
+            sh -= 32u;
+            wcur = wnxt;
+            wnxt = __builtin_bswap32(pre);
             ++nd;
-            nextw = fetch(nd);
+            pre = fetch(nd);
         }
         if (bad) continue;
         if (WRITE && bit > end_bit) { err |= 4; break; }                      // bits that are not in the interval were consumed
@@ -249,7 +250,7 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
             blk = blk + 1 == sel.bpm ? 0 : blk + 1;
             ++done; ++cur;
             comp = blk < sel.luma ? 0 : blk - sel.luma + 1;
-            tdc = (int)((sel.tsel >> (4 * comp)) & 15u); tac = (int)((sel.tsel >> (4 * comp + 12)) & 15u);
+            hdc = &tabs.t[(sel.tsel >> (4 * comp)) & 15u]; hac = &tabs.t[(sel.tsel >> (4 * comp + 12)) & 15u];
         }
     }
     st.bit = bit; st.blk = blk; st.k = k;
