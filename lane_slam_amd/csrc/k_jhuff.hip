@@ -257,7 +257,9 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
     return done;
 }
 
-struct JhShared { JhTabs tabs; int s_changed, s_redo, s_err, s_nsub, s_wsum[JH_TD / 64], s_carry; int s_dc[JH_TD / 64][4], s_dcc[JH_TD / 64 + 1][3]; };
+constexpr int JH_DL = 2048;         // subsequences of a frame the dirty list of a correction pass holds (a 96 KB scan: what fits LDS)
+struct JhShared { JhTabs tabs; int s_changed, s_redo, s_err, s_nsub, s_wsum[JH_TD / 64], s_carry; int s_dc[JH_TD / 64][4], s_dcc[JH_TD / 64 + 1][3];
+                  int s_nd; uint16_t s_dlist[JH_DL]; };
 
 // LDS = true: the clean scan sits in jh_dyn (the compiler sees an LDS address: ds_read instead of flat loads)
 template <bool LDS>
@@ -322,6 +324,52 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
     __syncthreads();
     const long long jt1 = getenv_debug ? (long long)wall_clock64() : 0;
     // ---- until every subsequence starts from what its predecessor hands over
+    if (n_sub <= JH_DL) {
+        // The subsequences a pass has to decode again are COMPACTED first (round 5): after the first two or three passes they are a few
+        // dozen, scattered over all sixteen waves -- and a wave with one live lane issues the symbol loop's ~100 instructions per symbol
+        // like a full one, four such waves to a SIMD.  Listed densely they keep one or two waves busy, one per SIMD.
+        for (int pass = 0; pass < n_sub + 1; ++pass) {
+            if (t == 0) sh.s_nd = 0;
+            __syncthreads();
+            for (int u0 = 0; u0 < n_sub; u0 += JH_T) {
+                const int u = u0 + t;
+                bool dirty = false;
+                if (u < n_sub) {
+                    const int g = (int)u_seg[u];
+                    if ((uint32_t)u != sub_first[g]) {
+                        const uint32_t cb = u_xbit[u - 1], cp = u_xph[u - 1];
+                        dirty = !(cb == u_ebit[u] && cp == u_eph[u]);
+                        if (dirty) { u_cbit[u] = cb; u_cph[u] = cp; }
+                    }
+                }
+                const unsigned long long bm = __ballot(dirty);
+                if (bm != 0ull) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&sh.s_nd, __popcll(bm));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (dirty) sh.s_dlist[base + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)u;
+                }
+            }
+            __syncthreads();
+            const int n_dirty = sh.s_nd;
+            if (n_dirty == 0) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d redone %d passes %d\n", f, n_sub, s_redo, pass + 1); break; }
+            if (getenv_debug && t == 0) s_redo += n_dirty;
+            for (int j = t; j < n_dirty; j += JH_T) {
+                const int u = (int)sh.s_dlist[j];
+                const int g = (int)u_seg[u];
+                const uint32_t cb = u_cbit[u], cp = u_cph[u];
+                const uint32_t local = (uint32_t)u - sub_first[g];
+                const uint32_t start = (sb[g] + local * JH_SB) * 8u, seg_end = sb[g + 1] * 8u;
+                uint32_t limit = start + JH_SB * 8u;
+                if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
+                JhState st; st.bit = cb; st.blk = (int)(cp >> 8); st.k = (int)(cp & 255u);
+                u_ebit[u] = cb; u_eph[u] = cp;
+                const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
+                u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
+            }
+            __syncthreads();
+        }
+    } else
     for (int pass = 0; pass < n_sub + 1; ++pass) {
         for (int u = t; u < n_sub; u += JH_T) {
             const int g = (int)u_seg[u];
