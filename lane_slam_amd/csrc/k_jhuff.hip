@@ -203,8 +203,11 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
     const uint32_t dmax = (end_bit >> 5) + 1u;
     uint32_t nd = bit >> 5;
     auto fetch = [&](uint32_t d) { const uint32_t dc_ = d < dmax ? d : dmax; return p[PAD ? dc_ + (dc_ >> 5) : dc_]; };
-    uint32_t wcur = __builtin_bswap32(fetch(nd)), wnxt = __builtin_bswap32(fetch(nd + 1));
+    // sh = bits of wcur already consumed, kept in 1 .. 32 (32: wcur is used up and the look is wnxt itself), so that the look is ONE
+    // v_alignbit_b32 without a special case: a stream position on a dword boundary starts with wcur = nothing, wnxt = that dword
     uint32_t sh = bit & 31u;
+    if (sh == 0u) { sh = 32u; --nd; }
+    uint32_t wcur = sh == 32u ? 0u : __builtin_bswap32(fetch(nd)), wnxt = __builtin_bswap32(fetch(nd + 1));
     nd += 2;
     uint32_t pre = fetch(nd);
     // the tables of the current block: DC and AC table of its component (their addresses change with the block, not with the symbol)
@@ -216,7 +219,7 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
         // one symbol = one Huffman code + its magnitude bits (at most 16 + 15 bits: one 32-bit look).  DC and AC share the
         // path: DC is "run 0, size = the symbol" (T.81 F.2.2.1), AC "run = high nibble, size = low nibble" with EOB / ZRL
         const bool dc = k == 0;
-        const uint32_t w = sh ? __builtin_amdgcn_alignbit(wcur, wnxt, 32u - sh) : wcur;      // the next 32 bits
+        const uint32_t w = __builtin_amdgcn_alignbit(wcur, wnxt, 32u - sh);      // the next 32 bits (sh = 32: a shift by 0 = wnxt)
         int sym;
         const int len = jh_code(*(dc ? hdc : hac), w, sym);
         const int run = dc ? 0 : sym >> 4, sz = dc ? sym : sym & 15;
@@ -236,7 +239,7 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
         }
         bit += (uint32_t)n;
         sh += (uint32_t)n;                              // n <= 16 + 15: at most one dword moves up
-        if (sh >= 32u) {
+        if (sh > 32u) {
             sh -= 32u;
             wcur = wnxt;
             wnxt = __builtin_bswap32(pre);
