@@ -62,3 +62,34 @@ def test_batch_handles_start_with_an_eighth_of_the_image():
     n = int(seg.frame_offset[-1])
     assert fe.lsd_list_capacity() == (entries, 0) and n > 0          # lane frames fit
     fe.close()
+
+
+def test_camera_frames_with_the_default_capacity_equal_whole_image_lists():
+    """The 28 camera frames of tests/golden/real_jpegs.npz through a batch handle that starts with the default eighth of the LSD
+    image per problem (camera colours have two to three times a lane frame's defined pixels; whether the lists grow is reported, not
+    required) against a handle with whole-image lists."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    zj = np.load(os.path.join(here, "golden", "real_jpegs.npz"))
+    streams = [bytes(zj["jpeg%02d" % k]) for k in range(len(zj["names"]))]
+    cfg = default_config("fullres")
+    fe0 = FrontEnd(cfg, max_frames=len(streams))
+    rf, st = fe0.decode_jpeg_batch(streams, n_threads=4)
+    fe0.close()
+    frames = np.stack([rf[k] for k in range(len(streams)) if st[k] == 0 and rf[k].shape == (480, 640, 3)])
+    assert frames.shape[0] > 16                                        # a batch handle: more than 16 frames
+    want, cap_full = _run(cfg, frames, "full")
+    old = os.environ.pop("LF_LSD_RECORDS", None)
+    try:
+        fe = FrontEnd(cfg, max_frames=frames.shape[0])
+        start = fe.lsd_list_capacity()
+        seg = fe.process_batch(frames, describe=True)
+        end = fe.lsd_list_capacity()
+        fe.close()
+    finally:
+        if old is not None:
+            os.environ["LF_LSD_RECORDS"] = old
+    assert start[0] * 7 < cap_full[0] and end[0] >= start[0]
+    assert np.array_equal(np.array(seg.frame_offset), want[0]["frame_offset"])
+    for k in FIELDS + ("code",):
+        assert np.array_equal(np.array(getattr(seg, k)), want[0][k]), k
+    print("camera frames: lists of %d entries at the start, %d at the end (%d growths)" % (start[0], end[0], end[1]))
