@@ -160,8 +160,14 @@ def main():
     free0, _total_b = torch.cuda.mem_get_info(local_rank)
     fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap)]
     handle_bytes = max(1, free0 - torch.cuda.mem_get_info(local_rank)[0])
+    # ... and budgeted as GROWN: the lists of a handle that meets busier content are reallocated larger by lf_wait (camera frames: 2.75 x;
+    # 102 bytes per list entry and problem) -- room for a fourfold growth of every handle, so that a growth in the
+    # middle of a run does not meet a device filled to the brim by handles sized before any growth
+    S0 = fes[0].lsd_list_capacity()[0]
+    grown_bytes = handle_bytes + 102 * 3 * B * max(0, min(fes[0].lsd_rows * fes[0].lsd_cols, 4 * S0) - S0)
     if args.depth == 0:
-        D = max(2, min(D, 1 + int((0.85 * free0 - handle_bytes) // handle_bytes)))
+        D = max(2, min(D, int((0.85 * free0) // grown_bytes)))
+    args.handle_bytes, args.grown_bytes = handle_bytes, grown_bytes          # (secondary(): the content rows add handles)
     fes += [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap) for _ in range(D - 1)]
     fe = fes[0]
     P = fe.rows * fe.cols
@@ -599,6 +605,9 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
         # problems, more batches in flight fill the machine; the extra handles are created once and kept for the other rows
         want = max(D, fes[0].suggested_depth()) if args.depth == 0 else D
         while len(fes) + len(extra["fes"]) < want:
+            if torch.cuda.mem_get_info(device_id)[0] < 2 * args.grown_bytes + (len(fes) + len(extra["fes"])) * (args.grown_bytes - args.handle_bytes):
+                want = len(fes) + len(extra["fes"])          # no room for one more handle AND the growth of those that exist
+                break
             extra["fes"].append(FrontEnd(fes[0].cfg, device=device_id, max_frames=B, max_lines_per_color=args.cap))
             o_ = alloc_out(torch, dev, B, cap)
             extra.setdefault("outs", []).append(o_)

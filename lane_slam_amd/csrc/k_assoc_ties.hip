@@ -113,6 +113,7 @@ __device__ __forceinline__ void assoc_ties_body(const uint8_t* __restrict__ q, c
     __shared__ int s_qid[TQW];
     __shared__ int2 s_hits[THCAP];
     __shared__ int s_nh;
+    __shared__ int s_flush[2];            // "flush after the next group", written by thread 0 alone (see group())
     __shared__ int s_items[129];          // items in front of chunk c (splits <= 128)
     __shared__ int s_wsum[4];
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
@@ -120,7 +121,7 @@ __device__ __forceinline__ void assoc_ties_body(const uint8_t* __restrict__ q, c
     const int r32 = lane & 31, half = lane >> 5;
     int* s_pfx = reinterpret_cast<int*>(tiles_b);          // the current chunk's running piece counts: n_pieces + 1 words, gone before tiles_b is filled
     xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
-    if (threadIdx.x == 0) s_nh = 0;
+    if (threadIdx.x == 0) { s_nh = 0; s_flush[0] = 0; s_flush[1] = 0; }
     // ---- the items: chunk c has ceil(listed(c) / 256) slabs x subs pieces
     for (int c = wave; c < splits; c += 4) {               // one wave per chunk adds its counts up
         int tot = 0;
@@ -139,7 +140,7 @@ __device__ __forceinline__ void assoc_ties_body(const uint8_t* __restrict__ q, c
         const int n = min(s_nh, THCAP);
         if ((int)threadIdx.x < n) { const int2 hpair = s_hits[threadIdx.x]; tie_eval(q, mcode, qcolor, mcolor, GATED, hpair.x, hpair.y, res); }
         __syncthreads();
-        if (threadIdx.x == 0) s_nh = 0;
+        if (threadIdx.x == 0) { s_nh = 0; s_flush[0] = 0; s_flush[1] = 0; }
         __syncthreads();
     };
     for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -263,8 +264,14 @@ __device__ __forceinline__ void assoc_ties_body(const uint8_t* __restrict__ q, c
                     }
                 }
             }
+            // Flush when the stage is half full -- decided by ONE thread and acted on a group later.  (s_nh itself cannot be the
+            // condition: a fast wave is already adding the next group's candidates while a slow one reads it here, the branch would
+            // not be uniform and flush()'s barriers would pair up with the wrong ones.)  Thread 0 writes s_flush[g & 1] behind this
+            // barrier; everybody reads it behind the NEXT group's barrier, and it is not written again before the one after that.
+            // A stage that fills up in between evaluates on the spot (above), so the delay costs time only.
             __syncthreads();
-            if (s_nh > THCAP / 2) flush();                                      // (uniform: read after the barrier)
+            if (s_flush[(g + 1) & 1]) flush();
+            if (threadIdx.x == 0) s_flush[g & 1] = s_nh > THCAP / 2;
         };
         for (int g = 0; g < n_groups; g += 2) {
             group(g, tiles_a, tiles_b);

@@ -1398,7 +1398,10 @@ __global__ __launch_bounds__(256) void k_kl_mask_flags(const int* __restrict__ f
         bool fails = false;
         if (j < n) {
             const float* e = start_end + 4 * (size_t)(base + j);
-            fails = mk[(size_t)(int)e[1] * cols + (int)e[0]] == 0 && mk[(size_t)(int)e[3] * cols + (int)e[2]] == 0;
+            // (clamped into the mask: a KeyLine end on the last row / column of an odd-sized image may round to rows / cols)
+            const int sx = min(max((int)e[0], 0), cols - 1), sy = min(max((int)e[1], 0), rows - 1);
+            const int ex = min(max((int)e[2], 0), cols - 1), ey = min(max((int)e[3], 0), rows - 1);
+            fails = mk[(size_t)sy * cols + sx] == 0 && mk[(size_t)ey * cols + ex] == 0;
         }
         int lg = (j < n && !fails) ? j : -1;                                // inclusive prefix maximum over the chunk
 #pragma unroll

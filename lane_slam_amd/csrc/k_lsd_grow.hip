@@ -156,7 +156,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     c.label = c_label + (size_t)pc * p.rec_cap;
     c.tags = tt; c.line_count = &line_count;
 #ifdef LFG_STAMPS
-    for (int k = 0; k < 24; ++k) c.stamps[k] = 0;
+    for (int k = 0; k < 32; ++k) c.stamps[k] = 0;
     unsigned long long tb0 = __builtin_readcyclecounter();
 #endif
     // components largest first (k_lsd_label sorted them), next one to whichever wave is free
@@ -200,7 +200,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     if (lane == 0) {
         // diagnostic: park the phase totals of every wave in the (otherwise unused) tail of the region scratch
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reg + (size_t)pc * reg_stride + reg_stride - 64 * GROW_WAVES) + 32 * wave;   // 32 u64 per wave
-        for (int k = 0; k < 24; ++k) dbg[k] = c.stamps[k];
+        for (int k = 0; k < 32; ++k) dbg[k] = c.stamps[k];
         dbg[24] = __builtin_readcyclecounter() - tb0;
         dbg[25] = (unsigned long long)norder[pc];
         dbg[26] = (unsigned long long)n_comp;

@@ -53,6 +53,7 @@ struct lf_handle {
     // geometry
     int Hc = 0, W = 0, Hs = 0, Ws = 0, Ww = 0;
     size_t P = 0, Ps = 0;
+    bool lists_lost = false;     // lsd_grow_lists ran out of memory twice: no per-problem lists, run_detect refuses
     int label_items_full = 0;    // LsdParams::label_items of a handle whose lists hold whole images (alloc_lsd_lists lowers it with rec_cap)
     PreParams pre;
     CannyParams canny;
@@ -651,6 +652,7 @@ extern "C" int lf_synchronize(lf_handle* h)
 static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_working_image)
 {
     hipStream_t s = h->stream;
+    if (h->lists_lost) { lf_set_error(h, LF_ERR_HIP, "the handle lost its LSD lists to an out-of-memory growth (lf_wait / lf_set_image reported it)"); return LF_ERR_HIP; }
     h->overflow_zeroed = false;          // (set at the successful END only: an error exit must not leave run_segments believing the overflow words are zero)
     PreParams pp = h->pre;
     if (from_working_image) {
@@ -785,9 +787,18 @@ static int lsd_grow_lists(lf_handle* h, int need)
     size_t cap = ((size_t)need + (size_t)need / 4 + 4095) / 4096 * 4096;
     if (cap > h->Ps) cap = h->Ps;
     if (alloc_trace()) fprintf(stderr, "lanefront: a problem needs %d list entries, the handle holds %d: growing to %zu\n", need, h->lsd.rec_cap, cap);
+    const int old_cap = h->lsd.rec_cap;
     free_lsd_lists(h);
-    ++h->lists_grown;
-    return alloc_lsd_lists(h, (int)cap);
+    int rc = alloc_lsd_lists(h, (int)cap);
+    if (rc == LF_OK) { ++h->lists_grown; h->lists_lost = false; return LF_OK; }
+    // Out of memory part way: never leave the handle with null lists behind a capacity that says otherwise (the next batch would launch
+    // the LSD kernels on them -- a GPU fault, not an error code).  Back to the capacity that did fit; when even that fails now, the
+    // handle refuses every later detect call (lists_lost) until a growth succeeds.
+    free_lsd_lists(h);
+    if (alloc_lsd_lists(h, old_cap) != LF_OK) { free_lsd_lists(h); h->lsd.rec_cap = old_cap; h->lists_lost = true; }
+    lf_set_error(h, LF_ERR_HIP, "out of device memory growing the LSD lists from %d to %zu entries per problem%s", old_cap, cap,
+                 h->lists_lost ? "; the lists are gone: the handle refuses detection" : "; the handle keeps its old lists");
+    return LF_ERR_HIP;
 }
 
 extern "C" int lf_wait(lf_handle* h, int* n_segments)

@@ -120,7 +120,15 @@ LFG_DEV int wave_max_i(int v)
     return max(a, b);
 }
 LFG_DEV void mem_fence() { __threadfence_block(); }
+// A condition that is the same in every lane, said so: computed from values that live in vector registers (a double compared with a
+// double) it counts as divergent for the compiler, and a loop that can be left through it becomes a loop over an exec mask -- every value
+// it carries (the region size, the phase) moves to vector registers, every inner loop bound becomes a vector compare, every exit a chain
+// of mask operations (13 cycles per dependent scalar instruction for a wave alone on its SIMD, tools/probe/lone_wave_issue.hip).
+LFG_DEV bool uni(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+LFG_DEV int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 #else
+LFG_DEV bool uni(bool b) { return b; }
+LFG_DEV int uni_i(int v) { return v; }
 LFG_DEV int wave_max_i(int v) { return v; }
 LFG_DEV int lane_id() { return 0; }
 LFG_DEV int rl_i(int v, int) { return v; }
@@ -216,7 +224,7 @@ struct Ctx {
     int* pend_n;              // LDS  entries appended so far (may pass pend_cap: the evaluation kernel reports it)
     int pend_cap;
 #if defined(LFG_STAMPS) && !defined(LF_HOST_SIM)
-    mutable unsigned long long stamps[24];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
+    mutable unsigned long long stamps[32];  // 0 seed scan, 1 grow, 2 rect, 3 refine, 4 nfa scan, 5 nfa math, 6 emit, 7 nfa calls/px,
                                             // 8 seed fetch, 9 regions, 10 region points, 11 grow batches
 #endif
 };
@@ -372,8 +380,8 @@ LFG_DEV bool aligned_val(double a, double theta, double prec)
 LFG_DEV double angle_diff_signed(double a, double b)
 {
     double diff = a - b;
-    while (diff <= -PI_) diff += M_2__PI_;
-    while (diff > PI_) diff -= M_2__PI_;
+    while (uni(diff <= -PI_)) diff += M_2__PI_;          // (every caller's operands are wave-uniform)
+    while (uni(diff > PI_)) diff -= M_2__PI_;
     return diff;
 }
 LFG_DEV double dabs(double v) { return v < 0 ? -v : v; }
@@ -566,6 +574,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             const int L = maskM ? __builtin_ctzll(maskM) : 64;
             const unsigned long long span = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
             const unsigned long long maskN = nearM & cb & span;
+            LFG_CNT(c, 27, 1) LFG_CNT(c, 28, (maskN == 0ull && L < 64)) LFG_CNT(c, 30, (maskN & (maskN - 1ull)) != 0ull)
             if (maskN != 0ull) {
                 // first offer wins inside the span: walk the near lanes in order, each new pixel strikes its later offers
                 unsigned long long maskA = maskN;
@@ -618,7 +627,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 candm &= ~lfg_ballot(e == eL);            // the same pixel seen from a later point is now USED
                 added = true;
                 LFG_CNT(c, 19, 1)
-            }
+            } else { LFG_CNT(c, 29, 1) }
             later = L >= 63 ? 0ull : (~0ull << (L + 1));
         }
         if (added) mem_fence();
@@ -654,6 +663,45 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
     reg_size = n;
 }
 
+#ifndef LF_HOST_SIM
+// Three ORDERED f64 sums at once: s0 += t0[0] + t0[1] + ..., s1 += t1[..], s2 += t2[..] (left to right, term j held by lane j, cnt <= 64
+// terms), the running sums in lanes 0, 1, 2 of `acc`.  The terms are first dealt out so that lane 3 j + L holds term j of sum L (21 terms
+// per deal: three ds_bpermute per sum), then step j is ONE v_add_f64 whose operand lanes 0 .. 2 fetch from lanes 3 j .. 3 j + 2 (a
+// ds_bpermute with the lane's own address + a constant: the LDS crossbar, no LDS memory, nothing on the chain but the addition).  Terms
+// past cnt are -0.0, which x + (-0.0) == x leaves alone for every x, so the steps come in straight-line groups of seven without a count
+// in the loop.  Before: v_readlane x 2 per term and sum, a scalar counter, a compare and a branch per term -- 12 instructions and ~100
+// cycles per region point and pass for a wave alone on its SIMD; region2rect was 13 % of the longest growing wave's time.
+LFG_DEV double bperm_d(int addr, double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xffffffffll));
+    const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+LFG_DEV void ordered_sums3(double& acc, double t0, double t1, double t2, int cnt)
+{
+    const int lane = lane_id();
+    const int third = lane / 3, rem = lane - 3 * third;
+    if (lane >= cnt) { t0 = -0.0; t1 = -0.0; t2 = -0.0; }
+    for (int sb = 0; sb * 21 < cnt; ++sb) {                  // (cnt is wave-uniform: scalar loops)
+        const int p = third + 21 * sb;                        // the term this lane is dealt
+        const double a0 = bperm_d(p << 2, t0), a1 = bperm_d(p << 2, t1), a2 = bperm_d(p << 2, t2);
+        double T = rem == 0 ? a0 : (rem == 1 ? a1 : a2);
+        if (p > 63) T = -0.0;                                 // (the address wraps: term 64 is not term 0)
+        for (int j0 = 0; j0 < 21; j0 += 7) {
+            if (21 * sb + j0 >= cnt) break;
+            // (all seven fetches in flight, then the seven additions: left to itself the compiler waits for each fetch in turn)
+            double u[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) u[j] = bperm_d((lane + 3 * (j0 + j)) << 2, T);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc += u[j];
+        }
+    }
+}
+#endif
+
 // ------------------------------------------------------------------ region2rect
 // LO (device build): the whole region list is in its LDS part (reg_size <= reg_lds, nearly always): plain LDS reads (reg_get_t).
 // The ordered f64 sums take their terms from lane registers in list order; the products that go into them do not depend on the
@@ -673,6 +721,9 @@ LFG_DEV void region2rect_t(const Ctx& c, int reg_size, double reg_angle, double 
     // (most regions are shorter than that: one row search + one trip to the magnitudes instead of two)
     uint32_t pk0 = 0u;
     double w0 = 0.0;
+#ifndef LF_HOST_SIM
+    double acc = 0.0;                                        // lanes 0, 1, 2: the three running sums (ordered_sums3)
+#endif
     for (int base = 0; base < reg_size; base += LFG_NL) {
         const int i = base + lane;
         const bool v = i < reg_size;
@@ -681,12 +732,20 @@ LFG_DEV void region2rect_t(const Ctx& c, int reg_size, double reg_angle, double 
         if (base == 0) { pk0 = pk; w0 = w; }
         const double xw = (double)(int)(pk & 0xffffu) * w, yw = (double)(int)(pk >> 16) * w;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
+#ifndef LF_HOST_SIM
+        ordered_sums3(acc, xw, yw, w, cnt);
+#else
         for (int j = 0; j < cnt; ++j) {
             x += rl_d(xw, j);
             y += rl_d(yw, j);
             sum += rl_d(w, j);
         }
+#endif
     }
+#ifndef LF_HOST_SIM
+    x = rl_d(acc, 0); y = rl_d(acc, 1); sum = rl_d(acc, 2);
+    acc = 0.0;
+#endif
     x /= sum;
     y /= sum;
     // get_theta
@@ -704,12 +763,19 @@ LFG_DEV void region2rect_t(const Ctx& c, int reg_size, double reg_angle, double 
         const double ddy = (double)(int)(pk >> 16) - y;
         const double tyy = ddy * ddy * w, txx = ddx * ddx * w, txy = ddx * ddy * w;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
+#ifndef LF_HOST_SIM
+        ordered_sums3(acc, tyy, txx, -txy, cnt);             // (Ixy -= t is Ixy += -t, bit for bit)
+#else
         for (int j = 0; j < cnt; ++j) {
             Ixx += rl_d(tyy, j);
             Iyy += rl_d(txx, j);
             Ixy -= rl_d(txy, j);
         }
+#endif
     }
+#ifndef LF_HOST_SIM
+    Ixx = rl_d(acc, 0); Iyy = rl_d(acc, 1); Ixy = rl_d(acc, 2);
+#endif
     const double lambda = 0.5 * (Ixx + Iyy - dm::dsqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (dabs(Ixx) > dabs(Iyy)) ? (double)dm::fast_atan2_deg((float)(lambda - Ixx), (float)Ixy)
                                            : (double)dm::fast_atan2_deg((float)Ixy, (float)(lambda - Iyy));
@@ -1496,13 +1562,14 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
                 region_grow(c, gx, gy, ge, reg_size, reg_angle, grow_prec);
 #endif
                 if (phase == 0) { LFG_T1(c, 1) LFG_CNT(c, 9, 1) LFG_CNT(c, 10, reg_size) } else { LFG_T1(c, 22) }
+                reg_size = uni_i(reg_size);
                 if (reg_size < (phase == 0 ? c.min_reg_size : 2)) { rejected = true; break; }
             }
             region2rect(c, reg_size, reg_angle, c.prec, c.p, rec);
             if (phase == 0) { LFG_T1(c, 2) } else { LFG_T1(c, 17) }
             if (c.refine <= 0) break;
             const double density = (double)reg_size / (dist_(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
-            if (density >= c.density_th) break;
+            if (uni(density >= c.density_th)) break;
             if (phase == 0) {
                 grow_prec = refine_tau(c, reg_size, rec, gx, gy, ge);
                 LFG_T1(c, 21)
@@ -1518,6 +1585,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
                 phase = 2;
             }
             reduce_radius_step(c, reg_size, xc, yc, radSq);
+            reg_size = uni_i(reg_size);
             LFG_T1(c, 23) LFG_CNT(c, 20, 0)
             if (reg_size < 2) { rejected = true; break; }
         }
@@ -1534,6 +1602,7 @@ LFG_DEV int detect(const Ctx& c, const uint32_t* order, int n_order, float* line
         // 16 x 60 k cycles behind) only ever means a short wait.
         if (c.refine >= 2) {
             while (!eval_push(c, rec, tag)) __builtin_amdgcn_s_sleep(16);
+            LFG_T1(c, 31)
             continue;
         }
         if (!evaluate_region<false>(c, rec, tag, lines, cap, n_lines)) { LFG_T1(c, 6) continue; }

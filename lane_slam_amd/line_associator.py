@@ -21,9 +21,11 @@ _WHEN_FULL = {"ring": 0, "error": 1}
 
 class LineAssociator(object):
     def __init__(self, capacity=65536, color_gating=False, max_distance=128, policy="append", kept_only=True,
-                 merge_distance=0, when_full="ring", device=0, tie_rule="mihasher"):
+                 merge_distance=0, when_full="ring", device=0, tie_rule=None):
         self.lib = _lib.load()
-        if tie_rule not in _lib.TIE_RULES:
+        # tie_rule=None: the library's default -- the reference's rule ("mihasher"), or "lowest" with the library's one warning under
+        # LF_ASSOC_INT8 (the int8 A/B kernels have no tie pass; an EXPLICIT "mihasher" there raises, as lf_map_set_tie_rule does)
+        if tie_rule is not None and tie_rule not in _lib.TIE_RULES:
             raise ValueError("tie_rule must be one of %r" % (sorted(_lib.TIE_RULES),))
         if policy not in _POLICY or when_full not in _WHEN_FULL:
             raise ValueError("policy must be 'append' or 'merge', when_full 'ring' or 'error'")
@@ -38,7 +40,8 @@ class LineAssociator(object):
             self.m = None
             from .frontend import LanefrontError
             raise LanefrontError(rc, msg)
-        self._check(self.lib.lf_map_set_tie_rule(self.m, _lib.TIE_RULES[tie_rule]))
+        if tie_rule is not None:
+            self._check(self.lib.lf_map_set_tie_rule(self.m, _lib.TIE_RULES[tie_rule]))
 
     def close(self):
         if getattr(self, "m", None):

@@ -44,16 +44,16 @@ if GW == 4:
     for w in worst:
         print("  problem %d evaluating wave: busy %.0f kcycles (scan %.0f + math %.0f) of %.0f, %d nfa calls" % (
             w, (raw[w, 3, 4] + raw[w, 3, 5]) / 1e3, raw[w, 3, 4] / 1e3, raw[w, 3, 5] / 1e3, tot_w[w, 3] / 1e3, raw[w, 3, 7] >> 40))
-d = raw[np.arange(n * 3), slow][:, :27].astype(np.float64)          # the slowest wave of every problem
+d = raw[np.arange(n * 3), slow][:, :32].astype(np.float64)          # the slowest wave of every problem
 names = ["seed", "grow", "rect", "refine", "nfa_scan", "nfa_math", "improve+emit", "-", "fetch", "regions", "reg_pts", "batches",
-         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "refine_rect", "bulk_acc", "exact_acc", "isolated_seeds", "refine_tau", "refine_regrow", "refine_reduce"] + ["total", "n_order", "n_comp"]
-CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 17, 21, 22, 23, 24}
+         "g_lookup", "g_fallback", "g_accept", "fallback_batches", "g_window", "refine_rect", "bulk_acc", "exact_acc", "isolated_seeds", "refine_tau", "refine_regrow", "refine_reduce"] + ["total", "n_order", "n_comp", "spans", "spans_pure_undecided", "undecided_rejected", "spans_dupwalk", "push"]
+CYC = {0, 1, 2, 3, 4, 5, 6, 8, 12, 13, 14, 16, 17, 21, 22, 23, 24, 31}
 raw7 = raw[:, :, 7].sum(1)
 print("nfa calls mean/max", (raw7 >> 40).mean(), (raw7 >> 40).max(), "px tested mean/max", (raw7 & ((1 << 40) - 1)).mean(), (raw7 & ((1 << 40) - 1)).max())
 # the growing waves (0..2) alone: the evaluating wave's total is "until the last grower is done" and hides them
 gtot = tot_w[:, :min(3, GW)]
 gslow = gtot.argmax(1)
-dg = raw[np.arange(n * 3), gslow][:, :27].astype(np.float64)
+dg = raw[np.arange(n * 3), gslow][:, :32].astype(np.float64)
 for w in np.argsort(gtot.max(1))[-3:]:
     print("longest growers: problem", int(w), " ".join("%s=%.0f" % (nm, v / (1000.0 if i in CYC else 1.0)) for i, (nm, v) in enumerate(zip(names, dg[w])) if nm != "-"), "(kcycles)")
 print("growers mean", " ".join("%s=%.0f" % (nm, v / (1000.0 if i in CYC else 1.0)) for i, (nm, v) in enumerate(zip(names, dg.mean(0))) if nm != "-"), "(kcycles)")
