@@ -367,6 +367,15 @@ LFG_DEV double angle_of(float deg) { return deg == NOTDEF_F ? NOTDEF_D : (double
 
 LFG_DEV bool aligned_val(double a, double theta, double prec)
 {
+#ifndef LF_HOST_SIM
+    // the same values without a branch (three nested ifs were three exec-mask regions on the growing wave's chain)
+    double n_theta = theta - a;
+    n_theta = n_theta < 0 ? -n_theta : n_theta;
+    double t2 = n_theta - M_2__PI_;
+    t2 = t2 < 0 ? -t2 : t2;
+    n_theta = n_theta > M_3_2_PI_ ? t2 : n_theta;
+    return (a != NOTDEF_D) & (n_theta <= prec);
+#else
     if (a == NOTDEF_D) return false;
     double n_theta = theta - a;
     if (n_theta < 0) n_theta = -n_theta;
@@ -375,6 +384,7 @@ LFG_DEV bool aligned_val(double a, double theta, double prec)
         if (n_theta < 0) n_theta = -n_theta;
     }
     return n_theta <= prec;
+#endif
 }
 
 LFG_DEV double angle_diff_signed(double a, double b)
@@ -561,20 +571,21 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 const float hm = 1.5707964f * (float)__popcll(lfg_ballot(ad <= precf) & cb);
                 const float sx_ = sumdx < 0.f ? -sumdx : sumdx, sy_ = sumdy < 0.f ? -sumdy : sumdy;
                 const float smax = sx_ > sy_ ? sx_ : sy_;
-                // (the sums are the same in every lane; said explicitly, or the branch and every mask behind it count as divergent)
-                if (__builtin_amdgcn_readfirstlane((int)((precf - EPSF - tn_cone) * smax > hm))) {            // the magnitude pair has the wider near band
-                    nearM = lfg_ballot((ad - precf + EPSF) * smax + hm <= 0.f);
-                    midM = ~nearM & ~lfg_ballot((ad - precf - EPSF) * smax - hm > 0.f);
-                } else {
-                    nearM = lfg_ballot(ad <= tn_cone);
-                    midM = ~nearM & lfg_ballot(ad <= tf_cone);
-                }
+                // the pair with the wider near band, chosen by SELECTS: both pairs as thresholds (delta a shade above (pi/2) m / smax -- the
+                // reciprocal is approximate; either way the slack is a millionth of what EPS allows for), no branch and no trip through a scalar
+                // register in front of the ballots
+                const float delta = hm * __builtin_amdgcn_rcpf(smax) * 1.000001f;
+                const float tn_mag = precf - EPSF - delta;
+                const bool mag = tn_mag > tn_cone;
+                const float tn = mag ? tn_mag : tn_cone, tf = mag ? precf + EPSF + delta : tf_cone;
+                nearM = lfg_ballot(ad <= tn);
+                midM = ~nearM & lfg_ballot(ad <= tf);
             }
             const unsigned long long maskM = midM & cb;
-            const int L = maskM ? __builtin_ctzll(maskM) : 64;
-            const unsigned long long span = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+            // the span = the lanes in front of the first undecided one (all of them when there is none): the bits below maskM's lowest
+            const unsigned long long span = (maskM - 1ull) & ~maskM;
             const unsigned long long maskN = nearM & cb & span;
-            LFG_CNT(c, 27, 1) LFG_CNT(c, 28, (maskN == 0ull && L < 64)) LFG_CNT(c, 30, (maskN & (maskN - 1ull)) != 0ull)
+            LFG_CNT(c, 27, 1) LFG_CNT(c, 28, (maskN == 0ull && maskM != 0ull)) LFG_CNT(c, 30, (maskN & (maskN - 1ull)) != 0ull)
             if (maskN != 0ull) {
                 // first offer wins inside the span: walk the near lanes in order, each new pixel strikes its later offers
                 unsigned long long maskA = maskN;
@@ -604,7 +615,8 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 added = true;
                 LFG_CNT(c, 18, __popcll(maskA))
             }
-            if (L >= 64) break;
+            if (maskM == 0ull) break;
+            const int L = __builtin_ctzll(maskM);
             if (maskN != 0ull) {
                 // later offers of the pixels just accepted are no longer candidates (measured: striking them by key in the loop
                 // above instead of this trip to the USED bits made the kernel 1.5 % slower)
@@ -628,7 +640,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 added = true;
                 LFG_CNT(c, 19, 1)
             } else { LFG_CNT(c, 29, 1) }
-            later = L >= 63 ? 0ull : (~0ull << (L + 1));
+            later = ~(maskM ^ (maskM - 1ull));                // the lanes behind the undecided one
         }
         if (added) mem_fence();
         LFG_T1(c, 14)
