@@ -568,7 +568,7 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             unsigned long long nearM = 0ull, midM = ~0ull;    // everything undecided = the reference's loop, lane by lane
             if (bulk_ok) {
                 // division free: ad <= prec - EPS - (pi/2) m / smax  <=>  (ad - prec + EPS) smax + (pi/2) m <= 0
-                const float hm = 1.5707964f * (float)__popcll(lfg_ballot(ad <= precf) & cb);
+                const float hm = 1.5707964f * (float)(int)__popcll(lfg_ballot(ad <= precf) & cb);
                 const float sx_ = sumdx < 0.f ? -sumdx : sumdx, sy_ = sumdy < 0.f ? -sumdy : sumdy;
                 const float smax = sx_ > sy_ ? sx_ : sy_;
                 // the pair with the wider near band, chosen by SELECTS: both pairs as thresholds (delta a shade above (pi/2) m / smax -- the
@@ -626,7 +626,18 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
             // the undecided lane: the reference's comparison under the angle of this moment
             // (measured: the same comparison on lane L's angle as a wave-uniform value -- readlane, scalar branches -- made the
             // kernel 15 % slower)
-            const bool hitL = ((lfg_ballot(aligned_val(a, reg_angle, prec)) & candm) >> L) & 1ull;
+            // When lane L fails under the angle of this moment, so does every candidate behind it up to the first that passes (the angle
+            // only moves when a pixel is accepted): the loop goes on AT that lane, one trip for all of them instead of one each (a third
+            // of all spans on the refined, narrow-tolerance growths).  (`later` is settled before the branch: nothing of this is live
+            // across the accept code)
+            const bool hitL = [&]() {
+                const unsigned long long hits = lfg_ballot(aligned_val(a, reg_angle, prec)) & candm;
+                const unsigned long long behind = ~(maskM ^ (maskM - 1ull));     // the lanes behind the undecided one
+                const bool hit = (hits >> L) & 1ull;
+                const unsigned long long h2 = hits & behind;
+                later = hit ? behind : ~((h2 & (0ull - h2)) - 1ull);            // miss: the lanes at or behind h2's lowest; none when h2 is empty
+                return hit;
+            }();
             if (hitL) {
                 const int eL = rl_i(e, L);
                 const int ay = rl_i(yy, L), ax = rl_i(xx, L);
@@ -640,7 +651,6 @@ LFG_DEV void region_grow(const Ctx& c, int sx, int sy, int seed_e, int& reg_size
                 added = true;
                 LFG_CNT(c, 19, 1)
             } else { LFG_CNT(c, 29, 1) }
-            later = ~(maskM ^ (maskM - 1ull));                // the lanes behind the undecided one
         }
         if (added) mem_fence();
         LFG_T1(c, 14)
