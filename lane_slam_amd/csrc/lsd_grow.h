@@ -940,6 +940,11 @@ LFG_DEV double refine_tau(const Ctx& c, int reg_size, const Rect& rec, int& x0, 
     const double ang_c = angle_of(c.deg[e0]);
     double sum = 0, s_sum = 0;
     int n = 0;
+#ifndef LF_HOST_SIM
+    // Every lane tests its own point (distance from the first point, a square root) and forms its own angle difference and square; the
+    // two ordered sums then take the selected points' terms in list order through ordered_sums3 -- a point outside the radius
+    // contributes -0.0, which leaves a sum as it is.  (Before: one point at a time on wave-uniform values, square root included.)
+    double acc = 0.0;
     for (int base = 0; base < reg_size; base += LFG_NL) {
         const int i = base + lane;
         const bool v = i < reg_size;
@@ -948,9 +953,28 @@ LFG_DEV double refine_tau(const Ctx& c, int reg_size, const Rect& rec, int& x0, 
         const int ei = v ? find_e(c, px, py) : 0;
         const float af = v ? c.deg[ei] : NOTDEF_F;
         const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
-#ifndef LF_HOST_SIM
         if (v) used_and(c, ei);                        // every lane releases its own point: the order of the releases means nothing
-#endif
+        const bool sel = v && dist_(xc, yc, (double)px, (double)py) < rec.width;
+        double ang_d = -0.0, ang_d2 = -0.0;
+        if (sel) {
+            double diff = angle_of(af) - ang_c;        // angle_diff_signed, per lane
+            while (diff <= -PI_) diff += M_2__PI_;
+            while (diff > PI_) diff -= M_2__PI_;
+            ang_d = diff; ang_d2 = diff * diff;
+        }
+        ordered_sums3(acc, ang_d, ang_d2, -0.0, cnt);
+        n += __popcll(lfg_ballot(sel));
+    }
+    sum = rl_d(acc, 0); s_sum = rl_d(acc, 1);
+#else
+    for (int base = 0; base < reg_size; base += LFG_NL) {
+        const int i = base + lane;
+        const bool v = i < reg_size;
+        const uint32_t pk = v ? reg_get(c, i) : 0u;
+        const int px = (int)(pk & 0xffffu), py = (int)(pk >> 16);
+        const int ei = v ? find_e(c, px, py) : 0;
+        const float af = v ? c.deg[ei] : NOTDEF_F;
+        const int cnt = reg_size - base < LFG_NL ? reg_size - base : LFG_NL;
         for (int j = 0; j < cnt; ++j) {
             const uint32_t q = (uint32_t)rl_i((int)pk, j);
             const int qx = (int)(q & 0xffffu), qy = (int)(q >> 16);
@@ -966,6 +990,7 @@ LFG_DEV double refine_tau(const Ctx& c, int reg_size, const Rect& rec, int& x0, 
             }
         }
     }
+#endif
     const double mean_angle = sum / (double)n;
     return 2.0 * dm::dsqrt((s_sum - 2.0 * mean_angle * sum) / (double)n + mean_angle * mean_angle);
 }
