@@ -17,6 +17,20 @@ if os.environ.get("LF_STAMPS_REAL"):          # the three real camera frames of 
     fr, st = fe.decode_jpeg_batch(streams, n_threads=4)
     rf = [fr[k] for k in range(len(streams)) if st[k] == 0]
     frames = np.stack([np.roll(rf[i % len(rf)], 7 * (i // len(rf)), axis=1) for i in range(n)])
+if os.environ.get("LF_STAMPS_CLUTTER"):       # bench.py's secondary.clutter_frames: speckle + 40 random strokes in lane colours per frame
+    rng_c = np.random.default_rng(4321)
+    for f_ in range(frames.shape[0]):
+        img = frames[f_]
+        r0 = img.shape[0] // 3
+        for _ in range(40):
+            y, x = rng_c.integers(r0 + 10, img.shape[0] - 10), rng_c.integers(10, img.shape[1] - 10)
+            dy, dx = rng_c.integers(-12, 13), rng_c.integers(-40, 41)
+            col = ((235, 235, 235), (40, 220, 235), (40, 40, 220))[rng_c.integers(0, 3)]
+            t_ = np.linspace(0, 1, 80)
+            yy = np.clip((y + t_ * dy + rng_c.normal(0, 0.7, 80)).astype(int), r0, img.shape[0] - 1)
+            xx = np.clip((x + t_ * dx + rng_c.normal(0, 0.7, 80)).astype(int), 0, img.shape[1] - 1)
+            img[yy, xx] = col
+        img[rng_c.random(img.shape[:2]) < 0.004] = (235, 235, 235)
 fe.process_batch(frames)
 seg = fe.process_batch(frames)
 scr = fe.fetch(_lib.LF_BUF_LSD_SCRATCH, n)
