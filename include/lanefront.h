@@ -387,7 +387,7 @@ LF_API const char* lf_map_stage_name(int stage);
  * oracle/lf_oracle_edlines.c, which restates the in-tree C++ -- unpinned against a real build of it (needs OpenCV).
  *
  * lf_edlines_params   EDLineDetector::EDLineDetector() defaults (:1374-1385): gradient_threshold 80, anchor_threshold 8,
- *                     scan_intervals 2, min_line_len 15 (<= 64), line_fit_err_threshold 1.6; ksize 5 (only 5 is built)
+ *                     scan_intervals 2, min_line_len 15 (<= 64), line_fit_err_threshold 1.6; ksize 5 (odd, 1 .. 31)
  * lf_keylines         struct of arrays, caller allocated for `capacity` lines, NULL arrays are skipped; field meaning =
  *                     KeyLine (include/line_descriptor/descriptor_custom.hpp:105-144): start_end = startPointX/Y,
  *                     endPointX/Y (original image scale), in_octave = s/ePointInOctaveX/Y, angle = direction of the line
@@ -425,6 +425,26 @@ typedef struct lf_keylines {
     uint8_t* code;
 } lf_keylines;
 LF_API void lf_edlines_default_params(lf_edlines_params* p);
+/* BinaryDescriptor::Params and its setters (binary_descriptor_custom.cpp:108-200; descriptor_custom.hpp Params) on a handle:
+ *   num_of_octave     numOfOctave_ (1): kept and returned; the entry points take n_octaves explicitly
+ *   width_of_band     widthOfBand_ (7): setWidthOfBand (:134-176) -- the support region is 9 w rows, both Gaussian tables F_g (9 w) and
+ *                     F_l (3 w) are recomputed with the reference's integer divisions.  Applies to EVERY descriptor the handle computes
+ *                     from then on (lf_process_batch with describe, lf_keylines_batch, lf_lsd_keylines_batch, lf_describe_keylines).
+ *                     1 .. 21, else LF_ERR_UNSUPPORTED
+ *   reduction_ratio   reductionRatio (2): computeGaussianPyramid (:366) asks pyrDown for Size(cols / r, rows / r), which cv::pyrDown
+ *                     only accepts within 2 pixels of half the source -- i.e. r = 2; with any other value a compute over more than one
+ *                     octave fails there (cv::Exception) and here (LF_ERR_UNSUPPORTED from lf_describe_keylines / the describe step of
+ *                     lf_lsd_keylines_batch); one octave never reaches the call
+ *   ksize             ksize_ (5): the Gaussian of OctaveKeyLines (:708) when lf_keylines_batch is given no lf_edlines_params (a params
+ *                     block names its own ksize); odd, 1 .. 31
+ * Params::read / write (:189-204: a cv::FileStorage node with numOfOctave_, widthOfBand_, reductionRatio; write adds numOfBand_ = 9)
+ * are host-side text handling: lane_slam_amd.matcher.BinaryDescriptorParams mirrors them.  Not while a batch is in flight. */
+typedef struct {
+    int32_t num_of_octave, width_of_band, reduction_ratio, ksize;
+} lf_descriptor_params;
+LF_API void lf_descriptor_default_params(lf_descriptor_params* p);
+LF_API int lf_set_descriptor_params(lf_handle* h, const lf_descriptor_params* p);
+LF_API int lf_get_descriptor_params(lf_handle* h, lf_descriptor_params* p);
 LF_API int lf_keylines_batch(lf_handle* h, const uint8_t* images, int n_frames, int input_kind, int images_on_device, int n_octaves,
                       const lf_edlines_params* params_or_null, lf_keylines* out, int out_on_device, int describe,
                       int* n_keylines, int32_t* frame_status_or_null);

@@ -16,8 +16,8 @@ HIP library or without a GPU raises.
 from .config import (COLOR_NAMES, DEFAULT_DETECTOR_CONFIGURATION, RED, WHITE, YELLOW, default_config)
 from .frontend import FrontEnd, LanefrontError, Segments
 from .line_associator import LineAssociator
-from .matcher import BinaryDescriptorMatcher, DMatch
+from .matcher import BinaryDescriptorMatcher, BinaryDescriptorParams, DMatch
 from .line_detector_hip import Detections, LineDetectorEDLines, LineDetectorHIP, LineDetectorInterface
 
-__all__ = ["BinaryDescriptorMatcher", "DMatch", "LineAssociator", "FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorEDLines", "LineDetectorInterface", "Detections",
+__all__ = ["BinaryDescriptorMatcher", "BinaryDescriptorParams", "DMatch", "LineAssociator", "FrontEnd", "LanefrontError", "Segments", "LineDetectorHIP", "LineDetectorEDLines", "LineDetectorInterface", "Detections",
            "default_config", "DEFAULT_DETECTOR_CONFIGURATION", "WHITE", "YELLOW", "RED", "COLOR_NAMES"]

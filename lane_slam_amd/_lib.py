@@ -25,6 +25,7 @@ EXPORTS = (
     "lf_map_create", "lf_map_destroy", "lf_map_last_error", "lf_map_get_stream", "lf_map_synchronize", "lf_map_seed", "lf_map_size",
     "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_step_host", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
+    "lf_descriptor_default_params", "lf_set_descriptor_params", "lf_get_descriptor_params",
     "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu",
     "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_lsd_list_capacity", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
     "lf_lsd_default_options", "lf_lsd_keylines_batch_ex", "lf_keylines_batch_masked",
@@ -49,6 +50,11 @@ class LfEdlinesParams(ctypes.Structure):
     """ctypes mirror of `lf_edlines_params` (include/lanefront.h)."""
     _fields_ = [("gradient_threshold", ctypes.c_int32), ("anchor_threshold", ctypes.c_int32), ("scan_intervals", ctypes.c_int32),
                 ("min_line_len", ctypes.c_int32), ("line_fit_err_threshold", ctypes.c_double), ("ksize", ctypes.c_int32)]
+
+
+class LfDescriptorParams(ctypes.Structure):
+    """lf_descriptor_params: BinaryDescriptor::Params (binary_descriptor_custom.cpp:108-116)."""
+    _fields_ = [("num_of_octave", ctypes.c_int32), ("width_of_band", ctypes.c_int32), ("reduction_ratio", ctypes.c_int32), ("ksize", ctypes.c_int32)]
 
 
 KEYLINE_FIELDS = (("start_end", "f4", 4), ("in_octave", "f4", 4), ("angle", "f4", 1), ("num_pixels", "i4", 1), ("line_length", "f4", 1),
@@ -162,6 +168,12 @@ def load():
     lib.lf_map_get_timing.restype = ci
     lib.lf_map_stage_name.argtypes = [ci]
     lib.lf_map_stage_name.restype = ctypes.c_char_p
+    lib.lf_descriptor_default_params.argtypes = [ctypes.POINTER(LfDescriptorParams)]
+    lib.lf_descriptor_default_params.restype = None
+    lib.lf_set_descriptor_params.argtypes = [vp, ctypes.POINTER(LfDescriptorParams)]
+    lib.lf_set_descriptor_params.restype = ci
+    lib.lf_get_descriptor_params.argtypes = [vp, ctypes.POINTER(LfDescriptorParams)]
+    lib.lf_get_descriptor_params.restype = ci
     lib.lf_edlines_default_params.argtypes = [ctypes.POINTER(LfEdlinesParams)]
     lib.lf_edlines_default_params.restype = None
     lib.lf_keylines_batch.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.POINTER(LfEdlinesParams), ctypes.POINTER(LfKeylines), ci, ci,

@@ -171,11 +171,12 @@ void launch_lbd_grad(int Hc, int W, int n_frames, const uint8_t* gray, uint32_t*
 struct LbdPlanes { const uint32_t* base[LF_MAX_OCTAVES]; int W[LF_MAX_OCTAVES], H[LF_MAX_OCTAVES]; };
 void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, int n_frames, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
                          const int* octave, const int* frame, const float* gauss_g, const float* gauss_l, float* desc, uint8_t* code,
-                         hipStream_t s);
+                         hipStream_t s, int wband = 7);
 void launch_lbd_split_debug(size_t n, const uint32_t* dxy, int16_t* dx, int16_t* dy, hipStream_t s);
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
                 const uint32_t* dxy, const float* gauss_g, const float* gauss_l,
-                float* desc, uint8_t* code, hipStream_t s);
+                float* desc, uint8_t* code, hipStream_t s, int wband = 7);
+int lbd_max_width_of_band();
 // ---- associator (k_assoc.hip): packed operands = [rows][256] int8 code bytes + [rows][32] int8 ninth-step operand
 size_t assoc_rows_padded_m(int nm);
 // Packed map operand layout (k_assoc.hip): blocked by the associator's 64-row LDS tile, [tile][16-byte chunk][row][16 B];

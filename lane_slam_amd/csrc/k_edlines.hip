@@ -278,6 +278,42 @@ void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* t
         hipLaunchKernelGGL(k_ed_grad<false>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g);
 }
 
+// cv::GaussianBlur(src, dst, Size(k, k), sigma) on u8 for a kernel size OTHER than the reference's default 5 (Params::ksize_,
+// binary_descriptor_custom.cpp:708): the same 8-bit fixed-point separable filter (row sums of taps x pixels, column sums of taps x row
+// sums, (s + 2^15) >> 16, BORDER_REFLECT_101) with run-time taps, as two plain passes through an int32 plane.  A completeness path:
+// k_ed_grad then runs with the identity taps (0 0 256 0 0), which hand the blurred pixels through unchanged.
+struct EdTaps { int n; int k[31]; };
+__global__ __launch_bounds__(256) void k_ed_blur_rows(int H, int W, const uint8_t* __restrict__ src, EdTaps t, int* __restrict__ tmp)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t* row = src + ((size_t)blockIdx.z * H + y) * W;
+    const int r = t.n / 2;
+    int sum = 0;
+    for (int j = -r; j <= r; ++j) sum += t.k[j + r] * (int)row[ed_reflect101(x + j, W)];
+    tmp[((size_t)blockIdx.z * H + y) * W + x] = sum;
+}
+__global__ __launch_bounds__(256) void k_ed_blur_cols(int H, int W, const int* __restrict__ tmp, EdTaps t, uint8_t* __restrict__ dst)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int* img = tmp + (size_t)blockIdx.z * H * W;
+    const int r = t.n / 2;
+    int sum = 0;
+    for (int j = -r; j <= r; ++j) sum += t.k[j + r] * img[(size_t)ed_reflect101(y + j, H) * W + x];
+    const int v = (sum + (1 << 15)) >> 16;
+    dst[((size_t)blockIdx.z * H + y) * W + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+}
+void launch_ed_blur_any(int H, int W, int n_frames, const uint8_t* src, const int* taps, int ksize, int* tmp, uint8_t* dst, hipStream_t s)
+{
+    EdTaps t;
+    t.n = ksize;
+    for (int i = 0; i < 31; ++i) t.k[i] = i < ksize ? taps[i] : 0;
+    const dim3 grid((W + 255) / 256, H, n_frames);
+    hipLaunchKernelGGL(k_ed_blur_rows, grid, dim3(256), 0, s, H, W, src, t, tmp);
+    hipLaunchKernelGGL(k_ed_blur_cols, grid, dim3(256), 0, s, H, W, tmp, t, dst);
+}
+
 // cv::resize(src, dst, Size(), inv, inv), INTER_LINEAR, u8: 11-bit coefficients from float weights.  The coefficient
 // tables -- per destination column (source column, its right neighbour, the two weights), per destination row (offsets of
 // the two source rows, the two weights) -- depend on the sizes alone: the host computes them once per octave

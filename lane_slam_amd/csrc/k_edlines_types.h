@@ -45,6 +45,7 @@ void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* t
 void ed_resize_tables(int H, int W, int DH, int DW, double scale, int* tab);        // 4 ints per destination column, then 4 per destination row
 void launch_ed_resize(int H, int W, int DH, int DW, const int* tab, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s);
 void launch_pyrdown(int H, int W, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s);
+void launch_ed_blur_any(int H, int W, int n_frames, const uint8_t* src, const int* taps, int ksize, int* tmp, uint8_t* dst, hipStream_t s);
 size_t ed_detect_lds_bytes(int W, int H, int scan, bool* marks_in_lds);
 int launch_ed_detect(const EdAll& all, const EdFitParams& fp, int n_octaves, int n_frames, size_t lds_bytes, hipStream_t s);
 void launch_ed_slots(const EdAll& all, int n_frames, const uint32_t* maskbits, int Ww, int cap_lines, float* slot_lines, int* counts, int* failed, hipStream_t s);

@@ -221,16 +221,22 @@ constexpr int LBD_STEPS = 8;      // support-region columns fetched per round tr
 // octave).  KL = true: KeyLines of the EDLines / multi-octave path (k_edlines.hip, lf_describe_keylines): endpoints in the
 // octave image, direction and numOfPixels are given, and every line names its octave's gradient plane (computeLBD,
 // binary_descriptor_custom.cpp:1070-1100: edLineVec_[octave]->dxImg_ or dxImg_vector[octave]).
-template <bool KL>
+// ANYW = true: BinaryDescriptor::setWidthOfBand (binary_descriptor_custom.cpp:134-176) with a width other than the default 7: the support
+// region is 9 w rows (w <= LBD_MAXW), a lane takes rows lane, lane + 64, ...; the tables (9 w global, 3 w local weights) come from the host
+// for that width.  The same statements otherwise -- a completeness path, the default width keeps its compile-time shape.
+constexpr int LBD_MAXW = 21;
+template <bool KL, bool ANYW = false>
 __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restrict__ n_seg_ptr,
                                              const float* __restrict__ lines, const int* __restrict__ seg_frame,
                                              const uint32_t* __restrict__ dxyi,
                                              const float* __restrict__ gauss_g /*63*/, const float* __restrict__ gauss_l /*21*/,
                                              float* __restrict__ desc, uint8_t* __restrict__ code,
                                              LbdPlanes planes, const float* __restrict__ kl_angle, const int* __restrict__ kl_npx,
-                                             const int* __restrict__ kl_octave, int n_cap, int n_frames)
+                                             const int* __restrict__ kl_octave, int n_cap, int n_frames, int wband_arg = WBAND)
 {
-    __shared__ float rows[4][LSP_H][4];      // per wave: row sums pgdL, ngdL, pgdO, ngdO (already * coefG)
+    const int WBAND = ANYW ? wband_arg : lf::WBAND;          // (shadow the file's constants: runtime values in the ANYW copy)
+    const int LSP_H = ANYW ? NBANDS * wband_arg : lf::LSP_H;
+    __shared__ float rows[4][ANYW ? NBANDS * LBD_MAXW : lf::LSP_H][4];      // per wave: row sums pgdL, ngdL, pgdO, ngdO (already * coefG)
     __shared__ float dsc[4][72];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // never past the capacity the buffers were sized for: a count beyond it is the caller's LF_ERR_CAPACITY case
@@ -286,9 +292,10 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restr
     const float dO0 = -dL1, dO1 = dL0;
     float sCorX0 = -dL0 * halfWidth + dL1 * halfHeight + midX;
     float sCorY0 = -dL1 * halfWidth - dL0 * halfHeight + midY;
-    if (lane < LSP_H) {
+    int row_done = 0;                                           // rows the running origin has been advanced by
+    for (int row = lane; row < LSP_H; row += 64) {
         // the reference advances the row origin by repeated float updates: replay them
-        for (int hh = 0; hh < lane; ++hh) { sCorX0 -= dL1; sCorY0 += dL0; }
+        for (; row_done < row; ++row_done) { sCorX0 -= dL1; sCorY0 += dL0; }
         float sCorX = sCorX0, sCorY = sCorY0;
         float pgdL = 0, ngdL = 0, pgdO = 0, ngdO = 0;
         // coordinates never depend on the gathered data: LBD_STEPS steps of addresses first, 2 * LBD_STEPS loads
@@ -316,11 +323,12 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restr
                 if (gDO > 0) pgdO += gDO; else ngdO -= gDO;
             }
         }
-        const float cg = gauss_g[lane];
-        rows[wave][lane][0] = cg * pgdL;
-        rows[wave][lane][1] = cg * ngdL;
-        rows[wave][lane][2] = cg * pgdO;
-        rows[wave][lane][3] = cg * ngdO;
+        const float cg = gauss_g[row];
+        rows[wave][row][0] = cg * pgdL;
+        rows[wave][row][1] = cg * ngdL;
+        rows[wave][row][2] = cg * pgdO;
+        rows[wave][row][3] = cg * ngdO;
+        if (!ANYW) break;                                       // (63 rows: one per lane)
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -338,7 +346,8 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restr
         const float* rp = &rows[wave][0][src] + 4 * h0;
         float acc = 0;
 #pragma unroll
-        for (int i = 0; i < 3 * WBAND; ++i) {
+        for (int i = 0; i < (ANYW ? 3 * LBD_MAXW : 3 * lf::WBAND); ++i) {
+            if (ANYW && i >= 3 * WBAND) break;
             const int hID = h0 + i;
             if (hID >= 0 && hID < LSP_H) {
                 const float coef = gauss_l[i];
@@ -412,26 +421,35 @@ __global__ __launch_bounds__(256) void k_lbd(int Hc_, int W_, const int* __restr
 
 void launch_lbd(int Hc, int W, int n_seg_cap, const int* n_seg, const float* lines, const int* seg_frame,
                 const uint32_t* dxy, const float* gauss_g, const float* gauss_l,
-                float* desc, uint8_t* code, hipStream_t s)
+                float* desc, uint8_t* code, hipStream_t s, int wband)
 {
     if (n_seg_cap <= 0) return;
     int blocks = (n_seg_cap + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     LbdPlanes none;
     for (int i = 0; i < LF_MAX_OCTAVES; ++i) { none.base[i] = nullptr; none.W[i] = 0; none.H[i] = 0; }
-    hipLaunchKernelGGL(k_lbd<false>, dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
-                       gauss_g, gauss_l, desc, code, none, nullptr, nullptr, nullptr, n_seg_cap, 0);
+    if (wband == WBAND)
+        hipLaunchKernelGGL((k_lbd<false, false>), dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
+                           gauss_g, gauss_l, desc, code, none, nullptr, nullptr, nullptr, n_seg_cap, 0, WBAND);
+    else
+        hipLaunchKernelGGL((k_lbd<false, true>), dim3(blocks), dim3(256), 0, s, Hc, W, n_seg, lines, seg_frame, dxy,
+                           gauss_g, gauss_l, desc, code, none, nullptr, nullptr, nullptr, n_seg_cap, 0, wband);
 }
+int lbd_max_width_of_band() { return LBD_MAXW; }
 
 void launch_lbd_keylines(const LbdPlanes& planes, int n_cap, int n_frames, const int* n_lines, const float* in_octave4, const float* angle, const int* npx,
                          const int* octave, const int* frame, const float* gauss_g, const float* gauss_l, float* desc, uint8_t* code,
-                         hipStream_t s)
+                         hipStream_t s, int wband)
 {
     if (n_cap <= 0) return;
     int blocks = (n_cap + 3) / 4;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_lbd<true>, dim3(blocks), dim3(256), 0, s, 0, 0, n_lines, in_octave4, frame, nullptr, gauss_g, gauss_l, desc, code,
-                       planes, angle, npx, octave, n_cap, n_frames);
+    if (wband == WBAND)
+        hipLaunchKernelGGL((k_lbd<true, false>), dim3(blocks), dim3(256), 0, s, 0, 0, n_lines, in_octave4, frame, nullptr, gauss_g, gauss_l, desc, code,
+                           planes, angle, npx, octave, n_cap, n_frames, WBAND);
+    else
+        hipLaunchKernelGGL((k_lbd<true, true>), dim3(blocks), dim3(256), 0, s, 0, 0, n_lines, in_octave4, frame, nullptr, gauss_g, gauss_l, desc, code,
+                           planes, angle, npx, octave, n_cap, n_frames, wband);
 }
 
 // Debug only: the two s16 planes tests compare with the oracle's Sobel output.

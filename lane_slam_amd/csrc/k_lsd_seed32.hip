@@ -2462,7 +2462,8 @@ bool lsd_seed32_supported(const LsdParams& p)
     const long long n = (long long)(p.Hs - 1) * (p.Ws - 1);
     // (a pixel with a defined gradient must not fall into bin 0, the anonymous one: its norm exceeds rho, and no 8-bit image has a
     // gradient norm above sqrt(2) * 255 = 360.63)
-    return p.n_bins <= 1024 && (long long)p.Hs * p.Ws < (1 << 21) && n >= 1 && (double)(p.n_bins - 1) * p.rho / 360.7 >= 1.0;
+    // (bins are 12-bit keys above the 20-bit payload: up to 4096 of them)
+    return p.n_bins <= 4096 && (long long)p.Hs * p.Ws < (1 << 21) && n >= 1 && (double)(p.n_bins - 1) * p.rho / 360.7 >= 1.0;
 }
 
 // big != 0: dense problems are expected (LSD of a gray image: most pixels have a gradient) -- the row tables of the dense phase

@@ -53,6 +53,7 @@ struct lf_handle {
     // geometry
     int Hc = 0, W = 0, Hs = 0, Ws = 0, Ww = 0;
     size_t P = 0, Ps = 0;
+    lf_descriptor_params desc_params = { 1, 7, 2, 5 };      // BinaryDescriptor::Params (lf_set_descriptor_params)
     bool lists_lost = false;     // lsd_grow_lists ran out of memory twice: no per-problem lists, run_detect refuses
     int label_items_full = 0;    // LsdParams::label_items of a handle whose lists hold whole images (alloc_lsd_lists lowers it with rec_cap)
     PreParams pre;
@@ -294,7 +295,7 @@ static int build_params(lf_handle* h)
     // LDS (k_lsd_grow.hip), canny hysteresis sweeps strips of >= 1 row + 2 halo rows (k_canny.hip)
     if ((size_t)((L.Hs + 2) & ~1) * 4 + 512 * 4 + 1024 > 64 * 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "scaled LSD image has %d rows: the row table exceeds the LDS of one problem", L.Hs); return LF_ERR_UNSUPPORTED; }
     if ((size_t)h->Hc * h->Ww > 8 * 1024 && (8192 / h->Ww < 1 || (int)((60 * 1024 / 4) / (2 * (size_t)h->Ww)) - 1 < 1)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "img_cols %d: one row of the edge bit planes exceeds the hysteresis strip budget", h->W); return LF_ERR_UNSUPPORTED; }
-    if (c.lsd_n_bins < 2 || c.lsd_n_bins > 1024) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_n_bins must be in [2,1024]"); return LF_ERR_UNSUPPORTED; }
+    if (c.lsd_n_bins < 2 || c.lsd_n_bins > 4096) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_n_bins must be in [2,4096] (a seed is its bin above a 20-bit pixel index in one word)"); return LF_ERR_UNSUPPORTED; }
     if (L.scaled) {
         const double sigma = (c.lsd_scale < 1) ? (c.lsd_sigma_scale / c.lsd_scale) : c.lsd_sigma_scale;
         const double sprec = 3;
@@ -316,7 +317,7 @@ static int build_params(lf_handle* h)
     L.log_eps = c.lsd_log_eps; L.density_th = c.lsd_density_th;
     L.n_bins = c.lsd_n_bins; L.refine = c.lsd_refine; L.cap_lines = h->cap_lines;
     if (c.lsd_seed_order != LF_LSD_SEED_OPENCV30 && c.lsd_seed_order != LF_LSD_SEED_OPENCV32) { lf_set_error(h, LF_ERR_BAD_ARG, "lsd_seed_order %d: LF_LSD_SEED_OPENCV30 or LF_LSD_SEED_OPENCV32", c.lsd_seed_order); return LF_ERR_BAD_ARG; }
-    if (c.lsd_seed_order == LF_LSD_SEED_OPENCV32 && !lsd_seed32_supported(L)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_seed_order OPENCV32: the %dx%d LSD image exceeds the row tables of the sort emulation (k_lsd_seed32.hip)", L.Ws, L.Hs); return LF_ERR_UNSUPPORTED; }
+    if (c.lsd_seed_order == LF_LSD_SEED_OPENCV32 && !lsd_seed32_supported(L)) { lf_set_error(h, LF_ERR_UNSUPPORTED, "lsd_seed_order OPENCV32: the %dx%d LSD image exceeds the row tables of the sort emulation, or (n_bins - 1) * quant / sin(ang_th) < 361 (k_lsd_seed32.hip)", L.Ws, L.Hs); return LF_ERR_UNSUPPORTED; }
     // component labelling (k_lsd_label): problems of up to label_lds = 6144 defined pixels in LDS (24 KB per workgroup: what one
     // workgroup of k_lsd_grow gives back when it leaves a CU), the larger ones in the problem's region scratch, up to label_items
     // -- a third of the scaled image (every growing wave has a region list of that size in the scratch) and below 2^16 (the
@@ -350,6 +351,24 @@ static int build_params(lf_handle* h)
         }
     S.lanewidth = c.lanewidth; S.linewidth_white = c.linewidth_white; S.linewidth_yellow = c.linewidth_yellow;
     S.d_min = c.d_min; S.d_max = c.d_max; S.phi_min = c.phi_min; S.phi_max = c.phi_max;
+    return LF_OK;
+}
+
+// LBD Gaussian weights for a band width w (binary_descriptor_custom.cpp:217-259 = setWidthOfBand :134-176; the integer divisions in u and
+// sigma are the reference's): 9 w global weights F_g, 3 w local weights F_l, into the handle's device tables
+static int lbd_weights(lf_handle* h, int w)
+{
+    std::vector<float> gg(9 * (size_t)w), gl(3 * (size_t)w);
+    double u = (w * 3 - 1) / 2;
+    double sigma = (w * 2 + 1) / 2;
+    double inv = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < 3 * w; ++i) { double d = i - u; gl[i] = (float)dm::dexp(d * d * inv); }
+    u = (9 * w - 1) / 2;
+    sigma = u;
+    inv = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < 9 * w; ++i) { double d = i - u; gg[i] = (float)dm::dexp(d * d * inv); }
+    LF_HIP_CHECK(h, hipMemcpy(h->d_gauss_g, gg.data(), gg.size() * sizeof(float), hipMemcpyHostToDevice));
+    LF_HIP_CHECK(h, hipMemcpy(h->d_gauss_l, gl.data(), gl.size() * sizeof(float), hipMemcpyHostToDevice));
     return LF_OK;
 }
 
@@ -430,21 +449,44 @@ static int upload_tables(lf_handle* h)
     LF_HIP_CHECK(h, hipMemcpy(h->d_xa, xa.data(), 2 * (size_t)Ws * sizeof(float), hipMemcpyHostToDevice));
     LF_HIP_CHECK(h, hipMemcpy(h->d_yb, yb.data(), 2 * (size_t)Hs * sizeof(float), hipMemcpyHostToDevice));
     h->rt.xofs = h->d_xofs; h->rt.xa = h->d_xa; h->rt.y0 = h->d_y0; h->rt.y1 = h->d_y1; h->rt.yb = h->d_yb; h->rt.xmax = xmax;
-    // LBD Gaussian weights (binary_descriptor_custom.cpp:217-259; integer divisions kept)
-    float gg[63], gl[21];
-    {
-        double u = (7 * 3 - 1) / 2;
-        double sigma = (7 * 2 + 1) / 2;
-        double inv = -1 / (2 * sigma * sigma);
-        for (int i = 0; i < 21; ++i) { double d = i - u; gl[i] = (float)dm::dexp(d * d * inv); }
-        u = (9 * 7 - 1) / 2;
-        sigma = u;
-        inv = -1 / (2 * sigma * sigma);
-        for (int i = 0; i < 63; ++i) { double d = i - u; gg[i] = (float)dm::dexp(d * d * inv); }
+    const int mw = lbd_max_width_of_band();
+    if (dalloc(h, &h->d_gauss_g, 9 * (size_t)mw) || dalloc(h, &h->d_gauss_l, 3 * (size_t)mw)) return LF_ERR_HIP;
+    return lbd_weights(h, h->desc_params.width_of_band);
+}
+
+// BinaryDescriptor::Params on a handle (binary_descriptor_custom.cpp:108-200)
+extern "C" void lf_descriptor_default_params(lf_descriptor_params* p)
+{
+    if (!p) return;
+    p->num_of_octave = 1; p->width_of_band = 7; p->reduction_ratio = 2; p->ksize = 5;      // :110-116
+}
+
+extern "C" int lf_get_descriptor_params(lf_handle* h, lf_descriptor_params* p)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!p) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_get_descriptor_params: null argument"); return LF_ERR_BAD_ARG; }
+    *p = h->desc_params;
+    return LF_OK;
+}
+
+extern "C" int lf_set_descriptor_params(lf_handle* h, const lf_descriptor_params* p)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    if (!p) { lf_set_error(h, LF_ERR_BAD_ARG, "lf_set_descriptor_params: null argument"); return LF_ERR_BAD_ARG; }
+    if (h->pending) { lf_set_error(h, LF_ERR_BAD_ARG, "a batch is in flight on this handle: call lf_wait first"); return LF_ERR_BAD_ARG; }
+    if (p->width_of_band < 1 || p->width_of_band > lbd_max_width_of_band()) {
+        lf_set_error(h, LF_ERR_UNSUPPORTED, "widthOfBand %d outside 1..%d", p->width_of_band, lbd_max_width_of_band());
+        return LF_ERR_UNSUPPORTED;
     }
-    if (dalloc(h, &h->d_gauss_g, 63) || dalloc(h, &h->d_gauss_l, 21)) return LF_ERR_HIP;
-    LF_HIP_CHECK(h, hipMemcpy(h->d_gauss_g, gg, sizeof(gg), hipMemcpyHostToDevice));
-    LF_HIP_CHECK(h, hipMemcpy(h->d_gauss_l, gl, sizeof(gl), hipMemcpyHostToDevice));
+    if (p->ksize < 1 || p->ksize > 31 || !(p->ksize & 1)) { lf_set_error(h, LF_ERR_BAD_ARG, "ksize %d: an odd size in 1..31 (cv::GaussianBlur asserts the oddness)", p->ksize); return LF_ERR_BAD_ARG; }
+    if (p->num_of_octave < 1 || p->num_of_octave > LF_MAX_OCTAVES || p->reduction_ratio < 1) {
+        lf_set_error(h, LF_ERR_BAD_ARG, "lf_set_descriptor_params: numOfOctave_ outside 1..%d or reductionRatio < 1", LF_MAX_OCTAVES);
+        return LF_ERR_BAD_ARG;
+    }
+    LF_HIP_CHECK(h, hipSetDevice(h->device));
+    LF_HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (p->width_of_band != h->desc_params.width_of_band) { const int rc = lbd_weights(h, p->width_of_band); if (rc != LF_OK) return rc; }
+    h->desc_params = *p;
     return LF_OK;
 }
 
@@ -730,7 +772,7 @@ static int run_segments(lf_handle* h, int n, lf_segments dev_out, bool describe)
             StageTimer t(h, ST_LBD);
             int cap = dev_out.capacity < n * 3 * h->cap_lines ? dev_out.capacity : n * 3 * h->cap_lines;
             launch_lbd(h->Hc, h->W, cap, h->d_seg_offset + n * 3, dev_out.lines, h->d_seg_frame, h->d_dxy,
-                       h->d_gauss_g, h->d_gauss_l, dev_out.desc, dev_out.code, s);
+                       h->d_gauss_g, h->d_gauss_l, dev_out.desc, dev_out.code, s, h->desc_params.width_of_band);
         }
     }
     LF_HIP_CHECK(h, hipGetLastError());

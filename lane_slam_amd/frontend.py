@@ -287,6 +287,23 @@ class FrontEnd(object):
         return centers, counts, inertia.value, n_iter.value
 
     # ------------------------------------------------------------------ EDLines / multi-octave KeyLines
+    def set_descriptor_params(self, num_of_octave=None, width_of_band=None, reduction_ratio=None, ksize=None):
+        """BinaryDescriptor's setters (setNumOfOctaves / setWidthOfBand / setReductionRatio, Params::ksize_;
+        ref: src/line_descriptor/src/binary_descriptor_custom.cpp:119-187) on this handle: lf_set_descriptor_params.  Arguments left at
+        None keep their value.  Returns the parameters now in force as a dict."""
+        p = _lib.LfDescriptorParams()
+        self._check(self.lib.lf_get_descriptor_params(self.h, ctypes.byref(p)))
+        for k, v in (("num_of_octave", num_of_octave), ("width_of_band", width_of_band), ("reduction_ratio", reduction_ratio), ("ksize", ksize)):
+            if v is not None:
+                setattr(p, k, int(v))
+        self._check(self.lib.lf_set_descriptor_params(self.h, ctypes.byref(p)))
+        return self.descriptor_params()
+
+    def descriptor_params(self):
+        p = _lib.LfDescriptorParams()
+        self._check(self.lib.lf_get_descriptor_params(self.h, ctypes.byref(p)))
+        return {"num_of_octave": p.num_of_octave, "width_of_band": p.width_of_band, "reduction_ratio": p.reduction_ratio, "ksize": p.ksize}
+
     def edlines_params(self, **kw):
         """EDLineDetector's defaults (ref: binary_descriptor_custom.cpp:1374-1385), optionally overridden."""
         p = _lib.LfEdlinesParams()

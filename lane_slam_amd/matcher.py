@@ -21,6 +21,39 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class BinaryDescriptorParams(object):
+    """BinaryDescriptor::Params (ref: src/line_descriptor/src/binary_descriptor_custom.cpp:108-116, 189-204): the four fields with the
+    reference's defaults, read() from / write() to a mapping with the keys its cv::FileStorage node uses -- read takes numOfOctave_,
+    widthOfBand_ and reductionRatio (not ksize_, exactly as the reference), write adds numOfBand_ = 9.  apply(frontend) hands them to a
+    handle (FrontEnd.set_descriptor_params)."""
+    NUM_OF_BANDS = 9
+
+    def __init__(self):
+        self.numOfOctave_ = 1
+        self.widthOfBand_ = 7
+        self.reductionRatio = 2
+        self.ksize_ = 5
+
+    def read(self, fn):
+        # a missing key reads as 0 from a cv::FileNode (the conversion operator of an empty node)
+        self.numOfOctave_ = int(fn.get("numOfOctave_", 0))
+        self.widthOfBand_ = int(fn.get("widthOfBand_", 0))
+        self.reductionRatio = int(fn.get("reductionRatio", 0))
+        return self
+
+    def write(self, fs=None):
+        fs = {} if fs is None else fs
+        fs["numOfOctave_"] = self.numOfOctave_
+        fs["numOfBand_"] = self.NUM_OF_BANDS
+        fs["widthOfBand_"] = self.widthOfBand_
+        fs["reductionRatio"] = self.reductionRatio
+        return fs
+
+    def apply(self, frontend):
+        return frontend.set_descriptor_params(num_of_octave=self.numOfOctave_, width_of_band=self.widthOfBand_,
+                                              reduction_ratio=self.reductionRatio, ksize=self.ksize_)
+
+
 class BinaryDescriptorMatcher(object):
     def __init__(self, frontend):
         """frontend: the FrontEnd whose handle (device, stream, tie rule) the searches run on."""

@@ -117,6 +117,9 @@ void lfo_keylines(const float* lines4, int n, int rows, int cols,
 void lfo_lbd(const int16_t* dx, const int16_t* dy, int rows, int cols,
              const float* ext4, const float* angle, const int32_t* num_pixels, int n,
              float* desc72, uint8_t* code32);
+/* BinaryDescriptor::Params::widthOfBand_ for every later lfo_lbd call (default 7, 1 .. 32) */
+void lfo_lbd_set_width_of_band(int w);
+int lfo_lbd_get_width_of_band(void);
 /* a-10: exact Hamming NN, distance > 128 => idx -1, dist -1; ties -> lowest train index */
 void lfo_match(const uint8_t* query32, int nq, const uint8_t* train32, int nt,
                int32_t* idx, float* dist);

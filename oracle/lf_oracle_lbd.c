@@ -18,7 +18,12 @@
 #include <stdlib.h>
 
 #define NUM_OF_BANDS 9
-#define WIDTH_OF_BAND 7
+#define MAX_WIDTH_OF_BAND 32
+/* BinaryDescriptor::Params::widthOfBand_ (binary_descriptor_custom.cpp:108-115: 7 by default; setWidthOfBand :134-176 recomputes both
+ * Gaussian tables from it).  A process-wide switch like lfo_lsd_set_seed_order: every lfo_lbd call -- frame, KeyLines, compute -- uses it. */
+static int g_width_of_band = 7;
+void lfo_lbd_set_width_of_band(int w) { g_width_of_band = w < 1 ? 1 : (w > MAX_WIDTH_OF_BAND ? MAX_WIDTH_OF_BAND : w); }
+int lfo_lbd_get_width_of_band(void) { return g_width_of_band; }
 
 static const int COMB[32][2] = {
     {0,1},{0,2},{0,3},{0,4},{0,5},{0,6},{1,2},{1,3},{1,4},{1,5},{1,6},{2,3},{2,4},{2,5},{2,6},{2,7},
@@ -71,8 +76,9 @@ void lfo_lbd(const int16_t* pdx, const int16_t* pdy, int rows, int cols,
              const float* ext, const float* angle, const int32_t* npx, int n,
              float* desc72, uint8_t* code32)
 {
-    /* binary_descriptor_custom.cpp:217-259 (integer divisions in u and sigma kept) */
-    double gaussCoefL[WIDTH_OF_BAND * 3], gaussCoefG[NUM_OF_BANDS * WIDTH_OF_BAND];
+    /* binary_descriptor_custom.cpp:217-259 = :134-176 (integer divisions in u and sigma kept) */
+    const int WIDTH_OF_BAND = g_width_of_band;
+    double gaussCoefL[MAX_WIDTH_OF_BAND * 3], gaussCoefG[NUM_OF_BANDS * MAX_WIDTH_OF_BAND];
     {
         double u = (WIDTH_OF_BAND * 3 - 1) / 2;
         double sigma = (WIDTH_OF_BAND * 2 + 1) / 2;
@@ -83,7 +89,7 @@ void lfo_lbd(const int16_t* pdx, const int16_t* pdy, int rows, int cols,
         invsigma2 = -1 / (2 * sigma * sigma);
         for (int i = 0; i < NUM_OF_BANDS * WIDTH_OF_BAND; ++i) { double dis = i - u; gaussCoefG[i] = lfo_exp(dis * dis * invsigma2); }
     }
-    const short heightOfLSP = WIDTH_OF_BAND * NUM_OF_BANDS;
+    const short heightOfLSP = (short)(WIDTH_OF_BAND * NUM_OF_BANDS);
     const short halfHeight = (heightOfLSP - 1) / 2;
     const short realWidth = (short)cols;
     const short imageWidth = realWidth - 1;

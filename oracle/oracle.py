@@ -288,6 +288,11 @@ class Oracle(object):
         fn(_p(q), q.shape[0], _p(t), t.shape[0], ctypes.c_float(max_distance), _p(offsets), _p(idx), _p(dist))
         return offsets, idx[:total], dist[:total]
 
+    def set_width_of_band(self, w):
+        """BinaryDescriptor::setWidthOfBand (binary_descriptor_custom.cpp:134-176) for every later descriptor of this PROCESS's oracle
+        library (frames, KeyLines, compute): 7 by default."""
+        self.lib.lfo_lbd_set_width_of_band(int(w))
+
     def set_lsd_seed_order(self, mode):
         """0: raster inside a gradient bin (default); 1: libstdc++ std::sort order (the later OpenCV 3.x)."""
         self.lib.lfo_lsd_set_seed_order(int(mode))

@@ -103,5 +103,5 @@ def test_lsd_options_min_length_and_mask():
     assert 0 < cut["n"] < plain["n"]
     from lane_slam_amd import LanefrontError
     with pytest.raises(LanefrontError):
-        k.lsd_keylines_batch(gray, 1, gray=True, options=k.lsd_options(n_bins=4096))
+        k.lsd_keylines_batch(gray, 1, gray=True, options=k.lsd_options(n_bins=4097))      # (up to 4096 since round 6: tests/test_gpu_descriptor_params.py)
     k.close()
