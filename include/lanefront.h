@@ -633,6 +633,8 @@ LF_API int lf_suggested_depth(const lf_handle* h);
  * *entries = the current capacity per problem, *grown = how many times it was raised.  LF_LSD_RECORDS=<entries> | full in the
  * environment sets the starting capacity of handles created afterwards (full = the whole LSD image: never a second run). */
 LF_API int lf_lsd_list_capacity(const lf_handle* h, int* entries, int* grown);
+/* u32 words per (frame, colour) of LF_BUF_LSD_SCRATCH (lf_debug_fetch): follows the list capacity */
+LF_API int lf_lsd_scratch_stride(const lf_handle* h);
 
 /* per-kernel timing with HIP events on the handle's stream */
 #define LF_N_STAGES 13

@@ -27,7 +27,7 @@ EXPORTS = (
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
     "lf_descriptor_default_params", "lf_set_descriptor_params", "lf_get_descriptor_params",
     "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu",
-    "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_lsd_list_capacity", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
+    "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_lsd_list_capacity", "lf_lsd_scratch_stride", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
     "lf_lsd_default_options", "lf_lsd_keylines_batch_ex", "lf_keylines_batch_masked",
     "lf_matcher_add", "lf_matcher_clear", "lf_matcher_size", "lf_matcher_match", "lf_matcher_knn_match", "lf_matcher_radius_match",
 )
@@ -215,6 +215,8 @@ def load():
     lib.lf_suggested_depth.argtypes = [vp]
     lib.lf_lsd_list_capacity.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.lf_lsd_list_capacity.restype = ci
+    lib.lf_lsd_scratch_stride.argtypes = [vp]
+    lib.lf_lsd_scratch_stride.restype = ci
     lib.lf_suggested_depth.restype = ci
     lib.lf_debug_std_sort.argtypes = [vp, vp, ci, vp]
     lib.lf_debug_std_sort.restype = ci

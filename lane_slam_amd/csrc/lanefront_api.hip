@@ -1301,6 +1301,12 @@ extern "C" int lf_lsd_list_capacity(const lf_handle* h, int* entries, int* grown
     return LF_OK;
 }
 
+extern "C" int lf_lsd_scratch_stride(const lf_handle* h)
+{
+    if (!h) return LF_ERR_NOT_INITIALISED;
+    return (int)lsd_grow_reg_stride(h->lsd);
+}
+
 extern "C" int lf_suggested_depth(const lf_handle* h)
 {
     if (!h) return LF_ERR_NOT_INITIALISED;

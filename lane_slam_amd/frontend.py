@@ -511,7 +511,7 @@ class FrontEnd(object):
             _lib.LF_BUF_LBD_DY: ((n_frames, self.rows, self.cols), np.int16),
             _lib.LF_BUF_LSD_COUNTS: ((n_frames, 3), np.int32),
             _lib.LF_BUF_LSD_NLOW: ((n_frames, 3), np.int32),
-            _lib.LF_BUF_LSD_SCRATCH: ((n_frames, 3, max(Ps, 3 * (24576 if Ps > 400000 else 8192))), np.uint32),     # k_lsd_grow.hip lsd_grow_reg_stride
+            _lib.LF_BUF_LSD_SCRATCH: ((n_frames, 3, int(self.lib.lf_lsd_scratch_stride(self.h))), np.uint32),     # follows the list capacity (k_lsd_grow.hip lsd_grow_reg_stride)
         }
         shape, dt = shapes[buffer_id]
         a = np.empty(shape, dt)

@@ -56,10 +56,26 @@ class BinaryDescriptorParams(object):
 
 class BinaryDescriptorMatcher(object):
     def __init__(self, frontend):
-        """frontend: the FrontEnd whose handle (device, stream, tie rule) the searches run on."""
+        """frontend: the FrontEnd whose handle (device, stream, tie rule) the searches run on.  The dataset lives IN that handle
+        (lf_matcher_add / lf_matcher_clear): one matcher per FrontEnd at a time -- a second one would share, and on construction wipe, the
+        first one's set, unlike the reference's independent objects -- so a second construction while the first is alive is refused;
+        close() (or dropping the object) releases the handle for another."""
+        import weakref
+        prev = getattr(frontend, "_matcher_ref", None)
+        if prev is not None and prev() is not None and not prev()._closed:
+            raise ValueError("this FrontEnd already carries a BinaryDescriptorMatcher's dataset: close() it first, or use another FrontEnd")
         self.fe = frontend
         self.lib = frontend.lib
+        self._closed = False
         self.fe._check(self.lib.lf_matcher_clear(self.fe.h))
+        frontend._matcher_ref = weakref.ref(self)
+
+    def close(self):
+        """Empty the set and give the FrontEnd's dataset slot back."""
+        if not self._closed:
+            self._closed = True
+            if getattr(self.fe, "h", None):
+                self.lib.lf_matcher_clear(self.fe.h)
 
     # ---- the set
     def add(self, descriptors):
