@@ -637,7 +637,7 @@ LF_API int lf_lsd_list_capacity(const lf_handle* h, int* entries, int* grown);
 LF_API int lf_lsd_scratch_stride(const lf_handle* h);
 
 /* per-kernel timing with HIP events on the handle's stream */
-#define LF_N_STAGES 13
+#define LF_N_STAGES 14
 LF_API int lf_set_profiling(lf_handle* h, int enabled);
 /* ms accumulated per stage since the last reset, and launches counted */
 LF_API int lf_get_timing(lf_handle* h, double* ms_per_stage, int32_t* launches_per_stage, int n);

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # -DLFG_STAMPS); the default is the in-tree product build.
 SO_PATH = os.environ.get("LANEFRONT_LIBRARY") or os.path.join(_HERE, "liblanefront.so")
 
-LF_N_STAGES = 13
+LF_N_STAGES = 14
 LF_MAP_N_STAGES = 4
 LF_MSG_DETECTOR, LF_MSG_GROUND, LF_MSG_FILTERED = 0, 1, 2
 (LF_BUF_BGR, LF_BUF_MASKS, LF_BUF_EDGES, LF_BUF_LSD_ANGLE, LF_BUF_LSD_MODGRAD, LF_BUF_LSD_ORDER,

@@ -24,7 +24,7 @@ constexpr int kCompCap = 1024;      // component list entries per problem (more 
 
 enum Stage {
     ST_PRE = 0, ST_CANNY, ST_HYST, ST_LSD_GRAD, ST_LSD_ORDER, ST_LSD_GROW, ST_SEGMENTS,
-    ST_LBD_GRAD, ST_LBD, ST_ASSOC_PACK, ST_ASSOC, ST_MISC, ST_JPEG, ST_COUNT
+    ST_LBD_GRAD, ST_LBD, ST_ASSOC_PACK, ST_ASSOC, ST_MISC, ST_JPEG, ST_LSD_LABEL, ST_COUNT
 };
 static_assert(ST_COUNT == LF_N_STAGES, "stage table out of sync with lanefront.h");
 

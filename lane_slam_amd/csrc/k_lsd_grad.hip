@@ -83,9 +83,12 @@ __global__ __launch_bounds__(256) void k_lsd_classify(LsdParams p, ResizeTables 
 // LDS as one 64-bit window per row.  Angles/sines are evaluated after compacting the tile's defined
 // pixels so the expensive double-precision path runs on full waves.
 #ifndef LF_LSD_GRAD_THREADS
-#define LF_LSD_GRAD_THREADS 256
+#define LF_LSD_GRAD_THREADS 512
 #endif
 constexpr int LG_T = LF_LSD_GRAD_THREADS;      // threads per tile
+#ifndef LF_GRAD_DIAG
+#define LF_GRAD_DIAG 0          // timing experiments only: bits 1 / 2 / 4 / 8 leave out the column filter / the two resizes / the row filter
+#endif
 #ifndef LF_GRAD_WAVES
 #define LF_GRAD_WAVES 0
 #endif
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
             }
         } else if (use_table && rw <= 64) {
             const int msk = (1 << p.ntaps) - 1;
-            for (int idx = threadIdx.x; idx < rh * nsx; idx += LG_T) {
+            for (int idx = threadIdx.x; idx < (LF_GRAD_DIAG & 8 ? 0 : rh * nsx); idx += LG_T) {
                 const int ry = small ? div_small(idx, m_nsx) : idx / nsx, cx = idx - ry * nsx;
                 const unsigned long long rb = rowbits[ry];
                 F[idx] = rb ? T[(int)(rb >> cx) & msk] : 0.0;
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         }
         __syncthreads();
         // column filter
-        for (int idx = threadIdx.x; idx < nsy * nsx; idx += LG_T) {
+        for (int idx = threadIdx.x; idx < (LF_GRAD_DIAG & 1 ? 0 : nsy * nsx); idx += LG_T) {
             const double* S = F + idx + h * nsx;                  // (by + h, cx) of idx = by * nsx + cx
             // F holds sums of positive constants or +0.0, so an all-zero window gives exactly +0.0 through the same
             // arithmetic (testing the window for zero first cost twice the instructions of the seven multiply-adds)
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         }
         __syncthreads();
         // horizontal resize
-        for (int idx = threadIdx.x; idx < nsy * nox; idx += LG_T) {
+        for (int idx = threadIdx.x; idx < (LF_GRAD_DIAG & 2 ? 0 : nsy * nox); idx += LG_T) {
             const int by = small ? div_small(idx, m_nox) : idx / nox, ox = idx - by * nox;
             const int dx = X0 + ox;
             const int sx = t_xofs[ox];
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
         }
         __syncthreads();
         // vertical resize
-        for (int idx = threadIdx.x; idx < noy * nox; idx += LG_T) {
+        for (int idx = threadIdx.x; idx < (LF_GRAD_DIAG & 4 ? 0 : noy * nox); idx += LG_T) {
             const int oy = small ? div_small(idx, m_nox) : idx / nox, ox = idx - oy * nox;
             const int r0 = t_y0[oy], r1 = t_y1[oy];
             Sc[oy * (GT + 1) + ox] = Hb[r0 * (GT + 1) + ox] * (double)t_yb[2 * oy] + Hb[r1 * (GT + 1) + ox] * (double)t_yb[2 * oy + 1];

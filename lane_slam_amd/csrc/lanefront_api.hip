@@ -21,7 +21,7 @@ using namespace lf;
 static const char* kStageNames[LF_N_STAGES] = {
     "pre(resize+correct+hsv+masks+dilate)", "canny_nms", "canny_hysteresis", "lsd_blur_resample_grad",
     "lsd_order", "lsd_grow", "segments(normal+project+sanity)", "lbd_gray_blur_sobel", "lbd_descriptor",
-    "assoc_pack", "assoc_mfma", "misc", "jpeg(idct+upsample+color)" };
+    "assoc_pack", "assoc_mfma", "misc", "jpeg(idct+upsample+color)", "lsd_label(components+launch order)" };
 
 struct EvPair { hipEvent_t a, b; int st; };
 struct DevBuf {
@@ -727,7 +727,7 @@ static int run_detect(lf_handle* h, const uint8_t* d_frames, int n, bool from_wo
             launch_lsd_seed32(h->lsd, n, h->d_nrec, h->d_norder, h->d_overflow + 5, h->d_maxgrad, h->d_cxy, h->d_cmod, h->d_laddr, h->d_lmod, h->d_nlow, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, 0, s);
     }
     {
-        StageTimer t(h, ST_LSD_ORDER);
+        StageTimer t(h, ST_LSD_LABEL);          // (its own stage since round 6: two brackets of different content under one name made the average meaningless)
         launch_lsd_label(h->lsd, n, h->d_norder, h->d_cxy, h->d_row_start, h->d_clabel, h->d_comp_list, h->d_comp_count, h->d_comp_key, h->d_reg, s);
         static const bool no_rank = getenv("LF_DIAG_NO_RANK") != nullptr;
         if (!no_rank) launch_lsd_rank(n * 3, h->d_comp_key, h->d_perm, s);
