@@ -53,7 +53,8 @@ for f in glob.glob(os.path.join(T, "bench_ab_*.json")) + glob.glob(os.path.join(
 if os.path.exists(os.path.join(T, "seed_stamps.txt")):
     with open(os.path.join(T, "seed_stamps.txt")) as f, open(os.path.join(P, prefix + "_seed32_stamps.txt"), "w") as g:
         g.writelines(l for l in f if l.startswith("[seed32"))
-for name, dst in (("whatif.txt", "_whatif.txt"), ("handle_footprint.txt", "_handle_footprint.txt")):
+for name, dst in (("whatif.txt", "_whatif.txt"), ("handle_footprint.txt", "_handle_footprint.txt"), ("content_whatif.txt", "_content_whatif.txt"),
+                  ("grow_stamps_SYNTHETIC.txt", "_grow_stamps_synthetic.txt"), ("grow_stamps_REAL.txt", "_grow_stamps_real.txt"), ("grow_stamps_CLUTTER.txt", "_grow_stamps_clutter.txt")):
     if os.path.exists(os.path.join(T, name)):
         with open(os.path.join(T, name)) as f, open(os.path.join(P, prefix + dst), "w") as g:
             g.writelines(l for l in f if "amdgpu.ids" not in l)

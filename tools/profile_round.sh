@@ -14,6 +14,11 @@ LF_TIE_SHAPE=small python tools/assoc_rate.py --tie-rule mihasher --pairs 4096x5
 for ab in "opencv32 lowest" "opencv30 mihasher" "opencv30 lowest"; do set -- $ab; python bench.py --steps 100 --secondary none --cpu-frames -1 --seed-order $1 --tie-rule $2 > $R/gpurun_out/$T/bench_ab_$1_$2.json 2>/dev/null; done
 python bench.py --geometry hd --steps 30 --secondary none --cpu-frames -1 > $R/gpurun_out/$T/bench_hd.json 2>/dev/null
 if [ -f lane_slam_amd/liblanefront_sstamps.so ]; then LANEFRONT_LIBRARY=$R/lane_slam_amd/liblanefront_sstamps.so python tools/seed_stamps.py > $R/gpurun_out/$T/seed_stamps.txt 2>&1; fi
+# round 6: the growing kernel's phase stamps on the three kinds of content (diagnostic build), the content rows with growing left out
+if [ -f lane_slam_amd/liblanefront_stamps.so ]; then
+  for m in SYNTHETIC REAL CLUTTER; do env LF_STAMPS_$m=1 LANEFRONT_LIBRARY=$R/lane_slam_amd/liblanefront_stamps.so python tools/grow_stamps.py 64 > $R/gpurun_out/$T/grow_stamps_$m.txt 2>&1; done
+fi
+for c in real clutter; do for sk in "" grow; do echo -n "$c skip=[$sk] "; LF_DIAG_SKIP=$sk python tools/pipe_content.py --content $c --rounds 4 2>&1 | tail -1; done; done > $R/gpurun_out/$T/content_whatif.txt 2>&1
 LF_ALLOC_TRACE=1 python tools/handle_footprint.py 2> $R/gpurun_out/$T/handle_footprint.txt
 bash tools/whatif_round.sh > $R/gpurun_out/$T/whatif.txt 2>&1
 python tools/assoc_rate.py --gating --pairs 16384x50000 >> $R/gpurun_out/$T/assoc_rate.txt 2>&1
