@@ -47,6 +47,10 @@ __device__ unsigned long long g_assoc_stamps[8 * 8192];
 constexpr int AQW = 256;      // queries per workgroup (4 waves x 64)
 constexpr int AM = 64;         // map entries per LDS tile
 constexpr int kMaxBlocksPerChunk = 512;   // the in-accumulator block counter t has 9 bits
+#ifndef LF_ASSOC_SMALL_MAX
+#define LF_ASSOC_SMALL_MAX 12288
+#endif
+constexpr int kAssocSmallMax = LF_ASSOC_SMALL_MAX;   // associations of up to this many queries take the small shape (launch_assoc_core)
 
 // Packs map rows for lf_associate's raw-map form (the live map keeps its rows packed: k_map.hip).  One thread per
 // (row, code byte): 8 int8 = 2 dwords; thread 0 of a row also writes the row's ninth-step operand (zero counter bytes,
@@ -106,7 +110,9 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
     // measured at 20-30 us per workgroup here).  The last workgroup of a query block to arrive reads the rows of all
     // chunks with sc1 loads, writes idx / dist for its 256 queries and puts the counter back to zero, so an association is
     // ONE kernel launch: no init pass, no finish pass.
-    __hip_atomic_store(part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * AQW + mine_q, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (QW = queries per workgroup: 256, or 128 in the small shape -- there only the first 128 threads carry a query, and mine_q < QW)
+    if (QW == AQW || (int)threadIdx.x < QW)
+        __hip_atomic_store(part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * QW + mine_q, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __shared__ int s_last;
     __syncthreads();
@@ -114,14 +120,15 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
     __syncthreads();
     LF_STAMP(5);
     if (!s_last) return;
-    const int qq = blockIdx.x * AQW + threadIdx.x;
+    const bool has_q = QW == AQW || (int)threadIdx.x < QW;
+    const int qq = has_q ? blockIdx.x * QW + (int)threadIdx.x : nq;       // (threads without a query: beyond the end)
     int best_ham = -1;                                                     // this query's reported distance (-1: none)
     if (qq < nq) {
         // eight rows in flight per thread: the merge is the serial tail of the launch (the last workgroup of the query block
         // runs it alone), a dependent load per chunk would cost a memory round trip each
         unsigned int v = 0x7fffffffu;
-        const unsigned int* col = part + (size_t)blockIdx.x * AQW + threadIdx.x;
-        const size_t stride = (size_t)gridDim.x * AQW;
+        const unsigned int* col = part + (size_t)blockIdx.x * QW + threadIdx.x;
+        const size_t stride = (size_t)gridDim.x * QW;
         const unsigned int nc = gridDim.y;
         unsigned int c = 0;
         for (; c + 8 <= nc; c += 8) {
@@ -140,11 +147,15 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
         // For the tie pass (k_assoc_ties.hip), in the same breath: per map chunk, the queries of this block whose best distance in the
         // chunk IS their best distance overall -- a candidate as near as the optimum can sit nowhere else.  Wave w of the block
         // writes them as piece (chunk, 4 blockIdx.x + w): up to 64 query numbers and a count (no atomics, no kernel of its own).
+        // (the tie pass counts pieces per 256-query block, four each: the small shape's 128-query workgroups write two, and its last
+        // workgroup also the empty ones an odd number of them leaves)
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        const int n_pieces = gridDim.x * 4, piece = blockIdx.x * 4 + wv;
+        const int n_pieces = QW == AQW ? (int)gridDim.x * 4 : ((nq + AQW - 1) / AQW) * 4;
+        const int piece = blockIdx.x * (QW / 64) + wv;
+        const bool writes_piece = wv < QW / 64 || (blockIdx.x == gridDim.x - 1 && piece < n_pieces);
         if (qq < nq) tie_res[qq] = ~0ull;
-        const unsigned int* col = part + (size_t)blockIdx.x * AQW + threadIdx.x;
-        const size_t stride = (size_t)gridDim.x * AQW;
+        const unsigned int* col = part + (size_t)blockIdx.x * QW + threadIdx.x;
+        const size_t stride = (size_t)gridDim.x * QW;
         const unsigned int nc = gridDim.y;
         for (unsigned int c0 = 0; c0 < nc; c0 += 8) {
             unsigned int t[8];
@@ -158,7 +169,7 @@ __device__ __forceinline__ void assoc_publish_and_merge(unsigned int mine, int m
                 // discovery keys are (weight 0, substring 0, place 0), and the train index decides -- the lowest, which this pass reports)
                 const bool on = best_ham > 0 && t[k] != 0x7fffffffu && (int)(t[k] >> 22) == best_ham;
                 const unsigned long long bo = __ballot(on);
-                if (lane == 0) tie_counts[(size_t)c * n_pieces + piece] = __popcll(bo);
+                if (lane == 0 && writes_piece) tie_counts[(size_t)c * n_pieces + piece] = __popcll(bo);
                 if (on) tie_pieces[((size_t)c * n_pieces + piece) * 64 + __popcll(bo & ((1ull << lane) - 1ull))] = qq;
             }
         }
@@ -310,7 +321,7 @@ __device__ __forceinline__ void assoc_body(const uint8_t* __restrict__ q, const 
 // The ungated kernel on the FP4 matrix instruction (k_assoc_loop.inc, LF_ASSOC_LOOP_FP4; gen_assoc_loop.py gen_fp4 has the
 // arithmetic): same work split and the same reduce / publish / merge tail as assoc_body; the map rows are e2m1 nibbles
 // (128 bytes per row, 8 KB tiles), the queries are expanded from the raw codes through a byte -> 8 nibbles table.
-template <bool GATED>
+template <bool GATED, int NRB = 2>
 __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
                                                const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
                                                int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk,
@@ -322,14 +333,14 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
     LF_STAMP(0); LF_STAMP(1);
     const int nm = nm_dev ? min(nm_bound, *nm_dev) : nm_bound;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int QW = 256;
-    const int q0 = blockIdx.x * QW + wave * 64;
+    constexpr int QW = 128 * NRB;                 // NRB 32-query row blocks per wave (1: the small shape, k_assoc_fp4_s)
+    const int q0 = blockIdx.x * QW + wave * 32 * NRB;
     const int r32 = lane & 31, half = lane >> 5;
     const int m_begin = blockIdx.y * m_chunk;
     const int m_end = min(nm_pad, m_begin + m_chunk);
     const int n_tiles = __builtin_amdgcn_readfirstlane((m_end - m_begin) / AM);
     unsigned int mine = 0x7fffffffu;
-    int mine_q = threadIdx.x;
+    int mine_q = NRB == 2 ? (int)threadIdx.x : wave * 32 + (lane & 31);
     if (n_tiles > 0) {
         xtab[threadIdx.x] = assoc_fp4_expand(threadIdx.x);
         // step five's map-side operand per block number t = 64 a + 8 b + c: minus the octal digits, each digit two e2m1 values
@@ -344,7 +355,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
         LF_STAMP(6);
         v4i A[2][4], AXC[2];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NRB; ++b) {
             const int qi = q0 + 32 * b + r32;
             uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;        // padding rows: any operand will do, they are never reported
             if (qi < nq) {
@@ -374,7 +385,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
         const uint32_t lds_tile = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)tile;
         const uint32_t vfrag = lds_tile + half * 1024 + r32 * 16;
         const uint32_t voff = (uint32_t)lane * 16u;
-        const uint32_t vdump = lds_tile + wave * 8192 + lane * 16;
+        const uint32_t vdump = lds_tile + wave * (4096 * NRB) + lane * 16;
         const uint64_t mbase = (uint64_t)(size_t)(mx + (size_t)m_begin * 128 + wave * 1024);
         const uint32_t mlo = __builtin_amdgcn_readfirstlane((uint32_t)mbase), mhi = __builtin_amdgcn_readfirstlane((uint32_t)(mbase >> 32));
         const uint64_t mpair = ((uint64_t)mhi << 32) | mlo;
@@ -387,6 +398,14 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
             const uint32_t clo = __builtin_amdgcn_readfirstlane((uint32_t)cbase), chi = __builtin_amdgcn_readfirstlane((uint32_t)(cbase >> 32));
             const uint64_t cpair = ((uint64_t)chi << 32) | clo;
             const uint32_t m0c = __builtin_amdgcn_readfirstlane(lds_ctile + (wave & 1) * 1024);
+            if (NRB == 1)
+            asm volatile(LF_ASSOC_LOOP_FP4_GATED_S
+                         :
+                         : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [ax] "v"(AX), [scl5] "v"(scl5), [vtab] "v"(vtab),
+                           [axc0] "v"(AXC[0]), [vcfrag] "v"(vcfrag), [cbase] "s"(cpair), [m0c] "s"(m0c),
+                           [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair), [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
+                         : LF_ASSOC_LOOP_CLOBBERS_FP4_S);
+            else
             asm volatile(LF_ASSOC_LOOP_FP4_GATED
                          :
                          : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [a10] "v"(A[1][0]), [a11] "v"(A[1][1]),
@@ -394,7 +413,13 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
                            [axc1] "v"(AXC[1]), [vcfrag] "v"(vcfrag), [cbase] "s"(cpair), [m0c] "s"(m0c),
                            [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair), [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
                          : LF_ASSOC_LOOP_CLOBBERS_FP4);
-        } else
+        } else if (NRB == 1)
+        asm volatile(LF_ASSOC_LOOP_FP4_S
+                     :
+                     : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [ax] "v"(AX), [scl5] "v"(scl5), [vtab] "v"(vtab),
+                       [vfrag] "v"(vfrag), [voff] "v"(voff), [vdump] "v"(vdump), [mbase] "s"(mpair), [m0base] "s"(m0base), [ntiles] "s"(n_tiles)
+                     : LF_ASSOC_LOOP_CLOBBERS_FP4_S);
+        else
         asm volatile(LF_ASSOC_LOOP_FP4
                      :
                      : [a00] "v"(A[0][0]), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a03] "v"(A[0][3]), [a10] "v"(A[1][0]), [a11] "v"(A[1][1]),
@@ -403,9 +428,9 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
                      : LF_ASSOC_LOOP_CLOBBERS_FP4);
         LF_STAMP(3);
         // keys are floats here: 512 * dot - t, exact integers
-        float* dump = reinterpret_cast<float*>(tile) + wave * 2048;
+        float* dump = reinterpret_cast<float*>(tile) + wave * (1024 * NRB);
 #pragma unroll 2
-        for (int g = 0; g < 8; ++g) {                                  // four keys per 16-byte access: no bank conflicts
+        for (int g = 0; g < 4 * NRB; ++g) {                            // four keys per 16-byte access: no bank conflicts
             float4* slot = reinterpret_cast<float4*>(dump + g * 256 + lane * 4);
             const float4 k4 = *slot;
             const float kf[4] = { k4.x, k4.y, k4.z, k4.w };
@@ -423,7 +448,7 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
             *reinterpret_cast<int4*>(slot) = make_int4(v[0], v[1], v[2], v[3]);
         }
         __syncthreads();
-        {
+        if (NRB == 2) {
             const int i = lane & 31, h = lane >> 5;
             const int* src = reinterpret_cast<const int*>(dump) + (i >> 2) * 256 + h * 128 + (i & 3);
             int v = 0x7fffffff;
@@ -432,7 +457,27 @@ __device__ __forceinline__ void assoc_body_fp4(const uint8_t* __restrict__ q, co
             const int b = i >> 4, r = i & 15;
             mine = (unsigned int)v;
             mine_q = wave * 64 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+        } else {
+            // one row block: 16 running registers x 2 k-halves = 32 queries per wave; the two halves of the wave split the 32 columns of
+            // a query between them and meet through one DPP-free shuffle
+            const int i = lane & 15, h = (lane >> 4) & 1, part2 = lane >> 5;
+            const int* src = reinterpret_cast<const int*>(dump) + (i >> 2) * 256 + h * 128 + (i & 3);
+            int v = 0x7fffffff;
+#pragma unroll 8
+            for (int k = 0; k < 16; ++k) v = min(v, src[((16 * part2 + ((k + (i >> 2)) & 15)) & 31) * 4]);
+            v = min(v, __shfl_xor(v, 32));
+            const int r = i;
+            mine = (unsigned int)v;
+            mine_q = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         }
+    }
+    // (small shape: the keys of the workgroup's 128 queries sit in the first 32 lanes of its four waves: hand them to threads 0 .. 127)
+    if (NRB == 1) {
+        __shared__ unsigned int s_keys[128];
+        __syncthreads();
+        if ((threadIdx.x & 63) < 32) s_keys[mine_q] = mine;
+        __syncthreads();
+        if (threadIdx.x < 128) { mine = s_keys[threadIdx.x]; mine_q = threadIdx.x; }
     }
     LF_STAMP(4);
     assoc_publish_and_merge<QW>(mine, mine_q, nq, max_distance, part, done, idx, dist, tie_pieces, tie_counts, tie_res);
@@ -447,6 +492,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ uint32_t xtab[256];
     __shared__ uint32_t ttab[1024];
     assoc_body_fp4<false>(q, nullptr, nq, mx, nullptr, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab, ttab, tie_pieces, tie_counts, tie_res);
+}
+
+// The SMALL shape (round 6): one row block per wave, three tile buffers -- 24 KB + tables and ~160 registers per workgroup, three waves per
+// SIMD.  In a pipeline whose CUs are full of region-growing waves the big shape's workgroups (54 KB, 239 registers: three growing waves
+// must leave every SIMD of a CU) wait four to ten times their own duration for room; this one runs longer alone and starts sooner.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_assoc_fp4_s(const uint8_t* __restrict__ q, int nq, const int8_t* __restrict__ mx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 128];     // three 8 KB tile buffers; the four 4 KB key dumps reuse them
+    __shared__ uint32_t xtab[256];
+    __shared__ uint32_t ttab[1024];
+    assoc_body_fp4<false, 1>(q, nullptr, nq, mx, nullptr, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, nullptr, xtab, ttab, tie_pieces, tie_counts, tie_res);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_assoc_fp4_gated_s(const uint8_t* __restrict__ q, const uint8_t* __restrict__ qcolor, int nq,
+                                               const int8_t* __restrict__ mx, const int8_t* __restrict__ mcx,
+                                               int nm_bound, const int* __restrict__ nm_dev, int nm_pad, int m_chunk, int max_distance,
+                                               unsigned int* __restrict__ part, int* __restrict__ done, int32_t* __restrict__ idx, float* __restrict__ dist,
+                                               int* __restrict__ tie_pieces, int* __restrict__ tie_counts, unsigned long long* __restrict__ tie_res)
+{
+    __shared__ __attribute__((aligned(1024))) int8_t tile[3 * AM * 128];
+    __shared__ __attribute__((aligned(1024))) int8_t ctile[3 * AM * 32];
+    __shared__ uint32_t xtab[256];
+    __shared__ uint32_t ttab[1024];
+    assoc_body_fp4<true, 1>(q, qcolor, nq, mx, mcx, nm_bound, nm_dev, nm_pad, m_chunk, max_distance, part, done, idx, dist, tile, ctile, xtab, ttab, tie_pieces, tie_counts, tie_res);
 }
 
 // colour gated: one more matrix step per row block (gen_fp4 gated = True), the map's colour rows stream beside the tiles
@@ -509,7 +580,7 @@ size_t assoc_rows_padded_m(int nm) { return ((size_t)nm + AM - 1) / AM * AM; }
 
 // part[] (one word per query and map chunk, written before it is read by every launch) and done[] (one arrival counter
 // per 256-query block, idle 0: the kernel leaves it idle, so it is cleared only when it is (re)allocated)
-static hipError_t assoc_scratch_reserve(AssocScratch& w, size_t qblocks, size_t splits, hipStream_t s)
+static hipError_t assoc_scratch_reserve(AssocScratch& w, size_t qblocks, size_t splits, size_t counters, hipStream_t s)
 {
     hipError_t e;
     if (qblocks * splits > w.cap_part) {
@@ -518,9 +589,9 @@ static hipError_t assoc_scratch_reserve(AssocScratch& w, size_t qblocks, size_t 
         if ((e = hipMalloc((void**)&w.part, cap * AQW * sizeof(unsigned int))) != hipSuccess) return e;
         w.cap_part = cap;
     }
-    if (qblocks > w.cap_blocks) {
+    if (counters > w.cap_blocks) {                          // (one arrival counter per workgroup column: 128-query blocks in the small shape)
         if (w.done) { if ((e = hipStreamSynchronize(s)) != hipSuccess) return e; (void)hipFree(w.done); w.done = nullptr; w.cap_blocks = 0; }
-        const size_t cap = qblocks + qblocks / 2 + 8;
+        const size_t cap = counters + counters / 2 + 8;
         if ((e = hipMalloc((void**)&w.done, cap * sizeof(int))) != hipSuccess) return e;
         if ((e = hipMemsetAsync(w.done, 0, cap * sizeof(int), s)) != hipSuccess) return e;
         w.cap_blocks = cap;
@@ -550,10 +621,18 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     const int nm_pad = (int)assoc_rows_padded_m(nm);
     const int tiles = nm_pad / AM;
     const int min_splits = (nm_pad + (kMaxBlocksPerChunk * 32) - 1) / (kMaxBlocksPerChunk * 32);
-    const int qblocks = (nq + AQW - 1) / AQW;
+    // The shape: big = 256 queries per workgroup (two row blocks per wave, six tile buffers: 54 KB, 239 registers -- the fastest alone);
+    // small = 128 (one row block, three buffers: 29 KB, ~160 registers -- the one that finds room beside other batches' region growing).
+    // LF_ASSOC_SHAPE=big|small forces one; otherwise small up to kAssocSmallMax queries (the pipelined front end's batches), big beyond.
+    static const int shape_env = getenv("LF_ASSOC_SHAPE") ? (getenv("LF_ASSOC_SHAPE")[0] == 's' ? 1 : (getenv("LF_ASSOC_SHAPE")[0] == 'b' ? 2 : 0)) : 0;
+    static const bool force_i8 = getenv("LF_ASSOC_INT8") != nullptr;
+    const bool small = !force_i8 && (shape_env == 1 || (shape_env == 0 && nq <= kAssocSmallMax));
+    const int qw = small ? AQW / 2 : AQW;
+    const int qblocks = (nq + qw - 1) / qw;
     // 2 workgroups are resident per CU: split the map so that the grid is one round of the 512 slots -- long chunks
-    // amortise the query expansion and the final cross-lane reduction (measured: 512 > 1024 > 768 > 256)
-    static const int slots = getenv("LF_ASSOC_SLOTS") ? atoi(getenv("LF_ASSOC_SLOTS")) : 512;
+    // amortise the query expansion and the final cross-lane reduction (measured: 512 > 1024 > 768 > 256); the small shape: 3 per CU
+    static const int slots_env = getenv("LF_ASSOC_SLOTS") ? atoi(getenv("LF_ASSOC_SLOTS")) : 0;
+    const int slots = slots_env > 0 ? slots_env : (small ? 1024 : 512);
     int splits = slots / qblocks;
     if (splits > 128) splits = 128;            // one or two query blocks: more, shorter chunks only lengthen the merge (32 -> 19 us at 256 x 50 000)
     if (splits < min_splits) splits = min_splits;
@@ -561,13 +640,14 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     if (splits < 1) splits = 1;
     const int m_chunk = (tiles + splits - 1) / splits * AM;
     splits = (nm_pad + m_chunk - 1) / m_chunk;
-    hipError_t e = assoc_scratch_reserve(w, (size_t)qblocks, (size_t)splits, s);
+    const int qblocks256 = (nq + AQW - 1) / AQW;                   // what the scratch sizes and the tie pass count in
+    hipError_t e = assoc_scratch_reserve(w, (size_t)qblocks256, (size_t)splits, (size_t)qblocks, s);
     if (e != hipSuccess) return e;
-    w.qblocks = qblocks; w.splits = splits; w.m_chunk = m_chunk;
+    w.qblocks = qblocks256; w.splits = splits; w.m_chunk = m_chunk;
     // the tie pass's lists are written by this launch's merge step when the caller asked for them (w.tie_res: the result words)
     int *tie_pieces = nullptr, *tie_counts = nullptr;
     if (w.tie_res) {
-        const size_t n_pieces = (size_t)qblocks * 4;
+        const size_t n_pieces = (size_t)qblocks256 * 4;
         const size_t need = (size_t)splits * n_pieces * 64 + (size_t)splits * n_pieces;
         if (need > w.cap_list) {
             if (w.tie_list) (void)hipFree(w.tie_list);
@@ -582,8 +662,9 @@ hipError_t launch_assoc_core(const uint8_t* q, const uint8_t* qcolor, int nq, co
     unsigned long long* tie_res = w.tie_res;
     // ungated: the FP4 kernel (its map operands are e2m1 rows: MapDevice::fp4 / launch_assoc_pack_map(fp4 = 1));
     // LF_ASSOC_INT8=1 keeps the int8 kernel for A/B runs -- the caller's operands must then be int8 rows
-    static const bool force_i8 = getenv("LF_ASSOC_INT8") != nullptr;
-    if (gating && !force_i8) hipLaunchKernelGGL(k_assoc_fp4_gated, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
+    if (small && gating) hipLaunchKernelGGL(k_assoc_fp4_gated_s, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
+    else if (small) hipLaunchKernelGGL(k_assoc_fp4_s, dim3(qblocks, splits), dim3(256), 0, s, q, nq, mx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
+    else if (gating && !force_i8) hipLaunchKernelGGL(k_assoc_fp4_gated, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
     else if (gating) hipLaunchKernelGGL(k_assoc, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
     else if (!force_i8) hipLaunchKernelGGL(k_assoc_fp4, dim3(qblocks, splits), dim3(256), 0, s, q, nq, mx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);
     else hipLaunchKernelGGL(k_assoc_plain, dim3(qblocks, splits), dim3(256), 0, s, q, qcolor, nq, mx, mcx, nm, nm_dev, nm_pad, m_chunk, max_distance, w.part, w.done, idx, dist, tie_pieces, tie_counts, tie_res);

@@ -183,3 +183,29 @@ def test_query_mask_of_the_matcher():
         s2, q2 = fe.select_queries(q, mk)
         assert len(q2) == int(mk.sum()) and np.array_equal(s2, q[mk != 0])
     fe.close()
+
+
+@pytest.mark.parametrize("nq", [129, 300, 385, 1, 12288, 12289, 13000])
+def test_both_shapes_of_the_distance_pass_list_ties_alike(nq):
+    """Round 6: the distance pass has a small shape (128 queries per workgroup: associations of up to 12 288 queries) beside the big one
+    (256).  Both write the tie pass's lists per 256-query block -- the small shape two pieces per workgroup, its last workgroup also the
+    empty pieces an odd number of 128-query blocks leaves.  Ties planted in the LAST queries (the partial block) and the first; every
+    index against the oracle's literal Mihasher rule.  (12 289 and 13 000: the big shape.)"""
+    from oracle.oracle import Oracle
+    o = Oracle(default_config("parity"))
+    fe = FrontEnd(default_config("parity"))
+    rng = np.random.default_rng(1000 + nq)
+    nt = 3000 if nq > 2000 else 20000
+    train = rng.integers(0, 256, (nt, 32), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, 32), dtype=np.uint8)
+    planted = sorted(set([0, nq - 1, max(nq - 2, 0), nq // 2] + [int(v) for v in rng.integers(0, nq, 40)]))
+    for i in planted:
+        d = int(rng.integers(1, 40))
+        for _ in range(3):
+            train[int(rng.integers(0, nt))] = _flip(rng, q[i], d)
+    wi, wd, ties = o.match_mih(q, train)
+    assert (ties[planted] > 1).sum() >= min(len(planted), 3) - 1
+    gi, gd = fe.associate(q, train)
+    assert np.array_equal(gd, wd)
+    assert np.array_equal(gi, wi), "%d of %d indices differ" % ((gi != wi).sum(), nq)
+    fe.close()

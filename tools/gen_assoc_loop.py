@@ -195,7 +195,7 @@ def gen(gated):
     return L
 
 
-def gen_fp4(nbuf=6, gated=False):
+def gen_fp4(nbuf=6, gated=False, nrb=2):
     """The ungated loop on the FP4 matrix instruction (gfx950 only): code bits as e2m1 +-1 nibbles, 64 bits per
     v_mfma_scale_f32_32x32x64_f8f6f4 (same 32 cycles as the int8 32x32x32: twice the bits per cycle), the query side
     scaled by 2^9 through the E8M0 block scale, f32 accumulation (exact: |512 dot| <= 2^17).  Four matrix steps per
@@ -214,11 +214,20 @@ def gen_fp4(nbuf=6, gated=False):
     gated: colour gating as one more matrix step per row block, first in the chain (C = nt): query side 6.0 in the nibble
     of ITS colour (k-half 0, block scale 2^12), map side -6.0 in the nibbles of the OTHER colours (32-byte rows streamed
     beside the tiles like the int8 kernel's ninth-step rows) -> -147 456 whenever the colours differ, below every key within
-    128 bits (>= -511).  v[232:235] BXC (refreshed in place like the fragments), v236 / v237 its read bases, v238 its scale."""
+    128 bits (>= -511).  v[232:235] BXC (refreshed in place like the fragments), v236 / v237 its read bases, v238 its scale.
+    nrb = 1 (round 6, the SMALL shape for pipelined use: k_assoc_fp4_s): ONE 32-query row block per wave -- 16 accumulator,
+    16 running and 16 + 16 counter registers less the second block's, the map in registers v48 .. v160 (three waves per SIMD),
+    three tile buffers: 24 KB and ~160 registers per workgroup instead of 54 KB and 239, so that its workgroups find room on
+    a chip full of region-growing waves; twice the LDS reads per matrix step (a fragment serves one row block), slower alone."""
     L = []
     e = L.append
-    BF, ACCP, ACCQ, RUN, NTP, NTQ, BXR, SCA, SCB, TMP, VBC, VBN = 80, 96, 128, 160, 200, 216, 76, 192, 193, 197, 198, 199
-    BXC, VCC, VCN, SCC = 232, 236, 237, 238
+    if nrb == 2:
+        BF, ACCP, ACCQ, RUN, NTP, NTQ, BXR, SCA, SCB, TMP, VBC, VBN = 80, 96, 128, 160, 200, 216, 76, 192, 193, 197, 198, 199
+        BXC, VCC, VCN, SCC = 232, 236, 237, 238
+    else:
+        BXR, BF, ACCP, ACCQ, RUN, NTP, NTQ, SCA, SCB, TMP, VBC, VBN = 48, 52, 68, 84, 100, 116, 132, 148, 149, 150, 151, 152
+        BXC, VCC, VCN, SCC = 154, 158, 159, 160
+    NA = 16 * nrb                        # accumulator / running registers per half tile
     npw = 3 if gated else 2              # LDS-DMA pieces per tile and wave
     lgk0 = 5 if gated else 4             # LDS reads in flight per half step, minus one
     MF = "v_mfma_scale_f32_32x32x64_f8f6f4"
@@ -286,18 +295,18 @@ def gen_fp4(nbuf=6, gated=False):
         if gated:
             if half == 0:
                 e("s_waitcnt lgkmcnt(%d)" % lgk0)
-            for b in range(2):
+            for b in range(nrb):
                 e("%s %s, %%[axc%d], %s, %s, v%d, v%d %s" % (MF, rng(acc + 16 * b, 16), b, rng(BXC, 4), rng(nt, 16), SCC, SCB, TAIL))
             e("ds_read_b128 %s, v%d offset:%d" % (rng(BXC, 4), VCC if half == 0 else VCN, 1024 if half == 0 else 0))
         for s in range(4):
             if half == 0:
                 e("s_waitcnt lgkmcnt(%d)" % lgk0)
-            for b in range(2):
+            for b in range(nrb):
                 c = rng(nt, 16) if (s == 0 and not gated) else rng(acc + 16 * b, 16)
                 e("%s %s, %%[a%d%d], %s, %s, v%d, v%d %s" % (MF, rng(acc + 16 * b, 16), b, s, rng(BF + 4 * s, 4), c, SCA, SCB, TAIL))
             e("ds_read_b128 %s, %s offset:%d" % (rng(BF + 4 * s, 4), vb, s * 2048 + roff))
-            for j in range(8):
-                i = 8 * s + j
+            for j in range(NA // 4):
+                i = (NA // 4) * s + j
                 e("v_max_f32 v%d, v%d, v%d" % (RUN + i, RUN + i, other + i))
             if half == 0 and s == 1:
                 tile_address(nbuf)
@@ -316,7 +325,7 @@ def gen_fp4(nbuf=6, gated=False):
         e("v_mov_b32 v%d, 0x8b8b8b8b" % SCC)
         e("v_mov_b32 v%d, %%[vcfrag]" % VCC)
         e("v_add_u32 v%d, 2048, %%[vcfrag]" % VCN)
-    for i in range(32):
+    for i in range(NA):
         e("v_mov_b32 v%d, 0xff800000" % (RUN + i))
         e("v_mov_b32 v%d, 0xff800000" % (ACCQ + i))
     for r in range(1, 4):
@@ -364,10 +373,10 @@ def gen_fp4(nbuf=6, gated=False):
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_nop 7")
     e("s_nop 7")
-    for i in range(32):
+    for i in range(NA):
         e("v_max_f32 v%d, v%d, v%d" % (RUN + i, RUN + i, ACCQ + i))
     e("s_barrier")
-    for i in range(8):
+    for i in range(NA // 4):
         e("ds_write_b128 %%[vdump], %s offset:%d" % (rng(RUN + 4 * i, 4), i * 1024))
     e("s_waitcnt lgkmcnt(0)")
     return L
@@ -390,6 +399,11 @@ def main():
         f.write("#define LF_ASSOC_LOOP_FP4_GATED \\\n" + c_string(gen_fp4(gated=True)).replace("\n", " \\\n") + "\n\n")
         clob_fp4 = ", ".join('"v%d"' % i for i in list(range(76, 200)) + list(range(200, 239))) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "m0", "memory", "scc"'
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_FP4 " + clob_fp4 + "\n")
+        # the small shape (round 6): one row block per wave, three tile buffers, registers v48 .. v160
+        f.write("#define LF_ASSOC_LOOP_FP4_S \\\n" + c_string(gen_fp4(nbuf=3, nrb=1)).replace("\n", " \\\n") + "\n\n")
+        f.write("#define LF_ASSOC_LOOP_FP4_GATED_S \\\n" + c_string(gen_fp4(nbuf=3, gated=True, nrb=1)).replace("\n", " \\\n") + "\n\n")
+        clob_fp4_s = ", ".join('"v%d"' % i for i in range(48, 161)) + ", " + ", ".join('"s%d"' % i for i in range(40, 60)) + ', "m0", "memory", "scc"'
+        f.write("#define LF_ASSOC_LOOP_CLOBBERS_FP4_S " + clob_fp4_s + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_PLAIN " + clob_plain + "\n")
         f.write("#define LF_ASSOC_LOOP_CLOBBERS_GATED " + clob_gated + "\n")
     print("wrote", os.path.normpath(out), "plain", len(gen(False)), "gated", len(gen(True)), "instructions")
