@@ -468,12 +468,16 @@ struct EdMarks {
     }
 };
 
+// v_writelane_b32 (no clang builtin in this toolchain: the LLVM intrinsic by name): old with lane `l` replaced by the uniform v
+extern "C" __device__ int ed_writelane(int v, int l, int old) __asm("llvm.amdgcn.writelane.i32");
+
 struct EdWalk {
     const uint16_t* g; EdMarks marks;
     int W, H;
     unsigned lastX, lastY;
     int wx0, wy0;           // the window the last walk ended in (an anchor's second walk starts in its first walk's window
-    uint32_t info;          //   when that walk never left it: most walks are a few pixels long)
+    uint32_t nAB;           //   when that walk never left it: most walks are a few pixels long): per lane the two step records,
+    uint64_t stopM, ngM, hzM;   // and per window the lanes a walk stops at (marked or no gradient), those without gradient, the horizontal-edge ones
     bool have;
 };
 
@@ -493,14 +497,17 @@ struct EdWalk {
 //     horizontal-edge pixel and the sign it takes at a vertical-edge one.  A step from a horizontal-edge pixel with sign
 //     s leaves (s, dy > 0), one from a vertical-edge pixel (dx > 0, s);
 //   * when a window is fetched, every lane works out FOR ITS PIXEL what a walk standing there would do, for both signs:
-//     it compares the three pixels ahead (neighbour values by two DPP row shifts and two ds_bpermute) and records the
-//     step to the winner as a lane offset (dx + 1) + 8 (dy + 1) together with the state after it, or 31 when the
-//     reference stops at the image border first, 30 when the three are not all inside the window.  The result is one
-//     `info` word per lane: gradient | direction bit | (step | state after << 5) for + << 16, for - << 23 |
-//     marked << 30 | no gradient << 31;
-//   * inside a window the walk is a walk over LANES: a step reads the current lane's info (v_readlane), picks the
-//     record of the sign the state asks for, and adds the step to the lane number -- ~25 scalar instructions, no memory
-//     access, no coordinates.  The lane it visits notes its place in the order of the visit;
+//     it compares the three pixels ahead (the neighbours' gradients AND direction bits by two DPP row shifts and two
+//     ds_bpermute) and records, per sign, the LANE of the winner and the sign the walk will have THERE (the state after
+//     the step is two bits, the winner's direction bit says which of them counts): 11 bits -- bit 0: the three ahead are
+//     not all inside the window, bit 1: the reference stops at the image border first, bit 4: the next sign is minus
+//     (as the shift that selects the minus record), bits 5 - 10: the next lane.  Both records in one word per lane
+//     (plus << 0 | minus << 16); the lanes a walk stops at (marked, or no gradient) and the horizontal-edge lanes are
+//     64-bit masks in scalar registers;
+//   * inside a window the walk is a walk over NODES (lane, sign): a step tests and sets the lane's bit of the stop mask,
+//     notes the lane's place in the visit (v_writelane), reads the lane's word (v_readlane), shifts by the sign's
+//     selector and splits the record -- about a dozen scalar instructions (25 with the state and the records decoded per
+//     step, round 5), no memory access, no coordinates;
 //   * when the walk leaves the window (or ends), the visited lanes store their pixels at their places of the output
 //     and set their edge marks in the bit plane, all at once.
 // first: an anchor's first walk (its window is centred); else the walk may start in the window c holds.
@@ -522,7 +529,8 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
     }
     unsigned off = off_io;
     int wx0 = c.wx0, wy0 = c.wy0, fx = 0, fy = 0, fgo = 0;
-    uint32_t info = c.info;
+    uint32_t nAB = c.nAB;
+    uint64_t stopM = c.stopM, ngM = c.ngM, hzM = c.hzM;
     int ord = -1, cnt = 0;                                  // this lane's place in the visit of the window; pixels visited in it
     int Lv = -1;                                            // the lane visited last
     bool ok = true;
@@ -538,9 +546,8 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         off += (unsigned)cnt;
         ord = -1; cnt = 0;
     };
-    // a new window for a walk standing at (x, y) on a pixel of kind gh (1: horizontal-edge), in state st
-    auto fetch = [&](uint32_t gh, bool centred) {
-        const uint32_t plus = (st >> gh) & 1u;
+    // a new window for a walk standing at (x, y) on a pixel of kind gh (1: horizontal-edge) with sign plus
+    auto fetch = [&](uint32_t gh, uint32_t plus, bool centred) {
         const int go = gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir);
         int drift = 0;
         if (go == fgo) drift = gh ? y - fy : x - fx;
@@ -556,23 +563,29 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         bool mk = c.marks.get(idx);
         v = in ? v : 0u;
         mk = in && mk;
-        // the eight neighbours' gradients (as unsigned char, :1607-1609): west | own | east of this row in one word,
-        // then the same word of the rows above and below.  Values from beyond the window's edge are never used (step 30)
-        const int g8 = (int)(v & 0xffu);
-        const int gW = __builtin_amdgcn_update_dpp(0, g8, 0x111, 0xf, 0xf, true);     // row_shr:1: from lane - 1
-        const int gE = __builtin_amdgcn_update_dpp(0, g8, 0x101, 0xf, 0xf, true);     // row_shl:1: from lane + 1
-        const int R = gW | (g8 << 8) | (gE << 16);
+        // the eight neighbours' gradients (as unsigned char, :1607-1609) and direction bits: west | own | east of this row
+        // in one word (9 bits each), then the same word of the rows above and below.  Values from beyond the window's
+        // edge are never used (bit 0 of the record)
+        const int g9 = (int)((v & 0xffu) | ((v >> 7) & 0x100u));
+        const int gW = __builtin_amdgcn_update_dpp(0, g9, 0x111, 0xf, 0xf, true);     // row_shr:1: from lane - 1
+        const int gE = __builtin_amdgcn_update_dpp(0, g9, 0x101, 0xf, 0xf, true);     // row_shl:1: from lane + 1
+        const int R = gW | (g9 << 9) | (gE << 18);
         const int RN = __builtin_amdgcn_ds_bpermute(((lane - 8) & 63) << 2, R), RS = __builtin_amdgcn_ds_bpermute(((lane + 8) & 63) << 2, R);
-        const int nNW = RN & 0xff, nN = (RN >> 8) & 0xff, nNE = (RN >> 16) & 0xff, nSW = RS & 0xff, nS = (RS >> 8) & 0xff, nSE = (RS >> 16) & 0xff;
+        const int nNW = RN & 0x1ff, nN = (RN >> 9) & 0x1ff, nNE = (RN >> 18) & 0x1ff, nSW = RS & 0x1ff, nS = (RS >> 9) & 0x1ff, nSE = (RS >> 18) & 0x1ff;
         const bool hz = (v & kHorizontal) != 0;
         // pixels 1 / 2 / 3 ahead: right NE E SE, left NW W SW, down SE S SW, up NE N NW; t = +1: pixel 1 wins, -1: pixel 3
-        const int a1 = hz ? nNE : nSE, a2 = hz ? gE : nS, a3 = hz ? nSE : nSW;
-        const int b1 = hz ? nNW : nNE, b2 = hz ? gW : nN, b3 = hz ? nSW : nNW;
+        const int A1 = hz ? nNE : nSE, A2 = hz ? gE : nS, A3 = hz ? nSE : nSW;
+        const int B1 = hz ? nNW : nNE, B2 = hz ? gW : nN, B3 = hz ? nSW : nNW;
+        const int a1 = A1 & 0xff, a2 = A2 & 0xff, a3 = A3 & 0xff, b1 = B1 & 0xff, b2 = B2 & 0xff, b3 = B3 & 0xff;
         const int ta = (a1 >= a2 && a1 >= a3) ? 1 : ((a3 >= a2 && a3 >= a1) ? -1 : 0);
         const int tb = (b1 >= b2 && b1 >= b3) ? 1 : ((b3 >= b2 && b3 >= b1) ? -1 : 0);
-        // right / left: (+-1, -t); down / up: (t, +-1); the state after: (sign, dy > 0) resp. (dx > 0, sign)
-        const int stepA = hz ? (2 + 8 * (1 - ta)) | (((ta < 0 ? 1 : 0) | 2) << 5) : ((1 + ta) + 16) | (((ta > 0 ? 2 : 0) | 1) << 5);
-        const int stepB = hz ? (0 + 8 * (1 - tb)) | ((tb < 0 ? 1 : 0) << 5) : ((1 + tb) + 0) | ((tb > 0 ? 2 : 0) << 5);
+        // the winner's direction bit
+        const bool hA = ((ta > 0 ? A1 : (ta < 0 ? A3 : A2)) & 0x100) != 0, hB = ((tb > 0 ? B1 : (tb < 0 ? B3 : B2)) & 0x100) != 0;
+        // right / left: (+-1, -t); down / up: (t, +-1); the state after: (sign, dy > 0) resp. (dx > 0, sign); the sign at
+        // the winner: the first of the two when it is a horizontal-edge pixel
+        const int laneA = lane + (hz ? 1 - 8 * ta : ta + 8), laneB = lane + (hz ? -1 - 8 * tb : tb - 8);
+        const bool sgA = hz ? (hA || ta < 0) : (hA ? ta > 0 : true);
+        const bool sgB = hz ? (!hB && tb < 0) : (hB && tb > 0);
         bool brkA = false, brkB = false;
         if (wx0 <= 0 || wy0 <= 0 || wx0 + 7 >= W - 1 || wy0 + 7 >= H - 1) {       // the window touches the image border
             const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
@@ -581,55 +594,68 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         }
         const bool reachA = hz ? (ldx <= 6 && inner_y) : (ldy <= 6 && inner_x);
         const bool reachB = hz ? (ldx >= 1 && inner_y) : (ldy >= 1 && inner_x);
-        const int fA = brkA ? 31 : (reachA ? stepA : 30), fB = brkB ? 31 : (reachB ? stepB : 30);
-        info = v | ((uint32_t)fA << 16) | ((uint32_t)fB << 23) | (mk ? 1u << 30 : 0u) | ((v & 0x7fffu) == 0u ? 1u << 31 : 0u);
+        const uint32_t rA = brkA ? 2u : (reachA ? ((uint32_t)(laneA & 63) << 5) | (sgA ? 0u : 16u) : 1u);          // read with selector 0
+        const uint32_t rB = brkB ? 2u : (reachB ? ((uint32_t)(laneB & 63) << 5) | (sgB ? 0u : 16u) : 17u);         // read with selector 16
+        nAB = rA | (rB << 16);
+        ngM = __ballot((v & 0x7fffu) == 0u);
+        stopM = ngM | __ballot(mk);
+        hzM = __ballot(hz);
     };
-    // the record of the walk's sign at a pixel of kind hz
-    auto record = [&](uint32_t s_, uint32_t hz_) { return (s_ >> (((st >> hz_) & 1u) ? 16 : 23)) & 127u; };
+    auto bit = [](uint64_t m, int l) { return (uint32_t)(m >> l) & 1u; };
+    // the record of the walk's sign (as its selector sh: 0 plus, 16 minus) at lane l
+    auto record = [&](int l, uint32_t sh_) { return ((uint32_t)__builtin_amdgcn_readlane((int)nAB, l) >> sh_) & 0xffffu; };
     int L;
-    uint32_t s;
+    uint32_t sh;
     {
         bool reuse = false;
         if (!first && c.have && (unsigned)(x - wx0) < 8u && (unsigned)(y - wy0) < 8u) {
             // the anchor lies in the window the first walk ended in: start there unless its first step leaves the window.
             // The caller has cleared the anchor's mark in the bit plane: the same here
             L = (y - wy0) * 8 + (x - wx0);
-            info &= lane == L ? ~(1u << 30) : ~0u;
-            s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
-            reuse = (record(s, (s >> 15) & 1u) & 31u) != 30u;
+            stopM = (stopM & ~(1ull << L)) | (ngM & (1ull << L));
+            sh = ((st >> bit(hzM, L)) & 1u) ? 0u : 16u;
+            reuse = (record(L, sh) & 1u) == 0u;
         }
         if (!reuse) {
-            fetch((ld & 1) ^ 1, first);
+            const uint32_t gh = (uint32_t)((ld & 1) ^ 1);
+            fetch(gh, (st >> gh) & 1u, first);
             L = (y - wy0) * 8 + (x - wx0);
-            s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
+            sh = ((st >> bit(hzM, L)) & 1u) ? 0u : 16u;
         }
     }
-    while ((s >> 30) == 0u) {                                 // neither marked nor without gradient
-        const bool here = lane == L;
-        info |= here ? 1u << 30 : 0u;
-        ord = here ? cnt : ord;
-        ++cnt;
-        Lv = L;
-        const uint32_t hz = (s >> 15) & 1u;
-        uint32_t fld = record(s, hz);
-        if ((fld & 31u) >= 30u) {
-            if ((fld & 31u) == 31u) break;                     // the image border ahead (:1583, :1620, ...)
-            x = wx0 + (L & 7); y = wy0 + (L >> 3);             // the three ahead are not all in the window
+    // The step loop has ONE exit test: the record's two flags or the next lane's stop bit (a flagged record names lane 0
+    // and keeps the selector it was read with)
+    if (bit(stopM, L) == 0u) {                                // neither marked nor without gradient
+        for (;;) {
+            uint32_t fl;
+            do {
+                stopM |= 1ull << L;
+                ord = ed_writelane(cnt, L, ord);               // ord[lane L] = cnt
+                ++cnt;
+                Lv = L;
+                const uint32_t e = record(L, sh);
+                sh = e & 16u;
+                L = (int)((e >> 5) & 63u);
+                fl = e & 3u;
+            } while ((fl | bit(stopM, L)) == 0u);
+            if (fl != 1u) break;                               // the image border ahead (:1583, :1620, ...), or a pixel that stops the walk
+            x = wx0 + (Lv & 7); y = wy0 + (Lv >> 3);           // the three ahead are not all in the window
+            const uint32_t hz = bit(hzM, Lv);
             retire();
             if (!ok) break;
-            fetch(hz, false);
+            fetch(hz, sh == 0u ? 1u : 0u, false);
             L = (y - wy0) * 8 + (x - wx0);
             Lv = L;
-            fld = record((uint32_t)__builtin_amdgcn_readlane((int)info, L), hz);
-            if ((fld & 31u) >= 30u) break;                     // the border (30 cannot happen: the window was placed around the three ahead)
+            const uint32_t e = record(L, sh);
+            if (e & 3u) break;                                 // the border (bit 0 cannot happen: the window was placed around the three ahead)
+            sh = e & 16u;
+            L = (int)((e >> 5) & 63u);
+            if (bit(stopM, L)) break;
         }
-        st = fld >> 5;
-        L += (int)(fld & 31u) - 9;
-        s = (uint32_t)__builtin_amdgcn_readlane((int)info, L);
     }
     if (Lv >= 0) { c.lastX = (unsigned)(wx0 + (Lv & 7)); c.lastY = (unsigned)(wy0 + (Lv >> 3)); }
     if (ok) retire();
-    c.wx0 = wx0; c.wy0 = wy0; c.info = info; c.have = true;
+    c.wx0 = wx0; c.wy0 = wy0; c.nAB = nAB; c.stopM = stopM; c.ngM = ngM; c.hzM = hzM; c.have = true;
     off_io = off;
     return ok;
 }
@@ -852,7 +878,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
         unsigned ps = 0, cpos = 0;                            // edges, chain pixels
         if (n_anchors > o.cap) st = 1;                        // the reference returns -1 ("anchor size is larger than its maximal size")
         else {
-            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0; wk.wx0 = 0; wk.wy0 = 0; wk.info = 0u; wk.have = false;
+            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0; wk.wx0 = 0; wk.wy0 = 0; wk.nAB = 0u; wk.stopM = 0ull; wk.ngM = 0ull; wk.hzM = 0ull; wk.have = false;
             const unsigned cap = (unsigned)o.cap;
             unsigned offF = 0, offS = 0;                      // kept first / second part pixels
             uint32_t ablk = 0u;
