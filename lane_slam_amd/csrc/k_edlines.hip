@@ -535,6 +535,9 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
     int Lv = -1;                                            // the lane visited last
     bool ok = true;
     const bool inner_x = ldx >= 1 && ldx <= 6, inner_y = ldy >= 1 && ldy <= 6;
+    // per lane, all ones when the three pixels ahead lie in the window: plus / minus at a horizontal-edge pixel, at a vertical-edge one
+    const uint32_t reachA_h = (ldx <= 6 && inner_y) ? ~0u : 0u, reachB_h = (ldx >= 1 && inner_y) ? ~0u : 0u;
+    const uint32_t reachA_v = (ldy <= 6 && inner_x) ? ~0u : 0u, reachB_v = (ldy >= 1 && inner_x) ? ~0u : 0u;
     // the visited pixels of the window -> output and bit plane
     auto retire = [&]() {
         if (off + (unsigned)cnt > cap) { ok = false; return; }
@@ -579,23 +582,28 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         const int a1 = A1 & 0xff, a2 = A2 & 0xff, a3 = A3 & 0xff, b1 = B1 & 0xff, b2 = B2 & 0xff, b3 = B3 & 0xff;
         const int ta = (a1 >= a2 && a1 >= a3) ? 1 : ((a3 >= a2 && a3 >= a1) ? -1 : 0);
         const int tb = (b1 >= b2 && b1 >= b3) ? 1 : ((b3 >= b2 && b3 >= b1) ? -1 : 0);
-        // the winner's direction bit
-        const bool hA = ((ta > 0 ? A1 : (ta < 0 ? A3 : A2)) & 0x100) != 0, hB = ((tb > 0 ? B1 : (tb < 0 ? B3 : B2)) & 0x100) != 0;
-        // right / left: (+-1, -t); down / up: (t, +-1); the state after: (sign, dy > 0) resp. (dx > 0, sign); the sign at
-        // the winner: the first of the two when it is a horizontal-edge pixel
-        const int laneA = lane + (hz ? 1 - 8 * ta : ta + 8), laneB = lane + (hz ? -1 - 8 * tb : tb - 8);
-        const bool sgA = hz ? (hA || ta < 0) : (hA ? ta > 0 : true);
-        const bool sgB = hz ? (!hB && tb < 0) : (hB && tb > 0);
-        bool brkA = false, brkB = false;
+        // From here on in integers: conditions combined as lane masks are scalar instructions, 13 cycles each on this wave's
+        // one chain.  right / left: (+-1, -t); down / up: (t, +-1); the state after: (sign, dy > 0) resp. (dx > 0, sign); the
+        // sign at the winner is the first of the two when its direction bit says horizontal: plus: hz ? h | t < 0 : !h | t > 0,
+        // minus: hz ? !h & t < 0 : h & t > 0 -- as bits of two constants indexed by hz << 3 | h << 2 | t + 1
+        const uint32_t hzi = (v >> 15) & 1u;
+        const uint32_t wA = (uint32_t)(ta > 0 ? A1 : (ta < 0 ? A3 : A2)), wB = (uint32_t)(tb > 0 ? B1 : (tb < 0 ? B3 : B2));   // the winner
+        const uint32_t iA = (hzi << 3) | ((wA >> 6) & 4u) | (uint32_t)(ta + 1), iB = (hzi << 3) | ((wB >> 6) & 4u) | (uint32_t)(tb + 1);
+        const uint32_t nsA = (~0x7147u >> iA) & 1u, nsB = (~0x0140u >> iB) & 1u;          // 1: minus
+        const int mul = hz ? -8 : 1, add = hz ? 1 : 8;
+        const int laneA = lane + add + ta * mul, laneB = lane - add + tb * mul;
+        const uint32_t recA = (((uint32_t)laneA << 5) & 0x7e0u) | (nsA << 4), recB = (((uint32_t)laneB << 5) & 0x7e0u) | (nsB << 4);
+        // the three ahead inside the window: else record 1 (read with selector 0) / 17 (with 16)
+        uint32_t rA, rB;
+        rA = (recA & (hz ? reachA_h : reachA_v)) | (~(hz ? reachA_h : reachA_v) & 1u);
+        rB = (recB & (hz ? reachB_h : reachB_v)) | (~(hz ? reachB_h : reachB_v) & 17u);
         if (wx0 <= 0 || wy0 <= 0 || wx0 + 7 >= W - 1 || wy0 + 7 >= H - 1) {       // the window touches the image border
             const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
-            brkA = hz ? (x_hi || y_lo || y_hi) : (x_lo || x_hi || y_hi);
-            brkB = hz ? (x_lo || y_lo || y_hi) : (x_lo || x_hi || y_lo);
+            const bool brkA = hz ? (x_hi || y_lo || y_hi) : (x_lo || x_hi || y_hi);
+            const bool brkB = hz ? (x_lo || y_lo || y_hi) : (x_lo || x_hi || y_lo);
+            rA = brkA ? 2u : rA;
+            rB = brkB ? 2u : rB;
         }
-        const bool reachA = hz ? (ldx <= 6 && inner_y) : (ldy <= 6 && inner_x);
-        const bool reachB = hz ? (ldx >= 1 && inner_y) : (ldy >= 1 && inner_x);
-        const uint32_t rA = brkA ? 2u : (reachA ? ((uint32_t)(laneA & 63) << 5) | (sgA ? 0u : 16u) : 1u);          // read with selector 0
-        const uint32_t rB = brkB ? 2u : (reachB ? ((uint32_t)(laneB & 63) << 5) | (sgB ? 0u : 16u) : 17u);         // read with selector 16
         nAB = rA | (rB << 16);
         ngM = __ballot((v & 0x7fffu) == 0u);
         stopM = ngM | __ballot(mk);
