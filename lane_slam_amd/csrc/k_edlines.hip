@@ -471,7 +471,22 @@ struct EdMarks {
 // v_writelane_b32 (no clang builtin in this toolchain: the LLVM intrinsic by name): old with lane `l` replaced by the uniform v
 extern "C" __device__ int ed_writelane(int v, int l, int old) __asm("llvm.amdgcn.writelane.i32");
 
+// -DLF_ED_STAMP=k (diagnostic builds, tools/ed_stamps.py): one quantity per build, summed over the walking wave of a frame,
+// returned in the frame's counts[3] (times in units of 4 cycles).  1: inside ed_walk, 2: of that, a window left until the
+// walk goes on in the next, 3: a walk's start (window reused or fetched), 4 / 5: windows fetched on leaving one / at a start,
+// 6: steps, 7: kernel start until the walk begins, 8: the walking phase, 9: from its end to the kernel's
+#ifdef LF_ED_STAMP
+#define ED_T0(k) unsigned long long t_##k = (LF_ED_STAMP == k) ? __builtin_amdgcn_s_memtime() : 0ull
+#define ED_T1(k, acc) do { if (LF_ED_STAMP == k) (acc) += __builtin_amdgcn_s_memtime() - t_##k; } while (0)
+#define ED_CNT(k, acc) do { if (LF_ED_STAMP == k) (acc) += 4ull; } while (0)
+#else
+#define ED_T0(k) do { } while (0)
+#define ED_T1(k, acc) do { } while (0)
+#define ED_CNT(k, acc) do { } while (0)
+#endif
+
 struct EdWalk {
+    unsigned long long diag;
     const uint16_t* g; EdMarks marks;
     int W, H;
     unsigned lastX, lastY;
@@ -527,8 +542,9 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         const uint32_t went_right = x > (int)c.lastX ? 1u : 0u, went_down = y > (int)c.lastY ? 1u : 0u;
         st = (ld & 1) == 0 ? (plus << 1) | went_down : (went_right << 1) | plus;
     }
+    ED_T0(1); ED_T0(3);
     unsigned off = off_io;
-    int wx0 = c.wx0, wy0 = c.wy0, fx = 0, fy = 0, fgo = 0;
+    int wx0 = c.wx0, wy0 = c.wy0;
     uint32_t nAB = c.nAB;
     uint64_t stopM = c.stopM, ngM = c.ngM, hzM = c.hzM;
     int ord = -1, cnt = 0;                                  // this lane's place in the visit of the window; pixels visited in it
@@ -538,9 +554,14 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
     // per lane, all ones when the three pixels ahead lie in the window: plus / minus at a horizontal-edge pixel, at a vertical-edge one
     const uint32_t reachA_h = (ldx <= 6 && inner_y) ? ~0u : 0u, reachB_h = (ldx >= 1 && inner_y) ? ~0u : 0u;
     const uint32_t reachA_v = (ldy <= 6 && inner_x) ? ~0u : 0u, reachB_v = (ldy >= 1 && inner_x) ? ~0u : 0u;
-    // the visited pixels of the window -> output and bit plane
+    // where the window goes when the walk leaves this one AT this lane, for a walk that has not drifted sideways since the
+    // window was fetched (side 3): the lane's place in the new window is (back, side) along / across the walk -- one column
+    // or row behind, six ahead.  As 1 | (ox + 8) << 5 | (oy + 8) << 10 with (ox, oy) the new origin relative to the old
+    // one: plus / minus at a horizontal-edge pixel, at a vertical-edge one
+    const uint32_t exitA_h = 1u | (uint32_t)(ldx - 1 + 8) << 5 | (uint32_t)(ldy - 3 + 8) << 10, exitB_h = 17u | (uint32_t)(ldx - 6 + 8) << 5 | (uint32_t)(ldy - 3 + 8) << 10;
+    const uint32_t exitA_v = 1u | (uint32_t)(ldx - 3 + 8) << 5 | (uint32_t)(ldy - 1 + 8) << 10, exitB_v = 17u | (uint32_t)(ldx - 3 + 8) << 5 | (uint32_t)(ldy - 6 + 8) << 10;
+    // the visited pixels of the window -> output and bit plane (the caller has checked that they fit)
     auto retire = [&]() {
-        if (off + (unsigned)cnt > cap) { ok = false; return; }
         if (ord >= 0) {
             const int px = wx0 + ldx, py = wy0 + ldy;
             out[base + off + (unsigned)ord] = (uint32_t)px | ((uint32_t)py << 16);
@@ -549,22 +570,31 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         off += (unsigned)cnt;
         ord = -1; cnt = 0;
     };
-    // a new window for a walk standing at (x, y) on a pixel of kind gh (1: horizontal-edge) with sign plus
-    auto fetch = [&](uint32_t gh, uint32_t plus, bool centred) {
-        const int go = gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir);
-        int drift = 0;
-        if (go == fgo) drift = gh ? y - fy : x - fx;
-        const int side = drift >= 2 ? 1 : (drift <= -2 ? 6 : 3);
+    // the origin of the first window of a walk standing at (x, y) on a pixel of kind gh (1: horizontal-edge) with sign plus
+    auto place = [&](uint32_t gh, uint32_t plus, bool centred, int& nx, int& ny) {
         const int back = centred ? (plus ? 3 : 4) : (plus ? 1 : 6);
-        wx0 = x - (gh ? back : side);
-        wy0 = y - (gh ? side : back);
-        fx = x; fy = y; fgo = go;
-        const int px = wx0 + ldx, py = wy0 + ldy;
+        nx = x - (gh ? back : 3);
+        ny = y - (gh ? 3 : back);
+    };
+    // the window at (nx, ny) for a walk standing at (x, y) and heading `go`.  Everything that does not need the loaded
+    // values comes between the load and its first use: the old window's pixels retired, the exits of the new one
+    auto fetch = [&](int nx, int ny, int go, bool with_retire) {
+        const int px = nx + ldx, py = ny + ldy;
         const bool in = px >= 0 && px < W && py >= 0 && py < H;
         const int idx = in ? py * W + px : 0;
-        uint32_t v = pg[idx];
+        const uint16_t v16 = pg[idx];
+        if (with_retire) retire();
+        wx0 = nx; wy0 = ny;
         bool mk = c.marks.get(idx);
-        v = in ? v : 0u;
+        // a walk that leaves this window heading the way it entered, two or more pixels to the side of where it entered,
+        // gets the next window shifted to that side (side 1 / 6 instead of 3): the one exit record of the four that this
+        // concerns, by a uniform factor
+        const int dY = py - y, dX = px - x;
+        const int sY = (dY >= 2 ? 1 : (dY <= -2 ? 6 : 3)) - 3, sX = (dX >= 2 ? 1 : (dX <= -2 ? 6 : 3)) - 3;
+        const uint32_t eA_h = exitA_h - (uint32_t)(sY * (go == RightDir ? 1 << 10 : 0)), eB_h = exitB_h - (uint32_t)(sY * (go == LeftDir ? 1 << 10 : 0));
+        const uint32_t eA_v = exitA_v - (uint32_t)(sX * (go == DownDir ? 1 << 5 : 0)), eB_v = exitB_v - (uint32_t)(sX * (go == UpDir ? 1 << 5 : 0));
+        __builtin_amdgcn_sched_barrier(0);                     // (left to itself the compiler waits for the load first)
+        const uint32_t v = in ? (uint32_t)v16 : 0u;
         mk = in && mk;
         // the eight neighbours' gradients (as unsigned char, :1607-1609) and direction bits: west | own | east of this row
         // in one word (9 bits each), then the same word of the rows above and below.  Values from beyond the window's
@@ -593,10 +623,10 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         const int mul = hz ? -8 : 1, add = hz ? 1 : 8;
         const int laneA = lane + add + ta * mul, laneB = lane - add + tb * mul;
         const uint32_t recA = (((uint32_t)laneA << 5) & 0x7e0u) | (nsA << 4), recB = (((uint32_t)laneB << 5) & 0x7e0u) | (nsB << 4);
-        // the three ahead inside the window: else record 1 (read with selector 0) / 17 (with 16)
+        // the three ahead inside the window: else the exit record
         uint32_t rA, rB;
-        rA = (recA & (hz ? reachA_h : reachA_v)) | (~(hz ? reachA_h : reachA_v) & 1u);
-        rB = (recB & (hz ? reachB_h : reachB_v)) | (~(hz ? reachB_h : reachB_v) & 17u);
+        rA = (recA & (hz ? reachA_h : reachA_v)) | (~(hz ? reachA_h : reachA_v) & (hz ? eA_h : eA_v));
+        rB = (recB & (hz ? reachB_h : reachB_v)) | (~(hz ? reachB_h : reachB_v) & (hz ? eB_h : eB_v));
         if (wx0 <= 0 || wy0 <= 0 || wx0 + 7 >= W - 1 || wy0 + 7 >= H - 1) {       // the window touches the image border
             const bool x_lo = px == 0, x_hi = px == W - 1, y_lo = py == 0, y_hi = py == H - 1;
             const bool brkA = hz ? (x_hi || y_lo || y_hi) : (x_lo || x_hi || y_hi);
@@ -625,36 +655,42 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
             reuse = (record(L, sh) & 1u) == 0u;
         }
         if (!reuse) {
-            const uint32_t gh = (uint32_t)((ld & 1) ^ 1);
-            fetch(gh, (st >> gh) & 1u, first);
+            const uint32_t gh = (uint32_t)((ld & 1) ^ 1), plus = (st >> gh) & 1u;
+            int nx, ny;
+            place(gh, plus, first, nx, ny);
+            fetch(nx, ny, gh ? (plus ? RightDir : LeftDir) : (plus ? DownDir : UpDir), false);
+            ED_CNT(5, c.diag);
             L = (y - wy0) * 8 + (x - wx0);
             sh = ((st >> bit(hzM, L)) & 1u) ? 0u : 16u;
         }
     }
+    ED_T1(3, c.diag);
     // The step loop has ONE exit test: the record's two flags or the next lane's stop bit (a flagged record names lane 0
     // and keeps the selector it was read with)
     if (bit(stopM, L) == 0u) {                                // neither marked nor without gradient
         for (;;) {
-            uint32_t fl;
+            uint32_t fl, e;
             do {
                 stopM |= 1ull << L;
                 ord = ed_writelane(cnt, L, ord);               // ord[lane L] = cnt
                 ++cnt;
                 Lv = L;
-                const uint32_t e = record(L, sh);
+                e = record(L, sh);
                 sh = e & 16u;
                 L = (int)((e >> 5) & 63u);
                 fl = e & 3u;
+                ED_CNT(6, c.diag);
             } while ((fl | bit(stopM, L)) == 0u);
             if (fl != 1u) break;                               // the image border ahead (:1583, :1620, ...), or a pixel that stops the walk
-            x = wx0 + (Lv & 7); y = wy0 + (Lv >> 3);           // the three ahead are not all in the window
+            if (off + (unsigned)cnt > cap) { ok = false; break; }
+            ED_T0(2); ED_CNT(4, c.diag);
+            x = wx0 + (Lv & 7); y = wy0 + (Lv >> 3);           // the three ahead are not all in the window: the next one, where the record says
             const uint32_t hz = bit(hzM, Lv);
-            retire();
-            if (!ok) break;
-            fetch(hz, sh == 0u ? 1u : 0u, false);
+            fetch(wx0 + (int)((e >> 5) & 31u) - 8, wy0 + (int)((e >> 10) & 31u) - 8, hz ? (sh == 0u ? RightDir : LeftDir) : (sh == 0u ? DownDir : UpDir), true);
             L = (y - wy0) * 8 + (x - wx0);
             Lv = L;
-            const uint32_t e = record(L, sh);
+            e = record(L, sh);
+            ED_T1(2, c.diag);
             if (e & 3u) break;                                 // the border (bit 0 cannot happen: the window was placed around the three ahead)
             sh = e & 16u;
             L = (int)((e >> 5) & 63u);
@@ -662,9 +698,11 @@ __device__ __forceinline__ bool ed_walk(EdWalk& c, unsigned x0, unsigned y0, int
         }
     }
     if (Lv >= 0) { c.lastX = (unsigned)(wx0 + (Lv & 7)); c.lastY = (unsigned)(wy0 + (Lv >> 3)); }
+    if (ok && off + (unsigned)cnt > cap) ok = false;
     if (ok) retire();
     c.wx0 = wx0; c.wy0 = wy0; c.nAB = nAB; c.stopM = stopM; c.ngM = ngM; c.hzM = hzM; c.have = true;
     off_io = off;
+    ED_T1(1, c.diag);
     return ok;
 }
 
@@ -802,6 +840,11 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
     __shared__ int s_wave_count[ED_WAVES];
     __shared__ int s_base, s_edges, s_walked, s_fail, s_next_edge, s_temp_next, s_total;
     const int oc = blockIdx.y, f = blockIdx.x;
+#ifdef LF_ED_STAMP
+    __shared__ unsigned long long s_diag;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long t_walk_end = 0ull;
+#endif
     const EdOct& o = all.o[oc];
     const int W = o.W, H = o.H, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t P = (size_t)W * H;
@@ -820,29 +863,35 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
     if (tid == 0) { s_base = 0; s_edges = 0; s_walked = 0; s_fail = 0; s_next_edge = 0; s_temp_next = 0; }
     __syncthreads();
     // ---- anchors (:1504-1532): tested row-major, recorded column-major.  All five loads of a candidate are issued
-    // whatever its direction, eight candidates per thread in flight: the phase is bound by the latency of the plane
-    for (int i0 = tid; i0 < n_cand; i0 += ED_THREADS * 8) {
-        uint32_t v[8], va[8], vb[8], vl[8], vr[8];
+    // whatever its direction, eight candidates per thread in flight: the phase is bound by the latency of the plane.  A
+    // thread's candidates are ED_THREADS apart: (row, column) advance by that stride's quotient and remainder -- one
+    // division per thread (two per candidate until round 6: 100 of its 150 instructions)
+    {
+        const int step_q = ED_THREADS / (nW > 0 ? nW : 1), step_r = ED_THREADS - step_q * nW;
+        int ch_n = tid / (nW > 0 ? nW : 1), cw_n = tid - ch_n * nW;
+        for (int i0 = tid; i0 < n_cand; i0 += ED_THREADS * 8) {
+            uint32_t v[8], va[8], vb[8], vl[8], vr[8];
+            int bit_i[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + ED_THREADS * u;
-            const int ic = i < n_cand ? i : n_cand - 1;
-            const int ch = ic / nW, cw = ic - ch * nW;
-            const int idx = (1 + scan * ch) * W + 1 + scan * cw;
-            v[u] = g[idx]; va[u] = g[idx - W]; vb[u] = g[idx + W]; vl[u] = g[idx - 1]; vr[u] = g[idx + 1];
-        }
+            for (int u = 0; u < 8; ++u) {
+                const bool live = i0 + ED_THREADS * u < n_cand;
+                const int ch = live ? ch_n : 0, cw = live ? cw_n : 0;
+                bit_i[u] = live ? cw * nH + ch : -1;
+                const int idx = (1 + scan * ch) * W + 1 + scan * cw;
+                v[u] = g[idx]; va[u] = g[idx - W]; vb[u] = g[idx + W]; vl[u] = g[idx - 1]; vr[u] = g[idx + 1];
+                cw_n += step_r; ch_n += step_q;
+                if (cw_n >= nW) { cw_n -= nW; ++ch_n; }
+            }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = i0 + ED_THREADS * u;
-            if (i >= n_cand) break;
-            const int ch = i / nW, cw = i - ch * nW;
-            const int gv = (int)(v[u] & 0x7fffu);
-            const bool hz = (v[u] & kHorizontal) != 0;
-            const int n1 = (int)((hz ? va[u] : vl[u]) & 0x7fffu), n2 = (int)((hz ? vb[u] : vr[u]) & 0x7fffu);
-            if (gv >= n1 + fp.anchor_threshold && gv >= n2 + fp.anchor_threshold) {
-                const int b = cw * nH + ch;
-                atomicOr(&flags[b >> 5], 1u << (b & 31));
-                if (hz) atomicOr(&fhz[b >> 5], 1u << (b & 31));
+            for (int u = 0; u < 8; ++u) {
+                const int gv = (int)(v[u] & 0x7fffu);
+                const bool hz = (v[u] & kHorizontal) != 0;
+                const int n1 = (int)((hz ? va[u] : vl[u]) & 0x7fffu), n2 = (int)((hz ? vb[u] : vr[u]) & 0x7fffu);
+                const int b = bit_i[u];
+                if (b >= 0 && gv >= n1 + fp.anchor_threshold && gv >= n2 + fp.anchor_threshold) {
+                    atomicOr(&flags[b >> 5], 1u << (b & 31));
+                    if (hz) atomicOr(&fhz[b >> 5], 1u << (b & 31));
+                }
             }
         }
     }
@@ -882,17 +931,26 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
     uint32_t* sid = o.sid + (size_t)f * (o.max_edges + 2);
     // ================= smart routing: one wave (a walk stops at pixels earlier walks marked) =================
     if (wave == 0) {
+#ifdef LF_ED_STAMP
+        const unsigned long long t_walk = __builtin_amdgcn_s_memtime();
+        if (LF_ED_STAMP == 7) s_diag = t_walk - t_start;
+#endif
         int st = 0;
         unsigned ps = 0, cpos = 0;                            // edges, chain pixels
         if (n_anchors > o.cap) st = 1;                        // the reference returns -1 ("anchor size is larger than its maximal size")
         else {
-            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0; wk.wx0 = 0; wk.wy0 = 0; wk.nAB = 0u; wk.stopM = 0ull; wk.ngM = 0ull; wk.hzM = 0ull; wk.have = false;
+            EdWalk wk; wk.g = g; wk.marks.p = marks; wk.marks.in_lds = o.marks_in_lds != 0; wk.W = W; wk.H = H; wk.lastX = 0; wk.lastY = 0; wk.wx0 = 0; wk.wy0 = 0; wk.diag = 0ull; wk.nAB = 0u; wk.stopM = 0ull; wk.ngM = 0ull; wk.hzM = 0ull; wk.have = false;
             const unsigned cap = (unsigned)o.cap;
             unsigned offF = 0, offS = 0;                      // kept first / second part pixels
-            uint32_t ablk = 0u;
-            for (int a = 0; a < n_anchors; ++a) {
-                if ((a & 63) == 0) ablk = a + lane < n_anchors ? anchors[a + lane] : 0u;      // the list, 64 anchors per load
-                const uint32_t an = (uint32_t)__builtin_amdgcn_readlane((int)ablk, a & 63);
+            // the list, 64 anchors per load; every lane looks up its anchor's mark first: most anchors lie on an edge drawn
+            // before their block is reached (marks are only ever added), the others are looked up again when their turn comes
+            for (int a0 = 0; a0 < n_anchors && !st; a0 += 64) {
+              const uint32_t ablk = a0 + lane < n_anchors ? anchors[a0 + lane] : 0u;
+              uint64_t todo = __ballot(a0 + lane < n_anchors && !wk.marks.get((int)((ablk >> 16) * W + (ablk & 0xffffu))));
+              while (todo) {
+                const int k = (int)__builtin_ctzll(todo), a = a0 + k;
+                todo &= todo - 1ull;
+                const uint32_t an = (uint32_t)__builtin_amdgcn_readlane((int)ablk, k);
                 const unsigned x = an & 0xffffu, y = an >> 16;
                 const int i = (int)(y * W + x);
                 if (__builtin_amdgcn_readfirstlane((int)wk.marks.get(i))) continue;
@@ -920,13 +978,21 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
                 // the chain is complete: the fitting waves may have it
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __hip_atomic_store(&s_edges, (int)ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
             }
             if (!st && ps > (unsigned)o.max_edges) st = 2;
+#ifdef LF_ED_STAMP
+            if (LF_ED_STAMP < 7) s_diag = wk.diag;
+#endif
         }
         if (!st) sid[ps] = cpos;
         __hip_atomic_store(&s_fail, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __hip_atomic_store(&s_walked, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifdef LF_ED_STAMP
+        t_walk_end = __builtin_amdgcn_s_memtime();
+        if (LF_ED_STAMP == 8) s_diag = t_walk_end - t_walk;
+#endif
     }
     // ================= EDline (:2242-2482): the chains are independent -- every wave takes the next one =================
     // ... WHILE the first wave is still walking: a chain is published (s_edges) as soon as it is complete, the other seven
@@ -1160,7 +1226,11 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
         *reinterpret_cast<float4*>(l_ep + 4 * (size_t)d) = ep;
         l_c[d] = tl.c[t]; l_dir[d] = tl.dir[t]; l_npx[d] = tl.npx[t]; l_sal[d] = tl.sal[t];
     }
+#ifdef LF_ED_STAMP
+    if (tid == 0) { if (LF_ED_STAMP == 9) s_diag = __builtin_amdgcn_s_memtime() - t_walk_end; cnt[0] = n_anchors; cnt[1] = n_edges; cnt[2] = total; cnt[3] = (int)(s_diag >> 2); }
+#else
     if (tid == 0) { cnt[0] = n_anchors; cnt[1] = n_edges; cnt[2] = total; cnt[3] = 0; }
+#endif
 }
 
 size_t ed_detect_lds_bytes(int W, int H, int scan, bool* marks_in_lds)
