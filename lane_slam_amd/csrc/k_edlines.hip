@@ -474,7 +474,8 @@ extern "C" __device__ int ed_writelane(int v, int l, int old) __asm("llvm.amdgcn
 // -DLF_ED_STAMP=k (diagnostic builds, tools/ed_stamps.py): one quantity per build, summed over the walking wave of a frame,
 // returned in the frame's counts[3] (times in units of 4 cycles).  1: inside ed_walk, 2: of that, a window left until the
 // walk goes on in the next, 3: a walk's start (window reused or fetched), 4 / 5: windows fetched on leaving one / at a start,
-// 6: steps, 7: kernel start until the walk begins, 8: the walking phase, 9: from its end to the kernel's
+// 6: steps, 7: kernel start until the walk begins (10: until the candidates are tested), 8: the walking phase, 9: from its end to
+// the kernel's
 #ifdef LF_ED_STAMP
 #define ED_T0(k) unsigned long long t_##k = (LF_ED_STAMP == k) ? __builtin_amdgcn_s_memtime() : 0ull
 #define ED_T1(k, acc) do { if (LF_ED_STAMP == k) (acc) += __builtin_amdgcn_s_memtime() - t_##k; } while (0)
@@ -863,39 +864,62 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
     if (tid == 0) { s_base = 0; s_edges = 0; s_walked = 0; s_fail = 0; s_next_edge = 0; s_temp_next = 0; }
     __syncthreads();
     // ---- anchors (:1504-1532): tested row-major, recorded column-major.  All five loads of a candidate are issued
-    // whatever its direction, eight candidates per thread in flight: the phase is bound by the latency of the plane.  A
+    // whatever its direction, 8 or 16 candidates per thread in flight: the phase is bound by the latency of the plane.  A
     // thread's candidates are ED_THREADS apart: (row, column) advance by that stride's quotient and remainder -- one
     // division per thread (two per candidate until round 6: 100 of its 150 instructions)
     {
         const int step_q = ED_THREADS / (nW > 0 ? nW : 1), step_r = ED_THREADS - step_q * nW;
         int ch_n = tid / (nW > 0 ? nW : 1), cw_n = tid - ch_n * nW;
-        for (int i0 = tid; i0 < n_cand; i0 += ED_THREADS * 8) {
-            uint32_t v[8], va[8], vb[8], vl[8], vr[8];
-            int bit_i[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = i0 + ED_THREADS * u < n_cand;
-                const int ch = live ? ch_n : 0, cw = live ? cw_n : 0;
-                bit_i[u] = live ? cw * nH + ch : -1;
-                const int idx = (1 + scan * ch) * W + 1 + scan * cw;
-                v[u] = g[idx]; va[u] = g[idx - W]; vb[u] = g[idx + W]; vl[u] = g[idx - 1]; vr[u] = g[idx + 1];
-                cw_n += step_r; ch_n += step_q;
-                if (cw_n >= nW) { cw_n -= nW; ++ch_n; }
+        auto test = [&](uint32_t v, uint32_t va, uint32_t vb, uint32_t vl, uint32_t vr, int b) {
+            const int gv = (int)(v & 0x7fffu);
+            const bool hz = (v & kHorizontal) != 0;
+            const int n1 = (int)((hz ? va : vl) & 0x7fffu), n2 = (int)((hz ? vb : vr) & 0x7fffu);
+            if (b >= 0 && gv >= n1 + fp.anchor_threshold && gv >= n2 + fp.anchor_threshold) {
+                atomicOr(&flags[b >> 5], 1u << (b & 31));
+                if (hz) atomicOr(&fhz[b >> 5], 1u << (b & 31));
             }
+        };
+        auto next = [&](int i, int& idx) {                     // the candidate's bit (-1 past the end) and pixel; on to the thread's next
+            const bool live = i < n_cand;
+            const int ch = live ? ch_n : 0, cw = live ? cw_n : 0;
+            idx = (1 + scan * ch) * W + 1 + scan * cw;
+            cw_n += step_r; ch_n += step_q;
+            if (cw_n >= nW) { cw_n -= nW; ++ch_n; }
+            return live ? cw * nH + ch : -1;
+        };
+        if (((scan | W) & 1) == 0) {
+            // even columns to the left of every candidate: west | own | east as one 8-byte load at a 4-byte boundary, three loads
+            // per candidate, sixteen candidates in flight
+            struct __attribute__((packed, aligned(4))) Px4 { uint32_t lo, hi; };
+            for (int i0 = tid; i0 < n_cand; i0 += ED_THREADS * 16) {
+                Px4 q[16]; uint32_t va[16], vb[16]; int bit_i[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int gv = (int)(v[u] & 0x7fffu);
-                const bool hz = (v[u] & kHorizontal) != 0;
-                const int n1 = (int)((hz ? va[u] : vl[u]) & 0x7fffu), n2 = (int)((hz ? vb[u] : vr[u]) & 0x7fffu);
-                const int b = bit_i[u];
-                if (b >= 0 && gv >= n1 + fp.anchor_threshold && gv >= n2 + fp.anchor_threshold) {
-                    atomicOr(&flags[b >> 5], 1u << (b & 31));
-                    if (hz) atomicOr(&fhz[b >> 5], 1u << (b & 31));
+                for (int u = 0; u < 16; ++u) {
+                    int idx;
+                    bit_i[u] = next(i0 + ED_THREADS * u, idx);
+                    q[u] = *reinterpret_cast<const Px4*>(g + idx - 1); va[u] = g[idx - W]; vb[u] = g[idx + W];
                 }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) test(q[u].lo >> 16, va[u], vb[u], q[u].lo & 0xffffu, q[u].hi & 0xffffu, bit_i[u]);
+            }
+        } else {
+            for (int i0 = tid; i0 < n_cand; i0 += ED_THREADS * 8) {
+                uint32_t v[8], va[8], vb[8], vl[8], vr[8]; int bit_i[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int idx;
+                    bit_i[u] = next(i0 + ED_THREADS * u, idx);
+                    v[u] = g[idx]; va[u] = g[idx - W]; vb[u] = g[idx + W]; vl[u] = g[idx - 1]; vr[u] = g[idx + 1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) test(v[u], va[u], vb[u], vl[u], vr[u], bit_i[u]);
             }
         }
     }
     __syncthreads();
+#ifdef LF_ED_STAMP
+    if (LF_ED_STAMP == 10 && tid == 0) s_diag = __builtin_amdgcn_s_memtime() - t_start;   // zeroing + candidates
+#endif
     uint32_t* anchors = o.anchors + (size_t)f * o.cap;
     for (int start = 0; start < n_cwords; start += ED_THREADS) {
         const int wi = start + tid;
@@ -983,6 +1007,7 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
             if (!st && ps > (unsigned)o.max_edges) st = 2;
 #ifdef LF_ED_STAMP
             if (LF_ED_STAMP < 7) s_diag = wk.diag;
+            if (LF_ED_STAMP == 11) s_diag = (unsigned long long)ps * 4ull;
 #endif
         }
         if (!st) sid[ps] = cpos;

@@ -8,7 +8,7 @@ the slowest frame's value of each quantity.
 import argparse, ctypes, os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NAMES = {1: "cycles inside ed_walk", 2: "  a window left -> the walk goes on", 3: "  a walk's start", 4: "windows fetched on leaving one", 5: "windows fetched at a start",
-         6: "steps", 7: "cycles kernel start -> walk begins", 8: "cycles walking phase", 9: "cycles walk's end -> kernel's end"}
+         6: "steps", 7: "cycles kernel start -> walk begins", 8: "cycles walking phase", 9: "cycles walk's end -> kernel's end", 10: "cycles kernel start -> candidates tested"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--content", default="synthetic")
 ap.add_argument("--k", type=int, default=0)
@@ -41,5 +41,5 @@ total = ctypes.c_int()
 for _ in range(2):
     fe._check(fe.lib.lf_keylines_batch(fe.h, ctypes.c_void_p(d.data_ptr()), B, 0, 1, 1, None, ctypes.byref(s), 1, 1, ctypes.byref(total), None))
 cnt = fe.keylines_fetch(0, 6, B)
-v = cnt[:, 3].astype(np.int64) * (4 if args.k not in (4, 5, 6) else 1)
+v = cnt[:, 3].astype(np.int64) * (4 if args.k not in (4, 5, 6, 11) else 1)
 print("%-40s mean %9.0f   max %9d (frame %d: %d anchors)   of the frame with most anchors (%d): %d" % (NAMES[args.k], v.mean(), v.max(), int(v.argmax()), cnt[int(v.argmax()), 0], cnt[:, 0].max(), v[int(cnt[:, 0].argmax())]))
