@@ -262,7 +262,7 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
 
 constexpr int JH_DL = 2048;         // subsequences of a frame the dirty list of a correction pass holds (a 96 KB scan: what fits LDS)
 struct JhShared { JhTabs tabs; int s_changed, s_redo, s_err, s_nsub, s_wsum[JH_TD / 64], s_carry; int s_dc[JH_TD / 64][4], s_dcc[JH_TD / 64 + 1][3];
-                  int s_nd; uint16_t s_dlist[JH_DL]; };
+                  int s_nd; uint16_t s_dlist[JH_DL]; unsigned long long s_wmap[JH_TD / 64]; };
 
 // LDS = true: the clean scan sits in jh_dyn (the compiler sees an LDS address: ds_read instead of flat loads)
 template <bool LDS>
@@ -312,17 +312,111 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
     __syncthreads();
     int dummy_err = 0;
     const long long jt0 = getenv_debug ? (long long)wall_clock64() : 0;     // (LF_JH_DEBUG: where a frame's time goes, x10 ns)
-    // ---- pass 0: assumed entry states
+    // ---- pass 0: assumed entry states.  A decoder that starts out of step finds the bit position and the coefficient index
+    // again within a block or two as long as it applies the right tables, i.e. knows its place in the MCU -- with the wrong place
+    // it stays lost for ~25 subsequences (22 - 31 correction passes per frame until round 6, each a subsequence's latency with two
+    // or three lanes at work).  So the scan is decoded once per PLACE: UNITS of `sup` consecutive subsequences, each from "block h
+    // of the MCU, coefficient 0 at its first bit" for h = 0 .. bpm - 1, one lane per (unit, h), the state noted where it crosses
+    // into each subsequence.  The place a unit is left in is a map h -> h': composing the maps along the interval (a scan) names the
+    // hypothesis every unit is really entered with -- a unit is long enough for that hypothesis to have locked on before its end --
+    // and the correction passes below start from its notes: the units' first subsequences (entered off by part of a symbol), then the
+    // ~5 % whose predecessor had not locked on yet, then nothing.
+    const int bpm = sel.bpm;
+    uint32_t *h_bit = S + 9 * (size_t)MS, *h_pn = S + (9 + (size_t)bpm) * MS;      // [bpm][MS]: exit bit; exit phase | blocks completed << 16
+    uint32_t* unit_q = S + (9 + 2 * (size_t)bpm) * MS;        // [MS]: a unit's hypothesis, kept at its first subsequence
+    uint32_t* unit_lock = S + (10 + 2 * (size_t)bpm) * MS;    // [MS]: one thread per pass rewrites a unit's subsequences
+    const bool listed = n_sub <= JH_DL;                       // (larger scans: every subsequence its own unit)
+    const int sup = listed ? ((n_sub * bpm + JH_T - 1) / JH_T > 1 ? (n_sub * bpm + JH_T - 1) / JH_T : 1) : 1;
+    // the units' first subsequences, in order
+    int n_units = n_sub;
+    if (listed) {
+        if (t == 0) s_carry = 0;
+        __syncthreads();
+        for (int base = 0; base < n_sub; base += JH_T) {
+            const int u = base + t;
+            const bool head = u < n_sub && ((uint32_t)u - sub_first[u_seg[u]]) % (uint32_t)sup == 0u;
+            const unsigned long long bm = __ballot(head);
+            if (lane == 0) s_wsum[wave] = __popcll(bm);
+            __syncthreads();
+            int off = s_carry;
+            for (int w = 0; w < wave; ++w) off += s_wsum[w];
+            if (head) sh.s_dlist[off + __popcll(bm & ((1ull << lane) - 1ull))] = (uint16_t)u;
+            __syncthreads();
+            if (t == JH_T - 1) s_carry = off + __popcll(bm);
+            __syncthreads();
+        }
+        n_units = s_carry;
+    }
+    auto unit_head = [&](int k) { return listed ? (int)sh.s_dlist[k] : k; };
+    for (int j = t; j < n_units * bpm; j += JH_T) {
+        const int h = j / n_units, u0 = unit_head(j - h * n_units);
+        const int g = (int)u_seg[u0];
+        const uint32_t local0 = (uint32_t)u0 - sub_first[g];
+        if (local0 == 0u && h != 0) continue;                 // an interval starts with block 0
+        const uint32_t seg_end = sb[g + 1] * 8u;
+        const int u_end = u0 + sup < (int)sub_first[g + 1] ? u0 + sup : (int)sub_first[g + 1];
+        JhState st; st.bit = (sb[g] + local0 * JH_SB) * 8u; st.blk = h; st.k = 0;
+        for (int u = u0; u < u_end; ++u) {
+            uint32_t limit = (sb[g] + ((uint32_t)u - sub_first[g] + 1u) * JH_SB) * 8u;
+            if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
+            const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
+            h_bit[(size_t)h * MS + u] = st.bit; h_pn[(size_t)h * MS + u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k | ((uint32_t)nb << 16);
+        }
+    }
+    __syncthreads();
+    {
+        // maps as 4 bits per place (bpm <= 10, T.81 B.2.3); "a then b" = b[a[h]].  A thread composes its run of consecutive units,
+        // the runs are scanned across the workgroup, and the thread walks its run again with the place it is entered in
+        auto then = [&](unsigned long long a, unsigned long long b) {
+            unsigned long long r = 0ull;
+            for (int h = 0; h < bpm; ++h) r |= ((b >> (4 * (int)((a >> (4 * h)) & 15ull))) & 15ull) << (4 * h);
+            return r;
+        };
+        auto unit_last = [&](int u0) { const int e = (int)sub_first[u_seg[u0] + 1]; return (u0 + sup < e ? u0 + sup : e) - 1; };
+        auto map_of = [&](int u0) {
+            unsigned long long m = 0ull;
+            const bool first = (uint32_t)u0 == sub_first[u_seg[u0]];
+            const int ul = unit_last(u0);
+            for (int h = 0; h < bpm; ++h) m |= (unsigned long long)((h_pn[(size_t)(first ? 0 : h) * MS + ul] >> 8) & 15u) << (4 * h);
+            return m;
+        };
+        unsigned long long ident = 0ull;
+        for (int h = 0; h < bpm; ++h) ident |= (unsigned long long)h << (4 * h);
+        const int R = (n_units + JH_T - 1) / JH_T, k0 = t * R < n_units ? t * R : n_units, k1 = k0 + R < n_units ? k0 + R : n_units;
+        unsigned long long run = ident;
+        for (int k = k0; k < k1; ++k) run = then(run, map_of(unit_head(k)));
+        unsigned long long inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long o = (unsigned long long)__shfl_up((long long)inc, d);
+            if (lane >= d) inc = then(o, inc);
+        }
+        if (lane == 63) sh.s_wmap[wave] = inc;
+        __syncthreads();
+        unsigned long long before = ident;
+        for (int w = 0; w < wave; ++w) before = then(before, sh.s_wmap[w]);
+        const unsigned long long up = (unsigned long long)__shfl_up((long long)inc, 1);
+        if (lane > 0) before = then(before, up);
+        int q = (int)(before & 15ull);                        // (the frame's first unit heads an interval: what comes before it is void)
+        for (int k = k0; k < k1; ++k) {
+            const int u0 = unit_head(k);
+            if ((uint32_t)u0 == sub_first[u_seg[u0]]) q = 0;
+            unit_q[u0] = (uint32_t)q;
+            q = (int)((h_pn[(size_t)q * MS + unit_last(u0)] >> 8) & 15u);
+        }
+    }
+    __syncthreads();
+    // every subsequence: exit as its unit's hypothesis notes it; entry = what that hypothesis entered it with -- its predecessor's
+    // exit inside a unit, and for a unit's first subsequence nothing a predecessor can hand over (so that the first pass decodes it)
     for (int u = t; u < n_sub; u += JH_T) {
         const int g = (int)u_seg[u];
-        const uint32_t local = (uint32_t)u - sub_first[g];
-        const uint32_t start = (sb[g] + local * JH_SB) * 8u, seg_end = sb[g + 1] * 8u;
-        uint32_t limit = start + JH_SB * 8u;
-        if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
-        JhState st; st.bit = start; st.blk = 0; st.k = 0;
-        u_ebit[u] = st.bit; u_eph[u] = 0u;
-        const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
-        u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
+        const uint32_t local = (uint32_t)u - sub_first[g], in_unit = local % (uint32_t)sup;
+        const int q = (int)unit_q[u - (int)in_unit];
+        const uint32_t pn = h_pn[(size_t)q * MS + u];
+        u_xbit[u] = h_bit[(size_t)q * MS + u]; u_xph[u] = pn & 0xffffu; u_nblk[u] = pn >> 16;
+        if (local == 0u) { u_ebit[u] = sb[g] * 8u; u_eph[u] = 0u; }
+        else if (in_unit == 0u) { u_ebit[u] = 0xffffffffu; u_eph[u] = 0u; }
+        else { u_ebit[u] = h_bit[(size_t)q * MS + u - 1]; u_eph[u] = h_pn[(size_t)q * MS + u - 1] & 0xffffu; }
     }
     __syncthreads();
     const long long jt1 = getenv_debug ? (long long)wall_clock64() : 0;
@@ -331,8 +425,20 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         // The subsequences a pass has to decode again are COMPACTED first (round 5): after the first two or three passes they are a few
         // dozen, scattered over all sixteen waves -- and a wave with one live lane issues the symbol loop's ~100 instructions per symbol
         // like a full one, four such waves to a SIMD.  Listed densely they keep one or two waves busy, one per SIMD.
-        for (int pass = 0; pass < n_sub + 1; ++pass) {
-            if (t == 0) sh.s_nd = 0;
+        // A subsequence whose entry is not what its predecessor hands over: inside a unit, the unit's hypotheses are looked at
+        // first -- the one that crossed into it in exactly that state has decoded the rest of the unit already, its notes ARE the
+        // decode from that state (no other hypothesis can have locked on: the next pass finds the unit's remaining subsequences in
+        // step); a unit's first subsequence is decoded, and the rest of the unit takes the notes of the hypothesis of its new place.
+        auto adopt = [&](int h, int u_from, int u_end) {      // subsequences u_from .. u_end - 1 as hypothesis h notes them (u_from inside the unit)
+            for (int w = u_from; w < u_end; ++w) {
+                const uint32_t pn = h_pn[(size_t)h * MS + w];
+                u_ebit[w] = h_bit[(size_t)h * MS + w - 1]; u_eph[w] = h_pn[(size_t)h * MS + w - 1] & 0xffffu;
+                u_xbit[w] = h_bit[(size_t)h * MS + w]; u_xph[w] = pn & 0xffffu; u_nblk[w] = pn >> 16;
+            }
+        };
+        for (int pass = 0; pass < 2 * n_sub + 2; ++pass) {
+            if (t == 0) { sh.s_nd = 0; s_changed = 0; }
+            for (int u = t; u < n_sub; u += JH_T) unit_lock[u] = 0u;
             __syncthreads();
             for (int u0 = 0; u0 < n_sub; u0 += JH_T) {
                 const int u = u0 + t;
@@ -342,6 +448,21 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
                     if ((uint32_t)u != sub_first[g]) {
                         const uint32_t cb = u_xbit[u - 1], cp = u_xph[u - 1];
                         dirty = !(cb == u_ebit[u] && cp == u_eph[u]);
+                        if (dirty && sup > 1) {
+                            const int in_unit = (int)(((uint32_t)u - sub_first[g]) % (uint32_t)sup);
+                            const int u_end = u - in_unit + sup < (int)sub_first[g + 1] ? u - in_unit + sup : (int)sub_first[g + 1];
+                            // (one thread per unit and pass writes beyond its own subsequence: a record is one decode's entry AND exit)
+                            if (atomicCAS(&unit_lock[u - in_unit], 0u, 1u) != 0u) { }
+                            else if (in_unit > 0) {
+                                int m = -1;
+                                for (int h = 0; h < bpm; ++h)
+                                    if (h_bit[(size_t)h * MS + u - 1] == cb && (h_pn[(size_t)h * MS + u - 1] & 0xffffu) == cp) { m = h; break; }
+                                if (m >= 0) { adopt(m, u, u_end); dirty = false; s_changed = 1; }
+                            } else {
+                                const int q = (int)(cp >> 8);
+                                if (q < bpm && (uint32_t)q != unit_q[u]) { unit_q[u] = (uint32_t)q; adopt(q, u + 1, u_end); }
+                            }
+                        }
                         if (dirty) { u_cbit[u] = cb; u_cph[u] = cp; }
                     }
                 }
@@ -355,8 +476,9 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
             }
             __syncthreads();
             const int n_dirty = sh.s_nd;
-            if (n_dirty == 0) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d redone %d passes %d\n", f, n_sub, s_redo, pass + 1); break; }
+            if (n_dirty == 0 && s_changed == 0) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d redone %d passes %d\n", f, n_sub, s_redo, pass + 1); break; }
             if (getenv_debug && t == 0) s_redo += n_dirty;
+            if (getenv_debug > 1 && t == 0 && f == 0) { printf("  pass %d sup %d dirty %d:", pass, sup, n_dirty); for (int j = 0; j < n_dirty && j < 24; ++j) printf(" %d", (int)sh.s_dlist[j]); printf("\n"); }
             for (int j = t; j < n_dirty; j += JH_T) {
                 const int u = (int)sh.s_dlist[j];
                 const int g = (int)u_seg[u];
@@ -683,7 +805,7 @@ void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, size_t ma
     if (lds_raw > JH_LDS_CLEAN) lds_raw = 0;                             // larger scans are read from global memory
     if (lds_raw > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jh_unstuff), hipFuncAttributeMaxDynamicSharedMemorySize, lds_raw);
     hipLaunchKernelGGL(k_jh_unstuff, dim3(n_frames), dim3(JH_T), (size_t)lds_raw, s, frames, bytes, clean, seg_begin, I, lds_raw);
-    static const int dbg = getenv("LF_JH_DEBUG") ? 1 : 0;          // diagnostic: passes until the subsequences agree, per frame
+    static const int dbg = getenv("LF_JH_DEBUG") ? atoi(getenv("LF_JH_DEBUG")) : 0;          // diagnostic: passes until the subsequences agree, per frame
     // LDS for the largest scan of the batch (clean <= raw), up to JH_LDS_CLEAN; larger scans are read from global memory
     int lds = (int)(max_scan_len + 64 + (max_scan_len + 64) / 32 + 32 + 15) & ~15;
     if (lds > JH_LDS_CLEAN) lds = JH_LDS_CLEAN;

@@ -1,6 +1,6 @@
 """Correction passes and phase times of the device Huffman decoder per frame (LF_JH_DEBUG=1): six synthetic and four camera streams."""
 import io, os, sys
-os.environ["LF_JH_DEBUG"] = "1"
+os.environ.setdefault("LF_JH_DEBUG", "1")
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from PIL import Image
