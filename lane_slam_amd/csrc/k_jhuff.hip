@@ -325,6 +325,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
     uint32_t *h_bit = S + 9 * (size_t)MS, *h_pn = S + (9 + (size_t)bpm) * MS;      // [bpm][MS]: exit bit; exit phase | blocks completed << 16
     uint32_t* unit_q = S + (9 + 2 * (size_t)bpm) * MS;        // [MS]: a unit's hypothesis, kept at its first subsequence
     uint32_t* unit_lock = S + (10 + 2 * (size_t)bpm) * MS;    // [MS]: one thread per pass rewrites a unit's subsequences
+    uint32_t* sub_pass = S + (11 + 2 * (size_t)bpm) * MS;     // [MS]: the pass (+ 1) a subsequence was last listed for decoding in
     const bool listed = n_sub <= JH_DL;                       // (larger scans: every subsequence its own unit)
     const int sup = listed ? ((n_sub * bpm + JH_T - 1) / JH_T > 1 ? (n_sub * bpm + JH_T - 1) / JH_T : 1) : 1;
     // the units' first subsequences, in order
@@ -463,7 +464,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
                                 if (q < bpm && (uint32_t)q != unit_q[u]) { unit_q[u] = (uint32_t)q; adopt(q, u + 1, u_end); }
                             }
                         }
-                        if (dirty) { u_cbit[u] = cb; u_cph[u] = cp; }
+                        if (dirty) { u_cbit[u] = cb; u_cph[u] = cp; sub_pass[u] = (uint32_t)pass + 1u; }
                     }
                 }
                 const unsigned long long bm = __ballot(dirty);
@@ -491,6 +492,31 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
                 u_ebit[u] = cb; u_eph[u] = cp;
                 const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
                 u_xbit[u] = st.bit; u_xph[u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[u] = (uint32_t)nb;
+                // ... and on through the rest of the unit while nothing there is in step with it: the subsequence after it that is
+                // entered in another state and not on this pass's list is looked up among the hypotheses (their notes from there to
+                // the next listed subsequence) or decoded in turn -- a front that no hypothesis meets walks a unit in one pass
+                if (sup > 1) {
+                    const int in_unit = (int)(local % (uint32_t)sup);
+                    const int ue = u - in_unit + sup < (int)sub_first[g + 1] ? u - in_unit + sup : (int)sub_first[g + 1];
+                    for (int w = u + 1; w < ue && sub_pass[w] != (uint32_t)pass + 1u; ++w) {
+                        const uint32_t xb = st.bit, xp = ((uint32_t)st.blk << 8) | (uint32_t)st.k;
+                        if (u_ebit[w] == xb && u_eph[w] == xp) break;
+                        int m = -1;
+                        for (int h = 0; h < bpm; ++h)
+                            if (h_bit[(size_t)h * MS + w - 1] == xb && (h_pn[(size_t)h * MS + w - 1] & 0xffffu) == xp) { m = h; break; }
+                        if (m >= 0) {
+                            int e = w + 1;
+                            while (e < ue && sub_pass[e] != (uint32_t)pass + 1u) ++e;
+                            adopt(m, w, e);
+                            break;
+                        }
+                        uint32_t lim = (sb[g] + ((uint32_t)w - sub_first[g] + 1u) * JH_SB) * 8u;
+                        if (lim > seg_end || (uint32_t)w + 1 == sub_first[g + 1]) lim = seg_end;
+                        u_ebit[w] = xb; u_eph[w] = xp;
+                        const int nbw = jh_span<false, LDS>(tabs, sel, clean, st, lim, seg_end, nullptr, 0, 0, dummy_err);
+                        u_xbit[w] = st.bit; u_xph[w] = ((uint32_t)st.blk << 8) | (uint32_t)st.k; u_nblk[w] = (uint32_t)nbw;
+                    }
+                }
             }
             __syncthreads();
         }
