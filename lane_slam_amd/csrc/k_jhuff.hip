@@ -229,6 +229,7 @@ __device__ __forceinline__ int jh_span(const JhTabs& tabs, const JhSel sel, cons
         if (bad) {
             if (WRITE) { err |= 2; break; }
             n = 1;                                      // speculative decode out of step: slide on, the true state arrives later
+            ++err;                                      // (speculative: err counts these)
         } else {
             if (WRITE && sz) {
                 const int v = (int)((w << len) >> (32 - sz));
@@ -357,11 +358,12 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         const uint32_t seg_end = sb[g + 1] * 8u;
         const int u_end = u0 + sup < (int)sub_first[g + 1] ? u0 + sup : (int)sub_first[g + 1];
         JhState st; st.bit = (sb[g] + local0 * JH_SB) * 8u; st.blk = h; st.k = 0;
+        const int bad0 = dummy_err;
         for (int u = u0; u < u_end; ++u) {
             uint32_t limit = (sb[g] + ((uint32_t)u - sub_first[g] + 1u) * JH_SB) * 8u;
             if (limit > seg_end || (uint32_t)u + 1 == sub_first[g + 1]) limit = seg_end;
             const int nb = jh_span<false, LDS>(tabs, sel, clean, st, limit, seg_end, nullptr, 0, 0, dummy_err);
-            h_bit[(size_t)h * MS + u] = st.bit; h_pn[(size_t)h * MS + u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k | ((uint32_t)nb << 16);
+            h_bit[(size_t)h * MS + u] = st.bit; h_pn[(size_t)h * MS + u] = ((uint32_t)st.blk << 8) | (uint32_t)st.k | ((uint32_t)nb << 16) | ((uint32_t)(dummy_err - bad0 < 255 ? dummy_err - bad0 : 255) << 24);
         }
     }
     __syncthreads();
@@ -414,7 +416,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         const uint32_t local = (uint32_t)u - sub_first[g], in_unit = local % (uint32_t)sup;
         const int q = (int)unit_q[u - (int)in_unit];
         const uint32_t pn = h_pn[(size_t)q * MS + u];
-        u_xbit[u] = h_bit[(size_t)q * MS + u]; u_xph[u] = pn & 0xffffu; u_nblk[u] = pn >> 16;
+        u_xbit[u] = h_bit[(size_t)q * MS + u]; u_xph[u] = pn & 0xffffu; u_nblk[u] = (pn >> 16) & 255u;
         if (local == 0u) { u_ebit[u] = sb[g] * 8u; u_eph[u] = 0u; }
         else if (in_unit == 0u) { u_ebit[u] = 0xffffffffu; u_eph[u] = 0u; }
         else { u_ebit[u] = h_bit[(size_t)q * MS + u - 1]; u_eph[u] = h_pn[(size_t)q * MS + u - 1] & 0xffffu; }
@@ -434,7 +436,7 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
             for (int w = u_from; w < u_end; ++w) {
                 const uint32_t pn = h_pn[(size_t)h * MS + w];
                 u_ebit[w] = h_bit[(size_t)h * MS + w - 1]; u_eph[w] = h_pn[(size_t)h * MS + w - 1] & 0xffffu;
-                u_xbit[w] = h_bit[(size_t)h * MS + w]; u_xph[w] = pn & 0xffffu; u_nblk[w] = pn >> 16;
+                u_xbit[w] = h_bit[(size_t)h * MS + w]; u_xph[w] = pn & 0xffffu; u_nblk[w] = (pn >> 16) & 255u;
             }
         };
         for (int pass = 0; pass < 2 * n_sub + 2; ++pass) {
@@ -553,6 +555,23 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
         if (!any) { if (t == 0 && getenv_debug) printf("frame %d: n_sub %d redone %d passes %d\n", f, n_sub, s_redo, pass + 1); break; }
     }
     const long long jt2 = getenv_debug ? (long long)wall_clock64() : 0;
+    if (getenv_debug > 2 && t == 0 && f == 0 && sup > 1) {
+        // (diagnostic) per position in the unit: hypotheses that had slid over an undecodable symbol by then -- among those whose
+        // notes ARE the truth there (exit equals the final exit), and among the others
+        int tb[8] = {0}, tn[8] = {0}, wb[8] = {0}, wn[8] = {0};
+        for (int u = 0; u < n_sub; ++u) {
+            const int g = (int)u_seg[u];
+            const uint32_t local = (uint32_t)u - sub_first[g];
+            const int i = (int)(local % (uint32_t)sup) < 8 ? (int)(local % (uint32_t)sup) : 7;
+            for (int h = 0; h < bpm; ++h) {
+                if (local < (uint32_t)sup && h != 0) continue;
+                const uint32_t pn = h_pn[(size_t)h * MS + u];
+                const bool truth = h_bit[(size_t)h * MS + u] == u_xbit[u] && (pn & 0xffffu) == u_xph[u];
+                if (truth) { ++tn[i]; tb[i] += (pn >> 24) != 0u; } else { ++wn[i]; wb[i] += (pn >> 24) != 0u; }
+            }
+        }
+        for (int i = 0; i < 8; ++i) printf("  unit position %d: true notes %d (flagged %d), others %d (flagged %d)\n", i, tn[i], tb[i], wn[i], wb[i]);
+    }
     // ---- blocks completed before every subsequence (exclusive prefix over the frame's subsequences)
     if (t == 0) s_carry = 0;
     __syncthreads();
