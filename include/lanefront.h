@@ -551,6 +551,15 @@ LF_API int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const 
 LF_API int lf_jpeg_decode_batch_gpu(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
                              int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
                              int* frame_status);
+/* The same, QUEUED (round 6): frames_device is a device address (the handle's own buffer, lf_frames_buffer, or the caller's); the call
+ * returns when the headers are parsed and the work is on the handle's stream -- hand the buffer to lf_process_batch_async on the
+ * same handle next, nothing in between waits for the device (lf_jpeg_decode_batch_gpu returns when the batch is decoded: a feeder
+ * thread spent the decoder's 1 - 3 ms per batch inside it).  The per-frame status (as lf_jpeg_decode_batch's frame_status; frames
+ * that could not be decoded are zeros) is read with lf_jpeg_status, which waits for the decode of the handle's last queued batch
+ * alone; one queued batch per handle at a time.  n_failed: optional count of frames whose status is not LF_OK. */
+LF_API int lf_jpeg_decode_batch_gpu_async(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
+                                   int rows, int cols, uint8_t* frames_device, int n_threads);
+LF_API int lf_jpeg_status(lf_handle* h, int* frame_status, int n_frames, int* n_failed);
 /* size and layout of one stream without decoding it (hmax x vmax = luma sampling factors) */
 LF_API int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax);
 /* the handle's own device staging buffer for input frames ([max_frames][in_rows][in_cols][3] u8): decode

@@ -41,6 +41,9 @@ struct JpegState {
     size_t h_stage_bytes = 0;
     hipEvent_t staged = nullptr;                    // the last H2D out of h_stage has completed
     bool staged_pending = false;
+    int* h_status_pinned = nullptr;                 // lf_jpeg_decode_batch_gpu_async: the per-frame status, read back behind status_done
+    int h_status_pinned_n = 0, status_frames = 0;
+    hipEvent_t status_done = nullptr;
 };
 
 struct lf_handle {
@@ -627,6 +630,8 @@ extern "C" void lf_destroy(lf_handle* h)
         for (DevBuf* b : { &j->planes, &j->entries, &j->block_end, &j->hdrs, &j->out, &j->gh_clean, &j->gh_sub, &j->gh_seg, &j->gh_info, &j->gh_coef }) if (b->p) (void)hipFree(b->p);
         if (j->h_stage) (void)hipHostFree(j->h_stage);
         if (j->staged) (void)hipEventDestroy(j->staged);
+        if (j->status_done) (void)hipEventDestroy(j->status_done);
+        if (j->h_status_pinned) (void)hipHostFree(j->h_status_pinned);
         delete j;
     }
     kl_free(h->kl);

@@ -489,6 +489,30 @@ class FrontEnd(object):
         self._check(fn(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), 1, n_threads, st))
         return status
 
+    def decode_jpeg_batch_async(self, streams, device_ptr=None, rows=None, cols=None, n_threads=0):
+        """The queued form of decode_jpeg_batch(entropy="gpu") (lf_jpeg_decode_batch_gpu_async): headers are parsed and the entropy-coded
+        bytes staged before the call returns, everything else runs behind it on the handle's stream -- follow it with submit_device on
+        the same buffer.  device_ptr None: the handle's own frame buffer.  The per-frame status comes from jpeg_status().  Returns the
+        device address the frames are written to."""
+        n = len(streams)
+        rows = self.cfg["in_size"][0] if rows is None else rows
+        cols = self.cfg["in_size"][1] if cols is None else cols
+        if device_ptr is None:
+            device_ptr = self.frames_buffer()[0]
+        keep = [b if isinstance(b, bytes) else bytes(b) for b in streams]
+        ptrs = ctypes.cast((ctypes.c_char_p * n)(*[b if len(b) else None for b in keep]), ctypes.POINTER(ctypes.c_void_p))
+        sizes = (ctypes.c_size_t * n)(*[len(b) for b in keep])
+        self._check(self.lib.lf_jpeg_decode_batch_gpu_async(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), n_threads))
+        self._jpeg_queued = n
+        return int(device_ptr)
+
+    def jpeg_status(self):
+        """Per-frame status (int32 [n]) of the batch decode_jpeg_batch_async queued last; waits for that decode alone."""
+        n = getattr(self, "_jpeg_queued", 0)
+        status = np.zeros(n, np.int32)
+        self._check(self.lib.lf_jpeg_status(self.h, status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n, None))
+        return status
+
     def frames_buffer(self):
         """(device address, bytes) of the handle's own input staging buffer ([max_frames][in_rows][in_cols][3])."""
         p, nb = ctypes.c_void_p(), ctypes.c_size_t()

@@ -6,6 +6,7 @@ import os
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before the HIP library is loaded: torch brings its own HIP runtime, which has to initialise first)
 
 from lane_slam_amd import FrontEnd, default_config, synth
 
@@ -212,4 +213,47 @@ def test_device_entropy_decoder_on_large_frames_and_restart_intervals():
         pil = np.asarray(Image.open(io.BytesIO(streams[i])).convert("RGB"))[..., ::-1]
         assert np.array_equal(g[i], pil), i
         assert np.array_equal(g[i], h[i]), i
+    fe2.close()
+
+
+def test_queued_decode_equals_the_waiting_call(fe, vectors):
+    """lf_jpeg_decode_batch_gpu_async + lf_jpeg_status: the same frames and the same per-frame status as the call that waits, a batch
+    with streams the reference would drop included; then the queued batch straight into the front end, nothing waited for in between."""
+    names = ["lane_q75_444", "lane_q30_422", "lane_q95_420", "gray", "lane_rst_420"]
+    streams = [bytes(vectors["jpeg_" + n]) for n in names]
+    streams.insert(2, bytes(vectors["jpeg_truncated"]))
+    streams.insert(4, bytes(vectors["jpeg_progressive"]))
+    streams.append(b"")
+    rows, cols = (int(v) for v in vectors["shape_lane_q75_444"][:2])
+    want, want_status = fe.decode_jpeg_batch(streams, rows=rows, cols=cols, n_threads=3)
+    d = torch.full((len(streams), rows, cols, 3), 7, dtype=torch.uint8, device="cuda")
+    assert fe.decode_jpeg_batch_async(streams, device_ptr=d.data_ptr(), rows=rows, cols=cols, n_threads=3) == d.data_ptr()
+    status = fe.jpeg_status()
+    assert list(status) == list(want_status) == [0, 0, -6, 0, -5, 0, 0, -1]
+    assert np.array_equal(d.cpu().numpy(), want)
+    # a status asked for without a queued batch, or for another number of frames, is an error
+    from lane_slam_amd import LanefrontError
+    import ctypes
+    st = (ctypes.c_int * 3)()
+    assert fe.lib.lf_jpeg_status(fe.h, st, 3, None) != 0
+    fe2 = FrontEnd(default_config("parity"), max_frames=8)
+    assert fe2.lib.lf_jpeg_status(fe2.h, st, 3, None) != 0
+    # decode -> detect on the handle's own buffer, queued back to back
+    B = 6
+    host = synth.make_batch(B, seed0=40, threads=2)
+    js = []
+    from PIL import Image
+    for i in range(B):
+        b = io.BytesIO()
+        Image.fromarray(host[i][..., ::-1].copy()).save(b, "JPEG", quality=85, subsampling=2)
+        js.append(b.getvalue())
+    frames, st_ = fe2.decode_jpeg_batch(js)
+    assert not st_.any()
+    ref = fe2.process_batch(frames)
+    buf = fe2.decode_jpeg_batch_async(js)
+    got = fe2.process_batch(buf, n_frames=B)
+    assert not fe2.jpeg_status().any()
+    assert got.n == ref.n and ref.n > 0
+    for k in ("frame_offset", "lines", "ground", "keep", "code"):
+        assert np.array_equal(getattr(got, k), getattr(ref, k)), k
     fe2.close()

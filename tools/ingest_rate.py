@@ -60,7 +60,10 @@ for ent, nt in [(e, int(t)) for e in args.entropy.split(",") for t in args.threa
         for k in range(n):
             sl = mine[k % len(mine)]
             if len(infl) == len(mine): fes[infl.pop(0)].wait()
-            fes[sl].decode_jpeg_batch(streams, n_threads=max(1, nt // F), device_ptr=bufs[sl], entropy=ent)
+            if ent == "gpu":                                   # queued (round 6): the feeder does not wait for the decoder
+                fes[sl].decode_jpeg_batch_async(streams, device_ptr=bufs[sl], n_threads=max(1, nt // F))
+            else:
+                fes[sl].decode_jpeg_batch(streams, n_threads=max(1, nt // F), device_ptr=bufs[sl], entropy=ent)
             fes[sl].submit_device(bufs[sl], B, ptrs[sl], cap, describe=True)
             infl.append(sl)
         while infl: fes[infl.pop(0)].wait()
