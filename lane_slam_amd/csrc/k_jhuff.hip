@@ -70,10 +70,11 @@ __device__ __forceinline__ int jh_classify(const uint8_t* raw, uint32_t i, uint3
 
 extern __shared__ uint32_t jh_dyn[];                         // k_jh_unstuff: the raw scan; k_jh_decode: the clean scan (when they fit)
 
-struct JhUShared { uint32_t s_term; int s_wk[4], s_wm[4], s_ck, s_cm, s_err; };
+template <int NT> struct JhUShared { uint32_t s_term; int s_wk[NT / 64], s_wm[NT / 64], s_ck, s_cm, s_err; };
 
-template <bool PAD>
-__device__ __forceinline__ void jh_unstuff_body(JhUShared& sh, const jpeg::DevFrame& F, JhInfo* I, const uint8_t* raw, uint8_t* __restrict__ out,
+// NT threads: k_jh_unstuff's 256, or the decoder's workgroup (k_jh_decode unstuffs its own frame when the raw scan fits LDS: round 6)
+template <bool PAD, int NT>
+__device__ __forceinline__ void jh_unstuff_body(JhUShared<NT>& sh, const jpeg::DevFrame& F, JhInfo* I, const uint8_t* raw, uint8_t* __restrict__ out,
                                                 uint32_t* __restrict__ sb)
 {
     uint32_t& s_term = sh.s_term; int* s_wk = sh.s_wk; int* s_wm = sh.s_wm; int& s_ck = sh.s_ck; int& s_cm = sh.s_cm; int& s_err = sh.s_err;
@@ -83,14 +84,14 @@ __device__ __forceinline__ void jh_unstuff_body(JhUShared& sh, const jpeg::DevFr
     __syncthreads();
     // the scan ends at the first marker that is not a restart marker (EOI, normally)
     uint32_t term = L;
-    for (uint32_t i = t; i < L; i += JH_T)
+    for (uint32_t i = t; i < L; i += NT)
         if (jh_raw<PAD>(raw, i) == 0xFFu && jh_classify<PAD>(raw, i, L, F.restart) == 3) { term = i; break; }
     atomicMin(&s_term, term);
     __syncthreads();
     const uint32_t T = s_term;
     const int expected_seg = F.restart > 0 ? (F.n_mcu + F.restart - 1) / F.restart : 1;
     // chunks of 128 raw bytes per thread, rounds of 256 chunks: kept bytes and restart markers before every chunk
-    for (uint32_t base = 0; base < T; base += (uint32_t)JH_T * 128u) {
+    for (uint32_t base = 0; base < T; base += (uint32_t)NT * 128u) {
         const uint32_t c0 = base + (uint32_t)t * 128u;
         const uint32_t c1 = c0 + 128u < T ? c0 + 128u : T;
         int kept = 0, marks = 0;
@@ -114,11 +115,11 @@ __device__ __forceinline__ void jh_unstuff_body(JhUShared& sh, const jpeg::DevFr
             }
         }
         __syncthreads();
-        if (t == JH_T - 1) { s_ck = pos; s_cm = ord; }
+        if (t == NT - 1) { s_ck = pos; s_cm = ord; }
         __syncthreads();
     }
     const int clean_len = s_ck, found = s_cm + 1;
-    for (int i = t; i < 32; i += JH_T) out[clean_len + i] = 0;          // the bit reader may look (never consume) past the end
+    for (int i = t; i < 32; i += NT) out[clean_len + i] = 0;          // the bit reader may look (never consume) past the end
     if (t == 0) {
         int err = s_err;
         int n_seg = found;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __res
                                                      uint8_t* __restrict__ clean, uint32_t* __restrict__ seg_begin, JhInfo* __restrict__ info,
                                                      int lds_raw_bytes)
 {
-    __shared__ JhUShared sh;
+    __shared__ JhUShared<JH_T> sh;
     const int f = blockIdx.x, t = threadIdx.x;
     const jpeg::DevFrame& F = frames[f];
     JhInfo* I = info + f;
@@ -151,9 +152,9 @@ __global__ __launch_bounds__(JH_T) void k_jh_unstuff(const jpeg::DevFrame* __res
         const int n4 = (int)((L + 3) / 4);
         for (int i = t; i < n4; i += JH_T) jh_dyn[i + (i >> 5)] = src[i];
         __syncthreads();
-        jh_unstuff_body<true>(sh, F, I, reinterpret_cast<const uint8_t*>(jh_dyn), out, sb);
+        jh_unstuff_body<true, JH_T>(sh, F, I, reinterpret_cast<const uint8_t*>(jh_dyn), out, sb);
     } else {
-        jh_unstuff_body<false>(sh, F, I, raw, out, sb);
+        jh_unstuff_body<false, JH_T>(sh, F, I, raw, out, sb);
     }
 }
 
@@ -676,19 +677,32 @@ __device__ __forceinline__ void jh_frame(JhShared& sh, jpeg::DevFrame& F, JhInfo
     }
 }
 
-__global__ __launch_bounds__(JH_TD) void k_jh_decode(jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ clean_all,
-                                                    const uint32_t* __restrict__ seg_begin_all, JhInfo* __restrict__ info,
+__global__ __launch_bounds__(JH_TD) void k_jh_decode(jpeg::DevFrame* __restrict__ frames, const uint8_t* __restrict__ bytes, uint8_t* __restrict__ clean_all,
+                                                    uint32_t* __restrict__ seg_begin_all, JhInfo* __restrict__ info,
                                                     uint32_t* __restrict__ sub_all, int16_t* __restrict__ coef_all, int* __restrict__ status, int getenv_debug,
-                                                    int lds_clean_bytes)
+                                                    int lds_clean_bytes, int unstuff_here)
 {
     __shared__ JhShared sh;
+    __shared__ JhUShared<JH_TD> shu;
     const int f = blockIdx.x, t = threadIdx.x;
     jpeg::DevFrame& F = frames[f];
     JhInfo* I = info + f;
-    if (!F.hdr.valid) return;
+    if (!F.hdr.valid) { if (unstuff_here && t == 0) { I->clean_len = 0; I->n_seg = 0; I->n_sub = 0; I->err = 0; } return; }
+    uint8_t* clean = clean_all + F.clean_off;
+    uint32_t* sb = seg_begin_all + F.seg_off;
+    if (unstuff_here) {
+        // the frame's raw scan through LDS (every scan of the batch fits: the host has checked), unstuffed into `clean` by all 1 024
+        // threads: k_jh_unstuff's 256 took 0.17 ms per batch for it, and a launch
+        const uint32_t L = F.scan_len;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(bytes + F.scan_off);     // scan_off is a multiple of 16
+        const int n4 = (int)((L + 3) / 4);
+        for (int i = t; i < n4; i += JH_TD) jh_dyn[i + (i >> 5)] = src[i];
+        __syncthreads();
+        jh_unstuff_body<true, JH_TD>(shu, F, I, reinterpret_cast<const uint8_t*>(jh_dyn), clean, sb);
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int i = t; i < (int)(sizeof(JhTabs) / 4); i += JH_TD) reinterpret_cast<uint32_t*>(&sh.tabs)[i] = reinterpret_cast<const uint32_t*>(F.tabs)[i];
-    const uint8_t* clean = clean_all + F.clean_off;
-    const uint32_t* sb = seg_begin_all + F.seg_off;
     if (lds_clean_bytes > 0 && (I->clean_len + 48) + (I->clean_len + 48) / 32 + 16 <= lds_clean_bytes) {
         // the unstuffed scan into LDS once: every pass reads it again
         const uint32_t* src = reinterpret_cast<const uint32_t*>(clean);     // clean_off is a multiple of 16
@@ -848,14 +862,18 @@ void launch_jh_decode(const JpegGeom& g, int n_frames, int max_blocks, size_t ma
     JhInfo* I = static_cast<JhInfo*>(info);
     int lds_raw = (int)(max_scan_len + max_scan_len / 32 + 64 + 15) & ~15;
     if (lds_raw > JH_LDS_CLEAN) lds_raw = 0;                             // larger scans are read from global memory
-    if (lds_raw > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jh_unstuff), hipFuncAttributeMaxDynamicSharedMemorySize, lds_raw);
-    hipLaunchKernelGGL(k_jh_unstuff, dim3(n_frames), dim3(JH_T), (size_t)lds_raw, s, frames, bytes, clean, seg_begin, I, lds_raw);
     static const int dbg = getenv("LF_JH_DEBUG") ? atoi(getenv("LF_JH_DEBUG")) : 0;          // diagnostic: passes until the subsequences agree, per frame
+    static const int split = getenv("LF_JH_SPLIT") ? 1 : 0;                                    // A/B: the unstuffing kernel of rounds 3 - 5 in front
     // LDS for the largest scan of the batch (clean <= raw), up to JH_LDS_CLEAN; larger scans are read from global memory
     int lds = (int)(max_scan_len + 64 + (max_scan_len + 64) / 32 + 32 + 15) & ~15;
     if (lds > JH_LDS_CLEAN) lds = JH_LDS_CLEAN;
+    const int unstuff_here = lds_raw > 0 && lds_raw <= lds && !split;    // every raw scan of the batch fits the decoder's LDS
+    if (!unstuff_here) {
+        if (lds_raw > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jh_unstuff), hipFuncAttributeMaxDynamicSharedMemorySize, lds_raw);
+        hipLaunchKernelGGL(k_jh_unstuff, dim3(n_frames), dim3(JH_T), (size_t)lds_raw, s, frames, bytes, clean, seg_begin, I, lds_raw);
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_jh_decode), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k_jh_decode, dim3(n_frames), dim3(JH_TD), (size_t)lds, s, frames, clean, seg_begin, I, sub, coef, status, dbg, lds);
+    hipLaunchKernelGGL(k_jh_decode, dim3(n_frames), dim3(JH_TD), (size_t)lds, s, frames, bytes, clean, seg_begin, I, sub, coef, status, dbg, lds, unstuff_here);
     // (DC prediction happens at the end of k_jh_decode; k_jh_dc is the stand-alone form, kept for scans decoded elsewhere)
     if (max_blocks > 0) {
         const dim3 grid((unsigned)((max_blocks + kDBlocksPerWg - 1) / kDBlocksPerWg), (unsigned)n_frames);
