@@ -75,4 +75,13 @@ if f:
                 continue
             g.write("%-32s VALU %8.2f M  SALU %8.2f M  LDS %7.2f M  wave quad-cycles %9.1f M\n" % (k[:32], v.get("SQ_INSTS_VALU", 0) / n / 1e6, v.get("SQ_INSTS_SALU", 0) / n / 1e6,
                                                                                                  v.get("SQ_INSTS_LDS", 0) / n / 1e6, v.get("SQ_WAVE_CYCLES", 0) / n / 1e6))
+# round 6: EDLines / KeyLines and JPEG ingest
+for sub, name in (("kl", "_keylines_kernel_stats.csv"), ("jp", "_ingest_kernel_stats.csv")):
+    f = glob.glob(os.path.join(T, sub + "/**/*kernel_stats.csv"), recursive=True)
+    if f:
+        shutil.copy(f[0], os.path.join(P, prefix + name))
+for name in ("keylines_rate.txt", "ingest_rate.txt", "jh_passes.txt", "ed_stamps.txt"):
+    if os.path.exists(os.path.join(T, name)):
+        with open(os.path.join(T, name)) as f, open(os.path.join(P, prefix + "_" + name), "w") as g:
+            g.writelines(l for l in f if "amdgpu.ids" not in l and "simple_timer" not in l)
 print("collected", prefix)

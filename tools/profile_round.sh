@@ -40,5 +40,16 @@ rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_V
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $R/gpurun_out/$T/pa -- python3 $R/tools/assoc_rate.py --pairs 16384x50000 --reps 5 > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/$T/pg -- python3 $R/tools/assoc_rate.py --pairs 16384x50000 --reps 5 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/as -- python3 $R/tools/assoc_rate.py --pairs 4096x50000,16384x50000 --reps 5 > /dev/null 2>&1
+# round 6: the second detector and the ingest stage: kernel times (rocprofv3), the walking wave's cycle budget (diagnostic builds), passes
+# per frame of the Huffman decoder, the ingest rates
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/kl -- python3 $R/tools/keylines_rate.py --octaves 1,3 > $R/gpurun_out/$T/keylines_rate.txt 2>/dev/null
+for c in real clutter; do python3 $R/tools/keylines_rate.py --octaves 1,3 --content $c 2>/dev/null | grep -v amdgpu.ids >> $R/gpurun_out/$T/keylines_rate.txt; done
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$T/jp -- python3 $R/tools/ingest_rate.py --threads 8 --entropy gpu --depth 8 --steps 64 --quality 80 --feeders 2 > $R/gpurun_out/$T/ingest_rate.txt 2>/dev/null
+python3 $R/tools/ingest_rate.py --threads 8 --entropy gpu --depth 8 --steps 64 --quality 80 --feeders 1 2>/dev/null | grep "entropy gpu" | sed -e 's/$/   (one feeder)/' >> $R/gpurun_out/$T/ingest_rate.txt
+LF_JH_SPLIT=1 python3 $R/tools/ingest_rate.py --threads 8 --entropy gpu --depth 8 --steps 64 --quality 80 --feeders 2 2>/dev/null | grep "entropy gpu" | sed -e 's/$/   (LF_JH_SPLIT=1: k_jh_unstuff in front)/' >> $R/gpurun_out/$T/ingest_rate.txt
+cd $R
+python3 tools/jpeg_host_time.py 2>/dev/null | grep "host time" >> $R/gpurun_out/$T/ingest_rate.txt
+LF_JH_DEBUG=3 python3 tools/jh_passes.py 2>&1 | grep "passes\|pass 0\|unit position" > $R/gpurun_out/$T/jh_passes.txt
+if [ -f lane_slam_amd/liblanefront_ed1.so ]; then python3 tools/ed_stamps.py 2>/dev/null | grep -v amdgpu.ids > $R/gpurun_out/$T/ed_stamps.txt; python3 tools/ed_stamps.py --content real 2>/dev/null | grep -v amdgpu.ids >> $R/gpurun_out/$T/ed_stamps.txt; fi
 find $R/gpurun_out/$T -name "*.csv" | head -40
 tail -3 $R/gpurun_out/$T/pytest.log; cat $R/gpurun_out/$T/assoc_rate.txt; tail -c 3000 $R/gpurun_out/$T/bench_n1.json
