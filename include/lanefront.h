@@ -544,7 +544,7 @@ LF_API int lf_jpeg_decode_batch(lf_handle* h, const uint8_t* const* jpeg, const 
                          int rows, int cols, uint8_t* frames, int frames_on_device, int n_threads,
                          int* frame_status);
 /* The same with the ENTROPY DECODER ON THE DEVICE as well (k_jhuff.hip): the host only parses the headers; unstuffing,
- * Huffman decoding (self-synchronising subsequences, one thread per 128 bytes), DC prediction and everything after it run on
+ * Huffman decoding (self-synchronising subsequences of 48 bytes, decoded once per place in the MCU), DC prediction and everything after it run on
  * the handle's stream.  Same streams accepted, same output bits, same per-frame status as lf_jpeg_decode_batch.  n_threads:
  * host threads for header parsing and for copying the entropy-coded bytes into pinned memory (<= 0: up to 16).  The call
  * returns when the batch is decoded (the per-frame status comes from the device). */
