@@ -121,6 +121,7 @@ extern "C" void lf_set_error(lf_handle* h, int code, const char* fmt, ...);
 
 // kernel launchers (one per translation unit)
 namespace lf {
+void launch_pre_gray(const PreParams& p, const uint8_t* frames, int n_frames, uint8_t* gray, hipStream_t s);
 void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* gray,
                 uint32_t* maskbits, const int* sdiv, const int* hdiv, hipStream_t s);
 void launch_canny(const CannyParams& p, const uint32_t* bgr, int n_frames, uint32_t* strong, uint32_t* weak,

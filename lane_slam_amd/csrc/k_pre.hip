@@ -26,15 +26,12 @@ constexpr int TW = 128, TH = LF_PRE_TILE_H, PRE_THREADS = 256;   // (TH + 2) row
 
 struct PixOut { uint32_t packed; };
 
-// p24: B | G << 8 | R << 16 as it sits in the frame (anything above bit 23 is ignored)
-__device__ __forceinline__ uint32_t convert_pixel(uint32_t p24, const PreParams& p, const int* sdiv, const int* hdiv,
-                                                  const uint8_t* boxes)
+// scaleandshift2 (float32) + convertScaleAbs of one pixel, B | G << 8 | R << 16 in and out (anything above bit 23 is ignored)
+__device__ __forceinline__ uint32_t correct_pixel(uint32_t p24, const PreParams& p)
 {
-    // scaleandshift2 (float32) + convertScaleAbs, then OpenCV RGB2HSV_b (hsv_shift 12, hue range 180) + 4 inRange boxes
     uint32_t pk = p24 & 0xFFFFFFu;
-    int b = (int)(p24 & 255u), g = (int)((p24 >> 8) & 255u), r = (int)((p24 >> 16) & 255u);
     if (!p.identity_ai) {                      // scale 1, shift 0 leaves every u8 value unchanged: the packed pixel is the output
-        int c[3] = { b, g, r };
+        int c[3] = { (int)(p24 & 255u), (int)((p24 >> 8) & 255u), (int)((p24 >> 16) & 255u) };
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             float v = (float)c[ch] * p.ai_scale[ch];
@@ -43,9 +40,27 @@ __device__ __forceinline__ uint32_t convert_pixel(uint32_t p24, const PreParams&
             int iv = (int)__builtin_rintf(a);  // v_rndne_f32: round half to even, as cvRound
             c[ch] = min(max(iv, 0), 255);
         }
-        b = c[0]; g = c[1]; r = c[2];
-        pk = (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+        pk = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
     }
+    return pk;
+}
+
+// BGR2GRAY (fixed point, as cvtColor): (B * 1868 + G * 9617 + R * 4899 + 2^13) >> 14 with the coefficients split into bytes: two
+// 4 x u8 dot products per pixel (byte 3 meets a zero coefficient); the result is <= 255
+__device__ __forceinline__ uint32_t gray_of(uint32_t pk)
+{
+    const uint32_t lo = __builtin_amdgcn_udot4(pk, 0x0023914Cu, 1u << 13, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(pk, 0x00132507u, 0u, false);
+    return ((hi << 8) + lo) >> 14;
+}
+
+// p24: B | G << 8 | R << 16 as it sits in the frame (anything above bit 23 is ignored)
+__device__ __forceinline__ uint32_t convert_pixel(uint32_t p24, const PreParams& p, const int* sdiv, const int* hdiv,
+                                                  const uint8_t* boxes)
+{
+    // scaleandshift2 (float32) + convertScaleAbs, then OpenCV RGB2HSV_b (hsv_shift 12, hue range 180) + 4 inRange boxes
+    const uint32_t pk = correct_pixel(p24, p);
+    const int b = (int)(pk & 255u), g = (int)((pk >> 8) & 255u), r = (int)((pk >> 16) & 255u);
     int v = max(b, max(g, r)), vmin = min(b, min(g, r));
     // Every inRange box needs its V interval first: a pixel whose V (= max channel) lies in none of them is in no mask
     // whatever its hue and saturation are, and those are the expensive part (two table divisions).  On road images most
@@ -231,13 +246,49 @@ __global__ __launch_bounds__(PRE_THREADS) void k_pre(PreParams p, const uint8_t*
         // per pixel (byte 3 meets a zero coefficient); the result is <= 255
         uint32_t gq = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t lo = __builtin_amdgcn_udot4(px[k], 0x0023914Cu, 1u << 13, false);
-            const uint32_t hi = __builtin_amdgcn_udot4(px[k], 0x00132507u, 0u, false);
-            gq |= (((hi << 8) + lo) >> 14) << (8 * k);
-        }
+        for (int k = 0; k < 4; ++k) gq |= gray_of(px[k]) << (8 * k);
         *reinterpret_cast<uint32_t*>(gray_out + (size_t)f * P + pix) = gq;
     }
+}
+
+// The gray working image alone -- resize-nearest / crop, colour correction, BGR2GRAY: what the octave detectors read
+// (lf_keylines_batch, lf_lsd_keylines_batch from BGR frames; k_pre's masks, HSV and BGRX image were 0.11 ms per batch for
+// nothing there).  One thread = four horizontally adjacent pixels; the same two functions as k_pre, so the same bytes.
+__global__ __launch_bounds__(256) void k_pre_gray(PreParams p, const uint8_t* __restrict__ frames, uint8_t* __restrict__ gray_out)
+{
+    const int gx = (blockIdx.x * 256 + threadIdx.x) * 4, gy = blockIdx.y, f = blockIdx.z;
+    if (gx >= p.W) return;
+    const uint8_t* src = frames + (size_t)f * p.in_rows * p.in_cols * 3;
+    uint32_t px[4] = {0, 0, 0, 0};
+    const bool fast = !p.resize && (p.in_cols & 3) == 0 && (p.W & 3) == 0;
+    if (fast) {
+        const uint32_t off = (__umul24((uint32_t)(gy + p.top_cutoff), (uint32_t)p.in_cols) + (uint32_t)gx) * 3u;
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + off);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        px[0] = d0; px[1] = (d0 >> 24) | (d1 << 8); px[2] = (d1 >> 16) | (d2 << 16); px[3] = d2 >> 8;
+    } else {
+        const int yy = gy + p.top_cutoff;
+        const int sy = p.resize ? min(dm::ifloor(yy * p.ify), p.in_rows - 1) : yy;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (gx + k >= p.W) break;
+            const int sx = p.resize ? min(dm::ifloor((gx + k) * p.ifx), p.in_cols - 1) : gx + k;
+            const uint8_t* q = src + ((size_t)sy * p.in_cols + sx) * 3;
+            px[k] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16);
+        }
+    }
+    uint32_t gq = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) gq |= gray_of(correct_pixel(px[k], p)) << (8 * k);
+    uint8_t* out = gray_out + (size_t)f * p.Hc * p.W + (size_t)gy * p.W + gx;
+    if ((p.W & 3) == 0) *reinterpret_cast<uint32_t*>(out) = gq;
+    else for (int k = 0; k < 4 && gx + k < p.W; ++k) out[k] = (uint8_t)(gq >> (8 * k));
+}
+
+void launch_pre_gray(const PreParams& p, const uint8_t* frames, int n_frames, uint8_t* gray, hipStream_t s)
+{
+    dim3 grid((p.W + 1023) / 1024, p.Hc, n_frames);
+    hipLaunchKernelGGL(k_pre_gray, grid, dim3(256), 0, s, p, frames, gray);
 }
 
 void launch_pre(const PreParams& p, const uint8_t* frames, int n_frames, uint32_t* bgr, uint8_t* gray,
