@@ -770,7 +770,7 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
                     if len(inflight) == len(slots):
                         fes[inflight.pop(0)].wait()
                     if entropy == "gpu":                     # queued since round 6: the feeder does not wait for the decoder
-                        fes[slot].decode_jpeg_batch_async(msgs, device_ptr=bufs[slot], n_threads=nthreads)
+                        fes[slot].decode_jpeg_batch_async(msgs, device_ptr=bufs[slot], n_threads=nthreads, for_detect=True)
                     else:
                         fes[slot].decode_jpeg_batch(msgs, n_threads=nthreads, device_ptr=bufs[slot], entropy=entropy)
                     fes[slot].submit_device(bufs[slot], B, ptrs[slot], cap, describe=True)
@@ -800,7 +800,7 @@ def secondary(args, torch, dev, device_id, fes, ptrs, a_idx, a_dist, host, B, D,
         nfeed = int(os.environ.get("LF_BENCH_FEEDERS", "2"))
         sec["jpeg_ingest"] = {"value": round(jpeg_rate("gpu", 8, feeders=nfeed), 1), "unit": "frames/s", "host_threads": 8, "feeder_threads": nfeed,
                               "one_feeder": round(jpeg_rate("gpu", 8, feeders=1), 1),
-                              "what": "JPEG streams (quality 80, 4:2:0, %.0f kB each) -> lf_jpeg_decode_batch_gpu_async (headers on 8 host threads; unstuffing, "
+                              "what": "JPEG streams (quality 80, 4:2:0, %.0f kB each) -> lf_jpeg_decode_for_detect_async (the rows the front end reads; headers on 8 host threads; unstuffing, "
                                       "Huffman decoding by self-synchronising subsequences, DC prediction, IDCT, upsampling and colour conversion on the "
                                       "GPU) -> detect->describe->project->sanity, %d batches in flight, %d batches timed, submitted by %d feeder threads with their share of the "
                                       "handles each (one_feeder: the same from one thread, rounds 3 - 4's form)" % (kb, D, 8 * D, nfeed)}

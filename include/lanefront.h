@@ -560,6 +560,12 @@ LF_API int lf_jpeg_decode_batch_gpu(lf_handle* h, const uint8_t* const* jpeg, co
 LF_API int lf_jpeg_decode_batch_gpu_async(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames,
                                    int rows, int cols, uint8_t* frames_device, int n_threads);
 LF_API int lf_jpeg_status(lf_handle* h, int* frame_status, int n_frames, int* n_failed);
+/* Queued decode of what lf_process_batch ON THIS HANDLE will read, into the handle's own frame buffer (lf_frames_buffer): streams of
+ * the configured input size; of every frame only the rows from the crop line on are produced (top_cutoff after the resize: a third of
+ * a 640 x 480 camera frame is never looked at by line_detector_node.py:163-166's crop, so its inverse DCT, upsampling and colour
+ * conversion are skipped) -- the rows above keep whatever the buffer held.  Follow with lf_process_batch_async(h, buffer, n, 1, ...);
+ * status through lf_jpeg_status as for lf_jpeg_decode_batch_gpu_async. */
+LF_API int lf_jpeg_decode_for_detect_async(lf_handle* h, const uint8_t* const* jpeg, const size_t* jpeg_size, int n_frames, int n_threads);
 /* size and layout of one stream without decoding it (hmax x vmax = luma sampling factors) */
 LF_API int lf_jpeg_info(const uint8_t* jpeg, size_t jpeg_size, int* rows, int* cols, int* components, int* hmax, int* vmax);
 /* the handle's own device staging buffer for input frames ([max_frames][in_rows][in_cols][3] u8): decode

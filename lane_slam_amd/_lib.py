@@ -26,7 +26,7 @@ EXPORTS = (
     "lf_map_associate", "lf_map_pack_block", "lf_map_update", "lf_map_step", "lf_map_step_host", "lf_map_fetch",
     "lf_map_set_profiling", "lf_map_get_timing", "lf_map_stage_name",
     "lf_descriptor_default_params", "lf_set_descriptor_params", "lf_get_descriptor_params",
-    "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu", "lf_jpeg_decode_batch_gpu_async", "lf_jpeg_status",
+    "lf_edlines_default_params", "lf_keylines_batch", "lf_describe_keylines", "lf_keylines_debug_fetch", "lf_set_image_edlines", "lf_knn_match", "lf_radius_match", "lf_jpeg_decode_batch_gpu", "lf_jpeg_decode_batch_gpu_async", "lf_jpeg_status", "lf_jpeg_decode_for_detect_async",
     "lf_set_tie_rule", "lf_map_set_tie_rule", "lf_debug_std_sort", "lf_suggested_depth", "lf_lsd_list_capacity", "lf_lsd_scratch_stride", "lf_set_detector", "lf_detector_failures", "lf_keylines_batch_async", "lf_keylines_frame_status", "lf_lsd_keylines_batch", "lf_select_queries",
     "lf_lsd_default_options", "lf_lsd_keylines_batch_ex", "lf_keylines_batch_masked",
     "lf_matcher_add", "lf_matcher_clear", "lf_matcher_size", "lf_matcher_match", "lf_matcher_knn_match", "lf_matcher_radius_match",
@@ -125,6 +125,8 @@ def load():
     lib.lf_jpeg_decode_batch_gpu_async.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ci, ci, ci, vp, ci]
     lib.lf_jpeg_decode_batch_gpu_async.restype = ci
     lib.lf_jpeg_status.argtypes = [vp, ctypes.POINTER(ci), ci, ctypes.POINTER(ci)]
+    lib.lf_jpeg_decode_for_detect_async.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t), ci, ci]
+    lib.lf_jpeg_decode_for_detect_async.restype = ci
     lib.lf_jpeg_status.restype = ci
     lib.lf_jpeg_info.argtypes = [vp, ctypes.c_size_t] + [ctypes.POINTER(ci)] * 5
     lib.lf_jpeg_info.restype = ci

@@ -249,7 +249,7 @@ void launch_assoc_float(const float* q, int nq, const float* m, int nm, float* q
                         unsigned long long* best, int32_t* idx, float* dist, hipStream_t s);
 // ---- JPEG ingest (k_jpeg.hip)
 namespace jpeg { struct FrameHeader; }
-struct JpegGeom { int rows, cols, Wp, Hp; };     // Wp x Hp: padded component plane (multiples of 16)
+struct JpegGeom { int rows, cols, Wp, Hp; int first_row = 0; };     // Wp x Hp: padded component plane (multiples of 16); first_row: rows above it are not wanted (the dense IDCT and the colour kernel skip them)
 void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const jpeg::FrameHeader* hdrs,
                         const uint32_t* entries, const uint32_t* block_end, uint8_t* planes, uint8_t* frames,
                         hipStream_t s);

@@ -813,9 +813,13 @@ __global__ __launch_bounds__(256) void k_jpeg_idct_dense(JpegGeom g, const jpeg:
     const int f = blockIdx.y;
     const jpeg::DevFrame& F = frames[f];
     const int t = threadIdx.x, lb = t >> 3, k = t & 7;
-    const int b = blockIdx.x * kDBlocksPerWg + lb;
+    // rows above g.first_row are not wanted: the MCU rows that lie wholly more than 16 rows above it (fancy upsampling looks one
+    // chroma row up) are the frame's first blocks -- skipped as whole workgroups
+    const int skip_rows = F.hdr.valid && g.first_row > 16 ? (g.first_row - 16) / (8 * F.hdr.vmax) : 0;
+    const int b0 = skip_rows * F.hdr.mcux * F.bpm;
+    const int b = b0 + blockIdx.x * kDBlocksPerWg + lb;
     const int nblocks = F.hdr.valid ? F.hdr.nblocks : 0;
-    if ((int)blockIdx.x * kDBlocksPerWg >= nblocks) return;
+    if (b0 + (int)blockIdx.x * kDBlocksPerWg >= nblocks) return;
     const bool act = b < nblocks;
     int32_t* w = ws + lb * kDStride;
     int comp = 0, bx = 0, by = 0;

@@ -191,7 +191,7 @@ __device__ __forceinline__ void chroma8(const uint8_t* pl, int Wp, int hm, int v
 __global__ __launch_bounds__(256) void k_jpeg_color(JpegGeom g, const jpeg::FrameHeader* __restrict__ hdrs, size_t hdr_stride,
                                                     const uint8_t* __restrict__ planes, uint8_t* __restrict__ frames)
 {
-    const int f = blockIdx.z, y = blockIdx.y;
+    const int f = blockIdx.z, y = blockIdx.y + g.first_row;
     const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (x0 >= g.cols) return;
     const jpeg::FrameHeader* H = reinterpret_cast<const jpeg::FrameHeader*>(reinterpret_cast<const char*>(hdrs) + (size_t)f * hdr_stride);
@@ -276,7 +276,7 @@ void launch_jpeg_decode(const JpegGeom& g, int n_frames, int max_blocks, const j
 void launch_jpeg_color(const JpegGeom& g, int n_frames, const void* hdrs, size_t hdr_stride, const uint8_t* planes, uint8_t* frames, hipStream_t s)
 {
     const int tx = 64;
-    const dim3 cgrid((unsigned)((g.cols + 8 * tx - 1) / (8 * tx)), (unsigned)g.rows, (unsigned)n_frames);
+    const dim3 cgrid((unsigned)((g.cols + 8 * tx - 1) / (8 * tx)), (unsigned)(g.rows - g.first_row), (unsigned)n_frames);
     hipLaunchKernelGGL(k_jpeg_color, cgrid, dim3(tx), 0, s, g, static_cast<const jpeg::FrameHeader*>(hdrs), hdr_stride, planes, frames);
 }
 

@@ -489,20 +489,29 @@ class FrontEnd(object):
         self._check(fn(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), 1, n_threads, st))
         return status
 
-    def decode_jpeg_batch_async(self, streams, device_ptr=None, rows=None, cols=None, n_threads=0):
+    def decode_jpeg_batch_async(self, streams, device_ptr=None, rows=None, cols=None, n_threads=0, for_detect=False):
         """The queued form of decode_jpeg_batch(entropy="gpu") (lf_jpeg_decode_batch_gpu_async): headers are parsed and the entropy-coded
         bytes staged before the call returns, everything else runs behind it on the handle's stream -- follow it with submit_device on
         the same buffer.  device_ptr None: the handle's own frame buffer.  The per-frame status comes from jpeg_status().  Returns the
-        device address the frames are written to."""
+        device address the frames are written to.
+
+        for_detect=True (lf_jpeg_decode_for_detect_async): into the handle's own buffer, and of every frame only the rows the front end
+        reads -- from the crop line on; what lies above is never looked at by the detector and is not decoded past the Huffman stage."""
         n = len(streams)
         rows = self.cfg["in_size"][0] if rows is None else rows
         cols = self.cfg["in_size"][1] if cols is None else cols
+        own = self.frames_buffer()[0]
         if device_ptr is None:
-            device_ptr = self.frames_buffer()[0]
+            device_ptr = own
         keep = [b if isinstance(b, bytes) else bytes(b) for b in streams]
         ptrs = ctypes.cast((ctypes.c_char_p * n)(*[b if len(b) else None for b in keep]), ctypes.POINTER(ctypes.c_void_p))
         sizes = (ctypes.c_size_t * n)(*[len(b) for b in keep])
-        self._check(self.lib.lf_jpeg_decode_batch_gpu_async(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), n_threads))
+        if for_detect:
+            if int(device_ptr) != own or (rows, cols) != tuple(self.cfg["in_size"]):
+                raise ValueError("for_detect decodes frames of the configured size into the handle's own buffer")
+            self._check(self.lib.lf_jpeg_decode_for_detect_async(self.h, ptrs, sizes, n, n_threads))
+        else:
+            self._check(self.lib.lf_jpeg_decode_batch_gpu_async(self.h, ptrs, sizes, n, rows, cols, ctypes.c_void_p(int(device_ptr)), n_threads))
         self._jpeg_queued = n
         return int(device_ptr)
 

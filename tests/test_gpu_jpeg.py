@@ -256,4 +256,26 @@ def test_queued_decode_equals_the_waiting_call(fe, vectors):
     assert got.n == ref.n and ref.n > 0
     for k in ("frame_offset", "lines", "ground", "keep", "code"):
         assert np.array_equal(getattr(got, k), getattr(ref, k)), k
+    # ... and the form that decodes only the rows the front end reads (from the crop line on): the same segments; the rows it produced
+    # are the whole decode's, the rows above it are left as they were
+    import torch as _t
+    rows, cols = fe2.cfg["in_size"]
+    nb = B * rows * cols * 3
+    filler = _t.full((nb,), 9, dtype=_t.uint8, device="cuda")
+    import ctypes as ct
+    hip = ct.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(ct.c_void_p(buf), ct.c_void_p(filler.data_ptr()), ct.c_size_t(nb), 3) == 0      # device to device
+    assert fe2.decode_jpeg_batch_async(js, for_detect=True) == buf
+    got2 = fe2.process_batch(buf, n_frames=B)
+    assert not fe2.jpeg_status().any()
+    for k in ("frame_offset", "lines", "ground", "keep", "code"):
+        assert np.array_equal(getattr(got2, k), getattr(ref, k)), k
+    back = _t.empty(nb, dtype=_t.uint8, device="cuda")
+    assert hip.hipMemcpy(ct.c_void_p(back.data_ptr()), ct.c_void_p(buf), ct.c_size_t(nb), 3) == 0
+    back = back.cpu().numpy().reshape(B, rows, cols, 3)
+    cut = fe2.cfg["top_cutoff"] * rows // fe2.cfg["img_size"][0]
+    assert np.array_equal(back[:, cut:], frames[:, cut:])
+    assert (back[:, :cut - 16] == 9).all()
+    with pytest.raises(ValueError):
+        fe2.decode_jpeg_batch_async(js, device_ptr=filler.data_ptr(), for_detect=True)
     fe2.close()

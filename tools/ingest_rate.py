@@ -61,7 +61,7 @@ for ent, nt in [(e, int(t)) for e in args.entropy.split(",") for t in args.threa
             sl = mine[k % len(mine)]
             if len(infl) == len(mine): fes[infl.pop(0)].wait()
             if ent == "gpu":                                   # queued (round 6): the feeder does not wait for the decoder
-                fes[sl].decode_jpeg_batch_async(streams, device_ptr=bufs[sl], n_threads=max(1, nt // F))
+                fes[sl].decode_jpeg_batch_async(streams, device_ptr=bufs[sl], n_threads=max(1, nt // F), for_detect=not os.environ.get("LF_INGEST_WHOLE_FRAMES"))
             else:
                 fes[sl].decode_jpeg_batch(streams, n_threads=max(1, nt // F), device_ptr=bufs[sl], entropy=ent)
             fes[sl].submit_device(bufs[sl], B, ptrs[sl], cap, describe=True)
