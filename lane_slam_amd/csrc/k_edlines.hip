@@ -64,14 +64,25 @@ __device__ __forceinline__ int ed_div4_half_even(int v)
 // reflected source, which for a symmetric kernel IS the reflected blurred image the Sobel's BORDER_REFLECT_101 asks for.
 // PACKED: the taps sum to <= 257, so a row sum (<= 255 * 257 = 65 535) fits 16 bits.  Rounding can make them sum to 258
 // (sigma sqrt 2, the third octave: 29 61 78 61 29) -- those octaves take the copy with 32-bit row sums.
+// Round 6: the ANCHORS of the detector (k_ed_detect: a candidate every second pixel in x and y whose gradient exceeds both neighbours
+// across its edge direction by anchor_thr) are tested HERE, where the tile's gradients are at hand -- k_ed_detect read the whole plane
+// back for it (105 MB per batch, HBM-bound: a tenth of its time).  A candidate's four neighbours lie in the tile or one pixel to its
+// right / below: the blurred tile already reaches two columns further than the 64 x 64 outputs need and gets two more rows, the
+// gradients of column 64 and row 64 are worked out beside the tile's own (never stored: the neighbouring tile writes them), all 65 x 65
+// sit in LDS (where the row sums were), and every candidate column's 32 bits go to the frame's column-major candidate planes
+// (aflags: [frame][2][n_cwords] -- candidate set, its pixel a horizontal-edge one) with two atomics each.  anchor planes: scan == 2 only.
+struct EdAnchorOut { uint32_t* flags; int thr, nW, nH, n_cwords; };
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __restrict__ src, int t0, int t1, int t2, int t3, int t4,
                                                  int grad_threshold, uint8_t* __restrict__ bluro, uint32_t* __restrict__ dxyo,
-                                                 uint16_t* __restrict__ go)
+                                                 uint16_t* __restrict__ go, EdAnchorOut an)
 {
-    constexpr int GW = 72, GH = ET_H + 6;            // source tile: 70 columns used (x0-3 .. x0+66), rows padded to dwords
-    constexpr int RW = 68, RG = RW / 4;              // row-filtered: 66 columns used (x0-1 .. x0+64)
-    constexpr int BW_ = 72, BH = ET_H + 2;           // blurred: column c <-> x0-1+c, 66 used
+    constexpr int GW = 72, GH = ET_H + 8;            // source tile: 70 columns used (x0-3 .. x0+66), rows y0-3 .. y0+68, padded to dwords / pairs
+    constexpr int RW = 68, RG = RW / 4;              // row-filtered: columns x0-1 .. x0+66
+    constexpr int BW_ = 72, BH = ET_H + 4;           // blurred: column c <-> x0-1+c (68 computed), row r <-> y0-1+r (67 used: the gradient of row y0+64)
+    constexpr int GLW = 68;                          // gradients of the tile and of column / row 64, 16 bits each (in rowp's place; rows 8-byte aligned)
+    static_assert(65 * GLW * 2 <= (int)sizeof(uint32_t) * (PACKED ? (GH / 2) * RW : GH * RW), "the gradient square fits where the row sums were");
     __shared__ __attribute__((aligned(16))) uint8_t gray[GH * GW];
     __shared__ __attribute__((aligned(16))) uint32_t rowp[PACKED ? (GH / 2) * RW : GH * RW];   // PACKED: (row 2m, row 2m + 1) per column, 16 bits each; else a row sum per word
     __shared__ __attribute__((aligned(16))) uint8_t blur[BH * BW_];
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __
     }
     __syncthreads();
     // Sobel 3x3 on the blurred tile, 4 outputs per lane and row; the three planes
+    uint16_t* gl = reinterpret_cast<uint16_t*>(rowp);        // (the row sums are done with)
     {
         constexpr int SROWS = ET_H / 16;
         const int g = tid & 15, seg = tid >> 4;
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __
                     const int sum = ax + ay;
                     gq[k] = (uint32_t)(ed_div4_half_even(sum > grad_threshold + 1 ? sum : 0) | (ax < ay ? kHorizontal : 0));
                 }
+                if (an.flags) *reinterpret_cast<uint2*>(gl + ry * GLW + lx) = make_uint2(gq[0] | (gq[1] << 16), gq[2] | (gq[3] << 16));
                 const size_t o = o00 + (size_t)i * W;
                 const uint32_t bl = mid[(i + 1) % 3];
                 if (gx + 3 < W) {
@@ -265,17 +278,78 @@ __global__ __launch_bounds__(256) void k_ed_grad(int H, int W, const uint8_t* __
             }
         }
     }
+    if (!an.flags) return;
+    // ---- the anchors of this tile's candidates
+    {
+        // column 64 (rows 0 .. 64) and row 64 (columns 0 .. 63): the same Sobel and quantisation, one pixel per thread
+        const int t = tid;
+        if (t < 129) {
+            const int cx = t < 65 ? 64 : t - 65, cy = t < 65 ? t : 64;
+            if (x0 + cx < W && y0 + cy < H) {
+                const uint8_t* b = blur + (cy + 1) * BW_ + cx + 1;
+                const int a00 = b[-BW_ - 1], a01 = b[-BW_], a02 = b[-BW_ + 1], a10 = b[-1], a12 = b[1], a20 = b[BW_ - 1], a21 = b[BW_], a22 = b[BW_ + 1];
+                const int vx = (a02 + 2 * a12 + a22) - (a00 + 2 * a10 + a20), vy = (a20 + 2 * a21 + a22) - (a00 + 2 * a01 + a02);
+                const int ax = vx < 0 ? -vx : vx, ay = vy < 0 ? -vy : vy, sum = ax + ay;
+                gl[cy * GLW + cx] = (uint16_t)(ed_div4_half_even(sum > grad_threshold + 1 ? sum : 0) | (ax < ay ? kHorizontal : 0));
+            }
+        }
+        uint32_t* s_col = reinterpret_cast<uint32_t*>(gray);      // [2][32]: a candidate column's 32 rows (the source tile is done with)
+        if (t < 64) s_col[t] = 0u;
+        __syncthreads();
+        // thread = (candidate column, four of its 32 rows)
+        const int cwl = t & 31, rg = t >> 5;
+        const int cw = (x0 >> 1) + cwl, lx = 1 + 2 * cwl;
+        uint32_t bits = 0u, hbits = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int chl = rg * 4 + j, ch = (y0 >> 1) + chl, ly = 1 + 2 * chl;
+            if (cw < an.nW && ch < an.nH) {
+                const uint32_t v = gl[ly * GLW + lx];
+                const bool hz = (v & kHorizontal) != 0;
+                const int gv = (int)(v & 0x7fffu);
+                const int n1 = (int)(gl[hz ? (ly - 1) * GLW + lx : ly * GLW + lx - 1] & 0x7fffu), n2 = (int)(gl[hz ? (ly + 1) * GLW + lx : ly * GLW + lx + 1] & 0x7fffu);
+                if (gv >= n1 + an.thr && gv >= n2 + an.thr) { bits |= 1u << chl; if (hz) hbits |= 1u << chl; }
+            }
+        }
+        if (bits) atomicOr(&s_col[cwl], bits);
+        if (hbits) atomicOr(&s_col[32 + cwl], hbits);
+        __syncthreads();
+        // a column's bits: plane positions cw * nH + ch0 .. + 31, two words
+        if (t < 64) {
+            const int c = t & 31, pl = t >> 5;
+            const uint32_t v = s_col[t];
+            const int cwc = (x0 >> 1) + c;
+            if (v && cwc < an.nW) {
+                const unsigned b0 = (unsigned)cwc * (unsigned)an.nH + (unsigned)(y0 >> 1);
+                uint32_t* dst = an.flags + ((size_t)f * 2 + pl) * an.n_cwords;
+                const unsigned w0 = b0 >> 5, sh = b0 & 31u;
+                atomicOr(dst + w0, v << sh);
+                if (sh && (v >> (32u - sh))) atomicOr(dst + w0 + 1, v >> (32u - sh));
+            }
+        }
+    }
 }
 
 void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* taps5, int grad_threshold, uint8_t* blur,
-                    uint32_t* dxy, uint16_t* g, hipStream_t s)
+                    uint32_t* dxy, uint16_t* g, hipStream_t s, uint32_t* anchor_flags, int anchor_thr)
 {
     dim3 grid((W + ET_W - 1) / ET_W, (H + ET_H - 1) / ET_H, n_frames);
     const int sum = taps5[0] + taps5[1] + taps5[2] + taps5[3] + taps5[4];
+    EdAnchorOut an;
+    an.flags = anchor_flags; an.thr = anchor_thr;
+    an.nW = W > 2 ? (W - 2 + 1) / 2 : 0; an.nH = H > 2 ? (H - 2 + 1) / 2 : 0;      // scan interval 2 (ed_anchor_words)
+    an.n_cwords = (an.nW * an.nH + 31) / 32;
     if (sum <= 257)
-        hipLaunchKernelGGL(k_ed_grad<true>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g);
+        hipLaunchKernelGGL(k_ed_grad<true>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g, an);
     else
-        hipLaunchKernelGGL(k_ed_grad<false>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g);
+        hipLaunchKernelGGL(k_ed_grad<false>, grid, dim3(256), 0, s, H, W, src, taps5[0], taps5[1], taps5[2], taps5[3], taps5[4], grad_threshold, blur, dxy, g, an);
+}
+
+// words of one candidate plane of a W x H octave image at scan interval 2 (k_ed_grad writes two per frame: set, horizontal-edge)
+size_t ed_anchor_words(int W, int H)
+{
+    const int nW = W > 2 ? (W - 2 + 1) / 2 : 0, nH = H > 2 ? (H - 2 + 1) / 2 : 0;
+    return ((size_t)nW * nH + 31) / 32;
 }
 
 // cv::GaussianBlur(src, dst, Size(k, k), sigma) on u8 for a kernel size OTHER than the reference's default 5 (Params::ksize_,
@@ -867,7 +941,11 @@ __global__ __launch_bounds__(ED_THREADS) void k_ed_detect(EdAll all, EdFitParams
     // whatever its direction, 8 or 16 candidates per thread in flight: the phase is bound by the latency of the plane.  A
     // thread's candidates are ED_THREADS apart: (row, column) advance by that stride's quotient and remainder -- one
     // division per thread (two per candidate until round 6: 100 of its 150 instructions)
-    {
+    if (o.aflags) {
+        // the candidates k_ed_grad has tested (scan interval 2): its two planes into LDS
+        const uint32_t* af = o.aflags + (size_t)f * 2 * n_cwords;
+        for (int i = tid; i < n_cwords; i += ED_THREADS) { flags[i] = af[i]; fhz[i] = af[n_cwords + i]; }
+    } else {
         const int step_q = ED_THREADS / (nW > 0 ? nW : 1), step_r = ED_THREADS - step_q * nW;
         int ch_n = tid / (nW > 0 ? nW : 1), cw_n = tid - ch_n * nW;
         auto test = [&](uint32_t v, uint32_t va, uint32_t vb, uint32_t vl, uint32_t vr, int b) {

@@ -17,6 +17,7 @@ struct EdOct {
     uint32_t* chain;       // [B][2*cap]      edge chains, packed x | y << 16
     uint32_t* sid;         // [B][max_edges + 2]
     uint32_t* gmarks;      // [B][(H*W+31)/32] when the marks do not fit LDS
+    const uint32_t* aflags; // [B][2][n_cwords] the anchor candidates as k_ed_grad tested them (scan interval 2), or null: k_ed_detect tests them
     int* counts;           // [B][4]: anchors, edges (-1: the detector gave up), lines, status
     float* l_ep;           // [B][max_lines][4]
     double* l_c;           // [B][max_lines]     lineEquation[2] of the normalised equation
@@ -40,8 +41,9 @@ struct KlOut {
 
 void launch_kl_mask(int n_frames, const int* fo_src, int* fo_dst, int* totals, int capacity, const uint8_t* masks, int rows, int cols, uint8_t* erased,
                     int* kept_count, const KlOut& src, const KlOut& dst, hipStream_t s);
+size_t ed_anchor_words(int W, int H);
 void launch_ed_grad(int H, int W, int n_frames, const uint8_t* src, const int* taps5, int grad_threshold, uint8_t* blur,
-                    uint32_t* dxy, uint16_t* g, hipStream_t s);
+                    uint32_t* dxy, uint16_t* g, hipStream_t s, uint32_t* anchor_flags = nullptr, int anchor_thr = 0);
 void ed_resize_tables(int H, int W, int DH, int DW, double scale, int* tab);        // 4 ints per destination column, then 4 per destination row
 void launch_ed_resize(int H, int W, int DH, int DW, const int* tab, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s);
 void launch_pyrdown(int H, int W, int n_frames, const uint8_t* src, uint8_t* dst, hipStream_t s);
