@@ -32,9 +32,12 @@ namespace lf {
 
 constexpr int JH_T = 256;          // k_jh_unstuff
 #ifndef LF_JH_THREADS
-#define LF_JH_THREADS 1024
+#define LF_JH_THREADS 512
 #endif
-constexpr int JH_TD = LF_JH_THREADS;        // k_jh_decode: one thread per subsequence of a typical camera frame (~300)
+// k_jh_decode's workgroup.  512 since round 6: alone the kernel is 12 % slower than with 1 024 (decode 142 k -> 126 k frames/s), behind the front end
+// it is what a CU can take in beside the other batches' kernels -- decode + front end 88.5 k -> 93.3 k frames/s, same call (768: 89.4 k, 384: 92.5 k,
+// 256: 85 k).  Until round 5's Jacobi form 1 024 was the fastest both ways.
+constexpr int JH_TD = LF_JH_THREADS;
 constexpr int JH_LDS_CLEAN = 96 * 1024;     // scans up to this many clean bytes are decoded out of LDS
 #ifndef LF_JH_SB
 #define LF_JH_SB 48
