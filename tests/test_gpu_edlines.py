@@ -123,6 +123,27 @@ def test_gray_working_image_of_the_octave_path_under_a_colour_transform(geometry
     fe.close()
 
 
+def test_keylines_on_an_odd_working_geometry_match_oracle():
+    """A working image with an odd number of rows behind a resize that is not by an integer factor (224 x 83; octaves 112 x 42 and 56 x 21):
+    the gray kernel's resize path, gradient tiles cut by the image on both sides, anchor candidate planes whose columns are not word aligned."""
+    cfg = default_config("parity")
+    cfg["img_size"] = [125, 224]
+    cfg["top_cutoff"] = 42
+    B = 3
+    frames = synth.make_batch(B, seed0=321)
+    gray = _gray_frames(cfg, frames)
+    assert gray.shape[1:] == (83, 224)
+    fe = FrontEnd(cfg, max_frames=B, max_lines_per_color=256)
+    k = fe.keylines_batch(frames, n_octaves=3)
+    _check_stages(fe, gray, 3)
+    assert _check_keylines(k, gray, 3) > 0
+    # another scan interval: the candidates are tested by the detector kernel itself
+    p = fe.edlines_params(scan_intervals=3)
+    k3 = fe.keylines_batch(gray, n_octaves=2, gray=True, params=p)
+    assert _check_keylines(k3, gray, 2, params=p) > 0
+    fe.close()
+
+
 def test_keylines_on_clutter_shapes_and_real_frames(golden_dir):
     cfg = default_config("fullres")
     rows, cols = cfg["img_size"][0] - cfg["top_cutoff"], cfg["img_size"][1]
