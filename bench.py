@@ -161,10 +161,10 @@ def main():
     fes = [FrontEnd(cfg, device=local_rank, max_frames=B, max_lines_per_color=args.cap)]
     handle_bytes = max(1, free0 - torch.cuda.mem_get_info(local_rank)[0])
     # ... and budgeted as GROWN: the lists of a handle that meets busier content are reallocated larger by lf_wait (camera frames: 2.75 x;
-    # 102 bytes per list entry and problem) -- room for a fourfold growth of every handle, so that a growth in the
+    # 118 bytes per list entry and problem (102 until the seed sums of round 6)) -- room for a fourfold growth of every handle, so that a growth in the
     # middle of a run does not meet a device filled to the brim by handles sized before any growth
     S0 = fes[0].lsd_list_capacity()[0]
-    grown_bytes = handle_bytes + 102 * 3 * B * max(0, min(fes[0].lsd_rows * fes[0].lsd_cols, 4 * S0) - S0)
+    grown_bytes = handle_bytes + 118 * 3 * B * max(0, min(fes[0].lsd_rows * fes[0].lsd_cols, 4 * S0) - S0)
     if args.depth == 0:
         D = max(2, min(D, int((0.85 * free0) // grown_bytes)))
     args.handle_bytes, args.grown_bytes = handle_bytes, grown_bytes          # (secondary(): the content rows add handles)

@@ -61,6 +61,12 @@ struct LsdParams {
     int label_lds;      // problems of up to this many defined pixels are labelled in LDS, the others in the region scratch (k_lsd_label)
     int rec_cap;        // entries per problem of every per-problem list (records, compact arrays, seed lists, sort scratch): the stride of those
                         // arrays.  Hs * Ws holds any problem; a batch handle starts lower and grows when a batch needs more (lanefront_api.hip)
+    // Round 6: what a region that STARTS at a pixel begins its two float sums with -- (float) cos / sin of the pixel's angle as a double
+    // (region_grow adds every other pixel with the cosine of the angle rounded to float: the c_cs / c_sn pairs).  k_lsd_grad works it out
+    // per record beside those, k_lsd_order gathers it ([rec_cap] float pairs per problem, like c_cs), k_lsd_grow loads the seed's pair
+    // instead of evaluating a double sine and cosine at every region start.  Null: k_lsd_grow evaluates them (the octave LSD path).
+    float* r_sd = nullptr;
+    float* c_sd = nullptr;
 };
 
 struct SegParams {

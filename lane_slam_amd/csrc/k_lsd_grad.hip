@@ -338,6 +338,11 @@ __global__ __launch_bounds__(LG_T) void k_lsd_grad(LsdParams p, ResizeTables rt,
             r_mod[rb + e] = dln[e];
             r_cs[rb + e] = c_;
             r_sn[rb + e] = s_;
+            if (p.r_sd) {                                         // the sums of a region that starts here (LsdParams::r_sd)
+                double s2, c2;
+                dm::dsincos(arad, s2, c2);
+                *reinterpret_cast<float2*>(p.r_sd + 2 * (rb + e)) = make_float2((float)c2, (float)s2);
+            }
         }
         if (l_addr) {
             const size_t lb = (size_t)pc * p.rec_cap + low_base;

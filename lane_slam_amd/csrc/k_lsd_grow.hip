@@ -142,6 +142,7 @@ __device__ __forceinline__ void lsd_grow_problem(const LsdParams& p, const uint3
     c.deg = c_deg + (size_t)pc * p.rec_cap;
     c.mod = c_mod + (size_t)pc * p.rec_cap;
     c.cs = c_cs + (size_t)pc * p.rec_cap * 2;                       // interleaved (cos, sin) pairs: lsd_grow.h cs_sn()
+    c.sd = p.c_sd ? p.c_sd + (size_t)pc * p.rec_cap * 2 : nullptr;
     c.sn = c_sn + (size_t)pc * p.rec_cap * 2;
     c.usedc = usedc; c.gused = gu; c.used_lds = BIG ? def_lds : 0x7fffffff;
     // every wave has its own region list: reg_lds entries in LDS, the rest in its slice of the problem's scratch.
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(64 * LFG_EVAL_WAVES) void k_lsd_eval(LsdParams p, c
     c.q = nullptr;
     c.rows = rows; c.lxs = lxs; c.gxy = gxy; c.def_lds = def_lds;
     c.deg = c_deg + (size_t)pc * p.rec_cap;
-    c.mod = nullptr; c.cs = nullptr; c.sn = nullptr; c.usedc = nullptr; c.gused = nullptr; c.used_lds = 0;
+    c.mod = nullptr; c.cs = nullptr; c.sn = nullptr; c.sd = nullptr; c.usedc = nullptr; c.gused = nullptr; c.used_lds = 0;
     c.lreg = nullptr; c.greg = nullptr; c.reg_lds = 0;
     c.log_nt = p.log_nt; c.log_eps = p.log_eps; c.density_th = p.density_th;
     c.prec = p.prec; c.p = p.p; c.scale = p.scaled ? p.scale : 1.0;

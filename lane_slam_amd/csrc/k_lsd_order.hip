@@ -241,6 +241,7 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
             c_mod[o + e] = m;
             c_cs[2 * (o + e)] = r_cs[o + ri];
             c_sn[2 * (o + e)] = r_sn[o + ri];
+            if (p.c_sd) *reinterpret_cast<float2*>(p.c_sd + 2 * (size_t)(o + e)) = *reinterpret_cast<const float2*>(p.r_sd + 2 * (size_t)(o + ri));
             const uint32_t key = (uint32_t)((p.n_bins - 1) - (int)(m * bin_coef));
             LA[e] = (key << 20) | e;
         }
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(OT) void k_lsd_order(LsdParams p, const uint32_t* _
         c_mod[o + e] = m;
         c_cs[2 * (o + e)] = r_cs[o + ri];
         c_sn[2 * (o + e)] = r_sn[o + ri];
+            if (p.c_sd) *reinterpret_cast<float2*>(p.c_sd + 2 * (size_t)(o + e)) = *reinterpret_cast<const float2*>(p.r_sd + 2 * (size_t)(o + ri));
         const int bin = (int)(m * bin_coef);
         B[e] = ((uint32_t)((p.n_bins - 1) - bin) << 20) | (uint32_t)e;     // seeds carry the compact index
         // rows (y_prev, y] start at e; the first entry also covers rows 0..y
@@ -357,6 +359,7 @@ __global__ __launch_bounds__(OBT) void k_lsd_order_bm(LsdParams p, const uint32_
             c_mod[o + e] = m;
             c_cs[2 * (o + e)] = r_cs[o + ri];
             c_sn[2 * (o + e)] = r_sn[o + ri];
+            if (p.c_sd) *reinterpret_cast<float2*>(p.c_sd + 2 * (size_t)(o + e)) = *reinterpret_cast<const float2*>(p.r_sd + 2 * (size_t)(o + ri));
             const int bin = (int)(m * bin_coef);
             A[e] = ((uint32_t)((p.n_bins - 1) - bin) << 20) | (uint32_t)e;
             const int yp = e == 0 ? -1 : (int)((uint32_t)(X[e - 1] >> 32) / (uint32_t)p.Ws);
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(OBT) void k_lsd_order_bm(LsdParams p, const uint32_
         c_mod[o + e] = m;
         c_cs[2 * (o + e)] = r_cs[o + i];
         c_sn[2 * (o + e)] = r_sn[o + i];
+            if (p.c_sd) *reinterpret_cast<float2*>(p.c_sd + 2 * (size_t)(o + e)) = *reinterpret_cast<const float2*>(p.r_sd + 2 * (size_t)(o + i));
         B[e] = ((uint32_t)((p.n_bins - 1) - (int)(m * bin_coef)) << 20) | e;
     }
     for (int y = t; y <= p.Hs; y += OBT) RS[y] = (int)bitplane_rank(dyn_lds, Ps, y * p.Ws);

@@ -78,6 +78,7 @@ struct lf_handle {
     uint32_t* d_raddr = nullptr;
     float* d_rdeg = nullptr;
     double *d_rmod = nullptr, *d_rcs = nullptr, *d_rsn = nullptr;
+    float *d_rsd = nullptr, *d_csd = nullptr;      // LsdParams::r_sd, c_sd
     int* d_nrec = nullptr;
     uint8_t* d_zero = nullptr; size_t zero_bytes = 0;   // d_maxgrad | d_nrec | d_nlow | d_tile_count | d_overflow: the counters a batch starts from zero, ONE memset (each memset is a dispatch of its own and waited 0.3 ms in a busy pipeline)
     bool overflow_zeroed = false;
@@ -497,8 +498,9 @@ extern "C" int lf_set_descriptor_params(lf_handle* h, const lf_descriptor_params
 static void free_lsd_lists(lf_handle* h)
 {
     void* ptrs[] = { h->d_raddr, h->d_rdeg, h->d_rmod, h->d_rcs, h->d_rsn, h->d_sort_a, h->d_sort_b, h->d_order_a, h->d_order_b, h->d_cxy, h->d_cdeg,
-                     h->d_cmod, h->d_ccs, h->d_reg, h->d_clabel, h->d_laddr, h->d_lmod };
+                     h->d_cmod, h->d_ccs, h->d_reg, h->d_clabel, h->d_laddr, h->d_lmod, h->d_rsd, h->d_csd };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->d_rsd = nullptr; h->d_csd = nullptr; h->lsd.r_sd = nullptr; h->lsd.c_sd = nullptr;
     h->d_raddr = nullptr; h->d_rdeg = nullptr; h->d_rmod = nullptr; h->d_rcs = nullptr; h->d_rsn = nullptr; h->d_sort_a = nullptr; h->d_sort_b = nullptr;
     h->d_order_a = nullptr; h->d_order_b = nullptr; h->d_cxy = nullptr; h->d_cdeg = nullptr; h->d_cmod = nullptr; h->d_ccs = nullptr; h->d_csn = nullptr;
     h->d_reg = nullptr; h->d_clabel = nullptr; h->d_laddr = nullptr; h->d_lmod = nullptr;
@@ -521,6 +523,8 @@ static int alloc_lsd_lists(lf_handle* h, int rec_cap)
         dalloc(h, &h->d_clabel, nprob * S))
         return LF_ERR_HIP;
     h->d_csn = h->d_ccs + 1;          // (cos, sin) pairs in one array: k_lsd_order.hip
+    if (dalloc(h, &h->d_rsd, nprob * S * 2) || dalloc(h, &h->d_csd, nprob * S * 2)) return LF_ERR_HIP;
+    L.r_sd = h->d_rsd; L.c_sd = h->d_csd;
     if (h->cfg.lsd_seed_order == LF_LSD_SEED_OPENCV32 && (dalloc(h, &h->d_laddr, nprob * S) || dalloc(h, &h->d_lmod, nprob * S)))
         return LF_ERR_HIP;
     return LF_OK;
